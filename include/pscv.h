@@ -1,0 +1,142 @@
+/*
+ * pscv.h -- C ABI of the MI355X (gfx950) plane-sweep cost-volume engine.
+ *
+ * The reference (fdarmon/wild_deep_mvs) has no FFI or operator registry: its hot
+ * path is a chain of ATen calls inside models/<arch> forward().  This header is
+ * the boundary a maintainer would bind instead of those calls (ctypes stub in
+ * INTEGRATION.md; the in-tree binding is wild_deep_mvs_amd/_lib.py).  Each entry
+ * point names the reference code it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every tensor pointer is a DEVICE pointer
+ *     borrowed for the duration of the call unless marked "host";
+ *   - asynchronous on the given hipStream_t (passed as void*); no allocation,
+ *     no global mutable state, re-entrant per stream;
+ *   - return 0 on success, negative on error; the message is available from
+ *     pscv_last_error() (thread-local);
+ *   - tensors are channels-last: feature maps [B,h,w,C], volumes [B,D,h,w,C];
+ *     dtype codes select fp32 or bf16 STORAGE, arithmetic is always fp32
+ *     (bf16 MFMA products accumulate in fp32).
+ */
+#ifndef PSCV_H
+#define PSCV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSCV_ABI_VERSION 1
+
+/* storage dtypes */
+#define PSCV_F32 0
+#define PSCV_BF16 1
+
+/* sampling geometry of the warp */
+#define PSCV_GEOM_PROJ 0  /* q = rot*(x,y,1)*d + trans, integer pixel centres, sample at index (u,v):
+                             MVSNet models/MVSNet/module.py:127-166, CVP models/CVP_MVSNet/models/modules.py:74-128 */
+#define PSCV_GEOM_HOMOG 1 /* hom = A*(x+.5,y+.5,1) - Bm*(..)/(d+1e-9), sample at index u*(W-1)/W:
+                             Vis-MVSNet models/VisMVSNet/homography.py:23-120 */
+
+/* cost aggregation fused behind the warp */
+#define PSCV_COST_VARIANCE 0     /* sum f^2/N - (sum f)^2/N^2          models/MVSNet/model.py:113-139 */
+#define PSCV_COST_VARIANCE_CVP 1 /* sum f^2/N - (sum f / N)^2          models/CVP_MVSNet/models/net.py:129-152, modules.py:229-293 */
+#define PSCV_COST_SOFTMIN 2      /* sum_v e diff/(sum_v e + 1e-6)      models/MVSNet/model.py:141-173 */
+#define PSCV_COST_GROUPCORR 3    /* per source, 4-channel group dot    models/VisMVSNet/nn_utils.py:473-490 (call model_cas.py:340) */
+#define PSCV_COST_WARP_ONLY 4    /* per source warped volume           homo_warping / homography_warping themselves */
+
+#define PSCV_MAX_SRC 16
+#define PSCV_CAM_FLOATS 18 /* per (source, batch): PROJ = rot[9] trans[3] pad[6]; HOMOG = A[9] Bm[9] */
+
+/* conv3d kinds */
+#define PSCV_CONV_S1 0 /* Conv3d k3 s1 p1 (also ConvTranspose3d k3 s1 p1, packed flipped) */
+#define PSCV_CONV_S2 1 /* Conv3d k3 s2 p1 */
+#define PSCV_CONV_T2 2 /* ConvTranspose3d k3 s2 p1 output_padding 1 */
+
+/* epilogue flags for pscv_conv3d */
+#define PSCV_EPI_RELU_PRE 1  /* y = max(y, 0) before the skip add   (MVSNet/CVP: skip + relu(bn(deconv))) */
+#define PSCV_EPI_RELU_POST 2 /* y = max(y, 0) after the skip add    (Vis BasicBlock: relu(bn(conv) + residual)) */
+
+const char* pscv_last_error(void);
+int pscv_abi_version(void);
+
+/*
+ * Fused plane-sweep warp + cost aggregation (one pass, the warped per-view volumes never reach HBM).
+ * Replaces: MVSNet.build_cost_volume (models/MVSNet/model.py:109-176) + homo_warping (module.py:111-169);
+ *           CVP net.py:129-152 and proj_cost (modules.py:229-293); Vis SingleStage.build_cost_volume +
+ *           groupwise_correlation (model_cas.py:176-186,340).
+ *
+ *   ref     [B,h,w,C]                 reference feature map (unused for WARP_ONLY, may be NULL)
+ *   srcs    host array of n_src device pointers, each [B,hs,ws,C]
+ *   cams    device [n_src][B][PSCV_CAM_FLOATS] fp32
+ *   depth   device fp32; per-batch planes: element (b,d) at depth[b*depth_bstride + d];
+ *           per-pixel planes (depth_per_pixel=1): element (b,d,y,x) at depth[b*depth_bstride + (d*h + y)*w + x]
+ *   out     VARIANCE*, SOFTMIN: [B,D,h,w,C];  GROUPCORR: [n_src][B,D,h,w,C/4];  WARP_ONLY: [n_src][B,D,h,w,C]
+ *   C must be a multiple of 8 with C/8 in {1,2,4,8}; n_src <= PSCV_MAX_SRC.
+ */
+int pscv_warp_cost(const void* ref, const void* const* srcs, int n_src, const float* cams, const float* depth,
+                   long depth_bstride, int depth_per_pixel, int geom, int cost, float temp, void* out, int B, int C,
+                   int h, int w, int hs, int ws, int D, int in_dtype, int out_dtype, void* stream);
+
+/*
+ * Weight packing for pscv_conv3d (host side, done once at model-load time).
+ * Replaces nothing in the reference; it is the layout contract between a checkpoint's
+ * [C_out,C_in,3,3,3] (Conv3d) / [C_in,C_out,3,3,3] (ConvTranspose3d) fp32 tensors and the MFMA kernel.
+ *   kind        PSCV_CONV_*
+ *   transposed  1 if `w` is a ConvTranspose3d weight ([C_in,C_out,3,3,3]); required for T2, and with S1 it
+ *               packs the spatially flipped kernel (ConvTranspose3d k3 s1 p1 == Conv3d with flipped taps)
+ *   returns the number of bf16 elements of the packed buffer (call with packed == NULL to query), <0 on error.
+ */
+long pscv_pack_conv3d_weights(const float* w /*host*/, int c_in, int c_out, int kind, int transposed,
+                              uint16_t* packed /*host, may be NULL*/);
+
+/*
+ * 3x3x3 convolution as an MFMA implicit GEMM with fused per-channel affine (folded eval-mode BatchNorm or bias),
+ * ReLU and skip-add epilogue.
+ * Replaces: ConvBnReLU3D / ConvBn3D (models/MVSNet/module.py:41-58), the Sequential(ConvTranspose3d, BatchNorm3d,
+ *           ReLU) blocks and `prob` of CostRegNet (models/MVSNet/model.py:43-84; CVP net.py:50-85) and the conv /
+ *           deconv members of the Vis UNet (models/VisMVSNet/nn_utils.py:194-278).
+ *
+ *   in       bf16 [B,Di,Hi,Wi,in_cstride], the layer reads channels [in_coff, in_coff + c_in)
+ *   packed   device copy of pscv_pack_conv3d_weights output
+ *   scale,bias  device fp32 [c_out]:  y = acc*scale + bias   (scale may be NULL = 1, bias may be NULL = 0)
+ *   floor    device fp32 [c_out] or NULL: with PSCV_EPI_RELU_PRE, y = max(y, floor[c]) instead of max(y, 0)
+ *            (floor = -inf keeps a channel linear; lets one launch carry ReLU and linear channels)
+ *   skip     NULL or bf16 [B,Do,Ho,Wo,skip_cstride] read at channel offset skip_coff, added after RELU_PRE
+ *   out      [B,Do,Ho,Wo,out_cstride] written at channel offset out_coff; out_dtype bf16 or fp32
+ *   (Do,Ho,Wo) = (Di,Hi,Wi) for S1, ceil(./2) for S2, 2x for T2.
+ *   c_in in {8,16,32,64}; c_out in {1,8,16,32,64}.
+ */
+int pscv_conv3d(const void* in, int in_cstride, int in_coff, const uint16_t* packed, const float* scale,
+                const float* bias, const float* floor, const void* skip, int skip_cstride, int skip_coff, void* out,
+                int out_cstride, int out_coff, int out_dtype, int B, int Di, int Hi, int Wi, int c_in, int c_out,
+                int kind, int epi_flags, void* stream);
+
+/*
+ * Softmax over the depth axis + expectation(s), fused.
+ * Replaces: F.softmax + depth_regression + photometric confidence (models/MVSNet/model.py:207-215, module.py:174-178;
+ *           CVP net.py:161-162,203-219) and soft_argmin / entropy (models/VisMVSNet/nn_utils.py:453-470).
+ *
+ *   logits        [B,D,h,w] fp32 or bf16 (logit_dtype)
+ *   depth         same addressing as pscv_warp_cost (per-batch or per-pixel planes); may be NULL (then out_depth must be NULL)
+ *   out_depth     [B,h,w] fp32  sum_d p_d depth_d                         (NULL to skip)
+ *   out_index     [B,h,w] fp32  sum_d p_d d                               (NULL to skip)
+ *   out_conf      [B,h,w] fp32  window probability (NULL to skip):
+ *                   conf_mode 0: p[i-1]+p[i]+p[i+1]+p[i+2], i = trunc(E[index])   (MVSNet / CVP)
+ *                   conf_mode 1: sum of p_d with |d - E[index]| <= window         (Vis soft_argmin(window=))
+ *   out_entropy   [B,h,w] fp32  -sum p log(clamp(p,1e-9,1))               (NULL to skip)
+ *   out_prob      [B,D,h,w] fp32 full probability volume                  (NULL to skip)
+ *   out_partials  [B,4,h,w] fp32 (max, sum exp, sum exp*depth, sum exp*index) of THIS depth shard, for the
+ *                 cross-GPU log-sum-exp merge (NULL to skip); index counts from index_offset.
+ */
+int pscv_softargmin(const void* logits, int logit_dtype, const float* depth, long depth_bstride, int depth_per_pixel,
+                    float* out_depth, float* out_index, float* out_conf, float* out_entropy, float* out_prob,
+                    float* out_partials, int conf_mode, float window, int index_offset, int B, int D, int h, int w,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSCV_H */

@@ -1,0 +1,142 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in tests/golden/*.npz from the reference itself.
+
+Runs ONLY in the build container (needs /root/reference, which never travels to
+the GPU box).  The reference is imported as-is; its unused imports (cv2,
+torchvision, h5py, matplotlib) are satisfied with empty stub modules and its
+hard-coded ``.cuda()`` calls are neutralised by making ``Tensor.cuda`` /
+``Module.cuda`` the identity in this process.
+
+What is stored is data only: seeded synthetic inputs are NOT stored when they can
+be re-created from ``wild_deep_mvs_amd.synthetic`` (the fixture records the
+generator arguments instead); every stage boundary of the reference's hot path is
+stored as fp32 arrays (tiny problem sizes; per-view warped volumes keep 3 planes).
+
+Usage:  python tests/golden/gen_golden.py [--only mvsnet|mvsnet_s|vis|cvp]
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("PSCV_REFERENCE", "/root/reference")
+
+
+def import_reference():
+    sys.dont_write_bytecode = True
+    for name in ["cv2", "torchvision", "torchvision.utils", "torchvision.transforms", "h5py", "matplotlib",
+                 "matplotlib.pyplot"]:
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                sys.modules[name] = types.ModuleType(name)
+    tv = sys.modules["torchvision.transforms"]
+    if not hasattr(tv, "ToPILImage"):
+        tv.ToPILImage = lambda *a, **k: None
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    sys.path.insert(0, REF)
+
+
+PLANES = [0, 5, 15]  # depth planes of the per-view warped volumes that are kept
+
+
+def np32(x):
+    return x.detach().to(torch.float32).cpu().numpy()
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+# --------------------------------------------------------------------------
+def gen_mvsnet(aggregation: str, tag: str, *, H=64, W=96, V=3, D=16, seed=0, behind_view=-1, scene_seed=0):
+    sys.path.insert(0, REPO)
+    from wild_deep_mvs_amd import synthetic
+    from models.MVSNet.model import MVSNet  # reference
+    from models.MVSNet.module import homo_warping, depth_regression  # reference
+
+    torch.manual_seed(0)
+    net = MVSNet(aggregation)
+    net.num_depth = D
+    sd = synthetic.sharpened_state_dict("mvsnet", synthetic.template_of(net), seed=seed)
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    scene = synthetic.make_scene(1, V, H, W, seed=scene_seed, behind_view=behind_view)
+
+    with torch.no_grad():
+        out = net(scene["imgs"], scene["K"], scene["R"], scene["t"], scene["depth_min"], scene["depth_max"])
+        # stage boundaries, re-run piecewise through the reference's own functions
+        imgs = torch.unbind(scene["imgs"], 1)
+        feats = net.extract_features(imgs)
+        from utils.utils_3D import build_proj_matrices
+        Ks = scene["K"].clone()
+        Ks[:, :, :2] /= 4
+        proj = build_proj_matrices(Ks, scene["R"], scene["t"])
+        rng = torch.arange(D).view(1, 1, -1)
+        step = (scene["depth_max"] - scene["depth_min"]) / (D - 1)
+        depth_values = scene["depth_min"].unsqueeze(-1) + step.unsqueeze(-1) * rng
+        dv = depth_values[:, 0]
+        warped = [homo_warping(feats[i], proj[:, i], proj[:, 0], dv, feats[0].shape[-2:]) for i in range(1, V)]
+        cost = net.build_cost_volume(feats[0], feats[1:], proj[:, 0], [proj[:, i] for i in range(1, V)], dv)
+        reg = net.cost_regularization
+        c0 = reg.conv0(cost)
+        c1 = reg.conv1(c0)
+        c2 = reg.conv2(c1)
+        c3 = reg.conv3(c2)
+        c4 = reg.conv4(c3)
+        c5 = reg.conv5(c4)
+        c6 = reg.conv6(c5)
+        u7 = c4 + reg.conv7(c6)
+        u9 = c2 + reg.conv9(u7)
+        u11 = c0 + reg.conv11(u9)
+        logits = reg.prob(u11)
+        prob = torch.softmax(logits.squeeze(1), dim=1)
+        # per-pixel depth planes through the reference warp (module.py:140-143)
+        hh, ww = feats[0].shape[-2:]
+        dpp = dv.view(1, D, 1, 1) * (1.0 + 0.05 * torch.rand(1, D, hh, ww, generator=torch.Generator().manual_seed(3)))
+        warped_pp = homo_warping(feats[1], proj[:, 1], proj[:, 0], dpp, (hh, ww))
+
+    print(f"[{tag}] max prob mean {prob.max(1)[0].mean():.3f}, logit std over D {logits.squeeze(1).std(1).mean():.3f}, "
+          f"cost abs mean {cost.abs().mean():.4f}, depth range {out['depth'].min():.3f}..{out['depth'].max():.3f}")
+    save(f"{tag}.npz",
+         meta=np.array([H, W, V, D, seed, scene_seed, behind_view], dtype=np.int64),
+         features=np.stack([np32(f) for f in feats]),
+         proj=np32(proj), depth_values=np32(depth_values),
+         warped_planes=np.array(PLANES, dtype=np.int64),
+         warped=np.stack([np32(w_[:, :, PLANES]) for w_ in warped]).astype(np.float32),
+         cost_volume=np32(cost),
+         conv0=np32(c0), conv2=np32(c2), conv6=np32(c6), up7=np32(u7), up11=np32(u11),
+         logits=np32(logits),
+         depth=np32(out["depth"]), photometric_confidence=np32(out["photometric_confidence"]),
+         depth_per_pixel=np32(dpp), warped_per_pixel=np32(warped_pp[:, :, PLANES]))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    import_reference()
+    torch.set_num_threads(8)
+    todo = {
+        "mvsnet": lambda: gen_mvsnet("variance", "mvsnet_tiny"),
+        "mvsnet_behind": lambda: gen_mvsnet("variance", "mvsnet_behind", V=4, behind_view=2, scene_seed=5),
+        "mvsnet_s": lambda: gen_mvsnet("softmin", "mvsnet_s_tiny", seed=1),
+    }
+    for k, fn in todo.items():
+        if args.only in (None, k):
+            fn()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,104 @@
+"""The CPU oracle against outputs of the reference itself (tests/golden/*.npz,
+made by tests/golden/gen_golden.py).  Every stage boundary of the MVSNet path."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mvsnet as O
+from oracle import sampling
+from wild_deep_mvs_amd import synthetic
+
+
+def _load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name))
+    return {k: z[k] for k in z.files}
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def _mvsnet_template(aggregation):
+    from wild_deep_mvs_amd.models.MVSNet.model import MVSNet
+    return synthetic.template_of(MVSNet(aggregation))
+
+
+CASES = [("mvsnet_tiny.npz", "variance"), ("mvsnet_behind.npz", "variance"), ("mvsnet_s_tiny.npz", "softmin")]
+
+
+@pytest.mark.parametrize("fname,agg", CASES)
+def test_mvsnet_stage_boundaries(golden_dir, fname, agg):
+    g = _load(golden_dir, fname)
+    H, W, V, D, seed, scene_seed, behind = [int(x) for x in g["meta"]]
+    sd = synthetic.sharpened_state_dict("mvsnet", _mvsnet_template(agg), seed=seed)
+    scene = synthetic.make_scene(1, V, H, W, seed=scene_seed, behind_view=behind)
+
+    taps = {}
+    with torch.no_grad():
+        out = O.forward(scene["imgs"], scene["K"], scene["R"], scene["t"], scene["depth_min"], scene["depth_max"], sd,
+                        num_depth=D, aggregation=agg, taps=taps)
+
+    def close(name, got, tol):
+        ref = g[name]
+        got = got.numpy() if isinstance(got, torch.Tensor) else got
+        assert got.shape == ref.shape, (name, got.shape, ref.shape)
+        err = np.abs(got - ref).max()
+        assert err <= tol * max(1.0, np.abs(ref).max()), f"{name}: max err {err}"
+
+    close("proj", taps["proj"], 1e-6)
+    close("depth_values", taps["depth_values"], 1e-6)
+    close("features", torch.stack(taps["features"]), 1e-5)
+    close("cost_volume", taps["cost_volume"], 1e-5)
+    for k in ("conv0", "conv2", "conv6", "up7", "up11", "logits"):
+        close(k, taps[k], 2e-5)
+    close("depth", out["depth"], 1e-5)
+    close("photometric_confidence", out["photometric_confidence"], 1e-5)
+    if behind >= 0:
+        # the turned-around source contributes exactly zero (q_z <= 0 -> sample at -10 px)
+        assert np.abs(g["warped"][behind - 1]).max() == 0.0
+
+
+@pytest.mark.parametrize("fname,agg", CASES[:2])
+def test_homo_warping_against_reference(golden_dir, fname, agg):
+    g = _load(golden_dir, fname)
+    feats, proj, dv = _t(g["features"]), _t(g["proj"]), _t(g["depth_values"])[:, 0]
+    planes = g["warped_planes"].tolist()
+    V = feats.shape[0]
+    for i in range(1, V):
+        w = O.homo_warping(feats[i], proj[:, i], proj[:, 0], dv, feats[0].shape[-2:])
+        np.testing.assert_allclose(w[:, :, planes].numpy(), g["warped"][i - 1], atol=1e-5, rtol=0)
+    # per-pixel depth planes [B,D,h,w] (reference module.py:140-143)
+    wpp = O.homo_warping(feats[1], proj[:, 1], proj[:, 0], _t(g["depth_per_pixel"]), feats[0].shape[-2:])
+    np.testing.assert_allclose(wpp[:, :, planes].numpy(), g["warped_per_pixel"], atol=1e-5, rtol=0)
+
+
+def test_bilinear_first_principles_matches_grid_sample(golden_dir):
+    """numpy restatement of grid_sample(bilinear, zeros, align_corners=True) == ATen, incl. partial
+    border taps and far out-of-range samples."""
+    g = _load(golden_dir, "mvsnet_tiny.npz")
+    feats, proj, dv = _t(g["features"]), _t(g["proj"]), _t(g["depth_values"])[:, 0]
+    src = feats[1]
+    hs, ws = src.shape[-2:]
+    u, v, _ = O.sweep_pixel_coords(proj[:, 1], proj[:, 0], dv, (hs, ws))
+    gx = (u / ((ws - 1) / 2) - 1).clamp(-10, 10).numpy()
+    gy = (v / ((hs - 1) / 2) - 1).clamp(-10, 10).numpy()
+    ix = sampling.unnormalize(gx[0], ws)
+    iy = sampling.unnormalize(gy[0], hs)
+    mine = sampling.bilinear_zero_pad(src[0].numpy(), ix, iy)  # [C, D, h*w]
+    ref = O.homo_warping(src, proj[:, 1], proj[:, 0], dv)[0].reshape(src.shape[1], -1, hs * ws).numpy()
+    np.testing.assert_allclose(mine, ref, atol=2e-5, rtol=0)
+    frac_partial = ((ix > -1) & (ix < 0) | (ix > ws - 1) & (ix < ws)).mean()
+    assert frac_partial > 0, "test scene should exercise partial border taps"
+
+
+def test_confidence_window_definition():
+    """photometric confidence == p[i-1]+p[i]+p[i+1]+p[i+2], i = trunc(E[index]) (model.py:211-215)."""
+    torch.manual_seed(0)
+    p = torch.softmax(torch.randn(2, 12, 5, 7) * 3, dim=1)
+    conf = O.photometric_confidence(p)
+    idx = (p * torch.arange(12.0).view(1, -1, 1, 1)).sum(1).long()
+    pp = torch.nn.functional.pad(p, (0, 0, 0, 0, 1, 2))
+    want = sum(torch.gather(pp, 1, (idx + k).unsqueeze(1)).squeeze(1) for k in range(4))
+    np.testing.assert_allclose(conf.numpy(), want.numpy(), atol=1e-6)

@@ -1,0 +1,24 @@
+"""wild_deep_mvs_amd -- MI355X-native plane-sweep cost-volume engine behind the reference's models/* API.
+
+    csrc/ + libpscv.so   hand-written HIP kernels for gfx950 behind a C ABI (include/pscv.h)
+    _lib.py / ops.py     ctypes binding and tensor-level wrappers (PyTorch = device memory + streams)
+    models/              mirror of the reference's ``models`` package (same import paths / names)
+    synthetic.py         seeded cameras, images, features and sharpened weights (no datasets here)
+    dist.py              multi-GPU sharding of the path (one process per GPU, RCCL via torch.distributed)
+"""
+import importlib
+import sys
+
+__all__ = ["install_as_models"]
+
+
+def install_as_models() -> None:
+    """Make ``import models.MVSNet.model`` (the reference's import paths, train.py:33-36,
+    evaluation/pipeline_utils.py:131-154) resolve to this package's mirror."""
+    pkg = importlib.import_module(__name__ + ".models")
+    sys.modules["models"] = pkg
+    for sub in ("MVSNet", "MVSNet.model", "MVSNet.module"):
+        try:
+            sys.modules["models." + sub] = importlib.import_module(f"{__name__}.models.{sub}")
+        except ImportError:
+            pass

@@ -1,0 +1,103 @@
+"""ctypes binding of libpscv.so (the C ABI declared in include/pscv.h).
+
+The library is built in-tree by ``wild_deep_mvs_amd/csrc/Makefile`` (``__graft_entry__.build()``)
+and must be present: there is no PyTorch / CPU fallback for the hot path.  ``lib()`` raises
+``PscvMissingError`` when the shared object cannot be loaded.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpscv.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+# mirror of include/pscv.h
+ABI_VERSION = 1
+F32, BF16 = 0, 1
+GEOM_PROJ, GEOM_HOMOG = 0, 1
+COST_VARIANCE, COST_VARIANCE_CVP, COST_SOFTMIN, COST_GROUPCORR, COST_WARP_ONLY = 0, 1, 2, 3, 4
+CONV_S1, CONV_S2, CONV_T2 = 0, 1, 2
+EPI_RELU_PRE, EPI_RELU_POST = 1, 2
+MAX_SRC = 16
+CAM_FLOATS = 18
+
+EXPORTS = ("pscv_last_error", "pscv_abi_version", "pscv_warp_cost", "pscv_pack_conv3d_weights", "pscv_conv3d",
+           "pscv_softargmin")
+
+
+class PscvMissingError(RuntimeError):
+    pass
+
+
+class PscvError(RuntimeError):
+    pass
+
+
+_lock = threading.Lock()
+_lib = None
+
+
+def build(verbose: bool = False) -> str:
+    """Compile libpscv.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j4"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+        print(res.stderr)
+    if res.returncode != 0:
+        raise RuntimeError("building libpscv.so failed")
+    return LIB_PATH
+
+
+def _declare(lib):
+    vp, i, l, f = C.c_void_p, C.c_int, C.c_long, C.c_float
+    lib.pscv_last_error.restype = C.c_char_p
+    lib.pscv_last_error.argtypes = []
+    lib.pscv_abi_version.restype = i
+    lib.pscv_abi_version.argtypes = []
+    lib.pscv_warp_cost.restype = i
+    lib.pscv_warp_cost.argtypes = [vp, C.POINTER(vp), i, vp, vp, l, i, i, i, f, vp, i, i, i, i, i, i, i, i, i, vp]
+    lib.pscv_pack_conv3d_weights.restype = l
+    lib.pscv_pack_conv3d_weights.argtypes = [vp, i, i, i, i, vp]
+    lib.pscv_conv3d.restype = i
+    lib.pscv_conv3d.argtypes = [vp, i, i, vp, vp, vp, vp, vp, i, i, vp, i, i, i, i, i, i, i, i, i, i, i, vp]
+    lib.pscv_softargmin.restype = i
+    lib.pscv_softargmin.argtypes = [vp, i, vp, l, i, vp, vp, vp, vp, vp, vp, i, f, i, i, i, i, i, vp]
+
+
+def lib():
+    """The loaded library (loads on first use; import torch first so that its HIP runtime is the one
+    both sides share -- both carry SONAME libamdhip64.so.7)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise PscvMissingError(
+                    f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(or make -C wild_deep_mvs_amd/csrc). The plane-sweep engine has no CPU / PyTorch fallback.")
+            try:
+                import torch  # noqa: F401  (loads torch's libamdhip64 first)
+            except Exception:  # pragma: no cover
+                pass
+            try:
+                handle = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+            except OSError as e:
+                raise PscvMissingError(f"cannot load {LIB_PATH}: {e}") from e
+            _declare(handle)
+            ver = handle.pscv_abi_version()
+            if ver != ABI_VERSION:
+                raise PscvMissingError(f"libpscv.so ABI {ver} != binding ABI {ABI_VERSION}: rebuild")
+            _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().pscv_last_error().decode("utf-8", "replace")
+        raise PscvError(f"{what} failed (rc={rc}): {msg}")

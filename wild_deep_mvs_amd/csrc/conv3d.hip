@@ -1,0 +1,321 @@
+// 3x3x3 convolution over a channels-last bf16 volume as an MFMA implicit GEMM (gfx950, wave64).
+//
+// GEMM view (per output voxel n, output channel m):  D[m][n] = sum_k W[m][k] * X[k][n],
+//   k = (tap, c_in) flattened, K = 27 * C_in (zero padded to a multiple of 32);
+//   A operand = packed weights (16 output channels x 32 k per v_mfma_f32_16x16x32_bf16),
+//   B operand = 16 x-adjacent output voxels x 32 k, read with ds_read_b128 from an LDS brick that holds
+//   the input halo region of the workgroup's output tile (every input voxel is fetched once per tile);
+//   D: lane (n = lane&15, g = lane>>4) owns 4 consecutive output channels of voxel n, so the epilogue
+//   (folded BatchNorm affine, ReLU, skip add) ends in one 8-byte bf16 store per lane.
+// Both MFMA operands use the same (lane, j) -> k mapping, so the contraction is independent of the
+// instruction's internal k ordering; only "row/col = lane & 15" and the D layout are relied on.
+//
+// Kinds: S1 (stride 1), S2 (stride 2), T2 (transposed, stride 2, output_padding 1: decomposed into its 8
+// output-parity classes, each a dense 1/2/4/8-tap convolution over the input grid -- no zero insertion).
+//
+// Replaces (fdarmon/wild_deep_mvs): models/MVSNet/module.py:41-58 ConvBnReLU3D/ConvBn3D, the
+// Sequential(ConvTranspose3d, BatchNorm3d, ReLU) blocks and `prob` of models/MVSNet/model.py:43-84,
+// models/CVP_MVSNet/models/net.py:50-85 and the 3-D members of models/VisMVSNet/nn_utils.py:194-278.
+#include "pscv_common.h"
+
+namespace pscv {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+struct ConvArgs {
+    const uint16_t* in;
+    const uint16_t* wpk;
+    const float* scale;
+    const float* bias;
+    const float* floor;
+    const uint16_t* skip;
+    void* out;
+    int in_cs, in_co, skip_cs, skip_co, out_cs, out_co;
+    int out_f32;
+    int B, Di, Hi, Wi, Do, Ho, Wo;
+    int cout, epi;
+    int ntd, nth, ntw;   // tile counts along d, h, w
+};
+
+// ---- compile-time geometry ----------------------------------------------------------------------
+template <int KIND, int TD, int TH> struct Brick;
+template <int TD, int TH> struct Brick<PSCV_CONV_S1, TD, TH> { static constexpr int BD = TD + 2, BH = TH + 2, BW = 18; };
+template <int TD, int TH> struct Brick<PSCV_CONV_S2, TD, TH> { static constexpr int BD = 2 * TD + 1, BH = 2 * TH + 1, BW = 33; };
+template <int TD, int TH> struct Brick<PSCV_CONV_T2, TD, TH> { static constexpr int BD = TD + 1, BH = TH + 1, BW = 17; };
+
+__host__ __device__ constexpr int ceil_div(int a, int b) { return (a + b - 1) / b; }
+// number of taps / k-steps of T2 parity class pc = pd*4 + ph*2 + pw
+__host__ __device__ constexpr int t2_ntaps(int pc) { return (1 + ((pc >> 2) & 1)) * (1 + ((pc >> 1) & 1)) * (1 + (pc & 1)); }
+__host__ __device__ constexpr int t2_nsteps(int pc, int cin) { return ceil_div(t2_ntaps(pc) * cin, 32); }
+__host__ __device__ constexpr int t2_stepbase(int pc, int cin) {
+    int s = 0;
+    for (int i = 0; i < pc; ++i) s += t2_nsteps(i, cin);
+    return s;
+}
+__host__ __device__ constexpr int conv_total_steps(int kind, int cin) {
+    return kind == PSCV_CONV_T2 ? t2_stepbase(8, cin) : ceil_div(27 * cin, 32);
+}
+
+// LDS byte offset (relative to the lane's output-voxel anchor) of tap `tap` for the dense kinds
+template <int KIND, int BH, int BW, int VS> __device__ __forceinline__ int tap_off_dense(int tap) {
+    tap = tap > 26 ? 26 : tap;   // k padding: any finite in-brick voxel (its weights are zero)
+    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+    return ((kd * BH + kh) * BW + kw) * VS;
+}
+// same for a T2 parity class: per dim, parity 0 -> one tap (k=1, offset 0); parity 1 -> two taps
+// (sub 0: k=0 at input offset +1, sub 1: k=2 at offset 0)
+template <int BH, int BW, int VS> __device__ __forceinline__ int tap_off_t2(int pc, int t) {
+    const int pd = (pc >> 2) & 1, ph = (pc >> 1) & 1, pw = pc & 1;
+    const int nt = (1 + pd) * (1 + ph) * (1 + pw);
+    t = t >= nt ? nt - 1 : t;
+    const int tw = t % (1 + pw), th = (t / (1 + pw)) % (1 + ph), td = t / ((1 + pw) * (1 + ph));
+    const int od = (pd && td == 0) ? 1 : 0, oh = (ph && th == 0) ? 1 : 0, ow = (pw && tw == 0) ? 1 : 0;
+    return ((od * BH + oh) * BW + ow) * VS;
+}
+
+template <int CIN, int NT, int KIND, int TD, int TH>
+__global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
+    using BR = Brick<KIND, TD, TH>;
+    constexpr int BD = BR::BD, BH = BR::BH, BW = BR::BW;
+    constexpr int VS = CIN * 2 + 16;             // LDS bytes per voxel (+16 B pad against bank conflicts)
+    constexpr int CCH = CIN / 8;                 // 16-byte chunks per voxel
+    constexpr int NVOX = BD * BH * BW;
+    constexpr int NMT = TD * TH;                 // M-tiles (rows of 16 x-adjacent voxels) per workgroup
+    constexpr int MB = NMT / 4;                  // M-tiles per wave
+    static_assert(NMT % 4 == 0, "tile rows must split evenly over the 4 waves");
+    constexpr int SXY = (KIND == PSCV_CONV_S2) ? 2 : 1;   // input step per output voxel
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    // ---- which tile (XCD-aware bijective remap: each XCD gets a contiguous run of tiles) ----
+    const int nwg = gridDim.x;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    const int tw_i = wg % a.ntw; wg /= a.ntw;
+    const int th_i = wg % a.nth; wg /= a.nth;
+    const int td_i = wg % a.ntd; wg /= a.ntd;
+    const int b = wg;
+
+    // tile anchor in "row space": output coords for S1/S2, input coords for T2
+    const int t0d = td_i * TD, t0h = th_i * TH, t0w = tw_i * 16;
+    // brick origin in input coords
+    const int o_d = (KIND == PSCV_CONV_S1) ? t0d - 1 : (KIND == PSCV_CONV_S2) ? 2 * t0d - 1 : t0d;
+    const int o_h = (KIND == PSCV_CONV_S1) ? t0h - 1 : (KIND == PSCV_CONV_S2) ? 2 * t0h - 1 : t0h;
+    const int o_w = (KIND == PSCV_CONV_S1) ? t0w - 1 : (KIND == PSCV_CONV_S2) ? 2 * t0w - 1 : t0w;
+
+    // ---- stage the input brick into LDS (zero fill outside the volume = the conv's padding) ----
+    const int tid = threadIdx.x;
+    {
+        const uint16_t* inb = a.in + (long)b * a.Di * a.Hi * a.Wi * a.in_cs + a.in_co;
+        for (int c = tid; c < NVOX * CCH; c += 256) {
+            const int v = c / CCH, cc = c - v * CCH;
+            const int bw = v % BW, t = v / BW;
+            const int bh = t % BH, bd = t / BH;
+            const int gd = o_d + bd, gh = o_h + bh, gw = o_w + bw;
+            uint4 val = make_uint4(0u, 0u, 0u, 0u);
+            if ((unsigned)gd < (unsigned)a.Di && (unsigned)gh < (unsigned)a.Hi && (unsigned)gw < (unsigned)a.Wi)
+                val = *reinterpret_cast<const uint4*>(inb + (((long)gd * a.Hi + gh) * a.Wi + gw) * a.in_cs + cc * 8);
+            *reinterpret_cast<uint4*>(smem + v * VS + cc * 16) = val;
+        }
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const uint4* wpk = reinterpret_cast<const uint4*>(a.wpk);
+
+    // per-M-tile LDS anchors of this lane's voxel column
+    int anchor[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+        const int mt = wave * MB + i;
+        const int td = mt / TH, th = mt % TH;
+        anchor[i] = ((td * SXY * BH + th * SXY) * BW + n * SXY) * VS;
+    }
+
+    // ---- epilogue (shared by all kinds) ----
+    auto epilogue = [&](const f32x4 (&acc)[NT], int od, int oh, int ow) {
+        if (od >= a.Do || oh >= a.Ho || ow >= a.Wo) return;
+        const long vox = (((long)b * a.Do + od) * a.Ho + oh) * a.Wo + ow;
+#pragma unroll
+        for (int m = 0; m < NT; ++m) {
+            const int c0 = m * 16 + g * 4;
+            if (c0 >= a.cout) continue;
+            float y[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = c0 + k;
+                const bool cv = c < a.cout;
+                const float sc = (a.scale && cv) ? a.scale[c] : 1.0f;
+                const float bi = (a.bias && cv) ? a.bias[c] : 0.0f;
+                float t = fmaf(acc[m][k], sc, bi);
+                if (a.epi & PSCV_EPI_RELU_PRE) t = fmaxf(t, (a.floor && cv) ? a.floor[c] : 0.0f);
+                y[k] = t;
+            }
+            if (a.skip) {
+                const uint16_t* sp = a.skip + vox * a.skip_cs + a.skip_co + c0;
+                if (a.cout - c0 >= 4) {
+                    const uint2 sv = *reinterpret_cast<const uint2*>(sp);
+                    y[0] += bf16lo(sv.x); y[1] += bf16hi(sv.x); y[2] += bf16lo(sv.y); y[3] += bf16hi(sv.y);
+                } else {
+                    for (int k = 0; k < a.cout - c0; ++k) y[k] += bf16_to_f32(sp[k]);
+                }
+            }
+            if (a.epi & PSCV_EPI_RELU_POST) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) y[k] = fmaxf(y[k], 0.0f);
+            }
+            if (a.out_f32) {
+                float* op = reinterpret_cast<float*>(a.out) + vox * a.out_cs + a.out_co + c0;
+                if (a.cout - c0 >= 4) *reinterpret_cast<float4*>(op) = make_float4(y[0], y[1], y[2], y[3]);
+                else for (int k = 0; k < a.cout - c0; ++k) op[k] = y[k];
+            } else {
+                uint16_t* op = reinterpret_cast<uint16_t*>(a.out) + vox * a.out_cs + a.out_co + c0;
+                if (a.cout - c0 >= 4) *reinterpret_cast<uint2*>(op) = make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
+                else for (int k = 0; k < a.cout - c0; ++k) op[k] = f32_to_bf16(y[k]);
+            }
+        }
+    };
+
+    if (KIND != PSCV_CONV_T2) {
+        constexpr int NSTEPS = ceil_div(27 * CIN, 32);
+        f32x4 acc[MB][NT];
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int m = 0; m < NT; ++m) acc[i][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+        for (int s = 0; s < NSTEPS; ++s) {
+            const int kk0 = s * 32 + g * 8;
+            const int koff = tap_off_dense<KIND, BH, BW, VS>(kk0 / CIN) + (kk0 % CIN) * 2;
+            bf16x8 wf[NT];
+#pragma unroll
+            for (int m = 0; m < NT; ++m) wf[m] = __builtin_bit_cast(bf16x8, wpk[(s * NT + m) * 64 + lane]);
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                const bf16x8 xf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(smem + anchor[i] + koff));
+#pragma unroll
+                for (int m = 0; m < NT; ++m) acc[i][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[m], xf, acc[i][m], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            const int mt = wave * MB + i;
+            epilogue(acc[i], t0d + mt / TH, t0h + mt % TH, t0w + n);
+        }
+    } else {
+#pragma unroll
+        for (int pc = 0; pc < 8; ++pc) {
+            const int nsteps = t2_nsteps(pc, CIN);
+            const int sbase = t2_stepbase(pc, CIN);
+            f32x4 acc[MB][NT];
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int m = 0; m < NT; ++m) acc[i][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {   // 16 = max k-steps of a class (8 taps x C_in 64)
+                if (s < nsteps) {
+                    const int kk0 = s * 32 + g * 8;
+                    const int koff = tap_off_t2<BH, BW, VS>(pc, kk0 / CIN) + (kk0 % CIN) * 2;
+                    bf16x8 wf[NT];
+#pragma unroll
+                    for (int m = 0; m < NT; ++m) wf[m] = __builtin_bit_cast(bf16x8, wpk[((sbase + s) * NT + m) * 64 + lane]);
+#pragma unroll
+                    for (int i = 0; i < MB; ++i) {
+                        const bf16x8 xf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(smem + anchor[i] + koff));
+#pragma unroll
+                        for (int m = 0; m < NT; ++m) acc[i][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[m], xf, acc[i][m], 0, 0, 0);
+                    }
+                }
+            }
+            const int pd = (pc >> 2) & 1, ph = (pc >> 1) & 1, pw = pc & 1;
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                const int mt = wave * MB + i;
+                const int id = t0d + mt / TH, ih = t0h + mt % TH, iw = t0w + n;
+                if (id < a.Di && ih < a.Hi && iw < a.Wi) epilogue(acc[i], 2 * id + pd, 2 * ih + ph, 2 * iw + pw);
+            }
+        }
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+template <int CIN, int NT, int KIND, int TD, int TH>
+static int launch_conv(ConvArgs& a, hipStream_t st) {
+    using BR = Brick<KIND, TD, TH>;
+    constexpr int VS = CIN * 2 + 16;
+    constexpr int LDS = BR::BD * BR::BH * BR::BW * VS;
+    static_assert(LDS <= 160 * 1024, "brick does not fit the 160 KiB LDS");
+    const int rd = KIND == PSCV_CONV_T2 ? a.Di : a.Do, rh = KIND == PSCV_CONV_T2 ? a.Hi : a.Ho,
+              rw = KIND == PSCV_CONV_T2 ? a.Wi : a.Wo;
+    a.ntd = ceil_div(rd, TD); a.nth = ceil_div(rh, TH); a.ntw = ceil_div(rw, 16);
+    const long nblk = (long)a.B * a.ntd * a.nth * a.ntw;
+    if (nblk <= 0 || nblk > 0x7fffffffL) { set_error("pscv_conv3d: bad grid %ld", nblk); return -1; }
+    auto kern = conv3d_kernel<CIN, NT, KIND, TD, TH>;
+    static bool attr_done = false;   // per instantiation
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) { set_error("pscv_conv3d: hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e)); return -2; }
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), LDS, st, a);
+    return 0;
+}
+
+template <int CIN, int NT>
+static int launch_kind(ConvArgs& a, int kind, hipStream_t st) {
+    switch (kind) {
+        case PSCV_CONV_S1: return launch_conv<CIN, NT, PSCV_CONV_S1, 4, 4>(a, st);
+        case PSCV_CONV_S2: return launch_conv<CIN, NT, PSCV_CONV_S2, 2, 2>(a, st);
+        case PSCV_CONV_T2: return launch_conv<CIN, NT, PSCV_CONV_T2, 2, 4>(a, st);
+    }
+    set_error("pscv_conv3d: unknown kind %d", kind);
+    return -1;
+}
+
+}  // namespace pscv
+
+extern "C" int pscv_conv3d(const void* in, int in_cstride, int in_coff, const uint16_t* packed, const float* scale,
+                           const float* bias, const float* floor, const void* skip, int skip_cstride, int skip_coff,
+                           void* out, int out_cstride, int out_coff, int out_dtype, int B, int Di, int Hi, int Wi,
+                           int c_in, int c_out, int kind, int epi_flags, void* stream) {
+    using namespace pscv;
+    PSCV_CHECK_ARG(in && packed && out, "pscv_conv3d: null pointer argument");
+    PSCV_CHECK_ARG(B > 0 && Di > 0 && Hi > 0 && Wi > 0, "pscv_conv3d: bad sizes");
+    PSCV_CHECK_ARG(in_cstride % 8 == 0 && in_coff % 8 == 0 && in_coff + c_in <= in_cstride,
+                   "pscv_conv3d: input channel slice [%d,%d) of stride %d must be 8-aligned", in_coff, in_coff + c_in, in_cstride);
+    PSCV_CHECK_ARG(out_coff + c_out <= out_cstride, "pscv_conv3d: output channel slice exceeds stride");
+    PSCV_CHECK_ARG(c_out < 4 || (out_cstride % 4 == 0 && out_coff % 4 == 0), "pscv_conv3d: output slice must be 4-aligned");
+    PSCV_CHECK_ARG(!skip || c_out < 4 || (skip_cstride % 4 == 0 && skip_coff % 4 == 0), "pscv_conv3d: skip slice must be 4-aligned");
+    PSCV_CHECK_ARG(out_dtype == PSCV_BF16 || out_dtype == PSCV_F32, "pscv_conv3d: bad out dtype %d", out_dtype);
+    ConvArgs a;
+    a.in = reinterpret_cast<const uint16_t*>(in);
+    a.wpk = packed; a.scale = scale; a.bias = bias; a.floor = floor;
+    a.skip = reinterpret_cast<const uint16_t*>(skip);
+    a.out = out;
+    a.in_cs = in_cstride; a.in_co = in_coff; a.skip_cs = skip_cstride; a.skip_co = skip_coff;
+    a.out_cs = out_cstride; a.out_co = out_coff; a.out_f32 = out_dtype == PSCV_F32;
+    a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi;
+    if (kind == PSCV_CONV_S1) { a.Do = Di; a.Ho = Hi; a.Wo = Wi; }
+    else if (kind == PSCV_CONV_S2) { a.Do = (Di + 1) / 2; a.Ho = (Hi + 1) / 2; a.Wo = (Wi + 1) / 2; }
+    else { a.Do = 2 * Di; a.Ho = 2 * Hi; a.Wo = 2 * Wi; }
+    a.cout = c_out; a.epi = epi_flags;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int nt = (c_out + 15) / 16;
+    int rc = -1;
+#define PSCV_CONV_CASE(CI, NTV) if (c_in == CI && nt == NTV) rc = launch_kind<CI, NTV>(a, kind, st); else
+    PSCV_CONV_CASE(8, 1) PSCV_CONV_CASE(8, 2)
+    PSCV_CONV_CASE(16, 1) PSCV_CONV_CASE(16, 2)
+    PSCV_CONV_CASE(32, 1) PSCV_CONV_CASE(32, 2) PSCV_CONV_CASE(32, 4)
+    PSCV_CONV_CASE(64, 2) PSCV_CONV_CASE(64, 4)
+    { set_error("pscv_conv3d: unsupported channel combination c_in=%d c_out=%d", c_in, c_out); return -1; }
+#undef PSCV_CONV_CASE
+    if (rc) return rc;
+    PSCV_CHECK_LAUNCH("pscv_conv3d");
+    return 0;
+}

@@ -1,0 +1,119 @@
+// Softmax over the depth axis fused with every expectation the three models take from it (gfx950).
+//
+// One lane per pixel, logits read plane by plane (coalesced across x), fp32 arithmetic:
+//   pass 1  running max;  pass 2  sum exp, sum exp*depth, sum exp*index;  optional pass 3 for the
+//   entropy / full probability volume; the confidence window re-reads only the 4-5 planes it needs.
+// Also emits the per-shard (max, sum, sum*depth, sum*index) partials used by the depth-plane-sharded
+// multi-GPU path (log-sum-exp merge = one tiny all-reduce).
+//
+// Replaces (fdarmon/wild_deep_mvs): F.softmax + depth_regression + photometric confidence
+// models/MVSNet/model.py:207-215, models/MVSNet/module.py:174-178, models/CVP_MVSNet/models/net.py:161-162,
+// 203-219; soft_argmin / entropy models/VisMVSNet/nn_utils.py:453-470.
+#include "pscv_common.h"
+
+namespace pscv {
+
+struct SoftArgs {
+    const void* logits;
+    const float* depth;
+    long depth_bstride;
+    int depth_per_pixel;
+    float *o_depth, *o_index, *o_conf, *o_entropy, *o_prob, *o_part;
+    int conf_mode;
+    float window;
+    int index_offset;
+    int B, D, h, w;
+};
+
+template <typename T> __device__ __forceinline__ float ldlogit(const T* p);
+template <> __device__ __forceinline__ float ldlogit<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ldlogit<uint16_t>(const uint16_t* p) { return bf16_to_f32(*p); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void softargmin_kernel(const SoftArgs a) {
+    const long hw = (long)a.h * a.w;
+    const long npix = (long)a.B * hw;
+    const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= npix) return;
+    const int b = (int)(pix / hw);
+    const long pf = pix - (long)b * hw;
+    const T* lp = reinterpret_cast<const T*>(a.logits) + (long)b * a.D * hw + pf;
+    const float* dp = a.depth ? a.depth + (long)b * a.depth_bstride + (a.depth_per_pixel ? pf : 0) : nullptr;
+    const long dstep = a.depth_per_pixel ? hw : 1;
+
+    float m = -INFINITY;
+    for (int d = 0; d < a.D; ++d) m = fmaxf(m, ldlogit<T>(lp + d * hw));
+
+    float se = 0.f, sd = 0.f, si = 0.f;
+    for (int d = 0; d < a.D; ++d) {
+        const float e = expf(ldlogit<T>(lp + d * hw) - m);
+        se += e;
+        if (dp) sd = fmaf(e, dp[d * dstep], sd);
+        si = fmaf(e, (float)(d + a.index_offset), si);
+    }
+    const float inv = 1.0f / se;
+    const float eidx = si * inv;   // expected plane index            model.py:213, nn_utils.py:459
+    if (a.o_depth) a.o_depth[pix] = sd * inv;
+    if (a.o_index) a.o_index[pix] = eidx;
+    if (a.o_part) {
+        float* pp = a.o_part + (long)b * 4 * hw + pf;
+        pp[0] = m; pp[hw] = se; pp[2 * hw] = sd; pp[3 * hw] = si;
+    }
+    if (a.o_conf) {
+        float c = 0.f;
+        const float lidx = eidx - (float)a.index_offset;   // index local to this logit block
+        if (a.conf_mode == 0) {
+            // planes i-1 .. i+2 around i = trunc(E[index]) (zero padded)        model.py:211-215
+            const int i = (int)lidx;
+            for (int k = -1; k <= 2; ++k) {
+                const int d = i + k;
+                if (d >= 0 && d < a.D) c += expf(ldlogit<T>(lp + d * hw) - m) * inv;
+            }
+        } else {
+            // planes with |d - E[index]| <= window                              nn_utils.py:464-465
+            int dlo = (int)ceilf(lidx - a.window), dhi = (int)floorf(lidx + a.window);
+            dlo = dlo < 0 ? 0 : dlo;
+            dhi = dhi > a.D - 1 ? a.D - 1 : dhi;
+            for (int d = dlo; d <= dhi; ++d)
+                if (fabsf((float)d - lidx) <= a.window) c += expf(ldlogit<T>(lp + d * hw) - m) * inv;
+        }
+        a.o_conf[pix] = c;
+    }
+    if (a.o_entropy || a.o_prob) {
+        float ent = 0.f;
+        float* pr = a.o_prob ? a.o_prob + (long)b * a.D * hw + pf : nullptr;
+        for (int d = 0; d < a.D; ++d) {
+            const float p = expf(ldlogit<T>(lp + d * hw) - m) * inv;
+            if (pr) pr[d * hw] = p;
+            ent -= p * logf(fminf(fmaxf(p, 1e-9f), 1.0f));   // nn_utils.py:469-470
+        }
+        if (a.o_entropy) a.o_entropy[pix] = ent;
+    }
+}
+
+}  // namespace pscv
+
+extern "C" int pscv_softargmin(const void* logits, int logit_dtype, const float* depth, long depth_bstride,
+                               int depth_per_pixel, float* out_depth, float* out_index, float* out_conf,
+                               float* out_entropy, float* out_prob, float* out_partials, int conf_mode, float window,
+                               int index_offset, int B, int D, int h, int w, void* stream) {
+    using namespace pscv;
+    PSCV_CHECK_ARG(logits, "pscv_softargmin: logits is null");
+    PSCV_CHECK_ARG(B > 0 && D > 0 && h > 0 && w > 0, "pscv_softargmin: bad sizes");
+    PSCV_CHECK_ARG(depth || !out_depth, "pscv_softargmin: out_depth requested without depth planes");
+    PSCV_CHECK_ARG(conf_mode == 0 || conf_mode == 1, "pscv_softargmin: conf_mode %d", conf_mode);
+    SoftArgs a;
+    a.logits = logits; a.depth = depth; a.depth_bstride = depth_bstride; a.depth_per_pixel = depth_per_pixel;
+    a.o_depth = out_depth; a.o_index = out_index; a.o_conf = out_conf; a.o_entropy = out_entropy;
+    a.o_prob = out_prob; a.o_part = out_partials;
+    a.conf_mode = conf_mode; a.window = window; a.index_offset = index_offset;
+    a.B = B; a.D = D; a.h = h; a.w = w;
+    const long npix = (long)B * h * w;
+    const unsigned nblk = (unsigned)((npix + 255) / 256);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (logit_dtype == PSCV_F32) hipLaunchKernelGGL(softargmin_kernel<float>, dim3(nblk), dim3(256), 0, st, a);
+    else if (logit_dtype == PSCV_BF16) hipLaunchKernelGGL(softargmin_kernel<uint16_t>, dim3(nblk), dim3(256), 0, st, a);
+    else { set_error("pscv_softargmin: bad logit dtype %d", logit_dtype); return -1; }
+    PSCV_CHECK_LAUNCH("pscv_softargmin");
+    return 0;
+}

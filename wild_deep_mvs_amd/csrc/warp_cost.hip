@@ -1,0 +1,377 @@
+// Fused plane-sweep warp + cost aggregation for gfx950 (MI355X).
+//
+// One pass: for every cost-volume voxel (b, d, y, x) the source feature maps are sampled at the
+// homography-warped position and folded straight into the cost statistic in fp32 registers; the
+// per-view warped volumes of the reference (503 MB fp32 each at 5-view 512x640 D=192) never exist.
+// Algorithmic HBM traffic = read V feature maps + write the cost volume once.
+//
+// Layout: feature maps are channels-last [B,h,w,C] so a bilinear tap is one contiguous C-vector;
+// the cost volume is [B,D,h,w,C], the layout the MFMA conv3d kernel consumes.
+// Mapping: LPV lanes share a voxel (each owns CPL = C/LPV channels, loaded 16 B at a time); a wave
+// therefore covers 64/LPV x-adjacent voxels and writes one contiguous 64/LPV * C * esize byte run.
+// A block owns 256/LPV pixels x PPD depth planes; blocks are remapped so that each XCD works on a
+// contiguous band of reference pixels (its source footprint stays inside that XCD's 4 MiB L2).
+//
+// Reference semantics restated here (file:line of fdarmon/wild_deep_mvs):
+//   PROJ  geometry  models/MVSNet/module.py:127-166, models/CVP_MVSNet/models/modules.py:74-128,241-281
+//   HOMOG geometry  models/VisMVSNet/homography.py:23-120
+//   variance        models/MVSNet/model.py:113-139   (CVP rounding order: models/CVP_MVSNet/models/net.py:148)
+//   softmin         models/MVSNet/model.py:141-173
+//   group corr.     models/VisMVSNet/nn_utils.py:473-490
+#include "pscv_common.h"
+
+namespace pscv {
+
+struct WarpArgs {
+    const void* ref;
+    const void* src[PSCV_MAX_SRC];
+    const float* cams;   // [n_src][B][18]
+    const float* depth;
+    void* out;
+    long depth_bstride;
+    long out_view_stride;  // elements between per-source outputs (GROUPCORR / WARP_ONLY)
+    int n_src, B, h, w, hs, ws, D;
+    int depth_per_pixel;
+    int ppd;             // depth planes per block
+    int npb_batch;       // pixel blocks per batch item: ceil(h*w / PPB)
+    int n_dchunks;       // ceil(D / ppd)
+    float temp;
+    float sx, sy;        // index scale: PROJ 1, HOMOG (W-1)/W
+    float xlo, xhi, ylo, yhi;  // clamp of the pixel index implied by the reference's grid clamp
+};
+
+template <int N> struct VecF { float v[N]; };
+
+template <typename T, int CPL> __device__ __forceinline__ VecF<CPL> load_chan(const T* p) {
+    VecF<CPL> r;
+#pragma unroll
+    for (int k = 0; k < CPL / 8; ++k) {
+        const f32x8 t = Elem<T>::load8(p + 8 * k);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r.v[8 * k + j] = t.v[j];
+    }
+    return r;
+}
+template <typename T, int CPL> __device__ __forceinline__ void store_chan(T* p, const VecF<CPL>& r) {
+#pragma unroll
+    for (int k = 0; k < CPL / 8; ++k) {
+        f32x8 t;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t.v[j] = r.v[8 * k + j];
+        Elem<T>::store8(p + 8 * k, t);
+    }
+}
+
+// Source-image pixel index (ix, iy) of reference pixel (px, py) on plane d for one source camera.
+template <int GEOM>
+__device__ __forceinline__ void sweep_index(const float* __restrict__ cam, float px, float py, float d,
+                                            const WarpArgs& a, float& ix, float& iy) {
+    float hx, hy, hz;
+    if (GEOM == PSCV_GEOM_PROJ) {
+        // q = rot * (x, y, 1) * d + trans                                  module.py:138-144
+        const float rx = fmaf(cam[1], py, cam[0] * px) + cam[2];
+        const float ry = fmaf(cam[4], py, cam[3] * px) + cam[5];
+        const float rz = fmaf(cam[7], py, cam[6] * px) + cam[8];
+        hx = fmaf(rx, d, cam[9]);
+        hy = fmaf(ry, d, cam[10]);
+        hz = fmaf(rz, d, cam[11]);
+    } else {
+        // hom = A p - (Bm p) / (d + 1e-9)                                  homography.py:63-69
+        const float ax = fmaf(cam[1], py, cam[0] * px) + cam[2];
+        const float ay = fmaf(cam[4], py, cam[3] * px) + cam[5];
+        const float az = fmaf(cam[7], py, cam[6] * px) + cam[8];
+        const float bx = fmaf(cam[10], py, cam[9] * px) + cam[11];
+        const float by = fmaf(cam[13], py, cam[12] * px) + cam[14];
+        const float bz = fmaf(cam[16], py, cam[15] * px) + cam[17];
+        const float inv_d = __builtin_amdgcn_rcpf(d + 1e-9f);
+        hx = fmaf(-bx, inv_d, ax);
+        hy = fmaf(-by, inv_d, ay);
+        hz = fmaf(-bz, inv_d, az);
+    }
+    // perspective divide; points at or behind the source camera go to (-10, -10)   module.py:146-150,
+    // homography.py:113-117 (which also clamps the divisor at 1e-9)
+    const bool front = hz > 0.0f;
+    const float inv_z = __builtin_amdgcn_rcpf(GEOM == PSCV_GEOM_HOMOG ? fmaxf(hz, 1e-9f) : hz);
+    float u = front ? hx * inv_z : -10.0f;
+    float v = front ? hy * inv_z : -10.0f;
+    // normalise -> clamp -> align_corners=True un-normalise collapses to a scaled, clamped index
+    ix = fminf(fmaxf(u * a.sx, a.xlo), a.xhi);
+    iy = fminf(fmaxf(v * a.sy, a.ylo), a.yhi);
+}
+
+// Zero-padded bilinear gather of this lane's CPL channels.
+template <typename TIn, int CPL>
+__device__ __forceinline__ VecF<CPL> gather_bilinear(const TIn* __restrict__ img, int b, int hs, int ws, int C,
+                                                     int choff, float ix, float iy) {
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const float fx = ix - x0f, fy = iy - y0f;
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const int x1 = x0 + 1, y1 = y0 + 1;
+    const bool vx0 = (unsigned)x0 < (unsigned)ws, vx1 = (unsigned)x1 < (unsigned)ws;
+    const bool vy0 = (unsigned)y0 < (unsigned)hs, vy1 = (unsigned)y1 < (unsigned)hs;
+    const float gx = 1.0f - fx, gy = 1.0f - fy;
+    const float w00 = (vx0 && vy0) ? gx * gy : 0.0f;
+    const float w01 = (vx1 && vy0) ? fx * gy : 0.0f;
+    const float w10 = (vx0 && vy1) ? gx * fy : 0.0f;
+    const float w11 = (vx1 && vy1) ? fx * fy : 0.0f;
+    const int xc0 = min(max(x0, 0), ws - 1), xc1 = min(max(x1, 0), ws - 1);
+    const int yc0 = min(max(y0, 0), hs - 1), yc1 = min(max(y1, 0), hs - 1);
+    const long row0 = ((long)b * hs + yc0) * ws, row1 = ((long)b * hs + yc1) * ws;
+    const VecF<CPL> f00 = load_chan<TIn, CPL>(img + (row0 + xc0) * C + choff);
+    const VecF<CPL> f01 = load_chan<TIn, CPL>(img + (row0 + xc1) * C + choff);
+    const VecF<CPL> f10 = load_chan<TIn, CPL>(img + (row1 + xc0) * C + choff);
+    const VecF<CPL> f11 = load_chan<TIn, CPL>(img + (row1 + xc1) * C + choff);
+    VecF<CPL> r;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j)
+        r.v[j] = fmaf(f11.v[j], w11, fmaf(f10.v[j], w10, fmaf(f01.v[j], w01, f00.v[j] * w00)));
+    return r;
+}
+
+template <typename TIn, typename TOut, int C, int LPV, int GEOM, int COST>
+__global__ __launch_bounds__(256) void warp_cost_kernel(const WarpArgs a) {
+    constexpr int CPL = C / LPV;        // channels per lane
+    constexpr int PPB = 256 / LPV;      // pixels per block
+    static_assert(CPL % 8 == 0, "a lane owns whole 8-channel groups");
+
+    // XCD-aware bijective remap: hardware places block `bid` on XCD bid % 8; give XCD k a contiguous
+    // run of work ids (pixel-block major, depth-chunk minor) = a band of reference pixels.
+    const int nwg = gridDim.x;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    const int pb = wg / a.n_dchunks;
+    const int dc = wg - pb * a.n_dchunks;
+
+    // a block never straddles batch items, so b (and with it every camera / depth-plane address) is
+    // wave-uniform and those reads become scalar loads
+    const int b = pb / a.npb_batch;
+    const int pbb = pb - b * a.npb_batch;
+
+    const int tid = threadIdx.x;
+    const int hw = a.h * a.w;
+    int pflat = pbb * PPB + tid / LPV;
+    const bool active = pflat < hw;
+    pflat = active ? pflat : hw - 1;
+    const int choff = (tid % LPV) * CPL;
+    const long pix = (long)b * hw + pflat;
+    const int y = pflat / a.w;
+    const int x = pflat - y * a.w;
+    const float off = (GEOM == PSCV_GEOM_HOMOG) ? 0.5f : 0.0f;   // homography.py:78-79 half-pixel centres
+    const float px = (float)x + off, py = (float)y + off;
+
+    const TIn* ref = reinterpret_cast<const TIn*>(a.ref);
+    VecF<CPL> rf;
+    if (COST != PSCV_COST_WARP_ONLY) {
+        rf = load_chan<TIn, CPL>(ref + pix * C + choff);
+    }
+
+    const int d0 = dc * a.ppd;
+    const int d1 = min(a.D, d0 + a.ppd);
+    const float invN = 1.0f / (float)(a.n_src + 1);
+    const float invN2 = 1.0f / ((float)(a.n_src + 1) * (float)(a.n_src + 1));
+    TOut* out = reinterpret_cast<TOut*>(a.out);
+
+    for (int d = d0; d < d1; ++d) {
+        const float dval = a.depth_per_pixel ? a.depth[(long)b * a.depth_bstride + (long)d * hw + pflat]
+                                             : a.depth[(long)b * a.depth_bstride + d];
+        const long vox = ((long)b * a.D + d) * hw + pflat;
+
+        VecF<CPL> acc0, acc1;   // variance: sum, sum of squares; softmin: sum e*diff
+        float sum_e = 0.0f;
+        if (COST == PSCV_COST_VARIANCE || COST == PSCV_COST_VARIANCE_CVP) {
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) { acc0.v[j] = rf.v[j]; acc1.v[j] = rf.v[j] * rf.v[j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) { acc0.v[j] = 0.0f; acc1.v[j] = 0.0f; }
+        }
+
+        for (int v = 0; v < a.n_src; ++v) {
+            const float* cam = a.cams + ((long)v * a.B + b) * PSCV_CAM_FLOATS;
+            float ix, iy;
+            sweep_index<GEOM>(cam, px, py, dval, a, ix, iy);
+            const VecF<CPL> wv = gather_bilinear<TIn, CPL>(reinterpret_cast<const TIn*>(a.src[v]), b, a.hs, a.ws, C,
+                                                           choff, ix, iy);
+            if (COST == PSCV_COST_VARIANCE || COST == PSCV_COST_VARIANCE_CVP) {
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) {
+                    acc0.v[j] += wv.v[j];
+                    acc1.v[j] = fmaf(wv.v[j], wv.v[j], acc1.v[j]);
+                }
+            } else if (COST == PSCV_COST_SOFTMIN) {
+                VecF<CPL> diff;
+                float part = 0.0f;
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) {
+                    const float t = rf.v[j] - wv.v[j];
+                    diff.v[j] = t * t;
+                    part += diff.v[j];
+                }
+                // sum over all C channels = over the LPV lanes that share this voxel
+#pragma unroll
+                for (int m = 1; m < LPV; m <<= 1) part += __shfl_xor(part, m, 64);
+                const float e = __expf(-a.temp * part);
+                sum_e += e;
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) acc0.v[j] = fmaf(e, diff.v[j], acc0.v[j]);
+            } else if (COST == PSCV_COST_GROUPCORR) {
+                constexpr int G = C / 4;
+                TOut* o = out + (long)v * a.out_view_stride + vox * G + choff / 4;
+                if (active) {
+#pragma unroll
+                    for (int g = 0; g < CPL / 4; g += 2) {
+                        const float c0 = rf.v[4 * g] * wv.v[4 * g] + rf.v[4 * g + 1] * wv.v[4 * g + 1] +
+                                         rf.v[4 * g + 2] * wv.v[4 * g + 2] + rf.v[4 * g + 3] * wv.v[4 * g + 3];
+                        const float c1 = rf.v[4 * g + 4] * wv.v[4 * g + 4] + rf.v[4 * g + 5] * wv.v[4 * g + 5] +
+                                         rf.v[4 * g + 6] * wv.v[4 * g + 6] + rf.v[4 * g + 7] * wv.v[4 * g + 7];
+                        Elem<TOut>::store2(o + g, c0, c1);
+                    }
+                }
+            } else {  // WARP_ONLY
+                if (active) store_chan<TOut, CPL>(out + (long)v * a.out_view_stride + vox * C + choff, wv);
+            }
+        }
+
+        if (COST == PSCV_COST_VARIANCE) {
+            VecF<CPL> o;
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) o.v[j] = acc1.v[j] * invN - (acc0.v[j] * acc0.v[j]) * invN2;
+            if (active) store_chan<TOut, CPL>(out + vox * C + choff, o);
+        } else if (COST == PSCV_COST_VARIANCE_CVP) {
+            VecF<CPL> o;
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) {
+                const float m = acc0.v[j] * invN;
+                o.v[j] = acc1.v[j] * invN - m * m;
+            }
+            if (active) store_chan<TOut, CPL>(out + vox * C + choff, o);
+        } else if (COST == PSCV_COST_SOFTMIN) {
+            VecF<CPL> o;
+            const float inv = 1.0f / (sum_e + 1e-6f);
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) o.v[j] = acc0.v[j] * inv;
+            if (active) store_chan<TOut, CPL>(out + vox * C + choff, o);
+        }
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+static int g_warp_lpv_override = 0;  // 0 = default heuristic; set through PSCV_WARP_LPV for tuning runs
+static int g_warp_ppd_override = 0;
+
+// Instantiated (geometry, cost) pairs: the variance / softmin statistics belong to the PROJ models (MVSNet,
+// CVP), group-wise correlation to the HOMOG model (Vis); the plain warp exists for both.
+template <typename TIn, typename TOut, int C, int LPV, int GEOM>
+static int launch_cost(const WarpArgs& a, int cost, int nblk, hipStream_t st) {
+#define PSCV_LAUNCH_COST(COSTV)                                                                              \
+    case COSTV:                                                                                              \
+        hipLaunchKernelGGL((warp_cost_kernel<TIn, TOut, C, LPV, GEOM, COSTV>), dim3(nblk), dim3(256), 0, st, a); \
+        return 0;
+    if constexpr (GEOM == PSCV_GEOM_PROJ) {
+        switch (cost) {
+            PSCV_LAUNCH_COST(PSCV_COST_VARIANCE)
+            PSCV_LAUNCH_COST(PSCV_COST_VARIANCE_CVP)
+            PSCV_LAUNCH_COST(PSCV_COST_SOFTMIN)
+            PSCV_LAUNCH_COST(PSCV_COST_WARP_ONLY)
+        }
+    } else {
+        switch (cost) {
+            PSCV_LAUNCH_COST(PSCV_COST_GROUPCORR)
+            PSCV_LAUNCH_COST(PSCV_COST_WARP_ONLY)
+        }
+    }
+#undef PSCV_LAUNCH_COST
+    set_error("pscv_warp_cost: cost mode %d is not available with geometry %d", cost, (int)GEOM);
+    return -1;
+}
+
+template <typename TIn, typename TOut, int C, int LPV>
+static int launch_geom(WarpArgs& a, int geom, int cost, hipStream_t st) {
+    constexpr int PPB = 256 / LPV;
+    a.npb_batch = (a.h * a.w + PPB - 1) / PPB;
+    const long n_pixblocks = (long)a.npb_batch * a.B;
+    int ppd = g_warp_ppd_override > 0 ? g_warp_ppd_override : 8;
+    // keep >= ~4096 blocks in flight for 256 CUs when the problem allows it
+    while (ppd > 1 && n_pixblocks * ((a.D + ppd - 1) / ppd) < 4096) ppd >>= 1;
+    a.ppd = ppd;
+    a.n_dchunks = (a.D + ppd - 1) / ppd;
+    const long nblk = n_pixblocks * a.n_dchunks;
+    if (nblk <= 0 || nblk > 0x7fffffffL) {
+        set_error("pscv_warp_cost: bad grid size %ld", nblk);
+        return -1;
+    }
+    if (geom == PSCV_GEOM_PROJ) return launch_cost<TIn, TOut, C, LPV, PSCV_GEOM_PROJ>(a, cost, (int)nblk, st);
+    if (geom == PSCV_GEOM_HOMOG) return launch_cost<TIn, TOut, C, LPV, PSCV_GEOM_HOMOG>(a, cost, (int)nblk, st);
+    set_error("pscv_warp_cost: unknown geometry %d", geom);
+    return -1;
+}
+
+template <typename TIn, typename TOut>
+static int launch_channels(WarpArgs& a, int C, int geom, int cost, hipStream_t st) {
+    // default: 8 channels (16 B of bf16) per lane, i.e. C/8 lanes per voxel
+    int lpv = g_warp_lpv_override > 0 ? g_warp_lpv_override : C / 8;
+    if (cost == PSCV_COST_GROUPCORR && C / lpv < 8) lpv = C / 8;
+#define PSCV_CASE(CC, LL) \
+    if (C == CC && lpv == LL) return launch_geom<TIn, TOut, CC, LL>(a, geom, cost, st);
+    PSCV_CASE(32, 4) PSCV_CASE(32, 2) PSCV_CASE(32, 1)
+    PSCV_CASE(16, 2)
+#undef PSCV_CASE
+    set_error("pscv_warp_cost: unsupported channels/lanes-per-voxel C=%d lpv=%d", C, lpv);
+    return -1;
+}
+
+}  // namespace pscv
+
+extern "C" int pscv_warp_cost(const void* ref, const void* const* srcs, int n_src, const float* cams,
+                              const float* depth, long depth_bstride, int depth_per_pixel, int geom, int cost,
+                              float temp, void* out, int B, int C, int h, int w, int hs, int ws, int D, int in_dtype,
+                              int out_dtype, void* stream) {
+    using namespace pscv;
+    PSCV_CHECK_ARG(n_src >= 1 && n_src <= PSCV_MAX_SRC, "pscv_warp_cost: n_src=%d outside [1,%d]", n_src, PSCV_MAX_SRC);
+    PSCV_CHECK_ARG(srcs && cams && depth && out, "pscv_warp_cost: null pointer argument");
+    PSCV_CHECK_ARG(cost == PSCV_COST_WARP_ONLY || ref, "pscv_warp_cost: ref is required for cost mode %d", cost);
+    PSCV_CHECK_ARG(B > 0 && h > 0 && w > 0 && hs > 1 && ws > 1 && D > 0, "pscv_warp_cost: bad sizes");
+    PSCV_CHECK_ARG(C % 8 == 0, "pscv_warp_cost: C=%d must be a multiple of 8", C);
+    static bool env_read = false;
+    if (!env_read) {
+        env_read = true;
+        if (const char* e = getenv("PSCV_WARP_LPV")) g_warp_lpv_override = atoi(e);
+        if (const char* e = getenv("PSCV_WARP_PPD")) g_warp_ppd_override = atoi(e);
+    }
+    WarpArgs a;
+    a.ref = ref;
+    for (int i = 0; i < PSCV_MAX_SRC; ++i) a.src[i] = i < n_src ? srcs[i] : nullptr;
+    for (int i = 0; i < n_src; ++i) PSCV_CHECK_ARG(srcs[i], "pscv_warp_cost: srcs[%d] is null", i);
+    a.cams = cams;
+    a.depth = depth;
+    a.out = out;
+    a.depth_bstride = depth_bstride;
+    a.n_src = n_src; a.B = B; a.h = h; a.w = w; a.hs = hs; a.ws = ws; a.D = D;
+    a.depth_per_pixel = depth_per_pixel;
+    a.temp = temp;
+    const long vol = (long)B * D * h * w;
+    a.out_view_stride = cost == PSCV_COST_GROUPCORR ? vol * (C / 4) : vol * C;
+    if (geom == PSCV_GEOM_PROJ) {
+        // grid = u/((W-1)/2) - 1 clamped to +-10, index = (grid+1)/2*(W-1)  ->  index = u clamped to
+        // [-4.5 (W-1), 5.5 (W-1)]                                            module.py:151-155
+        a.sx = 1.0f; a.sy = 1.0f;
+        a.xlo = -4.5f * (ws - 1); a.xhi = 5.5f * (ws - 1);
+        a.ylo = -4.5f * (hs - 1); a.yhi = 5.5f * (hs - 1);
+    } else {
+        // grid = u/W*2 - 1 clamped to +-1.1, index = (grid+1)/2*(W-1)       homography.py:92-96
+        a.sx = (float)(ws - 1) / (float)ws; a.sy = (float)(hs - 1) / (float)hs;
+        a.xlo = -0.05f * (ws - 1); a.xhi = 1.05f * (ws - 1);
+        a.ylo = -0.05f * (hs - 1); a.yhi = 1.05f * (hs - 1);
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int rc;
+    if (in_dtype == PSCV_BF16 && out_dtype == PSCV_BF16) rc = launch_channels<uint16_t, uint16_t>(a, C, geom, cost, st);
+    else if (in_dtype == PSCV_BF16 && out_dtype == PSCV_F32) rc = launch_channels<uint16_t, float>(a, C, geom, cost, st);
+    else if (in_dtype == PSCV_F32 && out_dtype == PSCV_F32) rc = launch_channels<float, float>(a, C, geom, cost, st);
+    else { set_error("pscv_warp_cost: bad dtype codes %d/%d", in_dtype, out_dtype); return -1; }
+    if (rc) return rc;
+    PSCV_CHECK_LAUNCH("pscv_warp_cost");
+    return 0;
+}

@@ -1,0 +1,177 @@
+"""Drop-in for the reference's ``models/MVSNet/model.py`` (MVSNet / MVSNet-s) on the pscv HIP engine.
+
+Same constructor, ``forward(imgs, K, R, t, depth_min, depth_max, reference_frame=0, **kwargs)`` signature,
+return dict and state-dict key names/shapes as the reference (models/MVSNet/model.py:87-218), so released
+checkpoints load unchanged.  The 2-D ``FeatureNet`` is upstream of the hot path and stays on
+PyTorch-ROCm; everything from the feature maps to depth + confidence runs as four kinds of HIP launches:
+
+    fused warp + variance/softmin  ->  11 MFMA conv3d launches (BN/ReLU/skip fused)  ->  fused softargmin
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from ... import _lib as L
+from ... import ops
+from .module import ConvBnReLU, ConvBnReLU3D, deconv_engine_layer, homo_warping, depth_regression  # noqa: F401
+
+
+def build_proj_matrices(K: torch.Tensor, R: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+    """[[K R, K t], [0 0 0 1]] (reference utils/utils_3D.py:50-62; A0 of the path, stays torch)."""
+    P = torch.zeros(K.shape[:-2] + (4, 4), device=K.device, dtype=K.dtype)
+    P[..., :3, :3] = K @ R
+    P[..., :3, 3:] = K @ t
+    P[..., 3, 3] = 1
+    return P
+
+
+class FeatureNet(nn.Module):
+    """Upstream 2-D extractor, [B,3,H,W] -> [B,32,H/4,W/4] (reference models/MVSNet/model.py:21-41)."""
+
+    def __init__(self):
+        super().__init__()
+        self.inplanes = 32
+        spec = [(3, 8, 3, 1, 1), (8, 8, 3, 1, 1), (8, 16, 5, 2, 2), (16, 16, 3, 1, 1), (16, 16, 3, 1, 1),
+                (16, 32, 5, 2, 2), (32, 32, 3, 1, 1)]
+        for i, (ci, co, k, s, p) in enumerate(spec):
+            setattr(self, f"conv{i}", ConvBnReLU(ci, co, k, s, p))
+        self.feature = nn.Conv2d(32, 32, 3, 1, 1)
+
+    def forward(self, x):
+        for i in range(7):
+            x = getattr(self, f"conv{i}")(x)
+        return self.feature(x)
+
+
+def _deconv_block(ci: int, co: int) -> nn.Sequential:
+    return nn.Sequential(nn.ConvTranspose3d(ci, co, kernel_size=3, padding=1, output_padding=1, stride=2, bias=False),
+                         nn.BatchNorm3d(co), nn.ReLU(inplace=True))
+
+
+class CostRegNet(nn.Module):
+    """3-D U-Net regulariser (reference models/MVSNet/model.py:43-84) on MFMA conv3d launches.
+
+    The sub-modules only hold parameters under the reference's names; ``forward`` takes and returns the
+    engine's channels-last bf16 volumes: [B,D,h,w,32] -> fp32 logits [B,D,h,w]."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv0 = ConvBnReLU3D(32, 8)
+        self.conv1 = ConvBnReLU3D(8, 16, stride=2)
+        self.conv2 = ConvBnReLU3D(16, 16)
+        self.conv3 = ConvBnReLU3D(16, 32, stride=2)
+        self.conv4 = ConvBnReLU3D(32, 32)
+        self.conv5 = ConvBnReLU3D(32, 64, stride=2)
+        self.conv6 = ConvBnReLU3D(64, 64)
+        self.conv7 = _deconv_block(64, 32)
+        self.conv9 = _deconv_block(32, 16)
+        self.conv11 = _deconv_block(16, 8)
+        self.prob = nn.Conv3d(8, 1, 3, stride=1, padding=1)
+        self._layers: Optional[Dict[str, ops.Conv3dLayer]] = None
+        self._layers_key = None
+
+    # -- weight residency ------------------------------------------------------------------
+    def _param_key(self):
+        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+
+    def engine_layers(self) -> Dict[str, ops.Conv3dLayer]:
+        """Packed bf16 weights + folded eval-mode BN, rebuilt whenever a parameter changed
+        (load_state_dict, .to(), optimizer step)."""
+        key = self._param_key()
+        if self._layers is None or key != self._layers_key:
+            dev = self.prob.weight.device
+            lay = {f"conv{i}": getattr(self, f"conv{i}").engine_layer(dev) for i in range(7)}
+            for n in ("conv7", "conv9", "conv11"):
+                lay[n] = deconv_engine_layer(getattr(self, n), dev)
+            lay["prob"] = ops.Conv3dLayer.build(self.prob.weight, kind=L.CONV_S1, device=dev, conv_bias=self.prob.bias)
+            self._layers, self._layers_key = lay, key
+        return self._layers
+
+    def forward(self, cost: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
+        if self.training:
+            raise NotImplementedError("pscv CostRegNet: training-mode BatchNorm / backward are not implemented yet "
+                                      "(SURVEY.md section 8f-1); call .eval()")
+        B, D, h, w, _ = cost.shape
+        if D % 8 or h % 8 or w % 8:
+            raise ValueError(f"MVSNet CostRegNet needs D,h,w multiples of 8 (got {D},{h},{w}), as in the reference")
+        ly = self.engine_layers()
+        c0 = ops.conv3d(cost, ly["conv0"])
+        c2 = ops.conv3d(ops.conv3d(c0, ly["conv1"]), ly["conv2"])
+        c4 = ops.conv3d(ops.conv3d(c2, ly["conv3"]), ly["conv4"])
+        c6 = ops.conv3d(ops.conv3d(c4, ly["conv5"]), ly["conv6"])
+        u7 = ops.conv3d(c6, ly["conv7"], skip=c4)      # conv4 + relu(bn(deconv))     model.py:79
+        u9 = ops.conv3d(u7, ly["conv9"], skip=c2)      # model.py:80
+        u11 = ops.conv3d(u9, ly["conv11"], skip=c0)    # model.py:81
+        logits = ops.conv3d(u11, ly["prob"], out_dtype=torch.float32)
+        if taps is not None:
+            taps.update(conv0=c0, conv2=c2, conv4=c4, conv6=c6, up7=u7, up9=u9, up11=u11)
+        return logits.view(B, D, h, w)
+
+
+class MVSNet(nn.Module):
+    def __init__(self, aggregation="variance"):
+        super().__init__()
+        if aggregation not in ("variance", "softmin"):
+            raise NotImplementedError("Aggregation: " + aggregation)
+        self.feature = FeatureNet()
+        self.cost_regularization = CostRegNet()
+        if aggregation == "softmin":
+            self.register_parameter("temp", torch.nn.Parameter(torch.ones((1))))   # model.py:94-95
+        self.aggregation = aggregation
+        self.num_depth = 192
+        self.storage_dtype = torch.bfloat16   # HBM storage of features / cost volume / activations
+
+    # -- upstream ---------------------------------------------------------------------------
+    def extract_features(self, imgs: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+        return [self.feature(img) for img in imgs]
+
+    # -- hot path ---------------------------------------------------------------------------
+    def build_cost_volume(self, ref_feature, src_features, ref_proj, src_projs, depth_values):
+        """Channels-last features [B,h,w,32] + [B,4,4] projections + planes [B,D] (or [B,D,h,w])
+        -> channels-last cost volume [B,D,h,w,32] in one fused launch (reference model.py:109-176)."""
+        cams = ops.proj_cams(src_projs, ref_proj)
+        if self.aggregation == "variance":
+            return ops.warp_cost(ref_feature, src_features, cams, depth_values, geom=L.GEOM_PROJ,
+                                 cost=L.COST_VARIANCE, out_dtype=self.storage_dtype)
+        return ops.warp_cost(ref_feature, src_features, cams, depth_values, geom=L.GEOM_PROJ, cost=L.COST_SOFTMIN,
+                             temp=float(self.temp.detach().float().item()), out_dtype=self.storage_dtype)
+
+    def hot_path(self, features_cl: Sequence[torch.Tensor], proj: torch.Tensor, depth_values: torch.Tensor,
+                 reference_frame: int = 0, taps: Optional[dict] = None):
+        """features_cl: V channels-last maps [B,h,w,32]; proj [B,V,4,4]; depth_values [B,D] fp32 (reference view).
+        Returns (depth [B,h,w], photometric_confidence [B,h,w]) -- reference model.py:197-215."""
+        V = len(features_cl)
+        src_idx = [i for i in range(V) if i != reference_frame]
+        cost = self.build_cost_volume(features_cl[reference_frame], [features_cl[i] for i in src_idx],
+                                      proj[:, reference_frame], [proj[:, i] for i in src_idx], depth_values)
+        logits = self.cost_regularization(cost, taps)
+        o = ops.softargmin(logits, depth_values, want_conf=True, conf_mode=0)
+        if taps is not None:
+            taps.update(cost_volume=cost, logits=logits)
+        return o["depth"], o["conf"]
+
+    def forward(self, imgs, K, R, t, depth_min, depth_max, reference_frame=0, **kwargs):
+        if self.training:
+            raise NotImplementedError("pscv MVSNet: the HIP engine is inference-only for now; call .eval() "
+                                      "(backward kernels are the next scope row, SURVEY.md section 8f-1)")
+        if isinstance(imgs, torch.Tensor):
+            imgs = torch.unbind(imgs, 1)
+        scaled_K = K.clone()
+        scaled_K[:, :, :2] /= 4                                        # model.py:183-184
+        proj = build_proj_matrices(scaled_K, R, t)                     # [B,V,4,4]
+        if len(imgs) != proj.shape[1]:
+            raise AssertionError("Different number of images and projection matrices")
+        D = int(self.num_depth)
+        steps = torch.arange(D, device=depth_min.device, dtype=torch.float32).view(1, 1, -1)
+        depth_values = depth_min.unsqueeze(-1) + ((depth_max - depth_min) / (D - 1)).unsqueeze(-1) * steps  # model.py:187-189
+        dv_ref = depth_values[:, reference_frame].to(torch.float32).contiguous()
+
+        with torch.no_grad():
+            feats = self.extract_features(imgs)
+            feats_cl = [ops.to_channels_last(f, self.storage_dtype) for f in feats]
+            depth, conf = self.hot_path(feats_cl, proj, dv_ref, reference_frame, kwargs.get("taps"))
+        return {"depth": depth, "depth_est_list": [depth, ], "depth_pair_list": [],
+                "photometric_confidence": conf}

@@ -1,0 +1,267 @@
+"""Tensor-level host wrappers over the pscv C ABI (include/pscv.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every op below hands raw device
+pointers to ``libpscv.so`` on ``torch.cuda.current_stream()``.  Nothing in this module computes the
+hot path with torch ops, and every entry point raises if the tensors are not on a HIP device.
+
+Layouts: feature maps ``[B,h,w,C]`` and volumes ``[B,D,h,w,C]`` (channels-last), bf16 or fp32 storage.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+_TORCH2PSCV = {torch.float32: L.F32, torch.bfloat16: L.BF16}
+
+
+def _dt(t: torch.Tensor) -> int:
+    try:
+        return _TORCH2PSCV[t.dtype]
+    except KeyError:
+        raise TypeError(f"pscv: unsupported dtype {t.dtype} (float32 / bfloat16 only)")
+
+
+def _dev(*ts: Optional[torch.Tensor]):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("pscv: the plane-sweep engine runs on MI355X only; got a CPU tensor "
+                               "(there is no CPU / PyTorch fallback for the hot path)")
+        if not t.is_contiguous():
+            raise ValueError("pscv: tensors handed to the C ABI must be contiguous")
+
+
+def _p(t: Optional[torch.Tensor]):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# --------------------------------------------------------------------------------------------
+# layout helpers (plumbing)
+# --------------------------------------------------------------------------------------------
+def to_channels_last(x: torch.Tensor, dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
+    """[B,C,h,w] -> [B,h,w,C] or [B,C,D,h,w] -> [B,D,h,w,C], contiguous, in the storage dtype."""
+    perm = (0, 2, 3, 1) if x.dim() == 4 else (0, 2, 3, 4, 1)
+    return x.permute(*perm).to(dtype).contiguous()
+
+
+def to_channels_first(x: torch.Tensor) -> torch.Tensor:
+    """View a channels-last pscv tensor with the reference's NCHW / NCDHW index order (no copy)."""
+    perm = (0, 3, 1, 2) if x.dim() == 4 else (0, 4, 1, 2, 3)
+    return x.permute(*perm)
+
+
+# --------------------------------------------------------------------------------------------
+# cameras (A0; stays torch, fp64 closed forms, no LAPACK call on the device)
+# --------------------------------------------------------------------------------------------
+def inv3x3(m: torch.Tensor) -> torch.Tensor:
+    """Batched adjugate inverse of [...,3,3]."""
+    a, b, c = m[..., 0, 0], m[..., 0, 1], m[..., 0, 2]
+    d, e, f = m[..., 1, 0], m[..., 1, 1], m[..., 1, 2]
+    g, h, i = m[..., 2, 0], m[..., 2, 1], m[..., 2, 2]
+    co = torch.stack([e * i - f * h, c * h - b * i, b * f - c * e,
+                      f * g - d * i, a * i - c * g, c * d - a * f,
+                      d * h - e * g, b * g - a * h, a * e - b * d], dim=-1)
+    det = a * co[..., 0] + b * co[..., 3] + c * co[..., 6]
+    return (co / det.unsqueeze(-1)).reshape(m.shape)
+
+
+def proj_cams(src_projs: Sequence[torch.Tensor], ref_proj: torch.Tensor) -> torch.Tensor:
+    """PROJ-geometry camera block [n_src,B,18]: rot[9], trans[3] of ``P_src P_ref^-1``
+    (reference models/MVSNet/module.py:128-130).  Projection matrices are [B,4,4] with last row (0,0,0,1)."""
+    Pr = ref_proj.double()
+    Ar_inv = inv3x3(Pr[:, :3, :3])
+    br = Pr[:, :3, 3:4]
+    out = []
+    for Ps in src_projs:
+        Ps = Ps.double()
+        rot = Ps[:, :3, :3] @ Ar_inv
+        trans = Ps[:, :3, 3:4] - rot @ br
+        blk = torch.cat([rot.reshape(-1, 9), trans.reshape(-1, 3), torch.zeros_like(rot.reshape(-1, 9)[:, :6])], dim=1)
+        out.append(blk)
+    return torch.stack(out).to(torch.float32).contiguous()
+
+
+# --------------------------------------------------------------------------------------------
+# fused warp + cost
+# --------------------------------------------------------------------------------------------
+def warp_cost(ref: Optional[torch.Tensor], srcs: Sequence[torch.Tensor], cams: torch.Tensor, depth: torch.Tensor, *,
+              geom: int = L.GEOM_PROJ, cost: int = L.COST_VARIANCE, temp: float = 0.0,
+              ref_hw: Optional[Sequence[int]] = None, out_dtype: torch.dtype = torch.bfloat16,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """ref [B,h,w,C] (None for WARP_ONLY), srcs n x [B,hs,ws,C], cams [n,B,18] fp32,
+    depth [B,D] or [B,D,h,w] fp32  ->  cost volume [B,D,h,w,C]
+    (GROUPCORR: [n,B,D,h,w,C/4]; WARP_ONLY: [n,B,D,h,w,C])."""
+    srcs = list(srcs)
+    _dev(ref, cams, depth, *srcs)
+    B, hs, ws, Cc = srcs[0].shape
+    for s in srcs:
+        if s.shape != srcs[0].shape or s.dtype != srcs[0].dtype:
+            raise ValueError("pscv.warp_cost: all source feature maps must share shape and dtype")
+    if ref is not None:
+        h, w = ref.shape[1:3]
+        if ref.dtype != srcs[0].dtype or ref.shape[0] != B or ref.shape[3] != Cc:
+            raise ValueError("pscv.warp_cost: ref / src feature mismatch")
+    else:
+        h, w = (hs, ws) if ref_hw is None else (int(ref_hw[0]), int(ref_hw[1]))
+    n = len(srcs)
+    if cams.shape != (n, B, L.CAM_FLOATS) or cams.dtype != torch.float32:
+        raise ValueError(f"pscv.warp_cost: cams must be fp32 [{n},{B},{L.CAM_FLOATS}], got {tuple(cams.shape)}")
+    if depth.dtype != torch.float32:
+        raise ValueError("pscv.warp_cost: depth planes must be fp32")
+    D = depth.shape[1]
+    per_pixel = depth.dim() == 4
+    if per_pixel and tuple(depth.shape) != (B, D, h, w):
+        raise ValueError("pscv.warp_cost: per-pixel depth must be [B,D,h,w]")
+    if not per_pixel and depth.dim() != 2:
+        raise ValueError("pscv.warp_cost: depth must be [B,D] or [B,D,h,w]")
+    bstride = depth.stride(0)
+    if cost == L.COST_GROUPCORR:
+        shape = (n, B, D, h, w, Cc // 4)
+    elif cost == L.COST_WARP_ONLY:
+        shape = (n, B, D, h, w, Cc)
+    else:
+        shape = (B, D, h, w, Cc)
+    if out is None:
+        out = torch.empty(shape, dtype=out_dtype, device=srcs[0].device)
+    elif tuple(out.shape) != shape or not out.is_contiguous():
+        raise ValueError("pscv.warp_cost: bad `out` tensor")
+    ptrs = (C.c_void_p * n)(*[s.data_ptr() for s in srcs])
+    rc = L.lib().pscv_warp_cost(_p(ref), ptrs, n, _p(cams), _p(depth), bstride, int(per_pixel), geom, cost,
+                                float(temp), _p(out), B, Cc, h, w, hs, ws, D, _dt(srcs[0]), _dt(out), _stream())
+    L.check(rc, "pscv_warp_cost")
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# conv3d
+# --------------------------------------------------------------------------------------------
+def pack_conv3d_weights(weight: torch.Tensor, kind: int, transposed: bool) -> np.ndarray:
+    """Host-side repack of a Conv3d [Co,Ci,3,3,3] / ConvTranspose3d [Ci,Co,3,3,3] weight into the MFMA
+    fragment order of the conv kernel (uint16 bf16 bits)."""
+    w = np.ascontiguousarray(weight.detach().to("cpu", torch.float32).numpy())
+    if w.ndim != 5 or w.shape[2:] != (3, 3, 3):
+        raise ValueError(f"pscv: conv3d weights must be [*,*,3,3,3], got {w.shape}")
+    c_in, c_out = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
+    lib = L.lib()
+    n = lib.pscv_pack_conv3d_weights(None, c_in, c_out, kind, int(transposed), None)
+    if n < 0:
+        L.check(int(n), "pscv_pack_conv3d_weights")
+    packed = np.empty(n, dtype=np.uint16)
+    n2 = lib.pscv_pack_conv3d_weights(w.ctypes.data_as(C.c_void_p), c_in, c_out, kind, int(transposed),
+                                      packed.ctypes.data_as(C.c_void_p))
+    if n2 != n:
+        L.check(-1 if n2 >= 0 else int(n2), "pscv_pack_conv3d_weights")
+    return packed
+
+
+@dataclass
+class Conv3dLayer:
+    """One 3x3x3 layer ready for the engine: packed bf16 weights + fp32 epilogue vectors, on device."""
+    packed: torch.Tensor            # int16 view of bf16 fragments
+    c_in: int
+    c_out: int
+    kind: int
+    epi: int
+    scale: Optional[torch.Tensor] = None
+    bias: Optional[torch.Tensor] = None
+    floor: Optional[torch.Tensor] = None
+
+    @staticmethod
+    def build(weight: torch.Tensor, *, kind: int, transposed: bool = False, device=None,
+              bn: Optional[Sequence[torch.Tensor]] = None, bn_eps: float = 1e-5,
+              conv_bias: Optional[torch.Tensor] = None, relu: bool = False, relu_post: bool = False,
+              floor: Optional[torch.Tensor] = None) -> "Conv3dLayer":
+        """``bn`` = (gamma, beta, running_mean, running_var) folds an eval-mode BatchNorm3d into the
+        epilogue: scale = gamma / sqrt(var + eps), bias = beta - mean * scale (+ scale * conv_bias)."""
+        device = device if device is not None else weight.device
+        c_in, c_out = (weight.shape[0], weight.shape[1]) if transposed else (weight.shape[1], weight.shape[0])
+        packed = torch.from_numpy(pack_conv3d_weights(weight, kind, transposed).view(np.int16)).to(device)
+        scale = bias = None
+        if bn is not None:
+            gamma, beta, mean, var = [t.detach().to(device, torch.float32) for t in bn]
+            scale = gamma / torch.sqrt(var + bn_eps)
+            bias = beta - mean * scale
+            if conv_bias is not None:
+                bias = bias + scale * conv_bias.detach().to(device, torch.float32)
+            scale, bias = scale.contiguous(), bias.contiguous()
+        elif conv_bias is not None:
+            bias = conv_bias.detach().to(device, torch.float32).contiguous()
+        epi = (L.EPI_RELU_PRE if relu else 0) | (L.EPI_RELU_POST if relu_post else 0)
+        if floor is not None:
+            floor = floor.detach().to(device, torch.float32).contiguous()
+        return Conv3dLayer(packed, int(c_in), int(c_out), kind, epi, scale, bias, floor)
+
+
+def conv_out_shape(kind: int, D: int, H: int, W: int):
+    if kind == L.CONV_S1:
+        return D, H, W
+    if kind == L.CONV_S2:
+        return (D + 1) // 2, (H + 1) // 2, (W + 1) // 2
+    return 2 * D, 2 * H, 2 * W
+
+
+def conv3d(x: torch.Tensor, layer: Conv3dLayer, *, skip: Optional[torch.Tensor] = None, in_coff: int = 0,
+           skip_coff: int = 0, out: Optional[torch.Tensor] = None, out_coff: int = 0,
+           out_dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
+    """x bf16 [B,D,H,W,Cs] (reads channels [in_coff, in_coff+c_in)) -> [B,Do,Ho,Wo,c_out] (or writes the
+    channel slice [out_coff, out_coff+c_out) of ``out``)."""
+    _dev(x, skip, out, layer.packed)
+    if x.dtype != torch.bfloat16 or x.dim() != 5:
+        raise TypeError("pscv.conv3d: input must be a bf16 [B,D,H,W,C] volume")
+    B, D, H, W, cs = x.shape
+    Do, Ho, Wo = conv_out_shape(layer.kind, D, H, W)
+    if out is None:
+        out = torch.empty((B, Do, Ho, Wo, layer.c_out), dtype=out_dtype, device=x.device)
+    if tuple(out.shape[:4]) != (B, Do, Ho, Wo):
+        raise ValueError(f"pscv.conv3d: out has shape {tuple(out.shape)}, expected [B,{Do},{Ho},{Wo},*]")
+    if skip is not None and (skip.dtype != torch.bfloat16 or tuple(skip.shape[:4]) != (B, Do, Ho, Wo)):
+        raise ValueError("pscv.conv3d: skip must be bf16 with the output's spatial shape")
+    rc = L.lib().pscv_conv3d(_p(x), cs, in_coff, _p(layer.packed), _p(layer.scale), _p(layer.bias), _p(layer.floor),
+                             _p(skip), 0 if skip is None else skip.shape[4], skip_coff, _p(out), out.shape[4],
+                             out_coff, _dt(out), B, D, H, W, layer.c_in, layer.c_out, layer.kind, layer.epi, _stream())
+    L.check(rc, "pscv_conv3d")
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# softargmin
+# --------------------------------------------------------------------------------------------
+def softargmin(logits: torch.Tensor, depth: Optional[torch.Tensor] = None, *, want_index: bool = False,
+               want_conf: bool = False, conf_mode: int = 0, window: float = 2.0, want_entropy: bool = False,
+               want_prob: bool = False, want_partials: bool = False, index_offset: int = 0) -> dict:
+    """logits [B,D,h,w] (fp32 or bf16); depth [B,D] or [B,D,h,w] fp32.  Returns a dict with the requested
+    maps, each [B,h,w] fp32 (``prob`` [B,D,h,w], ``partials`` [B,4,h,w])."""
+    _dev(logits, depth)
+    if logits.dim() != 4:
+        raise ValueError("pscv.softargmin: logits must be [B,D,h,w]")
+    B, D, h, w = logits.shape
+    per_pixel = depth is not None and depth.dim() == 4
+    if depth is not None:
+        if depth.dtype != torch.float32 or depth.shape[:2] != (B, D):
+            raise ValueError("pscv.softargmin: depth must be fp32 [B,D] or [B,D,h,w]")
+    mk = lambda *s: torch.empty(s, dtype=torch.float32, device=logits.device)
+    o = {
+        "depth": mk(B, h, w) if depth is not None else None,
+        "index": mk(B, h, w) if want_index else None,
+        "conf": mk(B, h, w) if want_conf else None,
+        "entropy": mk(B, h, w) if want_entropy else None,
+        "prob": mk(B, D, h, w) if want_prob else None,
+        "partials": mk(B, 4, h, w) if want_partials else None,
+    }
+    rc = L.lib().pscv_softargmin(_p(logits), _dt(logits), _p(depth), 0 if depth is None else depth.stride(0),
+                                 int(per_pixel), _p(o["depth"]), _p(o["index"]), _p(o["conf"]), _p(o["entropy"]),
+                                 _p(o["prob"]), _p(o["partials"]), conf_mode, float(window), index_offset, B, D, h, w,
+                                 _stream())
+    L.check(rc, "pscv_softargmin")
+    return {k: v for k, v in o.items() if v is not None}

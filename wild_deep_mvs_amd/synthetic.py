@@ -1,0 +1,164 @@
+"""Synthetic plane-sweep inputs and deterministic network weights.
+
+There are no datasets or checkpoints in the build environment, so the tests,
+``bench.py``, ``__graft_entry__.smoke()`` and the golden-vector generator
+(``tests/golden/gen_golden.py``) all draw their cameras, images, feature maps
+and weights from here.  Everything is seeded through ``numpy.random.Generator``
+(PCG64, platform independent) so that the same tensors can be re-created on the
+GPU box without committing them.
+
+The sample dict mirrors what the reference's dataset loaders hand to
+``forward()`` (reference ``data/dtu_yao.py:133-146``): ``imgs`` [B,V,3,H,W],
+``K``/``R`` [B,V,3,3], ``t`` [B,V,3,1], ``depth_min``/``depth_max`` [B,V].
+
+Weights are *sharpened*: with PyTorch default initialisation the reference's
+logits have a std of ~1e-6 over the depth axis, the softmax is uniform and the
+depth map is independent of the warp, which would make
+every depth-parity check vacuous.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Dict, Mapping, Sequence, Tuple
+
+import numpy as np
+import torch
+
+
+# --------------------------------------------------------------------------
+# cameras / scenes
+# --------------------------------------------------------------------------
+def make_cameras(B: int, V: int, H: int, W: int, *, depth_min: float = 2.0,
+                 depth_max: float = 6.0, behind_view: int = -1,
+                 dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    """Pinhole rig: reference camera at identity, source ``v`` rotated about the
+    y axis by ``0.05 v (-1)^v`` rad and shifted ``0.1 v (-1)^v`` along x.
+
+    ``behind_view >= 0`` turns that source camera around (rotation by ~pi about
+    y) so that every reference ray lands behind it -- the ``q_z <= 0`` branch of
+    the warp (reference ``models/MVSNet/module.py:147-150``).
+    """
+    K = torch.zeros(B, V, 3, 3, dtype=dtype)
+    R = torch.zeros(B, V, 3, 3, dtype=dtype)
+    t = torch.zeros(B, V, 3, 1, dtype=dtype)
+    for b in range(B):
+        for v in range(V):
+            f = 0.9 * W * (1.0 + 0.02 * v + 0.01 * b)
+            K[b, v] = torch.tensor([[f, 0.0, W / 2.0 + 0.5 * v],
+                                    [0.0, f, H / 2.0 - 0.25 * v],
+                                    [0.0, 0.0, 1.0]], dtype=dtype)
+            sgn = -1.0 if v % 2 else 1.0
+            a = 0.05 * v * sgn + 0.01 * b
+            if v == behind_view:
+                a = math.pi - 0.1
+            ca, sa = math.cos(a), math.sin(a)
+            R[b, v] = torch.tensor([[ca, 0.0, sa], [0.0, 1.0, 0.0], [-sa, 0.0, ca]], dtype=dtype)
+            t[b, v] = torch.tensor([[0.1 * v * sgn], [0.02 * v], [0.0]], dtype=dtype)
+    dmin = torch.full((B, V), float(depth_min), dtype=dtype)
+    dmax = torch.full((B, V), float(depth_max), dtype=dtype)
+    return {"K": K, "R": R, "t": t, "depth_min": dmin, "depth_max": dmax}
+
+
+def make_scene(B: int, V: int, H: int, W: int, *, seed: int = 0, depth_min: float = 2.0,
+               depth_max: float = 6.0, behind_view: int = -1) -> Dict[str, torch.Tensor]:
+    """Full sample dict with smooth-ish random images in [0, 1)."""
+    rng = np.random.default_rng(seed)
+    # low-frequency content + noise so that the 2D feature nets see structure
+    coarse = rng.random((B, V, 3, max(H // 8, 1), max(W // 8, 1)), dtype=np.float32)
+    coarse_t = torch.from_numpy(coarse).reshape(B * V, 3, coarse.shape[-2], coarse.shape[-1])
+    smooth = torch.nn.functional.interpolate(coarse_t, size=(H, W), mode="bilinear", align_corners=False)
+    noise = torch.from_numpy(rng.random((B * V, 3, H, W), dtype=np.float32))
+    imgs = (0.7 * smooth + 0.3 * noise).reshape(B, V, 3, H, W).contiguous()
+    out = make_cameras(B, V, H, W, depth_min=depth_min, depth_max=depth_max, behind_view=behind_view)
+    out["imgs"] = imgs
+    return out
+
+
+def make_features(B: int, V: int, C: int, h: int, w: int, *, seed: int = 1,
+                  scale: float = 0.5) -> torch.Tensor:
+    """Feature maps ~ N(0,1)*scale, [V,B,C,h,w] fp32 (hot-path-only timing input)."""
+    rng = np.random.default_rng(seed)
+    f = rng.standard_normal((V, B, C, h, w), dtype=np.float32) * np.float32(scale)
+    return torch.from_numpy(f)
+
+
+# --------------------------------------------------------------------------
+# weights
+# --------------------------------------------------------------------------
+def _fan_in(shape: Sequence[int], transposed: bool) -> int:
+    k = int(np.prod(shape[2:])) if len(shape) > 2 else 1
+    cin = shape[0] if transposed else shape[1]
+    return max(cin * k, 1)
+
+
+def make_state_dict(template: Mapping[str, Tuple[int, ...]], *, seed: int = 0,
+                    conv_gain: float = 1.6, head_gain: Mapping[str, float] | None = None,
+                    transposed_keys: Sequence[str] = ()) -> "OrderedDict[str, torch.Tensor]":
+    """Fill a ``{name: shape}`` template (a model's ``state_dict`` key/shape list)
+    with deterministic sharpened weights.
+
+    * conv / deconv weights ~ N(0, (gain / sqrt(fan_in))^2)
+    * BatchNorm weight ~ U(0.6, 1.4), bias ~ N(0, 0.2), running_mean ~ N(0, 0.2),
+      running_var ~ U(0.5, 1.5); ``num_batches_tracked`` = 1
+    * conv biases ~ N(0, 0.1); scalar parameters (MVSNet-s ``temp``) = 1
+    * ``head_gain`` maps a key substring to an extra multiplier (used to push the
+      final 1-channel ``prob`` convs to logit std ~3 so that the softmax peaks).
+
+    The draw order is the template's iteration order, so two models with the same
+    key list get identical tensors.
+    """
+    rng = np.random.default_rng(seed)
+    head_gain = dict(head_gain or {})
+    out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    for name, shape in template.items():
+        shape = tuple(int(s) for s in shape)
+        leaf = name.rsplit(".", 1)[-1]
+        if leaf == "num_batches_tracked":
+            out[name] = torch.tensor(1, dtype=torch.long)
+            continue
+        if len(shape) >= 3:  # convolution kernels (2D or 3D)
+            transposed = any(name.startswith(k) or k in name for k in transposed_keys)
+            std = conv_gain / math.sqrt(_fan_in(shape, transposed))
+            for sub, g in head_gain.items():
+                if sub in name:
+                    std *= g
+            arr = rng.standard_normal(shape, dtype=np.float32) * np.float32(std)
+        elif leaf == "running_var":
+            arr = rng.uniform(0.5, 1.5, size=shape).astype(np.float32)
+        elif leaf == "running_mean":
+            arr = (rng.standard_normal(shape) * 0.2).astype(np.float32)
+        elif leaf == "weight":  # BatchNorm gamma (1-D)
+            arr = rng.uniform(0.6, 1.4, size=shape).astype(np.float32)
+        elif leaf == "bias":
+            arr = (rng.standard_normal(shape) * (0.2 if len(shape) else 0.1)).astype(np.float32)
+        elif leaf == "temp":
+            arr = np.ones(shape, dtype=np.float32)
+        else:
+            arr = (rng.standard_normal(shape) * 0.1).astype(np.float32)
+        out[name] = torch.from_numpy(np.ascontiguousarray(arr))
+    return out
+
+
+def template_of(module: torch.nn.Module) -> "OrderedDict[str, Tuple[int, ...]]":
+    """``{name: shape}`` of a module's state dict, in registration order."""
+    return OrderedDict((k, tuple(v.shape)) for k, v in module.state_dict().items())
+
+
+# gains found by probing the reference on CPU (tests/golden/gen_golden.py prints the
+# resulting softmax peak): they give max_d p in the 0.3-0.9 band on make_scene inputs.
+SHARPEN = {
+    "mvsnet": dict(conv_gain=1.414, head_gain={"feature.": 0.85, "cost_regularization.prob.weight": 10.0}),
+    "vis": dict(conv_gain=1.6, head_gain={"final_conv.weight": 6.0}),
+    "cvp": dict(conv_gain=1.3, head_gain={"prob0.weight": 6.0}),
+}
+TRANSPOSED_KEYS = {
+    "mvsnet": ("cost_regularization.conv7.0", "cost_regularization.conv9.0", "cost_regularization.conv11.0"),
+    "vis": ("dec_blocks",),
+    "cvp": ("cost_reg_refine.conv5.0", "cost_reg_refine.conv6.0"),
+}
+
+
+def sharpened_state_dict(arch: str, template: Mapping[str, Tuple[int, ...]], seed: int = 0):
+    """``arch`` in {"mvsnet", "vis", "cvp"}."""
+    return make_state_dict(template, seed=seed, transposed_keys=TRANSPOSED_KEYS[arch], **SHARPEN[arch])
