@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Headline benchmark: cost-volume voxels/s of the MVSNet depth-inference hot path on MI355X.
+
+A step = one pass of the hot path (fused warp + variance cost volume -> 3-D U-Net regularisation ->
+softmax / depth regression / confidence) over one batch of synthetic input that is already resident in
+HBM: BASELINE.json configs[1] = MVSNet, 1 ref + 4 src views, 512x640 images (128x160x32 feature maps),
+D = 192 planes, bf16 storage / fp32 accumulation.  3 932 160 cost-volume voxels per reference view.
+
+Multi-GPU (--gpus N, one process per GPU via torch.distributed.run): reference views are independent
+objects, so each rank sweeps its own view (global batch = N) with no data-path collective -> weak scaling.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     the dominant kernel's achieved algorithmic GB/s vs the HBM peak (HIP events on the launch stream)
+  cpu_baseline the CPU oracle (a port of the reference's PyTorch path) timed on this box's host cores
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from wild_deep_mvs_amd import ops, synthetic  # noqa: E402
+from wild_deep_mvs_amd.models.MVSNet.model import MVSNet, build_proj_matrices  # noqa: E402
+
+V, IMG_H, IMG_W, C, D = 5, 512, 640, 32, 192
+h, w = IMG_H // 4, IMG_W // 4
+VOX = D * h * w
+HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def algorithmic_bytes(name: str) -> float:
+    """Algorithmic HBM bytes of one launch at the headline size."""
+    if name.startswith("warp_cost"):
+        return V * C * h * w * 2 + C * VOX * 2                      # read V feature maps + write the volume once
+    if name.startswith("conv3d[32->8,k0]"):
+        return C * VOX * 2 + 8 * VOX * 2                            # read 32-ch volume, write 8-ch volume
+    if name.startswith("conv3d[16->8,k2]"):
+        return 16 * (VOX // 8) * 2 + 2 * 8 * VOX * 2                # read half-res 16ch + skip, write 8ch
+    if name.startswith("conv3d[8->1,k0]"):
+        return 8 * VOX * 2 + VOX * 4
+    if name.startswith("conv3d[8->16,k1]"):
+        return 8 * VOX * 2 + 16 * (VOX // 8) * 2
+    if name.startswith("softargmin"):
+        return VOX * 4 + 2 * h * w * 4
+    return 0.0
+
+
+def build_inputs(device, rank: int):
+    net = MVSNet("variance")
+    sd = synthetic.sharpened_state_dict("mvsnet", synthetic.template_of(net), seed=0)
+    net.load_state_dict(sd)
+    net = net.to(device).eval()
+    net.num_depth = D
+    cams = synthetic.make_cameras(1, V, IMG_H, IMG_W)
+    Ks = cams["K"].clone()
+    Ks[:, :, :2] /= 4
+    proj = build_proj_matrices(Ks, cams["R"], cams["t"])
+    steps = torch.arange(D, dtype=torch.float32).view(1, -1)
+    dv = cams["depth_min"][:, :1] + (cams["depth_max"][:, :1] - cams["depth_min"][:, :1]) / (D - 1) * steps
+    feats = synthetic.make_features(1, V, C, h, w, seed=1 + rank)           # [V,1,C,h,w] fp32
+    feats_cl = [ops.to_channels_last(feats[i].to(device), torch.bfloat16) for i in range(V)]
+    return net, sd, feats, feats_cl, proj.to(device), dv.to(device).contiguous(), proj, dv
+
+
+def cpu_baseline(sd, feats, proj, dv):
+    """The oracle's hot path (same stages, fp32 ATen on the host cores) on the same workload, once."""
+    from oracle import mvsnet as O          # cpu_baseline leg only
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        O.hot_path([feats[i] for i in range(V)], proj, dv.unsqueeze(1).expand(-1, V, -1), sd)
+        dt = time.perf_counter() - t0
+    return {"value": VOX / dt, "unit": "voxels/s", "cores": cores, "kind": "port",
+            "sample": f"1 pass of the same workload (5-view 128x160x32 features, D=192, fp32, {dt:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    net, sd, feats, feats_cl, proj_d, dv_d, proj, dv = build_inputs(device, rank)
+
+    def step():
+        return net.hot_path(feats_cl, proj_d, dv_d)
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            depth, conf = step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        with ops.EventTimer() as tm:
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                depth, conf = step()
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+        kern = tm.summary()
+    assert torch.isfinite(depth).all()
+
+    t_max = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+    elapsed = float(t_max.item())
+
+    if rank == 0:
+        total_ms = sum(ms for _, ms in kern.values())
+        name, (n, ms) = max(kern.items(), key=lambda kv: kv[1][1])
+        avg_s = ms / n * 1e-3
+        ab = algorithmic_bytes(name)
+        roof = {"kernel": name, "bound": "hbm", "achieved": ab / avg_s / 1e9 if ab else None, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": (ab / avg_s / 1e9 / HBM_PEAK_GBS) if ab else None, "traffic": None,
+                "avg_us": avg_s * 1e6, "algorithmic_bytes": ab, "share_of_gpu_time": ms / total_ms}
+        line = {
+            "metric": "cost-volume voxels/sec (BxDxHxW), MVSNet hot path", "value": world * VOX * args.steps / elapsed,
+            "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "MVSNet variance, 1 ref + 4 src views, 512x640 images (128x160x32 features), D=192, "
+                                   "features resident in HBM -> depth + confidence", "global_batch": world,
+                       "voxels_per_step_per_gpu": VOX, "parallelism": f"reference-view shard x{world}, no collective"},
+            "roofline": roof,
+            "kernels_us": {k: round(ms / n * 1e3, 2) for k, (n, ms) in sorted(kern.items(), key=lambda kv: -kv[1][1])},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(sd, feats, proj, dv)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

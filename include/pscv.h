@@ -62,6 +62,11 @@ extern "C" {
 const char* pscv_last_error(void);
 int pscv_abi_version(void);
 
+/* Tuning knobs for measurement runs (not part of the reference's surface). Keys:
+ *   "warp_lpv"  lanes sharing one voxel in pscv_warp_cost (1, 2 or 4 for C=32; 0 = default C/8)
+ *   "warp_ppd"  depth planes per workgroup in pscv_warp_cost (0 = default 8) */
+int pscv_set_tuning(const char* key, int value);
+
 /*
  * Fused plane-sweep warp + cost aggregation (one pass, the warped per-view volumes never reach HBM).
  * Replaces: MVSNet.build_cost_volume (models/MVSNet/model.py:109-176) + homo_warping (module.py:111-169);

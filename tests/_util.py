@@ -1,0 +1,57 @@
+"""Shared helpers for the parity tests."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name))
+    return {k: z[k] for k in z.files}
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def bf16_round(x: torch.Tensor) -> torch.Tensor:
+    """fp32 tensor with values rounded to bf16 (what the engine stores)."""
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def err_stats(got: torch.Tensor, ref: torch.Tensor):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, f"shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    diff = (got - ref).abs()
+    k = int(diff.argmax())
+    idx = np.unravel_index(k, tuple(ref.shape)) if ref.numel() else ()
+    return {
+        "max_abs": float(diff.max()),
+        "mean_abs": float(diff.mean()),
+        "ref_max": float(ref.abs().max()),
+        "ref_mean": float(ref.abs().mean()),
+        "rel_l2": float((got - ref).norm() / (ref.norm() + 1e-30)),
+        "rel_l1": float(diff.mean() / (ref.abs().mean() + 1e-30)),
+        "argmax": tuple(int(i) for i in idx),
+        "got_at": float(got.flatten()[k]),
+        "ref_at": float(ref.flatten()[k]),
+        "nan": int(torch.isnan(got).sum()),
+    }
+
+
+def check_close(name, got, ref, *, max_abs=None, rel_l2=None, rel_l1=None):
+    s = err_stats(got, ref)
+    line = (f"[parity] {name}: max_abs={s['max_abs']:.3e} (ref max {s['ref_max']:.3e}) rel_l2={s['rel_l2']:.3e} "
+            f"rel_l1={s['rel_l1']:.3e} worst@{s['argmax']} got={s['got_at']:.6g} ref={s['ref_at']:.6g} nan={s['nan']}")
+    print(line, flush=True)
+    assert s["nan"] == 0, line
+    if max_abs is not None:
+        assert s["max_abs"] <= max_abs, line
+    if rel_l2 is not None:
+        assert s["rel_l2"] <= rel_l2, line
+    if rel_l1 is not None:
+        assert s["rel_l1"] <= rel_l1, line
+    return s

@@ -122,6 +122,25 @@ def gen_mvsnet(aggregation: str, tag: str, *, H=64, W=96, V=3, D=16, seed=0, beh
          depth_per_pixel=np32(dpp), warped_per_pixel=np32(warped_pp[:, :, PLANES]))
 
 
+def gen_state_dict_keys():
+    """Key order, names and shapes of the reference's state dicts (the checkpoint-compat contract)."""
+    import json
+    from models.MVSNet.model import MVSNet
+    out = {}
+    for tag, net in (("mvsnet", MVSNet("variance")), ("mvsnet_s", MVSNet("softmin"))):
+        out[tag] = [[k, list(v.shape)] for k, v in net.state_dict().items()]
+    try:
+        from models.VisMVSNet.frontend import Frontend as Vis
+        from models.CVP_MVSNet.frontend import Frontend as CVP
+        out["vis"] = [[k, list(v.shape)] for k, v in Vis().state_dict().items()]
+        out["cvp"] = [[k, list(v.shape)] for k, v in CVP().state_dict().items()]
+    except Exception as e:  # pragma: no cover
+        print("skipping vis/cvp key lists:", e)
+    path = os.path.join(HERE, "state_dict_keys.json")
+    json.dump(out, open(path, "w"), indent=0)
+    print("wrote", path)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -132,6 +151,7 @@ def main():
         "mvsnet": lambda: gen_mvsnet("variance", "mvsnet_tiny"),
         "mvsnet_behind": lambda: gen_mvsnet("variance", "mvsnet_behind", V=4, behind_view=2, scene_seed=5),
         "mvsnet_s": lambda: gen_mvsnet("softmin", "mvsnet_s_tiny", seed=1),
+        "keys": gen_state_dict_keys,
     }
     for k, fn in todo.items():
         if args.only in (None, k):

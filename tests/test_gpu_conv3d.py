@@ -1,0 +1,136 @@
+"""HIP MFMA conv3d vs ATen on the CPU (bf16-rounded operands, fp32 accumulation), through the C ABI."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _util import bf16_round, check_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from wild_deep_mvs_amd import _lib as L, ops
+    return L, ops
+
+
+def _ref_conv(x_ncdhw, w, kind, transposed, L):
+    if kind == L.CONV_T2:
+        return F.conv_transpose3d(x_ncdhw, w, stride=2, padding=1, output_padding=1)
+    if transposed:
+        return F.conv_transpose3d(x_ncdhw, w, stride=1, padding=1)
+    return F.conv3d(x_ncdhw, w, stride=1 if kind == L.CONV_S1 else 2, padding=1)
+
+
+# every (c_in, c_out, kind) of the MVSNet regulariser, on sizes that are NOT multiples of the tile
+MVSNET_LAYERS = [(32, 8, 0), (8, 16, 1), (16, 16, 0), (16, 32, 1), (32, 32, 0), (32, 64, 1), (64, 64, 0),
+                 (64, 32, 2), (32, 16, 2), (16, 8, 2), (8, 1, 0)]
+
+
+@pytest.mark.parametrize("cin,cout,kind", MVSNET_LAYERS)
+def test_conv3d_plain(env, cin, cout, kind):
+    L, ops = env
+    g = torch.Generator().manual_seed(cin * 1000 + cout * 10 + kind)
+    D, H, W = (6, 10, 21) if kind == L.CONV_S1 else (7, 9, 35) if kind == L.CONV_S2 else (3, 5, 19)
+    B = 2
+    transposed = kind == L.CONV_T2
+    x = bf16_round(torch.randn(B, cin, D, H, W, generator=g))
+    wshape = (cin, cout, 3, 3, 3) if transposed else (cout, cin, 3, 3, 3)
+    w = bf16_round(torch.randn(wshape, generator=g) / np.sqrt(27 * cin))
+    layer = ops.Conv3dLayer.build(w, kind=kind, transposed=transposed, device="cuda")
+    y = ops.conv3d(ops.to_channels_last(x.cuda(), torch.bfloat16), layer, out_dtype=torch.float32)
+    ref = _ref_conv(x, w, kind, transposed, L)
+    check_close(f"conv3d {cin}->{cout} kind {kind} fp32 out", y.permute(0, 4, 1, 2, 3).cpu(), ref, max_abs=2e-3, rel_l2=1e-4)
+
+
+@pytest.mark.parametrize("cin,cout,kind,relu,with_skip", [(32, 8, 0, True, False), (64, 32, 2, True, True),
+                                                           (16, 8, 2, True, True), (16, 16, 0, False, True),
+                                                           (8, 16, 1, True, False)])
+def test_conv3d_fused_epilogue(env, cin, cout, kind, relu, with_skip):
+    """folded BN affine, ReLU before the skip add (MVSNet: skip + relu(bn(deconv))), bf16 output."""
+    L, ops = env
+    g = torch.Generator().manual_seed(7 + cin + cout + kind)
+    D, H, W = (8, 8, 16) if kind != L.CONV_T2 else (4, 4, 8)
+    transposed = kind == L.CONV_T2
+    x = bf16_round(torch.randn(1, cin, D, H, W, generator=g))
+    wshape = (cin, cout, 3, 3, 3) if transposed else (cout, cin, 3, 3, 3)
+    w = bf16_round(torch.randn(wshape, generator=g) / np.sqrt(27 * cin))
+    gamma, beta = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.3
+    mean, var = torch.randn(cout, generator=g) * 0.2, torch.rand(cout, generator=g) + 0.5
+    layer = ops.Conv3dLayer.build(w, kind=kind, transposed=transposed, device="cuda", bn=(gamma, beta, mean, var), relu=relu)
+    ref = _ref_conv(x, w, kind, transposed, L)
+    ref = F.batch_norm(ref, mean, var, gamma, beta, training=False, eps=1e-5)
+    if relu:
+        ref = F.relu(ref)
+    skip = None
+    if with_skip:
+        skip = bf16_round(torch.randn(ref.shape, generator=g))
+        ref = ref + skip
+    y = ops.conv3d(ops.to_channels_last(x.cuda(), torch.bfloat16), layer,
+                   skip=None if skip is None else ops.to_channels_last(skip.cuda(), torch.bfloat16))
+    assert y.dtype == torch.bfloat16
+    s = check_close(f"conv3d+bn{'+relu' if relu else ''}{'+skip' if with_skip else ''} {cin}->{cout} kind {kind}",
+                    y.float().permute(0, 4, 1, 2, 3).cpu(), ref, rel_l2=4e-3)
+    assert s["max_abs"] <= 2 ** -7 * s["ref_max"] + 1e-3
+
+
+def test_conv3d_channel_slices_and_relu_post(env):
+    """Reads a channel slice of a wider tensor and writes a slice of a wider tensor (the Vis U-Net's
+    cat([deconv, enc]) without a copy); RELU_POST = relu(bn(conv) + residual) (Vis BasicBlock)."""
+    L, ops = env
+    g = torch.Generator().manual_seed(11)
+    x16 = bf16_round(torch.randn(1, 16, 4, 6, 16, generator=g))
+    w = bf16_round(torch.randn(8, 8, 3, 3, 3, generator=g) / np.sqrt(27 * 8))
+    res = bf16_round(torch.randn(1, 8, 4, 6, 16, generator=g))
+    layer = ops.Conv3dLayer.build(w, kind=L.CONV_S1, device="cuda", relu=False, relu_post=True)
+    out = torch.full((1, 4, 6, 16, 16), 7.0, dtype=torch.bfloat16, device="cuda")
+    ops.conv3d(ops.to_channels_last(x16.cuda(), torch.bfloat16), layer, in_coff=8,
+               skip=ops.to_channels_last(res.cuda(), torch.bfloat16), out=out, out_coff=8)
+    ref = F.relu(F.conv3d(x16[:, 8:], w, padding=1) + res)
+    check_close("slice conv + relu_post", out[..., 8:].float().permute(0, 4, 1, 2, 3).cpu(), ref, rel_l2=4e-3)
+    assert float((out[..., :8].float() - 7.0).abs().max()) == 0.0, "channels outside the output slice were touched"
+
+
+def test_conv3d_per_channel_floor(env):
+    """floor[c] = -inf keeps a channel linear while others get ReLU in the same launch."""
+    L, ops = env
+    g = torch.Generator().manual_seed(5)
+    x = bf16_round(torch.randn(1, 8, 4, 4, 16, generator=g))
+    w = bf16_round(torch.randn(16, 8, 3, 3, 3, generator=g) / np.sqrt(27 * 8))
+    floor = torch.zeros(16)
+    floor[8:] = float("-inf")
+    layer = ops.Conv3dLayer.build(w, kind=L.CONV_S1, device="cuda", relu=True, floor=floor)
+    y = ops.conv3d(ops.to_channels_last(x.cuda(), torch.bfloat16), layer, out_dtype=torch.float32).permute(0, 4, 1, 2, 3).cpu()
+    ref = F.conv3d(x, w, padding=1)
+    ref = torch.cat([F.relu(ref[:, :8]), ref[:, 8:]], 1)
+    check_close("per-channel floor", y, ref, max_abs=2e-3)
+
+
+def test_conv3d_linearity_at_full_size(env):
+    """Size-independent property at the headline volume (192x128x160, 32->8): without ReLU the layer is
+    linear, conv(a) + conv(b) == conv(a + b) up to bf16 input rounding of (a + b); plus a cropped-region
+    comparison against ATen around three far-apart voxels."""
+    L, ops = env
+    g = torch.Generator().manual_seed(3)
+    D, H, W, cin, cout = 192, 128, 160, 32, 8
+    a = torch.randn(1, D, H, W, cin, generator=g, dtype=torch.float32).to(torch.bfloat16)
+    b = torch.randn(1, D, H, W, cin, generator=g, dtype=torch.float32).to(torch.bfloat16) * 0.5
+    ab = (a.float() + b.float()).to(torch.bfloat16)
+    w = bf16_round(torch.randn(cout, cin, 3, 3, 3, generator=g) / np.sqrt(27 * cin))
+    layer = ops.Conv3dLayer.build(w, kind=L.CONV_S1, device="cuda")
+    ya = ops.conv3d(a.cuda(), layer, out_dtype=torch.float32)
+    yb = ops.conv3d(b.cuda(), layer, out_dtype=torch.float32)
+    yab = ops.conv3d(ab.cuda(), layer, out_dtype=torch.float32)
+    # (a+b) is rounded to bf16 once more -> tolerance of one bf16 ulp of the inputs through the contraction
+    err = float((ya + yb - yab).abs().max())
+    assert err <= 0.05, err
+    for (d0, h0, w0) in [(0, 0, 0), (95, 63, 79), (183, 119, 151)]:
+        crop = a[:, max(d0 - 1, 0):d0 + 9, max(h0 - 1, 0):h0 + 9, max(w0 - 1, 0):w0 + 9].float().permute(0, 4, 1, 2, 3)
+        ref = F.conv3d(crop, w, padding=1)
+        od, oh, ow = (1 if d0 else 0), (1 if h0 else 0), (1 if w0 else 0)
+        ref = ref[:, :, od:od + 7, oh:oh + 7, ow:ow + 7]
+        got = ya[:, d0:d0 + 7, h0:h0 + 7, w0:w0 + 7].permute(0, 4, 1, 2, 3).cpu()
+        check_close(f"full-size conv crop @({d0},{h0},{w0})", got, ref, max_abs=2e-3)

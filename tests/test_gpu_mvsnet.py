@@ -1,0 +1,95 @@
+"""End-to-end: the MVSNet mirror on the HIP engine vs the reference goldens / the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from _util import bf16_round, check_close, load_golden, t
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from wild_deep_mvs_amd import _lib as L, ops, synthetic
+    from wild_deep_mvs_amd.models.MVSNet.model import MVSNet
+    from oracle import mvsnet as O
+    return L, ops, synthetic, MVSNet, O
+
+
+def _model(env, agg, seed):
+    L, ops, synthetic, MVSNet, O = env
+    net = MVSNet(agg)
+    sd = synthetic.sharpened_state_dict("mvsnet", synthetic.template_of(net), seed=seed)
+    net.load_state_dict(sd, strict=True)
+    return net.cuda().eval(), sd
+
+
+def test_cost_reg_net_layers_vs_oracle(env):
+    """Every stored stage of the 3-D U-Net against the oracle run on the same bf16-rounded cost volume."""
+    L, ops, synthetic, MVSNet, O = env
+    g = load_golden("mvsnet_tiny.npz")
+    net, sd = _model(env, "variance", int(g["meta"][4]))
+    cost = bf16_round(t(g["cost_volume"]))
+    taps_ref, taps = {}, {}
+    with torch.no_grad():
+        ref_logits = O.cost_reg_net(cost, sd, taps=taps_ref).squeeze(1)
+        logits = net.cost_regularization(ops.to_channels_last(cost.cuda(), torch.bfloat16), taps)
+    for k in ("conv0", "conv2", "conv4", "conv6", "up7", "up9", "up11"):
+        check_close(f"reg {k}", taps[k].float().permute(0, 4, 1, 2, 3).cpu(), taps_ref[k], rel_l2=2e-2)
+    check_close("reg logits", logits.cpu(), ref_logits, rel_l2=2e-2)
+
+
+@pytest.mark.parametrize("fname,agg", [("mvsnet_tiny.npz", "variance"), ("mvsnet_behind.npz", "variance"),
+                                        ("mvsnet_s_tiny.npz", "softmin")])
+def test_forward_depth_parity_with_reference(env, fname, agg):
+    """forward(imgs, K, R, t, depth_min, depth_max) -> depth within 1e-3 relative L1 of the reference's
+    fp32 PyTorch path (BASELINE.json north_star), bf16 storage / fp32 accumulation."""
+    L, ops, synthetic, MVSNet, O = env
+    g = load_golden(fname)
+    H, W, V, D, seed, scene_seed, behind = [int(x) for x in g["meta"]]
+    net, sd = _model(env, agg, seed)
+    net.num_depth = D
+    scene = synthetic.make_scene(1, V, H, W, seed=scene_seed, behind_view=behind)
+    dev = {k: v.cuda() for k, v in scene.items()}
+    taps = {}
+    out = net(dev["imgs"], dev["K"], dev["R"], dev["t"], dev["depth_min"], dev["depth_max"], taps=taps)
+    assert set(out) == {"depth", "depth_est_list", "depth_pair_list", "photometric_confidence"}
+    assert tuple(out["depth"].shape) == (1, H // 4, W // 4) and out["depth_pair_list"] == []
+    check_close(f"{fname} cost volume (bf16)", taps["cost_volume"].float().permute(0, 4, 1, 2, 3).cpu(), t(g["cost_volume"]), rel_l2=1e-2)
+    check_close(f"{fname} logits", taps["logits"].cpu(), t(g["logits"]).squeeze(1), rel_l2=3e-2)
+    ref = t(g["depth"])
+    s = check_close(f"{fname} depth", out["depth"].cpu(), ref)
+    assert s["rel_l1"] <= 1e-3, s
+    check_close(f"{fname} confidence", out["photometric_confidence"].cpu(), t(g["photometric_confidence"]), max_abs=0.05)
+    # the reference's own evaluation quantity: error in units of (max-min)/128 (depthmap_eval.py:133-143)
+    unit = (float(scene["depth_max"][0, 0]) - float(scene["depth_min"][0, 0])) / 128
+    epe = float((out["depth"].cpu() - ref).abs().mean()) / unit
+    print(f"[parity] {fname} EPE vs reference = {epe:.4f} depth units", flush=True)
+    assert epe < 0.1
+
+
+def test_list_input_and_reference_frame(env):
+    """imgs may be a list of V tensors (test-mode loaders) and any view can be the reference."""
+    L, ops, synthetic, MVSNet, O = env
+    net, sd = _model(env, "variance", 0)
+    net.num_depth = 16
+    scene = synthetic.make_scene(1, 3, 64, 96, seed=2)
+    dev = {k: v.cuda() for k, v in scene.items()}
+    out = net(list(torch.unbind(dev["imgs"], 1)), dev["K"], dev["R"], dev["t"], dev["depth_min"], dev["depth_max"],
+              reference_frame=1)
+    with torch.no_grad():
+        ref = O.forward(scene["imgs"], scene["K"], scene["R"], scene["t"], scene["depth_min"], scene["depth_max"], sd,
+                        num_depth=16, reference_frame=1)
+    s = check_close("reference_frame=1 depth", out["depth"].cpu(), ref["depth"])
+    assert s["rel_l1"] <= 1e-3
+
+
+def test_training_mode_fails_loudly(env):
+    L, ops, synthetic, MVSNet, O = env
+    net, _ = _model(env, "variance", 0)
+    net.train()
+    scene = {k: v.cuda() for k, v in synthetic.make_scene(1, 3, 64, 96).items()}
+    with pytest.raises(NotImplementedError):
+        net(scene["imgs"], scene["K"], scene["R"], scene["t"], scene["depth_min"], scene["depth_max"])

@@ -1,0 +1,136 @@
+"""HIP fused warp + cost kernel vs the CPU oracle and the reference goldens (through the C ABI)."""
+import numpy as np
+import pytest
+import torch
+
+from _util import bf16_round, check_close, load_golden, t
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from wild_deep_mvs_amd import _lib as L, ops
+    from oracle import mvsnet as O
+    return L, ops, O
+
+
+def _cl(x, dtype):
+    from wild_deep_mvs_amd import ops
+    return ops.to_channels_last(x.cuda(), dtype)
+
+
+@pytest.mark.parametrize("fname", ["mvsnet_tiny.npz", "mvsnet_behind.npz"])
+def test_warp_only_fp32_matches_reference_golden(env, fname):
+    L, ops, O = env
+    g = load_golden(fname)
+    feats, proj, dv = t(g["features"]), t(g["proj"]), t(g["depth_values"])[:, 0].contiguous()
+    V = feats.shape[0]
+    planes = g["warped_planes"].tolist()
+    cams = ops.proj_cams([proj[:, i].cuda() for i in range(1, V)], proj[:, 0].cuda())
+    vol = ops.warp_cost(None, [_cl(feats[i], torch.float32) for i in range(1, V)], cams, dv.cuda(),
+                        cost=L.COST_WARP_ONLY, out_dtype=torch.float32)          # [n,B,D,h,w,C]
+    for i in range(V - 1):
+        got = vol[i].permute(0, 4, 1, 2, 3)[:, :, planes].cpu()
+        check_close(f"{fname} warp view {i + 1} vs reference", got, t(g["warped"][i]), max_abs=3e-4)
+        ref_full = O.homo_warping(feats[i + 1], proj[:, i + 1], proj[:, 0], dv, feats[0].shape[-2:])
+        check_close(f"{fname} warp view {i + 1} vs oracle (all planes)", vol[i].permute(0, 4, 1, 2, 3).cpu(), ref_full,
+                    max_abs=3e-4)
+
+
+def test_homo_warping_function_api(env):
+    """models.MVSNet.module.homo_warping(src_fea, src_proj, ref_proj, depth_values, ref_shape) drop-in,
+    per-batch and per-pixel depth planes."""
+    L, ops, O = env
+    from wild_deep_mvs_amd.models.MVSNet.module import homo_warping
+    g = load_golden("mvsnet_tiny.npz")
+    feats, proj, dv = t(g["features"]), t(g["proj"]), t(g["depth_values"])[:, 0].contiguous()
+    planes = g["warped_planes"].tolist()
+    w = homo_warping(feats[1].cuda(), proj[:, 1].cuda(), proj[:, 0].cuda(), dv.cuda(), feats[0].shape[-2:])
+    assert tuple(w.shape) == (1, 32, dv.shape[1]) + tuple(feats[0].shape[-2:])
+    check_close("homo_warping per-batch planes", w[:, :, planes].cpu(), t(g["warped"][0]), max_abs=3e-4)
+    wpp = homo_warping(feats[1].cuda(), proj[:, 1].cuda(), proj[:, 0].cuda(), t(g["depth_per_pixel"]).cuda(),
+                       feats[0].shape[-2:])
+    check_close("homo_warping per-pixel planes", wpp[:, :, planes].cpu(), t(g["warped_per_pixel"]), max_abs=3e-4)
+
+
+@pytest.mark.parametrize("fname,agg", [("mvsnet_tiny.npz", "variance"), ("mvsnet_behind.npz", "variance"),
+                                        ("mvsnet_s_tiny.npz", "softmin")])
+def test_cost_volume_fp32_matches_reference_golden(env, fname, agg):
+    L, ops, O = env
+    g = load_golden(fname)
+    feats, proj, dv = t(g["features"]), t(g["proj"]), t(g["depth_values"])[:, 0].contiguous()
+    V = feats.shape[0]
+    cams = ops.proj_cams([proj[:, i].cuda() for i in range(1, V)], proj[:, 0].cuda())
+    cost = ops.warp_cost(_cl(feats[0], torch.float32), [_cl(feats[i], torch.float32) for i in range(1, V)], cams,
+                         dv.cuda(), cost=L.COST_VARIANCE if agg == "variance" else L.COST_SOFTMIN, temp=1.0,
+                         out_dtype=torch.float32)
+    ref = t(g["cost_volume"])
+    check_close(f"{fname} {agg} cost volume fp32", cost.permute(0, 4, 1, 2, 3).cpu(), ref,
+                max_abs=2e-4 * max(1.0, float(ref.abs().max())), rel_l2=2e-4)
+
+
+@pytest.mark.parametrize("lpv", [4, 2, 1])
+def test_cost_volume_bf16_storage(env, lpv):
+    """bf16 feature maps in, bf16 cost volume out, fp32 accumulation: equals the oracle run on the
+    bf16-rounded features up to one output rounding."""
+    L, ops, O = env
+    g = load_golden("mvsnet_tiny.npz")
+    feats, proj, dv = t(g["features"]), t(g["proj"]), t(g["depth_values"])[:, 0].contiguous()
+    V = feats.shape[0]
+    fr = [bf16_round(f) for f in feats]
+    warped = [O.homo_warping(fr[i], proj[:, i], proj[:, 0], dv, fr[0].shape[-2:]) for i in range(1, V)]
+    ref = O.variance_cost(fr[0], warped)
+    cams = ops.proj_cams([proj[:, i].cuda() for i in range(1, V)], proj[:, 0].cuda())
+    L.set_tuning("warp_lpv", lpv)     # every lanes-per-voxel mapping must give the same volume
+    try:
+        cost = ops.warp_cost(_cl(feats[0], torch.bfloat16), [_cl(feats[i], torch.bfloat16) for i in range(1, V)],
+                             cams, dv.cuda(), cost=L.COST_VARIANCE, out_dtype=torch.bfloat16)
+    finally:
+        L.set_tuning("warp_lpv", 0)
+    s = check_close(f"variance cost bf16 storage lpv={lpv}", cost.float().permute(0, 4, 1, 2, 3).cpu(), ref, rel_l2=4e-3)
+    assert s["max_abs"] <= 2 ** -8 * s["ref_max"] + 3e-4
+
+
+def test_cvp_variance_rounding_and_16_channels(env):
+    """16-channel features (CVP) and the CVP rounding order sum f^2/N - (sum f/N)^2."""
+    L, ops, O = env
+    g = load_golden("mvsnet_tiny.npz")
+    feats, proj, dv = t(g["features"])[:, :, :16].contiguous(), t(g["proj"]), t(g["depth_values"])[:, 0].contiguous()
+    V = feats.shape[0]
+    warped = [O.homo_warping(feats[i], proj[:, i], proj[:, 0], dv, feats[0].shape[-2:]) for i in range(1, V)]
+    N = V
+    s = feats[0].unsqueeze(2) + sum(warped)
+    sq = feats[0].unsqueeze(2) ** 2 + sum(w ** 2 for w in warped)
+    ref = sq / N - (s / N) ** 2
+    cams = ops.proj_cams([proj[:, i].cuda() for i in range(1, V)], proj[:, 0].cuda())
+    cost = ops.warp_cost(_cl(feats[0], torch.float32), [_cl(feats[i], torch.float32) for i in range(1, V)], cams,
+                         dv.cuda(), cost=L.COST_VARIANCE_CVP, out_dtype=torch.float32)
+    check_close("cvp variance 16ch", cost.permute(0, 4, 1, 2, 3).cpu(), ref, max_abs=3e-4, rel_l2=2e-4)
+
+
+def test_identity_sweep_has_zero_variance_at_full_size(env):
+    """Size-independent property at the headline size (5 views, 128x160 features, D=192): when every
+    source view IS the reference view (same camera, same features) the warp is the identity and the
+    variance cost is exactly sum f^2/N - (N f)^2/N^2 = 0 up to fp32 rounding."""
+    L, ops, O = env
+    from wild_deep_mvs_amd import synthetic
+    B, V, C, h, w, D = 1, 5, 32, 128, 160, 192
+    f = synthetic.make_features(B, 1, C, h, w, seed=3)[0].cuda()
+    fcl = ops.to_channels_last(f, torch.bfloat16)
+    cam = synthetic.make_cameras(B, 1, 4 * h, 4 * w)
+    from oracle.mvsnet import mvsnet_cameras
+    proj, dvals = mvsnet_cameras(cam["K"], cam["R"], cam["t"], cam["depth_min"], cam["depth_max"], D)
+    P = proj[:, 0].cuda()
+    cams = ops.proj_cams([P] * (V - 1), P)
+    cost = ops.warp_cost(fcl, [fcl] * (V - 1), cams, dvals[:, 0].contiguous().cuda(), cost=L.COST_VARIANCE,
+                         out_dtype=torch.float32)
+    assert tuple(cost.shape) == (B, D, h, w, C)
+    scale = float(fcl.float().pow(2).max())
+    assert float(cost.abs().max()) <= 2e-5 * scale, float(cost.abs().max())
+    # and the plain warp reproduces the feature map on every plane
+    vol = ops.warp_cost(None, [fcl], cams[:1], dvals[:, 0].contiguous().cuda(), cost=L.COST_WARP_ONLY,
+                        out_dtype=torch.float32)
+    assert float((vol[0] - fcl.float().unsqueeze(1)).abs().max()) <= 1e-4 * float(fcl.float().abs().max())

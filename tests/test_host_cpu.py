@@ -1,0 +1,189 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol of include/pscv.h, the conv3d weight
+packer agrees with a numpy emulation of the kernel's contraction, host camera math, state-dict compatibility
+with the reference.  No compute call into the GPU kernels here."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _util import GOLDEN, load_golden, t
+from wild_deep_mvs_amd import _lib as L, ops, synthetic
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(REPO, "include", "pscv.h")).read()
+    hdr_nc = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(pscv_[a-z0-9_]+)\s*\(", hdr_nc))
+    assert declared == set(L.EXPORTS), (declared, L.EXPORTS)
+    lib = C.CDLL(L.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"libpscv.so does not export {name}"
+    assert L.lib().pscv_abi_version() == L.ABI_VERSION
+
+
+def test_error_channel_and_argument_checks():
+    lib = L.lib()
+    rc = lib.pscv_set_tuning(b"no_such_knob", 1)
+    assert rc != 0 and b"no_such_knob" in lib.pscv_last_error()
+    # bad arguments are rejected before any launch
+    rc = lib.pscv_softargmin(None, 0, None, 0, 0, None, None, None, None, None, None, 0, 2.0, 0, 1, 8, 4, 4, None)
+    assert rc != 0 and b"logits" in lib.pscv_last_error()
+    with pytest.raises(RuntimeError, match="no CPU"):
+        ops.softargmin(torch.zeros(1, 8, 4, 4))
+
+
+# ---- conv3d weight packing vs a numpy emulation of the kernel ------------------------------------
+def _bf16(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(torch.bfloat16).to(torch.float32).numpy()
+
+
+def _unpack(packed, nt):
+    w = (packed.astype(np.uint32) << 16).view(np.float32)
+    return w.reshape(-1, nt, 64, 8)        # [step][tile][lane][j]
+
+
+def _t2_class(pc):
+    pd, ph, pw = (pc >> 2) & 1, (pc >> 1) & 1, pc & 1
+    return pd, ph, pw, (1 + pd) * (1 + ph) * (1 + pw)
+
+
+def _emulate(x, wk, cin, cout, kind):
+    """x [D,H,W,cin] -> out [Do,Ho,Wo,cout]; follows conv3d.hip: for k-step s and lane group g the lane reads the
+    8 channels (s*32+g*8)%cin.. of the voxel at tap (s*32+g*8)//cin; contraction over (g, j) against the packed A."""
+    D, H, W, _ = x.shape
+    nt = (cout + 15) // 16
+
+    def X(d, h, w_, c0):
+        if 0 <= d < D and 0 <= h < H and 0 <= w_ < W:
+            return x[d, h, w_, c0:c0 + 8]
+        return np.zeros(8, np.float32)
+
+    if kind in (L.CONV_S1, L.CONV_S2):
+        st = 1 if kind == L.CONV_S1 else 2
+        Do, Ho, Wo = (D, H, W) if st == 1 else ((D + 1) // 2, (H + 1) // 2, (W + 1) // 2)
+        out = np.zeros((Do, Ho, Wo, cout), np.float32)
+        nsteps = (27 * cin + 31) // 32
+        for od in range(Do):
+            for oh in range(Ho):
+                for ow in range(Wo):
+                    for s in range(nsteps):
+                        for g in range(4):
+                            kk0 = s * 32 + g * 8
+                            tap, c0 = min(kk0 // cin, 26), kk0 % cin
+                            kd, kh, kw = tap // 9, (tap // 3) % 3, tap % 3
+                            xv = X(od * st + kd - 1, oh * st + kh - 1, ow * st + kw - 1, c0)
+                            for co in range(cout):
+                                out[od, oh, ow, co] += wk[s, co // 16, (co % 16) + 16 * g] @ xv
+        return out
+    out = np.zeros((2 * D, 2 * H, 2 * W, cout), np.float32)
+    sbase = 0
+    for pc in range(8):
+        pd, ph, pw, ntap = _t2_class(pc)
+        nsteps = (ntap * cin + 31) // 32
+        for id_ in range(D):
+            for ih in range(H):
+                for iw in range(W):
+                    for s in range(nsteps):
+                        for g in range(4):
+                            kk0 = s * 32 + g * 8
+                            tp, c0 = min(kk0 // cin, ntap - 1), kk0 % cin
+                            tw, th, td = tp % (1 + pw), (tp // (1 + pw)) % (1 + ph), tp // ((1 + pw) * (1 + ph))
+                            od = 1 if (pd and td == 0) else 0
+                            oh = 1 if (ph and th == 0) else 0
+                            ow = 1 if (pw and tw == 0) else 0
+                            xv = X(id_ + od, ih + oh, iw + ow, c0)
+                            for co in range(cout):
+                                out[2 * id_ + pd, 2 * ih + ph, 2 * iw + pw, co] += wk[sbase + s, co // 16, (co % 16) + 16 * g] @ xv
+        sbase += nsteps
+    return out
+
+
+@pytest.mark.parametrize("cin,cout,kind,transposed", [
+    (8, 16, L.CONV_S1, False), (32, 8, L.CONV_S1, False), (8, 1, L.CONV_S1, False), (16, 32, L.CONV_S2, False),
+    (8, 16, L.CONV_S2, False), (16, 8, L.CONV_T2, True), (64, 32, L.CONV_T2, True), (64, 32, L.CONV_S1, True),
+])
+def test_packed_weights_contract_like_the_kernel(cin, cout, kind, transposed):
+    rng = np.random.default_rng(cin * 100 + cout + kind)
+    wshape = (cin, cout, 3, 3, 3) if transposed else (cout, cin, 3, 3, 3)
+    w = _bf16(rng.standard_normal(wshape).astype(np.float32))
+    D, H, W = (3, 2, 3) if kind != L.CONV_S2 else (3, 4, 5)
+    x = _bf16(rng.standard_normal((D, H, W, cin)).astype(np.float32))
+    packed = ops.pack_conv3d_weights(torch.from_numpy(w), kind, transposed)
+    nt = (cout + 15) // 16
+    got = _emulate(x, _unpack(packed, nt), cin, cout, kind)
+    xt = torch.from_numpy(x).permute(3, 0, 1, 2).unsqueeze(0)
+    wt = torch.from_numpy(w)
+    if kind == L.CONV_T2:
+        ref = F.conv_transpose3d(xt, wt, stride=2, padding=1, output_padding=1)
+    elif transposed:
+        ref = F.conv_transpose3d(xt, wt, stride=1, padding=1)
+    else:
+        ref = F.conv3d(xt, wt, stride=1 if kind == L.CONV_S1 else 2, padding=1)
+    ref = ref[0].permute(1, 2, 3, 0).numpy()
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, atol=2e-4 * np.abs(ref).max(), rtol=0)
+
+
+def test_pack_rejects_bad_requests():
+    w = torch.zeros(8, 8, 3, 3, 3)
+    with pytest.raises(L.PscvError):
+        ops.pack_conv3d_weights(w, L.CONV_T2, False)       # T2 needs a ConvTranspose3d weight
+    with pytest.raises(ValueError):
+        ops.pack_conv3d_weights(torch.zeros(8, 8, 1, 1, 1), L.CONV_S1, False)
+
+
+# ---- host camera math ------------------------------------------------------------------------------
+def test_proj_cams_matches_reference_matrix_product():
+    g = load_golden("mvsnet_tiny.npz")
+    proj = t(g["proj"])
+    cams = ops.proj_cams([proj[:, 1], proj[:, 2]], proj[:, 0])
+    assert tuple(cams.shape) == (2, 1, L.CAM_FLOATS)
+    for i in (1, 2):
+        P = (proj[:, i].double() @ torch.linalg.inv(proj[:, 0].double()))
+        np.testing.assert_allclose(cams[i - 1, :, :9].reshape(-1, 3, 3).numpy(), P[:, :3, :3].numpy(), rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(cams[i - 1, :, 9:12].numpy(), P[:, :3, 3].numpy(), rtol=1e-6, atol=1e-6)
+        # and within fp32 LU noise of what the reference computes (module.py:128)
+        P32 = proj[:, i] @ torch.inverse(proj[:, 0])
+        np.testing.assert_allclose(cams[i - 1, :, :9].reshape(-1, 3, 3).numpy(), P32[:, :3, :3].numpy(), rtol=2e-5, atol=1e-6)
+
+
+def test_bn_folding_equals_eval_batchnorm():
+    torch.manual_seed(0)
+    bn = torch.nn.BatchNorm3d(8).eval()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(); bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0)
+    x = torch.randn(1, 8, 2, 3, 4)
+    scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    bias = bn.bias - bn.running_mean * scale
+    np.testing.assert_allclose((x * scale.view(1, -1, 1, 1, 1) + bias.view(1, -1, 1, 1, 1)).detach().numpy(),
+                               bn(x).detach().numpy(), atol=1e-5)
+
+
+# ---- drop-in contract ------------------------------------------------------------------------------
+@pytest.mark.parametrize("arch,ctor", [("mvsnet", "variance"), ("mvsnet_s", "softmin")])
+def test_state_dict_keys_and_shapes_match_reference(arch, ctor):
+    ref = json.load(open(os.path.join(GOLDEN, "state_dict_keys.json")))[arch]
+    from wild_deep_mvs_amd.models.MVSNet.model import MVSNet
+    mine = {k: list(v.shape) for k, v in MVSNet(ctor).state_dict().items()}
+    assert list(mine.keys()) == [k for k, _ in ref], "state-dict key order/names differ from the reference"
+    for k, shape in ref:
+        assert mine[k] == shape, (k, mine[k], shape)
+
+
+def test_reference_import_paths_resolve():
+    import wild_deep_mvs_amd
+    wild_deep_mvs_amd.install_as_models()
+    from models.MVSNet.model import MVSNet            # reference train.py:33
+    from models.MVSNet.module import homo_warping, depth_regression   # noqa: F401
+    net = MVSNet("variance")
+    assert net.num_depth == 192
+    with pytest.raises(RuntimeError, match="no CPU"):
+        net.eval()(torch.rand(1, 3, 3, 32, 32), torch.eye(3).expand(1, 3, 3, 3).clone(), torch.eye(3).expand(1, 3, 3, 3).clone(),
+                   torch.zeros(1, 3, 3, 1), torch.full((1, 3), 2.0), torch.full((1, 3), 6.0))

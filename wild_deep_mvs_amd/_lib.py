@@ -25,7 +25,7 @@ EPI_RELU_PRE, EPI_RELU_POST = 1, 2
 MAX_SRC = 16
 CAM_FLOATS = 18
 
-EXPORTS = ("pscv_last_error", "pscv_abi_version", "pscv_warp_cost", "pscv_pack_conv3d_weights", "pscv_conv3d",
+EXPORTS = ("pscv_last_error", "pscv_abi_version", "pscv_set_tuning", "pscv_warp_cost", "pscv_pack_conv3d_weights", "pscv_conv3d",
            "pscv_softargmin")
 
 
@@ -59,6 +59,8 @@ def _declare(lib):
     lib.pscv_last_error.argtypes = []
     lib.pscv_abi_version.restype = i
     lib.pscv_abi_version.argtypes = []
+    lib.pscv_set_tuning.restype = i
+    lib.pscv_set_tuning.argtypes = [C.c_char_p, i]
     lib.pscv_warp_cost.restype = i
     lib.pscv_warp_cost.argtypes = [vp, C.POINTER(vp), i, vp, vp, l, i, i, i, f, vp, i, i, i, i, i, i, i, i, i, vp]
     lib.pscv_pack_conv3d_weights.restype = l
@@ -95,6 +97,10 @@ def lib():
                 raise PscvMissingError(f"libpscv.so ABI {ver} != binding ABI {ABI_VERSION}: rebuild")
             _lib = handle
     return _lib
+
+
+def set_tuning(key: str, value: int) -> None:
+    check(lib().pscv_set_tuning(key.encode(), int(value)), "pscv_set_tuning")
 
 
 def check(rc: int, what: str):

@@ -18,6 +18,8 @@
 //   variance        models/MVSNet/model.py:113-139   (CVP rounding order: models/CVP_MVSNet/models/net.py:148)
 //   softmin         models/MVSNet/model.py:141-173
 //   group corr.     models/VisMVSNet/nn_utils.py:473-490
+#include <string.h>
+
 #include "pscv_common.h"
 
 namespace pscv {
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(256) void warp_cost_kernel(const WarpArgs a) {
 }
 
 // ---- host side ---------------------------------------------------------------------------------
-static int g_warp_lpv_override = 0;  // 0 = default heuristic; set through PSCV_WARP_LPV for tuning runs
+static int g_warp_lpv_override = 0;  // 0 = default heuristic; set through pscv_set_tuning("warp_lpv", n)
 static int g_warp_ppd_override = 0;
 
 // Instantiated (geometry, cost) pairs: the variance / softmin statistics belong to the PROJ models (MVSNet,
@@ -324,6 +326,15 @@ static int launch_channels(WarpArgs& a, int C, int geom, int cost, hipStream_t s
 
 }  // namespace pscv
 
+extern "C" int pscv_set_tuning(const char* key, int value) {
+    using namespace pscv;
+    PSCV_CHECK_ARG(key, "pscv_set_tuning: null key");
+    if (!strcmp(key, "warp_lpv")) { g_warp_lpv_override = value; return 0; }
+    if (!strcmp(key, "warp_ppd")) { g_warp_ppd_override = value; return 0; }
+    set_error("pscv_set_tuning: unknown key '%s'", key);
+    return -1;
+}
+
 extern "C" int pscv_warp_cost(const void* ref, const void* const* srcs, int n_src, const float* cams,
                               const float* depth, long depth_bstride, int depth_per_pixel, int geom, int cost,
                               float temp, void* out, int B, int C, int h, int w, int hs, int ws, int D, int in_dtype,
@@ -334,12 +345,6 @@ extern "C" int pscv_warp_cost(const void* ref, const void* const* srcs, int n_sr
     PSCV_CHECK_ARG(cost == PSCV_COST_WARP_ONLY || ref, "pscv_warp_cost: ref is required for cost mode %d", cost);
     PSCV_CHECK_ARG(B > 0 && h > 0 && w > 0 && hs > 1 && ws > 1 && D > 0, "pscv_warp_cost: bad sizes");
     PSCV_CHECK_ARG(C % 8 == 0, "pscv_warp_cost: C=%d must be a multiple of 8", C);
-    static bool env_read = false;
-    if (!env_read) {
-        env_read = true;
-        if (const char* e = getenv("PSCV_WARP_LPV")) g_warp_lpv_override = atoi(e);
-        if (const char* e = getenv("PSCV_WARP_PPD")) g_warp_ppd_override = atoi(e);
-    }
     WarpArgs a;
     a.ref = ref;
     for (int i = 0; i < PSCV_MAX_SRC; ++i) a.src[i] = i < n_src ? srcs[i] : nullptr;

@@ -46,6 +46,51 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class EventTimer:
+    """Per-kernel HIP-event timing on the launch stream (used by bench.py for the roofline figures).
+
+    ``with EventTimer() as tm: ...`` brackets every pscv launch with a pair of events recorded on the
+    stream the kernel is launched on; ``tm.summary()`` (after a device sync) returns
+    ``{name: (launches, total_ms)}``."""
+
+    def __init__(self):
+        self.records = []
+
+    def __enter__(self):
+        global _timer
+        self._prev, _timer = _timer, self
+        return self
+
+    def __exit__(self, *exc):
+        global _timer
+        _timer = self._prev
+        return False
+
+    def launch(self, name, fn):
+        st = torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        rc = fn()
+        e1.record(st)
+        self.records.append((name, e0, e1))
+        return rc
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, e0, e1 in self.records:
+            n, ms = out.get(name, (0, 0.0))
+            out[name] = (n + 1, ms + e0.elapsed_time(e1))
+        return out
+
+
+_timer: Optional[EventTimer] = None
+
+
+def _launch(name, fn):
+    return _timer.launch(name, fn) if _timer is not None else fn()
+
+
 # --------------------------------------------------------------------------------------------
 # layout helpers (plumbing)
 # --------------------------------------------------------------------------------------------
@@ -137,8 +182,9 @@ def warp_cost(ref: Optional[torch.Tensor], srcs: Sequence[torch.Tensor], cams: t
     elif tuple(out.shape) != shape or not out.is_contiguous():
         raise ValueError("pscv.warp_cost: bad `out` tensor")
     ptrs = (C.c_void_p * n)(*[s.data_ptr() for s in srcs])
-    rc = L.lib().pscv_warp_cost(_p(ref), ptrs, n, _p(cams), _p(depth), bstride, int(per_pixel), geom, cost,
-                                float(temp), _p(out), B, Cc, h, w, hs, ws, D, _dt(srcs[0]), _dt(out), _stream())
+    rc = _launch(f"warp_cost[{cost}]", lambda: L.lib().pscv_warp_cost(
+        _p(ref), ptrs, n, _p(cams), _p(depth), bstride, int(per_pixel), geom, cost, float(temp), _p(out), B, Cc, h, w,
+        hs, ws, D, _dt(srcs[0]), _dt(out), _stream()))
     L.check(rc, "pscv_warp_cost")
     return out
 
@@ -227,9 +273,10 @@ def conv3d(x: torch.Tensor, layer: Conv3dLayer, *, skip: Optional[torch.Tensor] 
         raise ValueError(f"pscv.conv3d: out has shape {tuple(out.shape)}, expected [B,{Do},{Ho},{Wo},*]")
     if skip is not None and (skip.dtype != torch.bfloat16 or tuple(skip.shape[:4]) != (B, Do, Ho, Wo)):
         raise ValueError("pscv.conv3d: skip must be bf16 with the output's spatial shape")
-    rc = L.lib().pscv_conv3d(_p(x), cs, in_coff, _p(layer.packed), _p(layer.scale), _p(layer.bias), _p(layer.floor),
-                             _p(skip), 0 if skip is None else skip.shape[4], skip_coff, _p(out), out.shape[4],
-                             out_coff, _dt(out), B, D, H, W, layer.c_in, layer.c_out, layer.kind, layer.epi, _stream())
+    rc = _launch(f"conv3d[{layer.c_in}->{layer.c_out},k{layer.kind}]", lambda: L.lib().pscv_conv3d(
+        _p(x), cs, in_coff, _p(layer.packed), _p(layer.scale), _p(layer.bias), _p(layer.floor), _p(skip),
+        0 if skip is None else skip.shape[4], skip_coff, _p(out), out.shape[4], out_coff, _dt(out), B, D, H, W,
+        layer.c_in, layer.c_out, layer.kind, layer.epi, _stream()))
     L.check(rc, "pscv_conv3d")
     return out
 
@@ -259,9 +306,9 @@ def softargmin(logits: torch.Tensor, depth: Optional[torch.Tensor] = None, *, wa
         "prob": mk(B, D, h, w) if want_prob else None,
         "partials": mk(B, 4, h, w) if want_partials else None,
     }
-    rc = L.lib().pscv_softargmin(_p(logits), _dt(logits), _p(depth), 0 if depth is None else depth.stride(0),
-                                 int(per_pixel), _p(o["depth"]), _p(o["index"]), _p(o["conf"]), _p(o["entropy"]),
-                                 _p(o["prob"]), _p(o["partials"]), conf_mode, float(window), index_offset, B, D, h, w,
-                                 _stream())
+    rc = _launch("softargmin", lambda: L.lib().pscv_softargmin(
+        _p(logits), _dt(logits), _p(depth), 0 if depth is None else depth.stride(0), int(per_pixel), _p(o["depth"]),
+        _p(o["index"]), _p(o["conf"]), _p(o["entropy"]), _p(o["prob"]), _p(o["partials"]), conf_mode, float(window),
+        index_offset, B, D, h, w, _stream()))
     L.check(rc, "pscv_softargmin")
     return {k: v for k, v in o.items() if v is not None}
