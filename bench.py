@@ -52,12 +52,16 @@ def algorithmic_bytes(name: str) -> float:
     return 0.0
 
 
-def build_inputs(device, rank: int):
+DTYPES = {"f16": torch.float16, "bf16": torch.bfloat16}
+
+
+def build_inputs(device, rank: int, dtype):
     net = MVSNet("variance")
     sd = synthetic.sharpened_state_dict("mvsnet", synthetic.template_of(net), seed=0)
     net.load_state_dict(sd)
     net = net.to(device).eval()
     net.num_depth = D
+    net.storage_dtype = dtype
     cams = synthetic.make_cameras(1, V, IMG_H, IMG_W)
     Ks = cams["K"].clone()
     Ks[:, :, :2] /= 4
@@ -65,7 +69,7 @@ def build_inputs(device, rank: int):
     steps = torch.arange(D, dtype=torch.float32).view(1, -1)
     dv = cams["depth_min"][:, :1] + (cams["depth_max"][:, :1] - cams["depth_min"][:, :1]) / (D - 1) * steps
     feats = synthetic.make_features(1, V, C, h, w, seed=1 + rank)           # [V,1,C,h,w] fp32
-    feats_cl = [ops.to_channels_last(feats[i].to(device), torch.bfloat16) for i in range(V)]
+    feats_cl = [ops.to_channels_last(feats[i].to(device), dtype) for i in range(V)]
     return net, sd, feats, feats_cl, proj.to(device), dv.to(device).contiguous(), proj, dv
 
 
@@ -88,6 +92,9 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=sorted(DTYPES), default="f16",
+                    help="16-bit HBM storage format (arithmetic is fp32); f16 is the engine default, see DESIGN.md section 5")
+    ap.add_argument("--dump-events", default=None, help="write every per-launch event duration to this file")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -102,7 +109,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
-    net, sd, feats, feats_cl, proj_d, dv_d, proj, dv = build_inputs(device, rank)
+    net, sd, feats, feats_cl, proj_d, dv_d, proj, dv = build_inputs(device, rank, DTYPES[args.dtype])
 
     def step():
         return net.hot_path(feats_cl, proj_d, dv_d)
@@ -123,7 +130,11 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
             elapsed = time.perf_counter() - t0
-        kern = tm.summary()
+        kern = {k: v for k, v in tm.summary().items() if k != "proj_cams"}
+        if args.dump_events and rank == 0:
+            with open(args.dump_events, "w") as f:
+                for name, e0, e1 in tm.records:
+                    f.write(f"{name}\t{e0.elapsed_time(e1) * 1e3:.1f}\n")
     assert torch.isfinite(depth).all()
 
     t_max = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -143,7 +154,7 @@ def main():
             "metric": "cost-volume voxels/sec (BxDxHxW), MVSNet hot path", "value": world * VOX * args.steps / elapsed,
             "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "MVSNet variance, 1 ref + 4 src views, 512x640 images (128x160x32 features), D=192, "
                                    "features resident in HBM -> depth + confidence", "global_batch": world,
                        "voxels_per_step_per_gpu": VOX, "parallelism": f"reference-view shard x{world}, no collective"},

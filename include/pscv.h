@@ -15,8 +15,8 @@
  *   - return 0 on success, negative on error; the message is available from
  *     pscv_last_error() (thread-local);
  *   - tensors are channels-last: feature maps [B,h,w,C], volumes [B,D,h,w,C];
- *     dtype codes select fp32 or bf16 STORAGE, arithmetic is always fp32
- *     (bf16 MFMA products accumulate in fp32).
+ *     dtype codes select fp32, bf16 or fp16 STORAGE, arithmetic is always fp32
+ *     (bf16 / fp16 MFMA products accumulate in fp32).
  */
 #ifndef PSCV_H
 #define PSCV_H
@@ -33,6 +33,7 @@ extern "C" {
 /* storage dtypes */
 #define PSCV_F32 0
 #define PSCV_BF16 1
+#define PSCV_F16 2 /* IEEE half, stores saturate at +-65504 */
 
 /* sampling geometry of the warp */
 #define PSCV_GEOM_PROJ 0  /* q = rot*(x,y,1)*d + trans, integer pixel centres, sample at index (u,v):
@@ -68,6 +69,15 @@ int pscv_abi_version(void);
 int pscv_set_tuning(const char* key, int value);
 
 /*
+ * Camera blocks of the PROJ geometry in one launch: for every source view v != reference_frame,
+ * rot|trans of P_v * P_ref^-1 (fp64 inside).  Replaces the torch.inverse / matmul pair of
+ * models/MVSNet/module.py:128-130 (models/CVP_MVSNet/models/modules.py:89-98).
+ *   proj  device fp32 [B,V,4,4] with last rows (0,0,0,1);  cams  device fp32 [V-1][B][PSCV_CAM_FLOATS],
+ *   sources in view order with the reference view skipped.
+ */
+int pscv_proj_cams(const float* proj, int B, int V, int reference_frame, float* cams, void* stream);
+
+/*
  * Fused plane-sweep warp + cost aggregation (one pass, the warped per-view volumes never reach HBM).
  * Replaces: MVSNet.build_cost_volume (models/MVSNet/model.py:109-176) + homo_warping (module.py:111-169);
  *           CVP net.py:129-152 and proj_cost (modules.py:229-293); Vis SingleStage.build_cost_volume +
@@ -92,9 +102,10 @@ int pscv_warp_cost(const void* ref, const void* const* srcs, int n_src, const fl
  *   kind        PSCV_CONV_*
  *   transposed  1 if `w` is a ConvTranspose3d weight ([C_in,C_out,3,3,3]); required for T2, and with S1 it
  *               packs the spatially flipped kernel (ConvTranspose3d k3 s1 p1 == Conv3d with flipped taps)
- *   returns the number of bf16 elements of the packed buffer (call with packed == NULL to query), <0 on error.
+ *   dtype       PSCV_BF16 or PSCV_F16: the 16-bit format of the packed weights (= the layer's activation format)
+ *   returns the number of 16-bit elements of the packed buffer (call with packed == NULL to query), <0 on error.
  */
-long pscv_pack_conv3d_weights(const float* w /*host*/, int c_in, int c_out, int kind, int transposed,
+long pscv_pack_conv3d_weights(const float* w /*host*/, int c_in, int c_out, int kind, int transposed, int dtype,
                               uint16_t* packed /*host, may be NULL*/);
 
 /*
@@ -104,17 +115,18 @@ long pscv_pack_conv3d_weights(const float* w /*host*/, int c_in, int c_out, int 
  *           ReLU) blocks and `prob` of CostRegNet (models/MVSNet/model.py:43-84; CVP net.py:50-85) and the conv /
  *           deconv members of the Vis UNet (models/VisMVSNet/nn_utils.py:194-278).
  *
- *   in       bf16 [B,Di,Hi,Wi,in_cstride], the layer reads channels [in_coff, in_coff + c_in)
+ *   dtype    PSCV_BF16 or PSCV_F16: format of `in`, `skip` and `packed` (one MFMA operand type per launch)
+ *   in       [B,Di,Hi,Wi,in_cstride], the layer reads channels [in_coff, in_coff + c_in)
  *   packed   device copy of pscv_pack_conv3d_weights output
  *   scale,bias  device fp32 [c_out]:  y = acc*scale + bias   (scale may be NULL = 1, bias may be NULL = 0)
  *   floor    device fp32 [c_out] or NULL: with PSCV_EPI_RELU_PRE, y = max(y, floor[c]) instead of max(y, 0)
  *            (floor = -inf keeps a channel linear; lets one launch carry ReLU and linear channels)
- *   skip     NULL or bf16 [B,Do,Ho,Wo,skip_cstride] read at channel offset skip_coff, added after RELU_PRE
- *   out      [B,Do,Ho,Wo,out_cstride] written at channel offset out_coff; out_dtype bf16 or fp32
+ *   skip     NULL or [B,Do,Ho,Wo,skip_cstride] read at channel offset skip_coff, added after RELU_PRE
+ *   out      [B,Do,Ho,Wo,out_cstride] written at channel offset out_coff; out_dtype = dtype or PSCV_F32
  *   (Do,Ho,Wo) = (Di,Hi,Wi) for S1, ceil(./2) for S2, 2x for T2.
  *   c_in in {8,16,32,64}; c_out in {1,8,16,32,64}.
  */
-int pscv_conv3d(const void* in, int in_cstride, int in_coff, const uint16_t* packed, const float* scale,
+int pscv_conv3d(const void* in, int dtype, int in_cstride, int in_coff, const uint16_t* packed, const float* scale,
                 const float* bias, const float* floor, const void* skip, int skip_cstride, int skip_coff, void* out,
                 int out_cstride, int out_coff, int out_dtype, int B, int Di, int Hi, int Wi, int c_in, int c_out,
                 int kind, int epi_flags, void* stream);
@@ -124,7 +136,7 @@ int pscv_conv3d(const void* in, int in_cstride, int in_coff, const uint16_t* pac
  * Replaces: F.softmax + depth_regression + photometric confidence (models/MVSNet/model.py:207-215, module.py:174-178;
  *           CVP net.py:161-162,203-219) and soft_argmin / entropy (models/VisMVSNet/nn_utils.py:453-470).
  *
- *   logits        [B,D,h,w] fp32 or bf16 (logit_dtype)
+ *   logits        [B,D,h,w] fp32, bf16 or fp16 (logit_dtype)
  *   depth         same addressing as pscv_warp_cost (per-batch or per-pixel planes); may be NULL (then out_depth must be NULL)
  *   out_depth     [B,h,w] fp32  sum_d p_d depth_d                         (NULL to skip)
  *   out_index     [B,h,w] fp32  sum_d p_d d                               (NULL to skip)

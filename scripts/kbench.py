@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmark at the headline sizes (MVSNet 5-view 128x160x32 features, D=192).
+Usage: python scripts/kbench.py [--reps 20] [--only substr] [--dtype bf16|f16]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from wild_deep_mvs_amd import _lib as L, ops, synthetic  # noqa: E402
+
+
+def timeit(fn, reps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3  # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--dtype", default="bf16")
+    args = ap.parse_args()
+    dt = {"bf16": torch.bfloat16, "f16": torch.float16}[args.dtype]
+    dev = "cuda"
+    D, h, w = 192, 128, 160
+    g = torch.Generator().manual_seed(0)
+
+    def vol(c, s):
+        return (torch.randn(1, D // s, h // s, w // s, c, generator=g) * 0.5).to(dt).to(dev)
+
+    rows = []
+    # ---- conv layers of the MVSNet regulariser ----
+    layers = [("conv0", 32, 8, 0, 1, False), ("conv1", 8, 16, 1, 1, False), ("conv2", 16, 16, 0, 2, False),
+              ("conv3", 16, 32, 1, 2, False), ("conv4", 32, 32, 0, 4, False), ("conv5", 32, 64, 1, 4, False),
+              ("conv6", 64, 64, 0, 8, False), ("conv7", 64, 32, 2, 8, True), ("conv9", 32, 16, 2, 4, True),
+              ("conv11", 16, 8, 2, 2, True), ("prob", 8, 1, 0, 1, False)]
+    for name, ci, co, kind, s, skip in layers:
+        if args.only and args.only not in name:
+            continue
+        x = vol(ci, s)
+        transposed = kind == L.CONV_T2
+        wshape = (ci, co, 3, 3, 3) if transposed else (co, ci, 3, 3, 3)
+        wt = torch.randn(wshape, generator=g) / (27 * ci) ** 0.5
+        try:
+            layer = ops.Conv3dLayer.build(wt, kind=kind, transposed=transposed, device=dev, relu=True, dtype=dt)
+        except TypeError:
+            layer = ops.Conv3dLayer.build(wt, kind=kind, transposed=transposed, device=dev, relu=True)
+        Do, Ho, Wo = ops.conv_out_shape(kind, *x.shape[1:4])
+        sk = (torch.randn(1, Do, Ho, Wo, co, generator=g)).to(dt).to(dev) if skip else None
+        out = torch.empty(1, Do, Ho, Wo, co, dtype=torch.float32 if name == "prob" else dt, device=dev)
+        us = timeit(lambda: ops.conv3d(x, layer, skip=sk, out=out), args.reps)
+        nbytes = x.numel() * 2 + out.numel() * out.element_size() + (sk.numel() * 2 if skip else 0)
+        flops = 2 * 27 * ci * co * (Do * Ho * Wo if kind != L.CONV_T2 else x.shape[1] * x.shape[2] * x.shape[3])
+        rows.append((f"conv3d {name} {ci}->{co} k{kind}", us, nbytes / us / 1e3, flops / us / 1e6))
+    # ---- warp + cost ----
+    if not args.only or "warp" in args.only:
+        feats = synthetic.make_features(1, 5, 32, h, w, seed=1)
+        fcl = [ops.to_channels_last(feats[i].to(dev), dt) for i in range(5)]
+        cams = synthetic.make_cameras(1, 5, 512, 640)
+        from wild_deep_mvs_amd.models.MVSNet.model import build_proj_matrices
+        Ks = cams["K"].clone(); Ks[:, :, :2] /= 4
+        proj = build_proj_matrices(Ks, cams["R"], cams["t"]).to(dev)
+        dv = torch.linspace(2.0, 6.0, D).view(1, D).to(dev)
+        cm = ops.proj_cams([proj[:, i] for i in range(1, 5)], proj[:, 0])
+        out = torch.empty(1, D, h, w, 32, dtype=dt, device=dev)
+        nbytes = 5 * 32 * h * w * 2 + out.numel() * 2
+        for lpv in (4, 2, 1):
+            for ppd in (4, 8, 16, 32):
+                L.set_tuning("warp_lpv", lpv); L.set_tuning("warp_ppd", ppd)
+                us = timeit(lambda: ops.warp_cost(fcl[0], fcl[1:], cm, dv, cost=L.COST_VARIANCE, out=out), args.reps)
+                rows.append((f"warp_cost variance lpv={lpv} ppd={ppd}", us, nbytes / us / 1e3, 0))
+        L.set_tuning("warp_lpv", 0); L.set_tuning("warp_ppd", 0)
+    # ---- softargmin ----
+    if not args.only or "soft" in args.only:
+        logits = torch.randn(1, D, h, w, generator=g).to(dev)
+        dv = torch.linspace(2.0, 6.0, D).view(1, D).to(dev)
+        us = timeit(lambda: ops.softargmin(logits, dv, want_conf=True), args.reps)
+        rows.append(("softargmin fp32 logits", us, logits.numel() * 4 / us / 1e3, 0))
+    for name, us, gbs, tf in rows:
+        print(f"{name:44s} {us:10.1f} us  {gbs:8.1f} GB/s(alg)  {tf:8.2f} TFLOP/s")
+
+
+if __name__ == "__main__":
+    main()

@@ -30,8 +30,9 @@ MVSNET_LAYERS = [(32, 8, 0), (8, 16, 1), (16, 16, 0), (16, 32, 1), (32, 32, 0), 
                  (64, 32, 2), (32, 16, 2), (16, 8, 2), (8, 1, 0)]
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("cin,cout,kind", MVSNET_LAYERS)
-def test_conv3d_plain(env, cin, cout, kind):
+def test_conv3d_plain(env, cin, cout, kind, dtype):
     L, ops = env
     g = torch.Generator().manual_seed(cin * 1000 + cout * 10 + kind)
     D, H, W = (6, 10, 21) if kind == L.CONV_S1 else (7, 9, 35) if kind == L.CONV_S2 else (3, 5, 19)
@@ -40,16 +41,17 @@ def test_conv3d_plain(env, cin, cout, kind):
     x = bf16_round(torch.randn(B, cin, D, H, W, generator=g))
     wshape = (cin, cout, 3, 3, 3) if transposed else (cout, cin, 3, 3, 3)
     w = bf16_round(torch.randn(wshape, generator=g) / np.sqrt(27 * cin))
-    layer = ops.Conv3dLayer.build(w, kind=kind, transposed=transposed, device="cuda")
-    y = ops.conv3d(ops.to_channels_last(x.cuda(), torch.bfloat16), layer, out_dtype=torch.float32)
+    layer = ops.Conv3dLayer.build(w, kind=kind, transposed=transposed, device="cuda", dtype=dtype)
+    y = ops.conv3d(ops.to_channels_last(x.cuda(), dtype), layer, out_dtype=torch.float32)   # bf16-exact values are fp16-exact
     ref = _ref_conv(x, w, kind, transposed, L)
-    check_close(f"conv3d {cin}->{cout} kind {kind} fp32 out", y.permute(0, 4, 1, 2, 3).cpu(), ref, max_abs=2e-3, rel_l2=1e-4)
+    check_close(f"conv3d {cin}->{cout} kind {kind} {dtype} operands, fp32 out", y.permute(0, 4, 1, 2, 3).cpu(), ref, max_abs=2e-3, rel_l2=1e-4)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("cin,cout,kind,relu,with_skip", [(32, 8, 0, True, False), (64, 32, 2, True, True),
                                                            (16, 8, 2, True, True), (16, 16, 0, False, True),
                                                            (8, 16, 1, True, False)])
-def test_conv3d_fused_epilogue(env, cin, cout, kind, relu, with_skip):
+def test_conv3d_fused_epilogue(env, cin, cout, kind, relu, with_skip, dtype):
     """folded BN affine, ReLU before the skip add (MVSNet: skip + relu(bn(deconv))), bf16 output."""
     L, ops = env
     g = torch.Generator().manual_seed(7 + cin + cout + kind)
@@ -60,7 +62,8 @@ def test_conv3d_fused_epilogue(env, cin, cout, kind, relu, with_skip):
     w = bf16_round(torch.randn(wshape, generator=g) / np.sqrt(27 * cin))
     gamma, beta = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.3
     mean, var = torch.randn(cout, generator=g) * 0.2, torch.rand(cout, generator=g) + 0.5
-    layer = ops.Conv3dLayer.build(w, kind=kind, transposed=transposed, device="cuda", bn=(gamma, beta, mean, var), relu=relu)
+    layer = ops.Conv3dLayer.build(w, kind=kind, transposed=transposed, device="cuda", bn=(gamma, beta, mean, var), relu=relu,
+                                  dtype=dtype)
     ref = _ref_conv(x, w, kind, transposed, L)
     ref = F.batch_norm(ref, mean, var, gamma, beta, training=False, eps=1e-5)
     if relu:
@@ -69,12 +72,13 @@ def test_conv3d_fused_epilogue(env, cin, cout, kind, relu, with_skip):
     if with_skip:
         skip = bf16_round(torch.randn(ref.shape, generator=g))
         ref = ref + skip
-    y = ops.conv3d(ops.to_channels_last(x.cuda(), torch.bfloat16), layer,
-                   skip=None if skip is None else ops.to_channels_last(skip.cuda(), torch.bfloat16))
-    assert y.dtype == torch.bfloat16
-    s = check_close(f"conv3d+bn{'+relu' if relu else ''}{'+skip' if with_skip else ''} {cin}->{cout} kind {kind}",
-                    y.float().permute(0, 4, 1, 2, 3).cpu(), ref, rel_l2=4e-3)
-    assert s["max_abs"] <= 2 ** -7 * s["ref_max"] + 1e-3
+    y = ops.conv3d(ops.to_channels_last(x.cuda(), dtype), layer,
+                   skip=None if skip is None else ops.to_channels_last(skip.cuda(), dtype))
+    assert y.dtype == dtype
+    ulp = 2 ** -8 if dtype == torch.bfloat16 else 2 ** -11      # half a unit in the last place, relative
+    s = check_close(f"conv3d+bn{'+relu' if relu else ''}{'+skip' if with_skip else ''} {cin}->{cout} kind {kind} {dtype}",
+                    y.float().permute(0, 4, 1, 2, 3).cpu(), ref, rel_l2=ulp)
+    assert s["max_abs"] <= ulp * s["ref_max"] + 1e-3
 
 
 def test_conv3d_channel_slices_and_relu_post(env):

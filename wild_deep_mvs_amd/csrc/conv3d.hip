@@ -21,7 +21,21 @@
 namespace pscv {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// one v_mfma_f32_16x16x32_{bf16,f16}: D[16 x 16] += A[16 x 32] * B[32 x 16], fp32 accumulate
+template <typename H> struct Mfma;
+template <> struct Mfma<bf16_t> {
+    __device__ static __forceinline__ f32x4 run(const uint4& a, const uint4& b, const f32x4& c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mfma<f16_t> {
+    __device__ static __forceinline__ f32x4 run(const uint4& a, const uint4& b, const f32x4& c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
 
 struct ConvArgs {
     const uint16_t* in;
@@ -74,7 +88,7 @@ template <int BH, int BW, int VS> __device__ __forceinline__ int tap_off_t2(int 
     return ((od * BH + oh) * BW + ow) * VS;
 }
 
-template <int CIN, int NT, int KIND, int TD, int TH>
+template <typename H, int CIN, int NT, int KIND, int TD, int TH>
 __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
     using BR = Brick<KIND, TD, TH>;
     constexpr int BD = BR::BD, BH = BR::BH, BW = BR::BW;
@@ -159,9 +173,10 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
                 const uint16_t* sp = a.skip + vox * a.skip_cs + a.skip_co + c0;
                 if (a.cout - c0 >= 4) {
                     const uint2 sv = *reinterpret_cast<const uint2*>(sp);
-                    y[0] += bf16lo(sv.x); y[1] += bf16hi(sv.x); y[2] += bf16lo(sv.y); y[3] += bf16hi(sv.y);
+                    y[0] += Half16<H>::lo(sv.x); y[1] += Half16<H>::hi(sv.x);
+                    y[2] += Half16<H>::lo(sv.y); y[3] += Half16<H>::hi(sv.y);
                 } else {
-                    for (int k = 0; k < a.cout - c0; ++k) y[k] += bf16_to_f32(sp[k]);
+                    for (int k = 0; k < a.cout - c0; ++k) y[k] += Half16<H>::one(sp[k]);
                 }
             }
             if (a.epi & PSCV_EPI_RELU_POST) {
@@ -174,8 +189,8 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
                 else for (int k = 0; k < a.cout - c0; ++k) op[k] = y[k];
             } else {
                 uint16_t* op = reinterpret_cast<uint16_t*>(a.out) + vox * a.out_cs + a.out_co + c0;
-                if (a.cout - c0 >= 4) *reinterpret_cast<uint2*>(op) = make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
-                else for (int k = 0; k < a.cout - c0; ++k) op[k] = f32_to_bf16(y[k]);
+                if (a.cout - c0 >= 4) *reinterpret_cast<uint2*>(op) = make_uint2(Half16<H>::pack(y[0], y[1]), Half16<H>::pack(y[2], y[3]));
+                else for (int k = 0; k < a.cout - c0; ++k) op[k] = Half16<H>::bits(y[k]);
             }
         }
     };
@@ -192,14 +207,14 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
         for (int s = 0; s < NSTEPS; ++s) {
             const int kk0 = s * 32 + g * 8;
             const int koff = tap_off_dense<KIND, BH, BW, VS>(kk0 / CIN) + (kk0 % CIN) * 2;
-            bf16x8 wf[NT];
+            uint4 wf[NT];
 #pragma unroll
-            for (int m = 0; m < NT; ++m) wf[m] = __builtin_bit_cast(bf16x8, wpk[(s * NT + m) * 64 + lane]);
+            for (int m = 0; m < NT; ++m) wf[m] = wpk[(s * NT + m) * 64 + lane];
 #pragma unroll
             for (int i = 0; i < MB; ++i) {
-                const bf16x8 xf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(smem + anchor[i] + koff));
+                const uint4 xf = *reinterpret_cast<const uint4*>(smem + anchor[i] + koff);
 #pragma unroll
-                for (int m = 0; m < NT; ++m) acc[i][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[m], xf, acc[i][m], 0, 0, 0);
+                for (int m = 0; m < NT; ++m) acc[i][m] = Mfma<H>::run(wf[m], xf, acc[i][m]);
             }
         }
 #pragma unroll
@@ -222,14 +237,14 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
                 if (s < nsteps) {
                     const int kk0 = s * 32 + g * 8;
                     const int koff = tap_off_t2<BH, BW, VS>(pc, kk0 / CIN) + (kk0 % CIN) * 2;
-                    bf16x8 wf[NT];
+                    uint4 wf[NT];
 #pragma unroll
-                    for (int m = 0; m < NT; ++m) wf[m] = __builtin_bit_cast(bf16x8, wpk[((sbase + s) * NT + m) * 64 + lane]);
+                    for (int m = 0; m < NT; ++m) wf[m] = wpk[((sbase + s) * NT + m) * 64 + lane];
 #pragma unroll
                     for (int i = 0; i < MB; ++i) {
-                        const bf16x8 xf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(smem + anchor[i] + koff));
+                        const uint4 xf = *reinterpret_cast<const uint4*>(smem + anchor[i] + koff);
 #pragma unroll
-                        for (int m = 0; m < NT; ++m) acc[i][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[m], xf, acc[i][m], 0, 0, 0);
+                        for (int m = 0; m < NT; ++m) acc[i][m] = Mfma<H>::run(wf[m], xf, acc[i][m]);
                     }
                 }
             }
@@ -245,7 +260,7 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
 }
 
 // ---- host side ---------------------------------------------------------------------------------
-template <int CIN, int NT, int KIND, int TD, int TH>
+template <typename H, int CIN, int NT, int KIND, int TD, int TH>
 static int launch_conv(ConvArgs& a, hipStream_t st) {
     using BR = Brick<KIND, TD, TH>;
     constexpr int VS = CIN * 2 + 16;
@@ -256,7 +271,7 @@ static int launch_conv(ConvArgs& a, hipStream_t st) {
     a.ntd = ceil_div(rd, TD); a.nth = ceil_div(rh, TH); a.ntw = ceil_div(rw, 16);
     const long nblk = (long)a.B * a.ntd * a.nth * a.ntw;
     if (nblk <= 0 || nblk > 0x7fffffffL) { set_error("pscv_conv3d: bad grid %ld", nblk); return -1; }
-    auto kern = conv3d_kernel<CIN, NT, KIND, TD, TH>;
+    auto kern = conv3d_kernel<H, CIN, NT, KIND, TD, TH>;
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -267,20 +282,33 @@ static int launch_conv(ConvArgs& a, hipStream_t st) {
     return 0;
 }
 
-template <int CIN, int NT>
+template <typename H, int CIN, int NT>
 static int launch_kind(ConvArgs& a, int kind, hipStream_t st) {
     switch (kind) {
-        case PSCV_CONV_S1: return launch_conv<CIN, NT, PSCV_CONV_S1, 4, 4>(a, st);
-        case PSCV_CONV_S2: return launch_conv<CIN, NT, PSCV_CONV_S2, 2, 2>(a, st);
-        case PSCV_CONV_T2: return launch_conv<CIN, NT, PSCV_CONV_T2, 2, 4>(a, st);
+        case PSCV_CONV_S1: return launch_conv<H, CIN, NT, PSCV_CONV_S1, 4, 4>(a, st);
+        case PSCV_CONV_S2: return launch_conv<H, CIN, NT, PSCV_CONV_S2, 2, 2>(a, st);
+        case PSCV_CONV_T2: return launch_conv<H, CIN, NT, PSCV_CONV_T2, 2, 4>(a, st);
     }
     set_error("pscv_conv3d: unknown kind %d", kind);
     return -1;
 }
 
+template <typename H>
+static int launch_channels(ConvArgs& a, int c_in, int c_out, int kind, hipStream_t st) {
+    const int nt = (c_out + 15) / 16;
+#define PSCV_CONV_CASE(CI, NTV) if (c_in == CI && nt == NTV) return launch_kind<H, CI, NTV>(a, kind, st);
+    PSCV_CONV_CASE(8, 1) PSCV_CONV_CASE(8, 2)
+    PSCV_CONV_CASE(16, 1) PSCV_CONV_CASE(16, 2)
+    PSCV_CONV_CASE(32, 1) PSCV_CONV_CASE(32, 2) PSCV_CONV_CASE(32, 4)
+    PSCV_CONV_CASE(64, 2) PSCV_CONV_CASE(64, 4)
+#undef PSCV_CONV_CASE
+    set_error("pscv_conv3d: unsupported channel combination c_in=%d c_out=%d", c_in, c_out);
+    return -1;
+}
+
 }  // namespace pscv
 
-extern "C" int pscv_conv3d(const void* in, int in_cstride, int in_coff, const uint16_t* packed, const float* scale,
+extern "C" int pscv_conv3d(const void* in, int dtype, int in_cstride, int in_coff, const uint16_t* packed, const float* scale,
                            const float* bias, const float* floor, const void* skip, int skip_cstride, int skip_coff,
                            void* out, int out_cstride, int out_coff, int out_dtype, int B, int Di, int Hi, int Wi,
                            int c_in, int c_out, int kind, int epi_flags, void* stream) {
@@ -292,7 +320,8 @@ extern "C" int pscv_conv3d(const void* in, int in_cstride, int in_coff, const ui
     PSCV_CHECK_ARG(out_coff + c_out <= out_cstride, "pscv_conv3d: output channel slice exceeds stride");
     PSCV_CHECK_ARG(c_out < 4 || (out_cstride % 4 == 0 && out_coff % 4 == 0), "pscv_conv3d: output slice must be 4-aligned");
     PSCV_CHECK_ARG(!skip || c_out < 4 || (skip_cstride % 4 == 0 && skip_coff % 4 == 0), "pscv_conv3d: skip slice must be 4-aligned");
-    PSCV_CHECK_ARG(out_dtype == PSCV_BF16 || out_dtype == PSCV_F32, "pscv_conv3d: bad out dtype %d", out_dtype);
+    PSCV_CHECK_ARG(dtype == PSCV_BF16 || dtype == PSCV_F16, "pscv_conv3d: storage dtype %d must be bf16 or fp16", dtype);
+    PSCV_CHECK_ARG(out_dtype == dtype || out_dtype == PSCV_F32, "pscv_conv3d: out dtype %d must be the storage dtype or fp32", out_dtype);
     ConvArgs a;
     a.in = reinterpret_cast<const uint16_t*>(in);
     a.wpk = packed; a.scale = scale; a.bias = bias; a.floor = floor;
@@ -306,15 +335,8 @@ extern "C" int pscv_conv3d(const void* in, int in_cstride, int in_coff, const ui
     else { a.Do = 2 * Di; a.Ho = 2 * Hi; a.Wo = 2 * Wi; }
     a.cout = c_out; a.epi = epi_flags;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int nt = (c_out + 15) / 16;
-    int rc = -1;
-#define PSCV_CONV_CASE(CI, NTV) if (c_in == CI && nt == NTV) rc = launch_kind<CI, NTV>(a, kind, st); else
-    PSCV_CONV_CASE(8, 1) PSCV_CONV_CASE(8, 2)
-    PSCV_CONV_CASE(16, 1) PSCV_CONV_CASE(16, 2)
-    PSCV_CONV_CASE(32, 1) PSCV_CONV_CASE(32, 2) PSCV_CONV_CASE(32, 4)
-    PSCV_CONV_CASE(64, 2) PSCV_CONV_CASE(64, 4)
-    { set_error("pscv_conv3d: unsupported channel combination c_in=%d c_out=%d", c_in, c_out); return -1; }
-#undef PSCV_CONV_CASE
+    const int rc = dtype == PSCV_BF16 ? launch_channels<bf16_t>(a, c_in, c_out, kind, st)
+                                      : launch_channels<f16_t>(a, c_in, c_out, kind, st);
     if (rc) return rc;
     PSCV_CHECK_LAUNCH("pscv_conv3d");
     return 0;

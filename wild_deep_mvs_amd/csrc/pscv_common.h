@@ -49,6 +49,43 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 __device__ __forceinline__ float bf16lo(uint32_t x) { return __uint_as_float(x << 16); }
 __device__ __forceinline__ float bf16hi(uint32_t x) { return __uint_as_float(x & 0xffff0000u); }
 
+// ---- fp16 <-> fp32: round to nearest even, SATURATING at +-65504 (a stored activation never becomes inf) ----
+__host__ __device__ __forceinline__ uint16_t f32_to_f16_bits(float f) {
+    union { uint32_t u; float f; } c;
+    c.f = f;
+    const uint32_t sign = (c.u >> 16) & 0x8000u;
+    uint32_t x = c.u & 0x7fffffffu;
+    if (x > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);            // NaN
+    if (x > 0x477fe000u) return (uint16_t)(sign | 0x7bffu);            // |f| > 65504 (incl. inf): saturate
+    if (x < 0x38800000u) {                                             // |f| < 2^-14: subnormal half or zero
+        if (x < 0x33000000u) return (uint16_t)sign;                    // < 2^-25
+        const uint32_t mant = (x & 0x7fffffu) | 0x800000u;
+        const int shift = 126 - (int)(x >> 23);
+        uint32_t h = mant >> shift;
+        const uint32_t rem = mant & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+        if (rem > halfway || (rem == halfway && (h & 1u))) ++h;
+        return (uint16_t)(sign | h);
+    }
+    uint32_t h = (x - 0x38000000u) >> 13;
+    const uint32_t rem = x & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;
+    return (uint16_t)(sign | h);
+}
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float f16lo(uint32_t x) { return (float)__builtin_bit_cast(h2_t, x)[0]; }
+__device__ __forceinline__ float f16hi(uint32_t x) { return (float)__builtin_bit_cast(h2_t, x)[1]; }
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+    h2_t v;
+    v[0] = (_Float16)__builtin_amdgcn_fmed3f(lo, -65504.0f, 65504.0f);
+    v[1] = (_Float16)__builtin_amdgcn_fmed3f(hi, -65504.0f, 65504.0f);
+    return __builtin_bit_cast(uint32_t, v);
+}
+
+// 16-bit storage type tags (both are raw uint16 in memory)
+struct bf16_t { uint16_t bits; };
+struct f16_t { uint16_t bits; };
+static_assert(sizeof(bf16_t) == 2 && sizeof(f16_t) == 2, "16-bit storage");
+
 // 8 consecutive channels of one texel / voxel
 struct f32x8 { float v[8]; };
 
@@ -71,28 +108,48 @@ template <> struct Elem<float> {
         *reinterpret_cast<float2*>(p) = make_float2(a, b);
     }
 };
-template <> struct Elem<uint16_t> {
+template <typename H> struct Half16;   // per-format pack / unpack of a 32-bit word holding two elements
+template <> struct Half16<bf16_t> {
     static constexpr int dtype = PSCV_BF16;
-    __device__ static __forceinline__ f32x8 load8(const uint16_t* p) {
+    __device__ static __forceinline__ float lo(uint32_t x) { return bf16lo(x); }
+    __device__ static __forceinline__ float hi(uint32_t x) { return bf16hi(x); }
+    __device__ static __forceinline__ uint32_t pack(float a, float b) { return pack_bf16x2(a, b); }
+    __device__ static __forceinline__ float one(uint16_t v) { return bf16_to_f32(v); }
+    __host__ __device__ static __forceinline__ uint16_t bits(float f) { return f32_to_bf16(f); }
+};
+template <> struct Half16<f16_t> {
+    static constexpr int dtype = PSCV_F16;
+    __device__ static __forceinline__ float lo(uint32_t x) { return f16lo(x); }
+    __device__ static __forceinline__ float hi(uint32_t x) { return f16hi(x); }
+    __device__ static __forceinline__ uint32_t pack(float a, float b) { return pack_f16x2(a, b); }
+    __device__ static __forceinline__ float one(uint16_t v) { return f16lo((uint32_t)v); }
+    __host__ __device__ static __forceinline__ uint16_t bits(float f) { return f32_to_f16_bits(f); }
+};
+
+template <typename H> struct Elem16 {
+    static constexpr int dtype = Half16<H>::dtype;
+    __device__ static __forceinline__ f32x8 load8(const H* p) {
         const uint4 a = *reinterpret_cast<const uint4*>(p);
         f32x8 r;
-        r.v[0] = bf16lo(a.x); r.v[1] = bf16hi(a.x);
-        r.v[2] = bf16lo(a.y); r.v[3] = bf16hi(a.y);
-        r.v[4] = bf16lo(a.z); r.v[5] = bf16hi(a.z);
-        r.v[6] = bf16lo(a.w); r.v[7] = bf16hi(a.w);
+        r.v[0] = Half16<H>::lo(a.x); r.v[1] = Half16<H>::hi(a.x);
+        r.v[2] = Half16<H>::lo(a.y); r.v[3] = Half16<H>::hi(a.y);
+        r.v[4] = Half16<H>::lo(a.z); r.v[5] = Half16<H>::hi(a.z);
+        r.v[6] = Half16<H>::lo(a.w); r.v[7] = Half16<H>::hi(a.w);
         return r;
     }
-    __device__ static __forceinline__ void store8(uint16_t* p, const f32x8& r) {
+    __device__ static __forceinline__ void store8(H* p, const f32x8& r) {
         uint4 a;
-        a.x = pack_bf16x2(r.v[0], r.v[1]);
-        a.y = pack_bf16x2(r.v[2], r.v[3]);
-        a.z = pack_bf16x2(r.v[4], r.v[5]);
-        a.w = pack_bf16x2(r.v[6], r.v[7]);
+        a.x = Half16<H>::pack(r.v[0], r.v[1]);
+        a.y = Half16<H>::pack(r.v[2], r.v[3]);
+        a.z = Half16<H>::pack(r.v[4], r.v[5]);
+        a.w = Half16<H>::pack(r.v[6], r.v[7]);
         *reinterpret_cast<uint4*>(p) = a;
     }
-    __device__ static __forceinline__ void store2(uint16_t* p, float a, float b) {
-        *reinterpret_cast<uint32_t*>(p) = pack_bf16x2(a, b);
+    __device__ static __forceinline__ void store2(H* p, float a, float b) {
+        *reinterpret_cast<uint32_t*>(p) = Half16<H>::pack(a, b);
     }
 };
+template <> struct Elem<bf16_t> : Elem16<bf16_t> {};
+template <> struct Elem<f16_t> : Elem16<f16_t> {};
 
 }  // namespace pscv

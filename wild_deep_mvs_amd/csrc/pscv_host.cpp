@@ -31,13 +31,14 @@ extern "C" int pscv_abi_version(void) { return PSCV_ABI_VERSION; }
 // row-major; T2 concatenates its 8 output-parity classes pc = pd*4 + ph*2 + pw, each with taps ordered
 // (sub_d, sub_h, sub_w) where along a parity-1 dim sub 0 is kernel index 0 (input offset +1) and sub 1 is
 // kernel index 2 (offset 0), and a parity-0 dim has the single kernel index 1.
-extern "C" long pscv_pack_conv3d_weights(const float* w, int c_in, int c_out, int kind, int transposed,
+extern "C" long pscv_pack_conv3d_weights(const float* w, int c_in, int c_out, int kind, int transposed, int dtype,
                                          uint16_t* packed) {
     using namespace pscv;
     PSCV_CHECK_ARG(c_in > 0 && c_in % 8 == 0 && c_out > 0, "pscv_pack_conv3d_weights: bad channels %d -> %d", c_in, c_out);
     PSCV_CHECK_ARG(kind == PSCV_CONV_S1 || kind == PSCV_CONV_S2 || kind == PSCV_CONV_T2, "pscv_pack_conv3d_weights: kind %d", kind);
     PSCV_CHECK_ARG(kind != PSCV_CONV_T2 || transposed, "pscv_pack_conv3d_weights: T2 needs a ConvTranspose3d weight");
     PSCV_CHECK_ARG(kind != PSCV_CONV_S2 || !transposed, "pscv_pack_conv3d_weights: S2 takes a Conv3d weight");
+    PSCV_CHECK_ARG(dtype == PSCV_BF16 || dtype == PSCV_F16, "pscv_pack_conv3d_weights: dtype %d must be bf16 or fp16", dtype);
     const int nt = ceil_div(c_out, 16);
     int total_steps = 0;
     if (kind == PSCV_CONV_T2) {
@@ -55,7 +56,7 @@ extern "C" long pscv_pack_conv3d_weights(const float* w, int c_in, int c_out, in
         return transposed ? w[((long)ci * c_out + co) * 27 + kidx] : w[((long)co * c_in + ci) * 27 + kidx];
     };
     auto put = [&](int step, int tile, int lane, int j, float v) {
-        packed[(((long)step * nt + tile) * 64 + lane) * 8 + j] = f32_to_bf16(v);
+        packed[(((long)step * nt + tile) * 64 + lane) * 8 + j] = dtype == PSCV_BF16 ? f32_to_bf16(v) : f32_to_f16_bits(v);
     };
 
     int step0 = 0;

@@ -1,8 +1,9 @@
 // Softmax over the depth axis fused with every expectation the three models take from it (gfx950).
 //
-// One lane per pixel, logits read plane by plane (coalesced across x), fp32 arithmetic:
-//   pass 1  running max;  pass 2  sum exp, sum exp*depth, sum exp*index;  optional pass 3 for the
-//   entropy / full probability volume; the confidence window re-reads only the 4-5 planes it needs.
+// A workgroup owns 32 x-adjacent pixels; 8 lane groups each reduce one eighth of the depth planes (coalesced
+// 128-byte rows), fp32 arithmetic:  pass 1 running max;  pass 2 sum exp, sum exp*depth, sum exp*index;  LDS
+// log-sum-exp merge of the 8 slices;  optional pass 3 for the entropy / full probability volume; the
+// confidence window re-reads only the 4-5 planes it needs.
 // Also emits the per-shard (max, sum, sum*depth, sum*index) partials used by the depth-plane-sharded
 // multi-GPU path (log-sum-exp merge = one tiny all-reduce).
 //
@@ -27,67 +28,101 @@ struct SoftArgs {
 
 template <typename T> __device__ __forceinline__ float ldlogit(const T* p);
 template <> __device__ __forceinline__ float ldlogit<float>(const float* p) { return *p; }
-template <> __device__ __forceinline__ float ldlogit<uint16_t>(const uint16_t* p) { return bf16_to_f32(*p); }
+template <> __device__ __forceinline__ float ldlogit<bf16_t>(const bf16_t* p) { return bf16_to_f32(p->bits); }
+template <> __device__ __forceinline__ float ldlogit<f16_t>(const f16_t* p) { return f16lo((uint32_t)p->bits); }
+
+// 256 threads = PX pixels x NS depth slices: each thread reduces D/NS planes, the slices merge through LDS with
+// the log-sum-exp rule (the same rule the multi-GPU depth-plane shard uses across ranks).
+constexpr int SA_PX = 32, SA_NS = 8;
 
 template <typename T>
 __global__ __launch_bounds__(256) void softargmin_kernel(const SoftArgs a) {
+    __shared__ float sh[4][SA_NS][SA_PX];
     const long hw = (long)a.h * a.w;
     const long npix = (long)a.B * hw;
-    const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (pix >= npix) return;
+    const int px = threadIdx.x % SA_PX, sl = threadIdx.x / SA_PX;
+    long pix = (long)blockIdx.x * SA_PX + px;
+    const bool active = pix < npix;
+    pix = active ? pix : npix - 1;
     const int b = (int)(pix / hw);
     const long pf = pix - (long)b * hw;
     const T* lp = reinterpret_cast<const T*>(a.logits) + (long)b * a.D * hw + pf;
     const float* dp = a.depth ? a.depth + (long)b * a.depth_bstride + (a.depth_per_pixel ? pf : 0) : nullptr;
     const long dstep = a.depth_per_pixel ? hw : 1;
+    const int per = (a.D + SA_NS - 1) / SA_NS;
+    const int d0 = sl * per, d1 = min(a.D, d0 + per);
 
     float m = -INFINITY;
-    for (int d = 0; d < a.D; ++d) m = fmaxf(m, ldlogit<T>(lp + d * hw));
-
+    for (int d = d0; d < d1; ++d) m = fmaxf(m, ldlogit<T>(lp + d * hw));
     float se = 0.f, sd = 0.f, si = 0.f;
-    for (int d = 0; d < a.D; ++d) {
+    for (int d = d0; d < d1; ++d) {
         const float e = expf(ldlogit<T>(lp + d * hw) - m);
         se += e;
         if (dp) sd = fmaf(e, dp[d * dstep], sd);
         si = fmaf(e, (float)(d + a.index_offset), si);
     }
-    const float inv = 1.0f / se;
-    const float eidx = si * inv;   // expected plane index            model.py:213, nn_utils.py:459
-    if (a.o_depth) a.o_depth[pix] = sd * inv;
-    if (a.o_index) a.o_index[pix] = eidx;
-    if (a.o_part) {
-        float* pp = a.o_part + (long)b * 4 * hw + pf;
-        pp[0] = m; pp[hw] = se; pp[2 * hw] = sd; pp[3 * hw] = si;
+    sh[0][sl][px] = m; sh[1][sl][px] = se; sh[2][sl][px] = sd; sh[3][sl][px] = si;
+    __syncthreads();
+    // every thread merges all slices (cheap) so that each knows the global max / normaliser
+    float M = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < SA_NS; ++k) M = fmaxf(M, sh[0][k][px]);
+    float SE = 0.f, SD = 0.f, SI = 0.f;
+#pragma unroll
+    for (int k = 0; k < SA_NS; ++k) {
+        const float mk = sh[0][k][px];
+        const float f = mk > -INFINITY ? expf(mk - M) : 0.0f;   // empty slice (D < NS*per): contributes nothing
+        SE = fmaf(sh[1][k][px], f, SE); SD = fmaf(sh[2][k][px], f, SD); SI = fmaf(sh[3][k][px], f, SI);
     }
-    if (a.o_conf) {
-        float c = 0.f;
-        const float lidx = eidx - (float)a.index_offset;   // index local to this logit block
-        if (a.conf_mode == 0) {
-            // planes i-1 .. i+2 around i = trunc(E[index]) (zero padded)        model.py:211-215
-            const int i = (int)lidx;
-            for (int k = -1; k <= 2; ++k) {
-                const int d = i + k;
-                if (d >= 0 && d < a.D) c += expf(ldlogit<T>(lp + d * hw) - m) * inv;
-            }
-        } else {
-            // planes with |d - E[index]| <= window                              nn_utils.py:464-465
-            int dlo = (int)ceilf(lidx - a.window), dhi = (int)floorf(lidx + a.window);
-            dlo = dlo < 0 ? 0 : dlo;
-            dhi = dhi > a.D - 1 ? a.D - 1 : dhi;
-            for (int d = dlo; d <= dhi; ++d)
-                if (fabsf((float)d - lidx) <= a.window) c += expf(ldlogit<T>(lp + d * hw) - m) * inv;
+    const float inv = 1.0f / SE;
+    const float eidx = SI * inv;   // expected plane index            model.py:213, nn_utils.py:459
+    if (sl == 0 && active) {
+        if (a.o_depth) a.o_depth[pix] = SD * inv;
+        if (a.o_index) a.o_index[pix] = eidx;
+        if (a.o_part) {
+            float* pp = a.o_part + (long)b * 4 * hw + pf;
+            pp[0] = M; pp[hw] = SE; pp[2 * hw] = SD; pp[3 * hw] = SI;
         }
-        a.o_conf[pix] = c;
+        if (a.o_conf) {
+            float c = 0.f;
+            const float lidx = eidx - (float)a.index_offset;   // index local to this logit block
+            if (a.conf_mode == 0) {
+                // planes i-1 .. i+2 around i = trunc(E[index]) (zero padded)        model.py:211-215
+                const int i = (int)lidx;
+                for (int k = -1; k <= 2; ++k) {
+                    const int d = i + k;
+                    if (d >= 0 && d < a.D) c += expf(ldlogit<T>(lp + d * hw) - M) * inv;
+                }
+            } else {
+                // planes with |d - E[index]| <= window                              nn_utils.py:464-465
+                int dlo = (int)ceilf(lidx - a.window), dhi = (int)floorf(lidx + a.window);
+                dlo = dlo < 0 ? 0 : dlo;
+                dhi = dhi > a.D - 1 ? a.D - 1 : dhi;
+                for (int d = dlo; d <= dhi; ++d)
+                    if (fabsf((float)d - lidx) <= a.window) c += expf(ldlogit<T>(lp + d * hw) - M) * inv;
+            }
+            a.o_conf[pix] = c;
+        }
     }
     if (a.o_entropy || a.o_prob) {
         float ent = 0.f;
-        float* pr = a.o_prob ? a.o_prob + (long)b * a.D * hw + pf : nullptr;
-        for (int d = 0; d < a.D; ++d) {
-            const float p = expf(ldlogit<T>(lp + d * hw) - m) * inv;
+        float* pr = (a.o_prob && active) ? a.o_prob + (long)b * a.D * hw + pf : nullptr;
+        for (int d = d0; d < d1; ++d) {
+            const float p = expf(ldlogit<T>(lp + d * hw) - M) * inv;
             if (pr) pr[d * hw] = p;
             ent -= p * logf(fminf(fmaxf(p, 1e-9f), 1.0f));   // nn_utils.py:469-470
         }
-        if (a.o_entropy) a.o_entropy[pix] = ent;
+        if (a.o_entropy) {
+            __syncthreads();
+            sh[0][sl][px] = ent;
+            __syncthreads();
+            if (sl == 0 && active) {
+                float e = 0.f;
+#pragma unroll
+                for (int k = 0; k < SA_NS; ++k) e += sh[0][k][px];
+                a.o_entropy[pix] = e;
+            }
+        }
     }
 }
 
@@ -109,10 +144,11 @@ extern "C" int pscv_softargmin(const void* logits, int logit_dtype, const float*
     a.conf_mode = conf_mode; a.window = window; a.index_offset = index_offset;
     a.B = B; a.D = D; a.h = h; a.w = w;
     const long npix = (long)B * h * w;
-    const unsigned nblk = (unsigned)((npix + 255) / 256);
+    const unsigned nblk = (unsigned)((npix + pscv::SA_PX - 1) / pscv::SA_PX);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (logit_dtype == PSCV_F32) hipLaunchKernelGGL(softargmin_kernel<float>, dim3(nblk), dim3(256), 0, st, a);
-    else if (logit_dtype == PSCV_BF16) hipLaunchKernelGGL(softargmin_kernel<uint16_t>, dim3(nblk), dim3(256), 0, st, a);
+    else if (logit_dtype == PSCV_BF16) hipLaunchKernelGGL(softargmin_kernel<bf16_t>, dim3(nblk), dim3(256), 0, st, a);
+    else if (logit_dtype == PSCV_F16) hipLaunchKernelGGL(softargmin_kernel<f16_t>, dim3(nblk), dim3(256), 0, st, a);
     else { set_error("pscv_softargmin: bad logit dtype %d", logit_dtype); return -1; }
     PSCV_CHECK_LAUNCH("pscv_softargmin");
     return 0;

@@ -37,11 +37,11 @@ class _Block3D(nn.Module):
         self.bn = nn.BatchNorm3d(out_channels)
         self.stride = stride
 
-    def engine_layer(self, device) -> ops.Conv3dLayer:
+    def engine_layer(self, device, dtype=torch.float16) -> ops.Conv3dLayer:
         bn = self.bn
         return ops.Conv3dLayer.build(self.conv.weight, kind=L.CONV_S1 if self.stride == 1 else L.CONV_S2,
                                      device=device, bn=(bn.weight, bn.bias, bn.running_mean, bn.running_var),
-                                     bn_eps=bn.eps, relu=self.relu)
+                                     bn_eps=bn.eps, relu=self.relu, dtype=dtype)
 
     def forward(self, x):
         raise RuntimeError("3-D blocks are executed by the pscv engine (CostRegNet.forward), not called directly")
@@ -55,13 +55,13 @@ class ConvBn3D(_Block3D):       # reference models/MVSNet/module.py:51-58
     relu = False
 
 
-def deconv_engine_layer(seq: nn.Sequential, device, stride: int = 2) -> ops.Conv3dLayer:
+def deconv_engine_layer(seq: nn.Sequential, device, stride: int = 2, dtype=torch.float16) -> ops.Conv3dLayer:
     """``Sequential(ConvTranspose3d(k3,p1,op=stride-1), BatchNorm3d, ReLU)`` -> engine layer
     (reference models/MVSNet/model.py:57-70)."""
     deconv, bn = seq[0], seq[1]
     return ops.Conv3dLayer.build(deconv.weight, kind=L.CONV_T2 if stride == 2 else L.CONV_S1, transposed=True,
                                  device=device, bn=(bn.weight, bn.bias, bn.running_mean, bn.running_var),
-                                 bn_eps=bn.eps, relu=True)
+                                 bn_eps=bn.eps, relu=True, dtype=dtype)
 
 
 def homo_warping(src_fea, src_proj, ref_proj, depth_values, ref_shape=None):
@@ -73,7 +73,7 @@ def homo_warping(src_fea, src_proj, ref_proj, depth_values, ref_shape=None):
     if src_fea.requires_grad and torch.is_grad_enabled():
         raise NotImplementedError("pscv homo_warping: backward (d/d src_fea) is not implemented yet")
     fea = ops.to_channels_last(src_fea.detach(), torch.float32)
-    cams = ops.proj_cams([src_proj], ref_proj)
+    cams = ops.proj_cams_device(torch.stack([ref_proj, src_proj], dim=1).to(torch.float32).contiguous(), 0)
     hw = src_fea.shape[-2:] if ref_shape is None else tuple(int(s) for s in ref_shape)
     vol = ops.warp_cost(None, [fea], cams, depth_values.to(torch.float32).contiguous(), geom=L.GEOM_PROJ,
                         cost=L.COST_WARP_ONLY, ref_hw=hw, out_dtype=torch.float32)

@@ -17,14 +17,15 @@ import torch
 
 from . import _lib as L
 
-_TORCH2PSCV = {torch.float32: L.F32, torch.bfloat16: L.BF16}
+_TORCH2PSCV = {torch.float32: L.F32, torch.bfloat16: L.BF16, torch.float16: L.F16}
+HALF_DTYPES = (torch.bfloat16, torch.float16)
 
 
 def _dt(t: torch.Tensor) -> int:
     try:
         return _TORCH2PSCV[t.dtype]
     except KeyError:
-        raise TypeError(f"pscv: unsupported dtype {t.dtype} (float32 / bfloat16 only)")
+        raise TypeError(f"pscv: unsupported dtype {t.dtype} (float32 / bfloat16 / float16 only)")
 
 
 def _dev(*ts: Optional[torch.Tensor]):
@@ -137,6 +138,19 @@ def proj_cams(src_projs: Sequence[torch.Tensor], ref_proj: torch.Tensor) -> torc
     return torch.stack(out).to(torch.float32).contiguous()
 
 
+def proj_cams_device(proj: torch.Tensor, reference_frame: int = 0) -> torch.Tensor:
+    """Same block as ``proj_cams`` for all source views of ``proj`` [B,V,4,4] in ONE HIP launch
+    (pscv_proj_cams): [V-1,B,18], sources in view order with the reference skipped."""
+    _dev(proj)
+    if proj.dim() != 4 or proj.shape[2:] != (4, 4) or proj.dtype != torch.float32:
+        raise ValueError("pscv.proj_cams_device: proj must be fp32 [B,V,4,4]")
+    B, V = proj.shape[:2]
+    cams = torch.empty((V - 1, B, L.CAM_FLOATS), dtype=torch.float32, device=proj.device)
+    rc = _launch("proj_cams", lambda: L.lib().pscv_proj_cams(_p(proj), B, V, int(reference_frame), _p(cams), _stream()))
+    L.check(rc, "pscv_proj_cams")
+    return cams
+
+
 # --------------------------------------------------------------------------------------------
 # fused warp + cost
 # --------------------------------------------------------------------------------------------
@@ -192,19 +206,21 @@ def warp_cost(ref: Optional[torch.Tensor], srcs: Sequence[torch.Tensor], cams: t
 # --------------------------------------------------------------------------------------------
 # conv3d
 # --------------------------------------------------------------------------------------------
-def pack_conv3d_weights(weight: torch.Tensor, kind: int, transposed: bool) -> np.ndarray:
+def pack_conv3d_weights(weight: torch.Tensor, kind: int, transposed: bool,
+                        dtype: torch.dtype = torch.bfloat16) -> np.ndarray:
     """Host-side repack of a Conv3d [Co,Ci,3,3,3] / ConvTranspose3d [Ci,Co,3,3,3] weight into the MFMA
-    fragment order of the conv kernel (uint16 bf16 bits)."""
+    fragment order of the conv kernel (uint16 bit patterns of ``dtype`` = bf16 or fp16)."""
     w = np.ascontiguousarray(weight.detach().to("cpu", torch.float32).numpy())
     if w.ndim != 5 or w.shape[2:] != (3, 3, 3):
         raise ValueError(f"pscv: conv3d weights must be [*,*,3,3,3], got {w.shape}")
     c_in, c_out = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
     lib = L.lib()
-    n = lib.pscv_pack_conv3d_weights(None, c_in, c_out, kind, int(transposed), None)
+    code = _TORCH2PSCV.get(dtype, -1)
+    n = lib.pscv_pack_conv3d_weights(None, c_in, c_out, kind, int(transposed), code, None)
     if n < 0:
         L.check(int(n), "pscv_pack_conv3d_weights")
     packed = np.empty(n, dtype=np.uint16)
-    n2 = lib.pscv_pack_conv3d_weights(w.ctypes.data_as(C.c_void_p), c_in, c_out, kind, int(transposed),
+    n2 = lib.pscv_pack_conv3d_weights(w.ctypes.data_as(C.c_void_p), c_in, c_out, kind, int(transposed), code,
                                       packed.ctypes.data_as(C.c_void_p))
     if n2 != n:
         L.check(-1 if n2 >= 0 else int(n2), "pscv_pack_conv3d_weights")
@@ -213,8 +229,9 @@ def pack_conv3d_weights(weight: torch.Tensor, kind: int, transposed: bool) -> np
 
 @dataclass
 class Conv3dLayer:
-    """One 3x3x3 layer ready for the engine: packed bf16 weights + fp32 epilogue vectors, on device."""
-    packed: torch.Tensor            # int16 view of bf16 fragments
+    """One 3x3x3 layer ready for the engine: packed 16-bit weights + fp32 epilogue vectors, on device."""
+    packed: torch.Tensor            # int16 bit patterns of the MFMA A fragments
+    dtype: torch.dtype              # bf16 or fp16: format of the weights AND of the activations it reads
     c_in: int
     c_out: int
     kind: int
@@ -227,12 +244,12 @@ class Conv3dLayer:
     def build(weight: torch.Tensor, *, kind: int, transposed: bool = False, device=None,
               bn: Optional[Sequence[torch.Tensor]] = None, bn_eps: float = 1e-5,
               conv_bias: Optional[torch.Tensor] = None, relu: bool = False, relu_post: bool = False,
-              floor: Optional[torch.Tensor] = None) -> "Conv3dLayer":
+              floor: Optional[torch.Tensor] = None, dtype: torch.dtype = torch.bfloat16) -> "Conv3dLayer":
         """``bn`` = (gamma, beta, running_mean, running_var) folds an eval-mode BatchNorm3d into the
         epilogue: scale = gamma / sqrt(var + eps), bias = beta - mean * scale (+ scale * conv_bias)."""
         device = device if device is not None else weight.device
         c_in, c_out = (weight.shape[0], weight.shape[1]) if transposed else (weight.shape[1], weight.shape[0])
-        packed = torch.from_numpy(pack_conv3d_weights(weight, kind, transposed).view(np.int16)).to(device)
+        packed = torch.from_numpy(pack_conv3d_weights(weight, kind, transposed, dtype).view(np.int16)).to(device)
         scale = bias = None
         if bn is not None:
             gamma, beta, mean, var = [t.detach().to(device, torch.float32) for t in bn]
@@ -246,7 +263,7 @@ class Conv3dLayer:
         epi = (L.EPI_RELU_PRE if relu else 0) | (L.EPI_RELU_POST if relu_post else 0)
         if floor is not None:
             floor = floor.detach().to(device, torch.float32).contiguous()
-        return Conv3dLayer(packed, int(c_in), int(c_out), kind, epi, scale, bias, floor)
+        return Conv3dLayer(packed, dtype, int(c_in), int(c_out), kind, epi, scale, bias, floor)
 
 
 def conv_out_shape(kind: int, D: int, H: int, W: int):
@@ -259,22 +276,24 @@ def conv_out_shape(kind: int, D: int, H: int, W: int):
 
 def conv3d(x: torch.Tensor, layer: Conv3dLayer, *, skip: Optional[torch.Tensor] = None, in_coff: int = 0,
            skip_coff: int = 0, out: Optional[torch.Tensor] = None, out_coff: int = 0,
-           out_dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
-    """x bf16 [B,D,H,W,Cs] (reads channels [in_coff, in_coff+c_in)) -> [B,Do,Ho,Wo,c_out] (or writes the
-    channel slice [out_coff, out_coff+c_out) of ``out``)."""
+           out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """x [B,D,H,W,Cs] in the layer's 16-bit format (reads channels [in_coff, in_coff+c_in)) ->
+    [B,Do,Ho,Wo,c_out] in the same format or fp32 (or writes the channel slice [out_coff, out_coff+c_out)
+    of ``out``)."""
     _dev(x, skip, out, layer.packed)
-    if x.dtype != torch.bfloat16 or x.dim() != 5:
-        raise TypeError("pscv.conv3d: input must be a bf16 [B,D,H,W,C] volume")
+    if x.dtype != layer.dtype or x.dim() != 5:
+        raise TypeError(f"pscv.conv3d: input must be a {layer.dtype} [B,D,H,W,C] volume, got {x.dtype} {tuple(x.shape)}")
+    out_dtype = layer.dtype if out_dtype is None else out_dtype
     B, D, H, W, cs = x.shape
     Do, Ho, Wo = conv_out_shape(layer.kind, D, H, W)
     if out is None:
         out = torch.empty((B, Do, Ho, Wo, layer.c_out), dtype=out_dtype, device=x.device)
     if tuple(out.shape[:4]) != (B, Do, Ho, Wo):
         raise ValueError(f"pscv.conv3d: out has shape {tuple(out.shape)}, expected [B,{Do},{Ho},{Wo},*]")
-    if skip is not None and (skip.dtype != torch.bfloat16 or tuple(skip.shape[:4]) != (B, Do, Ho, Wo)):
-        raise ValueError("pscv.conv3d: skip must be bf16 with the output's spatial shape")
+    if skip is not None and (skip.dtype != layer.dtype or tuple(skip.shape[:4]) != (B, Do, Ho, Wo)):
+        raise ValueError("pscv.conv3d: skip must have the layer's dtype and the output's spatial shape")
     rc = _launch(f"conv3d[{layer.c_in}->{layer.c_out},k{layer.kind}]", lambda: L.lib().pscv_conv3d(
-        _p(x), cs, in_coff, _p(layer.packed), _p(layer.scale), _p(layer.bias), _p(layer.floor), _p(skip),
+        _p(x), _dt(x), cs, in_coff, _p(layer.packed), _p(layer.scale), _p(layer.bias), _p(layer.floor), _p(skip),
         0 if skip is None else skip.shape[4], skip_coff, _p(out), out.shape[4], out_coff, _dt(out), B, D, H, W,
         layer.c_in, layer.c_out, layer.kind, layer.epi, _stream()))
     L.check(rc, "pscv_conv3d")
