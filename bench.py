@@ -16,6 +16,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -121,6 +122,10 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+        # no cyclic-GC pause inside the timed region (a gen-2 collection with torch loaded costs ~40 ms and
+        # would be billed to whichever kernel it happens to precede)
+        gc.collect()
+        gc.disable()
         with ops.EventTimer() as tm:
             t0 = time.perf_counter()
             for _ in range(args.steps):
@@ -130,6 +135,7 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
             elapsed = time.perf_counter() - t0
+        gc.enable()
         kern = {k: v for k, v in tm.summary().items() if k != "proj_cams"}
         if args.dump_events and rank == 0:
             with open(args.dump_events, "w") as f:

@@ -138,3 +138,31 @@ def test_conv3d_linearity_at_full_size(env):
         ref = ref[:, :, od:od + 7, oh:oh + 7, ow:ow + 7]
         got = ya[:, d0:d0 + 7, h0:h0 + 7, w0:w0 + 7].permute(0, 4, 1, 2, 3).cpu()
         check_close(f"full-size conv crop @({d0},{h0},{w0})", got, ref, max_abs=2e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(16, 16, 32), (13, 11, 21), (2, 8, 16), (37, 9, 40)])
+def test_sweep_kernel_matches_brick_kernel_and_aten(env, shape, dtype):
+    """The depth-sweep 32->8 kernel (PSCV_CONV_S1P8) against the generic brick kernel and ATen, on sizes that are
+    not multiples of the 8x16 tile / the depth chunk, odd D, with BN + ReLU + skip."""
+    L, ops = env
+    g = torch.Generator().manual_seed(sum(shape))
+    D, H, W = shape
+    x = bf16_round(torch.randn(2, 32, D, H, W, generator=g))
+    w = bf16_round(torch.randn(8, 32, 3, 3, 3, generator=g) / np.sqrt(27 * 32))
+    gamma, beta = torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g) * 0.3
+    mean, var = torch.randn(8, generator=g) * 0.2, torch.rand(8, generator=g) + 0.5
+    skip = bf16_round(torch.randn(2, 8, D, H, W, generator=g))
+    ref = F.relu(F.batch_norm(F.conv3d(x, w, padding=1), mean, var, gamma, beta, training=False, eps=1e-5)) + skip
+    xcl, scl = ops.to_channels_last(x.cuda(), dtype), ops.to_channels_last(skip.cuda(), dtype)
+    outs = {}
+    for use in (True, False):
+        ops.USE_SWEEP_KERNEL = use
+        try:
+            layer = ops.Conv3dLayer.build(w, kind=L.CONV_S1, device="cuda", bn=(gamma, beta, mean, var), relu=True, dtype=dtype)
+        finally:
+            ops.USE_SWEEP_KERNEL = True
+        assert layer.kind == (L.CONV_S1P8 if use else L.CONV_S1)
+        outs[use] = ops.conv3d(xcl, layer, skip=scl, out_dtype=torch.float32).permute(0, 4, 1, 2, 3).cpu()
+    check_close(f"sweep vs ATen {shape} {dtype}", outs[True], ref, max_abs=3e-3, rel_l2=2e-4)
+    check_close(f"sweep vs brick {shape} {dtype}", outs[True], outs[False], max_abs=1e-4)

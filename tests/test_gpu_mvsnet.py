@@ -73,7 +73,14 @@ def test_forward_depth_parity_with_reference(env, fname, agg, dtype):
     ref = t(g["depth"])
     s = check_close(f"{fname} depth ({dtype})", out["depth"].cpu(), ref)
     assert s["rel_l1"] <= DEPTH_TOL[dtype], s
-    check_close(f"{fname} confidence ({dtype})", out["photometric_confidence"].cpu(), t(g["photometric_confidence"]), max_abs=0.05)
+    # the confidence window is anchored at trunc(E[index]) (model.py:213), so it jumps where E[index] crosses an
+    # integer: compare in the mean, and point-wise only away from those crossings
+    conf, conf_ref = out["photometric_confidence"].cpu(), t(g["photometric_confidence"])
+    check_close(f"{fname} confidence ({dtype})", conf, conf_ref, rel_l1=2e-2)
+    prob = torch.softmax(t(g["logits"]).squeeze(1), 1)
+    eidx = (prob * torch.arange(D, dtype=torch.float32).view(1, D, 1, 1)).sum(1)
+    stable = (eidx - eidx.round()).abs() > 0.05
+    assert float((conf - conf_ref)[stable].abs().max()) <= 0.05
     # the reference's own evaluation quantity: error in units of (max-min)/128 (depthmap_eval.py:133-143)
     unit = (float(scene["depth_max"][0, 0]) - float(scene["depth_min"][0, 0])) / 128
     epe = float((out["depth"].cpu() - ref).abs().mean()) / unit

@@ -136,6 +136,34 @@ def test_packed_weights_contract_like_the_kernel(cin, cout, kind, transposed, dt
     np.testing.assert_allclose(got, ref, atol=2e-4 * np.abs(ref).max(), rtol=0)
 
 
+def test_sweep_pair_packing_contracts_like_the_kernel():
+    """PSCV_CONV_S1P8 layout: rows 0-7 of the MFMA tile = output plane d, rows 8-15 = plane d+1; four input
+    planes d-1..d+2 x nine (kh,kw) taps.  numpy emulation of conv3d_sweep.hip's contraction vs ATen."""
+    rng = np.random.default_rng(5)
+    cin, cout = 32, 8
+    w = _bf16(rng.standard_normal((cout, cin, 3, 3, 3)).astype(np.float32))
+    D, H, W = 5, 3, 4                              # odd D: the last pair's second plane is discarded
+    x = _bf16(rng.standard_normal((D, H, W, cin)).astype(np.float32))
+    packed = ops.pack_conv3d_weights(torch.from_numpy(w), L.CONV_S1P8, False, torch.float16)
+    wk = packed.view(np.float16).astype(np.float32).reshape(4, 9, 64, 8)     # [p_rel][tap][lane][j]
+    out = np.zeros((D + 1, H, W, cout), np.float32)
+    for d in range(0, D, 2):
+        for h in range(H):
+            for x_ in range(W):
+                for p in range(4):
+                    for t_ in range(9):
+                        kh, kw = t_ // 3, t_ % 3
+                        pd, ph, pw = d - 1 + p, h + kh - 1, x_ + kw - 1
+                        if not (0 <= pd < D and 0 <= ph < H and 0 <= pw < W):
+                            continue
+                        for g in range(4):
+                            xv = x[pd, ph, pw, g * 8:g * 8 + 8]
+                            for m in range(16):
+                                out[d + (m >> 3), h, x_, m & 7] += wk[p, t_, m + 16 * g] @ xv
+    ref = F.conv3d(torch.from_numpy(x).permute(3, 0, 1, 2).unsqueeze(0), torch.from_numpy(w), padding=1)[0]
+    np.testing.assert_allclose(out[:D], ref.permute(1, 2, 3, 0).numpy(), atol=2e-4 * float(ref.abs().max()), rtol=0)
+
+
 def test_fp16_packing_rounds_like_torch_and_saturates():
     """The host fp32->fp16 conversion used for the packed weights: round-to-nearest-even like torch's
     .to(float16), subnormals included, but SATURATING at +-65504 instead of overflowing to inf."""

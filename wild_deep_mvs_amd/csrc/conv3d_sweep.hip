@@ -1,0 +1,266 @@
+// Depth-sweep 3x3x3 convolution for the full-resolution 32 -> 8 layer (MVSNet CostRegNet.conv0: 68 % of the
+// regulariser's FLOPs and the only reader of the 32-channel cost volume).  gfx950, wave64.
+//
+// Design (vs the generic brick kernel in conv3d.hip):
+//   * A workgroup owns an 8 x 16 pixel tile and sweeps a run of depth planes.  Input planes live in a 6-slot
+//     LDS ring; every input plane is fetched once per sweep (2-D halo only), two new planes per iteration,
+//     prefetched into registers while the MFMAs of the current iteration run (issue early / write late).
+//   * Plane-pair packing: C_out = 8 fills only half of the 16 MFMA rows, so rows 0-7 compute output plane d
+//     and rows 8-15 output plane d+1.  An input plane p feeds plane d with kernel slice kd = p-d+1 and plane
+//     d+1 with kd = p-d, so 4 input planes x 9 (kh,kw) taps = 36 MFMAs produce TWO output planes
+//     (18 per plane instead of 27), and all 64 lanes end with a useful 8-byte store.
+//   * All 36 A fragments (144 VGPRs) stay in registers for the whole sweep: no weight traffic in the loop.
+//   * LDS voxels are 64 B (32 ch x 16 bit) with the XOR swizzle chunk ^= ((voxel >> 2) & 1) << 1, which makes
+//     every ds_read_b128 B-fragment read conflict-free for any tap offset (brute-forced over the gfx950
+//     lane-group model; unswizzled or +16 B padded rows are 2-way).
+//
+// Replaces (fdarmon/wild_deep_mvs): CostRegNet.conv0 = ConvBnReLU3D(32, 8) models/MVSNet/model.py:46,75
+// (block definition models/MVSNet/module.py:41-48).
+#include "pscv_common.h"
+
+namespace pscv {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 sw_bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 sw_f16x8;
+typedef __attribute__((ext_vector_type(4))) float sw_f32x4;
+
+template <typename H> struct SwMfma;
+template <> struct SwMfma<bf16_t> {
+    __device__ static __forceinline__ sw_f32x4 run(const uint4& a, const uint4& b, const sw_f32x4& c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sw_bf16x8, a), __builtin_bit_cast(sw_bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct SwMfma<f16_t> {
+    __device__ static __forceinline__ sw_f32x4 run(const uint4& a, const uint4& b, const sw_f32x4& c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(sw_f16x8, a), __builtin_bit_cast(sw_f16x8, b), c, 0, 0, 0);
+    }
+};
+
+struct SweepArgs {
+    const uint16_t* in;
+    const uint16_t* wpk;     // [4 p_rel][9 taps][64 lanes][8]
+    const float* scale;
+    const float* bias;
+    const float* floor;
+    const uint16_t* skip;
+    void* out;
+    int in_cs, in_co, skip_cs, skip_co, out_cs, out_co;
+    int out_f32;
+    int B, D, Hh, W;
+    int epi;
+    int nth, ntw, ndc, dc;   // tiles along h, w; depth chunks and planes per chunk (even)
+};
+
+constexpr int SW_TH = 8, SW_BH = SW_TH + 2, SW_BW = 18;
+constexpr int SW_PV = 184;                 // voxels per plane slot (180 used; multiple of 8 keeps the swizzle slot-invariant)
+constexpr int SW_VB = 64;                  // bytes per voxel (32 ch x 2 B)
+constexpr int SW_PB = SW_PV * SW_VB;       // bytes per plane slot
+constexpr int SW_NSLOT = 6;
+constexpr int SW_LDS = SW_NSLOT * SW_PB;   // 70656 B -> two workgroups per CU
+constexpr int SW_CHUNKS = SW_BH * SW_BW * 4;   // 16-byte chunks per plane (720)
+
+__device__ __forceinline__ int sw_lds_off(int v, int chunk) {   // v = in-plane voxel index
+    return v * SW_VB + ((chunk ^ (((v >> 2) & 1) << 1)) << 4);
+}
+
+template <typename H>
+__global__ __launch_bounds__(256, 2) void conv3d_sweep8_kernel(const SweepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int R = SW_TH / 4;   // rows (M-tiles) per wave
+
+    // ---- work decode (XCD-aware: each XCD gets a contiguous run of (tile, depth-chunk) ids) ----
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, slot_ = bid >> 3, q = nwg >> 3, r_ = nwg & 7;
+    int wg = (xcd < r_ ? xcd * (q + 1) : r_ * (q + 1) + (xcd - r_) * q) + slot_;
+    const int dci = wg % a.ndc; wg /= a.ndc;
+    const int twi = wg % a.ntw; wg /= a.ntw;
+    const int thi = wg % a.nth; wg /= a.nth;
+    const int b = wg;
+    const int h0 = thi * SW_TH, w0 = twi * 16;
+    const int dbeg = dci * a.dc, dend = min(a.D, dbeg + a.dc);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+
+    // ---- A fragments: all weights of the layer, resident for the whole sweep ----
+    uint4 wf[4][9];
+    {
+        const uint4* wp = reinterpret_cast<const uint4*>(a.wpk);
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) wf[p][t] = wp[(p * 9 + t) * 64 + lane];
+    }
+
+    // ---- per-lane B-fragment offsets inside a plane slot: rows row0 .. row0+R+1, kw 0..2 ----
+    const int row0 = wave * R;
+    int boff[R + 2][3];
+#pragma unroll
+    for (int rr = 0; rr < R + 2; ++rr)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) boff[rr][kw] = sw_lds_off((row0 + rr) * SW_BW + n + kw, g);
+
+    // ---- staging descriptors: 3 chunks per thread per plane ----
+    int goff[3], loff[3];
+    bool gval[3], lval[3];
+    const long plane_stride = (long)a.Hh * a.W * a.in_cs;
+    const uint16_t* inb = a.in + (long)b * a.D * plane_stride + a.in_co;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int id = tid + 256 * i;
+        const int v = id >> 2, c = id & 3;
+        const int bh = v / SW_BW, bw = v - bh * SW_BW;
+        const int gh = h0 - 1 + bh, gw = w0 - 1 + bw;
+        lval[i] = id < SW_CHUNKS;
+        gval[i] = lval[i] && (unsigned)gh < (unsigned)a.Hh && (unsigned)gw < (unsigned)a.W;
+        goff[i] = gval[i] ? (gh * a.W + gw) * a.in_cs + c * 8 : 0;
+        loff[i] = sw_lds_off(v, c);
+    }
+    const int plane_hi = min(a.D - 1, dend);   // last input plane this sweep can use
+    auto fetch = [&](int plane, uint4 (&reg)[3]) {
+        const bool pv = plane >= 0 && plane <= plane_hi;
+        const uint16_t* pp = inb + (long)(pv ? plane : 0) * plane_stride;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            reg[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (gval[i] && pv) reg[i] = *reinterpret_cast<const uint4*>(pp + goff[i]);
+        }
+    };
+    auto stash = [&](int ring, const uint4 (&reg)[3]) {
+        unsigned char* sp = smem + ring * SW_PB;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (lval[i]) *reinterpret_cast<uint4*>(sp + loff[i]) = reg[i];
+    };
+
+    // ---- epilogue constants: this lane always owns channels (g&1)*4 .. +3 of plane d + (g>>1) ----
+    const int c0 = (g & 1) * 4;
+    float sc[4], bi[4], fl[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        sc[k] = a.scale ? a.scale[c0 + k] : 1.0f;
+        bi[k] = a.bias ? a.bias[c0 + k] : 0.0f;
+        fl[k] = a.floor ? a.floor[c0 + k] : 0.0f;
+    }
+
+    // ---- prologue: planes dbeg-1 .. dbeg+2 into ring slots 0..3 ----
+    {
+        uint4 ra[3], rb[3];
+        fetch(dbeg - 1, ra); fetch(dbeg, rb);
+        stash(0, ra); stash(1, rb);
+        fetch(dbeg + 1, ra); fetch(dbeg + 2, rb);
+        stash(2, ra); stash(3, rb);
+    }
+    __syncthreads();
+
+    int ring = 0;   // slot holding plane d-1
+    for (int d = dbeg; d < dend; d += 2) {
+        // issue the next two planes (d+3, d+4) early; they land in LDS after this iteration's MFMAs
+        uint4 na[3], nb[3];
+        fetch(d + 3, na);
+        fetch(d + 4, nb);
+
+        sw_f32x4 acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = sw_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            int sl = ring + p;
+            sl = sl >= SW_NSLOT ? sl - SW_NSLOT : sl;
+            const unsigned char* sp = smem + sl * SW_PB;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const uint4 xf = *reinterpret_cast<const uint4*>(sp + boff[r + kh][kw]);
+                        acc[r] = SwMfma<H>::run(wf[p][kh * 3 + kw], xf, acc[r]);
+                    }
+        }
+
+        // epilogue: rows g*4.. of D = channels c0.. of plane d + (g >> 1)
+        const int od = d + (g >> 1);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int oh = h0 + row0 + r, ow = w0 + n;
+            if (od < dend && oh < a.Hh && ow < a.W) {
+                const long vox = (((long)b * a.D + od) * a.Hh + oh) * a.W + ow;
+                float y[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    y[k] = fmaf(acc[r][k], sc[k], bi[k]);
+                    if (a.epi & PSCV_EPI_RELU_PRE) y[k] = fmaxf(y[k], fl[k]);
+                }
+                if (a.skip) {
+                    const uint2 sv = *reinterpret_cast<const uint2*>(a.skip + vox * a.skip_cs + a.skip_co + c0);
+                    y[0] += Half16<H>::lo(sv.x); y[1] += Half16<H>::hi(sv.x);
+                    y[2] += Half16<H>::lo(sv.y); y[3] += Half16<H>::hi(sv.y);
+                }
+                if (a.epi & PSCV_EPI_RELU_POST) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) y[k] = fmaxf(y[k], 0.0f);
+                }
+                if (a.out_f32) {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + vox * a.out_cs + a.out_co + c0) =
+                        make_float4(y[0], y[1], y[2], y[3]);
+                } else {
+                    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.out) + vox * a.out_cs + a.out_co + c0) =
+                        make_uint2(Half16<H>::pack(y[0], y[1]), Half16<H>::pack(y[2], y[3]));
+                }
+            }
+        }
+
+        // planes d+3, d+4 replace d-3, d-2 (last read one iteration ago, fenced by that iteration's barrier)
+        int s4 = ring + 4, s5 = ring + 5;
+        s4 = s4 >= SW_NSLOT ? s4 - SW_NSLOT : s4;
+        s5 = s5 >= SW_NSLOT ? s5 - SW_NSLOT : s5;
+        stash(s4, na);
+        stash(s5, nb);
+        ring += 2;
+        ring = ring >= SW_NSLOT ? ring - SW_NSLOT : ring;
+        __syncthreads();
+    }
+}
+
+}  // namespace pscv
+
+// entry used by pscv_conv3d (conv3d.hip) for kind == PSCV_CONV_S1P8
+int pscv_conv3d_sweep8_launch(const void* in, int dtype, int in_cstride, int in_coff, const uint16_t* packed,
+                              const float* scale, const float* bias, const float* floor, const void* skip,
+                              int skip_cstride, int skip_coff, void* out, int out_cstride, int out_coff, int out_dtype,
+                              int B, int D, int Hh, int W, int epi_flags, hipStream_t st) {
+    using namespace pscv;
+    SweepArgs a;
+    a.in = reinterpret_cast<const uint16_t*>(in);
+    a.wpk = packed; a.scale = scale; a.bias = bias; a.floor = floor;
+    a.skip = reinterpret_cast<const uint16_t*>(skip);
+    a.out = out;
+    a.in_cs = in_cstride; a.in_co = in_coff; a.skip_cs = skip_cstride; a.skip_co = skip_coff;
+    a.out_cs = out_cstride; a.out_co = out_coff; a.out_f32 = out_dtype == PSCV_F32;
+    a.B = B; a.D = D; a.Hh = Hh; a.W = W; a.epi = epi_flags;
+    a.nth = (Hh + SW_TH - 1) / SW_TH;
+    a.ntw = (W + 15) / 16;
+    // depth chunk: even, and such that the grid is a few resident waves of 512 workgroups (2 per CU)
+    const long tiles = (long)B * a.nth * a.ntw;
+    int dc = 12;
+    while (dc < D && tiles * ((D + dc - 1) / dc) > 4096) dc += 2;
+    while (dc > 4 && tiles * ((D + dc - 1) / dc) < 1024) dc -= 2;
+    dc = dc > D ? ((D + 1) & ~1) : dc;
+    a.dc = dc;
+    a.ndc = (D + dc - 1) / dc;
+    const long nblk = tiles * a.ndc;
+    if (nblk <= 0 || nblk > 0x7fffffffL) { set_error("pscv_conv3d(sweep): bad grid %ld", nblk); return -1; }
+    static bool attr_done[2] = {false, false};
+    const int ti = dtype == PSCV_BF16 ? 0 : 1;
+    const void* kern = ti == 0 ? reinterpret_cast<const void*>(conv3d_sweep8_kernel<bf16_t>)
+                               : reinterpret_cast<const void*>(conv3d_sweep8_kernel<f16_t>);
+    if (!attr_done[ti]) {
+        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS);
+        if (e != hipSuccess) { set_error("pscv_conv3d(sweep): hipFuncSetAttribute: %s", hipGetErrorString(e)); return -2; }
+        attr_done[ti] = true;
+    }
+    if (ti == 0) hipLaunchKernelGGL(conv3d_sweep8_kernel<bf16_t>, dim3((unsigned)nblk), dim3(256), SW_LDS, st, a);
+    else hipLaunchKernelGGL(conv3d_sweep8_kernel<f16_t>, dim3((unsigned)nblk), dim3(256), SW_LDS, st, a);
+    return 0;
+}

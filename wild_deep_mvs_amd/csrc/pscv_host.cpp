@@ -35,10 +35,30 @@ extern "C" long pscv_pack_conv3d_weights(const float* w, int c_in, int c_out, in
                                          uint16_t* packed) {
     using namespace pscv;
     PSCV_CHECK_ARG(c_in > 0 && c_in % 8 == 0 && c_out > 0, "pscv_pack_conv3d_weights: bad channels %d -> %d", c_in, c_out);
-    PSCV_CHECK_ARG(kind == PSCV_CONV_S1 || kind == PSCV_CONV_S2 || kind == PSCV_CONV_T2, "pscv_pack_conv3d_weights: kind %d", kind);
+    PSCV_CHECK_ARG(kind == PSCV_CONV_S1 || kind == PSCV_CONV_S2 || kind == PSCV_CONV_T2 || kind == PSCV_CONV_S1P8,
+                   "pscv_pack_conv3d_weights: kind %d", kind);
     PSCV_CHECK_ARG(kind != PSCV_CONV_T2 || transposed, "pscv_pack_conv3d_weights: T2 needs a ConvTranspose3d weight");
     PSCV_CHECK_ARG(kind != PSCV_CONV_S2 || !transposed, "pscv_pack_conv3d_weights: S2 takes a Conv3d weight");
     PSCV_CHECK_ARG(dtype == PSCV_BF16 || dtype == PSCV_F16, "pscv_pack_conv3d_weights: dtype %d must be bf16 or fp16", dtype);
+    if (kind == PSCV_CONV_S1P8) {
+        // Depth-sweep layout [p_rel 0..3][tap (kh,kw) 0..8][lane][8]: rows 0-7 hold kernel slice kd = p_rel for
+        // output plane d, rows 8-15 hold kd = p_rel - 1 for output plane d+1 (zero where kd falls outside 0..2).
+        PSCV_CHECK_ARG(c_in == 32 && c_out == 8 && !transposed, "pscv_pack_conv3d_weights: S1P8 is Conv3d 32 -> 8 only");
+        const long n = 4L * 9 * 64 * 8;
+        if (!packed) return n;
+        PSCV_CHECK_ARG(w, "pscv_pack_conv3d_weights: null weight pointer");
+        for (int p = 0; p < 4; ++p)
+            for (int t = 0; t < 9; ++t)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int m = lane & 15, ci = (lane >> 4) * 8 + j;
+                        const int co = m & 7, kd = m < 8 ? p : p - 1;
+                        float v = 0.f;
+                        if (kd >= 0 && kd <= 2) v = w[((long)co * c_in + ci) * 27 + kd * 9 + t];
+                        packed[(((long)p * 9 + t) * 64 + lane) * 8 + j] = dtype == PSCV_BF16 ? f32_to_bf16(v) : f32_to_f16_bits(v);
+                    }
+        return n;
+    }
     const int nt = ceil_div(c_out, 16);
     int total_steps = 0;
     if (kind == PSCV_CONV_T2) {

@@ -249,6 +249,8 @@ class Conv3dLayer:
         epilogue: scale = gamma / sqrt(var + eps), bias = beta - mean * scale (+ scale * conv_bias)."""
         device = device if device is not None else weight.device
         c_in, c_out = (weight.shape[0], weight.shape[1]) if transposed else (weight.shape[1], weight.shape[0])
+        if kind == L.CONV_S1 and not transposed and c_in == 32 and c_out == 8 and USE_SWEEP_KERNEL:
+            kind = L.CONV_S1P8     # same result, depth-sweep kernel with plane-pair packed MFMA rows
         packed = torch.from_numpy(pack_conv3d_weights(weight, kind, transposed, dtype).view(np.int16)).to(device)
         scale = bias = None
         if bn is not None:
@@ -266,8 +268,11 @@ class Conv3dLayer:
         return Conv3dLayer(packed, dtype, int(c_in), int(c_out), kind, epi, scale, bias, floor)
 
 
+USE_SWEEP_KERNEL = True   # tests flip this to compare the two stride-1 kernels
+
+
 def conv_out_shape(kind: int, D: int, H: int, W: int):
-    if kind == L.CONV_S1:
+    if kind in (L.CONV_S1, L.CONV_S1P8):
         return D, H, W
     if kind == L.CONV_S2:
         return (D + 1) // 2, (H + 1) // 2, (W + 1) // 2
