@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--dtype", choices=sorted(DTYPES), default="f16",
                     help="16-bit HBM storage format (arithmetic is fp32); f16 is the engine default, see DESIGN.md section 5")
     ap.add_argument("--dump-events", default=None, help="write every per-launch event duration to this file")
+    ap.add_argument("--eager", action="store_true", help="time eager launches instead of hipGraph replays")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -116,25 +117,40 @@ def main():
         return net.hot_path(feats_cl, proj_d, dv_d)
 
     with torch.no_grad():
-        for _ in range(args.warmup):
+        for _ in range(max(args.warmup, 1)):
             depth, conf = step()
+        torch.cuda.synchronize()
+        graph = None
+        if not args.eager:
+            # the 15-launch step is launch-gap bound between its small kernels: capture it once, replay it
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                depth, conf = step()
+            for _ in range(2):
+                graph.replay()
+            torch.cuda.synchronize()
+        run = graph.replay if graph is not None else step
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        # no cyclic-GC pause inside a timed region (a gen-2 collection with torch loaded costs ~40 ms)
+        gc.collect()
+        gc.disable()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-        # no cyclic-GC pause inside the timed region (a gen-2 collection with torch loaded costs ~40 ms and
-        # would be billed to whichever kernel it happens to precede)
-        gc.collect()
-        gc.disable()
+        elapsed = time.perf_counter() - t0
+        # per-kernel durations: the same K steps launched eagerly with a HIP event pair around every launch
         with ops.EventTimer() as tm:
-            t0 = time.perf_counter()
+            t1 = time.perf_counter()
             for _ in range(args.steps):
                 depth, conf = step()
             torch.cuda.synchronize()
-            if dist is not None:
-                dist.barrier()
-            torch.cuda.synchronize()
-            elapsed = time.perf_counter() - t0
+            elapsed_eager = time.perf_counter() - t1
         gc.enable()
         kern = {k: v for k, v in tm.summary().items() if k != "proj_cams"}
         if args.dump_events and rank == 0:
@@ -164,6 +180,9 @@ def main():
             "config": {"workload": "MVSNet variance, 1 ref + 4 src views, 512x640 images (128x160x32 features), D=192, "
                                    "features resident in HBM -> depth + confidence", "global_batch": world,
                        "voxels_per_step_per_gpu": VOX, "parallelism": f"reference-view shard x{world}, no collective"},
+            "timing": ("hipGraph replay of the step" if graph is not None else "eager launches") +
+                      f"; per-kernel HIP events from an eager pass of the same {args.steps} steps "
+                      f"({elapsed_eager / args.steps * 1e3:.3f} ms/step eager)",
             "roofline": roof,
             "kernels_us": {k: round(ms / n * 1e3, 2) for k, (n, ms) in sorted(kern.items(), key=lambda kv: -kv[1][1])},
         }

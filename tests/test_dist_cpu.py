@@ -1,0 +1,88 @@
+"""World-size-2 gloo tests (CPU) of the multi-GPU sharding rules in wild_deep_mvs_amd/dist.py."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from wild_deep_mvs_amd import dist as pdist
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _partials(logits, depth, index_offset):
+    """torch restatement of pscv_softargmin's out_partials for one depth shard: [B,4,h,w]."""
+    m = logits.max(dim=1).values
+    e = torch.exp(logits - m.unsqueeze(1))
+    idx = torch.arange(logits.shape[1], dtype=torch.float32).view(1, -1, 1, 1) + index_offset
+    return torch.stack([m, e.sum(1), (e * depth.view(1, -1, 1, 1)).sum(1), (e * idx).sum(1)], dim=1)
+
+
+def _worker(rank, world, port, D, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(0)             # same full problem on every rank
+        logits = torch.randn(2, D, 6, 7, generator=g) * 4
+        depth = torch.linspace(2.0, 6.0, D)
+        d0, d1 = pdist.plane_shard(D, world, rank, multiple=8)
+        part = _partials(logits[:, d0:d1], depth[d0:d1], d0)
+        got_depth, got_index = pdist.merge_partials(part)
+        p = torch.softmax(logits, 1)
+        want_depth = (p * depth.view(1, -1, 1, 1)).sum(1)
+        want_index = (p * torch.arange(D, dtype=torch.float32).view(1, -1, 1, 1)).sum(1)
+        out_q.put((rank, float((got_depth - want_depth).abs().max()), float((got_index - want_index).abs().max()),
+                   (d0, d1), pdist.view_shard(5, world, rank)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_depth_plane_shard_lse_merge_world2():
+    world, D = 2, 48
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, D, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=100) for _ in range(world))
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert [r[3] for r in res] == [(0, 24), (24, 48)]
+    assert [r[4] for r in res] == [[0, 2, 4], [1, 3]]
+    for _, ed, ei, _, _ in res:
+        assert ed < 1e-5 and ei < 1e-4
+
+
+def test_plane_shard_covers_range_with_aligned_boundaries():
+    for D, world, mult in [(192, 8, 8), (192, 5, 8), (48, 4, 8), (64, 3, 2), (8, 8, 8)]:
+        spans = [pdist.plane_shard(D, world, r, mult) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == D
+        for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+            assert a1 == b0
+        assert all(a % mult == 0 and b % mult == 0 and b >= a for a, b in spans)
+    with pytest.raises(ValueError):
+        pdist.plane_shard(50, 2, 0, 8)
+
+
+def test_merge_is_exact_for_unequal_maxima():
+    torch.manual_seed(1)
+    logits = torch.randn(1, 32, 3, 3) * 10
+    logits[:, 20:] += 50.0                                # second shard dominates by e^50
+    depth = torch.linspace(1.0, 2.0, 32)
+    parts = [_partials(logits[:, :16], depth[:16], 0), _partials(logits[:, 16:], depth[16:], 16)]
+    d, i = pdist.merge_partials_local(parts)
+    p = torch.softmax(logits, 1)
+    np.testing.assert_allclose(d.numpy(), (p * depth.view(1, -1, 1, 1)).sum(1).numpy(), atol=1e-6)

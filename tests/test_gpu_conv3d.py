@@ -30,10 +30,14 @@ MVSNET_LAYERS = [(32, 8, 0), (8, 16, 1), (16, 16, 0), (16, 32, 1), (32, 32, 0), 
                  (64, 32, 2), (32, 16, 2), (16, 8, 2), (8, 1, 0)]
 
 
+@pytest.mark.parametrize("small_tiles", [1, 0])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("cin,cout,kind", MVSNET_LAYERS)
-def test_conv3d_plain(env, cin, cout, kind, dtype):
+def test_conv3d_plain(env, cin, cout, kind, dtype, small_tiles):
+    """small_tiles=1: 1x4x16 tiles with the output channels split over blockIdx.y (what small volumes get);
+    small_tiles=0: the large-tile variant (what the full-resolution layers get)."""
     L, ops = env
+    L.set_tuning("conv_small_tiles", small_tiles)
     g = torch.Generator().manual_seed(cin * 1000 + cout * 10 + kind)
     D, H, W = (6, 10, 21) if kind == L.CONV_S1 else (7, 9, 35) if kind == L.CONV_S2 else (3, 5, 19)
     B = 2
@@ -42,7 +46,10 @@ def test_conv3d_plain(env, cin, cout, kind, dtype):
     wshape = (cin, cout, 3, 3, 3) if transposed else (cout, cin, 3, 3, 3)
     w = bf16_round(torch.randn(wshape, generator=g) / np.sqrt(27 * cin))
     layer = ops.Conv3dLayer.build(w, kind=kind, transposed=transposed, device="cuda", dtype=dtype)
-    y = ops.conv3d(ops.to_channels_last(x.cuda(), dtype), layer, out_dtype=torch.float32)   # bf16-exact values are fp16-exact
+    try:
+        y = ops.conv3d(ops.to_channels_last(x.cuda(), dtype), layer, out_dtype=torch.float32)   # bf16-exact values are fp16-exact
+    finally:
+        L.set_tuning("conv_small_tiles", 1)
     ref = _ref_conv(x, w, kind, transposed, L)
     check_close(f"conv3d {cin}->{cout} kind {kind} {dtype} operands, fp32 out", y.permute(0, 4, 1, 2, 3).cpu(), ref, max_abs=2e-3, rel_l2=1e-4)
 

@@ -37,6 +37,8 @@ template <> struct Mfma<f16_t> {
     }
 };
 
+int g_conv_small_tiles = 1;   // pscv_set_tuning("conv_small_tiles", 0) forces the large-tile variant
+
 struct ConvArgs {
     const uint16_t* in;
     const uint16_t* wpk;
@@ -50,6 +52,7 @@ struct ConvArgs {
     int B, Di, Hi, Wi, Do, Ho, Wo;
     int cout, epi;
     int ntd, nth, ntw;   // tile counts along d, h, w
+    int nt_total;        // 16-channel output tiles of the layer (blockIdx.y picks this block's first tile)
 };
 
 // ---- compile-time geometry ----------------------------------------------------------------------
@@ -70,6 +73,12 @@ __host__ __device__ constexpr int t2_stepbase(int pc, int cin) {
 __host__ __device__ constexpr int conv_total_steps(int kind, int cin) {
     return kind == PSCV_CONV_T2 ? t2_stepbase(8, cin) : ceil_div(27 * cin, 32);
 }
+
+// LDS bytes per voxel: channels + padding.  For C_in = 32 a 96-byte stride makes the 16-lane groups of
+// ds_read_b128 hit 16 distinct 16-byte slots for every tap offset (brute-forced on the gfx950 lane-group model;
+// 64 / 80 / 112 are 2-way); the other widths keep one 16-byte pad.
+__host__ __device__ constexpr int conv_vs(int cin) { return cin == 32 ? 96 : cin * 2 + 16; }
+__host__ __device__ constexpr int conv_epi_bytes(int nt) { return 3 * nt * 16 * 4; }
 
 // LDS byte offset (relative to the lane's output-voxel anchor) of tap `tap` for the dense kinds
 template <int KIND, int BH, int BW, int VS> __device__ __forceinline__ int tap_off_dense(int tap) {
@@ -92,7 +101,7 @@ template <typename H, int CIN, int NT, int KIND, int TD, int TH>
 __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
     using BR = Brick<KIND, TD, TH>;
     constexpr int BD = BR::BD, BH = BR::BH, BW = BR::BW;
-    constexpr int VS = CIN * 2 + 16;             // LDS bytes per voxel (+16 B pad against bank conflicts)
+    constexpr int VS = conv_vs(CIN);             // LDS bytes per voxel (padded against bank conflicts)
     constexpr int CCH = CIN / 8;                 // 16-byte chunks per voxel
     constexpr int NVOX = BD * BH * BW;
     constexpr int NMT = TD * TH;                 // M-tiles (rows of 16 x-adjacent voxels) per workgroup
@@ -135,6 +144,18 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
             *reinterpret_cast<uint4*>(smem + v * VS + cc * 16) = val;
         }
     }
+    // per-channel epilogue constants of this block's NT output tiles -> LDS (one global read per block)
+    const int nt0 = blockIdx.y * NT;
+    float* epi_sc = reinterpret_cast<float*>(smem + ((NVOX * VS + 15) & ~15));
+    float* epi_bi = epi_sc + NT * 16;
+    float* epi_fl = epi_bi + NT * 16;
+    if (tid < NT * 16) {
+        const int c = nt0 * 16 + tid;
+        const bool cv = c < a.cout;
+        epi_sc[tid] = (a.scale && cv) ? a.scale[c] : 1.0f;
+        epi_bi[tid] = (a.bias && cv) ? a.bias[c] : 0.0f;
+        epi_fl[tid] = (a.floor && cv) ? a.floor[c] : 0.0f;
+    }
     __syncthreads();
 
     const int lane = tid & 63, wave = tid >> 6;
@@ -156,18 +177,15 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
         const long vox = (((long)b * a.Do + od) * a.Ho + oh) * a.Wo + ow;
 #pragma unroll
         for (int m = 0; m < NT; ++m) {
-            const int c0 = m * 16 + g * 4;
+            const int c0 = (nt0 + m) * 16 + g * 4;
             if (c0 >= a.cout) continue;
-            float y[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int c = c0 + k;
-                const bool cv = c < a.cout;
-                const float sc = (a.scale && cv) ? a.scale[c] : 1.0f;
-                const float bi = (a.bias && cv) ? a.bias[c] : 0.0f;
-                float t = fmaf(acc[m][k], sc, bi);
-                if (a.epi & PSCV_EPI_RELU_PRE) t = fmaxf(t, (a.floor && cv) ? a.floor[c] : 0.0f);
-                y[k] = t;
+            const float4 sc = *reinterpret_cast<const float4*>(epi_sc + m * 16 + g * 4);
+            const float4 bi = *reinterpret_cast<const float4*>(epi_bi + m * 16 + g * 4);
+            const float4 fl = *reinterpret_cast<const float4*>(epi_fl + m * 16 + g * 4);
+            float y[4] = {fmaf(acc[m][0], sc.x, bi.x), fmaf(acc[m][1], sc.y, bi.y), fmaf(acc[m][2], sc.z, bi.z),
+                          fmaf(acc[m][3], sc.w, bi.w)};
+            if (a.epi & PSCV_EPI_RELU_PRE) {
+                y[0] = fmaxf(y[0], fl.x); y[1] = fmaxf(y[1], fl.y); y[2] = fmaxf(y[2], fl.z); y[3] = fmaxf(y[3], fl.w);
             }
             if (a.skip) {
                 const uint16_t* sp = a.skip + vox * a.skip_cs + a.skip_co + c0;
@@ -209,7 +227,7 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
             const int koff = tap_off_dense<KIND, BH, BW, VS>(kk0 / CIN) + (kk0 % CIN) * 2;
             uint4 wf[NT];
 #pragma unroll
-            for (int m = 0; m < NT; ++m) wf[m] = wpk[(s * NT + m) * 64 + lane];
+            for (int m = 0; m < NT; ++m) wf[m] = wpk[(s * a.nt_total + nt0 + m) * 64 + lane];
 #pragma unroll
             for (int i = 0; i < MB; ++i) {
                 const uint4 xf = *reinterpret_cast<const uint4*>(smem + anchor[i] + koff);
@@ -239,7 +257,7 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
                     const int koff = tap_off_t2<BH, BW, VS>(pc, kk0 / CIN) + (kk0 % CIN) * 2;
                     uint4 wf[NT];
 #pragma unroll
-                    for (int m = 0; m < NT; ++m) wf[m] = wpk[((sbase + s) * NT + m) * 64 + lane];
+                    for (int m = 0; m < NT; ++m) wf[m] = wpk[((sbase + s) * a.nt_total + nt0 + m) * 64 + lane];
 #pragma unroll
                     for (int i = 0; i < MB; ++i) {
                         const uint4 xf = *reinterpret_cast<const uint4*>(smem + anchor[i] + koff);
@@ -261,10 +279,10 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
 
 // ---- host side ---------------------------------------------------------------------------------
 template <typename H, int CIN, int NT, int KIND, int TD, int TH>
-static int launch_conv(ConvArgs& a, hipStream_t st) {
+static int launch_conv(ConvArgs& a, int n_split, hipStream_t st) {
     using BR = Brick<KIND, TD, TH>;
-    constexpr int VS = CIN * 2 + 16;
-    constexpr int LDS = BR::BD * BR::BH * BR::BW * VS;
+    constexpr int VS = conv_vs(CIN);
+    constexpr int LDS = ((BR::BD * BR::BH * BR::BW * VS + 15) & ~15) + conv_epi_bytes(NT);
     static_assert(LDS <= 160 * 1024, "brick does not fit the 160 KiB LDS");
     const int rd = KIND == PSCV_CONV_T2 ? a.Di : a.Do, rh = KIND == PSCV_CONV_T2 ? a.Hi : a.Ho,
               rw = KIND == PSCV_CONV_T2 ? a.Wi : a.Wo;
@@ -278,16 +296,26 @@ static int launch_conv(ConvArgs& a, hipStream_t st) {
         if (e != hipSuccess) { set_error("pscv_conv3d: hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e)); return -2; }
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), LDS, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_split), dim3(256), LDS, st, a);
     return 0;
 }
 
+// Tile choice.  Large volumes: 4x4x16 (S1), 2x2x16 (S2), 2x4x16 input voxels (T2) with all NT output tiles in one
+// workgroup.  Small volumes (the 1/4 and 1/8 resolution levels: 61 k and 7.7 k voxels at the headline size) would
+// leave most of the 256 CUs idle, so they use 1x4x16 tiles and one 16-channel output tile per workgroup
+// (blockIdx.y splits the output channels): up to 16x more workgroups, each re-reading the L2-resident brick.
 template <typename H, int CIN, int NT>
 static int launch_kind(ConvArgs& a, int kind, hipStream_t st) {
+    a.nt_total = NT;
+    const int rd = kind == PSCV_CONV_T2 ? a.Di : a.Do, rh = kind == PSCV_CONV_T2 ? a.Hi : a.Ho,
+              rw = kind == PSCV_CONV_T2 ? a.Wi : a.Wo;
+    const int TDb = kind == PSCV_CONV_S1 ? 4 : 2, THb = kind == PSCV_CONV_S2 ? 2 : 4;
+    const long big = (long)a.B * ceil_div(rd, TDb) * ceil_div(rh, THb) * ceil_div(rw, 16);
+    const bool small = big < 1024 && g_conv_small_tiles;
     switch (kind) {
-        case PSCV_CONV_S1: return launch_conv<H, CIN, NT, PSCV_CONV_S1, 4, 4>(a, st);
-        case PSCV_CONV_S2: return launch_conv<H, CIN, NT, PSCV_CONV_S2, 2, 2>(a, st);
-        case PSCV_CONV_T2: return launch_conv<H, CIN, NT, PSCV_CONV_T2, 2, 4>(a, st);
+        case PSCV_CONV_S1: return small ? launch_conv<H, CIN, 1, PSCV_CONV_S1, 1, 4>(a, NT, st) : launch_conv<H, CIN, NT, PSCV_CONV_S1, 4, 4>(a, 1, st);
+        case PSCV_CONV_S2: return small ? launch_conv<H, CIN, 1, PSCV_CONV_S2, 1, 4>(a, NT, st) : launch_conv<H, CIN, NT, PSCV_CONV_S2, 2, 2>(a, 1, st);
+        case PSCV_CONV_T2: return small ? launch_conv<H, CIN, 1, PSCV_CONV_T2, 1, 4>(a, NT, st) : launch_conv<H, CIN, NT, PSCV_CONV_T2, 2, 4>(a, 1, st);
     }
     set_error("pscv_conv3d: unknown kind %d", kind);
     return -1;

@@ -262,6 +262,7 @@ __global__ __launch_bounds__(256) void warp_cost_kernel(const WarpArgs a) {
 // ---- host side ---------------------------------------------------------------------------------
 static int g_warp_lpv_override = 0;  // 0 = default heuristic; set through pscv_set_tuning("warp_lpv", n)
 static int g_warp_ppd_override = 0;
+extern int g_conv_small_tiles;   // conv3d.hip
 
 // Instantiated (geometry, cost) pairs: the variance / softmin statistics belong to the PROJ models (MVSNet,
 // CVP), group-wise correlation to the HOMOG model (Vis); the plain warp exists for both.
@@ -333,6 +334,7 @@ extern "C" int pscv_set_tuning(const char* key, int value) {
     PSCV_CHECK_ARG(key, "pscv_set_tuning: null key");
     if (!strcmp(key, "warp_lpv")) { g_warp_lpv_override = value; return 0; }
     if (!strcmp(key, "warp_ppd")) { g_warp_ppd_override = value; return 0; }
+    if (!strcmp(key, "conv_small_tiles")) { g_conv_small_tiles = value; return 0; }
     set_error("pscv_set_tuning: unknown key '%s'", key);
     return -1;
 }
