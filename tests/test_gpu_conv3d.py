@@ -173,3 +173,33 @@ def test_sweep_kernel_matches_brick_kernel_and_aten(env, shape, dtype):
         outs[use] = ops.conv3d(xcl, layer, skip=scl, out_dtype=torch.float32).permute(0, 4, 1, 2, 3).cpu()
     check_close(f"sweep vs ATen {shape} {dtype}", outs[True], ref, max_abs=3e-3, rel_l2=2e-4)
     check_close(f"sweep vs brick {shape} {dtype}", outs[True], outs[False], max_abs=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("cin,shape,out_dtype", [(8, (16, 16, 32), torch.float32), (8, (13, 11, 45), torch.float32),
+                                                 (16, (9, 8, 33), torch.float32), (8, (5, 17, 64), None)])
+def test_one_channel_dot2_kernel_matches_mfma_kernel_and_aten(env, cin, shape, out_dtype, dtype):
+    """The vector-ALU dot2 sweep kernel for the 1-channel heads (PSCV_CONV_S1C1) against the MFMA brick kernel and
+    ATen: bias, sizes off the 8x32 tile and off the depth chunk, fp32 and 16-bit outputs."""
+    L, ops = env
+    g = torch.Generator().manual_seed(cin + sum(shape))
+    D, H, W = shape
+    x = bf16_round(torch.randn(2, cin, D, H, W, generator=g))
+    w = bf16_round(torch.randn(1, cin, 3, 3, 3, generator=g) / np.sqrt(27 * cin))
+    bias = torch.randn(1, generator=g)
+    ref = F.conv3d(x, w, bias, padding=1)
+    xcl = ops.to_channels_last(x.cuda(), dtype)
+    outs = {}
+    for use in (True, False):
+        ops.USE_SWEEP_KERNEL = use
+        try:
+            layer = ops.Conv3dLayer.build(w, kind=L.CONV_S1, device="cuda", conv_bias=bias, dtype=dtype)
+        finally:
+            ops.USE_SWEEP_KERNEL = True
+        assert layer.kind == (L.CONV_S1C1 if use else L.CONV_S1)
+        y = ops.conv3d(xcl, layer, out_dtype=out_dtype)
+        assert y.dtype == (out_dtype or dtype)
+        outs[use] = y.float().permute(0, 4, 1, 2, 3).cpu()
+    tol = 3e-3 if out_dtype is not None else (2 ** -8 if dtype == torch.bfloat16 else 2 ** -11) * float(ref.abs().max()) + 1e-3
+    check_close(f"dot2 kernel vs ATen cin={cin} {shape} {dtype}", outs[True], ref, max_abs=tol)
+    check_close(f"dot2 kernel vs MFMA kernel cin={cin} {shape} {dtype}", outs[True], outs[False], max_abs=tol)

@@ -164,6 +164,16 @@ def test_sweep_pair_packing_contracts_like_the_kernel():
     np.testing.assert_allclose(out[:D], ref.permute(1, 2, 3, 0).numpy(), atol=2e-4 * float(ref.abs().max()), rtol=0)
 
 
+def test_one_channel_packing_layout():
+    """PSCV_CONV_S1C1: [tap = kd*9 + kh*3 + kw][c_in] 16-bit values."""
+    rng = np.random.default_rng(2)
+    for cin in (8, 16):
+        w = _bf16(rng.standard_normal((1, cin, 3, 3, 3)).astype(np.float32))
+        packed = ops.pack_conv3d_weights(torch.from_numpy(w), L.CONV_S1C1, False, torch.float16)
+        got = packed.view(np.float16).astype(np.float32).reshape(27, cin)
+        np.testing.assert_array_equal(got, w[0].reshape(cin, 27).T)
+
+
 def test_fp16_packing_rounds_like_torch_and_saturates():
     """The host fp32->fp16 conversion used for the packed weights: round-to-nearest-even like torch's
     .to(float16), subnormals included, but SATURATING at +-65504 instead of overflowing to inf."""

@@ -341,6 +341,11 @@ int pscv_conv3d_sweep8_launch(const void* in, int dtype, int in_cstride, int in_
                               int skip_cstride, int skip_coff, void* out, int out_cstride, int out_coff, int out_dtype,
                               int B, int D, int Hh, int W, int epi_flags, hipStream_t st);
 
+int pscv_conv3d_c1_launch(const void* in, int dtype, int in_cstride, int in_coff, const uint16_t* packed,
+                          const float* scale, const float* bias, const float* floor, const void* skip,
+                          int skip_cstride, int skip_coff, void* out, int out_cstride, int out_coff, int out_dtype,
+                          int B, int D, int Hh, int W, int c_in, int epi_flags, hipStream_t st);
+
 extern "C" int pscv_conv3d(const void* in, int dtype, int in_cstride, int in_coff, const uint16_t* packed, const float* scale,
                            const float* bias, const float* floor, const void* skip, int skip_cstride, int skip_coff,
                            void* out, int out_cstride, int out_coff, int out_dtype, int B, int Di, int Hi, int Wi,
@@ -362,6 +367,15 @@ extern "C" int pscv_conv3d(const void* in, int dtype, int in_cstride, int in_cof
                                                  reinterpret_cast<hipStream_t>(stream));
         if (rc) return rc;
         PSCV_CHECK_LAUNCH("pscv_conv3d(sweep)");
+        return 0;
+    }
+    if (kind == PSCV_CONV_S1C1) {
+        PSCV_CHECK_ARG(c_out == 1 && (c_in == 8 || c_in == 16), "pscv_conv3d: the 1-channel kernel (S1C1) is for c_in 8/16 -> 1 (got %d -> %d)", c_in, c_out);
+        const int rc = pscv_conv3d_c1_launch(in, dtype, in_cstride, in_coff, packed, scale, bias, floor, skip, skip_cstride,
+                                             skip_coff, out, out_cstride, out_coff, out_dtype, B, Di, Hi, Wi, c_in, epi_flags,
+                                             reinterpret_cast<hipStream_t>(stream));
+        if (rc) return rc;
+        PSCV_CHECK_LAUNCH("pscv_conv3d(c1)");
         return 0;
     }
     ConvArgs a;

@@ -35,7 +35,8 @@ extern "C" long pscv_pack_conv3d_weights(const float* w, int c_in, int c_out, in
                                          uint16_t* packed) {
     using namespace pscv;
     PSCV_CHECK_ARG(c_in > 0 && c_in % 8 == 0 && c_out > 0, "pscv_pack_conv3d_weights: bad channels %d -> %d", c_in, c_out);
-    PSCV_CHECK_ARG(kind == PSCV_CONV_S1 || kind == PSCV_CONV_S2 || kind == PSCV_CONV_T2 || kind == PSCV_CONV_S1P8,
+    PSCV_CHECK_ARG(kind == PSCV_CONV_S1 || kind == PSCV_CONV_S2 || kind == PSCV_CONV_T2 || kind == PSCV_CONV_S1P8 ||
+                       kind == PSCV_CONV_S1C1,
                    "pscv_pack_conv3d_weights: kind %d", kind);
     PSCV_CHECK_ARG(kind != PSCV_CONV_T2 || transposed, "pscv_pack_conv3d_weights: T2 needs a ConvTranspose3d weight");
     PSCV_CHECK_ARG(kind != PSCV_CONV_S2 || !transposed, "pscv_pack_conv3d_weights: S2 takes a Conv3d weight");
@@ -57,6 +58,19 @@ extern "C" long pscv_pack_conv3d_weights(const float* w, int c_in, int c_out, in
                         if (kd >= 0 && kd <= 2) v = w[((long)co * c_in + ci) * 27 + kd * 9 + t];
                         packed[(((long)p * 9 + t) * 64 + lane) * 8 + j] = dtype == PSCV_BF16 ? f32_to_bf16(v) : f32_to_f16_bits(v);
                     }
+        return n;
+    }
+    if (kind == PSCV_CONV_S1C1) {
+        // 1-channel layout: [tap = kd*9 + kh*3 + kw][c_in] 16-bit values (wave-uniform scalar operands of v_dot2)
+        PSCV_CHECK_ARG(c_out == 1 && (c_in == 8 || c_in == 16) && !transposed, "pscv_pack_conv3d_weights: S1C1 is Conv3d 8|16 -> 1 only");
+        const long n = 27L * c_in;
+        if (!packed) return n;
+        PSCV_CHECK_ARG(w, "pscv_pack_conv3d_weights: null weight pointer");
+        for (int t = 0; t < 27; ++t)
+            for (int ci = 0; ci < c_in; ++ci) {
+                const float v = w[(long)ci * 27 + t];
+                packed[(long)t * c_in + ci] = dtype == PSCV_BF16 ? f32_to_bf16(v) : f32_to_f16_bits(v);
+            }
         return n;
     }
     const int nt = ceil_div(c_out, 16);
