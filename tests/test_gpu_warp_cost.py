@@ -73,7 +73,7 @@ def test_cost_volume_fp32_matches_reference_golden(env, fname, agg):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("lpv", [4, 2, 1])
+@pytest.mark.parametrize("lpv", [0, 4, 2, 1])
 def test_cost_volume_16bit_storage(env, lpv, dtype):
     """16-bit feature maps in, 16-bit cost volume out, fp32 accumulation: equals the oracle run on the
     rounded features up to one output rounding."""
@@ -85,7 +85,7 @@ def test_cost_volume_16bit_storage(env, lpv, dtype):
     warped = [O.homo_warping(fr[i], proj[:, i], proj[:, 0], dv, fr[0].shape[-2:]) for i in range(1, V)]
     ref = O.variance_cost(fr[0], warped)
     cams = ops.proj_cams([proj[:, i].cuda() for i in range(1, V)], proj[:, 0].cuda())
-    L.set_tuning("warp_lpv", lpv)     # every lanes-per-voxel mapping must give the same volume
+    L.set_tuning("warp_lpv", lpv)     # 0 = LDS-staged tiled kernel; 4/2/1 = direct kernel, lanes per voxel
     try:
         cost = ops.warp_cost(_cl(feats[0], dtype), [_cl(feats[i], dtype) for i in range(1, V)],
                              cams, dv.cuda(), cost=L.COST_VARIANCE, out_dtype=dtype)
@@ -149,3 +149,34 @@ def test_identity_sweep_has_zero_variance_at_full_size(env):
     vol = ops.warp_cost(None, [fcl], cams[:1], dvals[:, 0].contiguous().cuda(), cost=L.COST_WARP_ONLY,
                         out_dtype=torch.float32)
     assert float((vol[0] - fcl.float().unsqueeze(1)).abs().max()) <= 1e-4 * float(fcl.float().abs().max())
+
+
+@pytest.mark.parametrize("cost_name", ["variance", "softmin", "variance_cvp"])
+@pytest.mark.parametrize("baseline_scale,shape", [(1.0, (64, 80)), (1.0, (37, 53)), (12.0, (64, 80))])
+def test_tiled_kernel_equals_direct_kernel(env, baseline_scale, shape, cost_name):
+    """The LDS-staged kernel and the direct-gather kernel run the same arithmetic on the same taps, so their cost
+    volumes must agree bit for bit: small epipolar spans (everything staged), tile sizes that do not divide the
+    image, and a 12x wider baseline where the per-view boxes overflow the LDS budget and views fall back to
+    direct taps inside the tiled kernel."""
+    L, ops, O = env
+    from wild_deep_mvs_amd import synthetic
+    from oracle.mvsnet import mvsnet_cameras
+    h, w = shape
+    B, V, C, D = 2, 5, 32, 24
+    feats = synthetic.make_features(B, V, C, h, w, seed=11)
+    cam = synthetic.make_cameras(B, V, 4 * h, 4 * w)
+    cam["t"] = cam["t"] * baseline_scale
+    proj, dvals = mvsnet_cameras(cam["K"], cam["R"], cam["t"], cam["depth_min"], cam["depth_max"], D)
+    cams = ops.proj_cams_device(proj.cuda().contiguous(), 0)
+    fcl = [ops.to_channels_last(feats[i].cuda(), torch.float16) for i in range(V)]
+    dv = dvals[:, 0].contiguous().cuda()
+    code = {"variance": L.COST_VARIANCE, "softmin": L.COST_SOFTMIN, "variance_cvp": L.COST_VARIANCE_CVP}[cost_name]
+    outs = []
+    for tiled in (1, 0):
+        L.set_tuning("warp_tiled", tiled)
+        try:
+            outs.append(ops.warp_cost(fcl[0], fcl[1:], cams, dv, cost=code, temp=0.7, out_dtype=torch.float16).float().cpu())
+        finally:
+            L.set_tuning("warp_tiled", 1)
+    s = check_close(f"tiled vs direct {cost_name} baseline x{baseline_scale} {shape}", outs[0], outs[1], max_abs=0.0)
+    assert float(outs[1].abs().max()) > 0

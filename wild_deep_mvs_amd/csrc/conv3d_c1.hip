@@ -102,6 +102,15 @@ __global__ __launch_bounds__(256) void conv3d_c1_kernel(const C1Args a) {
     }
     __syncthreads();
 
+    // C_in = 8: the 27 weight quads live in VGPRs (same value in every lane) for the whole sweep; re-reading them
+    // through the scalar cache every plane exposed its latency once per iteration.  C_in = 16 would need 216
+    // registers and keeps the scalar-operand path.
+    constexpr bool WREG = CIN == 8;
+    uint4 wreg[WREG ? 27 * CCH : 1];
+    if (WREG) {
+#pragma unroll
+        for (int t = 0; t < 27 * CCH; ++t) wreg[t] = a.wpk[t];
+    }
     const float e_scale = a.scale ? a.scale[0] : 1.0f, e_bias = a.bias ? a.bias[0] : 0.0f,
                 e_floor = a.floor ? a.floor[0] : 0.0f;
     const int lane_off = (row * C1_BW + col) * VB;   // this lane's voxel at tap (kh=0, kw=0)
@@ -123,7 +132,8 @@ __global__ __launch_bounds__(256) void conv3d_c1_kernel(const C1Args a) {
 #pragma unroll
                     for (int c = 0; c < CCH; ++c) {
                         const uint4 x = *reinterpret_cast<const uint4*>(sp + (kh * C1_BW + kw) * VB + c * 16);
-                        const uint4 w = a.wpk[((kd * 3 + kh) * 3 + kw) * CCH + c];   // wave-uniform -> scalar loads
+                        const uint4 w = WREG ? wreg[((kd * 3 + kh) * 3 + kw) * CCH + c]
+                                             : a.wpk[((kd * 3 + kh) * 3 + kw) * CCH + c];   // wave-uniform -> scalar loads
                         acc = dot2<H>(x.x, w.x, acc);
                         acc = dot2<H>(x.y, w.y, acc);
                         acc = dot2<H>(x.z, w.z, acc);
