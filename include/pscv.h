@@ -70,9 +70,9 @@ int pscv_abi_version(void);
 /* Tuning knobs for measurement runs (not part of the reference's surface). Keys:
  *   "warp_lpv"  lanes sharing one voxel in pscv_warp_cost (1, 2 or 4 for C=32; 0 = default C/8)
  *   "warp_ppd"  depth planes per workgroup in pscv_warp_cost (0 = default 8)
- *   "warp_tiled" 1 (default): pscv_warp_cost stages source patches in LDS where it applies (C = 32, 16-bit
- *               features, per-batch planes, PROJ geometry, variance / softmin); 0: always the direct-gather kernel.
- *               Setting "warp_lpv" != 0 also selects the direct kernel.
+ *   "warp_tiled" 1: pscv_warp_cost stages source patches in LDS where it applies (C = 32, 16-bit features,
+ *               per-batch planes, PROJ geometry, 2-4 source views, variance / softmin); 0 (default): the
+ *               direct-gather kernel, which measured faster on MI355X.  "warp_lpv" != 0 also selects the direct kernel.
  *   "conv_small_tiles"  1 (default): small volumes use 1x4x16 tiles with the output channels split over
  *               blockIdx.y; 0: always the large-tile variant */
 int pscv_set_tuning(const char* key, int value);

@@ -122,6 +122,79 @@ def gen_mvsnet(aggregation: str, tag: str, *, H=64, W=96, V=3, D=16, seed=0, beh
          depth_per_pixel=np32(dpp), warped_per_pixel=np32(warped_pp[:, :, PLANES]))
 
 
+def gen_vis(tag, *, H=64, W=96, V=3, depth_nums=(16, 8, 4), interval_scales=(8.0, 4.0, 2.0), seed=0, scene_seed=0):
+    sys.path.insert(0, REPO)
+    from wild_deep_mvs_amd import synthetic
+    from models.VisMVSNet.frontend import Frontend  # reference
+    import models.VisMVSNet.model_cas as MC
+
+    torch.manual_seed(0)
+    net = Frontend()
+    sd = synthetic.sharpened_state_dict("vis", synthetic.template_of(net), seed=seed)
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    net.depth_nums = list(depth_nums)
+    net.interval_scales = list(interval_scales)
+    scene = synthetic.make_scene(1, V, H, W, seed=scene_seed)
+
+    # capture stage-1 internals of the first source pair through the reference's own functions
+    cap = {}
+    orig_gc, orig_bcv = MC.groupwise_correlation, MC.SingleStage.build_cost_volume
+
+    def gc(v1, v2, groups, dim):
+        out = orig_gc(v1, v2, groups, dim)
+        cap.setdefault("cost", []).append(out)
+        return out
+
+    def bcv(self, *a, **k):
+        out = orig_bcv(self, *a, **k)
+        cap.setdefault("warped", []).append(out)
+        return out
+
+    MC.groupwise_correlation, MC.SingleStage.build_cost_volume = gc, bcv
+    hooks = []
+    for si, st in enumerate([net.model.stage1, net.model.stage2, net.model.stage3]):
+        hooks.append(st.reg.register_forward_hook(lambda m, i, o, si=si: cap.setdefault(f"interm{si}", []).append(o)))
+        hooks.append(st.reg_fuse.register_forward_hook(lambda m, i, o, si=si: cap.setdefault(f"fuse_in{si}", []).append(i[0]) or cap.setdefault(f"score{si}", []).append(o)))
+    try:
+        with torch.no_grad():
+            out = net(scene["imgs"], scene["K"], scene["R"], scene["t"], scene["depth_min"], scene["depth_max"],
+                      depth_nums=list(depth_nums), interval_scales=list(interval_scales))
+            feats = [net.model.feat_ext(im) for im in torch.unbind(scene["imgs"], 1)]
+    finally:
+        MC.groupwise_correlation, MC.SingleStage.build_cost_volume = orig_gc, orig_bcv
+        for h in hooks:
+            h.remove()
+    n_src = V - 1
+    pm = out["photometric_confidence"]
+    print(f"[{tag}] prob maps mean {pm.mean(dim=(0, 2, 3)).tolist()}, depth range {out['depth'].min():.3f}..{out['depth'].max():.3f}, "
+          f"uncert stage1 {out['depth_pair_list'][2][0][1][0].mean():.3f}")
+    arrays = dict(
+        meta=np.array([H, W, V, seed, scene_seed] + list(depth_nums), dtype=np.int64),
+        interval_scales=np.array(interval_scales, dtype=np.float32),
+        depth=np32(out["depth"]), photometric_confidence=np32(pm),
+        depth_est_list=np.array([0]),   # placeholder so the key order is stable
+    )
+    for i, d in enumerate(out["depth_est_list"]):
+        arrays[f"depth_est_{i}"] = np32(d)
+    for si, pr in enumerate(out["depth_pair_list"]):            # finest first: stage 3, 2, 1
+        for vi, (ed, unc) in enumerate(pr):
+            arrays[f"pair_depth_s{3 - si}_v{vi}"] = np32(ed)
+            arrays[f"pair_uncert_s{3 - si}_v{vi}"] = np32(unc[0])
+    for k in range(3):                                            # per-scale features of every view
+        arrays[f"feat_s{k + 1}"] = np.stack([np32(f[k]) for f in feats])
+    # stage-1 internals, first source view (cap lists are in call order: stage1 views..., stage2 ..., stage3 ...)
+    arrays["s1_warped_v0"] = np32(cap["warped"][0])
+    arrays["s1_cost_v0"] = np32(cap["cost"][0])
+    arrays["s1_interm_v0"] = np32(cap["interm0"][0])
+    arrays["s1_fused"] = np32(cap["fuse_in0"][0])
+    arrays["s1_score"] = np32(cap["score0"][0])
+    arrays["s3_cost_v1"] = np32(cap["cost"][2 * n_src + 1])
+    arrays["s3_fused"] = np32(cap["fuse_in2"][0])
+    arrays["s3_score"] = np32(cap["score2"][0])
+    save(f"{tag}.npz", **arrays)
+
+
 def gen_state_dict_keys():
     """Key order, names and shapes of the reference's state dicts (the checkpoint-compat contract)."""
     import json
@@ -151,6 +224,7 @@ def main():
         "mvsnet": lambda: gen_mvsnet("variance", "mvsnet_tiny"),
         "mvsnet_behind": lambda: gen_mvsnet("variance", "mvsnet_behind", V=4, behind_view=2, scene_seed=5),
         "mvsnet_s": lambda: gen_mvsnet("softmin", "mvsnet_s_tiny", seed=1),
+        "vis": lambda: gen_vis("vis_tiny"),
         "keys": gen_state_dict_keys,
     }
     for k, fn in todo.items():

@@ -156,7 +156,9 @@ __global__ __launch_bounds__(256) void warp_cost_kernel(const WarpArgs a) {
 // ---- host side ---------------------------------------------------------------------------------
 static int g_warp_lpv_override = 0;  // 0 = default heuristic; set through pscv_set_tuning("warp_lpv", n)
 static int g_warp_ppd_override = 0;
-static int g_warp_tiled = 1;     // 1: use the LDS-staged kernel (warp_cost_tiled.hip) where it applies
+static int g_warp_tiled = 0;     // 1: use the LDS-staged kernel (warp_cost_tiled.hip) where it applies.  Off by default:
+                                 // measured 252-275 us vs 218-228 us for the direct kernel at the headline size
+                                 // (profiles/README.md) -- the sweep is VALU-issue / latency limited, not L1-limited
 extern int g_conv_small_tiles;   // conv3d.hip
 int warp_cost_tiled_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, int out_dtype, int ppd_override, hipStream_t st);
 

@@ -56,7 +56,7 @@ __device__ __forceinline__ void sweep_uvz(const float* __restrict__ cam, float p
 
 struct WtPatch { int base, x0, y0, bw, bh, staged; };
 
-template <typename TIn, typename TOut, int GEOM, int COST>
+template <typename TIn, typename TOut, int GEOM, int COST, int NSRC>
 __global__ __launch_bounds__(256, 2) void warp_cost_tiled_kernel(const WarpArgs a) {
     constexpr int C = 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256, 2) void warp_cost_tiled_kernel(const WarpArgs 
     const int b = wg;
 
     const int tid = threadIdx.x;
-    const int p = tid >> 1, hh = tid & 1;
+    const int p = tid >> 1, hh = tid & 1, hsel = hh << 4;
     const int x0t = txi * WT_TW, y0t = tyi * WT_TH;
     int x = x0t + (p & (WT_TW - 1)), y = y0t + (p >> 4);
     const bool active = x < a.w && y < a.h;
@@ -133,13 +133,16 @@ __global__ __launch_bounds__(256, 2) void warp_cost_tiled_kernel(const WarpArgs 
         const int size = bw * bh;
         const bool staged = info[v * 8 + 4] && bw > 0 && bh > 0 && used + size <= WT_TEXELS;
         if (staged) {
+            // one wave per patch row (rows are contiguous runs of bw x 64 B in the source): no integer division
             const TIn* img = reinterpret_cast<const TIn*>(a.src[v]);
-            const int nch = size * 4;
-            for (int id = tid; id < nch; id += 256) {
-                const int t = id >> 2, c = id & 3;
-                const int ty = t / bw, tx = t - ty * bw;
-                const uint4 val = *reinterpret_cast<const uint4*>(img + (((long)b * a.hs + Y0 + ty) * a.ws + X0 + tx) * C + c * 8);
-                *reinterpret_cast<uint4*>(tex + wt_chunk_off(used + t, c)) = val;
+            const int lane = tid & 63, wave = tid >> 6;
+            for (int ty = wave; ty < bh; ty += 4) {
+                const TIn* rowp = img + (((long)b * a.hs + Y0 + ty) * a.ws + X0) * C;
+                const int t0 = used + ty * bw;
+                for (int id = lane; id < bw * 4; id += 64) {
+                    const uint4 val = *reinterpret_cast<const uint4*>(rowp + id * 8);
+                    *reinterpret_cast<uint4*>(tex + wt_chunk_off(t0 + (id >> 2), id & 3)) = val;
+                }
             }
         }
         __syncthreads();   // (also orders the info reads above before the rewrite below)
@@ -147,6 +150,17 @@ __global__ __launch_bounds__(256, 2) void warp_cost_tiled_kernel(const WarpArgs 
         if (staged) used += size;
     }
     __syncthreads();
+
+    // per-view patch descriptors -> scalar registers (the view loop below is fully unrolled: static indices)
+    int vbase[NSRC], pX0[NSRC], pY0[NSRC], pBW[NSRC], pBH[NSRC];
+#pragma unroll
+    for (int v = 0; v < NSRC; ++v) {
+        pX0[v] = __builtin_amdgcn_readfirstlane(info[v * 8 + 0]);
+        pY0[v] = __builtin_amdgcn_readfirstlane(info[v * 8 + 1]);
+        pBW[v] = __builtin_amdgcn_readfirstlane(info[v * 8 + 2]);
+        pBH[v] = __builtin_amdgcn_readfirstlane(info[v * 8 + 3]);
+        vbase[v] = __builtin_amdgcn_readfirstlane(info[v * 8 + 5]);
+    }
 
     // ---- 4. sweep the planes ----
     const TIn* ref = reinterpret_cast<const TIn*>(a.ref);
@@ -174,7 +188,8 @@ __global__ __launch_bounds__(256, 2) void warp_cost_tiled_kernel(const WarpArgs 
             for (int j = 0; j < 16; ++j) { acc0.v[j] = rf.v[j]; acc1.v[j] = rf.v[j] * rf.v[j]; }
         }
 
-        for (int v = 0; v < a.n_src; ++v) {
+#pragma unroll
+        for (int v = 0; v < NSRC; ++v) {
             const float* cam = a.cams + ((long)v * a.B + b) * PSCV_CAM_FLOATS;
             float ix, iy;
             sweep_index<GEOM>(cam, px, py, dval, a, ix, iy);
@@ -190,20 +205,23 @@ __global__ __launch_bounds__(256, 2) void warp_cost_tiled_kernel(const WarpArgs 
             const int xc0 = min(max(xi0, 0), a.ws - 1), xc1 = min(max(xi1, 0), a.ws - 1);
             const int yc0 = min(max(yi0, 0), a.hs - 1), yc1 = min(max(yi1, 0), a.hs - 1);
 
-            const int base = info[v * 8 + 5];   // wave-uniform
+            const int base = vbase[v];   // wave-uniform
             f32x8 t00a, t00b, t01a, t01b, t10a, t10b, t11a, t11b;
             if (base >= 0) {
-                const int X0 = info[v * 8 + 0], Y0 = info[v * 8 + 1], bw = info[v * 8 + 2], bh = info[v * 8 + 3];
+                const int X0 = pX0[v], Y0 = pY0[v], bw = pBW[v], bh = pBH[v];
                 // a zero-weight (out-of-image) tap may fall outside the box: clamp it into the box
                 const int bx0 = min(max(xc0 - X0, 0), bw - 1), bx1 = min(max(xc1 - X0, 0), bw - 1);
                 const int by0 = min(max(yc0 - Y0, 0), bh - 1), by1 = min(max(yc1 - Y0, 0), bh - 1);
-                const int e00 = base + by0 * bw + bx0, e01 = base + by0 * bw + bx1;
-                const int e10 = base + by1 * bw + bx0, e11 = base + by1 * bw + bx1;
-                const TIn* lt = reinterpret_cast<const TIn*>(tex);
-                t00a = Elem<TIn>::load8(lt + wt_chunk_off(e00, hh) / 2); t00b = Elem<TIn>::load8(lt + wt_chunk_off(e00, 2 + hh) / 2);
-                t01a = Elem<TIn>::load8(lt + wt_chunk_off(e01, hh) / 2); t01b = Elem<TIn>::load8(lt + wt_chunk_off(e01, 2 + hh) / 2);
-                t10a = Elem<TIn>::load8(lt + wt_chunk_off(e10, hh) / 2); t10b = Elem<TIn>::load8(lt + wt_chunk_off(e10, 2 + hh) / 2);
-                t11a = Elem<TIn>::load8(lt + wt_chunk_off(e11, hh) / 2); t11b = Elem<TIn>::load8(lt + wt_chunk_off(e11, 2 + hh) / 2);
+                const int r0 = base + by0 * bw, r1 = base + by1 * bw;
+                // byte offset of chunk hh of texel e: e*64 + ((hh*16) ^ swz), swz = bit 2 of e moved to bit 5;
+                // chunk 2+hh of the same texel is that offset with bit 5 flipped
+                auto toff = [&](int e) { return (e << 6) + (hsel ^ ((e << 3) & 32)); };
+                const int o00 = toff(r0 + bx0), o01 = toff(r0 + bx1), o10 = toff(r1 + bx0), o11 = toff(r1 + bx1);
+                auto ld = [&](int o) { return Elem<TIn>::load8(reinterpret_cast<const TIn*>(tex + o)); };
+                t00a = ld(o00); t00b = ld(o00 ^ 32);
+                t01a = ld(o01); t01b = ld(o01 ^ 32);
+                t10a = ld(o10); t10b = ld(o10 ^ 32);
+                t11a = ld(o11); t11b = ld(o11 ^ 32);
             } else {
                 const TIn* img = reinterpret_cast<const TIn*>(a.src[v]);
                 const long row0 = ((long)b * a.hs + yc0) * a.ws, row1 = ((long)b * a.hs + yc1) * a.ws;
@@ -268,9 +286,9 @@ __global__ __launch_bounds__(256, 2) void warp_cost_tiled_kernel(const WarpArgs 
     }
 }
 
-template <typename TIn, typename TOut, int GEOM, int COST>
-static int wt_launch(const WarpArgs& a, int nblk, hipStream_t st) {
-    auto kern = warp_cost_tiled_kernel<TIn, TOut, GEOM, COST>;
+template <typename TIn, typename TOut, int GEOM, int COST, int NSRC>
+static int wt_launch_n(const WarpArgs& a, int nblk, hipStream_t st) {
+    auto kern = warp_cost_tiled_kernel<TIn, TOut, GEOM, COST, NSRC>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, WT_LDS);
@@ -279,6 +297,17 @@ static int wt_launch(const WarpArgs& a, int nblk, hipStream_t st) {
     }
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), WT_LDS, st, a);
     return 0;
+}
+
+// the source-view loop is unrolled at compile time; other view counts use the direct kernel
+template <typename TIn, typename TOut, int GEOM, int COST>
+static int wt_launch(const WarpArgs& a, int nblk, hipStream_t st) {
+    switch (a.n_src) {
+        case 2: return wt_launch_n<TIn, TOut, GEOM, COST, 2>(a, nblk, st);
+        case 3: return wt_launch_n<TIn, TOut, GEOM, COST, 3>(a, nblk, st);
+        case 4: return wt_launch_n<TIn, TOut, GEOM, COST, 4>(a, nblk, st);
+    }
+    return 1;
 }
 
 template <typename T>
@@ -295,10 +324,10 @@ static int wt_dispatch(const WarpArgs& a, int geom, int cost, int nblk, hipStrea
 // kernel), negative on error.
 int warp_cost_tiled_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, int out_dtype, int ppd_override, hipStream_t st) {
     if (C != 32 || a.depth_per_pixel || in_dtype != out_dtype || (in_dtype != PSCV_F16 && in_dtype != PSCV_BF16)) return 1;
-    if (a.n_src > 16) return 1;
+    if (a.n_src < 2 || a.n_src > 4) return 1;   // unrolled view counts (more views spill registers: direct kernel)
     const long tiles = (long)a.B * ((a.h + WT_TH - 1) / WT_TH) * ((a.w + WT_TW - 1) / WT_TW);
-    int ppd = ppd_override > 0 ? ppd_override : 8;
-    while (ppd > 2 && tiles * ((a.D + ppd - 1) / ppd) < 2048) ppd >>= 1;
+    int ppd = ppd_override > 0 ? ppd_override : 16;   // planes per block: amortises the patch staging
+    while (ppd > 2 && tiles * ((a.D + ppd - 1) / ppd) < 1024) ppd >>= 1;
     a.ppd = ppd;
     a.n_dchunks = (a.D + ppd - 1) / ppd;
     const long nblk = tiles * a.n_dchunks;

@@ -149,7 +149,7 @@ def template_of(module: torch.nn.Module) -> "OrderedDict[str, Tuple[int, ...]]":
 # resulting softmax peak): they give max_d p in the 0.3-0.9 band on make_scene inputs.
 SHARPEN = {
     "mvsnet": dict(conv_gain=1.414, head_gain={"feature.": 0.85, "cost_regularization.prob.weight": 10.0}),
-    "vis": dict(conv_gain=1.6, head_gain={"final_conv.weight": 6.0}),
+    "vis": dict(conv_gain=1.0, head_gain={"final_conv.weight": 2.0}),
     "cvp": dict(conv_gain=1.3, head_gain={"prob0.weight": 6.0}),
 }
 TRANSPOSED_KEYS = {
