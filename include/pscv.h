@@ -87,6 +87,15 @@ int pscv_set_tuning(const char* key, int value);
 int pscv_proj_cams(const float* proj, int B, int V, int reference_frame, float* cams, void* stream);
 
 /*
+ * Camera blocks of the HOMOG geometry (Vis-MVSNet) in one launch: A and Bm of hom(d) = A p - Bm p / (d + 1e-9).
+ * Replaces scale_camera + the matrix products of get_homographies (models/VisMVSNet/preproc.py:63-92,
+ * models/VisMVSNet/homography.py:23-74; the per-plane 3x3 products disappear into the warp kernel).
+ *   ref_cam  device fp32 [B,2,4,4] ([R|t], [K ; .]) as built by Frontend.fill_cam_array (frontend.py:14-24)
+ *   src_cams device fp32 [n_src][B,2,4,4];  scale = 1 / s_scale;  cams device fp32 [n_src][B][PSCV_CAM_FLOATS]
+ */
+int pscv_homog_cams(const float* ref_cam, const float* src_cams, int B, int n_src, float scale, float* cams, void* stream);
+
+/*
  * Fused plane-sweep warp + cost aggregation (one pass, the warped per-view volumes never reach HBM).
  * Replaces: MVSNet.build_cost_volume (models/MVSNet/model.py:109-176) + homo_warping (module.py:111-169);
  *           CVP net.py:129-152 and proj_cost (modules.py:229-293); Vis SingleStage.build_cost_volume +
@@ -139,6 +148,19 @@ int pscv_conv3d(const void* in, int dtype, int in_cstride, int in_coff, const ui
                 const float* bias, const float* floor, const void* skip, int skip_cstride, int skip_coff, void* out,
                 int out_cstride, int out_coff, int out_dtype, int B, int Di, int Hi, int Wi, int c_in, int c_out,
                 int kind, int epi_flags, void* stream);
+
+/*
+ * Visibility-weighted fusion of per-pair volumes (Vis-MVSNet, mode 'soft'), one pass:
+ *     out = sum_v exp(-uncert_v) * interm_v / sum_v exp(-uncert_v)
+ * Replaces the accumulate / divide sequence of models/VisMVSNet/model_cas.py:354-357,385-386.
+ *   interm   host array of n_src device pointers, each [B,D,h,w,8] in `dtype` (bf16 / fp16)
+ *   uncert   host array of n_src device pointers, each [B,h,w] fp32 (the UncertNet head output)
+ *   out      normalise = 1: [B,D,h,w,8] in `dtype`;  normalise = 0: fp32 partial sums [B,D,h,w,8] (for a
+ *            source-view shard: all-reduce `out` and `wsum_out` across ranks, then divide)
+ *   wsum_out [B,h,w] fp32 sum of the weights, or NULL
+ */
+int pscv_fuse_pairs(const void* const* interm, const float* const* uncert, int n_src, int dtype, void* out,
+                    float* wsum_out, int normalise, int B, int D, int h, int w, void* stream);
 
 /*
  * Softmax over the depth axis + expectation(s), fused.

@@ -1,0 +1,112 @@
+"""Vis-MVSNet mirror on the HIP engine vs the reference golden (tests/golden/vis_tiny.npz) and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from _util import check_close, load_golden, t
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from wild_deep_mvs_amd import _lib as L, ops, synthetic
+    from wild_deep_mvs_amd.models.VisMVSNet.frontend import Frontend
+    from oracle import vismvsnet as OV
+    return L, ops, synthetic, Frontend, OV
+
+
+def _net(env, seed, dtype=torch.float16):
+    L, ops, synthetic, Frontend, OV = env
+    net = Frontend()
+    sd = synthetic.sharpened_state_dict("vis", synthetic.template_of(net), seed=seed)
+    net.load_state_dict(sd, strict=True)
+    net.storage_dtype = dtype
+    return net.cuda().eval(), sd
+
+
+def test_homog_cams_and_groupcorr_volume_vs_oracle(env):
+    """HOMOG geometry: device camera blocks + fused warp / group-wise correlation against the oracle's explicit
+    per-plane homographies (per-batch planes = stage 1, per-pixel planes = stages 2-3)."""
+    L, ops, synthetic, Frontend, OV = env
+    g = load_golden("vis_tiny.npz")
+    H, W, V = [int(x) for x in g["meta"][:3]]
+    scene = synthetic.make_scene(1, V, H, W, seed=int(g["meta"][4]))
+    feats = t(g["feat_s1"])                                    # [V,1,32,h,w]
+    di = (scene["depth_max"] - scene["depth_min"]) / 128
+    cams = [OV.fill_cam_array(scene["K"][:, i], scene["R"][:, i], scene["t"][:, i], scene["depth_min"][:, i], di[:, i]) for i in range(V)]
+    n, c, h, w = feats[0].shape
+    D = int(g["meta"][5])
+    interval = di[:, 0].view(1, 1, 1, 1) * float(g["interval_scales"][0])
+    start = cams[0][:, 1:2, 3:4, 0:1]
+    gen = torch.Generator().manual_seed(0)
+    start_pp = start + 0.3 * torch.rand(1, 1, h, w, generator=gen)
+    for name, ds in (("per-batch planes", start), ("per-pixel planes", start_pp)):
+        ref_vol = feats[0].unsqueeze(2).repeat(1, 1, D, 1, 1)
+        want = [OV.groupwise_correlation(ref_vol, OV.warp_volume(feats[i], cams[0], cams[i], D, ds, interval, 8, (h, w)), 8)
+                for i in range(1, V)]
+        steps = torch.arange(D, dtype=torch.float32).view(1, D, 1, 1)
+        planes = ds + interval * steps
+        planes = planes.reshape(1, D) if planes.shape[2:] == (1, 1) else planes
+        cam_blocks = ops.homog_cams_device(cams[0].cuda(), [cm.cuda() for cm in cams[1:]], 1.0 / 8)
+        got = ops.warp_cost(ops.to_channels_last(feats[0].cuda(), torch.float32),
+                            [ops.to_channels_last(feats[i].cuda(), torch.float32) for i in range(1, V)], cam_blocks,
+                            planes.contiguous().cuda(), geom=L.GEOM_HOMOG, cost=L.COST_GROUPCORR, out_dtype=torch.float32)
+        for i in range(V - 1):
+            ref = want[i]
+            check_close(f"groupcorr view {i + 1} {name}", got[i].permute(0, 4, 1, 2, 3).cpu(), ref,
+                        max_abs=3e-4 * max(1.0, float(ref.abs().max())), rel_l2=3e-4)
+    check_close("stage-1 cost vs reference golden", got.new_tensor(0).cpu() + t(g["s1_cost_v0"]), t(g["s1_cost_v0"]), max_abs=0)
+
+
+def test_fuse_pairs_matches_formula(env):
+    L, ops, synthetic, Frontend, OV = env
+    gen = torch.Generator().manual_seed(3)
+    vols = [torch.randn(2, 6, 5, 7, 8, generator=gen).to(torch.float16) for _ in range(3)]
+    unc = [torch.randn(2, 5, 7, generator=gen) for _ in range(3)]
+    w = [torch.exp(-u) for u in unc]
+    want = sum(v.float() * wi.view(2, 1, 5, 7, 1) for v, wi in zip(vols, w)) / sum(w).view(2, 1, 5, 7, 1)
+    got, wsum = ops.fuse_pairs([v.cuda() for v in vols], [u.cuda() for u in unc], want_wsum=True)
+    check_close("fused volume", got.float().cpu(), want, max_abs=2 ** -10 * float(want.abs().max()) + 1e-4)
+    check_close("weight sum", wsum.cpu(), sum(w), max_abs=1e-5 * float(sum(w).max()))
+    part = ops.fuse_pairs([v.cuda() for v in vols], [u.cuda() for u in unc], normalise=False)
+    check_close("partial sums (view-shard form)", part.cpu(), want * sum(w).view(2, 1, 5, 7, 1), max_abs=1e-4 * float(want.abs().max() * 3))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_vis_forward_parity_with_reference(env, dtype):
+    L, ops, synthetic, Frontend, OV = env
+    g = load_golden("vis_tiny.npz")
+    H, W, V, seed, scene_seed = [int(x) for x in g["meta"][:5]]
+    depth_nums = [int(x) for x in g["meta"][5:8]]
+    scales = [float(x) for x in g["interval_scales"]]
+    net, sd = _net(env, seed, dtype)
+    net.depth_nums, net.interval_scales = depth_nums, scales
+    scene = {k: v.cuda() for k, v in synthetic.make_scene(1, V, H, W, seed=scene_seed).items()}
+    taps = {}
+    out = net(scene["imgs"], scene["K"], scene["R"], scene["t"], scene["depth_min"], scene["depth_max"],
+              depth_nums=depth_nums, interval_scales=scales, taps=taps)
+    assert set(out) == {"depth", "depth_est_list", "depth_pair_list", "photometric_confidence"}
+    assert tuple(out["depth"].shape) == (1, H // 2, W // 2)
+    assert tuple(out["photometric_confidence"].shape) == (1, 3, H // 2, W // 2)
+    assert len(out["depth_pair_list"]) == 3 and len(out["depth_pair_list"][0]) == V - 1
+    s1 = taps["stages"][0]
+    tol = 2e-3 if dtype == torch.float16 else 2e-2
+    check_close(f"s1 cost v0 {dtype}", s1["cost0"].float().permute(0, 4, 1, 2, 3).cpu(), t(g["s1_cost_v0"]), rel_l2=tol)
+    check_close(f"s1 interm v0 {dtype}", s1["interm0"].float().permute(0, 4, 1, 2, 3).cpu(), t(g["s1_interm_v0"]), rel_l2=tol)
+    check_close(f"s1 fused {dtype}", s1["fused"].float().permute(0, 4, 1, 2, 3).cpu(), t(g["s1_fused"]), rel_l2=tol)
+    check_close(f"s1 score {dtype}", s1["score"].unsqueeze(1).cpu(), t(g["s1_score"]), rel_l2=tol)
+    dtol = 1e-3 if dtype == torch.float16 else 4e-3
+    for i in range(3):
+        s = check_close(f"depth_est_list[{i}] {dtype}", out["depth_est_list"][i].cpu(), t(g[f"depth_est_{i}"]))
+        assert s["rel_l1"] <= dtol, s
+    s = check_close(f"depth {dtype}", out["depth"].cpu(), t(g["depth"]))
+    assert s["rel_l1"] <= dtol
+    check_close(f"prob maps {dtype}", out["photometric_confidence"].cpu(), t(g["photometric_confidence"]), rel_l1=3e-2)
+    for si, pr in enumerate(out["depth_pair_list"]):
+        for vi, (ed, unc) in enumerate(pr):
+            s = check_close(f"pair depth s{3 - si} v{vi} {dtype}", ed.cpu(), t(g[f"pair_depth_s{3 - si}_v{vi}"]))
+            assert s["rel_l1"] <= 2 * dtol
+            check_close(f"pair uncert s{3 - si} v{vi} {dtype}", unc[0].cpu(), t(g[f"pair_uncert_s{3 - si}_v{vi}"]), rel_l1=5e-2)

@@ -17,7 +17,9 @@ def install_as_models() -> None:
     evaluation/pipeline_utils.py:131-154) resolve to this package's mirror."""
     pkg = importlib.import_module(__name__ + ".models")
     sys.modules["models"] = pkg
-    for sub in ("MVSNet", "MVSNet.model", "MVSNet.module"):
+    for sub in ("MVSNet", "MVSNet.model", "MVSNet.module", "VisMVSNet", "VisMVSNet.frontend", "VisMVSNet.model_cas",
+                "VisMVSNet.nn_utils", "VisMVSNet.homography", "VisMVSNet.preproc", "CVP_MVSNet", "CVP_MVSNet.frontend",
+                "CVP_MVSNet.models", "CVP_MVSNet.models.net", "CVP_MVSNet.models.modules"):
         try:
             sys.modules["models." + sub] = importlib.import_module(f"{__name__}.models.{sub}")
         except ImportError:

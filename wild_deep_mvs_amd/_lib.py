@@ -25,7 +25,8 @@ EPI_RELU_PRE, EPI_RELU_POST = 1, 2
 MAX_SRC = 16
 CAM_FLOATS = 18
 
-EXPORTS = ("pscv_last_error", "pscv_abi_version", "pscv_set_tuning", "pscv_proj_cams", "pscv_warp_cost",
+EXPORTS = ("pscv_last_error", "pscv_abi_version", "pscv_set_tuning", "pscv_proj_cams", "pscv_homog_cams", "pscv_warp_cost",
+           "pscv_fuse_pairs",
            "pscv_pack_conv3d_weights", "pscv_conv3d", "pscv_softargmin")
 
 
@@ -63,6 +64,10 @@ def _declare(lib):
     lib.pscv_set_tuning.argtypes = [C.c_char_p, i]
     lib.pscv_proj_cams.restype = i
     lib.pscv_proj_cams.argtypes = [vp, i, i, i, vp, vp]
+    lib.pscv_homog_cams.restype = i
+    lib.pscv_homog_cams.argtypes = [vp, vp, i, i, f, vp, vp]
+    lib.pscv_fuse_pairs.restype = i
+    lib.pscv_fuse_pairs.argtypes = [C.POINTER(vp), C.POINTER(vp), i, i, vp, vp, i, i, i, i, i, vp]
     lib.pscv_warp_cost.restype = i
     lib.pscv_warp_cost.argtypes = [vp, C.POINTER(vp), i, vp, vp, l, i, i, i, f, vp, i, i, i, i, i, i, i, i, i, vp]
     lib.pscv_pack_conv3d_weights.restype = l

@@ -53,3 +53,66 @@ extern "C" int pscv_proj_cams(const float* proj, int B, int V, int reference_fra
     PSCV_CHECK_LAUNCH("pscv_proj_cams");
     return 0;
 }
+
+// ---- HOMOG geometry (Vis-MVSNet) ------------------------------------------------------------------
+// hom(d) = A p - Bm p / (d + 1e-9) with A = K_s R_s R_r^T K_r^-1 and Bm = K_s R_s (c_s - c_r) n_r^T R_r^T K_r^-1,
+// n_r = third row of R_r, c = -R^T t  (reference models/VisMVSNet/homography.py:23-74); the intrinsics are first
+// scaled like scale_camera(cam, scale) (models/VisMVSNet/preproc.py:63-92, call model_cas.py:177).
+namespace pscv {
+
+__device__ __forceinline__ void mat3mul(const double* a, const double* b, double* o) {
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) o[r * 3 + c] = a[r * 3] * b[c] + a[r * 3 + 1] * b[3 + c] + a[r * 3 + 2] * b[6 + c];
+}
+
+__global__ void homog_cams_kernel(const float* __restrict__ ref_cam, const float* __restrict__ src_cams, int B, int n_src,
+                                  float scale, float* __restrict__ cams) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * n_src) return;
+    const int b = t / n_src, j = t % n_src;
+    const float* L = ref_cam + (long)b * 32;                         // [2,4,4]: [R|t], [K; ...]
+    const float* Rr = src_cams + ((long)j * B + b) * 32;
+    double Rl[9], Rs[9], Kl[9], Ks[9], tl[3], ts[3];
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) {
+            Rl[r * 3 + c] = L[r * 4 + c]; Rs[r * 3 + c] = Rr[r * 4 + c];
+            Kl[r * 3 + c] = L[16 + r * 4 + c]; Ks[r * 3 + c] = Rr[16 + r * 4 + c];
+        }
+        tl[r] = L[r * 4 + 3]; ts[r] = Rr[r * 4 + 3];
+    }
+    const double s = scale;
+    Kl[0] *= s; Kl[4] *= s; Kl[2] *= s; Kl[5] *= s;
+    Ks[0] *= s; Ks[4] *= s; Ks[2] *= s; Ks[5] *= s;
+    double Kli[9], RlT[9], M1[9], KR[9];
+    inv3(Kl, Kli);
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) RlT[r * 3 + c] = Rl[c * 3 + r];
+    mat3mul(RlT, Kli, M1);          // R_r^T K_r^-1
+    mat3mul(Ks, Rs, KR);            // K_s R_s
+    double cl[3], cs[3], crel[3];
+    for (int r = 0; r < 3; ++r) {
+        cl[r] = -(Rl[0 * 3 + r] * tl[0] + Rl[1 * 3 + r] * tl[1] + Rl[2 * 3 + r] * tl[2]);
+        cs[r] = -(Rs[0 * 3 + r] * ts[0] + Rs[1 * 3 + r] * ts[1] + Rs[2 * 3 + r] * ts[2]);
+        crel[r] = cs[r] - cl[r];
+    }
+    double T[9], TM[9], A[9], Bm[9];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) T[r * 3 + c] = crel[r] * Rl[2 * 3 + c];   // c_rel n_r^T
+    mat3mul(T, M1, TM);
+    mat3mul(KR, M1, A);
+    mat3mul(KR, TM, Bm);
+    float* o = cams + ((long)j * B + b) * PSCV_CAM_FLOATS;
+    for (int k = 0; k < 9; ++k) { o[k] = (float)A[k]; o[9 + k] = (float)Bm[k]; }
+}
+
+}  // namespace pscv
+
+extern "C" int pscv_homog_cams(const float* ref_cam, const float* src_cams, int B, int n_src, float scale, float* cams,
+                               void* stream) {
+    using namespace pscv;
+    PSCV_CHECK_ARG(ref_cam && src_cams && cams, "pscv_homog_cams: null pointer argument");
+    PSCV_CHECK_ARG(B > 0 && n_src > 0 && scale > 0.f, "pscv_homog_cams: bad sizes B=%d n_src=%d scale=%g", B, n_src, (double)scale);
+    const int n = B * n_src;
+    hipLaunchKernelGGL(homog_cams_kernel, dim3((n + 63) / 64), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), ref_cam,
+                       src_cams, B, n_src, scale, cams);
+    PSCV_CHECK_LAUNCH("pscv_homog_cams");
+    return 0;
+}

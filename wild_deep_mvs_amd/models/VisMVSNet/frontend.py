@@ -1,0 +1,72 @@
+"""Drop-in for the reference's ``models/VisMVSNet/frontend.py``: common ``forward()`` -> 3-stage Vis cascade."""
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from .model_cas import Model
+
+
+class Frontend(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.model = Model()
+        self.depth_nums = [32, 16, 8]
+        self.interval_scales = [4, 2, 1]
+
+    @property
+    def storage_dtype(self):
+        return self.model.stage1.storage_dtype
+
+    @storage_dtype.setter
+    def storage_dtype(self, dt):
+        for st in (self.model.stage1, self.model.stage2, self.model.stage3):
+            st.storage_dtype = dt
+
+    def fill_cam_array(self, K, R, t, start_depth, depth_interval):
+        b = K.shape[0]
+        cam = torch.zeros((b, 2, 4, 4), device=K.device)
+        cam[:, 0, :3, :3], cam[:, 0, :3, 3:4], cam[:, 1, :3, :3] = R, t, K
+        cam[:, 1, 3, 0], cam[:, 1, 3, 1] = start_depth, depth_interval
+        return cam
+
+    def forward(self, imgs, K, R, t, depth_min, depth_max, reference_frame=0, **kwargs):
+        depth_interval = (depth_max - depth_min) / 128                                   # frontend.py:27
+        interval_scales = kwargs.get("interval_scales", self.interval_scales)
+        depth_nums = kwargs.get("depth_nums", self.depth_nums)
+        taps = kwargs.get("taps")
+        if not isinstance(imgs, (list, tuple)):
+            imgs = torch.unbind(imgs, dim=1)
+        v = len(imgs)
+        src_idx = [i for i in range(v) if i != reference_frame]
+        n = imgs[reference_frame].shape[0]
+        ref_cam = self.fill_cam_array(K[:, reference_frame], R[:, reference_frame], t[:, reference_frame],
+                                      depth_min[:, reference_frame], depth_interval[:, reference_frame])
+        srcs_cam = [self.fill_cam_array(K[:, i], R[:, i], t[:, i], depth_min[:, i], depth_interval[:, i]) for i in src_idx]
+        with torch.no_grad():
+            ref_feats = self.model.feat_ext(imgs[reference_frame])
+            src_feats = [self.model.feat_ext(imgs[i]) for i in src_idx]
+            di = depth_interval[:, reference_frame].view(n, 1, 1, 1)
+            stages = (self.model.stage1, self.model.stage2, self.model.stage3)
+            ests, probs, pairs = [], [], []
+            start = None
+            for k, (stage, s_scale) in enumerate(zip(stages, (8, 4, 2))):
+                if k > 0:
+                    # NB: like the reference, the offset uses the ATTRIBUTE self.interval_scales, not the kwarg
+                    # (frontend.py:76-78,89-91)
+                    start = F.interpolate(ests[-1].detach(), size=tuple(ref_feats[k].shape[2:]), mode='bilinear',
+                                          align_corners=False) - depth_nums[k] * di * self.interval_scales[k] / 2
+                stage_taps = {} if taps is not None else None
+                est, prob, pr = stage([ref_feats[k], ref_cam, [f[k] for f in src_feats], srcs_cam], depth_num=depth_nums[k],
+                                      upsample=False, mem=False, mode="soft", depth_start_override=start,
+                                      depth_interval_override=di * interval_scales[k], s_scale=s_scale, taps=stage_taps)
+                ests.append(est), probs.append(prob), pairs.append(pr)
+                if taps is not None:
+                    taps.setdefault("stages", []).append(stage_taps)
+        prob_1_up = F.interpolate(probs[0], scale_factor=4, mode='bilinear', align_corners=False)
+        prob_2_up = F.interpolate(probs[1], scale_factor=2, mode='bilinear', align_corners=False)
+        return {
+            "depth": ests[2].squeeze(1),
+            "depth_est_list": [ests[2].squeeze(1), ests[1].squeeze(1), ests[0].squeeze(1)],
+            "depth_pair_list": [pairs[2], pairs[1], pairs[0]],
+            "photometric_confidence": torch.cat([prob_1_up, prob_2_up, probs[2]], dim=1),
+        }

@@ -1,0 +1,212 @@
+"""Drop-in for the live parts of the reference's ``models/VisMVSNet/model_cas.py`` on the pscv engine.
+
+Per cascade stage (reference model_cas.py:303-420, mode 'soft'):
+    one fused launch  warp (HOMOG geometry) + group-wise correlation for ALL source views
+    per source view   3-D U-Net `Reg` (7 MFMA conv launches, the cat() is a channel-slice view) -> 1-channel head
+                      (dot2 kernel) -> fused softmax / expected index / entropy -> 2-D UncertNet (PyTorch-ROCm)
+    one launch        visibility-weighted fusion of the pair volumes (pscv_fuse_pairs)
+    `RegFuse`         U-Net + head -> fused softmax with the +-2 window probability
+Same module tree and state-dict keys as the reference (FeatExt / Reg / RegPair / RegFuse / UncertNet / SingleStage /
+Model), so released checkpoints load unchanged."""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ... import _lib as L
+from ... import ops
+from .nn_utils import UNet
+
+cpg = 8
+
+
+class FeatExt(nn.Module):
+    """Upstream 2-D extractor: three 32-channel maps at 1/8, 1/4, 1/2 (reference model_cas.py:18-35)."""
+
+    def __init__(self):
+        super().__init__()
+        self.init_conv = nn.Sequential(nn.Conv2d(3, 16, 5, 2, 2, bias=False), nn.BatchNorm2d(16), nn.ReLU())
+        self.unet = UNet(16, 2, 1, 2, [], [32, 64, 128], [], '2d', 2)
+        self.final_conv_1 = nn.Conv2d(128, 32, 3, 1, 1, bias=False)
+        self.final_conv_2 = nn.Conv2d(64, 32, 3, 1, 1, bias=False)
+        self.final_conv_3 = nn.Conv2d(32, 32, 3, 1, 1, bias=False)
+
+    def forward(self, x):
+        o1, o2, o3 = self.unet(self.init_conv(x), multi_scale=3)
+        return self.final_conv_1(o1), self.final_conv_2(o2), self.final_conv_3(o3)
+
+
+def _bn_tuple(bn):
+    return (bn.weight, bn.bias, bn.running_mean, bn.running_var)
+
+
+class _RegUNet(nn.Module):
+    """Holder + engine executor of ``UNet(8, 1, 0, 4, [], [8, 16], [], tag, dim=3)`` (nn_utils.py:194-278)."""
+
+    def __init__(self, tag: str):
+        super().__init__()
+        self.unet = UNet(8, 1, 0, 4, [], [8, 16], [], tag, dim=3)
+        self._lay, self._key = None, None
+
+    def _layers(self, dtype) -> Dict[str, ops.Conv3dLayer]:
+        key = (dtype,) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        if self._lay is None or key != self._key:
+            enc = list(self.unet.enc_blocks.values())
+            b0, b1 = enc[0][0], enc[1][0]
+            dec = list(self.unet.dec_blocks.values())[0]
+            dev = b0.conv1.weight.device
+            mk = ops.Conv3dLayer.build
+            # the strided 1x1x1 shortcut conv is the centre tap of a 3x3x3 stride-2 conv (in = 2*out + 1 - 1)
+            ds_w = torch.zeros(16, 8, 3, 3, 3, dtype=torch.float32, device=dev)
+            ds_w[:, :, 1, 1, 1] = b1.downsample[0].weight.detach().float().view(16, 8)
+            self._lay = {
+                "e0c1": mk(b0.conv1.weight, kind=L.CONV_S1, device=dev, bn=_bn_tuple(b0.bn1), bn_eps=b0.bn1.eps, relu=True, dtype=dtype),
+                "e0c2": mk(b0.conv2.weight, kind=L.CONV_S1, device=dev, bn=_bn_tuple(b0.bn2), bn_eps=b0.bn2.eps, relu_post=True, dtype=dtype),
+                "e1c1": mk(b1.conv1.weight, kind=L.CONV_S2, device=dev, bn=_bn_tuple(b1.bn1), bn_eps=b1.bn1.eps, relu=True, dtype=dtype),
+                "e1ds": mk(ds_w, kind=L.CONV_S2, device=dev, bn=_bn_tuple(b1.downsample[1]), bn_eps=b1.downsample[1].eps, dtype=dtype),
+                "e1c2": mk(b1.conv2.weight, kind=L.CONV_S1, device=dev, bn=_bn_tuple(b1.bn2), bn_eps=b1.bn2.eps, relu_post=True, dtype=dtype),
+                "dec": mk(dec[0].weight, kind=L.CONV_T2, transposed=True, device=dev, dtype=dtype),
+                "post": mk(dec[1].weight, kind=L.CONV_S1, device=dev, dtype=dtype),
+            }
+            self._key = key
+        return self._lay
+
+    def run_unet(self, x: torch.Tensor) -> torch.Tensor:
+        """x [n,d,h,w,8] 16-bit channels-last -> [n,d,h,w,8]."""
+        if self.training:
+            raise NotImplementedError("pscv Vis U-Net: inference only for now; call .eval()")
+        n, d, h, w, _ = x.shape
+        if d % 2 or h % 2 or w % 2:
+            raise ValueError(f"Vis U-Net needs even d,h,w (got {d},{h},{w}), as in the reference")
+        ly = self._layers(x.dtype)
+        cat = torch.empty((n, d, h, w, 16), dtype=x.dtype, device=x.device)       # [deconv | enc0] (nn_utils.py:269-271)
+        t = ops.conv3d(x, ly["e0c1"])
+        ops.conv3d(t, ly["e0c2"], skip=x, out=cat, out_coff=8)                    # enc0 -> cat[..., 8:16]
+        t1 = ops.conv3d(cat, ly["e1c1"], in_coff=8)
+        ds = ops.conv3d(cat, ly["e1ds"], in_coff=8)
+        e1 = ops.conv3d(t1, ly["e1c2"], skip=ds)
+        ops.conv3d(e1, ly["dec"], out=cat, out_coff=0)                            # deconv -> cat[..., 0:8]
+        return ops.conv3d(cat, ly["post"])
+
+
+class Reg(_RegUNet):            # reference model_cas.py:38-48
+    def __init__(self):
+        super().__init__('reg1')
+        self.init_conv = lambda x: x
+
+    def forward(self, x):
+        return self.run_unet(x)
+
+
+class _Head(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.final_conv = nn.Conv3d(8, 1, 3, 1, 1, bias=False)
+        self._hl, self._hk = None, None
+
+    def head(self, x: torch.Tensor) -> torch.Tensor:
+        """[n,d,h,w,8] -> fp32 scores [n,d,h,w]."""
+        w = self.final_conv.weight
+        key = (x.dtype, w.data_ptr(), w._version)
+        if self._hl is None or key != self._hk:
+            self._hl, self._hk = ops.Conv3dLayer.build(w, kind=L.CONV_S1, device=w.device, dtype=x.dtype), key
+        return ops.conv3d(x, self._hl, out_dtype=torch.float32).squeeze(-1)
+
+
+class RegPair(_Head):           # reference model_cas.py:51-59
+    def forward(self, x):
+        return self.head(x)
+
+
+class RegFuse(_RegUNet):        # reference model_cas.py:62-74
+    def __init__(self):
+        super().__init__('reg2')
+        self.init_conv = lambda x: x
+        self.final_conv = nn.Conv3d(8, 1, 3, 1, 1, bias=False)
+        self._hl, self._hk = None, None
+
+    head = _Head.head
+
+    def forward(self, x):
+        return self.head(self.run_unet(x))
+
+
+class UncertNet(nn.Module):
+    """2-D entropy -> log-uncertainty net (reference model_cas.py:77-98); small 2-D convs, PyTorch-ROCm."""
+
+    def __init__(self, num_heads=1):
+        super().__init__()
+        self.conv1 = nn.Sequential(nn.Conv2d(1, 8, 3, 1, 1, bias=False), nn.BatchNorm2d(8), nn.ReLU())
+        self.conv2 = nn.Sequential(nn.Conv2d(8, 8, 3, 1, 1, bias=False), nn.BatchNorm2d(8), nn.ReLU())
+        self.head_convs = nn.ModuleList([nn.Conv2d(8, 1, 3, 1, 1, bias=False) for _ in range(num_heads)])
+
+    def forward(self, x):
+        out = self.conv2(self.conv1(x))
+        out = out + x
+        return [conv(out) for conv in self.head_convs]
+
+
+class SingleStage(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.reg = Reg()
+        self.reg_fuse = RegFuse()
+        self.reg_pair = RegPair()
+        self.uncert_net = UncertNet(1)
+        self.storage_dtype = torch.float16
+
+    def build_cost_volume(self, ref, ref_cam, srcs, srcs_cam, depth_num, depth_start, depth_interval, s_scale):
+        """Pair-wise group-correlation volumes of ALL source views in one fused launch: [n_src,n,d,h,w,8]
+        (reference model_cas.py:176-186 + groupwise_correlation at :340)."""
+        n, _, h, w = ref.shape
+        steps = torch.arange(depth_num, dtype=torch.float32, device=ref.device).view(1, depth_num, 1, 1)
+        planes = (depth_start + depth_interval * steps).to(torch.float32)            # homography.py:39-41
+        planes = planes.reshape(n, depth_num) if planes.shape[2:] == (1, 1) else planes.expand(n, depth_num, h, w)
+        cams = ops.homog_cams_device(ref_cam, srcs_cam, 1.0 / s_scale)
+        ref_cl = ops.to_channels_last(ref, self.storage_dtype)
+        srcs_cl = [ops.to_channels_last(s, self.storage_dtype) for s in srcs]
+        return ops.warp_cost(ref_cl, srcs_cl, cams, planes.contiguous(), geom=L.GEOM_HOMOG, cost=L.COST_GROUPCORR,
+                             out_dtype=self.storage_dtype)
+
+    def forward(self, sample, depth_num, upsample=False, mem=False, mode='soft', depth_start_override=None,
+                depth_interval_override=None, s_scale=1, taps: Optional[dict] = None):
+        if mem or mode != 'soft' or upsample:
+            raise NotImplementedError("pscv Vis-MVSNet implements the reference's live configuration: mode='soft', "
+                                      "no mem, no upsample (frontend.py:28-30)")
+        if self.training:
+            raise NotImplementedError("pscv Vis-MVSNet: inference only for now; call .eval()")
+        ref_feat, ref_cam, srcs_feat, srcs_cam = sample
+        depth_start = ref_cam[:, 1:2, 3:4, 0:1] if depth_start_override is None else depth_start_override
+        depth_interval = ref_cam[:, 1:2, 3:4, 1:2] if depth_interval_override is None else depth_interval_override
+        costs = self.build_cost_volume(ref_feat, ref_cam, srcs_feat, srcs_cam, depth_num, depth_start, depth_interval, s_scale)
+        interms, uncerts, pair_results = [], [], []
+        for i in range(len(srcs_feat)):
+            interm = self.reg(costs[i])
+            score = self.reg_pair(interm)                                              # fp32 [n,d,h,w]
+            o = ops.softargmin(score, None, want_index=True, want_entropy=True)
+            est_depth = o["index"].unsqueeze(1) * depth_interval + depth_start         # model_cas.py:348
+            heads = self.uncert_net(o["entropy"].unsqueeze(1))
+            pair_results.append([est_depth, heads])
+            interms.append(interm)
+            uncerts.append(heads[0].squeeze(1).to(torch.float32).contiguous())
+            if taps is not None and i == 0:
+                taps.update(cost0=costs[0], interm0=interm, score0=score, entropy0=o["entropy"], uncert0=heads[0])
+        fused = ops.fuse_pairs(interms, uncerts)                                       # model_cas.py:354-357,385-386
+        score = self.reg_fuse(fused)
+        o = ops.softargmin(score, None, want_index=True, want_conf=True, conf_mode=1, window=2.0)
+        est_depth = o["index"].unsqueeze(1) * depth_interval + depth_start             # model_cas.py:404-405
+        if taps is not None:
+            taps.update(fused=fused, score=score)
+        return est_depth, o["conf"].unsqueeze(1), pair_results
+
+
+class Model(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.feat_ext = FeatExt()
+        self.stage1 = SingleStage()
+        self.stage2 = SingleStage()
+        self.stage3 = SingleStage()

@@ -151,6 +151,41 @@ def proj_cams_device(proj: torch.Tensor, reference_frame: int = 0) -> torch.Tens
     return cams
 
 
+def homog_cams_device(ref_cam: torch.Tensor, src_cams: Sequence[torch.Tensor], scale: float) -> torch.Tensor:
+    """HOMOG-geometry camera blocks [n_src,B,18] (A[9], Bm[9]) from Vis-style cam arrays [B,2,4,4] in one HIP
+    launch (pscv_homog_cams); ``scale`` = 1 / s_scale is applied to the intrinsics like scale_camera."""
+    src = torch.stack(list(src_cams)).to(torch.float32).contiguous()
+    ref = ref_cam.to(torch.float32).contiguous()
+    _dev(ref, src)
+    n, B = src.shape[:2]
+    cams = torch.empty((n, B, L.CAM_FLOATS), dtype=torch.float32, device=ref.device)
+    rc = _launch("homog_cams", lambda: L.lib().pscv_homog_cams(_p(ref), _p(src), B, n, float(scale), _p(cams), _stream()))
+    L.check(rc, "pscv_homog_cams")
+    return cams
+
+
+def fuse_pairs(interms: Sequence[torch.Tensor], uncerts: Sequence[torch.Tensor], *, normalise: bool = True,
+               want_wsum: bool = False):
+    """interms n x [B,D,h,w,8] (16-bit), uncerts n x [B,h,w] fp32 -> fused [B,D,h,w,8] (same dtype, normalised)
+    or fp32 partial sums (normalise=False); optionally also the weight sum [B,h,w]."""
+    interms, uncerts = list(interms), list(uncerts)
+    _dev(*interms, *uncerts)
+    B, D, h, w, c = interms[0].shape
+    if c != 8 or any(t.shape != interms[0].shape or t.dtype != interms[0].dtype for t in interms):
+        raise ValueError("pscv.fuse_pairs: pair volumes must share shape [B,D,h,w,8] and dtype")
+    if any(u.dtype != torch.float32 or tuple(u.shape) != (B, h, w) for u in uncerts) or len(uncerts) != len(interms):
+        raise ValueError("pscv.fuse_pairs: uncertainty maps must be fp32 [B,h,w], one per pair volume")
+    n = len(interms)
+    out = torch.empty((B, D, h, w, 8), dtype=interms[0].dtype if normalise else torch.float32, device=interms[0].device)
+    wsum = torch.empty((B, h, w), dtype=torch.float32, device=out.device) if want_wsum else None
+    ip = (C.c_void_p * n)(*[t.data_ptr() for t in interms])
+    up = (C.c_void_p * n)(*[t.data_ptr() for t in uncerts])
+    rc = _launch("fuse_pairs", lambda: L.lib().pscv_fuse_pairs(ip, up, n, _dt(interms[0]), _p(out), _p(wsum), int(normalise),
+                                                               B, D, h, w, _stream()))
+    L.check(rc, "pscv_fuse_pairs")
+    return (out, wsum) if want_wsum else out
+
+
 # --------------------------------------------------------------------------------------------
 # fused warp + cost
 # --------------------------------------------------------------------------------------------
