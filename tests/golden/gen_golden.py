@@ -195,6 +195,66 @@ def gen_vis(tag, *, H=64, W=96, V=3, depth_nums=(16, 8, 4), interval_scales=(8.0
     save(f"{tag}.npz", **arrays)
 
 
+def gen_cvp(tag, *, H=32, W=48, V=3, nscale=2, seed=0, scene_seed=0, baseline_scale=8):
+    sys.path.insert(0, REPO)
+    from wild_deep_mvs_amd import synthetic
+    from models.CVP_MVSNet.frontend import Frontend  # reference
+    import models.CVP_MVSNet.models.net as NET
+
+    torch.manual_seed(0)
+    net = Frontend()
+    sd = synthetic.sharpened_state_dict("cvp", synthetic.template_of(net), seed=seed)
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    net.model.nscale = nscale
+    scene = synthetic.make_scene(1, V, H, W, seed=scene_seed)
+    # wider baseline: calDepthHypo's interval (depth change per source pixel) stays a fraction of the depth range
+    scene["t"] = scene["t"] * baseline_scale
+    cap = {}
+    orig_reg = net.model.cost_reg_refine.forward
+    orig_hypo, orig_pc = NET.calDepthHypo, NET.proj_cost
+
+    def reg(x):
+        cap.setdefault("cost", []).append(x.clone())
+        out = orig_reg(x)
+        cap.setdefault("logits", []).append(out)
+        return out
+
+    def hypo(*a, **k):
+        out = orig_hypo(*a, **k)
+        cap.setdefault("hypos", []).append(out)
+        return out
+
+    net.model.cost_reg_refine.forward = reg
+    NET.calDepthHypo = hypo
+    try:
+        with torch.no_grad():
+            out = net(scene["imgs"], scene["K"], scene["R"], scene["t"], scene["depth_min"], scene["depth_max"], nscale=nscale)
+            pyr = [net.model.featurePyramid(im, nscale) for im in torch.unbind(scene["imgs"], 1)]
+    finally:
+        net.model.cost_reg_refine.forward = orig_reg
+        NET.calDepthHypo = orig_hypo
+    p0 = torch.softmax(cap["logits"][0], 1)
+    print(f"[{tag}] coarse max prob mean {p0.max(1)[0].mean():.3f}, refine max prob {torch.softmax(cap['logits'][-1], 1).max(1)[0].mean():.3f}, "
+          f"depth range {out['depth'].min():.3f}..{out['depth'].max():.3f}, conf mean {out['photometric_confidence'].mean():.3f}")
+    arrays = dict(meta=np.array([H, W, V, nscale, seed, scene_seed, baseline_scale], dtype=np.int64),
+                  depth=np32(out["depth"]), photometric_confidence=np32(out["photometric_confidence"]),
+                  coarse_planes=np.array(PLANES96, dtype=np.int64),
+                  coarse_cost=np32(cap["cost"][0][:, :, PLANES96]), coarse_logits=np32(cap["logits"][0]))
+    for i, d in enumerate(out["depth_est_list"]):
+        arrays[f"depth_est_{i}"] = np32(d)
+    for lvl in range(nscale):
+        arrays[f"pyr_l{lvl}"] = np.stack([np32(p[lvl]) for p in pyr])
+    for i in range(1, len(cap["cost"])):
+        arrays[f"refine{i}_hypos"] = np32(cap["hypos"][i - 1])
+        arrays[f"refine{i}_cost"] = np32(cap["cost"][i])
+        arrays[f"refine{i}_logits"] = np32(cap["logits"][i])
+    save(f"{tag}.npz", **arrays)
+
+
+PLANES96 = [0, 40, 95]
+
+
 def gen_state_dict_keys():
     """Key order, names and shapes of the reference's state dicts (the checkpoint-compat contract)."""
     import json
@@ -225,6 +285,7 @@ def main():
         "mvsnet_behind": lambda: gen_mvsnet("variance", "mvsnet_behind", V=4, behind_view=2, scene_seed=5),
         "mvsnet_s": lambda: gen_mvsnet("softmin", "mvsnet_s_tiny", seed=1),
         "vis": lambda: gen_vis("vis_tiny"),
+        "cvp": lambda: gen_cvp("cvp_tiny"),
         "keys": gen_state_dict_keys,
     }
     for k, fn in todo.items():

@@ -253,11 +253,25 @@ def test_vis_state_dict_keys_and_shapes_match_reference():
     assert net.depth_nums == [32, 16, 8] and net.interval_scales == [4, 2, 1]      # frontend.py:10-11
 
 
+def test_cvp_state_dict_keys_and_shapes_match_reference():
+    ref = json.load(open(os.path.join(GOLDEN, "state_dict_keys.json")))["cvp"]
+    from wild_deep_mvs_amd.models.CVP_MVSNet.frontend import Frontend
+    net = Frontend()
+    assert [[k, list(v.shape)] for k, v in net.state_dict().items()] == ref
+    assert net.model.nscale == 2                                                   # net.py:92-93
+
+
 def test_reference_import_paths_resolve():
     import wild_deep_mvs_amd
     wild_deep_mvs_amd.install_as_models()
     from models.MVSNet.model import MVSNet            # reference train.py:33
     from models.MVSNet.module import homo_warping, depth_regression   # noqa: F401
+    from models.VisMVSNet.frontend import Frontend as Vis             # reference train.py:34
+    from models.CVP_MVSNet.frontend import Frontend as CVP            # reference train.py:35
+    from models.VisMVSNet.homography import homography_warping, get_homographies   # noqa: F401
+    from models.VisMVSNet.nn_utils import soft_argmin, entropy, groupwise_correlation   # noqa: F401
+    from models.CVP_MVSNet.models.modules import proj_cost            # noqa: F401
+    assert Vis().depth_nums == [32, 16, 8] and CVP().model.nscale == 2
     net = MVSNet("variance")
     assert net.num_depth == 192
     with pytest.raises(RuntimeError, match="no CPU"):

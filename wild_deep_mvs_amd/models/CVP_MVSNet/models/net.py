@@ -1,0 +1,144 @@
+"""Drop-in for the reference's ``models/CVP_MVSNet/models/net.py`` on the pscv engine: feature pyramid (upstream,
+PyTorch-ROCm), the CVP 3-D regulariser on MFMA conv launches, and the coarse-to-fine ``network.forward``."""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .... import _lib as L
+from .... import ops
+from ...MVSNet.module import deconv_engine_layer
+from .modules import (ConvBnReLU3D, calDepthHypo, calSweepingDepthHypo, conditionIntrinsics, conv, proj_cost, _cams)
+
+
+class FeaturePyramid(nn.Module):
+    """16-channel features at every pyramid level, finest first (reference net.py:21-47)."""
+    _names = ("conv0aa", "conv0ba", "conv0bb", "conv0bc", "conv0bd", "conv0be", "conv0bf", "conv0bg", "conv0bh")
+    _chans = ((3, 64), (64, 64), (64, 64), (64, 32), (32, 32), (32, 32), (32, 16), (16, 16), (16, 16))
+
+    def __init__(self):
+        super().__init__()
+        for name, (ci, co) in zip(self._names, self._chans):
+            setattr(self, name, conv(ci, co, kernel_size=3, stride=1))
+
+    def _tower(self, x):
+        for name in self._names:
+            x = getattr(self, name)(x)
+        return x
+
+    def forward(self, img, scales=5):
+        levels = [self._tower(img)]
+        for _ in range(scales - 1):
+            img = F.interpolate(img, scale_factor=0.5, mode='bilinear', align_corners=None).detach()
+            levels.append(self._tower(img))
+        return levels
+
+
+class CostRegNet(nn.Module):
+    """CVP regulariser (reference net.py:50-85) on the engine: [B,D,h,w,16] 16-bit -> fp32 logits [B,D,h,w]."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv0 = ConvBnReLU3D(16, 16, kernel_size=3, pad=1)
+        self.conv0a = ConvBnReLU3D(16, 16, kernel_size=3, pad=1)
+        self.conv1 = ConvBnReLU3D(16, 32, stride=2, kernel_size=3, pad=1)
+        self.conv2 = ConvBnReLU3D(32, 32, kernel_size=3, pad=1)
+        self.conv2a = ConvBnReLU3D(32, 32, kernel_size=3, pad=1)
+        self.conv3 = ConvBnReLU3D(32, 64, kernel_size=3, pad=1)
+        self.conv4 = ConvBnReLU3D(64, 64, kernel_size=3, pad=1)
+        self.conv4a = ConvBnReLU3D(64, 64, kernel_size=3, pad=1)
+        self.conv5 = nn.Sequential(nn.ConvTranspose3d(64, 32, kernel_size=3, padding=1, output_padding=0, stride=1, bias=False),
+                                   nn.BatchNorm3d(32), nn.ReLU(inplace=True))
+        self.conv6 = nn.Sequential(nn.ConvTranspose3d(32, 16, kernel_size=3, padding=1, output_padding=1, stride=2, bias=False),
+                                   nn.BatchNorm3d(16), nn.ReLU(inplace=True))
+        self.prob0 = nn.Conv3d(16, 1, 3, stride=1, padding=1)
+        self._lay, self._key = None, None
+
+    def engine_layers(self, dtype) -> Dict[str, ops.Conv3dLayer]:
+        key = (dtype,) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        if self._lay is None or key != self._key:
+            dev = self.prob0.weight.device
+            lay = {n: getattr(self, n).engine_layer(dev, dtype)
+                   for n in ("conv0", "conv0a", "conv1", "conv2", "conv2a", "conv3", "conv4", "conv4a")}
+            lay["conv5"] = deconv_engine_layer(self.conv5, dev, stride=1, dtype=dtype)   # stride-1 deconv == flipped conv
+            lay["conv6"] = deconv_engine_layer(self.conv6, dev, stride=2, dtype=dtype)
+            lay["prob0"] = ops.Conv3dLayer.build(self.prob0.weight, kind=L.CONV_S1, device=dev, conv_bias=self.prob0.bias, dtype=dtype)
+            self._lay, self._key = lay, key
+        return self._lay
+
+    def forward(self, x: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
+        if self.training:
+            raise NotImplementedError("pscv CVP CostRegNet: inference only for now; call .eval()")
+        B, D, h, w, _ = x.shape
+        if D % 2 or h % 2 or w % 2:
+            raise ValueError(f"CVP CostRegNet needs even D,h,w (got {D},{h},{w}), as in the reference")
+        ly = self.engine_layers(x.dtype)
+        c0 = ops.conv3d(ops.conv3d(x, ly["conv0"]), ly["conv0a"])
+        c2 = ops.conv3d(ops.conv3d(ops.conv3d(c0, ly["conv1"]), ly["conv2"]), ly["conv2a"])
+        c4 = ops.conv3d(ops.conv3d(ops.conv3d(c2, ly["conv3"]), ly["conv4"]), ly["conv4a"])
+        c5 = ops.conv3d(c4, ly["conv5"], skip=c2)          # conv2 + relu(bn(deconv))   net.py:81
+        c6 = ops.conv3d(c5, ly["conv6"], skip=c0)          # net.py:82
+        logits = ops.conv3d(c6, ly["prob0"], out_dtype=torch.float32)
+        if taps is not None:
+            taps.update(conv0=c0, conv2=c2, conv4=c4, conv5=c5, conv6=c6)
+        return logits.view(B, D, h, w)
+
+
+class network(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.featurePyramid = FeaturePyramid()
+        self.cost_reg_refine = CostRegNet()
+        self.nscale = 2
+        self.storage_dtype = torch.float16
+
+    def forward(self, ref_img, src_imgs, ref_in, src_in, ref_ex, src_ex, depth_min, depth_max, **kwargs):
+        if self.training:
+            raise NotImplementedError("pscv CVP-MVSNet: inference only for now; call .eval()")
+        nscale = kwargs.get("nscale", self.nscale)
+        taps = kwargs.get("taps")
+        nsrc = len(src_imgs)
+        dt = self.storage_dtype
+        with torch.no_grad():
+            ref_pyr = self.featurePyramid(ref_img, nscale)
+            src_pyrs = [self.featurePyramid(s, nscale) for s in src_imgs]
+            ref_in_ms = conditionIntrinsics(ref_in, ref_img.shape, [f.shape for f in ref_pyr])
+            src_in_ms = torch.stack([conditionIntrinsics(src_in[:, i], ref_img.shape, [f.shape for f in src_pyrs[i]])
+                                     for i in range(nsrc)]).permute(1, 0, 2, 3, 4)
+
+            # coarsest level: fronto-parallel sweep, 96 planes in eval mode (net.py:126-127)
+            hypos = calSweepingDepthHypo(ref_in_ms[:, -1], src_in_ms[:, 0, -1], ref_ex, src_ex, depth_min, depth_max,
+                                         nhypothesis_init=96).to(torch.float32).contiguous()
+            cams = _cams(ref_in_ms[:, -1], [src_in_ms[:, i, -1] for i in range(nsrc)], ref_ex, [src_ex[:, i] for i in range(nsrc)])
+            cost = ops.warp_cost(ops.to_channels_last(ref_pyr[-1], dt), [ops.to_channels_last(p[-1], dt) for p in src_pyrs],
+                                 cams, hypos, geom=L.GEOM_PROJ, cost=L.COST_VARIANCE_CVP, out_dtype=dt)
+            lt = {} if taps is not None else None
+            logits = self.cost_reg_refine(cost, lt)
+            is_last = nscale == 1
+            o = ops.softargmin(logits, hypos, want_conf=is_last, conf_mode=0)
+            depth = o["depth"]
+            depth_est_list = [depth]
+            if taps is not None:
+                lt.update(cost=cost, logits=logits, hypos=hypos)
+                taps.update(coarse=lt, refine=[])
+
+            for id_level, level in enumerate(range(nscale - 2, -1, -1)):
+                depth_up = F.interpolate(depth[None, :], size=None, scale_factor=2, mode='bicubic', align_corners=None).squeeze(0)
+                hyp = calDepthHypo(depth_up, ref_in_ms[:, level], src_in_ms[:, :, level], ref_ex, src_ex, depth_min,
+                                   depth_max, level).contiguous()
+                cost = proj_cost(nsrc, ref_pyr[level], src_pyrs, level, ref_in_ms[:, level], src_in_ms[:, :, level],
+                                 ref_ex, src_ex, hyp, storage_dtype=dt)
+                lt = {} if taps is not None else None
+                logits = self.cost_reg_refine(cost, lt)
+                is_last = level == 0
+                o = ops.softargmin(logits, hyp, want_conf=is_last, conf_mode=0)
+                depth = o["depth"]
+                depth_est_list.append(depth)
+                if taps is not None:
+                    lt.update(cost=cost, logits=logits, hypos=hyp)
+                    taps["refine"].append(lt)
+        depth_est_list.reverse()
+        return {"depth_est_list": depth_est_list, "prob_confidence": o["conf"]}

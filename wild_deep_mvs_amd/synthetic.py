@@ -150,7 +150,7 @@ def template_of(module: torch.nn.Module) -> "OrderedDict[str, Tuple[int, ...]]":
 SHARPEN = {
     "mvsnet": dict(conv_gain=1.414, head_gain={"feature.": 0.85, "cost_regularization.prob.weight": 10.0}),
     "vis": dict(conv_gain=1.0, head_gain={"final_conv.weight": 2.0}),
-    "cvp": dict(conv_gain=1.3, head_gain={"prob0.weight": 6.0}),
+    "cvp": dict(conv_gain=1.2, head_gain={"prob0.weight": 12.0}),
 }
 TRANSPOSED_KEYS = {
     "mvsnet": ("cost_regularization.conv7.0", "cost_regularization.conv9.0", "cost_regularization.conv11.0"),
