@@ -203,3 +203,41 @@ def test_one_channel_dot2_kernel_matches_mfma_kernel_and_aten(env, cin, shape, o
     tol = 3e-3 if out_dtype is not None else (2 ** -8 if dtype == torch.bfloat16 else 2 ** -11) * float(ref.abs().max()) + 1e-3
     check_close(f"dot2 kernel vs ATen cin={cin} {shape} {dtype}", outs[True], ref, max_abs=tol)
     check_close(f"dot2 kernel vs MFMA kernel cin={cin} {shape} {dtype}", outs[True], outs[False], max_abs=tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(4, 8, 16), (3, 5, 19), (7, 9, 33)])
+def test_parity_pair_deconv_matches_generic_kernel_and_aten(env, shape, dtype):
+    """The 16->8 stride-2 transposed conv on the parity-pair kernel (PSCV_CONV_T2P8) against the generic T2 kernel and
+    ATen, with BN + ReLU + skip, sizes off the 2x4x16 tile, and a channel-slice output (the Vis U-Net's cat buffer)."""
+    L, ops = env
+    g = torch.Generator().manual_seed(sum(shape))
+    D, H, W = shape
+    x = bf16_round(torch.randn(2, 16, D, H, W, generator=g))
+    w = bf16_round(torch.randn(16, 8, 3, 3, 3, generator=g) / np.sqrt(27 * 16))
+    gamma, beta = torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g) * 0.3
+    mean, var = torch.randn(8, generator=g) * 0.2, torch.rand(8, generator=g) + 0.5
+    skip = bf16_round(torch.randn(2, 8, 2 * D, 2 * H, 2 * W, generator=g))
+    ref = F.relu(F.batch_norm(F.conv_transpose3d(x, w, stride=2, padding=1, output_padding=1), mean, var, gamma, beta,
+                              training=False, eps=1e-5)) + skip
+    xcl, scl = ops.to_channels_last(x.cuda(), dtype), ops.to_channels_last(skip.cuda(), dtype)
+    outs = {}
+    for use in (True, False):
+        ops.USE_SWEEP_KERNEL = use
+        try:
+            layer = ops.Conv3dLayer.build(w, kind=L.CONV_T2, transposed=True, device="cuda", bn=(gamma, beta, mean, var),
+                                          relu=True, dtype=dtype)
+        finally:
+            ops.USE_SWEEP_KERNEL = True
+        assert layer.kind == (L.CONV_T2P8 if use else L.CONV_T2)
+        outs[use] = ops.conv3d(xcl, layer, skip=scl, out_dtype=torch.float32).permute(0, 4, 1, 2, 3).cpu()
+    check_close(f"t2p8 vs ATen {shape} {dtype}", outs[True], ref, max_abs=3e-3, rel_l2=2e-4)
+    check_close(f"t2p8 vs generic T2 {shape} {dtype}", outs[True], outs[False], max_abs=1e-4)
+    # write into channels [0, 8) of a 16-channel buffer, linear epilogue (Vis decoder)
+    lin = ops.Conv3dLayer.build(w, kind=L.CONV_T2, transposed=True, device="cuda", dtype=dtype)
+    buf = torch.full((2, 2 * D, 2 * H, 2 * W, 16), 3.0, dtype=dtype, device="cuda")
+    ops.conv3d(xcl, lin, out=buf, out_coff=0)
+    want = F.conv_transpose3d(x, w, stride=2, padding=1, output_padding=1)
+    check_close("t2p8 slice output", buf[..., :8].float().permute(0, 4, 1, 2, 3).cpu(), want,
+                max_abs=(2 ** -8 if dtype == torch.bfloat16 else 2 ** -11) * float(want.abs().max()) + 1e-3)
+    assert float((buf[..., 8:].float() - 3.0).abs().max()) == 0.0

@@ -164,6 +164,42 @@ def test_sweep_pair_packing_contracts_like_the_kernel():
     np.testing.assert_allclose(out[:D], ref.permute(1, 2, 3, 0).numpy(), atol=2e-4 * float(ref.abs().max()), rtol=0)
 
 
+def test_parity_pair_deconv_packing_contracts_like_the_kernel():
+    """PSCV_CONV_T2P8: numpy emulation of conv3d_t2p8.hip's contraction (9 k-steps, rows 0-7 / 8-15 = output x
+    parity 0 / 1, K = two W taps x 16 channels) vs ATen's ConvTranspose3d(k3, s2, p1, op1)."""
+    rng = np.random.default_rng(9)
+    w = _bf16(rng.standard_normal((16, 8, 3, 3, 3)).astype(np.float32))
+    D, H, W = 2, 3, 3
+    x = _bf16(rng.standard_normal((D, H, W, 16)).astype(np.float32))
+    wk = ops.pack_conv3d_weights(torch.from_numpy(w), L.CONV_T2P8, True, torch.float16).view(np.float16).astype(np.float32).reshape(9, 64, 8)
+    out = np.zeros((2 * D, 2 * H, 2 * W, 8), np.float32)
+
+    def X(d, h, w_, c0):
+        return x[d, h, w_, c0:c0 + 8] if (d < D and h < H and w_ < W) else np.zeros(8, np.float32)
+
+    for id_ in range(D):
+        for ih in range(H):
+            for iw in range(W):
+                step = 0
+                for pd in range(2):
+                    for ph in range(2):
+                        acc = np.zeros(16, np.float32)
+                        for sd in range(pd + 1):
+                            for sh in range(ph + 1):
+                                od = 1 if (pd and sd == 0) else 0
+                                oh = 1 if (ph and sh == 0) else 0
+                                for g in range(4):
+                                    xv = X(id_ + od, ih + oh, iw + (g >> 1), (g & 1) * 8)
+                                    for m in range(16):
+                                        acc[m] += wk[step, m + 16 * g] @ xv
+                                step += 1
+                        out[2 * id_ + pd, 2 * ih + ph, 2 * iw] = acc[:8]
+                        out[2 * id_ + pd, 2 * ih + ph, 2 * iw + 1] = acc[8:]
+    ref = F.conv_transpose3d(torch.from_numpy(x).permute(3, 0, 1, 2).unsqueeze(0), torch.from_numpy(w), stride=2, padding=1,
+                             output_padding=1)[0].permute(1, 2, 3, 0).numpy()
+    np.testing.assert_allclose(out, ref, atol=2e-4 * np.abs(ref).max(), rtol=0)
+
+
 def test_one_channel_packing_layout():
     """PSCV_CONV_S1C1: [tap = kd*9 + kh*3 + kw][c_in] 16-bit values."""
     rng = np.random.default_rng(2)

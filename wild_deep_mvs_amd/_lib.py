@@ -20,7 +20,7 @@ ABI_VERSION = 1
 F32, BF16, F16 = 0, 1, 2
 GEOM_PROJ, GEOM_HOMOG = 0, 1
 COST_VARIANCE, COST_VARIANCE_CVP, COST_SOFTMIN, COST_GROUPCORR, COST_WARP_ONLY = 0, 1, 2, 3, 4
-CONV_S1, CONV_S2, CONV_T2, CONV_S1P8, CONV_S1C1 = 0, 1, 2, 3, 4
+CONV_S1, CONV_S2, CONV_T2, CONV_S1P8, CONV_S1C1, CONV_T2P8 = 0, 1, 2, 3, 4, 5
 EPI_RELU_PRE, EPI_RELU_POST = 1, 2
 MAX_SRC = 16
 CAM_FLOATS = 18

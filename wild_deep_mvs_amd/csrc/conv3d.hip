@@ -311,7 +311,9 @@ static int launch_kind(ConvArgs& a, int kind, hipStream_t st) {
               rw = kind == PSCV_CONV_T2 ? a.Wi : a.Wo;
     const int TDb = kind == PSCV_CONV_S1 ? 4 : 2, THb = kind == PSCV_CONV_S2 ? 2 : 4;
     const long big = (long)a.B * ceil_div(rd, TDb) * ceil_div(rh, THb) * ceil_div(rw, 16);
-    const bool small = big < 1024 && g_conv_small_tiles;
+    // (stride-2 layers keep the large variant: both have 4 row-tiles per workgroup and the N-split would only
+    //  re-read the 5x5x33 input brick once per output tile)
+    const bool small = big < 1024 && g_conv_small_tiles && kind != PSCV_CONV_S2;
     switch (kind) {
         case PSCV_CONV_S1: return small ? launch_conv<H, CIN, 1, PSCV_CONV_S1, 1, 4>(a, NT, st) : launch_conv<H, CIN, NT, PSCV_CONV_S1, 4, 4>(a, 1, st);
         case PSCV_CONV_S2: return small ? launch_conv<H, CIN, 1, PSCV_CONV_S2, 1, 4>(a, NT, st) : launch_conv<H, CIN, NT, PSCV_CONV_S2, 2, 2>(a, 1, st);
@@ -346,6 +348,11 @@ int pscv_conv3d_c1_launch(const void* in, int dtype, int in_cstride, int in_coff
                           int skip_cstride, int skip_coff, void* out, int out_cstride, int out_coff, int out_dtype,
                           int B, int D, int Hh, int W, int c_in, int epi_flags, hipStream_t st);
 
+int pscv_conv3d_t2p8_launch(const void* in, int dtype, int in_cstride, int in_coff, const uint16_t* packed,
+                            const float* scale, const float* bias, const float* floor, const void* skip, int skip_cstride,
+                            int skip_coff, void* out, int out_cstride, int out_coff, int out_dtype, int B, int Di, int Hi,
+                            int Wi, int epi_flags, hipStream_t st);
+
 extern "C" int pscv_conv3d(const void* in, int dtype, int in_cstride, int in_coff, const uint16_t* packed, const float* scale,
                            const float* bias, const float* floor, const void* skip, int skip_cstride, int skip_coff,
                            void* out, int out_cstride, int out_coff, int out_dtype, int B, int Di, int Hi, int Wi,
@@ -367,6 +374,15 @@ extern "C" int pscv_conv3d(const void* in, int dtype, int in_cstride, int in_cof
                                                  reinterpret_cast<hipStream_t>(stream));
         if (rc) return rc;
         PSCV_CHECK_LAUNCH("pscv_conv3d(sweep)");
+        return 0;
+    }
+    if (kind == PSCV_CONV_T2P8) {
+        PSCV_CHECK_ARG(c_in == 16 && c_out == 8, "pscv_conv3d: the parity-pair kernel (T2P8) is for c_in=16, c_out=8 (got %d -> %d)", c_in, c_out);
+        const int rc = pscv_conv3d_t2p8_launch(in, dtype, in_cstride, in_coff, packed, scale, bias, floor, skip, skip_cstride,
+                                               skip_coff, out, out_cstride, out_coff, out_dtype, B, Di, Hi, Wi, epi_flags,
+                                               reinterpret_cast<hipStream_t>(stream));
+        if (rc) return rc;
+        PSCV_CHECK_LAUNCH("pscv_conv3d(t2p8)");
         return 0;
     }
     if (kind == PSCV_CONV_S1C1) {

@@ -36,7 +36,7 @@ extern "C" long pscv_pack_conv3d_weights(const float* w, int c_in, int c_out, in
     using namespace pscv;
     PSCV_CHECK_ARG(c_in > 0 && c_in % 8 == 0 && c_out > 0, "pscv_pack_conv3d_weights: bad channels %d -> %d", c_in, c_out);
     PSCV_CHECK_ARG(kind == PSCV_CONV_S1 || kind == PSCV_CONV_S2 || kind == PSCV_CONV_T2 || kind == PSCV_CONV_S1P8 ||
-                       kind == PSCV_CONV_S1C1,
+                       kind == PSCV_CONV_S1C1 || kind == PSCV_CONV_T2P8,
                    "pscv_pack_conv3d_weights: kind %d", kind);
     PSCV_CHECK_ARG(kind != PSCV_CONV_T2 || transposed, "pscv_pack_conv3d_weights: T2 needs a ConvTranspose3d weight");
     PSCV_CHECK_ARG(kind != PSCV_CONV_S2 || !transposed, "pscv_pack_conv3d_weights: S2 takes a Conv3d weight");
@@ -57,6 +57,35 @@ extern "C" long pscv_pack_conv3d_weights(const float* w, int c_in, int c_out, in
                         float v = 0.f;
                         if (kd >= 0 && kd <= 2) v = w[((long)co * c_in + ci) * 27 + kd * 9 + t];
                         packed[(((long)p * 9 + t) * 64 + lane) * 8 + j] = dtype == PSCV_BF16 ? f32_to_bf16(v) : f32_to_f16_bits(v);
+                    }
+        return n;
+    }
+    if (kind == PSCV_CONV_T2P8) {
+        // Parity-pair layout: 9 k-steps ordered (pd, ph, sub_d <= pd, sub_h <= ph); K = 32 = two W taps (input x, x+1)
+        // x 16 channels; rows 0-7 = output x parity 0 (kernel index kw = 1 on tap 0), rows 8-15 = parity 1 (kw = 2 on
+        // tap 0, kw = 0 on tap 1).  Along D / H a parity-1 class takes kernel index 0 at input offset +1 (sub 0) and
+        // kernel index 2 at offset 0 (sub 1); a parity-0 class takes kernel index 1.
+        PSCV_CHECK_ARG(c_in == 16 && c_out == 8 && transposed, "pscv_pack_conv3d_weights: T2P8 is ConvTranspose3d 16 -> 8 only");
+        const long n = 9L * 64 * 8;
+        if (!packed) return n;
+        PSCV_CHECK_ARG(w, "pscv_pack_conv3d_weights: null weight pointer");
+        int step = 0;
+        for (int pd = 0; pd < 2; ++pd)
+            for (int ph = 0; ph < 2; ++ph)
+                for (int sd = 0; sd <= pd; ++sd)
+                    for (int sh = 0; sh <= ph; ++sh, ++step) {
+                        const int kd = pd ? (sd == 0 ? 0 : 2) : 1, kh = ph ? (sh == 0 ? 0 : 2) : 1;
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 8; ++j) {
+                                const int m = lane & 15, gk = lane >> 4;
+                                const int tap = gk >> 1, ci = (gk & 1) * 8 + j, co = m & 7;
+                                int kw = -1;
+                                if (m < 8) kw = tap == 0 ? 1 : -1;
+                                else kw = tap == 0 ? 2 : 0;
+                                float v = 0.f;
+                                if (kw >= 0) v = w[((long)ci * c_out + co) * 27 + (kd * 3 + kh) * 3 + kw];
+                                packed[((long)step * 64 + lane) * 8 + j] = dtype == PSCV_BF16 ? f32_to_bf16(v) : f32_to_f16_bits(v);
+                            }
                     }
         return n;
     }

@@ -286,6 +286,8 @@ class Conv3dLayer:
         c_in, c_out = (weight.shape[0], weight.shape[1]) if transposed else (weight.shape[1], weight.shape[0])
         if kind == L.CONV_S1 and not transposed and c_in == 32 and c_out == 8 and USE_SWEEP_KERNEL:
             kind = L.CONV_S1P8     # same result, depth-sweep kernel with plane-pair packed MFMA rows
+        if kind == L.CONV_T2 and transposed and c_in == 16 and c_out == 8 and USE_SWEEP_KERNEL:
+            kind = L.CONV_T2P8     # same result, parity-pair packed MFMA rows + contiguous 32-byte stores
         if kind == L.CONV_S1 and not transposed and c_in in (8, 16) and c_out == 1 and USE_SWEEP_KERNEL:
             kind = L.CONV_S1C1     # same result, vector-ALU dot2 sweep kernel for the 1-channel heads
         packed = torch.from_numpy(pack_conv3d_weights(weight, kind, transposed, dtype).view(np.int16)).to(device)
@@ -313,7 +315,7 @@ def conv_out_shape(kind: int, D: int, H: int, W: int):
         return D, H, W
     if kind == L.CONV_S2:
         return (D + 1) // 2, (H + 1) // 2, (W + 1) // 2
-    return 2 * D, 2 * H, 2 * W
+    return 2 * D, 2 * H, 2 * W   # CONV_T2, CONV_T2P8
 
 
 def conv3d(x: torch.Tensor, layer: Conv3dLayer, *, skip: Optional[torch.Tensor] = None, in_coff: int = 0,
