@@ -148,8 +148,9 @@ def test_conv3d_linearity_at_full_size(env):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("shape", [(16, 16, 32), (13, 11, 21), (2, 8, 16), (37, 9, 40)])
-def test_sweep_kernel_matches_brick_kernel_and_aten(env, shape, dtype):
+@pytest.mark.parametrize("shape,th16", [((16, 16, 32), 1), ((16, 16, 32), 0), ((13, 11, 21), 1), ((2, 8, 16), 1), ((37, 9, 40), 1),
+                                        ((9, 37, 24), 1), ((9, 37, 24), 0)])
+def test_sweep_kernel_matches_brick_kernel_and_aten(env, shape, th16, dtype):
     """The depth-sweep 32->8 kernel (PSCV_CONV_S1P8) against the generic brick kernel and ATen, on sizes that are
     not multiples of the 8x16 tile / the depth chunk, odd D, with BN + ReLU + skip."""
     L, ops = env
@@ -170,7 +171,11 @@ def test_sweep_kernel_matches_brick_kernel_and_aten(env, shape, dtype):
         finally:
             ops.USE_SWEEP_KERNEL = True
         assert layer.kind == (L.CONV_S1P8 if use else L.CONV_S1)
-        outs[use] = ops.conv3d(xcl, layer, skip=scl, out_dtype=torch.float32).permute(0, 4, 1, 2, 3).cpu()
+        L.set_tuning("sweep_th16", th16)       # 16-row / 512-thread tiles (when H >= 16) or 8-row / 256-thread tiles
+        try:
+            outs[use] = ops.conv3d(xcl, layer, skip=scl, out_dtype=torch.float32).permute(0, 4, 1, 2, 3).cpu()
+        finally:
+            L.set_tuning("sweep_th16", 1)
     check_close(f"sweep vs ATen {shape} {dtype}", outs[True], ref, max_abs=3e-3, rel_l2=2e-4)
     check_close(f"sweep vs brick {shape} {dtype}", outs[True], outs[False], max_abs=1e-4)
 

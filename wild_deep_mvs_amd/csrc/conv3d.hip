@@ -53,6 +53,7 @@ struct ConvArgs {
     int cout, epi;
     int ntd, nth, ntw;   // tile counts along d, h, w
     int nt_total;        // 16-channel output tiles of the layer (blockIdx.y picks this block's first tile)
+    int wlds;            // 1: stage this block's weight fragments in LDS (small grids only)
 };
 
 // ---- compile-time geometry ----------------------------------------------------------------------
@@ -130,18 +131,31 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
     const int o_w = (KIND == PSCV_CONV_S1) ? t0w - 1 : (KIND == PSCV_CONV_S2) ? 2 * t0w - 1 : t0w;
 
     // ---- stage the input brick into LDS (zero fill outside the volume = the conv's padding) ----
+    // Loads are issued in batches of up to 8 per thread before any of them is written to LDS, so the batch shares
+    // one memory latency (a load -> wait -> ds_write loop exposed the L2/HBM latency once per 16-byte chunk).
     const int tid = threadIdx.x;
     {
         const uint16_t* inb = a.in + (long)b * a.Di * a.Hi * a.Wi * a.in_cs + a.in_co;
-        for (int c = tid; c < NVOX * CCH; c += 256) {
-            const int v = c / CCH, cc = c - v * CCH;
-            const int bw = v % BW, t = v / BW;
-            const int bh = t % BH, bd = t / BH;
-            const int gd = o_d + bd, gh = o_h + bh, gw = o_w + bw;
-            uint4 val = make_uint4(0u, 0u, 0u, 0u);
-            if ((unsigned)gd < (unsigned)a.Di && (unsigned)gh < (unsigned)a.Hi && (unsigned)gw < (unsigned)a.Wi)
-                val = *reinterpret_cast<const uint4*>(inb + (((long)gd * a.Hi + gh) * a.Wi + gw) * a.in_cs + cc * 8);
-            *reinterpret_cast<uint4*>(smem + v * VS + cc * 16) = val;
+        constexpr int NCHUNK = NVOX * CCH;
+        constexpr int BATCH = 8;
+        for (int c0 = 0; c0 < NCHUNK; c0 += 256 * BATCH) {
+            uint4 val[BATCH];
+            int dst[BATCH];
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k) {
+                const int c = c0 + k * 256 + tid;
+                const int v = c / CCH, cc = c - v * CCH;
+                const int bw = v % BW, t = v / BW;
+                const int bh = t % BH, bd = t / BH;
+                const int gd = o_d + bd, gh = o_h + bh, gw = o_w + bw;
+                val[k] = make_uint4(0u, 0u, 0u, 0u);
+                dst[k] = c < NCHUNK ? v * VS + cc * 16 : -1;
+                if (c < NCHUNK && (unsigned)gd < (unsigned)a.Di && (unsigned)gh < (unsigned)a.Hi && (unsigned)gw < (unsigned)a.Wi)
+                    val[k] = *reinterpret_cast<const uint4*>(inb + (((long)gd * a.Hi + gh) * a.Wi + gw) * a.in_cs + cc * 8);
+            }
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k)
+                if (dst[k] >= 0) *reinterpret_cast<uint4*>(smem + dst[k]) = val[k];
         }
     }
     // per-channel epilogue constants of this block's NT output tiles -> LDS (one global read per block)
@@ -149,6 +163,29 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
     float* epi_sc = reinterpret_cast<float*>(smem + ((NVOX * VS + 15) & ~15));
     float* epi_bi = epi_sc + NT * 16;
     float* epi_fl = epi_bi + NT * 16;
+    // small-tile variant: this block's A fragments are copied to LDS together with the brick (one exposed memory
+    // latency for both) instead of being fetched from L2 step by step inside the short, latency-bound k-loop
+    const bool WLDS = (TD == 1) && a.wlds;   // small-tile variant on small grids only (wave-uniform)
+    constexpr int WSTEPS = conv_total_steps(KIND, CIN);
+    uint4* wlds = reinterpret_cast<uint4*>(epi_fl + NT * 16);
+    if (WLDS) {
+        const uint4* wsrc = reinterpret_cast<const uint4*>(a.wpk);
+        constexpr int NW = WSTEPS * NT * 64;
+        for (int i0 = 0; i0 < NW; i0 += 256 * 8) {
+            uint4 wv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = i0 + k * 256 + tid;
+                const int l = i & 63, sm = i >> 6, m = sm % NT, st = sm / NT;
+                if (i < NW) wv[k] = wsrc[(st * a.nt_total + nt0 + m) * 64 + l];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = i0 + k * 256 + tid;
+                if (i < NW) wlds[i] = wv[k];
+            }
+        }
+    }
     if (tid < NT * 16) {
         const int c = nt0 * 16 + tid;
         const bool cv = c < a.cout;
@@ -227,7 +264,7 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
             const int koff = tap_off_dense<KIND, BH, BW, VS>(kk0 / CIN) + (kk0 % CIN) * 2;
             uint4 wf[NT];
 #pragma unroll
-            for (int m = 0; m < NT; ++m) wf[m] = wpk[(s * a.nt_total + nt0 + m) * 64 + lane];
+            for (int m = 0; m < NT; ++m) wf[m] = WLDS ? wlds[(s * NT + m) * 64 + lane] : wpk[(s * a.nt_total + nt0 + m) * 64 + lane];
 #pragma unroll
             for (int i = 0; i < MB; ++i) {
                 const uint4 xf = *reinterpret_cast<const uint4*>(smem + anchor[i] + koff);
@@ -257,7 +294,7 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
                     const int koff = tap_off_t2<BH, BW, VS>(pc, kk0 / CIN) + (kk0 % CIN) * 2;
                     uint4 wf[NT];
 #pragma unroll
-                    for (int m = 0; m < NT; ++m) wf[m] = wpk[((sbase + s) * a.nt_total + nt0 + m) * 64 + lane];
+                    for (int m = 0; m < NT; ++m) wf[m] = WLDS ? wlds[((sbase + s) * NT + m) * 64 + lane] : wpk[((sbase + s) * a.nt_total + nt0 + m) * 64 + lane];
 #pragma unroll
                     for (int i = 0; i < MB; ++i) {
                         const uint4 xf = *reinterpret_cast<const uint4*>(smem + anchor[i] + koff);
@@ -282,7 +319,8 @@ template <typename H, int CIN, int NT, int KIND, int TD, int TH>
 static int launch_conv(ConvArgs& a, int n_split, hipStream_t st) {
     using BR = Brick<KIND, TD, TH>;
     constexpr int VS = conv_vs(CIN);
-    constexpr int LDS = ((BR::BD * BR::BH * BR::BW * VS + 15) & ~15) + conv_epi_bytes(NT);
+    constexpr int LDS_BASE = ((BR::BD * BR::BH * BR::BW * VS + 15) & ~15) + conv_epi_bytes(NT);
+    constexpr int LDS = LDS_BASE + (TD == 1 ? conv_total_steps(KIND, CIN) * NT * 1024 : 0);
     static_assert(LDS <= 160 * 1024, "brick does not fit the 160 KiB LDS");
     const int rd = KIND == PSCV_CONV_T2 ? a.Di : a.Do, rh = KIND == PSCV_CONV_T2 ? a.Hi : a.Ho,
               rw = KIND == PSCV_CONV_T2 ? a.Wi : a.Wo;
@@ -296,7 +334,10 @@ static int launch_conv(ConvArgs& a, int n_split, hipStream_t st) {
         if (e != hipSuccess) { set_error("pscv_conv3d: hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e)); return -2; }
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_split), dim3(256), LDS, st, a);
+    // weights through LDS pay off only when the grid is a round or two of workgroups (latency-bound); on larger
+    // grids the extra 27-54 KB per workgroup costs more than the per-step L2 fetches it hides
+    a.wlds = (TD == 1 && nblk * n_split <= 512) ? 1 : 0;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_split), dim3(256), a.wlds ? LDS : LDS_BASE, st, a);
     return 0;
 }
 
@@ -316,7 +357,7 @@ static int launch_kind(ConvArgs& a, int kind, hipStream_t st) {
     const bool small = big < 1024 && g_conv_small_tiles && kind != PSCV_CONV_S2;
     switch (kind) {
         case PSCV_CONV_S1: return small ? launch_conv<H, CIN, 1, PSCV_CONV_S1, 1, 4>(a, NT, st) : launch_conv<H, CIN, NT, PSCV_CONV_S1, 4, 4>(a, 1, st);
-        case PSCV_CONV_S2: return small ? launch_conv<H, CIN, 1, PSCV_CONV_S2, 1, 4>(a, NT, st) : launch_conv<H, CIN, NT, PSCV_CONV_S2, 2, 2>(a, 1, st);
+        case PSCV_CONV_S2: return launch_conv<H, CIN, NT, PSCV_CONV_S2, 2, 2>(a, 1, st);
         case PSCV_CONV_T2: return small ? launch_conv<H, CIN, 1, PSCV_CONV_T2, 1, 4>(a, NT, st) : launch_conv<H, CIN, NT, PSCV_CONV_T2, 2, 4>(a, 1, st);
     }
     set_error("pscv_conv3d: unknown kind %d", kind);

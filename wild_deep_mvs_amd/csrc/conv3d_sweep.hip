@@ -36,6 +36,8 @@ template <> struct SwMfma<f16_t> {
     }
 };
 
+int g_sweep_th16 = 1;   // pscv_set_tuning("sweep_th16", 0) selects the 8-row tile variant
+
 struct SweepArgs {
     const uint16_t* in;
     const uint16_t* wpk;     // [4 p_rel][9 taps][64 lanes][8]
@@ -51,22 +53,31 @@ struct SweepArgs {
     int nth, ntw, ndc, dc;   // tiles along h, w; depth chunks and planes per chunk (even)
 };
 
-constexpr int SW_TH = 8, SW_BH = SW_TH + 2, SW_BW = 18;
-constexpr int SW_PV = 184;                 // voxels per plane slot (180 used; multiple of 8 keeps the swizzle slot-invariant)
+constexpr int SW_BW = 18;
 constexpr int SW_VB = 64;                  // bytes per voxel (32 ch x 2 B)
-constexpr int SW_PB = SW_PV * SW_VB;       // bytes per plane slot
 constexpr int SW_NSLOT = 6;
-constexpr int SW_LDS = SW_NSLOT * SW_PB;   // 70656 B -> two workgroups per CU
-constexpr int SW_CHUNKS = SW_BH * SW_BW * 4;   // 16-byte chunks per plane (720)
+// Tile height TH (rows) is a template parameter: TH = 8 -> 256 threads, 70 KiB ring, two workgroups per CU;
+// TH = 16 -> 512 threads, 123 KiB ring, one workgroup per CU but 18/16 instead of 10/8 halo rows per tile.
+template <int TH> struct SwGeom {
+    static constexpr int BH = TH + 2;
+    static constexpr int PV = ((BH * SW_BW + 7) / 8) * 8;   // voxels per plane slot (multiple of 8: swizzle is slot-invariant)
+    static constexpr int PB = PV * SW_VB;
+    static constexpr int LDS = SW_NSLOT * PB;
+    static constexpr int CHUNKS = BH * SW_BW * 4;            // 16-byte chunks per plane
+    static constexpr int THREADS = 32 * TH;                  // 2 rows (M-tiles) per wave
+    static constexpr int NLD = (CHUNKS + THREADS - 1) / THREADS;
+};
 
 __device__ __forceinline__ int sw_lds_off(int v, int chunk) {   // v = in-plane voxel index
     return v * SW_VB + ((chunk ^ (((v >> 2) & 1) << 1)) << 4);
 }
 
-template <typename H>
-__global__ __launch_bounds__(256, 2) void conv3d_sweep8_kernel(const SweepArgs a) {
+template <typename H, int SW_TH>
+__global__ __launch_bounds__(32 * SW_TH, 2) void conv3d_sweep8_kernel(const SweepArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int R = SW_TH / 4;   // rows (M-tiles) per wave
+    using G = SwGeom<SW_TH>;
+    constexpr int SW_PB = G::PB, SW_CHUNKS = G::CHUNKS, NTHR = G::THREADS, NLD = G::NLD;
+    constexpr int R = 2;   // rows (M-tiles) per wave
 
     // ---- work decode (XCD-aware: each XCD gets a contiguous run of (tile, depth-chunk) ids) ----
     const int nwg = gridDim.x, bid = blockIdx.x;
@@ -101,13 +112,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_sweep8_kernel(const SweepArgs a
         for (int kw = 0; kw < 3; ++kw) boff[rr][kw] = sw_lds_off((row0 + rr) * SW_BW + n + kw, g);
 
     // ---- staging descriptors: 3 chunks per thread per plane ----
-    int goff[3], loff[3];
-    bool gval[3], lval[3];
+    int goff[NLD], loff[NLD];
+    bool gval[NLD], lval[NLD];
     const long plane_stride = (long)a.Hh * a.W * a.in_cs;
     const uint16_t* inb = a.in + (long)b * a.D * plane_stride + a.in_co;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int id = tid + 256 * i;
+    for (int i = 0; i < NLD; ++i) {
+        const int id = tid + NTHR * i;
         const int v = id >> 2, c = id & 3;
         const int bh = v / SW_BW, bw = v - bh * SW_BW;
         const int gh = h0 - 1 + bh, gw = w0 - 1 + bw;
@@ -117,19 +128,19 @@ __global__ __launch_bounds__(256, 2) void conv3d_sweep8_kernel(const SweepArgs a
         loff[i] = sw_lds_off(v, c);
     }
     const int plane_hi = min(a.D - 1, dend);   // last input plane this sweep can use
-    auto fetch = [&](int plane, uint4 (&reg)[3]) {
+    auto fetch = [&](int plane, uint4 (&reg)[NLD]) {
         const bool pv = plane >= 0 && plane <= plane_hi;
         const uint16_t* pp = inb + (long)(pv ? plane : 0) * plane_stride;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < NLD; ++i) {
             reg[i] = make_uint4(0u, 0u, 0u, 0u);
             if (gval[i] && pv) reg[i] = *reinterpret_cast<const uint4*>(pp + goff[i]);
         }
     };
-    auto stash = [&](int ring, const uint4 (&reg)[3]) {
+    auto stash = [&](int ring, const uint4 (&reg)[NLD]) {
         unsigned char* sp = smem + ring * SW_PB;
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < NLD; ++i)
             if (lval[i]) *reinterpret_cast<uint4*>(sp + loff[i]) = reg[i];
     };
 
@@ -145,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_sweep8_kernel(const SweepArgs a
 
     // ---- prologue: planes dbeg-1 .. dbeg+2 into ring slots 0..3 ----
     {
-        uint4 ra[3], rb[3];
+        uint4 ra[NLD], rb[NLD];
         fetch(dbeg - 1, ra); fetch(dbeg, rb);
         stash(0, ra); stash(1, rb);
         fetch(dbeg + 1, ra); fetch(dbeg + 2, rb);
@@ -156,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_sweep8_kernel(const SweepArgs a
     int ring = 0;   // slot holding plane d-1
     for (int d = dbeg; d < dend; d += 2) {
         // issue the next two planes (d+3, d+4) early; they land in LDS after this iteration's MFMAs
-        uint4 na[3], nb[3];
+        uint4 na[NLD], nb[NLD];
         fetch(d + 3, na);
         fetch(d + 4, nb);
 
@@ -239,28 +250,37 @@ int pscv_conv3d_sweep8_launch(const void* in, int dtype, int in_cstride, int in_
     a.in_cs = in_cstride; a.in_co = in_coff; a.skip_cs = skip_cstride; a.skip_co = skip_coff;
     a.out_cs = out_cstride; a.out_co = out_coff; a.out_f32 = out_dtype == PSCV_F32;
     a.B = B; a.D = D; a.Hh = Hh; a.W = W; a.epi = epi_flags;
-    a.nth = (Hh + SW_TH - 1) / SW_TH;
+    const bool tall = g_sweep_th16 && Hh >= 16;
+    const int TH = tall ? 16 : 8;
+    a.nth = (Hh + TH - 1) / TH;
     a.ntw = (W + 15) / 16;
-    // depth chunk: even, and such that the grid is a few resident waves of 512 workgroups (2 per CU)
+    // depth chunk: even, and such that the grid is a few resident rounds of workgroups
     const long tiles = (long)B * a.nth * a.ntw;
+    const long lo = tall ? 768 : 1024, hi = tall ? 2048 : 4096;
     int dc = 12;
-    while (dc < D && tiles * ((D + dc - 1) / dc) > 4096) dc += 2;
-    while (dc > 4 && tiles * ((D + dc - 1) / dc) < 1024) dc -= 2;
+    while (dc < D && tiles * ((D + dc - 1) / dc) > hi) dc += 2;
+    while (dc > 4 && tiles * ((D + dc - 1) / dc) < lo) dc -= 2;
     dc = dc > D ? ((D + 1) & ~1) : dc;
     a.dc = dc;
     a.ndc = (D + dc - 1) / dc;
     const long nblk = tiles * a.ndc;
     if (nblk <= 0 || nblk > 0x7fffffffL) { set_error("pscv_conv3d(sweep): bad grid %ld", nblk); return -1; }
-    static bool attr_done[2] = {false, false};
-    const int ti = dtype == PSCV_BF16 ? 0 : 1;
-    const void* kern = ti == 0 ? reinterpret_cast<const void*>(conv3d_sweep8_kernel<bf16_t>)
-                               : reinterpret_cast<const void*>(conv3d_sweep8_kernel<f16_t>);
+    static bool attr_done[4] = {false, false, false, false};
+    const int ti = (dtype == PSCV_BF16 ? 0 : 1) + (tall ? 2 : 0);
+    const void* kern = ti == 0 ? reinterpret_cast<const void*>(conv3d_sweep8_kernel<bf16_t, 8>)
+                     : ti == 1 ? reinterpret_cast<const void*>(conv3d_sweep8_kernel<f16_t, 8>)
+                     : ti == 2 ? reinterpret_cast<const void*>(conv3d_sweep8_kernel<bf16_t, 16>)
+                               : reinterpret_cast<const void*>(conv3d_sweep8_kernel<f16_t, 16>);
+    const int lds = tall ? SwGeom<16>::LDS : SwGeom<8>::LDS;
     if (!attr_done[ti]) {
-        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS);
+        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) { set_error("pscv_conv3d(sweep): hipFuncSetAttribute: %s", hipGetErrorString(e)); return -2; }
         attr_done[ti] = true;
     }
-    if (ti == 0) hipLaunchKernelGGL(conv3d_sweep8_kernel<bf16_t>, dim3((unsigned)nblk), dim3(256), SW_LDS, st, a);
-    else hipLaunchKernelGGL(conv3d_sweep8_kernel<f16_t>, dim3((unsigned)nblk), dim3(256), SW_LDS, st, a);
+    const dim3 grid((unsigned)nblk);
+    if (ti == 0) hipLaunchKernelGGL((conv3d_sweep8_kernel<bf16_t, 8>), grid, dim3(256), lds, st, a);
+    else if (ti == 1) hipLaunchKernelGGL((conv3d_sweep8_kernel<f16_t, 8>), grid, dim3(256), lds, st, a);
+    else if (ti == 2) hipLaunchKernelGGL((conv3d_sweep8_kernel<bf16_t, 16>), grid, dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((conv3d_sweep8_kernel<f16_t, 16>), grid, dim3(512), lds, st, a);
     return 0;
 }

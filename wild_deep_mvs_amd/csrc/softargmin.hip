@@ -33,7 +33,7 @@ template <> __device__ __forceinline__ float ldlogit<f16_t>(const f16_t* p) { re
 
 // 256 threads = PX pixels x NS depth slices: each thread reduces D/NS planes, the slices merge through LDS with
 // the log-sum-exp rule (the same rule the multi-GPU depth-plane shard uses across ranks).
-constexpr int SA_PX = 32, SA_NS = 8;
+constexpr int SA_PX = 32, SA_NS = 8, SA_PMAX = 32;
 
 template <typename T>
 __global__ __launch_bounds__(256) void softargmin_kernel(const SoftArgs a) {
@@ -52,14 +52,32 @@ __global__ __launch_bounds__(256) void softargmin_kernel(const SoftArgs a) {
     const int per = (a.D + SA_NS - 1) / SA_NS;
     const int d0 = sl * per, d1 = min(a.D, d0 + per);
 
-    float m = -INFINITY;
-    for (int d = d0; d < d1; ++d) m = fmaxf(m, ldlogit<T>(lp + d * hw));
-    float se = 0.f, sd = 0.f, si = 0.f;
-    for (int d = d0; d < d1; ++d) {
-        const float e = expf(ldlogit<T>(lp + d * hw) - m);
-        se += e;
-        if (dp) sd = fmaf(e, dp[d * dstep], sd);
-        si = fmaf(e, (float)(d + a.index_offset), si);
+    // a slice of up to SA_PMAX planes is read ONCE into registers (all loads in flight together), then reduced;
+    // longer slices fall back to two passes over memory
+    float m = -INFINITY, se = 0.f, sd = 0.f, si = 0.f;
+    if (per <= SA_PMAX) {
+        float v[SA_PMAX];
+#pragma unroll
+        for (int k = 0; k < SA_PMAX; ++k) v[k] = (d0 + k < d1) ? ldlogit<T>(lp + (long)(d0 + k) * hw) : -INFINITY;
+#pragma unroll
+        for (int k = 0; k < SA_PMAX; ++k) m = fmaxf(m, v[k]);
+#pragma unroll
+        for (int k = 0; k < SA_PMAX; ++k) {
+            if (d0 + k < d1) {
+                const float e = expf(v[k] - m);
+                se += e;
+                if (dp) sd = fmaf(e, dp[(d0 + k) * dstep], sd);
+                si = fmaf(e, (float)(d0 + k + a.index_offset), si);
+            }
+        }
+    } else {
+        for (int d = d0; d < d1; ++d) m = fmaxf(m, ldlogit<T>(lp + d * hw));
+        for (int d = d0; d < d1; ++d) {
+            const float e = expf(ldlogit<T>(lp + d * hw) - m);
+            se += e;
+            if (dp) sd = fmaf(e, dp[d * dstep], sd);
+            si = fmaf(e, (float)(d + a.index_offset), si);
+        }
     }
     sh[0][sl][px] = m; sh[1][sl][px] = se; sh[2][sl][px] = sd; sh[3][sl][px] = si;
     __syncthreads();

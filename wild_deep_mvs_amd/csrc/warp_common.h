@@ -81,6 +81,18 @@ __device__ __forceinline__ void sweep_index(const float* __restrict__ cam, float
     iy = fminf(fmaxf(v * a.sy, a.ylo), a.yhi);
 }
 
+// d = float(half of h2) * w + acc in one VALU instruction (op_sel_hi marks src0 as fp16, op_sel picks its high half)
+__device__ __forceinline__ float fma_mix_lo(uint32_t h2, float w, float acc) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(w), "v"(acc));
+    return d;
+}
+__device__ __forceinline__ float fma_mix_hi(uint32_t h2, float w, float acc) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(w), "v"(acc));
+    return d;
+}
+
 // Zero-padded bilinear gather of this lane's CPL channels.
 template <typename TIn, int CPL>
 __device__ __forceinline__ VecF<CPL> gather_bilinear(const TIn* __restrict__ img, int b, int hs, int ws, int C,
@@ -98,15 +110,38 @@ __device__ __forceinline__ VecF<CPL> gather_bilinear(const TIn* __restrict__ img
     const float w11 = (vx1 && vy1) ? fx * fy : 0.0f;
     const int xc0 = min(max(x0, 0), ws - 1), xc1 = min(max(x1, 0), ws - 1);
     const int yc0 = min(max(y0, 0), hs - 1), yc1 = min(max(y1, 0), hs - 1);
-    const long row0 = ((long)b * hs + yc0) * ws, row1 = ((long)b * hs + yc1) * ws;
-    const VecF<CPL> f00 = load_chan<TIn, CPL>(img + (row0 + xc0) * C + choff);
-    const VecF<CPL> f01 = load_chan<TIn, CPL>(img + (row0 + xc1) * C + choff);
-    const VecF<CPL> f10 = load_chan<TIn, CPL>(img + (row1 + xc0) * C + choff);
-    const VecF<CPL> f11 = load_chan<TIn, CPL>(img + (row1 + xc1) * C + choff);
+    // 32-bit element offsets from the (wave-uniform) batch base: feature maps are far below 2^31 elements
+    const TIn* base = img + (long)b * hs * ws * C + choff;
+    const int o00 = (yc0 * ws + xc0) * C, o01 = (yc0 * ws + xc1) * C;
+    const int o10 = (yc1 * ws + xc0) * C, o11 = (yc1 * ws + xc1) * C;
     VecF<CPL> r;
+    if constexpr (sizeof(TIn) == 2 && Elem<TIn>::dtype == PSCV_F16) {
+        // fp16 taps: v_fma_mix_f32 converts the half operand and does the fp32 FMA in ONE instruction, so the 64
+        // v_cvt_f32_f16 of a 16-channel blend disappear; the arithmetic (exact convert, fp32 FMA chain in the same
+        // order) is bit-identical to the generic path below.  The kernel is VALU-issue bound (profiles/).
 #pragma unroll
-    for (int j = 0; j < CPL; ++j)
-        r.v[j] = fmaf(f11.v[j], w11, fmaf(f10.v[j], w10, fmaf(f01.v[j], w01, f00.v[j] * w00)));
+        for (int k = 0; k < CPL / 8; ++k) {
+            const uint4 a = *reinterpret_cast<const uint4*>(base + o00 + 8 * k);
+            const uint4 bq = *reinterpret_cast<const uint4*>(base + o01 + 8 * k);
+            const uint4 c = *reinterpret_cast<const uint4*>(base + o10 + 8 * k);
+            const uint4 d = *reinterpret_cast<const uint4*>(base + o11 + 8 * k);
+            const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {bq.x, bq.y, bq.z, bq.w};
+            const uint32_t cw[4] = {c.x, c.y, c.z, c.w}, dw[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                r.v[8 * k + 2 * q] = fma_mix_lo(dw[q], w11, fma_mix_lo(cw[q], w10, fma_mix_lo(bw[q], w01, fma_mix_lo(aw[q], w00, 0.0f))));
+                r.v[8 * k + 2 * q + 1] = fma_mix_hi(dw[q], w11, fma_mix_hi(cw[q], w10, fma_mix_hi(bw[q], w01, fma_mix_hi(aw[q], w00, 0.0f))));
+            }
+        }
+    } else {
+        const VecF<CPL> f00 = load_chan<TIn, CPL>(base + o00);
+        const VecF<CPL> f01 = load_chan<TIn, CPL>(base + o01);
+        const VecF<CPL> f10 = load_chan<TIn, CPL>(base + o10);
+        const VecF<CPL> f11 = load_chan<TIn, CPL>(base + o11);
+#pragma unroll
+        for (int j = 0; j < CPL; ++j)
+            r.v[j] = fmaf(f11.v[j], w11, fmaf(f10.v[j], w10, fmaf(f01.v[j], w01, f00.v[j] * w00)));
+    }
     return r;
 }
 
