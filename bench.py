@@ -56,6 +56,20 @@ def algorithmic_bytes(name: str) -> float:
 DTYPES = {"f16": torch.float16, "bf16": torch.bfloat16}
 
 
+def pmc_traffic(name: str):
+    """HBM bytes per launch of `name` from the committed rocprofv3 PMC capture (profiles/r01_traffic.json, made by
+    scripts/profile.sh + scripts/prof_summary.py on the same command), or None."""
+    path = os.path.join(REPO, "profiles", "r01_traffic.json")
+    try:
+        table = json.load(open(path))
+    except Exception:
+        return None
+    for key, rec in table.items():
+        if name.startswith(key):
+            return rec.get("hbm_bytes")
+    return None
+
+
 def build_inputs(device, rank: int, dtype):
     net = MVSNet("variance")
     sd = synthetic.sharpened_state_dict("mvsnet", synthetic.template_of(net), seed=0)
@@ -170,7 +184,8 @@ def main():
         avg_s = ms / n * 1e-3
         ab = algorithmic_bytes(name)
         roof = {"kernel": name, "bound": "hbm", "achieved": ab / avg_s / 1e9 if ab else None, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": (ab / avg_s / 1e9 / HBM_PEAK_GBS) if ab else None, "traffic": None,
+                "unit": "GB/s", "frac": (ab / avg_s / 1e9 / HBM_PEAK_GBS) if ab else None,
+                "traffic": pmc_traffic(name) if args.dtype == "f16" else None,
                 "avg_us": avg_s * 1e6, "algorithmic_bytes": ab, "share_of_gpu_time": ms / total_ms}
         line = {
             "metric": "cost-volume voxels/sec (BxDxHxW), MVSNet hot path", "value": world * VOX * args.steps / elapsed,

@@ -74,12 +74,13 @@ def main():
         cm = ops.proj_cams([proj[:, i] for i in range(1, 5)], proj[:, 0])
         out = torch.empty(1, D, h, w, 32, dtype=dt, device=dev)
         nbytes = 5 * 32 * h * w * 2 + out.numel() * 2
-        for ppd in (4, 8, 16, 24, 48):
-            L.set_tuning("warp_lpv", 0); L.set_tuning("warp_ppd", ppd)
+        for ppd in (16,):
+            L.set_tuning("warp_lpv", 0); L.set_tuning("warp_tiled", 1); L.set_tuning("warp_ppd", ppd)
             us = timeit(lambda: ops.warp_cost(fcl[0], fcl[1:], cm, dv, cost=L.COST_VARIANCE, out=out), args.reps)
             rows.append((f"warp_cost variance TILED ppd={ppd}", us, nbytes / us / 1e3, 0))
-        for lpv in (2,):
-            for ppd in (8, 32):
+            L.set_tuning("warp_tiled", 0)
+        for lpv in (4, 2, 1):
+            for ppd in (4, 8, 16):
                 L.set_tuning("warp_lpv", lpv); L.set_tuning("warp_ppd", ppd)
                 us = timeit(lambda: ops.warp_cost(fcl[0], fcl[1:], cm, dv, cost=L.COST_VARIANCE, out=out), args.reps)
                 rows.append((f"warp_cost variance lpv={lpv} ppd={ppd}", us, nbytes / us / 1e3, 0))

@@ -54,8 +54,38 @@ def pmc(path):
             print(f"      {c:32s} {v:18.1f}")
 
 
+def traffic_json(root):
+    """Per-launch HBM bytes of the single-instance kernels from the FETCH_SIZE / WRITE_SIZE passes, corrected as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes: both counters are in KiB; FETCH_SIZE counts 64 B per 128-B
+    request on gfx950 for wide coalesced reads, so it is doubled (calibrated here: the warp kernel then reads exactly
+    its 5 feature maps); WRITE_SIZE matched the written bytes exactly (the cost volume) and is used as is."""
+    import json
+    vals = {}
+    for sub, cname in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+        for db in dbs(os.path.join(root, sub)):
+            con = sqlite3.connect(db)
+            q = ("select kernel_name, avg(v) from (select kernel_name, dispatch_id, sum(value) as v from counters_collection "
+                 f"where counter_name = '{cname}' group by kernel_name, dispatch_id) group by kernel_name")
+            for k, v in con.execute(q):
+                vals.setdefault(k, {})[cname] = v
+    keymap = (("warp_cost_kernel", "warp_cost"), ("conv3d_sweep8_kernel", "conv3d[32->8,k3]"),
+              ("conv3d_c1_kernel", "conv3d[8->1,k4]"), ("conv3d_t2p8_kernel", "conv3d[16->8,k5]"), ("softargmin_kernel", "softargmin"))
+    out = {}
+    for k, d in vals.items():
+        for sub, name in keymap:
+            if sub in k and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+                out[name] = {"fetch_kib": d["FETCH_SIZE"], "write_kib": d["WRITE_SIZE"],
+                             "hbm_bytes": (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0}
+    with open(os.path.join(root, "traffic.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+
+
 def main():
     root = sys.argv[1]
+    try:
+        traffic_json(root)
+    except Exception as e:  # pragma: no cover
+        print("traffic.json: error", e)
     for sub in sorted(os.listdir(root)):
         p = os.path.join(root, sub)
         if not os.path.isdir(p):

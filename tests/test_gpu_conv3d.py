@@ -175,7 +175,7 @@ def test_sweep_kernel_matches_brick_kernel_and_aten(env, shape, th16, dtype):
         try:
             outs[use] = ops.conv3d(xcl, layer, skip=scl, out_dtype=torch.float32).permute(0, 4, 1, 2, 3).cpu()
         finally:
-            L.set_tuning("sweep_th16", 1)
+            L.set_tuning("sweep_th16", 0)
     check_close(f"sweep vs ATen {shape} {dtype}", outs[True], ref, max_abs=3e-3, rel_l2=2e-4)
     check_close(f"sweep vs brick {shape} {dtype}", outs[True], outs[False], max_abs=1e-4)
 

@@ -36,7 +36,8 @@ template <> struct SwMfma<f16_t> {
     }
 };
 
-int g_sweep_th16 = 1;   // pscv_set_tuning("sweep_th16", 0) selects the 8-row tile variant
+int g_sweep_th16 = 0;   // pscv_set_tuning("sweep_th16", 1) selects the 16-row / 512-thread tile variant (measured
+                        // 116 us vs 107 us for 8-row tiles at the headline size: one workgroup per CU hides less latency)
 
 struct SweepArgs {
     const uint16_t* in;

@@ -110,10 +110,11 @@ __device__ __forceinline__ VecF<CPL> gather_bilinear(const TIn* __restrict__ img
     const float w11 = (vx1 && vy1) ? fx * fy : 0.0f;
     const int xc0 = min(max(x0, 0), ws - 1), xc1 = min(max(x1, 0), ws - 1);
     const int yc0 = min(max(y0, 0), hs - 1), yc1 = min(max(y1, 0), hs - 1);
-    // 32-bit element offsets from the (wave-uniform) batch base: feature maps are far below 2^31 elements
-    const TIn* base = img + (long)b * hs * ws * C + choff;
-    const int o00 = (yc0 * ws + xc0) * C, o01 = (yc0 * ws + xc1) * C;
-    const int o10 = (yc1 * ws + xc0) * C, o11 = (yc1 * ws + xc1) * C;
+    // wave-uniform batch base (SGPR pair) + 32-bit per-lane element offsets (feature maps are far below 2^31
+    // elements): the loads use the scalar-base addressing form, no 64-bit vector address arithmetic
+    const TIn* base = img + (long)b * hs * ws * C;
+    const int o00 = (yc0 * ws + xc0) * C + choff, o01 = (yc0 * ws + xc1) * C + choff;
+    const int o10 = (yc1 * ws + xc0) * C + choff, o11 = (yc1 * ws + xc1) * C + choff;
     VecF<CPL> r;
     if constexpr (sizeof(TIn) == 2 && Elem<TIn>::dtype == PSCV_F16) {
         // fp16 taps: v_fma_mix_f32 converts the half operand and does the fp32 FMA in ONE instruction, so the 64

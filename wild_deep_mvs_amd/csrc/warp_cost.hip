@@ -46,6 +46,15 @@ __global__ __launch_bounds__(256) void warp_cost_kernel(const WarpArgs a) {
     const int pbb = pb - b * a.npb_batch;
 
     const int tid = threadIdx.x;
+    // camera blocks of this batch item -> LDS once per workgroup.  (Read straight from global they were fetched with
+    // VECTOR loads -- the compiler cannot use the scalar cache for memory the kernel might also store to -- which put a
+    // second dependent memory latency and 3 extra VMEM instructions into every (plane, view) iteration.)
+    __shared__ float cam_lds[PSCV_MAX_SRC * PSCV_CAM_FLOATS];
+    for (int i = tid; i < a.n_src * PSCV_CAM_FLOATS; i += 256) {
+        const int v = i / PSCV_CAM_FLOATS, k = i - v * PSCV_CAM_FLOATS;
+        cam_lds[i] = a.cams[((long)v * a.B + b) * PSCV_CAM_FLOATS + k];
+    }
+    __syncthreads();
     const int hw = a.h * a.w;
     int pflat = pbb * PPB + tid / LPV;
     const bool active = pflat < hw;
@@ -85,7 +94,7 @@ __global__ __launch_bounds__(256) void warp_cost_kernel(const WarpArgs a) {
         }
 
         for (int v = 0; v < a.n_src; ++v) {
-            const float* cam = a.cams + ((long)v * a.B + b) * PSCV_CAM_FLOATS;
+            const float* cam = cam_lds + v * PSCV_CAM_FLOATS;
             float ix, iy;
             sweep_index<GEOM>(cam, px, py, dval, a, ix, iy);
             const VecF<CPL> wv = gather_bilinear<TIn, CPL>(reinterpret_cast<const TIn*>(a.src[v]), b, a.hs, a.ws, C,
