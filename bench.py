@@ -137,12 +137,18 @@ def main():
         graph = None
         if not args.eager:
             # the 15-launch step is launch-gap bound between its small kernels: capture it once, replay it
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                depth, conf = step()
-            for _ in range(2):
-                graph.replay()
-            torch.cuda.synchronize()
+            try:
+                graph = torch.cuda.CUDAGraph()
+                # thread_local: the RCCL watchdog thread of a multi-GPU run must not invalidate the capture
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    depth, conf = step()
+                for _ in range(2):
+                    graph.replay()
+                torch.cuda.synchronize()
+            except Exception as e:   # pragma: no cover  (never seen on 1 GPU; keeps an N-GPU run alive)
+                print(f"[bench] hipGraph capture failed ({e}); timing eager launches", file=sys.stderr)
+                graph = None
+                torch.cuda.synchronize()
         run = graph.replay if graph is not None else step
         if dist is not None:
             dist.barrier()
