@@ -166,6 +166,12 @@ int pscv_fuse_pairs(const void* const* interm, const float* const* uncert, int n
                     float* wsum_out, int normalise, int B, int D, int h, int w, void* stream);
 
 /*
+ * Second half of a source-view-sharded fusion: out = partial / wsum after the partial sums of all ranks were
+ * all-reduced (RCCL).  partial fp32 [B,D,h,w,8], wsum fp32 [B,h,w], out [B,D,h,w,8] in `dtype`.
+ */
+int pscv_fuse_finish(const float* partial, const float* wsum, int dtype, void* out, int B, int D, int h, int w, void* stream);
+
+/*
  * Softmax over the depth axis + expectation(s), fused.
  * Replaces: F.softmax + depth_regression + photometric confidence (models/MVSNet/model.py:207-215, module.py:174-178;
  *           CVP net.py:161-162,203-219) and soft_argmin / entropy (models/VisMVSNet/nn_utils.py:453-470).

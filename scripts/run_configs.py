@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Run the five BASELINE.json configurations (single-GPU forms) through the engine: full forward() incl. the 2-D feature
+nets, synthetic inputs, sharpened weights.  Prints time per forward, cost-volume voxels and sanity of the outputs.
+Usage: python scripts/run_configs.py [--only N] [--reps 3]"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from wild_deep_mvs_amd import synthetic  # noqa: E402
+
+
+def build(arch):
+    if arch in ("mvsnet", "mvsnet_s"):
+        from wild_deep_mvs_amd.models.MVSNet.model import MVSNet
+        net = MVSNet("variance" if arch == "mvsnet" else "softmin")
+        key = "mvsnet"
+    elif arch == "vis":
+        from wild_deep_mvs_amd.models.VisMVSNet.frontend import Frontend
+        net, key = Frontend(), "vis"
+    else:
+        from wild_deep_mvs_amd.models.CVP_MVSNet.frontend import Frontend
+        net, key = Frontend(), "cvp"
+    net.load_state_dict(synthetic.sharpened_state_dict(key, synthetic.template_of(net), seed=0))
+    return net.cuda().eval()
+
+
+CONFIGS = {
+    1: dict(arch="mvsnet_s", V=3, H=128, W=160, setup=lambda n: setattr(n, "num_depth", 48), kw={}, vox=lambda: 48 * 32 * 40),
+    2: dict(arch="mvsnet", V=5, H=512, W=640, setup=lambda n: None, kw={}, vox=lambda: 192 * 128 * 160),
+    3: dict(arch="vis", V=5, H=512, W=640, setup=lambda n: None,
+            kw=dict(depth_nums=[192, 32, 16], interval_scales=[128 / 192, 1, 0.5]),
+            vox=lambda: 192 * 64 * 80 + 32 * 128 * 160 + 16 * 256 * 320),
+    4: dict(arch="cvp", V=5, H=1024, W=1280, setup=lambda n: None, kw=dict(nscale=5),
+            vox=lambda: 96 * 64 * 80 + 8 * (128 * 160 + 256 * 320 + 512 * 640 + 1024 * 1280), bscale=8),
+    5: dict(arch="vis", V=9, H=1152, W=1600, setup=lambda n: None, kw=dict(depth_nums=[256, 32, 16], interval_scales=[0.5, 1, 0.5]),
+            vox=lambda: 256 * 144 * 200 + 32 * 288 * 400 + 16 * 576 * 800),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", type=int, default=0)
+    ap.add_argument("--reps", type=int, default=3)
+    args = ap.parse_args()
+    for cid, cfg in CONFIGS.items():
+        if args.only and cid != args.only:
+            continue
+        net = build(cfg["arch"])
+        cfg["setup"](net)
+        scene = synthetic.make_scene(1, cfg["V"], cfg["H"], cfg["W"], seed=cid)
+        if "bscale" in cfg:
+            scene["t"] = scene["t"] * cfg["bscale"]
+        dev = {k: v.cuda() for k, v in scene.items()}
+        call = lambda: net(dev["imgs"], dev["K"], dev["R"], dev["t"], dev["depth_min"], dev["depth_max"], **cfg["kw"])
+        out = call()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.reps):
+            out = call()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.reps
+        d = out["depth"]
+        ok = bool(torch.isfinite(d).all()) and bool(torch.isfinite(out["photometric_confidence"]).all())
+        print(f"config {cid} {cfg['arch']:8s} V={cfg['V']} {cfg['H']}x{cfg['W']}: {dt * 1e3:8.2f} ms / forward (with 2-D features), "
+              f"{cfg['vox']() / dt / 1e9:6.3f} G cost-volume voxels/s, depth {tuple(d.shape)} range {float(d.min()):.3f}..{float(d.max()):.3f}, "
+              f"finite={ok}, peak mem {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB", flush=True)
+        del net, out
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+
+
+if __name__ == "__main__":
+    main()

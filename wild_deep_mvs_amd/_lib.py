@@ -26,7 +26,7 @@ MAX_SRC = 16
 CAM_FLOATS = 18
 
 EXPORTS = ("pscv_last_error", "pscv_abi_version", "pscv_set_tuning", "pscv_proj_cams", "pscv_homog_cams", "pscv_warp_cost",
-           "pscv_fuse_pairs",
+           "pscv_fuse_pairs", "pscv_fuse_finish",
            "pscv_pack_conv3d_weights", "pscv_conv3d", "pscv_softargmin")
 
 
@@ -68,6 +68,8 @@ def _declare(lib):
     lib.pscv_homog_cams.argtypes = [vp, vp, i, i, f, vp, vp]
     lib.pscv_fuse_pairs.restype = i
     lib.pscv_fuse_pairs.argtypes = [C.POINTER(vp), C.POINTER(vp), i, i, vp, vp, i, i, i, i, i, vp]
+    lib.pscv_fuse_finish.restype = i
+    lib.pscv_fuse_finish.argtypes = [vp, vp, i, vp, i, i, i, i, vp]
     lib.pscv_warp_cost.restype = i
     lib.pscv_warp_cost.argtypes = [vp, C.POINTER(vp), i, vp, vp, l, i, i, i, f, vp, i, i, i, i, i, i, i, i, i, vp]
     lib.pscv_pack_conv3d_weights.restype = l

@@ -49,7 +49,37 @@ __global__ __launch_bounds__(256) void fuse_pairs_kernel(const FuseArgs a) {
     if (a.wsum_out && vox / a.hw % a.D == 0) a.wsum_out[pix] = wsum;
 }
 
+// second half of a source-view-sharded fusion: out = partial_sum / weight_sum after the cross-rank all-reduce
+template <typename H>
+__global__ __launch_bounds__(256) void fuse_finish_kernel(const float* __restrict__ part, const float* __restrict__ wsum,
+                                                         H* __restrict__ out, int B, int D, int hw) {
+    const long nvox = (long)B * D * hw;
+    const long vox = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vox >= nvox) return;
+    const int b = (int)(vox / ((long)D * hw));
+    const float inv = 1.0f / wsum[(long)b * hw + (int)(vox % hw)];
+    f32x8 x = Elem<float>::load8(part + vox * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x.v[j] *= inv;
+    Elem<H>::store8(out + vox * 8, x);
+}
+
 }  // namespace pscv
+
+extern "C" int pscv_fuse_finish(const float* partial, const float* wsum, int dtype, void* out, int B, int D, int h, int w,
+                                void* stream) {
+    using namespace pscv;
+    PSCV_CHECK_ARG(partial && wsum && out, "pscv_fuse_finish: null pointer argument");
+    PSCV_CHECK_ARG(dtype == PSCV_BF16 || dtype == PSCV_F16, "pscv_fuse_finish: dtype %d must be bf16 or fp16", dtype);
+    PSCV_CHECK_ARG(B > 0 && D > 0 && h > 0 && w > 0, "pscv_fuse_finish: bad sizes");
+    const long nvox = (long)B * D * h * w;
+    const unsigned nblk = (unsigned)((nvox + 255) / 256);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == PSCV_BF16) hipLaunchKernelGGL(fuse_finish_kernel<bf16_t>, dim3(nblk), dim3(256), 0, st, partial, wsum, reinterpret_cast<bf16_t*>(out), B, D, h * w);
+    else hipLaunchKernelGGL(fuse_finish_kernel<f16_t>, dim3(nblk), dim3(256), 0, st, partial, wsum, reinterpret_cast<f16_t*>(out), B, D, h * w);
+    PSCV_CHECK_LAUNCH("pscv_fuse_finish");
+    return 0;
+}
 
 extern "C" int pscv_fuse_pairs(const void* const* interm, const float* const* uncert, int n_src, int dtype, void* out,
                                float* wsum_out, int normalise, int B, int D, int h, int w, void* stream) {

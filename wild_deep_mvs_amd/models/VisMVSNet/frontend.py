@@ -22,6 +22,11 @@ class Frontend(nn.Module):
         for st in (self.model.stage1, self.model.stage2, self.model.stage3):
             st.storage_dtype = dt
 
+    def set_view_group(self, group):
+        """Shard the source views of every stage over a torch.distributed group (None = no sharding)."""
+        for st in (self.model.stage1, self.model.stage2, self.model.stage3):
+            st.view_group = group
+
     def fill_cam_array(self, K, R, t, start_depth, depth_interval):
         b = K.shape[0]
         cam = torch.zeros((b, 2, 4, 4), device=K.device)
@@ -44,7 +49,14 @@ class Frontend(nn.Module):
         srcs_cam = [self.fill_cam_array(K[:, i], R[:, i], t[:, i], depth_min[:, i], depth_interval[:, i]) for i in src_idx]
         with torch.no_grad():
             ref_feats = self.model.feat_ext(imgs[reference_frame])
-            src_feats = [self.model.feat_ext(imgs[i]) for i in src_idx]
+            grp = self.model.stage1.view_group
+            if grp is None:
+                src_feats = [self.model.feat_ext(imgs[i]) for i in src_idx]
+            else:   # view shard: a rank only extracts the features of the source views it will sweep
+                import torch.distributed as dist
+                world, rank = dist.get_world_size(grp), dist.get_rank(grp)
+                src_feats = [self.model.feat_ext(imgs[i]) if j % world == rank else (None, None, None)
+                             for j, i in enumerate(src_idx)]
             di = depth_interval[:, reference_frame].view(n, 1, 1, 1)
             stages = (self.model.stage1, self.model.stage2, self.model.stage3)
             ests, probs, pairs = [], [], []

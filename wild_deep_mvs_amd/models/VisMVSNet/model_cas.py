@@ -157,6 +157,10 @@ class SingleStage(nn.Module):
         self.reg_pair = RegPair()
         self.uncert_net = UncertNet(1)
         self.storage_dtype = torch.float16
+        # source-view shard: with a torch.distributed group set here, rank r warps and
+        # regularises source views r, r+G, ... only; the visibility-weighted sums are all-reduced (RCCL) and every rank
+        # then runs RegFuse on the same fused volume.  The reference has no counterpart (it loops over all views).
+        self.view_group = None
 
     def build_cost_volume(self, ref, ref_cam, srcs, srcs_cam, depth_num, depth_start, depth_interval, s_scale):
         """Pair-wise group-correlation volumes of ALL source views in one fused launch: [n_src,n,d,h,w,8]
@@ -181,6 +185,15 @@ class SingleStage(nn.Module):
         ref_feat, ref_cam, srcs_feat, srcs_cam = sample
         depth_start = ref_cam[:, 1:2, 3:4, 0:1] if depth_start_override is None else depth_start_override
         depth_interval = ref_cam[:, 1:2, 3:4, 1:2] if depth_interval_override is None else depth_interval_override
+        n_views = len(srcs_feat)
+        world, rank = 1, 0
+        if self.view_group is not None:
+            import torch.distributed as dist
+            world, rank = dist.get_world_size(self.view_group), dist.get_rank(self.view_group)
+        mine = [i for i in range(n_views) if i % world == rank]
+        srcs_feat, srcs_cam = [srcs_feat[i] for i in mine], [srcs_cam[i] for i in mine]
+        if not mine:
+            raise ValueError("view shard: more ranks than source views")
         costs = self.build_cost_volume(ref_feat, ref_cam, srcs_feat, srcs_cam, depth_num, depth_start, depth_interval, s_scale)
         interms, uncerts, pair_results = [], [], []
         for i in range(len(srcs_feat)):
@@ -194,7 +207,25 @@ class SingleStage(nn.Module):
             uncerts.append(heads[0].squeeze(1).to(torch.float32).contiguous())
             if taps is not None and i == 0:
                 taps.update(cost0=costs[0], interm0=interm, score0=score, entropy0=o["entropy"], uncert0=heads[0])
-        fused = ops.fuse_pairs(interms, uncerts)                                       # model_cas.py:354-357,385-386
+        if world == 1:
+            fused = ops.fuse_pairs(interms, uncerts)                                   # model_cas.py:354-357,385-386
+        else:
+            import torch.distributed as dist
+            part, wsum = ops.fuse_pairs(interms, uncerts, normalise=False, want_wsum=True)
+            dist.all_reduce(part, group=self.view_group)                               # sum_v w_v interm_v  over all ranks
+            dist.all_reduce(wsum, group=self.view_group)                               # sum_v w_v
+            fused = ops.fuse_finish(part, wsum, interms[0].dtype)
+            # every rank reports the pair results of ALL views, in view order
+            flat = torch.stack([torch.cat([ed, hd[0]], dim=1) for ed, hd in pair_results])   # [mine,n,2,h,w]
+            slots = (n_views + world - 1) // world
+            padded = torch.zeros((slots,) + tuple(flat.shape[1:]), dtype=flat.dtype, device=flat.device)
+            padded[:flat.shape[0]] = flat
+            gathered = [torch.empty_like(padded) for _ in range(world)]
+            dist.all_gather(gathered, padded, group=self.view_group)
+            pair_results = []
+            for i in range(n_views):
+                rec = gathered[i % world][i // world]
+                pair_results.append([rec[:, 0:1], [rec[:, 1:2]]])
         score = self.reg_fuse(fused)
         o = ops.softargmin(score, None, want_index=True, want_conf=True, conf_mode=1, window=2.0)
         est_depth = o["index"].unsqueeze(1) * depth_interval + depth_start             # model_cas.py:404-405

@@ -186,6 +186,18 @@ def fuse_pairs(interms: Sequence[torch.Tensor], uncerts: Sequence[torch.Tensor],
     return (out, wsum) if want_wsum else out
 
 
+def fuse_finish(partial: torch.Tensor, wsum: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """partial fp32 [B,D,h,w,8] (all-reduced sum of w*interm), wsum fp32 [B,h,w] -> normalised 16-bit volume."""
+    _dev(partial, wsum)
+    B, D, h, w, c = partial.shape
+    if c != 8 or partial.dtype != torch.float32 or tuple(wsum.shape) != (B, h, w) or wsum.dtype != torch.float32:
+        raise ValueError("pscv.fuse_finish: partial fp32 [B,D,h,w,8] and wsum fp32 [B,h,w] expected")
+    out = torch.empty((B, D, h, w, 8), dtype=dtype, device=partial.device)
+    rc = _launch("fuse_finish", lambda: L.lib().pscv_fuse_finish(_p(partial), _p(wsum), _TORCH2PSCV[dtype], _p(out), B, D, h, w, _stream()))
+    L.check(rc, "pscv_fuse_finish")
+    return out
+
+
 # --------------------------------------------------------------------------------------------
 # fused warp + cost
 # --------------------------------------------------------------------------------------------
