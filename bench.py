@@ -111,6 +111,7 @@ def main():
                     help="16-bit HBM storage format (arithmetic is fp32); f16 is the engine default, see DESIGN.md section 5")
     ap.add_argument("--dump-events", default=None, help="write every per-launch event duration to this file")
     ap.add_argument("--eager", action="store_true", help="time eager launches instead of hipGraph replays")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="pscv_set_tuning knob (measurement runs)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -125,6 +126,10 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
+    for kv in args.tune:
+        from wild_deep_mvs_amd import _lib
+        k, v = kv.split("=")
+        _lib.set_tuning(k, int(v))
     net, sd, feats, feats_cl, proj_d, dv_d, proj, dv = build_inputs(device, rank, DTYPES[args.dtype])
 
     def step():

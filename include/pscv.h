@@ -75,6 +75,7 @@ int pscv_abi_version(void);
  *   "warp_tiled" 1: pscv_warp_cost stages source patches in LDS where it applies (C = 32, 16-bit features,
  *               per-batch planes, PROJ geometry, 2-4 source views, variance / softmin); 0 (default): the
  *               direct-gather kernel, which measured faster on MI355X.  "warp_lpv" != 0 also selects the direct kernel.
+ *   "sweep_dc"  depth planes per workgroup of the 32->8 depth-sweep conv (0 = default heuristic)
  *   "sweep_th16" 1: the 32->8 depth-sweep conv uses 16-row tiles / 512 threads; 0 (default): 8-row tiles / 256 threads
  *   "conv_small_tiles"  1 (default): small volumes use 1x4x16 tiles with the output channels split over
  *               blockIdx.y; 0: always the large-tile variant */

@@ -44,6 +44,17 @@ def main():
               ("conv3", 16, 32, 1, 2, False), ("conv4", 32, 32, 0, 4, False), ("conv5", 32, 64, 1, 4, False),
               ("conv6", 64, 64, 0, 8, False), ("conv7", 64, 32, 2, 8, True), ("conv9", 32, 16, 2, 4, True),
               ("conv11", 16, 8, 2, 2, True), ("prob", 8, 1, 0, 1, False)]
+    if args.only == "conv0dc":
+        x = vol(32, 1)
+        wt = torch.randn(8, 32, 3, 3, 3, generator=g) / (27 * 32) ** 0.5
+        layer = ops.Conv3dLayer.build(wt, kind=L.CONV_S1, device=dev, relu=True, dtype=dt)
+        out = torch.empty(1, D, h, w, 8, dtype=dt, device=dev)
+        for dc in (8, 12, 16, 24, 32, 48, 64, 96):
+            L.set_tuning("sweep_dc", dc)
+            us = timeit(lambda: ops.conv3d(x, layer, out=out), args.reps)
+            print(f"conv0 sweep dc={dc:3d}: {us:8.1f} us")
+        L.set_tuning("sweep_dc", 0)
+        return
     for name, ci, co, kind, s, skip in layers:
         if args.only and args.only not in name:
             continue

@@ -176,9 +176,11 @@ int pscv_conv3d_c1_launch(const void* in, int dtype, int in_cstride, int in_coff
     a.nth = (Hh + C1_TH - 1) / C1_TH;
     a.ntw = (W + C1_TW - 1) / C1_TW;
     const long tiles = (long)B * a.nth * a.ntw;
-    int dc = 12;
-    while (dc < D && tiles * ((D + dc - 1) / dc) > 4096) dc += 4;
-    while (dc > 4 && tiles * ((D + dc - 1) / dc) < 1024) dc -= 2;
+    // one resident round of workgroups (about 4 per CU at this kernel's register / LDS footprint), fewest chunk seams
+    const long slots = 1024;
+    const long ndc_want = tiles >= slots ? 1 : slots / tiles;
+    int dc = (int)((D + ndc_want - 1) / ndc_want);
+    dc = dc < 4 ? 4 : dc;
     dc = dc > D ? D : dc;
     a.dc = dc;
     a.ndc = (D + dc - 1) / dc;

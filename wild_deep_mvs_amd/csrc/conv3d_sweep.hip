@@ -36,6 +36,7 @@ template <> struct SwMfma<f16_t> {
     }
 };
 
+int g_sweep_dc = 0;     // pscv_set_tuning("sweep_dc", n): depth planes per workgroup sweep (0 = heuristic)
 int g_sweep_th16 = 0;   // pscv_set_tuning("sweep_th16", 1) selects the 16-row / 512-thread tile variant (measured
                         // 116 us vs 107 us for 8-row tiles at the headline size: one workgroup per CU hides less latency)
 
@@ -255,12 +256,16 @@ int pscv_conv3d_sweep8_launch(const void* in, int dtype, int in_cstride, int in_
     const int TH = tall ? 16 : 8;
     a.nth = (Hh + TH - 1) / TH;
     a.ntw = (W + 15) / 16;
-    // depth chunk: even, and such that the grid is a few resident rounds of workgroups
+    // depth chunk: the whole grid should be ONE resident round of workgroups (256 CUs x 2 for 8-row tiles, x 1 for
+    // 16-row tiles): no tail round, and the fewest chunk seams (each seam re-reads 2 halo planes).  Measured at the
+    // headline size: 64 planes / 480 workgroups 90 us, 12 planes / 2560 workgroups 130 us.
     const long tiles = (long)B * a.nth * a.ntw;
-    const long lo = tall ? 768 : 1024, hi = tall ? 2048 : 4096;
-    int dc = 12;
-    while (dc < D && tiles * ((D + dc - 1) / dc) > hi) dc += 2;
-    while (dc > 4 && tiles * ((D + dc - 1) / dc) < lo) dc -= 2;
+    const long slots = tall ? 256 : 512;
+    const long ndc_want = tiles >= slots ? 1 : slots / tiles;
+    int dc = (int)((D + ndc_want - 1) / ndc_want);
+    dc = (dc + 1) & ~1;
+    dc = dc < 4 ? 4 : dc;
+    if (g_sweep_dc > 0) dc = g_sweep_dc & ~1;
     dc = dc > D ? ((D + 1) & ~1) : dc;
     a.dc = dc;
     a.ndc = (D + dc - 1) / dc;

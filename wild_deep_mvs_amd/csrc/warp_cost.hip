@@ -170,6 +170,7 @@ static int g_warp_tiled = 0;     // 1: use the LDS-staged kernel (warp_cost_tile
                                  // (profiles/README.md) -- the sweep is VALU-issue / latency limited, not L1-limited
 extern int g_conv_small_tiles;   // conv3d.hip
 extern int g_sweep_th16;         // conv3d_sweep.hip
+extern int g_sweep_dc;
 int warp_cost_tiled_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, int out_dtype, int ppd_override, hipStream_t st);
 
 // Instantiated (geometry, cost) pairs: the variance / softmin statistics belong to the PROJ models (MVSNet,
@@ -245,6 +246,7 @@ extern "C" int pscv_set_tuning(const char* key, int value) {
     if (!strcmp(key, "conv_small_tiles")) { g_conv_small_tiles = value; return 0; }
     if (!strcmp(key, "warp_tiled")) { g_warp_tiled = value; return 0; }
     if (!strcmp(key, "sweep_th16")) { g_sweep_th16 = value; return 0; }
+    if (!strcmp(key, "sweep_dc")) { g_sweep_dc = value; return 0; }
     set_error("pscv_set_tuning: unknown key '%s'", key);
     return -1;
 }
