@@ -103,8 +103,14 @@ class network(nn.Module):
         nsrc = len(src_imgs)
         dt = self.storage_dtype
         with torch.no_grad():
-            ref_pyr = self.featurePyramid(ref_img, nscale)
-            src_pyrs = [self.featurePyramid(s, nscale) for s in src_imgs]
+            if all(s.shape == ref_img.shape for s in src_imgs):
+                # all views through the pyramid tower as one batch (same result as the per-view loop)
+                levels = [torch.chunk(f, nsrc + 1, 0) for f in self.featurePyramid(torch.cat([ref_img] + list(src_imgs), 0), nscale)]
+                ref_pyr = [lv[0] for lv in levels]
+                src_pyrs = [[lv[i + 1] for lv in levels] for i in range(nsrc)]
+            else:
+                ref_pyr = self.featurePyramid(ref_img, nscale)
+                src_pyrs = [self.featurePyramid(s, nscale) for s in src_imgs]
             ref_in_ms = conditionIntrinsics(ref_in, ref_img.shape, [f.shape for f in ref_pyr])
             src_in_ms = torch.stack([conditionIntrinsics(src_in[:, i], ref_img.shape, [f.shape for f in src_pyrs[i]])
                                      for i in range(nsrc)]).permute(1, 0, 2, 3, 4)

@@ -130,6 +130,11 @@ class MVSNet(nn.Module):
 
     # -- upstream ---------------------------------------------------------------------------
     def extract_features(self, imgs: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+        """All views through the 2-D extractor as ONE batch (V x fewer MIOpen launches; eval-mode BatchNorm is a
+        per-channel affine, so the result equals the reference's per-view loop, model.py:101-107)."""
+        imgs = list(imgs)
+        if len({tuple(i.shape) for i in imgs}) == 1:
+            return list(torch.chunk(self.feature(torch.cat(imgs, 0)), len(imgs), 0))
         return [self.feature(img) for img in imgs]
 
     # -- hot path ---------------------------------------------------------------------------

@@ -48,12 +48,18 @@ class Frontend(nn.Module):
                                       depth_min[:, reference_frame], depth_interval[:, reference_frame])
         srcs_cam = [self.fill_cam_array(K[:, i], R[:, i], t[:, i], depth_min[:, i], depth_interval[:, i]) for i in src_idx]
         with torch.no_grad():
-            ref_feats = self.model.feat_ext(imgs[reference_frame])
             grp = self.model.stage1.view_group
-            if grp is None:
+            if grp is None and len({tuple(i.shape) for i in imgs}) == 1:
+                # all views through the 2-D extractor as one batch (same result as the per-view loop in eval mode)
+                packs = [torch.chunk(f, v, 0) for f in self.model.feat_ext(torch.cat([imgs[reference_frame]] + [imgs[i] for i in src_idx], 0))]
+                ref_feats = tuple(p[0] for p in packs)
+                src_feats = [tuple(p[j + 1] for p in packs) for j in range(len(src_idx))]
+            elif grp is None:
+                ref_feats = self.model.feat_ext(imgs[reference_frame])
                 src_feats = [self.model.feat_ext(imgs[i]) for i in src_idx]
             else:   # view shard: a rank only extracts the features of the source views it will sweep
                 import torch.distributed as dist
+                ref_feats = self.model.feat_ext(imgs[reference_frame])
                 world, rank = dist.get_world_size(grp), dist.get_rank(grp)
                 src_feats = [self.model.feat_ext(imgs[i]) if j % world == rank else (None, None, None)
                              for j, i in enumerate(src_idx)]
