@@ -130,10 +130,29 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
     const int o_h = (KIND == PSCV_CONV_S1) ? t0h - 1 : (KIND == PSCV_CONV_S2) ? 2 * t0h - 1 : t0h;
     const int o_w = (KIND == PSCV_CONV_S1) ? t0w - 1 : (KIND == PSCV_CONV_S2) ? 2 * t0w - 1 : t0w;
 
+    // ---- weight prefetch ring (dense kinds): the A fragments of the first PF k-steps are requested BEFORE the brick is
+    // staged, so their L2 latency overlaps the brick's; inside the k-loop step s+PF is requested as soon as step s has
+    // been consumed.  (Left to the compiler, weight loads were issued 1-2 steps ahead and every k-step waited on L2.)
+    const int tid = threadIdx.x;
+    const int nt0 = blockIdx.y * NT;
+    const uint4* wpk = reinterpret_cast<const uint4*>(a.wpk);
+    const bool WLDS = (TD == 1) && a.wlds;   // small-tile variant on small grids only (wave-uniform)
+    constexpr int PF_WANT = 24 / NT;
+    // (dense kinds only: in the transposed kind the step index depends on the parity class and the ring index would not
+    //  be a compile-time constant everywhere -- the ring then lands in scratch memory)
+    constexpr int NSTEPS_ALL = conv_total_steps(KIND, CIN);
+    constexpr int PF = (KIND == PSCV_CONV_T2) ? 1 : (NSTEPS_ALL < PF_WANT ? NSTEPS_ALL : PF_WANT);
+    uint4 wring[PF][NT];
+    if (KIND != PSCV_CONV_T2 && !WLDS) {
+#pragma unroll
+        for (int s = 0; s < PF; ++s)
+#pragma unroll
+            for (int m = 0; m < NT; ++m) wring[s][m] = wpk[(s * a.nt_total + nt0 + m) * 64 + (tid & 63)];
+    }
+
     // ---- stage the input brick into LDS (zero fill outside the volume = the conv's padding) ----
     // Loads are issued in batches of up to 8 per thread before any of them is written to LDS, so the batch shares
     // one memory latency (a load -> wait -> ds_write loop exposed the L2/HBM latency once per 16-byte chunk).
-    const int tid = threadIdx.x;
     {
         const uint16_t* inb = a.in + (long)b * a.Di * a.Hi * a.Wi * a.in_cs + a.in_co;
         constexpr int NCHUNK = NVOX * CCH;
@@ -159,13 +178,11 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
         }
     }
     // per-channel epilogue constants of this block's NT output tiles -> LDS (one global read per block)
-    const int nt0 = blockIdx.y * NT;
     float* epi_sc = reinterpret_cast<float*>(smem + ((NVOX * VS + 15) & ~15));
     float* epi_bi = epi_sc + NT * 16;
     float* epi_fl = epi_bi + NT * 16;
     // small-tile variant: this block's A fragments are copied to LDS together with the brick (one exposed memory
     // latency for both) instead of being fetched from L2 step by step inside the short, latency-bound k-loop
-    const bool WLDS = (TD == 1) && a.wlds;   // small-tile variant on small grids only (wave-uniform)
     constexpr int WSTEPS = conv_total_steps(KIND, CIN);
     uint4* wlds = reinterpret_cast<uint4*>(epi_fl + NT * 16);
     if (WLDS) {
@@ -175,9 +192,9 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
             uint4 wv[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const int i = i0 + k * 256 + tid;
+                const int i = min(i0 + k * 256 + tid, NW - 1);   // clamped: unconditional load keeps wv[] in registers
                 const int l = i & 63, sm = i >> 6, m = sm % NT, st = sm / NT;
-                if (i < NW) wv[k] = wsrc[(st * a.nt_total + nt0 + m) * 64 + l];
+                wv[k] = wsrc[(st * a.nt_total + nt0 + m) * 64 + l];
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -197,7 +214,6 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
 
     const int lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
-    const uint4* wpk = reinterpret_cast<const uint4*>(a.wpk);
 
     // per-M-tile LDS anchors of this lane's voxel column
     int anchor[MB];
@@ -264,12 +280,16 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
             const int koff = tap_off_dense<KIND, BH, BW, VS>(kk0 / CIN) + (kk0 % CIN) * 2;
             uint4 wf[NT];
 #pragma unroll
-            for (int m = 0; m < NT; ++m) wf[m] = WLDS ? wlds[(s * NT + m) * 64 + lane] : wpk[(s * a.nt_total + nt0 + m) * 64 + lane];
+            for (int m = 0; m < NT; ++m) wf[m] = WLDS ? wlds[(s * NT + m) * 64 + lane] : wring[s % PF][m];
 #pragma unroll
             for (int i = 0; i < MB; ++i) {
                 const uint4 xf = *reinterpret_cast<const uint4*>(smem + anchor[i] + koff);
 #pragma unroll
                 for (int m = 0; m < NT; ++m) acc[i][m] = Mfma<H>::run(wf[m], xf, acc[i][m]);
+            }
+            if (!WLDS && s + PF < NSTEPS) {
+#pragma unroll
+                for (int m = 0; m < NT; ++m) wring[s % PF][m] = wpk[((s + PF) * a.nt_total + nt0 + m) * 64 + lane];
             }
         }
 #pragma unroll
@@ -292,15 +312,17 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
                 if (s < nsteps) {
                     const int kk0 = s * 32 + g * 8;
                     const int koff = tap_off_t2<BH, BW, VS>(pc, kk0 / CIN) + (kk0 % CIN) * 2;
+                    const int fs = sbase + s;   // flat step index over all classes (compile-time after unrolling)
                     uint4 wf[NT];
 #pragma unroll
-                    for (int m = 0; m < NT; ++m) wf[m] = WLDS ? wlds[((sbase + s) * NT + m) * 64 + lane] : wpk[((sbase + s) * a.nt_total + nt0 + m) * 64 + lane];
+                    for (int m = 0; m < NT; ++m) wf[m] = WLDS ? wlds[(fs * NT + m) * 64 + lane] : wpk[(fs * a.nt_total + nt0 + m) * 64 + lane];
 #pragma unroll
                     for (int i = 0; i < MB; ++i) {
                         const uint4 xf = *reinterpret_cast<const uint4*>(smem + anchor[i] + koff);
 #pragma unroll
                         for (int m = 0; m < NT; ++m) acc[i][m] = Mfma<H>::run(wf[m], xf, acc[i][m]);
                     }
+
                 }
             }
             const int pd = (pc >> 2) & 1, ph = (pc >> 1) & 1, pw = pc & 1;
