@@ -70,7 +70,9 @@ const char* pscv_last_error(void);
 int pscv_abi_version(void);
 
 /* Tuning knobs for measurement runs (not part of the reference's surface). Keys:
- *   "warp_lpv"  lanes sharing one voxel in pscv_warp_cost (1, 2 or 4 for C=32; 0 = default C/8)
+ *   "warp_q2"   1 (default): 32-channel 16-bit sweeps run on the quad-mapped kernel (one texel per lane quad, two depth
+ *               planes per quad); 0: always the generic kernel.  "warp_lpv" != 0 also selects the generic kernel.
+ *   "warp_lpv"  lanes sharing one voxel in the generic pscv_warp_cost kernel (1, 2 or 4 for C=32; 0 = default)
  *   "warp_ppd"  depth planes per workgroup in pscv_warp_cost (0 = default 8)
  *   "warp_tiled" 1: pscv_warp_cost stages source patches in LDS where it applies (C = 32, 16-bit features,
  *               per-batch planes, PROJ geometry, 2-4 source views, variance / softmin); 0 (default): the

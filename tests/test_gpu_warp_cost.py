@@ -185,3 +185,54 @@ def test_tiled_kernel_equals_direct_kernel(env, baseline_scale, shape, cost_name
     s = check_close(f"tiled vs direct {cost_name} baseline x{baseline_scale} {shape}", outs[0], outs[1],
                     max_abs=2 ** -10 * float(outs[1].abs().max()), rel_l2=2e-5)
     assert float(outs[1].abs().max()) > 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("cost_name", ["variance", "variance_cvp", "softmin", "warp_only", "groupcorr", "warp_only_homog"])
+@pytest.mark.parametrize("baseline_scale,shape,D,per_pixel", [(1.0, (64, 80), 24, False), (1.0, (37, 53), 23, True),
+                                                              (12.0, (40, 48), 7, False)])
+def test_quad_kernel_equals_generic_kernel(env, baseline_scale, shape, D, per_pixel, cost_name, dtype):
+    """The quad-mapped kernel (warp_cost_quad.hip: one texel per lane quad, two depth planes per quad) and the generic
+    2-lanes-per-voxel kernel run the same arithmetic on the same taps: every cost mode of both geometries, an odd
+    plane count (the unpaired tail plane), image sizes that do not divide the 64-pixel blocks, per-pixel planes (CVP /
+    Vis refinement stages), and a 12x wider baseline where most samples leave the image (border path, zero padding,
+    points behind the camera).  Agreement to one stored ulp (the compiler contracts the final variance / softmin
+    expression differently in the two kernels)."""
+    L, ops, O = env
+    from wild_deep_mvs_amd import synthetic
+    from oracle.mvsnet import mvsnet_cameras
+    h, w = shape
+    B, V, C = 2, 4, 32
+    feats = synthetic.make_features(B, V, C, h, w, seed=5)
+    cam = synthetic.make_cameras(B, V, 4 * h, 4 * w)
+    cam["t"] = cam["t"] * baseline_scale
+    proj, dvals = mvsnet_cameras(cam["K"], cam["R"], cam["t"], cam["depth_min"], cam["depth_max"], D)
+    fcl = [ops.to_channels_last(feats[i].cuda(), dtype) for i in range(V)]
+    dv = dvals[:, 0].contiguous()
+    if per_pixel:
+        gen = torch.Generator().manual_seed(1)
+        dv = (dv.view(B, D, 1, 1) * (1.0 + 0.05 * torch.rand(B, 1, h, w, generator=gen))).contiguous()
+    homog = cost_name in ("groupcorr", "warp_only_homog")
+    if homog:
+        import oracle.vismvsnet as OV
+        di = (cam["depth_max"] - cam["depth_min"]) / D
+        arr = [OV.fill_cam_array(cam["K"][:, i], cam["R"][:, i], cam["t"][:, i], cam["depth_min"][:, i], di[:, i]) for i in range(V)]
+        cams = ops.homog_cams_device(arr[0].cuda(), [a.cuda() for a in arr[1:]], 1.0 / 4)
+        geom = L.GEOM_HOMOG
+    else:
+        cams = ops.proj_cams_device(proj.cuda().contiguous(), 0)
+        geom = L.GEOM_PROJ
+    code = {"variance": L.COST_VARIANCE, "variance_cvp": L.COST_VARIANCE_CVP, "softmin": L.COST_SOFTMIN,
+            "warp_only": L.COST_WARP_ONLY, "groupcorr": L.COST_GROUPCORR, "warp_only_homog": L.COST_WARP_ONLY}[cost_name]
+    ref_in = None if code == L.COST_WARP_ONLY else fcl[0]
+    outs = []
+    for q2 in (1, 0):
+        L.set_tuning("warp_q2", q2)
+        try:
+            outs.append(ops.warp_cost(ref_in, fcl[1:], cams, dv.cuda(), geom=geom, cost=code, temp=0.7, out_dtype=dtype).float().cpu())
+        finally:
+            L.set_tuning("warp_q2", 1)
+    ulp = 2 ** -7 if dtype == torch.bfloat16 else 2 ** -10
+    assert float(outs[1].abs().max()) > 0
+    check_close(f"quad vs generic {cost_name} {dtype} baseline x{baseline_scale} {shape} D={D}", outs[0], outs[1],
+                max_abs=ulp * float(outs[1].abs().max()), rel_l2=ulp / 16)

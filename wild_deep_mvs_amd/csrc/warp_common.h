@@ -93,55 +93,104 @@ __device__ __forceinline__ float fma_mix_hi(uint32_t h2, float w, float acc) {
     return d;
 }
 
-// Zero-padded bilinear gather of this lane's CPL channels.
-template <typename TIn, int CPL>
-__device__ __forceinline__ VecF<CPL> gather_bilinear(const TIn* __restrict__ img, int b, int hs, int ws, int C,
-                                                     int choff, float ix, float iy) {
-    const float x0f = floorf(ix), y0f = floorf(iy);
-    const float fx = ix - x0f, fy = iy - y0f;
-    const int x0 = (int)x0f, y0 = (int)y0f;
-    const int x1 = x0 + 1, y1 = y0 + 1;
-    const bool vx0 = (unsigned)x0 < (unsigned)ws, vx1 = (unsigned)x1 < (unsigned)ws;
-    const bool vy0 = (unsigned)y0 < (unsigned)hs, vy1 = (unsigned)y1 < (unsigned)hs;
+// ---- direct-gather kernel helpers (warp_cost.hip) -----------------------------------------------------------------
+// The sweep is VALU-issue bound (profiles/), so the per-(plane, view) instruction count is what these are shaped for.
+
+// first blend term: float(half) * w  (fma with an inline 0.0 accumulator: bit-identical to the plain product)
+__device__ __forceinline__ float mul_mix_lo(uint32_t h2, float w) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(w));
+    return d;
+}
+__device__ __forceinline__ float mul_mix_hi(uint32_t h2, float w) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(w));
+    return d;
+}
+__device__ __forceinline__ int med3_i32(int x, int lo, int hi) {
+    int d;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(lo), "v"(hi));
+    return d;
+}
+
+// Bilinear taps of one (voxel, view): byte offsets from the (wave-uniform) image base and the four weights.
+struct Taps {
+    unsigned o00, o01, o10, o11;
+    float w00, w01, w10, w11;
+};
+
+// Pixel index -> taps.  INTERIOR: the caller has established (for the whole wave) that all four taps lie inside the
+// image, so the validity masks, the index clamps and two of the offsets disappear; the arithmetic that remains is the
+// same as in the general form, so both produce identical bits.
+template <bool INTERIOR, int PIXB>
+__device__ __forceinline__ void make_taps(float fx, float fy, int x0, int y0, int hs, int ws, unsigned chb, Taps& t) {
     const float gx = 1.0f - fx, gy = 1.0f - fy;
-    const float w00 = (vx0 && vy0) ? gx * gy : 0.0f;
-    const float w01 = (vx1 && vy0) ? fx * gy : 0.0f;
-    const float w10 = (vx0 && vy1) ? gx * fy : 0.0f;
-    const float w11 = (vx1 && vy1) ? fx * fy : 0.0f;
-    const int xc0 = min(max(x0, 0), ws - 1), xc1 = min(max(x1, 0), ws - 1);
-    const int yc0 = min(max(y0, 0), hs - 1), yc1 = min(max(y1, 0), hs - 1);
-    // wave-uniform batch base (SGPR pair) + 32-bit per-lane element offsets (feature maps are far below 2^31
-    // elements): the loads use the scalar-base addressing form, no 64-bit vector address arithmetic
-    const TIn* base = img + (long)b * hs * ws * C;
-    const int o00 = (yc0 * ws + xc0) * C + choff, o01 = (yc0 * ws + xc1) * C + choff;
-    const int o10 = (yc1 * ws + xc0) * C + choff, o11 = (yc1 * ws + xc1) * C + choff;
+    if (INTERIOR) {
+        t.w00 = gx * gy; t.w01 = fx * gy; t.w10 = gx * fy; t.w11 = fx * fy;
+        t.o00 = (__umul24((unsigned)y0, (unsigned)ws) + (unsigned)x0) * PIXB + chb;
+        t.o10 = t.o00 + (unsigned)ws * PIXB;
+        t.o01 = 0; t.o11 = 0;   // = o00 + PIXB, o10 + PIXB: folded into the load's immediate offset
+    } else {
+        const int x1 = x0 + 1, y1 = y0 + 1;
+        const bool vx0 = (unsigned)x0 < (unsigned)ws, vx1 = (unsigned)x1 < (unsigned)ws;
+        const bool vy0 = (unsigned)y0 < (unsigned)hs, vy1 = (unsigned)y1 < (unsigned)hs;
+        t.w00 = (vx0 && vy0) ? gx * gy : 0.0f;
+        t.w01 = (vx1 && vy0) ? fx * gy : 0.0f;
+        t.w10 = (vx0 && vy1) ? gx * fy : 0.0f;
+        t.w11 = (vx1 && vy1) ? fx * fy : 0.0f;
+        const unsigned xc0 = (unsigned)med3_i32(x0, 0, ws - 1), xc1 = (unsigned)med3_i32(x1, 0, ws - 1);
+        const unsigned r0 = __umul24((unsigned)med3_i32(y0, 0, hs - 1), (unsigned)ws);
+        const unsigned r1 = __umul24((unsigned)med3_i32(y1, 0, hs - 1), (unsigned)ws);
+        t.o00 = (r0 + xc0) * PIXB + chb; t.o01 = (r0 + xc1) * PIXB + chb;
+        t.o10 = (r1 + xc0) * PIXB + chb; t.o11 = (r1 + xc1) * PIXB + chb;
+    }
+}
+
+// Zero-padded bilinear blend of this lane's CPL channels.  `base` is wave-uniform (SGPR pair) and the offsets are
+// unsigned 32-bit byte offsets, so every tap is a `global_load_dwordx4 v, voff, s[base] offset:imm`: no 64-bit
+// vector address arithmetic.  All CPL/8 x 4 loads are issued before the first use.
+template <typename TIn, int CPL, bool INTERIOR, int PIXB>
+__device__ __forceinline__ VecF<CPL> blend_taps(const char* __restrict__ base, const Taps& t) {
+    constexpr int NK = CPL / 8;
+    constexpr int CB = 8 * (int)sizeof(TIn);   // bytes of one 8-channel chunk
+    const char* p00 = base + t.o00;
+    const char* p10 = base + t.o10;
+    const char* p01 = INTERIOR ? p00 + PIXB : base + t.o01;
+    const char* p11 = INTERIOR ? p10 + PIXB : base + t.o11;
     VecF<CPL> r;
     if constexpr (sizeof(TIn) == 2 && Elem<TIn>::dtype == PSCV_F16) {
-        // fp16 taps: v_fma_mix_f32 converts the half operand and does the fp32 FMA in ONE instruction, so the 64
-        // v_cvt_f32_f16 of a 16-channel blend disappear; the arithmetic (exact convert, fp32 FMA chain in the same
-        // order) is bit-identical to the generic path below.  The kernel is VALU-issue bound (profiles/).
+        // fp16 taps: v_fma_mix_f32 converts the half operand and does the fp32 FMA in ONE instruction.  The four
+        // blend stages run across all channels of a chunk (independent chains back to back: no dependent-issue nops).
+        uint4 a[NK], b[NK], c[NK], d[NK];
 #pragma unroll
-        for (int k = 0; k < CPL / 8; ++k) {
-            const uint4 a = *reinterpret_cast<const uint4*>(base + o00 + 8 * k);
-            const uint4 bq = *reinterpret_cast<const uint4*>(base + o01 + 8 * k);
-            const uint4 c = *reinterpret_cast<const uint4*>(base + o10 + 8 * k);
-            const uint4 d = *reinterpret_cast<const uint4*>(base + o11 + 8 * k);
-            const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {bq.x, bq.y, bq.z, bq.w};
-            const uint32_t cw[4] = {c.x, c.y, c.z, c.w}, dw[4] = {d.x, d.y, d.z, d.w};
+        for (int k = 0; k < NK; ++k) {
+            a[k] = *reinterpret_cast<const uint4*>(p00 + CB * k);
+            b[k] = *reinterpret_cast<const uint4*>(p01 + CB * k);
+            c[k] = *reinterpret_cast<const uint4*>(p10 + CB * k);
+            d[k] = *reinterpret_cast<const uint4*>(p11 + CB * k);
+        }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                r.v[8 * k + 2 * q] = fma_mix_lo(dw[q], w11, fma_mix_lo(cw[q], w10, fma_mix_lo(bw[q], w01, fma_mix_lo(aw[q], w00, 0.0f))));
-                r.v[8 * k + 2 * q + 1] = fma_mix_hi(dw[q], w11, fma_mix_hi(cw[q], w10, fma_mix_hi(bw[q], w01, fma_mix_hi(aw[q], w00, 0.0f))));
-            }
+        for (int k = 0; k < NK; ++k) {
+            const uint32_t aw[4] = {a[k].x, a[k].y, a[k].z, a[k].w}, bw[4] = {b[k].x, b[k].y, b[k].z, b[k].w};
+            const uint32_t cw[4] = {c[k].x, c[k].y, c[k].z, c[k].w}, dw[4] = {d[k].x, d[k].y, d[k].z, d[k].w};
+            float* o = r.v + 8 * k;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { o[2 * q] = mul_mix_lo(aw[q], t.w00); o[2 * q + 1] = mul_mix_hi(aw[q], t.w00); }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { o[2 * q] = fma_mix_lo(bw[q], t.w01, o[2 * q]); o[2 * q + 1] = fma_mix_hi(bw[q], t.w01, o[2 * q + 1]); }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { o[2 * q] = fma_mix_lo(cw[q], t.w10, o[2 * q]); o[2 * q + 1] = fma_mix_hi(cw[q], t.w10, o[2 * q + 1]); }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { o[2 * q] = fma_mix_lo(dw[q], t.w11, o[2 * q]); o[2 * q + 1] = fma_mix_hi(dw[q], t.w11, o[2 * q + 1]); }
         }
     } else {
-        const VecF<CPL> f00 = load_chan<TIn, CPL>(base + o00);
-        const VecF<CPL> f01 = load_chan<TIn, CPL>(base + o01);
-        const VecF<CPL> f10 = load_chan<TIn, CPL>(base + o10);
-        const VecF<CPL> f11 = load_chan<TIn, CPL>(base + o11);
+        const VecF<CPL> f00 = load_chan<TIn, CPL>(reinterpret_cast<const TIn*>(p00));
+        const VecF<CPL> f01 = load_chan<TIn, CPL>(reinterpret_cast<const TIn*>(p01));
+        const VecF<CPL> f10 = load_chan<TIn, CPL>(reinterpret_cast<const TIn*>(p10));
+        const VecF<CPL> f11 = load_chan<TIn, CPL>(reinterpret_cast<const TIn*>(p11));
 #pragma unroll
         for (int j = 0; j < CPL; ++j)
-            r.v[j] = fmaf(f11.v[j], w11, fmaf(f10.v[j], w10, fmaf(f01.v[j], w01, f00.v[j] * w00)));
+            r.v[j] = fmaf(f11.v[j], t.w11, fmaf(f10.v[j], t.w10, fmaf(f01.v[j], t.w01, f00.v[j] * t.w00)));
     }
     return r;
 }

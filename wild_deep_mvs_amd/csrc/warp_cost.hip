@@ -25,9 +25,11 @@
 namespace pscv {
 
 template <typename TIn, typename TOut, int C, int LPV, int GEOM, int COST>
-__global__ __launch_bounds__(256) void warp_cost_kernel(const WarpArgs a) {
+__global__ __launch_bounds__(256, 4) void warp_cost_kernel(const WarpArgs a) {
     constexpr int CPL = C / LPV;        // channels per lane
     constexpr int PPB = 256 / LPV;      // pixels per block
+    constexpr int PIXB = C * (int)sizeof(TIn);   // bytes of one source texel
+    constexpr int RQ = (GEOM == PSCV_GEOM_HOMOG) ? 2 : 1;   // float4s of depth-independent ray terms per (view, pixel)
     static_assert(CPL % 8 == 0, "a lane owns whole 8-channel groups");
 
     // XCD-aware bijective remap: hardware places block `bid` on XCD bid % 8; give XCD k a contiguous
@@ -37,34 +39,60 @@ __global__ __launch_bounds__(256) void warp_cost_kernel(const WarpArgs a) {
     const int xcd = bid & 7, slot = bid >> 3;
     const int q = nwg >> 3, r = nwg & 7;
     const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    const int pb = wg / a.n_dchunks;
-    const int dc = wg - pb * a.n_dchunks;
+    const int pb = __builtin_amdgcn_readfirstlane(wg / a.n_dchunks);
+    const int dc = __builtin_amdgcn_readfirstlane(wg - pb * a.n_dchunks);
 
     // a block never straddles batch items, so b (and with it every camera / depth-plane address) is
     // wave-uniform and those reads become scalar loads
-    const int b = pb / a.npb_batch;
-    const int pbb = pb - b * a.npb_batch;
+    // (integer division runs on the vector ALU: readfirstlane tells the compiler the results are scalars again)
+    const int b = __builtin_amdgcn_readfirstlane(pb / a.npb_batch);
+    const int pbb = __builtin_amdgcn_readfirstlane(pb - b * a.npb_batch);
 
     const int tid = threadIdx.x;
     // camera blocks of this batch item -> LDS once per workgroup.  (Read straight from global they were fetched with
     // VECTOR loads -- the compiler cannot use the scalar cache for memory the kernel might also store to -- which put a
     // second dependent memory latency and 3 extra VMEM instructions into every (plane, view) iteration.)
     __shared__ float cam_lds[PSCV_MAX_SRC * PSCV_CAM_FLOATS];
+    extern __shared__ __attribute__((aligned(16))) float4 ray_lds[];   // [n_src][PPB][RQ]
     for (int i = tid; i < a.n_src * PSCV_CAM_FLOATS; i += 256) {
         const int v = i / PSCV_CAM_FLOATS, k = i - v * PSCV_CAM_FLOATS;
         cam_lds[i] = a.cams[((long)v * a.B + b) * PSCV_CAM_FLOATS + k];
     }
     __syncthreads();
     const int hw = a.h * a.w;
-    int pflat = pbb * PPB + tid / LPV;
+    const int pl = tid / LPV;           // pixel slot inside the block
+    int pflat = pbb * PPB + pl;
     const bool active = pflat < hw;
     pflat = active ? pflat : hw - 1;
     const int choff = (tid % LPV) * CPL;
+    const unsigned chb = (unsigned)choff * (unsigned)sizeof(TIn);
     const long pix = (long)b * hw + pflat;
     const int y = pflat / a.w;
     const int x = pflat - y * a.w;
     const float off = (GEOM == PSCV_GEOM_HOMOG) ? 0.5f : 0.0f;   // homography.py:78-79 half-pixel centres
     const float px = (float)x + off, py = (float)y + off;
+
+    // Depth-independent part of the warp, once per (pixel, view) instead of once per (plane, view):
+    //   PROJ   q = rot (x, y, 1) * d + trans         -> rot (x, y, 1)                        module.py:138-144
+    //   HOMOG  hom = A p - (Bm p) / (d + 1e-9)       -> A p, Bm p                            homography.py:63-69
+    // Every lane of a pixel computes the same values; a pixel's lanes sit in one wave and only that wave reads the
+    // slot back, so program order is all the synchronisation this needs.
+    for (int v = 0; v < a.n_src; ++v) {
+        const float* cam = cam_lds + v * PSCV_CAM_FLOATS;
+        float4* slot_p = ray_lds + (v * PPB + pl) * RQ;
+        const float ax = fmaf(cam[1], py, cam[0] * px) + cam[2];
+        const float ay = fmaf(cam[4], py, cam[3] * px) + cam[5];
+        const float az = fmaf(cam[7], py, cam[6] * px) + cam[8];
+        if (GEOM == PSCV_GEOM_PROJ) {
+            slot_p[0] = make_float4(ax, ay, az, 0.0f);
+        } else {
+            const float bx = fmaf(cam[10], py, cam[9] * px) + cam[11];
+            const float by = fmaf(cam[13], py, cam[12] * px) + cam[14];
+            const float bz = fmaf(cam[16], py, cam[15] * px) + cam[17];
+            slot_p[0] = make_float4(ax, ay, az, bx);
+            slot_p[1] = make_float4(by, bz, 0.0f, 0.0f);
+        }
+    }
 
     const TIn* ref = reinterpret_cast<const TIn*>(a.ref);
     VecF<CPL> rf;
@@ -76,11 +104,17 @@ __global__ __launch_bounds__(256) void warp_cost_kernel(const WarpArgs a) {
     const int d1 = min(a.D, d0 + a.ppd);
     const float invN = 1.0f / (float)(a.n_src + 1);
     const float invN2 = 1.0f / ((float)(a.n_src + 1) * (float)(a.n_src + 1));
+    // wave-uniform byte offset of batch item b inside a source map, kept in scalar registers so that the taps use the
+    // scalar-base + 32-bit vector-offset addressing form
+    const unsigned long img_bytes_v = (unsigned long)b * a.hs * a.ws * PIXB;
+    const unsigned long img_bytes = ((unsigned long)__builtin_amdgcn_readfirstlane((unsigned)(img_bytes_v >> 32)) << 32) |
+                                    (unsigned)__builtin_amdgcn_readfirstlane((unsigned)img_bytes_v);
     TOut* out = reinterpret_cast<TOut*>(a.out);
 
     for (int d = d0; d < d1; ++d) {
         const float dval = a.depth_per_pixel ? a.depth[(long)b * a.depth_bstride + (long)d * hw + pflat]
                                              : a.depth[(long)b * a.depth_bstride + d];
+        const float inv_d = (GEOM == PSCV_GEOM_HOMOG) ? __builtin_amdgcn_rcpf(dval + 1e-9f) : 0.0f;
         const long vox = ((long)b * a.D + d) * hw + pflat;
 
         VecF<CPL> acc0, acc1;   // variance: sum, sum of squares; softmin: sum e*diff
@@ -95,10 +129,45 @@ __global__ __launch_bounds__(256) void warp_cost_kernel(const WarpArgs a) {
 
         for (int v = 0; v < a.n_src; ++v) {
             const float* cam = cam_lds + v * PSCV_CAM_FLOATS;
-            float ix, iy;
-            sweep_index<GEOM>(cam, px, py, dval, a, ix, iy);
-            const VecF<CPL> wv = gather_bilinear<TIn, CPL>(reinterpret_cast<const TIn*>(a.src[v]), b, a.hs, a.ws, C,
-                                                           choff, ix, iy);
+            const float4* ray = ray_lds + (v * PPB + pl) * RQ;
+            float hx, hy, hz;
+            if (GEOM == PSCV_GEOM_PROJ) {
+                const float4 r0 = ray[0];
+                hx = fmaf(r0.x, dval, cam[9]);
+                hy = fmaf(r0.y, dval, cam[10]);
+                hz = fmaf(r0.z, dval, cam[11]);
+            } else {
+                const float4 r0 = ray[0], r1 = ray[1];
+                hx = fmaf(-r0.w, inv_d, r0.x);
+                hy = fmaf(-r1.x, inv_d, r0.y);
+                hz = fmaf(-r1.y, inv_d, r0.z);
+            }
+            // perspective divide; points at or behind the source camera go to (-10, -10)   module.py:146-150,
+            // homography.py:113-117 (which also clamps the divisor at 1e-9)
+            const bool front = hz > 0.0f;
+            const float inv_z = __builtin_amdgcn_rcpf(GEOM == PSCV_GEOM_HOMOG ? fmaxf(hz, 1e-9f) : hz);
+            float u = front ? hx * inv_z : -10.0f;
+            float w_ = front ? hy * inv_z : -10.0f;
+            if (GEOM == PSCV_GEOM_HOMOG) { u *= a.sx; w_ *= a.sy; }   // PROJ: index scale is exactly 1
+            // normalise -> clamp -> align_corners=True un-normalise collapses to a (scaled,) clamped index
+            const float ix = __builtin_amdgcn_fmed3f(u, a.xlo, a.xhi);
+            const float iy = __builtin_amdgcn_fmed3f(w_, a.ylo, a.yhi);
+            const float x0f = floorf(ix), y0f = floorf(iy);
+            const float fx = ix - x0f, fy = iy - y0f;
+            const int x0 = (int)x0f, y0 = (int)y0f;
+
+            const char* img = reinterpret_cast<const char*>(a.src[v]) + img_bytes;
+            // all four taps of every voxel of this wave inside the image?  (the common case away from the border)
+            const bool interior = (unsigned)x0 < (unsigned)(a.ws - 1) && (unsigned)y0 < (unsigned)(a.hs - 1);
+            Taps taps;
+            VecF<CPL> wv;
+            if (__builtin_amdgcn_ballot_w64(!interior) == 0) {
+                make_taps<true, PIXB>(fx, fy, x0, y0, a.hs, a.ws, chb, taps);
+                wv = blend_taps<TIn, CPL, true, PIXB>(img, taps);
+            } else {
+                make_taps<false, PIXB>(fx, fy, x0, y0, a.hs, a.ws, chb, taps);
+                wv = blend_taps<TIn, CPL, false, PIXB>(img, taps);
+            }
             if (COST == PSCV_COST_VARIANCE || COST == PSCV_COST_VARIANCE_CVP) {
 #pragma unroll
                 for (int j = 0; j < CPL; ++j) {
@@ -171,16 +240,29 @@ static int g_warp_tiled = 0;     // 1: use the LDS-staged kernel (warp_cost_tile
 extern int g_conv_small_tiles;   // conv3d.hip
 extern int g_sweep_th16;         // conv3d_sweep.hip
 extern int g_sweep_dc;
+static int g_warp_q2 = 1;        // 1: 32-channel 16-bit sweeps use the quad-mapped kernel (warp_cost_q2.hip)
+int warp_cost_q2_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, int out_dtype, int ppd_override, hipStream_t st);
 int warp_cost_tiled_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, int out_dtype, int ppd_override, hipStream_t st);
 
 // Instantiated (geometry, cost) pairs: the variance / softmin statistics belong to the PROJ models (MVSNet,
 // CVP), group-wise correlation to the HOMOG model (Vis); the plain warp exists for both.
+// dynamic LDS = the per-(view, pixel) ray terms; above the 64 KiB default (many views) the kernel needs the opt-in
+template <typename K>
+static int launch_one(K kern, const WarpArgs& a, int nblk, size_t ray_bytes, hipStream_t st) {
+    if (ray_bytes > 60000) {   // rare (> 14 HOMOG views): not worth caching per kernel
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ray_bytes);
+        if (e != hipSuccess) { set_error("pscv_warp_cost: hipFuncSetAttribute(%zu B LDS): %s", ray_bytes, hipGetErrorString(e)); return -2; }
+    }
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), ray_bytes, st, a);
+    return 0;
+}
+
 template <typename TIn, typename TOut, int C, int LPV, int GEOM>
 static int launch_cost(const WarpArgs& a, int cost, int nblk, hipStream_t st) {
+    const size_t ray_bytes = (size_t)a.n_src * (256 / LPV) * (GEOM == PSCV_GEOM_HOMOG ? 32 : 16);
 #define PSCV_LAUNCH_COST(COSTV)                                                                              \
     case COSTV:                                                                                              \
-        hipLaunchKernelGGL((warp_cost_kernel<TIn, TOut, C, LPV, GEOM, COSTV>), dim3(nblk), dim3(256), 0, st, a); \
-        return 0;
+        return launch_one(warp_cost_kernel<TIn, TOut, C, LPV, GEOM, COSTV>, a, nblk, ray_bytes, st);
     if constexpr (GEOM == PSCV_GEOM_PROJ) {
         switch (cost) {
             PSCV_LAUNCH_COST(PSCV_COST_VARIANCE)
@@ -245,6 +327,7 @@ extern "C" int pscv_set_tuning(const char* key, int value) {
     if (!strcmp(key, "warp_ppd")) { g_warp_ppd_override = value; return 0; }
     if (!strcmp(key, "conv_small_tiles")) { g_conv_small_tiles = value; return 0; }
     if (!strcmp(key, "warp_tiled")) { g_warp_tiled = value; return 0; }
+    if (!strcmp(key, "warp_q2")) { g_warp_q2 = value; return 0; }
     if (!strcmp(key, "sweep_th16")) { g_sweep_th16 = value; return 0; }
     if (!strcmp(key, "sweep_dc")) { g_sweep_dc = value; return 0; }
     set_error("pscv_set_tuning: unknown key '%s'", key);
@@ -261,6 +344,8 @@ extern "C" int pscv_warp_cost(const void* ref, const void* const* srcs, int n_sr
     PSCV_CHECK_ARG(cost == PSCV_COST_WARP_ONLY || ref, "pscv_warp_cost: ref is required for cost mode %d", cost);
     PSCV_CHECK_ARG(B > 0 && h > 0 && w > 0 && hs > 1 && ws > 1 && D > 0, "pscv_warp_cost: bad sizes");
     PSCV_CHECK_ARG(C % 8 == 0, "pscv_warp_cost: C=%d must be a multiple of 8", C);
+    // taps are addressed with 24-bit texel indices and 32-bit byte offsets inside one source image
+    PSCV_CHECK_ARG((long)hs * ws < (1L << 24) && (long)hs * ws * C * 4 < (1L << 32), "pscv_warp_cost: source map %dx%dx%d too large", hs, ws, C);
     WarpArgs a;
     a.ref = ref;
     for (int i = 0; i < PSCV_MAX_SRC; ++i) a.src[i] = i < n_src ? srcs[i] : nullptr;
@@ -293,6 +378,14 @@ extern "C" int pscv_warp_cost(const void* ref, const void* const* srcs, int n_sr
         if (rc < 0) return rc;
         if (rc == 0) {
             PSCV_CHECK_LAUNCH("pscv_warp_cost(tiled)");
+            return 0;
+        }
+    }
+    if (g_warp_q2 && g_warp_lpv_override == 0) {
+        rc = warp_cost_q2_try(a, C, geom, cost, in_dtype, out_dtype, g_warp_ppd_override, st);
+        if (rc < 0) return rc;
+        if (rc == 0) {
+            PSCV_CHECK_LAUNCH("pscv_warp_cost(q2)");
             return 0;
         }
     }
