@@ -59,8 +59,8 @@ extern "C" {
                             MFMA rows, register-resident weights); same result as PSCV_CONV_S1, own packed layout */
 #define PSCV_CONV_T2P8 5 /* ConvTranspose3d k3 s2 p1 op1 with c_in = 16, c_out = 8 on the parity-pair packed kernel; same
                             result as PSCV_CONV_T2, own packed layout */
-#define PSCV_CONV_S1C1 4 /* Conv3d k3 s1 p1 with c_out = 1, c_in = 8 or 16 (the `prob` heads) on the vector-ALU
-                            dot2 sweep kernel; same result as PSCV_CONV_S1, own packed layout */
+#define PSCV_CONV_S1C1 4 /* Conv3d k3 s1 p1 with c_out = 1, c_in = 8 or 16 (the `prob` heads) on the depth-in-rows MFMA
+                            kernel (six output planes share one MFMA tile); same result as PSCV_CONV_S1, own packed layout */
 
 /* epilogue flags for pscv_conv3d */
 #define PSCV_EPI_RELU_PRE 1  /* y = max(y, 0) before the skip add   (MVSNet/CVP: skip + relu(bn(deconv))) */

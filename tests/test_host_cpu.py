@@ -201,13 +201,39 @@ def test_parity_pair_deconv_packing_contracts_like_the_kernel():
 
 
 def test_one_channel_packing_layout():
-    """PSCV_CONV_S1C1: [tap = kd*9 + kh*3 + kw][c_in] 16-bit values."""
+    """PSCV_CONV_S1C1: depth-in-rows MFMA layout [step][lane][8] (conv3d_c1.hip).  Emulates the kernel's operand
+    addressing in numpy -- A rows = 6 output planes, K = 8 input planes x 9 taps x c_in, step s = (q, tap), lane group
+    g = lane >> 4 reads plane 4 (g >> 1) + 2 q + (g & 1) (c_in 8) or plane 4 (g >> 1) + q, channel half g & 1
+    (c_in 16) -- and checks the result of D = A B against torch's conv3d."""
+    import torch.nn.functional as F
     rng = np.random.default_rng(2)
     for cin in (8, 16):
-        w = _bf16(rng.standard_normal((1, cin, 3, 3, 3)).astype(np.float32))
+        w = _bf16(rng.standard_normal((1, cin, 3, 3, 3)).astype(np.float32) / 8)
         packed = ops.pack_conv3d_weights(torch.from_numpy(w), L.CONV_S1C1, False, torch.float16)
-        got = packed.view(np.float16).astype(np.float32).reshape(27, cin)
-        np.testing.assert_array_equal(got, w[0].reshape(cin, 27).T)
+        nsteps = 8 * 9 * cin // 32
+        wk = packed.view(np.float16).astype(np.float32).reshape(nsteps, 64, 8)
+        Dd, Hh, Ww = 6, 3, 16
+        x = _bf16(rng.standard_normal((Dd, Hh, Ww, cin)).astype(np.float32))
+        xp = np.zeros((Dd + 2, Hh + 2, Ww + 2, cin), np.float32)
+        xp[1:-1, 1:-1, 1:-1] = x                                     # brick: plane p = d0 - 1 + p
+        out = np.zeros((Dd, Hh, Ww), np.float32)
+        for row in range(Hh):
+            acc = np.zeros((16, 16), np.float32)                    # [m][n]
+            for s in range(nsteps):
+                A = np.zeros((16, 32), np.float32)
+                Bm = np.zeros((32, 16), np.float32)
+                for lane in range(64):
+                    mn, g = lane & 15, lane >> 4
+                    A[mn, g * 8:(g + 1) * 8] = wk[s, lane]
+                    q, t = s // 9, s % 9
+                    p = 4 * (g >> 1) + 2 * q + (g & 1) if cin == 8 else 4 * (g >> 1) + q
+                    ch = slice(0, 8) if cin == 8 else slice(8 * (g & 1), 8 * (g & 1) + 8)
+                    Bm[g * 8:(g + 1) * 8, mn] = xp[p, row + t // 3, mn + t % 3, ch]
+                acc += A @ Bm
+            out[:, row, :] = acc[:6]
+            assert np.all(acc[6:] == 0)
+        ref = F.conv3d(torch.from_numpy(x).permute(3, 0, 1, 2).unsqueeze(0), torch.from_numpy(w), padding=1)[0, 0].numpy()
+        np.testing.assert_allclose(out, ref, atol=2e-4 * np.abs(ref).max(), rtol=0)
 
 
 def test_fp16_packing_rounds_like_torch_and_saturates():

@@ -1,10 +1,20 @@
-// 3x3x3 convolution with ONE output channel (the `prob` heads: MVSNet 8->1, CVP 16->1, Vis final_conv 8->1).
+// 3x3x3 convolution with ONE output channel (the `prob` heads: MVSNet 8->1, CVP 16->1, Vis final_conv 8->1) on the
+// matrix cores, with the DEPTH axis packed into the MFMA rows.  gfx950.
 //
-// A 1-channel output would waste 15 of the 16 MFMA rows, and at 216 (432) MACs per voxel the layer is HBM-bound
-// anyway, so it runs on the vector ALU: one lane per output voxel, `v_dot2_f32_f16` / `v_dot2_f32_bf16` (two MACs
-// per instruction, fp32 accumulate), input planes swept through a 4-slot LDS ring (each input plane is fetched
-// once per sweep, prefetched into registers one iteration ahead), weights as wave-uniform scalar operands.
-// A workgroup owns an 8 x 32 pixel tile; a wave reads 2 rows x 32 consecutive voxels = conflict-free LDS rows.
+// A 1-channel output uses one of the 16 MFMA rows.  Here the rows are six consecutive OUTPUT PLANES instead: for a
+// block of output planes d0..d0+5 the reduction runs over the eight input planes d0-1..d0+6, and row m of the A operand
+// holds kernel slice kd = p - m for input plane p (zero where kd falls outside 0..2) -- a banded (Toeplitz) weight
+// matrix built once on the host (pscv_pack_conv3d_weights, kind S1C1).  K = 8 planes x 9 taps x C_in = 576 (1152) is
+// exactly 18 (36) k-steps of 32, so one 16-pixel x 6-plane output tile costs 18 (36) MFMAs and 18 (36) ds_read_b128,
+// 0.19 MFMA and 192 LDS bytes per voxel, and no vector-ALU work beyond the epilogue.  (The previous vector-ALU dot2
+// sweep needed 108 dependent v_dot2 and 27 LDS reads per voxel behind a per-plane barrier: 38 us at the headline size,
+// a quarter of its HBM roofline.)
+//
+// Workgroup: 4 x 32 output pixels x NB blocks of 6 planes; the (6 NB + 2) x 6 x 34 input brick is staged into LDS once
+// (all loads in flight together, one barrier); wave w owns tile row w (two 16-pixel MFMA column tiles, sharing A).
+// k-step operand order (what lane group g = lane >> 4 holds) is chosen so that every ds_read_b128 is bank-conflict
+// free and its address is lane base + immediate: step s = (q, tap); C_in = 8: plane 4 (g >> 1) + 2 q + (g & 1), with a
+// plane stride of 208 voxels (= 0 mod 16 chunks); C_in = 16: plane 4 (g >> 1) + q, g & 1 = channel half.
 //
 // Replaces (fdarmon/wild_deep_mvs): CostRegNet.prob models/MVSNet/model.py:72,82; prob0 models/CVP_MVSNet/models/
 // net.py:76,83; RegPair / RegFuse final_conv models/VisMVSNet/model_cas.py:55,68.
@@ -12,20 +22,25 @@
 
 namespace pscv {
 
-typedef _Float16 c1_h2 __attribute__((ext_vector_type(2)));
-typedef __bf16 c1_b2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((ext_vector_type(8))) __bf16 c1_bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 c1_f16x8;
+typedef __attribute__((ext_vector_type(4))) float c1_f32x4;
 
-template <typename H> __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c);
-template <> __device__ __forceinline__ float dot2<f16_t>(uint32_t a, uint32_t b, float c) {
-    return __builtin_amdgcn_fdot2(__builtin_bit_cast(c1_h2, a), __builtin_bit_cast(c1_h2, b), c, false);
-}
-template <> __device__ __forceinline__ float dot2<bf16_t>(uint32_t a, uint32_t b, float c) {
-    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(c1_b2, a), __builtin_bit_cast(c1_b2, b), c, false);
-}
+template <typename H> struct C1Mfma;
+template <> struct C1Mfma<bf16_t> {
+    __device__ static __forceinline__ c1_f32x4 run(const uint4& a, const uint4& b, const c1_f32x4& c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(c1_bf16x8, a), __builtin_bit_cast(c1_bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct C1Mfma<f16_t> {
+    __device__ static __forceinline__ c1_f32x4 run(const uint4& a, const uint4& b, const c1_f32x4& c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(c1_f16x8, a), __builtin_bit_cast(c1_f16x8, b), c, 0, 0, 0);
+    }
+};
 
 struct C1Args {
     const uint16_t* in;
-    const uint4* wpk;        // [27 taps][CIN/8] x 8 halves, tap = kd*9 + kh*3 + kw
+    const uint4* wpk;        // [NSTEPS][64 lanes] x 8 halves (A fragments)
     const uint16_t* skip;
     void* out;
     const float* scale;      // device, [1] each (may be null)
@@ -35,129 +50,196 @@ struct C1Args {
     int out_f32;
     int B, D, Hh, W;
     int epi;
-    int nth, ntw, ndc, dc;
+    int nth, ntw, ndc, nb;   // tiles, depth chunks, 6-plane blocks per workgroup
 };
 
-constexpr int C1_TH = 8, C1_TW = 32, C1_BH = C1_TH + 2, C1_BW = C1_TW + 2, C1_PV = C1_BH * C1_BW, C1_NSLOT = 4;
+constexpr int C1_P = 6;                        // output planes per block (MFMA rows 0..5)
+constexpr int C1_TH = 4, C1_TW = 32, C1_BH = C1_TH + 2, C1_BW = C1_TW + 2;
+constexpr int C1_PS = 208;                     // plane stride in voxels: 6 x 34 = 204 padded to 0 mod 16
+constexpr int C1_NB_MAX = 2;
 
 template <typename H, int CIN>
 __global__ __launch_bounds__(256) void conv3d_c1_kernel(const C1Args a) {
-    constexpr int CCH = CIN / 8;             // 16-byte chunks per voxel
-    constexpr int VB = CIN * 2;              // bytes per voxel
-    constexpr int PB = C1_PV * VB;           // bytes per plane slot
-    constexpr int NCH = C1_PV * CCH;         // chunks per plane
-    constexpr int NLD = (NCH + 255) / 256;   // chunks per thread per plane
-    __shared__ __attribute__((aligned(16))) unsigned char smem[C1_NSLOT * PB];
+    constexpr int CCH = CIN / 8;                       // 16-byte chunks per voxel
+    constexpr int VB = CIN * 2;                        // bytes per voxel
+    constexpr int NSTEPS = 8 * 9 * CIN / 32;           // 18 / 36
+    constexpr int PV = C1_BH * C1_BW;                  // 204 voxels per brick plane
+    constexpr int MAXP = C1_NB_MAX * C1_P + 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [(6 nb + 2)][C1_PS][VB]
 
     const int nwg = gridDim.x, bid = blockIdx.x;
-    const int xcd = bid & 7, slot_ = bid >> 3, q = nwg >> 3, r_ = nwg & 7;
-    int wg = (xcd < r_ ? xcd * (q + 1) : r_ * (q + 1) + (xcd - r_) * q) + slot_;
+    const int xcd = bid & 7, slot_ = bid >> 3, q_ = nwg >> 3, r_ = nwg & 7;
+    int wg = (xcd < r_ ? xcd * (q_ + 1) : r_ * (q_ + 1) + (xcd - r_) * q_) + slot_;
     const int dci = wg % a.ndc; wg /= a.ndc;
     const int twi = wg % a.ntw; wg /= a.ntw;
     const int thi = wg % a.nth; wg /= a.nth;
     const int b = wg;
     const int h0 = thi * C1_TH, w0 = twi * C1_TW;
-    const int dbeg = dci * a.dc, dend = min(a.D, dbeg + a.dc);
+    const int brick_planes = a.nb * C1_P;              // output planes of this workgroup
+    const int nplanes = brick_planes + 2;              // staged planes dbeg-1 .. dbeg + brick_planes
+    const int dbeg = dci * brick_planes;
+    const bool interior = dbeg >= 1 && dbeg + brick_planes < a.D && a.nb == C1_NB_MAX;   // all staged planes exist
 
     const int tid = threadIdx.x;
-    const int row = tid / C1_TW, col = tid % C1_TW;
-
-    // staging descriptors
-    int goff[NLD], loff[NLD];
-    bool gval[NLD], lval[NLD];
-    const long plane_stride = (long)a.Hh * a.W * a.in_cs;
-    const uint16_t* inb = a.in + (long)b * a.D * plane_stride + a.in_co;
+    {   // ---- stage the brick: every load of the workgroup is in flight before the first LDS write.  Thread t < 204
+        // owns brick voxel t of EVERY plane: its offset inside a plane and its LDS offset are computed once, the plane
+        // advances through an immediate / scalar offset -- no per-load vector arithmetic, and for an interior brick
+        // one predicate for the whole batch (a flat chunk-id decomposition made this kernel vector-ALU bound).
+        const unsigned long plane_bytes = (unsigned long)a.Hh * a.W * a.in_cs * 2;
+        const char* inb = reinterpret_cast<const char*>(a.in) + ((unsigned long)b * a.D * plane_bytes + (unsigned long)a.in_co * 2);
+        const int sbh = tid / C1_BW, sbw = tid - sbh * C1_BW;
+        const int sgh = h0 - 1 + sbh, sgw = w0 - 1 + sbw;
+        const bool vox_ok = tid < PV && (unsigned)sgh < (unsigned)a.Hh && (unsigned)sgw < (unsigned)a.W;
+        const unsigned goff = vox_ok ? (unsigned)(sgh * a.W + sgw) * (unsigned)(a.in_cs * 2) : 0u;
+        uint4 reg[MAXP][CCH];
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-        const int id = tid + 256 * i;
-        const int v = id / CCH, c = id - v * CCH;
-        const int bh = v / C1_BW, bw = v - bh * C1_BW;
-        const int gh = h0 - 1 + bh, gw = w0 - 1 + bw;
-        lval[i] = id < NCH;
-        gval[i] = lval[i] && (unsigned)gh < (unsigned)a.Hh && (unsigned)gw < (unsigned)a.W;
-        goff[i] = gval[i] ? (gh * a.W + gw) * a.in_cs + c * 8 : 0;
-        loff[i] = v * VB + c * 16;
-    }
-    const int plane_hi = min(a.D - 1, dend);
-    auto fetch = [&](int plane, uint4 (&reg)[NLD]) {
-        const bool pv = plane >= 0 && plane <= plane_hi;
-        const uint16_t* pp = inb + (long)(pv ? plane : 0) * plane_stride;
+        for (int p = 0; p < MAXP; ++p)
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            reg[i] = make_uint4(0u, 0u, 0u, 0u);
-            if (gval[i] && pv) reg[i] = *reinterpret_cast<const uint4*>(pp + goff[i]);
+            for (int c = 0; c < CCH; ++c) reg[p][c] = make_uint4(0u, 0u, 0u, 0u);
+        if (interior) {
+            const char* pp = inb + (unsigned long)(dbeg - 1) * plane_bytes + goff;
+            if (vox_ok) {
+#pragma unroll
+                for (int p = 0; p < MAXP; ++p)
+#pragma unroll
+                    for (int c = 0; c < CCH; ++c) reg[p][c] = *reinterpret_cast<const uint4*>(pp + p * plane_bytes + c * 16);
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < MAXP; ++p) {
+                const int gd = dbeg - 1 + p;                       // wave-uniform
+                const bool pv = p < nplanes && (unsigned)gd < (unsigned)a.D;
+                const char* pp = inb + (unsigned long)(pv ? gd : 0) * plane_bytes;
+#pragma unroll
+                for (int c = 0; c < CCH; ++c)
+                    if (pv && vox_ok) reg[p][c] = *reinterpret_cast<const uint4*>(pp + goff + c * 16);
+            }
         }
-    };
-    auto stash = [&](int ring, const uint4 (&reg)[NLD]) {
-        unsigned char* sp = smem + ring * PB;
+        unsigned char* sp = smem + tid * VB;
+        if (tid < PV) {
 #pragma unroll
-        for (int i = 0; i < NLD; ++i)
-            if (lval[i]) *reinterpret_cast<uint4*>(sp + loff[i]) = reg[i];
-    };
-
-    {   // prologue: planes dbeg-1, dbeg, dbeg+1 -> slots 0, 1, 2
-        uint4 r0[NLD], r1[NLD], r2[NLD];
-        fetch(dbeg - 1, r0); fetch(dbeg, r1); fetch(dbeg + 1, r2);
-        stash(0, r0); stash(1, r1); stash(2, r2);
-    }
-    __syncthreads();
-
-    // C_in = 8: the 27 weight quads live in VGPRs (same value in every lane) for the whole sweep; re-reading them
-    // through the scalar cache every plane exposed its latency once per iteration.  C_in = 16 would need 216
-    // registers and keeps the scalar-operand path.
-    constexpr bool WREG = CIN == 8;
-    uint4 wreg[WREG ? 27 * CCH : 1];
-    if (WREG) {
+            for (int p = 0; p < MAXP; ++p)
+                if (p < nplanes) {
 #pragma unroll
-        for (int t = 0; t < 27 * CCH; ++t) wreg[t] = a.wpk[t];
+                    for (int c = 0; c < CCH; ++c) *reinterpret_cast<uint4*>(sp + p * (C1_PS * VB) + c * 16) = reg[p][c];
+                }
+        }
     }
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    uint4 wf[NSTEPS];
+#pragma unroll
+    for (int s = 0; s < NSTEPS; ++s) wf[s] = a.wpk[s * 64 + lane];
     const float e_scale = a.scale ? a.scale[0] : 1.0f, e_bias = a.bias ? a.bias[0] : 0.0f,
                 e_floor = a.floor ? a.floor[0] : 0.0f;
-    const int lane_off = (row * C1_BW + col) * VB;   // this lane's voxel at tap (kh=0, kw=0)
-    const int oh = h0 + row, ow = w0 + col;
-    const bool inside = oh < a.Hh && ow < a.W;
-    int ring = 0;   // slot of plane d-1
-    for (int d = dbeg; d < dend; ++d) {
-        uint4 nxt[NLD];
-        fetch(d + 2, nxt);
+    // ReLU switches as clamps against -inf (no branches in the epilogue)
+    const float lo_pre = (a.epi & PSCV_EPI_RELU_PRE) ? e_floor : -__builtin_inff();
+    const float lo_post = (a.epi & PSCV_EPI_RELU_POST) ? 0.0f : -__builtin_inff();
+    __syncthreads();
 
-        float acc = 0.0f;
+    // byte offset of this lane's B operand at step (q = 0, tap 0) of column tile 0: voxel (row = wave, col = n) of the
+    // lane group's first plane
+    const int lane_off = (CIN == 8) ? ((4 * (g >> 1) + (g & 1)) * C1_PS + wave * C1_BW + n) * VB
+                                    : (4 * (g >> 1) * C1_PS + wave * C1_BW + n) * VB + (g & 1) * 16;
+    const int oh = h0 + wave;
+    // output addressing: wave-uniform 64-bit base per (block, plane), 32-bit lane offsets computed once
+    const int OB = a.out_f32 ? 4 : 2;
+    const unsigned long out_plane = (unsigned long)a.Hh * a.W * a.out_cs * OB;
+    const unsigned long skip_plane = (unsigned long)a.Hh * a.W * a.skip_cs * 2;
+    const unsigned pix0 = (unsigned)(oh * a.W + w0 + n);
+    const bool row_ok = g < 2 && oh < a.Hh;
+    const unsigned ostep = (unsigned)a.out_cs * (unsigned)OB;                           // bytes between x-adjacent outputs
+    // fast-path lane offset: pixel (oh, w0 + n) of plane 4 g of the block (6 planes of output stay below 4 GiB)
+    const unsigned ooff_g = (pix0 * (unsigned)a.out_cs + (unsigned)a.out_co) * (unsigned)OB + (unsigned)(4 * g) * (unsigned)out_plane;
+    const bool full = w0 + C1_TW <= a.W && dbeg + brick_planes <= a.D && !a.skip && oh < a.Hh;
+
+    for (int blk = 0; blk < a.nb; ++blk) {
+        const int d0 = dbeg + blk * C1_P;
+        if (d0 >= a.D) break;
+        const unsigned char* sp = smem + blk * (C1_P * C1_PS * VB) + lane_off;
+        c1_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kd = 0; kd < 3; ++kd) {
-            const unsigned char* sp = smem + ((ring + kd) & (C1_NSLOT - 1)) * PB + lane_off;
+        for (int s = 0; s < NSTEPS; ++s) {
+            // step s = (q, tap): lane group g reads plane 4 (g >> 1) + 2 q + (g & 1) (C_in 8) or 4 (g >> 1) + q
+            // (C_in 16); the lane-group part sits in lane_off, the rest is a compile-time immediate
+            const int q = s / 9, t = s % 9;
+            const int off = (((CIN == 8) ? 2 * q : q) * C1_PS + (t / 3) * C1_BW + (t % 3)) * VB;
+            const uint4 x0 = *reinterpret_cast<const uint4*>(sp + off);
+            const uint4 x1 = *reinterpret_cast<const uint4*>(sp + off + 16 * VB);
+            acc0 = C1Mfma<H>::run(wf[s], x0, acc0);
+            acc1 = C1Mfma<H>::run(wf[s], x1, acc1);
+        }
+        // ---- epilogue: lane (n, g) holds rows 4g..4g+3 = output planes d0 + 4g + r of pixel n ----
+        if (full) {
+            // interior brick without a skip tensor (the common case): straight-line code, two predicates in total
+            // (the generic path below spends ~30 scalar instructions and four branches per 4-byte store)
+            char* ob = reinterpret_cast<char*>(a.out) + ((unsigned long)b * a.D + d0) * out_plane;
+            float y[2][4];
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
+            for (int r = 0; r < 4; ++r) {
+                y[0][r] = fmaxf(fmaxf(fmaf(acc0[r], e_scale, e_bias), lo_pre), lo_post);
+                y[1][r] = fmaxf(fmaxf(fmaf(acc1[r], e_scale, e_bias), lo_pre), lo_post);
+            }
+            if (g < 2) {          // rows 0,1 (g = 0) and 4,5 (g = 1)
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw)
+                for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-                    for (int c = 0; c < CCH; ++c) {
-                        const uint4 x = *reinterpret_cast<const uint4*>(sp + (kh * C1_BW + kw) * VB + c * 16);
-                        const uint4 w = WREG ? wreg[((kd * 3 + kh) * 3 + kw) * CCH + c]
-                                             : a.wpk[((kd * 3 + kh) * 3 + kw) * CCH + c];   // wave-uniform -> scalar loads
-                        acc = dot2<H>(x.x, w.x, acc);
-                        acc = dot2<H>(x.y, w.y, acc);
-                        acc = dot2<H>(x.z, w.z, acc);
-                        acc = dot2<H>(x.w, w.w, acc);
+                    for (int r = 0; r < 2; ++r) {
+                        char* o = ob + (unsigned long)r * out_plane + (ooff_g + ct * 16 * ostep);
+                        if (a.out_f32) *reinterpret_cast<float*>(o) = y[ct][r];
+                        else *reinterpret_cast<uint16_t*>(o) = Half16<H>::bits(y[ct][r]);
                     }
+            }
+            if (g == 0) {         // rows 2,3
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 2; r < 4; ++r) {
+                        char* o = ob + (unsigned long)r * out_plane + (ooff_g + ct * 16 * ostep);
+                        if (a.out_f32) *reinterpret_cast<float*>(o) = y[ct][r];
+                        else *reinterpret_cast<uint16_t*>(o) = Half16<H>::bits(y[ct][r]);
+                    }
+            }
+        } else if (row_ok) {
+            char* ob = reinterpret_cast<char*>(a.out) + ((unsigned long)b * a.D + d0 + 4 * g) * out_plane;
+            const char* sb = reinterpret_cast<const char*>(a.skip) + ((unsigned long)b * a.D + d0 + 4 * g) * skip_plane;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                if (w0 + ct * 16 + n >= a.W) continue;
+                const unsigned pix = pix0 + ct * 16;
+                const unsigned ooff = (pix * (unsigned)a.out_cs + (unsigned)a.out_co) * (unsigned)OB;
+                const unsigned soff = (pix * (unsigned)a.skip_cs + (unsigned)a.skip_co) * 2u;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = 4 * g + r;
+                    if (m >= C1_P || d0 + m >= a.D) continue;
+                    float y = fmaxf(fmaf(ct ? acc1[r] : acc0[r], e_scale, e_bias), lo_pre);
+                    if (a.skip) y += Half16<H>::one(*reinterpret_cast<const uint16_t*>(sb + r * skip_plane + soff));
+                    y = fmaxf(y, lo_post);
+                    if (a.out_f32) *reinterpret_cast<float*>(ob + r * out_plane + ooff) = y;
+                    else *reinterpret_cast<uint16_t*>(ob + r * out_plane + ooff) = Half16<H>::bits(y);
+                }
+            }
         }
-
-        if (inside) {
-            const long vox = (((long)b * a.D + d) * a.Hh + oh) * a.W + ow;
-            float y = fmaf(acc, e_scale, e_bias);
-            if (a.epi & PSCV_EPI_RELU_PRE) y = fmaxf(y, e_floor);
-            if (a.skip) y += Half16<H>::one(a.skip[vox * a.skip_cs + a.skip_co]);
-            if (a.epi & PSCV_EPI_RELU_POST) y = fmaxf(y, 0.0f);
-            if (a.out_f32) reinterpret_cast<float*>(a.out)[vox * a.out_cs + a.out_co] = y;
-            else reinterpret_cast<uint16_t*>(a.out)[vox * a.out_cs + a.out_co] = Half16<H>::bits(y);
-        }
-
-        stash((ring + 3) & (C1_NSLOT - 1), nxt);   // plane d+2 replaces plane d-2 (last read one iteration ago)
-        ring = (ring + 1) & (C1_NSLOT - 1);
-        __syncthreads();
     }
 }
 
+template <typename H, int CIN>
+static int c1_launch(const C1Args& a, long nblk, hipStream_t st) {
+    auto kern = conv3d_c1_kernel<H, CIN>;
+    const size_t lds = (size_t)(a.nb * C1_P + 2) * C1_PS * CIN * 2;
+    if (lds > 60000) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { set_error("pscv_conv3d(c1): hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e)); return -2; }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, a);
+    return 0;
+}
+
 }  // namespace pscv
+
+int g_c1_nb = 0;
 
 int pscv_conv3d_c1_launch(const void* in, int dtype, int in_cstride, int in_coff, const uint16_t* packed,
                           const float* scale, const float* bias, const float* floor, const void* skip, int skip_cstride, int skip_coff, void* out,
@@ -176,21 +258,18 @@ int pscv_conv3d_c1_launch(const void* in, int dtype, int in_cstride, int in_coff
     a.nth = (Hh + C1_TH - 1) / C1_TH;
     a.ntw = (W + C1_TW - 1) / C1_TW;
     const long tiles = (long)B * a.nth * a.ntw;
-    // one resident round of workgroups (about 4 per CU at this kernel's register / LDS footprint), fewest chunk seams
-    const long slots = 1024;
-    const long ndc_want = tiles >= slots ? 1 : slots / tiles;
-    int dc = (int)((D + ndc_want - 1) / ndc_want);
-    dc = dc < 4 ? 4 : dc;
-    dc = dc > D ? D : dc;
-    a.dc = dc;
-    a.ndc = (D + dc - 1) / dc;
+    const int nblocks = (D + C1_P - 1) / C1_P;
+    // two 6-plane blocks per workgroup (the 2-plane halo of the brick costs 1/6 instead of 1/3) when that still leaves
+    // the chip a few rounds of workgroups; C_in = 16 keeps one (LDS: 53 KB per workgroup instead of 93)
+    a.nb = (c_in == 8 && tiles * ((nblocks + 1) / 2) >= 1024) ? 2 : 1;
+    if (g_c1_nb) a.nb = g_c1_nb;
+    a.ndc = (nblocks + a.nb - 1) / a.nb;
     const long nblk = tiles * a.ndc;
     if (nblk <= 0 || nblk > 0x7fffffffL) { set_error("pscv_conv3d(c1): bad grid %ld", nblk); return -1; }
-    const dim3 grid((unsigned)nblk), block(256);
-    if (dtype == PSCV_BF16 && c_in == 8) hipLaunchKernelGGL((conv3d_c1_kernel<bf16_t, 8>), grid, block, 0, st, a);
-    else if (dtype == PSCV_BF16 && c_in == 16) hipLaunchKernelGGL((conv3d_c1_kernel<bf16_t, 16>), grid, block, 0, st, a);
-    else if (dtype == PSCV_F16 && c_in == 8) hipLaunchKernelGGL((conv3d_c1_kernel<f16_t, 8>), grid, block, 0, st, a);
-    else if (dtype == PSCV_F16 && c_in == 16) hipLaunchKernelGGL((conv3d_c1_kernel<f16_t, 16>), grid, block, 0, st, a);
-    else { set_error("pscv_conv3d(c1): c_in=%d dtype=%d not supported (c_in 8 or 16)", c_in, dtype); return -1; }
-    return 0;
+    if (dtype == PSCV_BF16 && c_in == 8) return c1_launch<bf16_t, 8>(a, nblk, st);
+    if (dtype == PSCV_BF16 && c_in == 16) return c1_launch<bf16_t, 16>(a, nblk, st);
+    if (dtype == PSCV_F16 && c_in == 8) return c1_launch<f16_t, 8>(a, nblk, st);
+    if (dtype == PSCV_F16 && c_in == 16) return c1_launch<f16_t, 16>(a, nblk, st);
+    set_error("pscv_conv3d(c1): c_in=%d dtype=%d not supported (c_in 8 or 16)", c_in, dtype);
+    return -1;
 }

@@ -90,16 +90,29 @@ extern "C" long pscv_pack_conv3d_weights(const float* w, int c_in, int c_out, in
         return n;
     }
     if (kind == PSCV_CONV_S1C1) {
-        // 1-channel layout: [tap = kd*9 + kh*3 + kw][c_in] 16-bit values (wave-uniform scalar operands of v_dot2)
+        // Depth-in-rows layout [step][lane][8] for the 1-channel MFMA kernel (conv3d_c1.hip): row m < 6 of the A operand
+        // is output plane d0 + m of a 6-plane block, the reduction runs over input planes p = 0..7 (d0 - 1 + p), taps
+        // t = kh*3 + kw and channels; A[m][p, t, ci] = w[ci][kd = p - m][t], zero outside 0 <= kd <= 2.
+        // k-step s = (q = s / 9, tap t = s % 9); lane group g = lane >> 4 holds
+        //   c_in = 8:  plane 4 (g >> 1) + 2 q + (g & 1), channels j            (q = 0..1)
+        //   c_in = 16: plane 4 (g >> 1) + q, channels 8 (g & 1) + j            (q = 0..3)
         PSCV_CHECK_ARG(c_out == 1 && (c_in == 8 || c_in == 16) && !transposed, "pscv_pack_conv3d_weights: S1C1 is Conv3d 8|16 -> 1 only");
-        const long n = 27L * c_in;
+        const int nsteps = 8 * 9 * c_in / 32;
+        const long n = (long)nsteps * 64 * 8;
         if (!packed) return n;
         PSCV_CHECK_ARG(w, "pscv_pack_conv3d_weights: null weight pointer");
-        for (int t = 0; t < 27; ++t)
-            for (int ci = 0; ci < c_in; ++ci) {
-                const float v = w[(long)ci * 27 + t];
-                packed[(long)t * c_in + ci] = dtype == PSCV_BF16 ? f32_to_bf16(v) : f32_to_f16_bits(v);
-            }
+        for (int s = 0; s < nsteps; ++s)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int m = lane & 15, g = lane >> 4;
+                    const int q = s / 9, t = s % 9;
+                    const int p = c_in == 8 ? 4 * (g >> 1) + 2 * q + (g & 1) : 4 * (g >> 1) + q;
+                    const int ci = c_in == 8 ? j : 8 * (g & 1) + j;
+                    const int kd = p - m;
+                    float v = 0.f;
+                    if (m < 6 && kd >= 0 && kd <= 2) v = w[(long)ci * 27 + kd * 9 + t];
+                    packed[((long)s * 64 + lane) * 8 + j] = dtype == PSCV_BF16 ? f32_to_bf16(v) : f32_to_f16_bits(v);
+                }
         return n;
     }
     const int nt = ceil_div(c_out, 16);

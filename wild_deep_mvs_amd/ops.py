@@ -301,7 +301,7 @@ class Conv3dLayer:
         if kind == L.CONV_T2 and transposed and c_in == 16 and c_out == 8 and USE_SWEEP_KERNEL:
             kind = L.CONV_T2P8     # same result, parity-pair packed MFMA rows + contiguous 32-byte stores
         if kind == L.CONV_S1 and not transposed and c_in in (8, 16) and c_out == 1 and USE_SWEEP_KERNEL:
-            kind = L.CONV_S1C1     # same result, vector-ALU dot2 sweep kernel for the 1-channel heads
+            kind = L.CONV_S1C1     # same result, depth-in-rows MFMA kernel for the 1-channel heads
         packed = torch.from_numpy(pack_conv3d_weights(weight, kind, transposed, dtype).view(np.int16)).to(device)
         scale = bias = None
         if bn is not None:
