@@ -54,7 +54,30 @@ __device__ __forceinline__ void sweep_uvz(const float* __restrict__ cam, float p
     v = hy * inv_z * a.sy;
 }
 
-struct WtPatch { int base, x0, y0, bw, bh, staged; };
+typedef float wt_f2 __attribute__((ext_vector_type(2)));
+
+// 8 channels of one chunk column (ck = 0: chunk hh, 1: chunk 2 + hh) from the four taps
+template <typename TIn>
+__device__ __forceinline__ void wt_mix8(const uint4 (&t)[4][2], int ck, const float (&w)[4], float* o) {
+    const uint32_t aw[4] = {t[0][ck].x, t[0][ck].y, t[0][ck].z, t[0][ck].w}, bw[4] = {t[1][ck].x, t[1][ck].y, t[1][ck].z, t[1][ck].w};
+    const uint32_t cw[4] = {t[2][ck].x, t[2][ck].y, t[2][ck].z, t[2][ck].w}, dw[4] = {t[3][ck].x, t[3][ck].y, t[3][ck].z, t[3][ck].w};
+    if constexpr (Half16<TIn>::dtype == PSCV_F16) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { o[2 * q] = mul_mix_lo(aw[q], w[0]); o[2 * q + 1] = mul_mix_hi(aw[q], w[0]); }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { o[2 * q] = fma_mix_lo(bw[q], w[1], o[2 * q]); o[2 * q + 1] = fma_mix_hi(bw[q], w[1], o[2 * q + 1]); }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { o[2 * q] = fma_mix_lo(cw[q], w[2], o[2 * q]); o[2 * q + 1] = fma_mix_hi(cw[q], w[2], o[2 * q + 1]); }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { o[2 * q] = fma_mix_lo(dw[q], w[3], o[2 * q]); o[2 * q + 1] = fma_mix_hi(dw[q], w[3], o[2 * q + 1]); }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            o[2 * q] = fmaf(Half16<TIn>::lo(dw[q]), w[3], fmaf(Half16<TIn>::lo(cw[q]), w[2], fmaf(Half16<TIn>::lo(bw[q]), w[1], Half16<TIn>::lo(aw[q]) * w[0])));
+            o[2 * q + 1] = fmaf(Half16<TIn>::hi(dw[q]), w[3], fmaf(Half16<TIn>::hi(cw[q]), w[2], fmaf(Half16<TIn>::hi(bw[q]), w[1], Half16<TIn>::hi(aw[q]) * w[0])));
+        }
+    }
+}
 
 template <typename TIn, typename TOut, int GEOM, int COST, int NSRC>
 __global__ __launch_bounds__(256, 2) void warp_cost_tiled_kernel(const WarpArgs a) {
@@ -163,125 +186,152 @@ __global__ __launch_bounds__(256, 2) void warp_cost_tiled_kernel(const WarpArgs 
     }
 
     // ---- 4. sweep the planes ----
+    // Per-view constants of this lane's pixel stay in registers for the whole sweep (the view loop is unrolled): the
+    // depth-independent ray terms rot (x, y, 1) and the translation.  PROJ only (wt_dispatch).
+    float rayx[NSRC], rayy[NSRC], rayz[NSRC], trx[NSRC], try_[NSRC], trz[NSRC];
+#pragma unroll
+    for (int v = 0; v < NSRC; ++v) {
+        const float* cam = a.cams + ((long)v * a.B + b) * PSCV_CAM_FLOATS;
+        rayx[v] = fmaf(cam[1], py, cam[0] * px) + cam[2];
+        rayy[v] = fmaf(cam[4], py, cam[3] * px) + cam[5];
+        rayz[v] = fmaf(cam[7], py, cam[6] * px) + cam[8];
+        trx[v] = cam[9]; try_[v] = cam[10]; trz[v] = cam[11];
+    }
     const TIn* ref = reinterpret_cast<const TIn*>(a.ref);
-    TOut* out = reinterpret_cast<TOut*>(a.out);
-    VecF<16> rf;   // channels [8h, 8h+8) and [16+8h, 24+8h)
+    char* const out = reinterpret_cast<char*>(a.out);
+    wt_f2 rf2[8], rfsq[8];   // channels [8h, 8h+8) and [16+8h, 24+8h) as pairs
+    float rf[16];
     {
         const f32x8 lo = Elem<TIn>::load8(ref + pix * C + hh * 8);
         const f32x8 hi = Elem<TIn>::load8(ref + pix * C + 16 + hh * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { rf.v[j] = lo.v[j]; rf.v[8 + j] = hi.v[j]; }
+        for (int j = 0; j < 8; ++j) { rf[j] = lo.v[j]; rf[8 + j] = hi.v[j]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { rf2[j] = wt_f2{rf[2 * j], rf[2 * j + 1]}; rfsq[j] = rf2[j] * rf2[j]; }
     }
     const float invN = 1.0f / (float)(a.n_src + 1);
     const float invN2 = invN * invN;
+    const unsigned long plane_bytes = (unsigned long)hw * C * sizeof(TOut);
+    const unsigned lane_out = (unsigned)pflat * (C * (unsigned)sizeof(TOut)) + (unsigned)hh * (8 * (unsigned)sizeof(TOut));
+    const unsigned long img_bytes = (unsigned long)b * a.hs * a.ws * 64;
 
     for (int d = d0; d < d1; ++d) {
         const float dval = a.depth[(long)b * a.depth_bstride + d];
-        const long vox = ((long)b * a.D + d) * hw + pflat;
-        VecF<16> acc0, acc1;
+        wt_f2 s2[8], q2[8];
         float sum_e = 0.0f;
         if (COST == PSCV_COST_SOFTMIN) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) { acc0.v[j] = 0.0f; acc1.v[j] = 0.0f; }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) { acc0.v[j] = rf.v[j]; acc1.v[j] = rf.v[j] * rf.v[j]; }
+            for (int j = 0; j < 8; ++j) s2[j] = wt_f2{0.f, 0.f};
         }
 
 #pragma unroll
         for (int v = 0; v < NSRC; ++v) {
-            const float* cam = a.cams + ((long)v * a.B + b) * PSCV_CAM_FLOATS;
-            float ix, iy;
-            sweep_index<GEOM>(cam, px, py, dval, a, ix, iy);
-            // bilinear taps, identical arithmetic to gather_bilinear (warp_common.h)
+            const float hx = fmaf(rayx[v], dval, trx[v]), hy = fmaf(rayy[v], dval, try_[v]), hz = fmaf(rayz[v], dval, trz[v]);
+            const bool front = hz > 0.0f;
+            const float inv_z = __builtin_amdgcn_rcpf(hz);
+            const float u = front ? hx * inv_z : -10.0f, w_ = front ? hy * inv_z : -10.0f;
+            const float ix = __builtin_amdgcn_fmed3f(u, a.xlo, a.xhi), iy = __builtin_amdgcn_fmed3f(w_, a.ylo, a.yhi);
             const float x0f = floorf(ix), y0f = floorf(iy);
             const float fx = ix - x0f, fy = iy - y0f;
-            const int xi0 = (int)x0f, yi0 = (int)y0f, xi1 = xi0 + 1, yi1 = yi0 + 1;
-            const bool vx0 = (unsigned)xi0 < (unsigned)a.ws, vx1 = (unsigned)xi1 < (unsigned)a.ws;
-            const bool vy0 = (unsigned)yi0 < (unsigned)a.hs, vy1 = (unsigned)yi1 < (unsigned)a.hs;
-            const float gx = 1.0f - fx, gy = 1.0f - fy;
-            const float w00 = (vx0 && vy0) ? gx * gy : 0.0f, w01 = (vx1 && vy0) ? fx * gy : 0.0f;
-            const float w10 = (vx0 && vy1) ? gx * fy : 0.0f, w11 = (vx1 && vy1) ? fx * fy : 0.0f;
-            const int xc0 = min(max(xi0, 0), a.ws - 1), xc1 = min(max(xi1, 0), a.ws - 1);
-            const int yc0 = min(max(yi0, 0), a.hs - 1), yc1 = min(max(yi1, 0), a.hs - 1);
-
-            const int base = vbase[v];   // wave-uniform
-            f32x8 t00a, t00b, t01a, t01b, t10a, t10b, t11a, t11b;
-            if (base >= 0) {
-                const int X0 = pX0[v], Y0 = pY0[v], bw = pBW[v], bh = pBH[v];
-                // a zero-weight (out-of-image) tap may fall outside the box: clamp it into the box
-                const int bx0 = min(max(xc0 - X0, 0), bw - 1), bx1 = min(max(xc1 - X0, 0), bw - 1);
-                const int by0 = min(max(yc0 - Y0, 0), bh - 1), by1 = min(max(yc1 - Y0, 0), bh - 1);
-                const int r0 = base + by0 * bw, r1 = base + by1 * bw;
-                // byte offset of chunk hh of texel e: e*64 + ((hh*16) ^ swz), swz = bit 2 of e moved to bit 5;
-                // chunk 2+hh of the same texel is that offset with bit 5 flipped
+            const int xi0 = (int)x0f, yi0 = (int)y0f;
+            const bool interior = (unsigned)xi0 < (unsigned)(a.ws - 1) && (unsigned)yi0 < (unsigned)(a.hs - 1);
+            const int base = vbase[v];   // wave-uniform; < 0: this view's box is not staged
+            uint4 t[4][2];               // [tap][chunk hh / 2 + hh]
+            float w4[4];
+            if (base >= 0 && __builtin_amdgcn_ballot_w64(!interior) == 0) {
+                // every tap of the wave is inside the image, hence inside the staged box: no masks, no clamps
+                const float gx = 1.0f - fx, gy = 1.0f - fy;
+                w4[0] = gx * gy; w4[1] = fx * gy; w4[2] = gx * fy; w4[3] = fx * fy;
+                const int e00 = base + (yi0 - pY0[v]) * pBW[v] + (xi0 - pX0[v]);
+                const int e10 = e00 + pBW[v];
+                // byte offset of chunk hh of texel e: e*64 + ((hh*16) ^ swz), swz = bit 2 of e moved to bit 5; chunk
+                // 2+hh of the same texel is that offset with bit 5 flipped
                 auto toff = [&](int e) { return (e << 6) + (hsel ^ ((e << 3) & 32)); };
-                const int o00 = toff(r0 + bx0), o01 = toff(r0 + bx1), o10 = toff(r1 + bx0), o11 = toff(r1 + bx1);
-                auto ld = [&](int o) { return Elem<TIn>::load8(reinterpret_cast<const TIn*>(tex + o)); };
-                t00a = ld(o00); t00b = ld(o00 ^ 32);
-                t01a = ld(o01); t01b = ld(o01 ^ 32);
-                t10a = ld(o10); t10b = ld(o10 ^ 32);
-                t11a = ld(o11); t11b = ld(o11 ^ 32);
+                const int o00 = toff(e00), o01 = toff(e00 + 1), o10 = toff(e10), o11 = toff(e10 + 1);
+                t[0][0] = *reinterpret_cast<const uint4*>(tex + o00); t[0][1] = *reinterpret_cast<const uint4*>(tex + (o00 ^ 32));
+                t[1][0] = *reinterpret_cast<const uint4*>(tex + o01); t[1][1] = *reinterpret_cast<const uint4*>(tex + (o01 ^ 32));
+                t[2][0] = *reinterpret_cast<const uint4*>(tex + o10); t[2][1] = *reinterpret_cast<const uint4*>(tex + (o10 ^ 32));
+                t[3][0] = *reinterpret_cast<const uint4*>(tex + o11); t[3][1] = *reinterpret_cast<const uint4*>(tex + (o11 ^ 32));
             } else {
-                const TIn* img = reinterpret_cast<const TIn*>(a.src[v]);
-                const long row0 = ((long)b * a.hs + yc0) * a.ws, row1 = ((long)b * a.hs + yc1) * a.ws;
-                t00a = Elem<TIn>::load8(img + (row0 + xc0) * C + hh * 8); t00b = Elem<TIn>::load8(img + (row0 + xc0) * C + 16 + hh * 8);
-                t01a = Elem<TIn>::load8(img + (row0 + xc1) * C + hh * 8); t01b = Elem<TIn>::load8(img + (row0 + xc1) * C + 16 + hh * 8);
-                t10a = Elem<TIn>::load8(img + (row1 + xc0) * C + hh * 8); t10b = Elem<TIn>::load8(img + (row1 + xc0) * C + 16 + hh * 8);
-                t11a = Elem<TIn>::load8(img + (row1 + xc1) * C + hh * 8); t11b = Elem<TIn>::load8(img + (row1 + xc1) * C + 16 + hh * 8);
+                Taps tp;
+                make_taps<false, 64>(fx, fy, xi0, yi0, a.hs, a.ws, 0u, tp);
+                w4[0] = tp.w00; w4[1] = tp.w01; w4[2] = tp.w10; w4[3] = tp.w11;
+                if (base >= 0) {
+                    // a zero-weight (out-of-image) tap may fall outside the box: clamp it into the box
+                    const int X0 = pX0[v], Y0 = pY0[v], bw = pBW[v], bh = pBH[v];
+                    const int xc0 = med3_i32(xi0, 0, a.ws - 1), xc1 = med3_i32(xi0 + 1, 0, a.ws - 1);
+                    const int yc0 = med3_i32(yi0, 0, a.hs - 1), yc1 = med3_i32(yi0 + 1, 0, a.hs - 1);
+                    const int bx0 = med3_i32(xc0 - X0, 0, bw - 1), bx1 = med3_i32(xc1 - X0, 0, bw - 1);
+                    const int r0 = base + med3_i32(yc0 - Y0, 0, bh - 1) * bw, r1 = base + med3_i32(yc1 - Y0, 0, bh - 1) * bw;
+                    auto toff = [&](int e) { return (e << 6) + (hsel ^ ((e << 3) & 32)); };
+                    const int o00 = toff(r0 + bx0), o01 = toff(r0 + bx1), o10 = toff(r1 + bx0), o11 = toff(r1 + bx1);
+                    t[0][0] = *reinterpret_cast<const uint4*>(tex + o00); t[0][1] = *reinterpret_cast<const uint4*>(tex + (o00 ^ 32));
+                    t[1][0] = *reinterpret_cast<const uint4*>(tex + o01); t[1][1] = *reinterpret_cast<const uint4*>(tex + (o01 ^ 32));
+                    t[2][0] = *reinterpret_cast<const uint4*>(tex + o10); t[2][1] = *reinterpret_cast<const uint4*>(tex + (o10 ^ 32));
+                    t[3][0] = *reinterpret_cast<const uint4*>(tex + o11); t[3][1] = *reinterpret_cast<const uint4*>(tex + (o11 ^ 32));
+                } else {
+                    const char* img = reinterpret_cast<const char*>(a.src[v]) + img_bytes + hh * 16;
+                    t[0][0] = *reinterpret_cast<const uint4*>(img + tp.o00); t[0][1] = *reinterpret_cast<const uint4*>(img + tp.o00 + 32);
+                    t[1][0] = *reinterpret_cast<const uint4*>(img + tp.o01); t[1][1] = *reinterpret_cast<const uint4*>(img + tp.o01 + 32);
+                    t[2][0] = *reinterpret_cast<const uint4*>(img + tp.o10); t[2][1] = *reinterpret_cast<const uint4*>(img + tp.o10 + 32);
+                    t[3][0] = *reinterpret_cast<const uint4*>(img + tp.o11); t[3][1] = *reinterpret_cast<const uint4*>(img + tp.o11 + 32);
+                }
             }
-            VecF<16> wv;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                wv.v[j] = fmaf(t11a.v[j], w11, fmaf(t10a.v[j], w10, fmaf(t01a.v[j], w01, t00a.v[j] * w00)));
-                wv.v[8 + j] = fmaf(t11b.v[j], w11, fmaf(t10b.v[j], w10, fmaf(t01b.v[j], w01, t00b.v[j] * w00)));
-            }
+            float wv[16];
+            wt_mix8<TIn>(t, 0, w4, wv);
+            wt_mix8<TIn>(t, 1, w4, wv + 8);
 
             if (COST == PSCV_COST_SOFTMIN) {
-                VecF<16> diff;
-                float part = 0.0f;
+                float diff[16], part = 0.0f;
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
-                    const float t = rf.v[j] - wv.v[j];
-                    diff.v[j] = t * t;
-                    part += diff.v[j];
+                    const float tt = rf[j] - wv[j];
+                    diff[j] = tt * tt;
+                    part += diff[j];
                 }
                 part += __shfl_xor(part, 1, 64);
                 const float e = __expf(-a.temp * part);
                 sum_e += e;
 #pragma unroll
-                for (int j = 0; j < 16; ++j) acc0.v[j] = fmaf(e, diff.v[j], acc0.v[j]);
+                for (int j = 0; j < 8; ++j) s2[j] = __builtin_elementwise_fma(wt_f2{e, e}, wt_f2{diff[2 * j], diff[2 * j + 1]}, s2[j]);
             } else {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    acc0.v[j] += wv.v[j];
-                    acc1.v[j] = fmaf(wv.v[j], wv.v[j], acc1.v[j]);
+                for (int j = 0; j < 8; ++j) {
+                    const wt_f2 x = wt_f2{wv[2 * j], wv[2 * j + 1]};
+                    if (v == 0) { s2[j] = rf2[j] + x; q2[j] = __builtin_elementwise_fma(x, x, rfsq[j]); }
+                    else { s2[j] += x; q2[j] = __builtin_elementwise_fma(x, x, q2[j]); }
                 }
             }
         }
 
         f32x8 oa, ob;
         if (COST == PSCV_COST_VARIANCE) {
+            const wt_f2 n1 = wt_f2{invN, invN}, n2 = wt_f2{invN2, invN2};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                oa.v[j] = acc1.v[j] * invN - (acc0.v[j] * acc0.v[j]) * invN2;
-                ob.v[j] = acc1.v[8 + j] * invN - (acc0.v[8 + j] * acc0.v[8 + j]) * invN2;
+            for (int j = 0; j < 4; ++j) {
+                const wt_f2 ra = q2[j] * n1 - (s2[j] * s2[j]) * n2, rb = q2[4 + j] * n1 - (s2[4 + j] * s2[4 + j]) * n2;
+                oa.v[2 * j] = ra[0]; oa.v[2 * j + 1] = ra[1]; ob.v[2 * j] = rb[0]; ob.v[2 * j + 1] = rb[1];
             }
         } else if (COST == PSCV_COST_VARIANCE_CVP) {
+            const wt_f2 n1 = wt_f2{invN, invN};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float ma = acc0.v[j] * invN, mb = acc0.v[8 + j] * invN;
-                oa.v[j] = acc1.v[j] * invN - ma * ma;
-                ob.v[j] = acc1.v[8 + j] * invN - mb * mb;
+            for (int j = 0; j < 4; ++j) {
+                const wt_f2 ma = s2[j] * n1, mb = s2[4 + j] * n1;
+                const wt_f2 ra = q2[j] * n1 - ma * ma, rb = q2[4 + j] * n1 - mb * mb;
+                oa.v[2 * j] = ra[0]; oa.v[2 * j + 1] = ra[1]; ob.v[2 * j] = rb[0]; ob.v[2 * j + 1] = rb[1];
             }
         } else {
             const float inv = 1.0f / (sum_e + 1e-6f);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { oa.v[j] = acc0.v[j] * inv; ob.v[j] = acc0.v[8 + j] * inv; }
+            for (int j = 0; j < 4; ++j) {
+                oa.v[2 * j] = s2[j][0] * inv; oa.v[2 * j + 1] = s2[j][1] * inv;
+                ob.v[2 * j] = s2[4 + j][0] * inv; ob.v[2 * j + 1] = s2[4 + j][1] * inv;
+            }
         }
         if (active) {
-            Elem<TOut>::store8(out + vox * C + hh * 8, oa);
-            Elem<TOut>::store8(out + vox * C + 16 + hh * 8, ob);
+            TOut* op = reinterpret_cast<TOut*>(out + ((unsigned long)b * a.D + d) * plane_bytes + lane_out);
+            Elem<TOut>::store8(op, oa);
+            Elem<TOut>::store8(op + 16, ob);
         }
     }
 }
