@@ -175,6 +175,27 @@ int pscv_fuse_pairs(const void* const* interm, const float* const* uncert, int n
 int pscv_fuse_finish(const float* partial, const float* wsum, int dtype, void* out, int B, int D, int h, int w, void* stream);
 
 /*
+ * Geometric-consistency filter of one depth map against its source views (the step after the
+ * path).  Replaces the body of evaluation/filtering.py:60-83 (unproject -> project_all -> grid_sample of the source
+ * depth -> unproj_all -> project -> reprojection / relative-depth / triangulation-angle tests -> per-pixel vote).
+ *   depth      device fp32 [h,w]            reference depth map
+ *   src_depth  host array of n_src device pointers, fp32 [src_hw[2i], src_hw[2i+1]] (maps may differ in size)
+ *   src_hw     host int array [n_src][2] = (height, width) of each source map
+ *   cams       device fp32 [n_src+1][PSCV_GEO_CAM_FLOATS]: K, K^-1, R (row-major 3x3 each), t (3); view 0 = reference;
+ *              intrinsics at the resolution of the respective depth map
+ *   max_reproj_error (pixels), depth_threshold (relative), min_tri_angle (degrees), num_consistent: the reference's
+ *              command-line parameters (pipeline_utils.py:49-52); a pixel passes a test when at least
+ *              num_consistent - 1 sources agree
+ *   mask_depth, mask_disp, geo_mask   device uint8 [h,w] (0/1), each may be NULL
+ *   counts     device int32 [3][h,w] number of agreeing sources per test (depth, disp, geo), or NULL
+ */
+#define PSCV_GEO_MAX_SRC 32
+#define PSCV_GEO_CAM_FLOATS 30
+int pscv_geo_filter(const float* depth, const float* const* src_depth, const int* src_hw, int n_src, const float* cams,
+                    int h, int w, float max_reproj_error, float depth_threshold, float min_tri_angle, int num_consistent,
+                    unsigned char* mask_depth, unsigned char* mask_disp, unsigned char* geo_mask, int* counts, void* stream);
+
+/*
  * Softmax over the depth axis + expectation(s), fused.
  * Replaces: F.softmax + depth_regression + photometric confidence (models/MVSNet/model.py:207-215, module.py:174-178;
  *           CVP net.py:161-162,203-219) and soft_argmin / entropy (models/VisMVSNet/nn_utils.py:453-470).

@@ -12,7 +12,7 @@ be re-created from ``wild_deep_mvs_amd.synthetic`` (the fixture records the
 generator arguments instead); every stage boundary of the reference's hot path is
 stored as fp32 arrays (tiny problem sizes; per-view warped volumes keep 3 planes).
 
-Usage:  python tests/golden/gen_golden.py [--only mvsnet|mvsnet_s|vis|cvp]
+Usage:  python tests/golden/gen_golden.py [--only mvsnet|mvsnet_s|vis|cvp|filter]
 """
 from __future__ import annotations
 
@@ -274,6 +274,49 @@ def gen_state_dict_keys():
     print("wrote", path)
 
 
+# --------------------------------------------------------------------------
+def gen_filter(tag: str, *, V=5, H=48, W=64, seed=0, behind_view=-1, half_res_view=-1, near_view=-1, upsample=False,
+               downscale=1, num_consistent=3):
+    """Geometric-consistency filter: the reference's own ``evaluation.filtering.run`` on depth maps written to a
+    scratch directory (its only interface is files + a dataloader batch).  Stores inputs and the three masks."""
+    import tempfile
+    from argparse import Namespace
+    sys.path.insert(0, REPO)
+    from wild_deep_mvs_amd import synthetic
+    from evaluation import filtering as ref_filtering  # reference
+    from evaluation.pipeline_utils import depth_folder_name  # reference
+
+    sc = synthetic.make_filter_scene(V, H, W, seed=seed, behind_view=behind_view, half_res_view=half_res_view,
+                                     near_view=near_view)
+    depth, src = sc["depth"], sc["src_depth"]
+    if upsample:   # the stored maps are at 1/downscale resolution and the filter upsamples them (filtering.py:54-58)
+        depth = depth[::downscale, ::downscale].contiguous()
+        src = [d[::downscale, ::downscale].contiguous() for d in src]
+    with tempfile.TemporaryDirectory() as tmp:
+        args = Namespace(model="m", nviews=V, data_path=tmp, scene="scene0", upsample=upsample, downscale=downscale,
+                         max_reproj_error=1.0, depth_threshold=0.01, min_tri_angle=1.0, num_consistent=num_consistent,
+                         debug=False)
+        folder = os.path.join(tmp, "IntRes", "depthmaps", depth_folder_name(args), "scene0")
+        os.makedirs(folder)
+        np.savez(os.path.join(folder, "ref_out.npz"), depthmap=np32(depth))
+        for i, d in enumerate(src):
+            np.savez(os.path.join(folder, f"src{i}_out.npz"), depthmap=np32(d))
+        batch = {"filename": ["ref"], "K": sc["K"].clone().unsqueeze(0), "R": sc["R"].clone().unsqueeze(0),
+                 "t": sc["t"].clone().unsqueeze(0), "src_filenames": [[f"src{i}"] for i in range(V - 1)]}
+        ref_filtering.tqdm = lambda it, **k: it
+        ref_filtering.run([batch], args)
+        out = np.load(os.path.join(tmp, "IntRes", "geometric_filtering", depth_folder_name(args), "scene0", "ref_out.npz"))
+        masks = {k: out[k].copy() for k in ("mask_depth", "mask_disp", "geo_mask")}
+    arrays = {"depth": np32(depth), "K": np32(sc["K"]), "R": np32(sc["R"]), "t": np32(sc["t"]),
+              "meta": np.array([V, H, W, seed, behind_view, half_res_view, int(upsample), downscale, num_consistent, near_view]),
+              "params": np.array([1.0, 0.01, 1.0], dtype=np.float32)}
+    for i, d in enumerate(src):
+        arrays[f"src_depth_{i}"] = np32(d)
+    arrays.update(masks)
+    save(f"{tag}.npz", **arrays)
+    print({k: float(v.mean()) for k, v in masks.items()})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -287,6 +330,8 @@ def main():
         "vis": lambda: gen_vis("vis_tiny"),
         "cvp": lambda: gen_cvp("cvp_tiny"),
         "keys": gen_state_dict_keys,
+        "filter": lambda: (gen_filter("filter_tiny", V=6, behind_view=4, half_res_view=3, near_view=2),
+                           gen_filter("filter_upsample", V=4, seed=3, upsample=True, downscale=2, num_consistent=2)),
     }
     for k, fn in todo.items():
         if args.only in (None, k):

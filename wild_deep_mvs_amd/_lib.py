@@ -24,9 +24,11 @@ CONV_S1, CONV_S2, CONV_T2, CONV_S1P8, CONV_S1C1, CONV_T2P8 = 0, 1, 2, 3, 4, 5
 EPI_RELU_PRE, EPI_RELU_POST = 1, 2
 MAX_SRC = 16
 CAM_FLOATS = 18
+GEO_MAX_SRC = 32
+GEO_CAM_FLOATS = 30
 
 EXPORTS = ("pscv_last_error", "pscv_abi_version", "pscv_set_tuning", "pscv_proj_cams", "pscv_homog_cams", "pscv_warp_cost",
-           "pscv_fuse_pairs", "pscv_fuse_finish",
+           "pscv_fuse_pairs", "pscv_fuse_finish", "pscv_geo_filter",
            "pscv_pack_conv3d_weights", "pscv_conv3d", "pscv_softargmin")
 
 
@@ -70,6 +72,8 @@ def _declare(lib):
     lib.pscv_fuse_pairs.argtypes = [C.POINTER(vp), C.POINTER(vp), i, i, vp, vp, i, i, i, i, i, vp]
     lib.pscv_fuse_finish.restype = i
     lib.pscv_fuse_finish.argtypes = [vp, vp, i, vp, i, i, i, i, vp]
+    lib.pscv_geo_filter.restype = i
+    lib.pscv_geo_filter.argtypes = [vp, C.POINTER(vp), C.POINTER(i), i, vp, i, i, f, f, f, i, vp, vp, vp, vp, vp]
     lib.pscv_warp_cost.restype = i
     lib.pscv_warp_cost.argtypes = [vp, C.POINTER(vp), i, vp, vp, l, i, i, i, f, vp, i, i, i, i, i, i, i, i, i, vp]
     lib.pscv_pack_conv3d_weights.restype = l

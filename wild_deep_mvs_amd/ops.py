@@ -199,6 +199,44 @@ def fuse_finish(partial: torch.Tensor, wsum: torch.Tensor, dtype: torch.dtype) -
 
 
 # --------------------------------------------------------------------------------------------
+# geometric-consistency filter (the step after the path)
+# --------------------------------------------------------------------------------------------
+def geo_filter_cams(K: torch.Tensor, R: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+    """[V,3,3], [V,3,3], [V,3,1] (view 0 = reference) -> camera blocks [V,30] fp32 (K, K^-1, R, t) for
+    ``geo_filter``.  The inverse is ``torch.inverse`` in fp32, what the reference uses (utils_3D.py:131,155)."""
+    K = K.to(torch.float32)
+    blocks = torch.cat((K.reshape(-1, 9), torch.inverse(K).reshape(-1, 9), R.to(torch.float32).reshape(-1, 9),
+                        t.to(torch.float32).reshape(-1, 3)), dim=1)
+    return blocks.contiguous()
+
+
+def geo_filter(depth: torch.Tensor, src_depth: Sequence[torch.Tensor], cams: torch.Tensor, *, max_reproj_error: float = 1.0,
+               depth_threshold: float = 0.01, min_tri_angle: float = 1.0, num_consistent: int = 3,
+               want_counts: bool = False):
+    """depth [h,w] fp32, src_depth N x [h_i,w_i] fp32, cams [N+1,30] (``geo_filter_cams``), all on the GPU ->
+    (mask_depth, mask_disp, geo_mask) bool [h,w] (and int32 counts [3,h,w] with ``want_counts``): the masks of
+    evaluation/filtering.py:73-83 in one launch (pscv_geo_filter)."""
+    src_depth = [s.to(torch.float32).contiguous() for s in src_depth]
+    depth = depth.to(torch.float32).contiguous()
+    cams = cams.to(torch.float32).contiguous()
+    _dev(depth, cams, *src_depth)
+    n = len(src_depth)
+    if n < 1 or n > L.GEO_MAX_SRC or tuple(cams.shape) != (n + 1, L.GEO_CAM_FLOATS) or depth.dim() != 2:
+        raise ValueError(f"pscv.geo_filter: depth [h,w], 1..{L.GEO_MAX_SRC} source maps and cams [N+1,{L.GEO_CAM_FLOATS}] expected")
+    h, w = depth.shape
+    masks = torch.empty((3, h, w), dtype=torch.uint8, device=depth.device)
+    counts = torch.empty((3, h, w), dtype=torch.int32, device=depth.device) if want_counts else None
+    ptrs = (C.c_void_p * n)(*[s.data_ptr() for s in src_depth])
+    hw = (C.c_int * (2 * n))(*[v for s in src_depth for v in s.shape])
+    rc = _launch("geo_filter", lambda: L.lib().pscv_geo_filter(
+        _p(depth), ptrs, hw, n, _p(cams), h, w, float(max_reproj_error), float(depth_threshold), float(min_tri_angle),
+        int(num_consistent), _p(masks[0]), _p(masks[1]), _p(masks[2]), _p(counts), _stream()))
+    L.check(rc, "pscv_geo_filter")
+    out = (masks[0].bool(), masks[1].bool(), masks[2].bool())
+    return out + (counts,) if want_counts else out
+
+
+# --------------------------------------------------------------------------------------------
 # fused warp + cost
 # --------------------------------------------------------------------------------------------
 def warp_cost(ref: Optional[torch.Tensor], srcs: Sequence[torch.Tensor], cams: torch.Tensor, depth: torch.Tensor, *,

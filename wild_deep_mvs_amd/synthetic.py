@@ -60,6 +60,47 @@ def make_cameras(B: int, V: int, H: int, W: int, *, depth_min: float = 2.0,
     return {"K": K, "R": R, "t": t, "depth_min": dmin, "depth_max": dmax}
 
 
+def make_filter_scene(V: int, H: int, W: int, *, seed: int = 0, behind_view: int = -1, half_res_view: int = -1,
+                      near_view: int = -1, baseline: float = 4.0) -> Dict[str, object]:
+    """Depth maps of one tilted world plane seen by the ``make_cameras`` rig, for the geometric-consistency filter
+    (the step after the hot path): ``depth`` [H,W] of view 0, ``src_depth`` list of V-1 maps, ``K``, ``R`` [V,3,3],
+    ``t`` [V,3,1].  The plane depth is analytic per view (``d = (c + n.R^T t) / (n.R^T K^-1 p)``), so the maps are
+    mutually consistent; smooth multiplicative perturbations of 0-3 % (independent per view) then move pixels to
+    either side of the filter's 1 % / 1 px thresholds, and a block of gross outliers is planted in source 1.
+    ``half_res_view`` renders that source at half resolution (own intrinsics): the filter takes per-source shapes.
+    ``baseline`` scales the camera translations (wider baseline = larger triangulation angles); ``near_view`` keeps
+    that source almost at the reference's position (triangulation angle below the 1 degree default)."""
+    cam = make_cameras(1, V, H, W, behind_view=behind_view)
+    K, R, t = cam["K"][0].clone(), cam["R"][0].clone(), cam["t"][0].clone() * baseline
+    if near_view >= 0:
+        t[near_view] = t[near_view] * 0.02
+        R[near_view] = torch.eye(3)
+    rng = np.random.default_rng(seed)
+    n = torch.tensor([0.10, -0.06, 1.0])
+    n = n / n.norm()
+    c = 4.0 * float(n[2])
+    maps = []
+    for v in range(V):
+        h, w = H, W
+        Kv = K[v].clone()
+        if v == half_res_view:
+            h, w = H // 2, W // 2
+            Kv[:2] *= 0.5
+            K[v] = Kv
+        ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+        p = torch.stack((xs, ys, torch.ones_like(xs)), dim=-1).reshape(-1, 3)
+        ray = (p @ torch.inverse(Kv).t()) @ R[v]                       # R^T K^-1 p, as rows
+        num = c + float(n @ (R[v].t() @ t[v]).squeeze(-1))
+        d = (num / (ray @ n)).reshape(h, w)
+        coarse = torch.from_numpy(rng.standard_normal((1, 1, max(h // 12, 2), max(w // 12, 2))).astype(np.float32))
+        bump = torch.nn.functional.interpolate(coarse, size=(h, w), mode="bilinear", align_corners=False)[0, 0]
+        d = d * (1.0 + 0.012 * bump * (0.3 if v == 0 else 1.0))
+        if v == 1:
+            d[h // 4:h // 2, w // 3:w // 2] *= 1.4                    # gross outliers
+        maps.append(d.contiguous())
+    return {"depth": maps[0], "src_depth": maps[1:], "K": K, "R": R, "t": t}
+
+
 def make_scene(B: int, V: int, H: int, W: int, *, seed: int = 0, depth_min: float = 2.0,
                depth_max: float = 6.0, behind_view: int = -1) -> Dict[str, torch.Tensor]:
     """Full sample dict with smooth-ish random images in [0, 1)."""
