@@ -175,6 +175,21 @@ int pscv_fuse_pairs(const void* const* interm, const float* const* uncert, int n
 int pscv_fuse_finish(const float* partial, const float* wsum, int dtype, void* out, int B, int D, int h, int w, void* stream);
 
 /*
+ * 2-D convolution over channels-last 16-bit feature maps with a fused per-channel affine (folded BatchNorm) and ReLU:
+ * the 2-D feature extractor in front of the path.  Replaces ConvBnReLU / Conv2d of
+ * models/MVSNet/module.py:23-38, models/MVSNet/model.py:21-41.  Supported layers: k3 s1 p1 and k5 s2 p2,
+ * c_in 8 / 16 / 32 / 64 (a 3-channel image is zero-padded to 8 by the caller), c_out 8 / 16 / 32 / 64.
+ *   pscv_pack_conv2d_weights: w fp32 [c_out, c_in, k, k] (PyTorch layout) -> MFMA A-fragment order for a layer whose
+ *       input has c_in_padded channels; returns the number of 16-bit elements (packed may be NULL to query).
+ *   pscv_conv2d: in [B,Hi,Wi,c_in] (c_in = the padded count), out [B,Ho,Wo,c_out] in `out_dtype` (the storage dtype or
+ *       fp32); scale / bias fp32 [c_out] or NULL; v = conv * scale + bias, y = max(v, neg_slope * v): neg_slope 0 = ReLU,
+ *       0.1 = LeakyReLU(0.1) (models/CVP_MVSNet/models/modules.py:24-28), 1 = no activation.
+ */
+long pscv_pack_conv2d_weights(const float* w, int c_in, int c_in_padded, int c_out, int ks, int dtype, uint16_t* packed);
+int pscv_conv2d(const void* in, int dtype, const uint16_t* packed, const float* scale, const float* bias, void* out,
+                int out_dtype, int B, int Hi, int Wi, int c_in, int c_out, int ks, int stride, float neg_slope, void* stream);
+
+/*
  * Geometric-consistency filter of one depth map against its source views (the step after the
  * path).  Replaces the body of evaluation/filtering.py:60-83 (unproject -> project_all -> grid_sample of the source
  * depth -> unproj_all -> project -> reprojection / relative-depth / triangulation-angle tests -> per-pixel vote).

@@ -45,24 +45,31 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", type=int, default=0)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--feature-engine", default="", help="pscv | torch: 2-D extractor of MVSNet / CVP (default: the model's)")
     args = ap.parse_args()
     for cid, cfg in CONFIGS.items():
         if args.only and cid != args.only:
             continue
         net = build(cfg["arch"])
         cfg["setup"](net)
+        if args.feature_engine and hasattr(net, "feature_engine"):
+            net.feature_engine = args.feature_engine
         scene = synthetic.make_scene(1, cfg["V"], cfg["H"], cfg["W"], seed=cid)
         if "bscale" in cfg:
             scene["t"] = scene["t"] * cfg["bscale"]
         dev = {k: v.cuda() for k, v in scene.items()}
         call = lambda: net(dev["imgs"], dev["K"], dev["R"], dev["t"], dev["depth_min"], dev["depth_max"], **cfg["kw"])
+        import gc
+        out = call()
         out = call()
         torch.cuda.synchronize()
+        gc.collect(); gc.disable()      # a generation-2 collection inside the loop costs ~40 ms (seen in bench.py too)
         t0 = time.perf_counter()
         for _ in range(args.reps):
             out = call()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / args.reps
+        gc.enable()
         d = out["depth"]
         ok = bool(torch.isfinite(d).all()) and bool(torch.isfinite(out["photometric_confidence"]).all())
         print(f"config {cid} {cfg['arch']:8s} V={cfg['V']} {cfg['H']}x{cfg['W']}: {dt * 1e3:8.2f} ms / forward (with 2-D features), "

@@ -1,0 +1,90 @@
+"""GPU: pscv_conv2d (MFMA 2-D convolution of the feature extractor) against ATen conv2d on the same 16-bit-rounded
+operands, every layer shape of MVSNet's FeatureNet, ragged sizes, both storage formats, fused BN/ReLU epilogue."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from tests._util import check_close
+
+
+@pytest.fixture(scope="module")
+def env():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from wild_deep_mvs_amd import _lib as L, ops
+    L.lib()
+    return L, ops
+
+
+LAYERS = [(3, 8, 3, 1), (8, 8, 3, 1), (8, 16, 5, 2), (16, 16, 3, 1), (16, 32, 5, 2), (32, 32, 3, 1), (16, 32, 3, 1), (32, 16, 3, 1)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("ci,co,ks,stride", LAYERS)
+@pytest.mark.parametrize("B,H,W", [(2, 40, 72), (1, 37, 53)])
+def test_conv2d_matches_aten(env, ci, co, ks, stride, B, H, W, dtype):
+    L, ops = env
+    g = torch.Generator().manual_seed(ci * 100 + co + ks)
+    x = torch.randn(B, ci, H, W, generator=g)
+    w = torch.randn(co, ci, ks, ks, generator=g) / (ci * ks * ks) ** 0.5
+    gamma, beta = torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g) * 0.1
+    mean, var = torch.randn(co, generator=g) * 0.1, torch.rand(co, generator=g) + 0.5
+    xr, wr = x.to(dtype).float(), w.to(dtype).float()
+    ref = F.conv2d(xr, wr, stride=stride, padding=ks // 2)
+    ref = F.relu(F.batch_norm(ref, mean, var, gamma, beta, False, 0.0, 1e-5))
+    layer = ops.Conv2dLayer.build(w, stride=stride, device="cuda", bn=(gamma, beta, mean, var), relu=True, dtype=dtype)
+    cpad = layer.c_in
+    xcl = torch.zeros(B, H, W, cpad, dtype=dtype)
+    xcl[..., :ci] = x.permute(0, 2, 3, 1).to(dtype)
+    got = ops.conv2d(xcl.cuda(), layer, out_dtype=torch.float32)
+    assert tuple(got.shape) == (B, ref.shape[2], ref.shape[3], co)
+    check_close(f"conv2d {ci}->{co} k{ks}s{stride} {dtype}", got.permute(0, 3, 1, 2).cpu(), ref,
+                max_abs=3e-5 * float(ref.abs().max()) + 1e-6, rel_l2=1e-5)
+    # 16-bit output = the fp32 result rounded once
+    got16 = ops.conv2d(xcl.cuda(), layer)
+    assert got16.dtype == dtype
+    ulp = 2 ** -8 if dtype == torch.bfloat16 else 2 ** -11
+    check_close("16-bit store", got16.float().cpu(), got.cpu(), max_abs=ulp * float(got.abs().max()) + 1e-6, rel_l2=ulp)
+
+
+@pytest.mark.parametrize("ci,co", [(3, 64), (64, 64), (64, 32), (32, 16), (16, 16)])
+def test_conv2d_leaky_relu_layers_of_the_cvp_pyramid(env, ci, co):
+    """conv 3x3 + bias + LeakyReLU(0.1) (models/CVP_MVSNet/models/modules.py:24-28), incl. the 64-channel layers whose
+    72 weight fragments stream through the prefetch ring."""
+    L, ops = env
+    g = torch.Generator().manual_seed(ci + co)
+    B, H, W = 2, 45, 70
+    x = torch.randn(B, ci, H, W, generator=g)
+    w = torch.randn(co, ci, 3, 3, generator=g) / (ci * 9) ** 0.5
+    bias = torch.randn(co, generator=g) * 0.2
+    dtype = torch.float16
+    ref = F.leaky_relu(F.conv2d(x.to(dtype).float(), w.to(dtype).float(), bias, padding=1), 0.1)
+    layer = ops.Conv2dLayer.build(w, stride=1, device="cuda", conv_bias=bias, leaky=0.1, dtype=dtype)
+    xcl = torch.zeros(B, H, W, layer.c_in, dtype=dtype)
+    xcl[..., :ci] = x.permute(0, 2, 3, 1).to(dtype)
+    got = ops.conv2d(xcl.cuda(), layer, out_dtype=torch.float32)
+    check_close(f"leaky conv2d {ci}->{co}", got.permute(0, 3, 1, 2).cpu(), ref, max_abs=3e-5 * float(ref.abs().max()) + 1e-6, rel_l2=1e-5)
+    assert float((ref < 0).float().mean()) > 0.2     # the negative branch is exercised
+
+
+def test_conv2d_plain_conv_with_bias_at_feature_size(env):
+    """The extractor's last layer (plain Conv2d 32->32 with bias, no BN / ReLU) at the headline feature size, and the
+    linearity of the layer (a size-independent property): conv(a x + b y) = a conv(x) + b conv(y) - (a + b - 1) bias."""
+    L, ops = env
+    g = torch.Generator().manual_seed(5)
+    B, H, W, c = 5, 128, 160, 32
+    w = torch.randn(c, c, 3, 3, generator=g) / (c * 9) ** 0.5
+    bias = torch.randn(c, generator=g) * 0.1
+    layer = ops.Conv2dLayer.build(w, stride=1, device="cuda", conv_bias=bias, relu=False, dtype=torch.float16)
+    x = torch.randn(B, H, W, c, generator=g).to(torch.float16).cuda()
+    y = torch.randn(B, H, W, c, generator=g).to(torch.float16).cuda()
+    fx, fy = ops.conv2d(x, layer, out_dtype=torch.float32), ops.conv2d(y, layer, out_dtype=torch.float32)
+    z = (0.5 * x.float() + 0.25 * y.float()).to(torch.float16)          # exactly representable combination
+    fz = ops.conv2d(z, layer, out_dtype=torch.float32)
+    want = 0.5 * fx + 0.25 * fy + 0.25 * bias.cuda().view(1, 1, 1, c)
+    check_close("linearity", fz.cpu(), want.cpu(), max_abs=2e-3 * float(want.abs().max()), rel_l2=1e-3)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.to(torch.float16).float().cuda(), bias.cuda(), padding=1).permute(0, 2, 3, 1)
+    check_close("vs ATen on the GPU", fx.cpu(), ref.cpu(), max_abs=1e-4 * float(ref.abs().max()), rel_l2=2e-5)

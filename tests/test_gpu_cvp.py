@@ -18,14 +18,18 @@ def env():
     return L, ops, synthetic, Frontend
 
 
+@pytest.mark.parametrize("feature_engine", ["pscv", "torch"])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-def test_cvp_forward_parity_with_reference(env, dtype):
+def test_cvp_forward_parity_with_reference(env, dtype, feature_engine):
+    """Full forward vs the reference golden, with the 2-D pyramid tower on the HIP conv2d kernels (default) and on
+    PyTorch-ROCm."""
     L, ops, synthetic, Frontend = env
     g = load_golden("cvp_tiny.npz")
     scene, nscale, seed = cvp_scene(g)
     net = Frontend()
     net.load_state_dict(synthetic.sharpened_state_dict("cvp", synthetic.template_of(net), seed=seed), strict=True)
     net.storage_dtype = dtype
+    net.feature_engine = feature_engine
     net = net.cuda().eval()
     dev = {k: v.cuda() for k, v in scene.items()}
     taps = {}

@@ -52,15 +52,41 @@ def test_cost_reg_net_layers_vs_oracle(env, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_feature_net_engine_vs_reference_features(env, dtype):
+    """The 2-D extractor as eight MFMA conv2d launches (16-bit activations between the layers, BatchNorm folded)
+    against the reference's fp32 feature maps (golden), next to the PyTorch-ROCm path rounded once at the end."""
+    L, ops, synthetic, MVSNet, O = env
+    g = load_golden("mvsnet_tiny.npz")
+    H, W, V, D, seed, scene_seed, behind = [int(x) for x in g["meta"]]
+    net, sd = _model(env, "variance", seed, dtype)
+    scene = synthetic.make_scene(1, V, H, W, seed=scene_seed, behind_view=behind)
+    imgs = [scene["imgs"][:, v].cuda() for v in range(V)]
+    ref = t(g["features"])                                                   # [V,1,32,h,w]
+    with torch.no_grad():
+        net.feature_engine = "pscv"
+        got = torch.stack([f.float().permute(0, 3, 1, 2).cpu() for f in net.extract_features_cl(imgs)])
+        net.feature_engine = "torch"
+        base = torch.stack([f.float().permute(0, 3, 1, 2).cpu() for f in net.extract_features_cl(imgs)])
+    ulp = 2 ** -8 if dtype == torch.bfloat16 else 2 ** -11
+    check_close(f"torch features rounded to {dtype}", base, ref, rel_l2=ulp)
+    # eight stored layers instead of one final rounding: a few ulp of relative L2
+    check_close(f"pscv conv2d features {dtype}", got, ref, rel_l2=6 * ulp)
+    assert got.shape == ref.shape
+
+
+@pytest.mark.parametrize("feature_engine", ["pscv", "torch"])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("fname,agg", [("mvsnet_tiny.npz", "variance"), ("mvsnet_behind.npz", "variance"),
                                         ("mvsnet_s_tiny.npz", "softmin")])
-def test_forward_depth_parity_with_reference(env, fname, agg, dtype):
+def test_forward_depth_parity_with_reference(env, fname, agg, dtype, feature_engine):
     """forward(imgs, K, R, t, depth_min, depth_max) -> depth within 1e-3 relative L1 of the reference's
-    fp32 PyTorch path (BASELINE.json north_star) with fp16 storage / fp32 accumulation (see DEPTH_TOL for bf16)."""
+    fp32 PyTorch path (BASELINE.json north_star) with fp16 storage / fp32 accumulation (see DEPTH_TOL for bf16),
+    with the 2-D extractor on the HIP engine (default) and on PyTorch-ROCm."""
     L, ops, synthetic, MVSNet, O = env
     g = load_golden(fname)
     H, W, V, D, seed, scene_seed, behind = [int(x) for x in g["meta"]]
     net, sd = _model(env, agg, seed, dtype)
+    net.feature_engine = feature_engine
     net.num_depth = D
     scene = synthetic.make_scene(1, V, H, W, seed=scene_seed, behind_view=behind)
     dev = {k: v.cuda() for k, v in scene.items()}
@@ -68,8 +94,11 @@ def test_forward_depth_parity_with_reference(env, fname, agg, dtype):
     out = net(dev["imgs"], dev["K"], dev["R"], dev["t"], dev["depth_min"], dev["depth_max"], taps=taps)
     assert set(out) == {"depth", "depth_est_list", "depth_pair_list", "photometric_confidence"}
     assert tuple(out["depth"].shape) == (1, H // 4, W // 4) and out["depth_pair_list"] == []
-    check_close(f"{fname} cost volume ({dtype})", taps["cost_volume"].float().permute(0, 4, 1, 2, 3).cpu(), t(g["cost_volume"]), rel_l2=1e-2)
-    check_close(f"{fname} logits ({dtype})", taps["logits"].cpu(), t(g["logits"]).squeeze(1), rel_l2=3e-2)
+    # (bf16 activations through the eight 2-D layers add ~1e-2 of relative error to the features' variance)
+    loose = dtype == torch.bfloat16 and feature_engine == "pscv"
+    check_close(f"{fname} cost volume ({dtype})", taps["cost_volume"].float().permute(0, 4, 1, 2, 3).cpu(), t(g["cost_volume"]),
+                rel_l2=2e-2 if loose else 1e-2)
+    check_close(f"{fname} logits ({dtype})", taps["logits"].cpu(), t(g["logits"]).squeeze(1), rel_l2=6e-2 if loose else 3e-2)
     ref = t(g["depth"])
     s = check_close(f"{fname} depth ({dtype})", out["depth"].cpu(), ref)
     assert s["rel_l1"] <= DEPTH_TOL[dtype], s

@@ -28,7 +28,7 @@ GEO_MAX_SRC = 32
 GEO_CAM_FLOATS = 30
 
 EXPORTS = ("pscv_last_error", "pscv_abi_version", "pscv_set_tuning", "pscv_proj_cams", "pscv_homog_cams", "pscv_warp_cost",
-           "pscv_fuse_pairs", "pscv_fuse_finish", "pscv_geo_filter",
+           "pscv_fuse_pairs", "pscv_fuse_finish", "pscv_geo_filter", "pscv_pack_conv2d_weights", "pscv_conv2d",
            "pscv_pack_conv3d_weights", "pscv_conv3d", "pscv_softargmin")
 
 
@@ -72,6 +72,10 @@ def _declare(lib):
     lib.pscv_fuse_pairs.argtypes = [C.POINTER(vp), C.POINTER(vp), i, i, vp, vp, i, i, i, i, i, vp]
     lib.pscv_fuse_finish.restype = i
     lib.pscv_fuse_finish.argtypes = [vp, vp, i, vp, i, i, i, i, vp]
+    lib.pscv_pack_conv2d_weights.restype = l
+    lib.pscv_pack_conv2d_weights.argtypes = [vp, i, i, i, i, i, vp]
+    lib.pscv_conv2d.restype = i
+    lib.pscv_conv2d.argtypes = [vp, i, vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, vp]
     lib.pscv_geo_filter.restype = i
     lib.pscv_geo_filter.argtypes = [vp, C.POINTER(vp), C.POINTER(i), i, vp, i, i, f, f, f, i, vp, vp, vp, vp, vp]
     lib.pscv_warp_cost.restype = i

@@ -18,6 +18,14 @@ class Frontend(nn.Module):
     def storage_dtype(self, dt):
         self.model.storage_dtype = dt
 
+    @property
+    def feature_engine(self):
+        return self.model.feature_engine
+
+    @feature_engine.setter
+    def feature_engine(self, name):
+        self.model.feature_engine = name
+
     def forward(self, imgs, K, R, t, depth_min, depth_max, reference_frame=0, **kwargs):
         src_idx = [i for i in range(K.shape[1]) if i != reference_frame]
         if isinstance(imgs, torch.Tensor):

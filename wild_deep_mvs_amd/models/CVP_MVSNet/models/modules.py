@@ -62,13 +62,15 @@ def homo_warping(src_feature, ref_in, src_in, ref_ex, src_ex, depth_hypos, ref_s
 
 
 def proj_cost(nsrc, ref_feature, src_feature, level, ref_in, src_in, ref_ex, src_ex, depth_hypos,
-              storage_dtype=torch.float16):
+              storage_dtype=torch.float16, channels_last=False):
     """Refinement cost volume with per-pixel hypotheses (modules.py:229-293) in ONE fused launch.
     ref_feature [B,16,h,w]; src_feature[src][level] [B,16,h,w]; depth_hypos [B,D,h,w]
-    -> channels-last variance volume [B,D,h,w,16] (``sum f^2/N - (sum f/N)^2``)."""
-    srcs = [ops.to_channels_last(src_feature[s][level], storage_dtype) for s in range(nsrc)]
+    -> channels-last variance volume [B,D,h,w,16] (``sum f^2/N - (sum f/N)^2``).
+    ``channels_last``: the features already are the engine's [B,h,w,16] 16-bit maps (HIP pyramid tower)."""
+    cl = (lambda f: f.contiguous()) if channels_last else (lambda f: ops.to_channels_last(f, storage_dtype))
+    srcs = [cl(src_feature[s][level]) for s in range(nsrc)]
     cams = _cams(ref_in, [src_in[:, s] for s in range(nsrc)], ref_ex, [src_ex[:, s] for s in range(nsrc)])
-    return ops.warp_cost(ops.to_channels_last(ref_feature, storage_dtype), srcs, cams,
+    return ops.warp_cost(cl(ref_feature), srcs, cams,
                          depth_hypos.to(torch.float32).contiguous(), geom=L.GEOM_PROJ, cost=L.COST_VARIANCE_CVP,
                          out_dtype=storage_dtype)
 

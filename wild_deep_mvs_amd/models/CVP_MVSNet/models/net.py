@@ -36,6 +36,31 @@ class FeaturePyramid(nn.Module):
             levels.append(self._tower(img))
         return levels
 
+    # -- HIP path: nine MFMA conv2d launches per level (bias + LeakyReLU(0.1) fused), channels-last 16-bit maps --
+    def engine_layers(self, dtype: torch.dtype):
+        key = (dtype,) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if getattr(self, "_layers", None) is None or self._layers_key != key:
+            self._layers = [ops.Conv2dLayer.build(getattr(self, n)[0].weight, stride=1, conv_bias=getattr(self, n)[0].bias,
+                                                  leaky=0.1, dtype=dtype) for n in self._names]
+            self._layers_key = key
+        return self._layers
+
+    def forward_engine(self, img, scales: int, dtype: torch.dtype):
+        """[B,3,H,W] on the GPU -> list of channels-last feature maps [B,H_l,W_l,16] in ``dtype``, finest first
+        (the image pyramid itself stays ``F.interpolate``: plumbing)."""
+        layers = self.engine_layers(dtype)
+
+        def tower(x):
+            y = ops.image_to_channels_last8(x, dtype)
+            for layer in layers:
+                y = ops.conv2d(y, layer)
+            return y
+        levels = [tower(img)]
+        for _ in range(scales - 1):
+            img = F.interpolate(img, scale_factor=0.5, mode='bilinear', align_corners=None)
+            levels.append(tower(img))
+        return levels
+
 
 class CostRegNet(nn.Module):
     """CVP regulariser (reference net.py:50-85) on the engine: [B,D,h,w,16] 16-bit -> fp32 logits [B,D,h,w]."""
@@ -94,6 +119,9 @@ class network(nn.Module):
         self.cost_reg_refine = CostRegNet()
         self.nscale = 2
         self.storage_dtype = torch.float16
+        # 2-D pyramid tower: "pscv" = MFMA conv2d launches writing channels-last 16-bit maps (default);
+        # "torch" = PyTorch-ROCm in fp32, converted where the warp kernel reads them
+        self.feature_engine = "pscv"
 
     def forward(self, ref_img, src_imgs, ref_in, src_in, ref_ex, src_ex, depth_min, depth_max, **kwargs):
         if self.training:
@@ -102,24 +130,29 @@ class network(nn.Module):
         taps = kwargs.get("taps")
         nsrc = len(src_imgs)
         dt = self.storage_dtype
+        engine = self.feature_engine == "pscv"
         with torch.no_grad():
+            pyramid = (lambda x: self.featurePyramid.forward_engine(x, nscale, dt)) if engine else (lambda x: self.featurePyramid(x, nscale))
             if all(s.shape == ref_img.shape for s in src_imgs):
                 # all views through the pyramid tower as one batch (same result as the per-view loop)
-                levels = [torch.chunk(f, nsrc + 1, 0) for f in self.featurePyramid(torch.cat([ref_img] + list(src_imgs), 0), nscale)]
+                levels = [torch.chunk(f, nsrc + 1, 0) for f in pyramid(torch.cat([ref_img] + list(src_imgs), 0))]
                 ref_pyr = [lv[0] for lv in levels]
                 src_pyrs = [[lv[i + 1] for lv in levels] for i in range(nsrc)]
             else:
-                ref_pyr = self.featurePyramid(ref_img, nscale)
-                src_pyrs = [self.featurePyramid(s, nscale) for s in src_imgs]
-            ref_in_ms = conditionIntrinsics(ref_in, ref_img.shape, [f.shape for f in ref_pyr])
-            src_in_ms = torch.stack([conditionIntrinsics(src_in[:, i], ref_img.shape, [f.shape for f in src_pyrs[i]])
+                ref_pyr = pyramid(ref_img)
+                src_pyrs = [pyramid(s) for s in src_imgs]
+            # NCHW-style shapes of the levels (the engine's maps are [B,h,w,16])
+            shp = (lambda f: (f.shape[0], f.shape[3], f.shape[1], f.shape[2])) if engine else (lambda f: tuple(f.shape))
+            cl = (lambda f: f.contiguous()) if engine else (lambda f: ops.to_channels_last(f, dt))
+            ref_in_ms = conditionIntrinsics(ref_in, ref_img.shape, [shp(f) for f in ref_pyr])
+            src_in_ms = torch.stack([conditionIntrinsics(src_in[:, i], ref_img.shape, [shp(f) for f in src_pyrs[i]])
                                      for i in range(nsrc)]).permute(1, 0, 2, 3, 4)
 
             # coarsest level: fronto-parallel sweep, 96 planes in eval mode (net.py:126-127)
             hypos = calSweepingDepthHypo(ref_in_ms[:, -1], src_in_ms[:, 0, -1], ref_ex, src_ex, depth_min, depth_max,
                                          nhypothesis_init=96).to(torch.float32).contiguous()
             cams = _cams(ref_in_ms[:, -1], [src_in_ms[:, i, -1] for i in range(nsrc)], ref_ex, [src_ex[:, i] for i in range(nsrc)])
-            cost = ops.warp_cost(ops.to_channels_last(ref_pyr[-1], dt), [ops.to_channels_last(p[-1], dt) for p in src_pyrs],
+            cost = ops.warp_cost(cl(ref_pyr[-1]), [cl(p[-1]) for p in src_pyrs],
                                  cams, hypos, geom=L.GEOM_PROJ, cost=L.COST_VARIANCE_CVP, out_dtype=dt)
             lt = {} if taps is not None else None
             logits = self.cost_reg_refine(cost, lt)
@@ -136,7 +169,7 @@ class network(nn.Module):
                 hyp = calDepthHypo(depth_up, ref_in_ms[:, level], src_in_ms[:, :, level], ref_ex, src_ex, depth_min,
                                    depth_max, level).contiguous()
                 cost = proj_cost(nsrc, ref_pyr[level], src_pyrs, level, ref_in_ms[:, level], src_in_ms[:, :, level],
-                                 ref_ex, src_ex, hyp, storage_dtype=dt)
+                                 ref_ex, src_ex, hyp, storage_dtype=dt, channels_last=engine)
                 lt = {} if taps is not None else None
                 logits = self.cost_reg_refine(cost, lt)
                 is_last = level == 0

@@ -2,9 +2,9 @@
 
 Same constructor, ``forward(imgs, K, R, t, depth_min, depth_max, reference_frame=0, **kwargs)`` signature,
 return dict and state-dict key names/shapes as the reference (models/MVSNet/model.py:87-218), so released
-checkpoints load unchanged.  The 2-D ``FeatureNet`` is upstream of the hot path and stays on
-PyTorch-ROCm; everything from the feature maps to depth + confidence runs as four kinds of HIP launches:
+checkpoints load unchanged.  Everything from the images to depth + confidence runs as HIP launches:
 
+    8 MFMA conv2d launches (2-D FeatureNet, all views batched; ``feature_engine = "torch"`` keeps PyTorch-ROCm)  ->
     fused warp + variance/softmin  ->  11 MFMA conv3d launches (BN/ReLU/skip fused)  ->  fused softargmin
 """
 from __future__ import annotations
@@ -29,21 +29,53 @@ def build_proj_matrices(K: torch.Tensor, R: torch.Tensor, t: torch.Tensor) -> to
 
 
 class FeatureNet(nn.Module):
-    """Upstream 2-D extractor, [B,3,H,W] -> [B,32,H/4,W/4] (reference models/MVSNet/model.py:21-41)."""
+    """Upstream 2-D extractor, [B,3,H,W] -> [B,32,H/4,W/4] (reference models/MVSNet/model.py:21-41).
+
+    ``forward`` is the plain PyTorch module (training, CPU tools).  ``forward_engine`` runs the same eight layers as
+    eight MFMA ``pscv_conv2d`` launches on channels-last 16-bit maps (BatchNorm folded, ReLU fused) and returns the
+    [B,h,w,32] map the warp kernel reads -- SURVEY section 8f-2."""
+
+    SPEC = [(3, 8, 3, 1, 1), (8, 8, 3, 1, 1), (8, 16, 5, 2, 2), (16, 16, 3, 1, 1), (16, 16, 3, 1, 1),
+            (16, 32, 5, 2, 2), (32, 32, 3, 1, 1)]
 
     def __init__(self):
         super().__init__()
         self.inplanes = 32
-        spec = [(3, 8, 3, 1, 1), (8, 8, 3, 1, 1), (8, 16, 5, 2, 2), (16, 16, 3, 1, 1), (16, 16, 3, 1, 1),
-                (16, 32, 5, 2, 2), (32, 32, 3, 1, 1)]
-        for i, (ci, co, k, s, p) in enumerate(spec):
+        for i, (ci, co, k, s, p) in enumerate(self.SPEC):
             setattr(self, f"conv{i}", ConvBnReLU(ci, co, k, s, p))
         self.feature = nn.Conv2d(32, 32, 3, 1, 1)
+        self._layers = None
+        self._layers_key = None
 
     def forward(self, x):
         for i in range(7):
             x = getattr(self, f"conv{i}")(x)
         return self.feature(x)
+
+    def engine_layers(self, dtype: torch.dtype):
+        """Packed weights + folded BatchNorm of the eight layers, rebuilt when a parameter / buffer changes."""
+        key = (dtype,) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        if self._layers is None or self._layers_key != key:
+            dev = self.feature.weight.device
+            layers = []
+            for i, (ci, co, k, s, p) in enumerate(self.SPEC):
+                blk = getattr(self, f"conv{i}")
+                bn = blk.bn
+                layers.append(ops.Conv2dLayer.build(blk.conv.weight, stride=s, device=dev, relu=True, dtype=dtype, bn_eps=bn.eps,
+                                                    bn=(bn.weight, bn.bias, bn.running_mean, bn.running_var)))
+            layers.append(ops.Conv2dLayer.build(self.feature.weight, stride=1, device=dev, conv_bias=self.feature.bias,
+                                                relu=False, dtype=dtype))
+            self._layers, self._layers_key = layers, key
+        return self._layers
+
+    def forward_engine(self, x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+        """[B,3,H,W] image batch on the GPU -> channels-last features [B,H/4,W/4,32] in ``dtype`` (eval mode)."""
+        if self.training:
+            raise NotImplementedError("pscv FeatureNet: the HIP path is inference-only (eval-mode BatchNorm is folded)")
+        y = ops.image_to_channels_last8(x, dtype)
+        for layer in self.engine_layers(dtype):
+            y = ops.conv2d(y, layer)
+        return y
 
 
 def _deconv_block(ci: int, co: int) -> nn.Sequential:
@@ -127,15 +159,29 @@ class MVSNet(nn.Module):
         # fp16 (11-bit significand) keeps depth within ~2e-4 relative L1 of the fp32 reference; bf16 (8-bit)
         # sits at ~1e-3 on peaked-but-unsaturated softmaxes, so fp16 is the default.
         self.storage_dtype = torch.float16
+        # 2-D extractor: "pscv" = eight MFMA conv2d launches writing the warp kernel's layout directly (16-bit
+        # activations between the layers); "torch" = PyTorch-ROCm in fp32, converted once at the end.
+        self.feature_engine = "pscv"
 
     # -- upstream ---------------------------------------------------------------------------
     def extract_features(self, imgs: Sequence[torch.Tensor]) -> List[torch.Tensor]:
-        """All views through the 2-D extractor as ONE batch (V x fewer MIOpen launches; eval-mode BatchNorm is a
-        per-channel affine, so the result equals the reference's per-view loop, model.py:101-107)."""
+        """All views through the PyTorch 2-D extractor as ONE batch (eval-mode BatchNorm is a per-channel affine, so
+        the result equals the reference's per-view loop, model.py:101-107).  NCHW fp32 maps."""
         imgs = list(imgs)
         if len({tuple(i.shape) for i in imgs}) == 1:
             return list(torch.chunk(self.feature(torch.cat(imgs, 0)), len(imgs), 0))
         return [self.feature(img) for img in imgs]
+
+    def extract_features_cl(self, imgs: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+        """Channels-last 16-bit feature maps [B,h,w,32] of all views: the HIP extractor (``feature_engine = "pscv"``,
+        default) or PyTorch-ROCm followed by a layout / precision conversion (``"torch"``)."""
+        imgs = list(imgs)
+        if self.feature_engine == "pscv":
+            if len({tuple(i.shape) for i in imgs}) == 1:
+                f = self.feature.forward_engine(torch.cat(imgs, 0), self.storage_dtype)
+                return list(torch.chunk(f, len(imgs), 0))
+            return [self.feature.forward_engine(img, self.storage_dtype) for img in imgs]
+        return [ops.to_channels_last(f, self.storage_dtype) for f in self.extract_features(imgs)]
 
     # -- hot path ---------------------------------------------------------------------------
     def build_cost_volume(self, ref_feature, src_features, ref_proj, src_projs, depth_values, cams=None):
@@ -181,8 +227,7 @@ class MVSNet(nn.Module):
         dv_ref = depth_values[:, reference_frame].to(torch.float32).contiguous()
 
         with torch.no_grad():
-            feats = self.extract_features(imgs)
-            feats_cl = [ops.to_channels_last(f, self.storage_dtype) for f in feats]
+            feats_cl = self.extract_features_cl(imgs)
             depth, conf = self.hot_path(feats_cl, proj, dv_ref, reference_frame, kwargs.get("taps"))
         return {"depth": depth, "depth_est_list": [depth, ], "depth_pair_list": [],
                 "photometric_confidence": conf}

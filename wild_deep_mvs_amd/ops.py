@@ -199,6 +199,89 @@ def fuse_finish(partial: torch.Tensor, wsum: torch.Tensor, dtype: torch.dtype) -
 
 
 # --------------------------------------------------------------------------------------------
+# 2-D feature extractor layers (the step before the path)
+# --------------------------------------------------------------------------------------------
+def pack_conv2d_weights(weight: torch.Tensor, c_in_padded: int, dtype: torch.dtype = torch.float16) -> np.ndarray:
+    """Host-side repack of a Conv2d weight [Co,Ci,k,k] (k = 3 or 5) into the MFMA fragment order of pscv_conv2d for
+    an input that carries ``c_in_padded`` >= Ci channels (uint16 bit patterns of ``dtype``)."""
+    w = np.ascontiguousarray(weight.detach().to("cpu", torch.float32).numpy())
+    if w.ndim != 4 or w.shape[2] != w.shape[3]:
+        raise ValueError(f"pscv: conv2d weights must be [Co,Ci,k,k], got {w.shape}")
+    c_out, c_in, ks = w.shape[0], w.shape[1], w.shape[2]
+    lib = L.lib()
+    code = _TORCH2PSCV.get(dtype, -1)
+    n = lib.pscv_pack_conv2d_weights(None, c_in, c_in_padded, c_out, ks, code, None)
+    if n < 0:
+        L.check(int(n), "pscv_pack_conv2d_weights")
+    packed = np.empty(n, dtype=np.uint16)
+    n2 = lib.pscv_pack_conv2d_weights(w.ctypes.data_as(C.c_void_p), c_in, c_in_padded, c_out, ks, code, packed.ctypes.data_as(C.c_void_p))
+    if n2 != n:
+        L.check(-1 if n2 >= 0 else int(n2), "pscv_pack_conv2d_weights")
+    return packed
+
+
+@dataclass
+class Conv2dLayer:
+    """One 2-D layer ready for the engine: packed 16-bit weights + fp32 epilogue vectors, on device."""
+    packed: torch.Tensor
+    dtype: torch.dtype
+    c_in: int        # channels of the input map (padded count)
+    c_out: int
+    ks: int
+    stride: int
+    neg_slope: float   # activation max(v, neg_slope * v): 0 = ReLU, 0.1 = LeakyReLU(0.1), 1 = none
+    scale: Optional[torch.Tensor] = None
+    bias: Optional[torch.Tensor] = None
+
+    @staticmethod
+    def build(weight: torch.Tensor, *, stride: int, device=None, bn: Optional[Sequence[torch.Tensor]] = None,
+              bn_eps: float = 1e-5, conv_bias: Optional[torch.Tensor] = None, relu: bool = False,
+              leaky: Optional[float] = None, dtype: torch.dtype = torch.float16) -> "Conv2dLayer":
+        """``bn`` = (gamma, beta, running_mean, running_var) folds an eval-mode BatchNorm2d into the epilogue;
+        ``relu`` / ``leaky`` (negative slope) select the fused activation."""
+        device = device if device is not None else weight.device
+        c_out, c_in, ks = int(weight.shape[0]), int(weight.shape[1]), int(weight.shape[2])
+        c_pad = (c_in + 7) // 8 * 8
+        packed = torch.from_numpy(pack_conv2d_weights(weight, c_pad, dtype).view(np.int16)).to(device)
+        scale = bias = None
+        if bn is not None:
+            gamma, beta, mean, var = [t.detach().to(device, torch.float32) for t in bn]
+            scale = gamma / torch.sqrt(var + bn_eps)
+            bias = beta - mean * scale
+            if conv_bias is not None:
+                bias = bias + scale * conv_bias.detach().to(device, torch.float32)
+            scale, bias = scale.contiguous(), bias.contiguous()
+        elif conv_bias is not None:
+            bias = conv_bias.detach().to(device, torch.float32).contiguous()
+        slope = float(leaky) if leaky is not None else (0.0 if relu else 1.0)
+        return Conv2dLayer(packed, dtype, c_pad, c_out, ks, int(stride), slope, scale, bias)
+
+
+def conv2d(x: torch.Tensor, layer: Conv2dLayer, *, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """x [B,H,W,C] in the layer's 16-bit format -> [B,Ho,Wo,c_out] in the same format or fp32 (pscv_conv2d)."""
+    _dev(x, layer.packed)
+    if x.dtype != layer.dtype or x.dim() != 4 or x.shape[3] != layer.c_in:
+        raise TypeError(f"pscv.conv2d: input must be a {layer.dtype} [B,H,W,{layer.c_in}] map, got {x.dtype} {tuple(x.shape)}")
+    out_dtype = layer.dtype if out_dtype is None else out_dtype
+    B, H, W, _ = x.shape
+    Ho, Wo = (H, W) if layer.stride == 1 else ((H - 1) // 2 + 1, (W - 1) // 2 + 1)
+    out = torch.empty((B, Ho, Wo, layer.c_out), dtype=out_dtype, device=x.device)
+    rc = _launch(f"conv2d[{layer.c_in}->{layer.c_out},k{layer.ks}s{layer.stride}]", lambda: L.lib().pscv_conv2d(
+        _p(x), _dt(x), _p(layer.packed), _p(layer.scale), _p(layer.bias), _p(out), _dt(out), B, H, W, layer.c_in,
+        layer.c_out, layer.ks, layer.stride, float(layer.neg_slope), _stream()))
+    L.check(rc, "pscv_conv2d")
+    return out
+
+
+def image_to_channels_last8(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """[B,3,H,W] image -> [B,H,W,8] in the storage dtype, channels 3-7 zero (the first layer's padded input)."""
+    B, c, H, W = x.shape
+    out = torch.zeros((B, H, W, 8), dtype=dtype, device=x.device)
+    out[..., :c] = x.permute(0, 2, 3, 1)
+    return out
+
+
+# --------------------------------------------------------------------------------------------
 # geometric-consistency filter (the step after the path)
 # --------------------------------------------------------------------------------------------
 def geo_filter_cams(K: torch.Tensor, R: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
