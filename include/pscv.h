@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PSCV_ABI_VERSION 1
+#define PSCV_ABI_VERSION 2
 
 /* storage dtypes */
 #define PSCV_F32 0
@@ -231,6 +231,75 @@ int pscv_softargmin(const void* logits, int logit_dtype, const float* depth, lon
                     float* out_depth, float* out_index, float* out_conf, float* out_entropy, float* out_prob,
                     float* out_partials, int conf_mode, float window, int index_offset, int B, int D, int h, int w,
                     void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Training path: what loss.backward() needs from the hot path when train.py drives the model
+ * (train.py:185-191, models/trainer.py:96-206).  The reference gets all of it from ATen autograd; here each piece
+ * is one entry point.  Forward in train() mode = pscv_warp_cost, pscv_conv3d without folded statistics
+ * (scale = bias = NULL, no ReLU), pscv_bn_stats, pscv_bn_act, pscv_softargmin.
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* number of floats of the `workspace` argument of pscv_bn_stats / pscv_bn_bwd_reduce */
+long pscv_train_workspace_floats(void);
+
+/*
+ * Per-channel batch statistics of a channels-last 16-bit volume: sums[0][c] = sum y, sums[1][c] = sum y^2 over all
+ * nvox voxels (BatchNorm3d in train(): models/MVSNet/module.py:41-58 normalise with the statistics of the batch).
+ * Two-phase, fixed summation order (bit-reproducible).  sums: device fp32 [2][C].  C in {8,16,32,64}.
+ */
+int pscv_bn_stats(const void* y, int dtype, long nvox, int C, float* workspace, float* sums, void* stream);
+
+/* out = [relu](y * scale + bias) + skip   (scale / bias fp32 [C] = the batch-statistics affine; skip may be NULL;
+ * `skip + relu(bn(deconv(x)))` of models/MVSNet/model.py:79-81). */
+int pscv_bn_act(const void* y, int dtype, long nvox, int C, const float* scale, const float* bias, int relu,
+                const void* skip, void* out, void* stream);
+
+/* BatchNorm(+ReLU) backward, pass 1: with z = y * scale + bias and dz = dact * [z > 0] (dz = dact when relu = 0),
+ * sums[0][c] = sum dz, sums[1][c] = sum dz * y. */
+int pscv_bn_bwd_reduce(const void* dact, const void* y, int dtype, long nvox, int C, const float* scale,
+                       const float* bias, int relu, float* workspace, float* sums, void* stream);
+
+/* BatchNorm(+ReLU) backward, pass 2: dy = ca[c] * dz + cb[c] * y + cc[c] (the caller folds gamma, 1/std, the batch
+ * mean and the two sums of pass 1 into the three per-channel coefficients). */
+int pscv_bn_bwd_apply(const void* dact, const void* y, int dtype, long nvox, int C, const float* scale,
+                      const float* bias, int relu, const float* ca, const float* cb, const float* cc, void* dy,
+                      void* stream);
+
+/*
+ * Backward of softmax over D + depth regression (models/MVSNet/model.py:207-209, module.py:174-178):
+ * d depth / d logit_d = p_d (depth_d - depth).  logits fp32 [B,D,h,w], depth planes as in pscv_softargmin,
+ * grad_depth fp32 [B,h,w]  ->  dlogits8 [B,D,h,w,8] in `dtype` with the gradient in channel 0 and zeros in
+ * channels 1-7 (the layout the 8-channel MFMA kernels read: the 1-channel `prob` head's backward runs on them).
+ */
+int pscv_softargmin_bwd(const float* logits, const float* depth, long depth_bstride, int depth_per_pixel,
+                        const float* grad_depth, void* dlogits8, int dtype, int B, int D, int h, int w, void* stream);
+
+/*
+ * Weight gradient of a 3x3x3 convolution, an MFMA contraction over voxels:
+ *     dw[a][b][t] = sum_{n,o} P[n,o,a] * Q[n, stride*o + t - 1, b]        (t = (tz,ty,tx), zero outside Q)
+ *   Conv3d weight [C_out,C_in,27]:           P = grad of the layer output (a = c_out), Q = layer input  (b = c_in)
+ *   ConvTranspose3d weight [C_in,C_out,27]:  P = layer input (a = c_in),  Q = grad of the layer output (b = c_out)
+ * P [B,Dp,Hp,Wp,p_cstride] read at channel offset p_coff; Q [B,stride*Dp,stride*Hp,stride*Wp,q_cstride] at q_coff;
+ * both in `dtype` (bf16 / fp16).  ca, cb multiples of 8 in [8,64].  workspace: device fp32,
+ * pscv_conv3d_wgrad_workspace(...) floats.  dw: device fp32 [ca][cb][27]; accumulate != 0 adds to it.
+ * Fixed summation order (bit-reproducible).
+ */
+long pscv_conv3d_wgrad_workspace(int B, int Dp, int Hp, int Wp, int ca, int cb, int stride);
+int pscv_conv3d_wgrad(const void* p, int p_cstride, int p_coff, int ca, const void* q, int q_cstride, int q_coff, int cb,
+                      int dtype, int B, int Dp, int Hp, int Wp, int stride, float* workspace, float* dw, int accumulate,
+                      void* stream);
+
+/*
+ * Backward of pscv_warp_cost with respect to the feature maps (the sampling grid carries no gradient in the
+ * reference: models/MVSNet/module.py:127).  Arguments as pscv_warp_cost; grad_out has the layout of that call's
+ * `out` in grad_dtype (the features' 16-bit format or fp32).  dref fp32 [B,h,w,C] (may be NULL for WARP_ONLY),
+ * dsrcs host array of n_src device fp32 [B,hs,ws,C], dtemp device fp32 [1] (SOFTMIN, may be NULL): all are
+ * ACCUMULATED into with float atomics, the caller zero-fills them.  C in {16, 32}.
+ */
+int pscv_warp_cost_bwd(const void* ref, const void* const* srcs, int n_src, const float* cams, const float* depth,
+                       long depth_bstride, int depth_per_pixel, int geom, int cost, float temp, const void* grad_out,
+                       float* dref, float* const* dsrcs, float* dtemp, int B, int C, int h, int w, int hs, int ws, int D,
+                       int in_dtype, int grad_dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -3,7 +3,9 @@
 Functional form: every network stage takes the reference's ``state_dict``
 (same key names as ``models/MVSNet/model.py``) instead of ``nn.Module`` objects,
 so the same weights drive the reference (golden generation), this oracle and the
-HIP engine.  fp32 throughout, eval-mode BatchNorm.
+HIP engine.  fp32 throughout; BatchNorm in eval mode by default, with the batch statistics
+of ``nn.BatchNorm*.train()`` when ``training=True`` (the reference under ``train.py``: gradients
+then come from ATen autograd through these same functions, exactly as in the reference).
 """
 from __future__ import annotations
 
@@ -129,58 +131,117 @@ def build_cost_volume(ref_fea, src_feas, ref_proj, src_projs, depth_values, aggr
 # --------------------------------------------------------------------------
 # conv blocks (functional)
 # --------------------------------------------------------------------------
-def _bn(x, sd: SD, prefix: str):
-    return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"],
-                        sd[prefix + ".weight"], sd[prefix + ".bias"], training=False, eps=BN_EPS)
+BN_MOMENTUM = 0.1  # nn.BatchNorm default
 
 
-def conv_bn_relu_3d(x, sd: SD, prefix: str, stride: int = 1):
-    """``ConvBnReLU3D`` reference ``models/MVSNet/module.py:41-48``."""
-    return F.relu(_bn(F.conv3d(x, sd[prefix + ".conv.weight"], None, stride=stride, padding=1), sd, prefix + ".bn"))
+class _StoreFn(torch.autograd.Function):
+    """Emulates a tensor that the engine keeps in 16-bit storage: the value is rounded on the way forward and its
+    gradient on the way back (the engine stores both in that format); arithmetic stays fp32."""
+
+    @staticmethod
+    def forward(ctx, x, dtype, round_grad):
+        ctx.dtype, ctx.round_grad = dtype, round_grad
+        return x.to(dtype).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g.to(ctx.dtype).to(g.dtype) if ctx.round_grad else g), None, None
 
 
-def deconv_bn_relu_3d(x, sd: SD, prefix: str, stride: int = 2, output_padding: int = 1):
+class _GradStoreFn(torch.autograd.Function):
+    """Value untouched (fp32 logits), gradient rounded to the 16-bit storage format."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.dtype = dtype
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dtype).to(g.dtype), None
+
+
+def stored(x: torch.Tensor, dtype: Optional[torch.dtype], round_grad: bool = True) -> torch.Tensor:
+    """Identity when ``dtype`` is None (the fp32 reference semantics); otherwise the 16-bit storage emulation used by
+    the tests to separate storage-precision effects from implementation errors."""
+    return x if dtype is None else _StoreFn.apply(x, dtype, round_grad)
+
+
+def _bn(x, sd: SD, prefix: str, training: bool = False, new_stats: Optional[dict] = None):
+    """eval: running statistics.  training: batch statistics (``nn.BatchNorm*.train()``); the running statistics
+    the module would hold after the step are written to ``new_stats`` (the state dict itself is not modified)."""
+    if not training:
+        return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"],
+                            sd[prefix + ".weight"], sd[prefix + ".bias"], training=False, eps=BN_EPS)
+    rm, rv = sd[prefix + ".running_mean"].detach().clone(), sd[prefix + ".running_var"].detach().clone()
+    y = F.batch_norm(x, rm, rv, sd[prefix + ".weight"], sd[prefix + ".bias"], training=True, momentum=BN_MOMENTUM, eps=BN_EPS)
+    if new_stats is not None:
+        new_stats[prefix + ".running_mean"], new_stats[prefix + ".running_var"] = rm, rv
+    return y
+
+
+def _w(sd: SD, key: str, store):
+    """Conv weight as the MFMA kernels see it under storage emulation (16-bit operands; the gradient stays fp32)."""
+    return stored(sd[key], store, round_grad=False)
+
+
+def conv_bn_relu_3d(x, sd: SD, prefix: str, stride: int = 1, training: bool = False, new_stats: Optional[dict] = None,
+                    store=None, skip=None):
+    """``ConvBnReLU3D`` reference ``models/MVSNet/module.py:41-48``.  (``store``: 16-bit storage emulation of the raw conv
+    output and of the block output; ``skip`` is added after the ReLU, before the block output is stored.)"""
+    y = stored(F.conv3d(x, _w(sd, prefix + ".conv.weight", store), None, stride=stride, padding=1), store)
+    out = F.relu(_bn(y, sd, prefix + ".bn", training, new_stats))
+    return stored(out if skip is None else skip + out, store)
+
+
+def deconv_bn_relu_3d(x, sd: SD, prefix: str, stride: int = 2, output_padding: int = 1, training: bool = False,
+                      new_stats: Optional[dict] = None, store=None, skip=None):
     """``Sequential(ConvTranspose3d(k3,p1), BatchNorm3d, ReLU)`` reference ``model.py:57-70``."""
-    y = F.conv_transpose3d(x, sd[prefix + ".0.weight"], None, stride=stride, padding=1, output_padding=output_padding)
-    return F.relu(_bn(y, sd, prefix + ".1"))
+    y = F.conv_transpose3d(x, _w(sd, prefix + ".0.weight", store), None, stride=stride, padding=1, output_padding=output_padding)
+    out = F.relu(_bn(stored(y, store), sd, prefix + ".1", training, new_stats))
+    return stored(out if skip is None else skip + out, store)
 
 
-def cost_reg_net(cost: torch.Tensor, sd: SD, prefix: str = "cost_regularization", taps: Optional[dict] = None):
+def cost_reg_net(cost: torch.Tensor, sd: SD, prefix: str = "cost_regularization", taps: Optional[dict] = None,
+                 training: bool = False, new_stats: Optional[dict] = None, store=None):
     """MVSNet ``CostRegNet.forward`` reference ``models/MVSNet/model.py:74-84``.
     [B,32,D,h,w] -> [B,1,D,h,w].  ``taps`` (optional dict) receives every layer output."""
     p = prefix + "."
-    c0 = conv_bn_relu_3d(cost, sd, p + "conv0")
-    c1 = conv_bn_relu_3d(c0, sd, p + "conv1", stride=2)
-    c2 = conv_bn_relu_3d(c1, sd, p + "conv2")
-    c3 = conv_bn_relu_3d(c2, sd, p + "conv3", stride=2)
-    c4 = conv_bn_relu_3d(c3, sd, p + "conv4")
-    c5 = conv_bn_relu_3d(c4, sd, p + "conv5", stride=2)
-    c6 = conv_bn_relu_3d(c5, sd, p + "conv6")
-    u7 = c4 + deconv_bn_relu_3d(c6, sd, p + "conv7")
-    u9 = c2 + deconv_bn_relu_3d(u7, sd, p + "conv9")
-    u11 = c0 + deconv_bn_relu_3d(u9, sd, p + "conv11")
-    logits = F.conv3d(u11, sd[p + "prob.weight"], sd[p + "prob.bias"], stride=1, padding=1)
+    kw = dict(training=training, new_stats=new_stats, store=store)
+    c0 = conv_bn_relu_3d(cost, sd, p + "conv0", **kw)
+    c1 = conv_bn_relu_3d(c0, sd, p + "conv1", stride=2, **kw)
+    c2 = conv_bn_relu_3d(c1, sd, p + "conv2", **kw)
+    c3 = conv_bn_relu_3d(c2, sd, p + "conv3", stride=2, **kw)
+    c4 = conv_bn_relu_3d(c3, sd, p + "conv4", **kw)
+    c5 = conv_bn_relu_3d(c4, sd, p + "conv5", stride=2, **kw)
+    c6 = conv_bn_relu_3d(c5, sd, p + "conv6", **kw)
+    u7 = deconv_bn_relu_3d(c6, sd, p + "conv7", skip=c4, **kw)
+    u9 = deconv_bn_relu_3d(u7, sd, p + "conv9", skip=c2, **kw)
+    u11 = deconv_bn_relu_3d(u9, sd, p + "conv11", skip=c0, **kw)
+    logits = F.conv3d(u11, _w(sd, p + "prob.weight", store), sd[p + "prob.bias"], stride=1, padding=1)
+    if store is not None:   # the engine hands d loss / d logits to the conv kernels as a 16-bit volume
+        logits = _GradStoreFn.apply(logits, store)
     if taps is not None:
         taps.update(conv0=c0, conv1=c1, conv2=c2, conv3=c3, conv4=c4, conv5=c5, conv6=c6, up7=u7, up9=u9, up11=u11,
                     logits=logits)
     return logits
 
 
-def conv_bn_relu_2d(x, sd: SD, prefix: str, stride: int, pad: int):
-    return F.relu(_bn(F.conv2d(x, sd[prefix + ".conv.weight"], None, stride=stride, padding=pad), sd, prefix + ".bn"))
+def conv_bn_relu_2d(x, sd: SD, prefix: str, stride: int, pad: int, training: bool = False):
+    return F.relu(_bn(F.conv2d(x, sd[prefix + ".conv.weight"], None, stride=stride, padding=pad), sd, prefix + ".bn", training))
 
 
-def feature_net(img: torch.Tensor, sd: SD, prefix: str = "feature") -> torch.Tensor:
+def feature_net(img: torch.Tensor, sd: SD, prefix: str = "feature", training: bool = False) -> torch.Tensor:
     """2-D ``FeatureNet`` reference ``models/MVSNet/model.py:21-41`` (upstream of the hot
     path; restated so that the full ``forward()`` can be checked).  [B,3,H,W] -> [B,32,H/4,W/4]."""
     p = prefix + "."
-    x = conv_bn_relu_2d(img, sd, p + "conv0", 1, 1)
-    x = conv_bn_relu_2d(x, sd, p + "conv1", 1, 1)
-    x = conv_bn_relu_2d(x, sd, p + "conv2", 2, 2)
-    x = conv_bn_relu_2d(x, sd, p + "conv3", 1, 1)
-    x = conv_bn_relu_2d(x, sd, p + "conv4", 1, 1)
-    x = conv_bn_relu_2d(x, sd, p + "conv5", 2, 2)
-    x = conv_bn_relu_2d(x, sd, p + "conv6", 1, 1)
+    x = conv_bn_relu_2d(img, sd, p + "conv0", 1, 1, training)
+    x = conv_bn_relu_2d(x, sd, p + "conv1", 1, 1, training)
+    x = conv_bn_relu_2d(x, sd, p + "conv2", 2, 2, training)
+    x = conv_bn_relu_2d(x, sd, p + "conv3", 1, 1, training)
+    x = conv_bn_relu_2d(x, sd, p + "conv4", 1, 1, training)
+    x = conv_bn_relu_2d(x, sd, p + "conv5", 2, 2, training)
+    x = conv_bn_relu_2d(x, sd, p + "conv6", 1, 1, training)
     return F.conv2d(x, sd[p + "feature.weight"], sd[p + "feature.bias"], stride=1, padding=1)
 
 
@@ -216,7 +277,8 @@ def regress(logits: torch.Tensor, depth_values: torch.Tensor):
 # whole path
 # --------------------------------------------------------------------------
 def hot_path(features: Sequence[torch.Tensor], proj: torch.Tensor, depth_values: torch.Tensor, sd: SD,
-             aggregation: str = "variance", reference_frame: int = 0, taps: Optional[dict] = None):
+             aggregation: str = "variance", reference_frame: int = 0, taps: Optional[dict] = None, training: bool = False,
+             new_stats: Optional[dict] = None, store=None):
     """Features + cameras -> depth, confidence (the timed region of bench.py).
 
     ``features``: V tensors [B,32,h,w]; ``proj`` [B,V,4,4]; ``depth_values`` [B,V,D].
@@ -228,7 +290,8 @@ def hot_path(features: Sequence[torch.Tensor], proj: torch.Tensor, depth_values:
     src_projs = [proj[:, i] for i in range(V) if i != reference_frame]
     dv = depth_values[:, reference_frame]
     cost = build_cost_volume(ref_fea, src_feas, ref_proj, src_projs, dv, aggregation, sd.get("temp"))
-    logits = cost_reg_net(cost, sd, taps=taps).squeeze(1)
+    cost = stored(cost, store)
+    logits = cost_reg_net(cost, sd, taps=taps, training=training, new_stats=new_stats, store=store).squeeze(1)
     prob, depth, conf = regress(logits, dv)
     if taps is not None:
         taps.update(cost_volume=cost, prob=prob)
@@ -236,13 +299,14 @@ def hot_path(features: Sequence[torch.Tensor], proj: torch.Tensor, depth_values:
 
 
 def forward(imgs, K, R, t, depth_min, depth_max, sd: SD, num_depth: int = 192, aggregation: str = "variance",
-            reference_frame: int = 0, taps: Optional[dict] = None) -> Dict[str, object]:
+            reference_frame: int = 0, taps: Optional[dict] = None, training: bool = False,
+            new_stats: Optional[dict] = None, store=None) -> Dict[str, object]:
     """Full ``MVSNet.forward`` reference ``models/MVSNet/model.py:178-218``."""
     if isinstance(imgs, torch.Tensor):
         imgs = list(torch.unbind(imgs, 1))
     proj, depth_values = mvsnet_cameras(K, R, t, depth_min, depth_max, num_depth)
-    feats = [feature_net(im, sd) for im in imgs]
+    feats = [stored(feature_net(im, sd, training=training), store, round_grad=False) for im in imgs]   # per view, model.py:101-107
     if taps is not None:
         taps.update(features=feats, proj=proj, depth_values=depth_values)
-    depth, conf = hot_path(feats, proj, depth_values, sd, aggregation, reference_frame, taps)
+    depth, conf = hot_path(feats, proj, depth_values, sd, aggregation, reference_frame, taps, training, new_stats, store)
     return {"depth": depth, "depth_est_list": [depth], "depth_pair_list": [], "photometric_confidence": conf}

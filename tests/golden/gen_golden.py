@@ -12,7 +12,7 @@ be re-created from ``wild_deep_mvs_amd.synthetic`` (the fixture records the
 generator arguments instead); every stage boundary of the reference's hot path is
 stored as fp32 arrays (tiny problem sizes; per-view warped volumes keep 3 planes).
 
-Usage:  python tests/golden/gen_golden.py [--only mvsnet|mvsnet_s|vis|cvp|filter]
+Usage:  python tests/golden/gen_golden.py [--only mvsnet|mvsnet_s|mvsnet_train|mvsnet_s_train|vis|cvp|filter]
 """
 from __future__ import annotations
 
@@ -120,6 +120,43 @@ def gen_mvsnet(aggregation: str, tag: str, *, H=64, W=96, V=3, D=16, seed=0, beh
          logits=np32(logits),
          depth=np32(out["depth"]), photometric_confidence=np32(out["photometric_confidence"]),
          depth_per_pixel=np32(dpp), warped_per_pixel=np32(warped_pp[:, :, PLANES]))
+
+
+def gen_mvsnet_train(aggregation: str, tag: str, *, H=64, W=96, V=3, D=16, seed=0, scene_seed=0, B=2):
+    """One training step of the reference in train() mode: forward with batch-statistics BatchNorm, the supervised L1 loss
+    of models/trainer.py:163-167, backward.  Stores depth, loss, every parameter gradient's norm, full gradients of a
+    subset, and the BatchNorm running statistics after the step."""
+    sys.path.insert(0, REPO)
+    from wild_deep_mvs_amd import synthetic
+    from models.MVSNet.model import MVSNet  # reference
+
+    torch.manual_seed(0)
+    net = MVSNet(aggregation)
+    net.num_depth = D
+    sd = synthetic.train_state_dict("mvsnet", synthetic.template_of(net), seed=seed)
+    net.load_state_dict(sd, strict=True)
+    net.train()
+    scene = synthetic.make_scene(B, V, H, W, seed=scene_seed)
+    out = net(scene["imgs"], scene["K"], scene["R"], scene["t"], scene["depth_min"], scene["depth_max"])
+    depth = out["depth"]
+    gt, mask = synthetic.train_target(scene, depth.shape[1], depth.shape[2])
+    loss = synthetic.supervised_loss(depth, gt, mask, scene["depth_min"], scene["depth_max"])
+    loss.backward()
+    grads = {k: p.grad for k, p in net.named_parameters()}
+    norms = {k: float(g.norm()) for k, g in grads.items()}
+    keep = [k for k in grads if k.startswith("cost_regularization.") and (".bn." in k or ".1." in k or "prob" in k or "conv0." in k
+                                                                        or "conv1." in k or "conv6." in k or "conv11." in k)]
+    keep += ["feature.conv0.conv.weight", "feature.feature.weight", "feature.feature.bias"] + (["temp"] if "temp" in grads else [])
+    stats = {k: v for k, v in net.state_dict().items() if "running_" in k and k.startswith("cost_regularization.")}
+    print(f"[{tag}] loss {float(loss):.5f}, depth range {depth.min():.3f}..{depth.max():.3f}, "
+          f"|g conv0| {norms['cost_regularization.conv0.conv.weight']:.3e}, |g feature.conv0| {norms['feature.conv0.conv.weight']:.3e}")
+    arrays = {"meta": np.array([H, W, V, D, seed, scene_seed, B], dtype=np.int64), "depth": np32(depth), "loss": np.float32(float(loss)),
+              "norm_keys": np.array(list(norms.keys())), "norm_vals": np.array(list(norms.values()), dtype=np.float64)}
+    for k in keep:
+        arrays["grad:" + k] = np32(grads[k])
+    for k, v in stats.items():
+        arrays["stat:" + k] = np32(v)
+    save(f"{tag}.npz", **arrays)
 
 
 def gen_vis(tag, *, H=64, W=96, V=3, depth_nums=(16, 8, 4), interval_scales=(8.0, 4.0, 2.0), seed=0, scene_seed=0):
@@ -327,6 +364,8 @@ def main():
         "mvsnet": lambda: gen_mvsnet("variance", "mvsnet_tiny"),
         "mvsnet_behind": lambda: gen_mvsnet("variance", "mvsnet_behind", V=4, behind_view=2, scene_seed=5),
         "mvsnet_s": lambda: gen_mvsnet("softmin", "mvsnet_s_tiny", seed=1),
+        "mvsnet_train": lambda: gen_mvsnet_train("variance", "mvsnet_train"),
+        "mvsnet_s_train": lambda: gen_mvsnet_train("softmin", "mvsnet_s_train", seed=1),
         "vis": lambda: gen_vis("vis_tiny"),
         "cvp": lambda: gen_cvp("cvp_tiny"),
         "keys": gen_state_dict_keys,

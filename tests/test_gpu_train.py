@@ -1,0 +1,363 @@
+"""Training path on the GPU, through the C ABI: every backward kernel against ATen autograd of the same op
+on the same (16-bit rounded) operands, then one full train() step of the MVSNet mirror against the CPU oracle's
+autograd (which tests/test_oracle_train.py pins to a training step of the reference itself).
+
+Tolerances: the engine stores activations and gradients in 16 bits (bf16 by default in training) and accumulates in
+fp32.  Kernel-level checks feed both sides identical rounded operands, so they are tight (fp32 accumulation order only);
+end-to-end gradients carry ~a dozen 16-bit roundings each way and are compared in relative L2 per tensor."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _util import check_close, load_golden, t
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.bfloat16, torch.float16]
+
+
+def _cl(x, dtype):   # NCDHW fp32 -> channels-last 16-bit on the GPU
+    from wild_deep_mvs_amd import ops
+    return ops.to_channels_last(x.cuda(), dtype)
+
+
+def _cf(x):          # channels-last -> NCDHW fp32 on the CPU
+    from wild_deep_mvs_amd import ops
+    return ops.to_channels_first(x.detach()).float().cpu()
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("C", [8, 16, 32, 64])
+def test_bn_stats_and_act(C, dtype):
+    from wild_deep_mvs_amd import ops
+    g = torch.Generator().manual_seed(C)
+    x = (torch.randn(2, C, 6, 10, 12, generator=g) * 2 + 0.5).to(dtype).float()
+    skip = torch.randn(2, C, 6, 10, 12, generator=g).to(dtype).float()
+    sums = ops.bn_stats(_cl(x, dtype)).cpu()
+    check_close("sum", sums[0], x.sum((0, 2, 3, 4)), rel_l2=1e-5)
+    check_close("sumsq", sums[1], (x * x).sum((0, 2, 3, 4)), rel_l2=1e-5)
+    sc, bi = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    for relu in (True, False):
+        z = x * sc.view(1, C, 1, 1, 1) + bi.view(1, C, 1, 1, 1)
+        ref = (F.relu(z) if relu else z) + skip
+        got = ops.bn_act(_cl(x, dtype), sc.cuda(), bi.cuda(), relu=relu, skip=_cl(skip, dtype))
+        check_close(f"bn_act relu={relu}", _cf(got), ref.to(dtype).float(), rel_l2=3e-3 if dtype == torch.bfloat16 else 4e-4)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("C,relu", [(8, True), (16, True), (32, False), (64, True)])
+def test_bn_backward(C, relu, dtype):
+    """pscv_bn_bwd_reduce + pscv_bn_bwd_apply (+ the host's [C]-vector coefficient math) == autograd of
+    batch_norm(training=True) -> relu on the same stored y."""
+    from wild_deep_mvs_amd import ops
+    g = torch.Generator().manual_seed(7 + C)
+    y = (torch.randn(2, C, 4, 6, 16, generator=g) * 1.5 + 0.3).to(dtype).float().requires_grad_(True)
+    dact = torch.randn(2, C, 4, 6, 16, generator=g).to(dtype).float()
+    gamma = (torch.rand(C, generator=g) + 0.5).requires_grad_(True)
+    beta = (torch.randn(C, generator=g) * 0.3).requires_grad_(True)
+    z = F.batch_norm(y, None, None, gamma, beta, training=True, eps=1e-5)
+    out = F.relu(z) if relu else z
+    out.backward(dact)
+    n = y.numel() // C
+    mean = y.detach().mean((0, 2, 3, 4))
+    var = y.detach().var((0, 2, 3, 4), unbiased=False)
+    invstd = torch.rsqrt(var + 1e-5)
+    scale = (gamma.detach() * invstd).cuda()
+    bias = (beta.detach() - mean * gamma.detach() * invstd).cuda()
+    ycl, dcl = _cl(y.detach(), dtype), _cl(dact, dtype)
+    s = ops.bn_bwd_reduce(dcl, ycl, scale, bias, relu=relu).cpu()
+    s1, s2 = s[0], invstd * (s[1] - mean * s[0])
+    check_close("dbeta", s1, beta.grad, rel_l2=1e-4)
+    check_close("dgamma", s2, gamma.grad, rel_l2=1e-4)
+    k = gamma.detach() * invstd
+    ca, cb, cc = k, -k * invstd * s2 / n, -k * s1 / n + k * invstd * mean * s2 / n
+    dy = ops.bn_bwd_apply(dcl, ycl, scale, bias, ca.cuda(), cb.cuda(), cc.cuda(), relu=relu)
+    check_close("dy", _cf(dy), y.grad, rel_l2=6e-3 if dtype == torch.bfloat16 else 1e-3)
+
+
+@pytest.mark.parametrize("per_pixel", [False, True])
+def test_softargmin_backward(per_pixel):
+    from wild_deep_mvs_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, D, h, w = 2, 24, 10, 14
+    logits = (torch.randn(B, D, h, w, generator=g) * 2).requires_grad_(True)
+    depth = (torch.rand(B, D, h, w, generator=g) + torch.arange(D).view(1, D, 1, 1)) if per_pixel else \
+        (torch.arange(D).float().view(1, D) * 0.3 + torch.tensor([[2.0], [3.0]]))
+    dv = depth if per_pixel else depth.view(B, D, 1, 1)
+    d = (F.softmax(logits, 1) * dv).sum(1)
+    gd = torch.randn(B, h, w, generator=g)
+    d.backward(gd)
+    got = ops.softargmin_bwd(logits.detach().cuda(), depth.contiguous().cuda(), gd.cuda(), torch.float16).float().cpu()
+    assert float(got[..., 1:].abs().max()) == 0.0
+    check_close("dlogits", got[..., 0], logits.grad, rel_l2=1e-3)
+
+
+WG = [  # (c_out_or_a, c_in_or_b, stride, transposed)   every block shape of the MVSNet / CVP / Vis regularisers
+    (8, 32, 1, False), (16, 8, 2, False), (16, 16, 1, False), (32, 16, 2, False), (32, 32, 1, False), (64, 32, 2, False),
+    (64, 64, 1, False), (64, 32, 2, True), (32, 16, 2, True), (16, 8, 2, True), (8, 8, 1, False), (64, 32, 1, True),
+    (8, 16, 1, False),
+]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("ca,cb,stride,transposed", WG)
+def test_conv3d_wgrad_and_dgrad(ca, cb, stride, transposed, dtype):
+    """pscv_conv3d_wgrad == autograd's weight gradient; the adjoint layer of training._dgrad_layer on the forward conv
+    kernels == autograd's input gradient.  Odd tile remainders on purpose (W = 20: partial 16-wide tiles)."""
+    from wild_deep_mvs_amd import ops, training as T
+    g = torch.Generator().manual_seed(ca * 100 + cb + stride)
+    B, Do, Ho, Wo = 2, 4, 6, 20          # grid of the conv OUTPUT (Conv3d) / INPUT (ConvTranspose3d) = the coarse grid
+    fine = (B, 0, stride * Do, stride * Ho, stride * Wo)
+    if not transposed:                   # Conv3d weight [Co=ca, Ci=cb]
+        w = (torch.randn(ca, cb, 3, 3, 3, generator=g) * 0.1).to(dtype).float().requires_grad_(True)
+        x = torch.randn(B, cb, *fine[2:], generator=g).to(dtype).float().requires_grad_(True)
+        y = F.conv3d(x, w, None, stride=stride, padding=1)
+        dy = torch.randn(y.shape, generator=g).to(dtype).float()
+        y.backward(dy)
+        dw = ops.conv3d_wgrad(_cl(dy, dtype), _cl(x.detach(), dtype), ca=ca, cb=cb, stride=stride)
+        blk = T.Block("b", "x", w.detach().cuda(), stride=stride, transposed=False)
+    else:                                # ConvTranspose3d weight [Ci=ca, Co=cb]
+        w = (torch.randn(ca, cb, 3, 3, 3, generator=g) * 0.1).to(dtype).float().requires_grad_(True)
+        x = torch.randn(B, ca, Do, Ho, Wo, generator=g).to(dtype).float().requires_grad_(True)
+        y = F.conv_transpose3d(x, w, None, stride=stride, padding=1, output_padding=stride - 1)
+        dy = torch.randn(y.shape, generator=g).to(dtype).float()
+        y.backward(dy)
+        dw = ops.conv3d_wgrad(_cl(x.detach(), dtype), _cl(dy, dtype), ca=ca, cb=cb, stride=stride)
+        blk = T.Block("b", "x", w.detach().cuda(), stride=stride, transposed=True)
+    check_close("dW", dw.cpu(), w.grad, rel_l2=2e-5)
+    lay = T._dgrad_layer(blk, dtype, "cuda")
+    dx = ops.conv3d(_cl(dy, dtype), lay, out_dtype=torch.float32)
+    check_close("dX", _cf(dx), x.grad, rel_l2=2e-5)
+
+
+def _sweep_case(C, V, h, w, D, seed, behind=False):
+    from wild_deep_mvs_amd import synthetic
+    scene = synthetic.make_scene(1, V, 4 * h, 4 * w, seed=seed, behind_view=1 if behind else -1)
+    from oracle import mvsnet as O
+    proj, dv = O.mvsnet_cameras(scene["K"], scene["R"], scene["t"], scene["depth_min"], scene["depth_max"], D)
+    g = torch.Generator().manual_seed(seed + 1)
+    feats = [torch.randn(1, C, h, w, generator=g) * 0.5 for _ in range(V)]
+    return proj, dv[:, 0].contiguous(), feats
+
+
+@pytest.mark.parametrize("cost,C", [("variance", 32), ("variance_cvp", 16), ("softmin", 32), ("warp_only", 32)])
+def test_warp_cost_backward_fp32(cost, C):
+    """pscv_warp_cost_bwd with fp32 features / gradients == autograd through the oracle's grid_sample + cost statistic
+    (zero-padded border taps, a camera with points behind it, softmin's temperature gradient)."""
+    from wild_deep_mvs_amd import ops, _lib as L
+    from oracle import mvsnet as O
+    V, h, w, D = 4, 16, 24, 8
+    proj, dv, feats = _sweep_case(C, V, h, w, D, seed=2, behind=True)
+    feats = [f.requires_grad_(True) for f in feats]
+    temp = torch.tensor([0.7], requires_grad=True)
+    warped = [O.homo_warping(feats[i], proj[:, i], proj[:, 0], dv, (h, w)) for i in range(1, V)]
+    if cost == "variance":
+        vol, mode = O.variance_cost(feats[0], warped), L.COST_VARIANCE
+    elif cost == "variance_cvp":
+        N = V
+        s = feats[0].unsqueeze(2) + sum(warped)
+        sq = feats[0].unsqueeze(2) ** 2 + sum(w_ ** 2 for w_ in warped)
+        vol, mode = sq / N - (s / N) ** 2, L.COST_VARIANCE_CVP
+    elif cost == "softmin":
+        vol, mode = O.softmin_cost(feats[0], warped, temp), L.COST_SOFTMIN
+    else:
+        vol, mode = torch.stack(warped), L.COST_WARP_ONLY
+    gen = torch.Generator().manual_seed(9)
+    gvol = torch.randn(vol.shape, generator=gen)
+    vol.backward(gvol)
+    cl = lambda x: ops.to_channels_last(x.detach().cuda(), torch.float32)
+    cams = ops.proj_cams_device(proj.cuda().contiguous(), 0)
+    if mode == L.COST_WARP_ONLY:
+        g_cl = torch.stack([ops.to_channels_last(gv.cuda(), torch.float32) for gv in gvol])
+    else:
+        g_cl = ops.to_channels_last(gvol.cuda(), torch.float32)
+    dref, dsrcs, dtemp = ops.warp_cost_bwd(None if mode == L.COST_WARP_ONLY else cl(feats[0]), [cl(f) for f in feats[1:]], cams,
+                                           dv.cuda(), g_cl, geom=L.GEOM_PROJ, cost=mode, temp=0.7, ref_hw=(h, w),
+                                           want_dtemp=(mode == L.COST_SOFTMIN))
+    for i in range(1, V):
+        check_close(f"d src{i}", dsrcs[i - 1].permute(0, 3, 1, 2).cpu(), feats[i].grad, rel_l2=2e-4)
+    if mode != L.COST_WARP_ONLY:
+        check_close("d ref", dref.permute(0, 3, 1, 2).cpu(), feats[0].grad, rel_l2=2e-4)
+    if mode == L.COST_SOFTMIN:
+        check_close("d temp", dtemp.cpu(), temp.grad, rel_l2=1e-3)
+
+
+def _train_step_engine(agg, H, W, V, D, seed, scene_seed, B, dtype):
+    from wild_deep_mvs_amd import synthetic
+    from wild_deep_mvs_amd.models.MVSNet.model import MVSNet
+    net = MVSNet(agg)
+    net.load_state_dict(synthetic.train_state_dict("mvsnet", synthetic.template_of(net), seed=seed))
+    net = net.cuda().train()
+    net.num_depth = D
+    net.train_storage_dtype = dtype
+    scene = synthetic.make_scene(B, V, H, W, seed=scene_seed)
+    out = net(*[scene[k].cuda() for k in ("imgs", "K", "R", "t", "depth_min", "depth_max")])
+    depth = out["depth"]
+    assert depth.requires_grad and not out["photometric_confidence"].requires_grad
+    gt, mask = synthetic.train_target(scene, depth.shape[1], depth.shape[2])
+    loss = synthetic.supervised_loss(depth, gt.cuda(), mask.cuda(), scene["depth_min"].cuda(), scene["depth_max"].cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    return net, depth.detach().cpu(), float(loss)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_regress_fn_blockwise_against_autograd(dtype):
+    """training.RegressFn (train()-mode U-Net + softmax regression, forward AND backward on the engine), checked block
+    by block: the engine records every block's tensors (training.TRACE) and each block is replayed through ATen autograd
+    on exactly those tensors -- forward (conv -> batch-statistics BN -> ReLU -> + skip), then backward from the recorded
+    upstream gradient: d weight, d gamma, d beta, d input (including the gradient that arrived over a skip connection).
+    A random-weight BatchNorm net amplifies a 1-ulp difference ~3x per layer (measured), so end-to-end comparisons only
+    see storage noise; per-block comparisons on shared inputs are sharp and cover the whole wiring of the executor."""
+    from wild_deep_mvs_amd import ops, synthetic, training as T
+    from wild_deep_mvs_amd.models.MVSNet.model import MVSNet
+    net = MVSNet("variance")
+    net.load_state_dict(synthetic.train_state_dict("mvsnet", synthetic.template_of(net), seed=3))
+    net = net.cuda().train()
+    reg = net.cost_regularization
+    gen = torch.Generator().manual_seed(5)
+    B, D, h, w = 2, 16, 24, 32
+    cost = (torch.rand(B, 32, D, h, w, generator=gen) * 0.5).to(dtype)
+    dv = torch.linspace(2.0, 6.0, D).view(1, D).repeat(B, 1).contiguous()
+    gd = torch.randn(B, h, w, generator=gen)
+    cost_cl = ops.to_channels_last(cost.cuda(), dtype).requires_grad_(True)
+    blocks = reg.train_blocks()
+    T.TRACE = {}
+    try:
+        depth, conf = T.RegressFn.apply(blocks, dv.cuda(), dtype, cost_cl, *T.RegressFn.block_params(blocks))
+        (depth * gd.cuda()).sum().backward()
+        torch.cuda.synchronize()
+        tr = T.TRACE
+    finally:
+        T.TRACE = None
+    bf = dtype == torch.bfloat16
+    q = lambda x: x.to(dtype).float()
+    for b in blocks[:-1]:
+        r = tr[b.name]
+        x = _cf(r["x"]).requires_grad_(True)
+        wq = q(b.weight.detach().cpu()).requires_grad_(True)
+        gamma = b.bn.weight.detach().cpu().clone().requires_grad_(True)
+        beta = b.bn.bias.detach().cpu().clone().requires_grad_(True)
+        if b.transposed:
+            y = F.conv_transpose3d(x, wq, None, stride=b.stride, padding=1, output_padding=b.stride - 1)
+        else:
+            y = F.conv3d(x, wq, None, stride=b.stride, padding=1)
+        check_close(f"{b.name} raw conv", _cf(r["y"]), q(y.detach()), rel_l2=1e-4)
+        # BN + ReLU (+ skip) on the ENGINE's stored y, so that the mask and the statistics are shared
+        ye = _cf(r["y"]).requires_grad_(True)
+        z = F.relu(F.batch_norm(ye, None, None, gamma, beta, training=True, eps=b.bn.eps))
+        act = z if r["skip"] is None else z + _cf(r["skip"])
+        check_close(f"{b.name} act", _cf(r["act"]), q(act.detach()), rel_l2=2e-4)
+        dact = _cf(r["dact"])
+        act.backward(dact)
+        check_close(f"{b.name} d gamma", r["dgamma"].cpu(), gamma.grad, rel_l2=2e-4)
+        check_close(f"{b.name} d beta", r["dbeta"].cpu(), beta.grad, rel_l2=2e-4)
+        check_close(f"{b.name} dy", _cf(r["dy"]), q(ye.grad), rel_l2=2e-3 if bf else 3e-4)
+        # conv backward from the ENGINE's stored dy
+        y.backward(_cf(r["dy"]))
+        check_close(f"{b.name} d weight", r["dw"].cpu(), wq.grad, rel_l2=1e-4)
+        dx = x.grad if r["dx_prev"] is None else x.grad + _cf(r["dx_prev"])
+        check_close(f"{b.name} d input", _cf(r["dx"]), q(dx), rel_l2=2e-3 if bf else 3e-4)
+        if b.skip:   # the gradient handed to the skip source is the block's upstream gradient itself
+            assert tr[b.skip]["dact"] is not None
+    # head: 1-channel conv with bias -> softmax -> regression
+    r = tr["prob"]
+    head = blocks[-1]
+    x = _cf(r["x"]).requires_grad_(True)
+    wq = q(head.weight.detach().cpu()).requires_grad_(True)
+    bias = head.conv_bias.detach().cpu().clone().requires_grad_(True)
+    logits = F.conv3d(x, wq, bias, padding=1).squeeze(1)
+    check_close("logits", r["logits"].cpu(), logits.detach(), rel_l2=1e-5)
+    le = r["logits"].cpu().clone().requires_grad_(True)
+    ((F.softmax(le, 1) * dv.view(B, D, 1, 1)).sum(1) * gd).sum().backward()
+    check_close("d logits", r["dl8"][..., 0].float().cpu(), q(le.grad), rel_l2=2e-3 if bf else 3e-4)
+    logits.backward(r["dl8"][..., 0].float().cpu())
+    check_close("prob d weight", r["dw"].cpu(), wq.grad, rel_l2=1e-4)
+    check_close("prob d bias", r["dbias"].cpu(), bias.grad, max_abs=1e-4 * float(wq.grad.abs().max()) + 1e-6)
+    check_close("prob d input", _cf(r["dx"]), q(x.grad), rel_l2=2e-3 if bf else 3e-4)
+    check_close("d cost (returned by autograd)", _cf(cost_cl.grad), _cf(tr["conv0"]["dx"]), max_abs=0.0)
+    for blk in blocks:   # every parameter received the recorded gradient
+        assert torch.equal(blk.weight.grad, tr[blk.name]["dw"])
+
+
+def _grad_report(tag, net, o_grads):
+    """Per-tensor relative L2 (against the tensor's own norm, floored at 1e-3 of the largest gradient tensor: a gradient
+    that is zero by symmetry -- prob.bias under the softmax -- has no relative error) and the cosine of the whole vector."""
+    floor = 1e-3 * max(float(g.norm()) for g in o_grads.values())
+    worst, rows, dot, n1, n2 = 0.0, [], 0.0, 0.0, 0.0
+    for k, p in net.named_parameters():
+        assert p.grad is not None, f"no gradient for {k}"
+        got, ref = p.grad.detach().float().cpu(), o_grads[k].float()
+        assert torch.isfinite(got).all(), k
+        rel = float((got - ref).norm() / max(float(ref.norm()), floor))
+        rows.append((k, rel))
+        worst = max(worst, rel)
+        dot += float((got * ref).sum()); n1 += float((got * got).sum()); n2 += float((ref * ref).sum())
+    cos = dot / (n1 ** 0.5 * n2 ** 0.5)
+    print(f"[train parity] {tag}: worst per-tensor rel-L2 {worst:.3e} ({max(rows, key=lambda r: r[1])[0]}), cosine {cos:.6f}")
+    return worst, cos, rows
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("fname,agg", [("mvsnet_train.npz", "variance"), ("mvsnet_s_train.npz", "softmin")])
+def test_mvsnet_train_step(fname, agg, dtype):
+    """One full training step of the MVSNet mirror (forward in train() mode + loss.backward()).
+
+    (1) Against the oracle's autograd with the engine's 16-bit storage emulated.  Unlike the U-Net-only test above the two
+        sides do not see identical inputs here (the GPU 2-D extractor and the fp32 sample coordinates differ at the 1e-6
+        level and the variance's cancellation lifts that to the storage ulp), so they are two realisations of the same
+        storage noise: bounds sit at the noise level.
+    (2) Against the plain fp32 oracle (pinned to the reference's own step by tests/test_oracle_train.py) and the
+        reference golden: depth within the path's bar; gradients reported and bounded by the cosine of the full gradient
+        vector -- at this fixture size (12 voxels per channel and image at the coarsest level, logits std ~2.7) the
+        softmax Jacobian amplifies storage noise; the U-Net-only test shows that is precision, not arithmetic."""
+    from test_oracle_train import oracle_train_step
+    g = load_golden(fname)
+    H, W, V, D, seed, scene_seed, B = [int(x) for x in g["meta"]]
+    net, depth, loss = _train_step_engine(agg, H, W, V, D, seed, scene_seed, B, dtype)
+    bf = dtype == torch.bfloat16
+    # (1) storage-emulated oracle
+    e_depth, e_loss, e_grads, e_stats = oracle_train_step(agg, H, W, V, D, seed, scene_seed, B, store=dtype)
+    check_close("depth vs storage-emulated oracle", depth, e_depth, rel_l1=4e-3 if bf else 6e-4)
+    worst, cos, rows = _grad_report(f"{agg} {dtype} vs storage-emulated oracle", net, e_grads)
+    assert cos >= (0.93 if bf else 0.99), (cos, rows)
+    sd = net.state_dict()
+    for k, ref in e_stats.items():
+        check_close(f"stat {k}", sd[k].cpu(), ref, rel_l2=2e-2 if bf else 3e-3)
+    assert int(sd["cost_regularization.conv0.bn.num_batches_tracked"]) == 2   # the fixture starts at 1
+    # (2) fp32 oracle / reference golden
+    o_depth, o_loss, o_grads, o_stats = oracle_train_step(agg, H, W, V, D, seed, scene_seed, B)
+    check_close("depth vs oracle", depth, o_depth, rel_l1=4e-3 if bf else 6e-4)
+    check_close("depth vs reference golden", depth, t(g["depth"]), rel_l1=4e-3 if bf else 6e-4)
+    assert abs(loss - o_loss) <= (2e-2 if bf else 3e-3) * abs(o_loss), (loss, o_loss)
+    worst, cos, rows = _grad_report(f"{agg} {dtype} vs fp32 oracle", net, o_grads)
+    assert cos >= (0.93 if bf else 0.99), (cos, rows)
+
+
+def test_train_step_then_eval_and_optimizer():
+    """A few Adam steps through the engine lower the loss, and the model still runs in eval() afterwards (packed eval
+    weights are rebuilt from the updated parameters)."""
+    from wild_deep_mvs_amd import synthetic
+    from wild_deep_mvs_amd.models.MVSNet.model import MVSNet
+    net = MVSNet("variance")
+    net.load_state_dict(synthetic.train_state_dict("mvsnet", synthetic.template_of(net), seed=0))
+    net = net.cuda().train()
+    net.num_depth = 16
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    scene = {k: v.cuda() for k, v in synthetic.make_scene(1, 3, 64, 96, seed=0).items() if isinstance(v, torch.Tensor)}
+    gt, mask = synthetic.train_target({k: v.cpu() for k, v in scene.items()}, 16, 24)
+    losses = []
+    for _ in range(6):
+        opt.zero_grad()
+        out = net(scene["imgs"], scene["K"], scene["R"], scene["t"], scene["depth_min"], scene["depth_max"])
+        loss = synthetic.supervised_loss(out["depth"], gt.cuda(), mask.cuda(), scene["depth_min"], scene["depth_max"])
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    print("[train] losses", [f"{v:.3f}" for v in losses])
+    assert losses[-1] < losses[0]
+    net.eval()
+    with torch.no_grad():
+        out = net(scene["imgs"], scene["K"], scene["R"], scene["t"], scene["depth_min"], scene["depth_max"])
+    assert torch.isfinite(out["depth"]).all()

@@ -1,0 +1,43 @@
+"""The CPU oracle in train() mode against one training step of the reference itself (tests/golden/*_train.npz, made by
+tests/golden/gen_golden.py): forward with batch-statistics BatchNorm, the supervised loss of models/trainer.py:163-167,
+every gradient ATen autograd produces, and the running statistics after the step."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mvsnet as O
+from wild_deep_mvs_amd import synthetic
+from _util import check_close, load_golden, t
+
+
+def oracle_train_step(agg, H, W, V, D, seed, scene_seed, B, store=None):
+    from wild_deep_mvs_amd.models.MVSNet.model import MVSNet
+    sd = synthetic.train_state_dict("mvsnet", synthetic.template_of(MVSNet(agg)), seed=seed)
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v) for k, v in sd.items()}
+    scene = synthetic.make_scene(B, V, H, W, seed=scene_seed)
+    stats = {}
+    out = O.forward(scene["imgs"], scene["K"], scene["R"], scene["t"], scene["depth_min"], scene["depth_max"], sd, num_depth=D,
+                    aggregation=agg, training=True, new_stats=stats, store=store)
+    depth = out["depth"]
+    gt, mask = synthetic.train_target(scene, depth.shape[1], depth.shape[2])
+    loss = synthetic.supervised_loss(depth, gt, mask, scene["depth_min"], scene["depth_max"])
+    loss.backward()
+    grads = {k: v.grad for k, v in sd.items() if isinstance(v, torch.Tensor) and v.requires_grad}
+    return depth.detach(), float(loss), grads, stats
+
+
+@pytest.mark.parametrize("fname,agg", [("mvsnet_train.npz", "variance"), ("mvsnet_s_train.npz", "softmin")])
+def test_oracle_train_step_matches_reference(fname, agg):
+    g = load_golden(fname)
+    H, W, V, D, seed, scene_seed, B = [int(x) for x in g["meta"]]
+    depth, loss, grads, stats = oracle_train_step(agg, H, W, V, D, seed, scene_seed, B)
+    check_close("depth", depth, t(g["depth"]), max_abs=2e-4)
+    assert abs(loss - float(g["loss"])) <= 2e-4 * abs(float(g["loss"])), (loss, float(g["loss"]))
+    for k, ref in zip(g["norm_keys"], g["norm_vals"]):
+        got = float(grads[str(k)].norm())
+        assert abs(got - ref) <= 2e-3 * ref + 1e-6, (k, got, ref)
+    for k in g:
+        if k.startswith("grad:"):
+            check_close(k, grads[k[5:]], t(g[k]), rel_l2=2e-3)
+        if k.startswith("stat:"):
+            check_close(k, stats[k[5:]], t(g[k]), rel_l2=1e-4)

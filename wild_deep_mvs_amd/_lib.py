@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libpscv.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 # mirror of include/pscv.h
-ABI_VERSION = 1
+ABI_VERSION = 2
 F32, BF16, F16 = 0, 1, 2
 GEOM_PROJ, GEOM_HOMOG = 0, 1
 COST_VARIANCE, COST_VARIANCE_CVP, COST_SOFTMIN, COST_GROUPCORR, COST_WARP_ONLY = 0, 1, 2, 3, 4
@@ -29,7 +29,9 @@ GEO_CAM_FLOATS = 30
 
 EXPORTS = ("pscv_last_error", "pscv_abi_version", "pscv_set_tuning", "pscv_proj_cams", "pscv_homog_cams", "pscv_warp_cost",
            "pscv_fuse_pairs", "pscv_fuse_finish", "pscv_geo_filter", "pscv_pack_conv2d_weights", "pscv_conv2d",
-           "pscv_pack_conv3d_weights", "pscv_conv3d", "pscv_softargmin")
+           "pscv_pack_conv3d_weights", "pscv_conv3d", "pscv_softargmin", "pscv_train_workspace_floats", "pscv_bn_stats",
+           "pscv_bn_act", "pscv_bn_bwd_reduce", "pscv_bn_bwd_apply", "pscv_softargmin_bwd", "pscv_conv3d_wgrad_workspace",
+           "pscv_conv3d_wgrad", "pscv_warp_cost_bwd")
 
 
 class PscvMissingError(RuntimeError):
@@ -86,6 +88,25 @@ def _declare(lib):
     lib.pscv_conv3d.argtypes = [vp, i, i, i, vp, vp, vp, vp, vp, i, i, vp, i, i, i, i, i, i, i, i, i, i, i, vp]
     lib.pscv_softargmin.restype = i
     lib.pscv_softargmin.argtypes = [vp, i, vp, l, i, vp, vp, vp, vp, vp, vp, i, f, i, i, i, i, i, vp]
+    lib.pscv_train_workspace_floats.restype = l
+    lib.pscv_train_workspace_floats.argtypes = []
+    lib.pscv_bn_stats.restype = i
+    lib.pscv_bn_stats.argtypes = [vp, i, l, i, vp, vp, vp]
+    lib.pscv_bn_act.restype = i
+    lib.pscv_bn_act.argtypes = [vp, i, l, i, vp, vp, i, vp, vp, vp]
+    lib.pscv_bn_bwd_reduce.restype = i
+    lib.pscv_bn_bwd_reduce.argtypes = [vp, vp, i, l, i, vp, vp, i, vp, vp, vp]
+    lib.pscv_bn_bwd_apply.restype = i
+    lib.pscv_bn_bwd_apply.argtypes = [vp, vp, i, l, i, vp, vp, i, vp, vp, vp, vp, vp]
+    lib.pscv_softargmin_bwd.restype = i
+    lib.pscv_softargmin_bwd.argtypes = [vp, vp, l, i, vp, vp, i, i, i, i, i, vp]
+    lib.pscv_conv3d_wgrad_workspace.restype = l
+    lib.pscv_conv3d_wgrad_workspace.argtypes = [i, i, i, i, i, i, i]
+    lib.pscv_conv3d_wgrad.restype = i
+    lib.pscv_conv3d_wgrad.argtypes = [vp, i, i, i, vp, i, i, i, i, i, i, i, i, i, vp, vp, i, vp]
+    lib.pscv_warp_cost_bwd.restype = i
+    lib.pscv_warp_cost_bwd.argtypes = [vp, C.POINTER(vp), i, vp, vp, l, i, i, i, f, vp, vp, C.POINTER(vp), vp, i, i, i, i, i,
+                                       i, i, i, i, vp]
 
 
 def lib():

@@ -1,0 +1,283 @@
+// Weight gradient of the 3x3x3 convolutions as an MFMA contraction over VOXELS (gfx950, wave64).
+//
+//     G[a][b][t] = sum_{n, o}  P[n, o, a] * Q[n, s*o + t - 1, b]          t = (tz, ty, tx) in 0..2^3, zero outside Q
+//
+//   Conv3d (stride s = 1 or 2), weight [C_out, C_in, 27]:          P = grad of the output (a = c_out), Q = the layer input
+//   ConvTranspose3d (stride s, padding 1), weight [C_in, C_out, 27]: P = the layer input (a = c_in),  Q = grad of the output
+// i.e. the backward-to-weights of every block of the reference's 3-D U-Nets (models/MVSNet/model.py:43-84,
+// models/CVP_MVSNet/models/net.py:50-85, models/VisMVSNet/nn_utils.py:194-278) under loss.backward().
+//
+// GEMM view per tap: D[16 a x 16 b] += A[16 a x 32 k] * B[32 k x 16 b] with k = 32 voxels of the tile
+// (v_mfma_f32_16x16x32: a lane group holds 8 CONSECUTIVE k = 8 x-adjacent voxels of one channel).  The tensors are
+// channels-last, so both operands are transposed on their way into LDS ([channel][voxel], 16-bit); Q is staged once per
+// x-tap, already shifted (and, for s = 2, decimated), so every fragment is one aligned ds_read_b128 and the k-loop is
+// identical for both strides.  Channel strides are padded to an odd number of 16-byte slots: conflict-free reads.
+// A workgroup owns one 16-channel a-tile and NB 16-channel b-tiles (blockIdx.y) and walks voxel tiles persistently
+// (blockIdx.x, grid-stride); its 4 waves split the 27 taps, accumulators stay in registers across tiles.  Partial sums go
+// to a workspace [nblk][27][CA16][CB16] and a finishing kernel adds them in a fixed order: bit-reproducible, no atomics.
+#include "pscv_common.h"
+
+namespace pscv {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 wg_bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 wg_f16x8;
+typedef __attribute__((ext_vector_type(4))) float wg_f32x4;
+
+template <typename H> struct WMfma;
+template <> struct WMfma<bf16_t> {
+    __device__ static __forceinline__ wg_f32x4 run(const uint4& a, const uint4& b, const wg_f32x4& c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wg_bf16x8, a), __builtin_bit_cast(wg_bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct WMfma<f16_t> {
+    __device__ static __forceinline__ wg_f32x4 run(const uint4& a, const uint4& b, const wg_f32x4& c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wg_f16x8, a), __builtin_bit_cast(wg_f16x8, b), c, 0, 0, 0);
+    }
+};
+
+struct WgradArgs {
+    const uint16_t* p;
+    const uint16_t* q;
+    float* part;        // [gridDim.x][27][ca16][cb16]
+    int p_cs, p_co, q_cs, q_co;
+    int ca, cb, ca16, cb16;
+    int B, Dp, Hp, Wp, Dq, Hq, Wq;
+    int ntz, nty, ntx, ntiles;
+};
+
+template <int S, int TZ, int TY, int NB> struct WgGeom {
+    static constexpr int NV = TZ * TY * 16;                 // P voxels per tile
+    static constexpr int QZ = S * (TZ - 1) + 3, QY = S * (TY - 1) + 3, QX = S * 15 + 3;
+    static constexpr int PAS = NV * 2 + 16;                 // bytes per P channel row (odd number of 16-byte slots)
+    static constexpr int QBS = QZ * QY * 32 + 16;           // bytes per Q channel block
+    static constexpr int QTS = 16 * NB * QBS;               // bytes per x-tap copy of Q
+    static constexpr int P_BYTES = 16 * PAS;
+    static constexpr int LDS = P_BYTES + 3 * QTS;
+    static constexpr int KSTEPS = TZ * TY * 2 / 4;
+    static_assert((TZ * TY * 2) % 4 == 0, "tile must hold whole k-steps");
+    static_assert((PAS / 16) % 2 == 1 && (QBS / 16) % 2 == 1, "odd slot strides");
+};
+
+template <typename H, int S, int TZ, int TY, int NB>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
+    using G = WgGeom<S, TZ, TY, NB>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* p_lds = smem;
+    unsigned char* q_lds = smem + G::P_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int nbg = a.cb16 / (16 * NB);
+    const int at = blockIdx.y / nbg, bg = blockIdx.y % nbg;
+    const int a0 = at * 16, b0 = bg * 16 * NB;
+
+    wg_f32x4 acc[7][NB];
+#pragma unroll
+    for (int ti = 0; ti < 7; ++ti)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[ti][nb] = wg_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int tx_i = t % a.ntx; t /= a.ntx;
+        const int ty_i = t % a.nty; t /= a.nty;
+        const int tz_i = t % a.ntz; t /= a.ntz;
+        const int b = t;
+        const int z0 = tz_i * TZ, y0 = ty_i * TY, x0 = tx_i * 16;
+
+        // ---- stage P, transposed: p_lds[channel][voxel] ----
+        {
+            const uint16_t* pb = a.p + (long)b * a.Dp * a.Hp * a.Wp * a.p_cs + a.p_co;
+            constexpr int NCH = G::NV * 2;
+            for (int c = tid; c < NCH; c += 256) {
+                const int vox = c % G::NV, c8 = c / G::NV;
+                const int xl = vox & 15, yl = (vox >> 4) % TY, zl = (vox >> 4) / TY;
+                const int gz = z0 + zl, gy = y0 + yl, gx = x0 + xl;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (gz < a.Dp && gy < a.Hp && gx < a.Wp && a0 + c8 * 8 < a.ca)
+                    v = *reinterpret_cast<const uint4*>(pb + (((long)gz * a.Hp + gy) * a.Wp + gx) * a.p_cs + a0 + c8 * 8);
+                const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+                unsigned char* dst = p_lds + (c8 * 8) * G::PAS + vox * 2;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    *reinterpret_cast<uint16_t*>(dst + j * G::PAS) = (uint16_t)(w4[j >> 1] >> ((j & 1) * 16));
+            }
+        }
+        // ---- stage Q, transposed, once per x-tap: q_lds[tx][channel][qz][qy][ox] = Q[.., S*(x0+ox) + tx - 1] ----
+        {
+            const uint16_t* qb = a.q + (long)b * a.Dq * a.Hq * a.Wq * a.q_cs + a.q_co;
+            constexpr int CCH = 2 * NB;                         // 8-channel chunks of this block's b slice
+            constexpr int NCH = G::QZ * G::QY * G::QX * CCH;
+            constexpr int BATCH = 4;
+            const int oz = S * z0 - 1, oy = S * y0 - 1, ox0 = S * x0 - 1;
+            for (int c0 = 0; c0 < NCH; c0 += 256 * BATCH) {
+                uint4 val[BATCH];
+#pragma unroll
+                for (int k = 0; k < BATCH; ++k) {
+                    const int c = c0 + k * 256 + tid;
+                    const int cc = c % CCH, v = c / CCH;
+                    const int xl = v % G::QX, r = v / G::QX;
+                    const int yl = r % G::QY, zl = r / G::QY;
+                    const int gz = oz + zl, gy = oy + yl, gx = ox0 + xl;
+                    val[k] = make_uint4(0u, 0u, 0u, 0u);
+                    if (c < NCH && (unsigned)gz < (unsigned)a.Dq && (unsigned)gy < (unsigned)a.Hq && (unsigned)gx < (unsigned)a.Wq &&
+                        b0 + cc * 8 < a.cb)
+                        val[k] = *reinterpret_cast<const uint4*>(qb + (((long)gz * a.Hq + gy) * a.Wq + gx) * a.q_cs + b0 + cc * 8);
+                }
+#pragma unroll
+                for (int k = 0; k < BATCH; ++k) {
+                    const int c = c0 + k * 256 + tid;
+                    if (c >= NCH) continue;
+                    const int cc = c % CCH, v = c / CCH;
+                    const int xl = v % G::QX, r = v / G::QX;
+                    const int yl = r % G::QY, zl = r / G::QY;
+                    const uint32_t w4[4] = {val[k].x, val[k].y, val[k].z, val[k].w};
+#pragma unroll
+                    for (int tx = 0; tx < 3; ++tx) {
+                        const int d = xl - tx;
+                        if (d < 0 || (S == 2 && (d & 1))) continue;
+                        const int ox = d / S;
+                        if (ox >= 16) continue;
+                        unsigned char* dst = q_lds + tx * G::QTS + (cc * 8) * G::QBS + ((zl * G::QY + yl) * 16 + ox) * 2;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            *reinterpret_cast<uint16_t*>(dst + j * G::QBS) = (uint16_t)(w4[j >> 1] >> ((j & 1) * 16));
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- contraction: this wave's taps x all k-steps ----
+#pragma unroll
+        for (int ks = 0; ks < G::KSTEPS; ++ks) {
+            const int chunk = ks * 4 + g;
+            const int x8 = chunk & 1, yl = (chunk >> 1) % TY, zl = (chunk >> 1) / TY;
+            const uint4 af = *reinterpret_cast<const uint4*>(p_lds + n * G::PAS + ((zl * TY + yl) * 16 + x8 * 8) * 2);
+#pragma unroll
+            for (int ti = 0; ti < 7; ++ti) {
+                const int tap = wave + 4 * ti;
+                if (tap < 27) {
+                    const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
+                    const unsigned char* qrow = q_lds + tx * G::QTS + (((S * zl + tz) * G::QY + (S * yl + ty)) * 16 + x8 * 8) * 2;
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const uint4 bf = *reinterpret_cast<const uint4*>(qrow + (nb * 16 + n) * G::QBS);
+                        acc[ti][nb] = WMfma<H>::run(af, bf, acc[ti][nb]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- partial sums of this workgroup: part[blockIdx.x][tap][a][b] (lane (n, g) holds a = 4g..4g+3, b = n) ----
+    float* part = a.part + (long)blockIdx.x * 27 * a.ca16 * a.cb16;
+#pragma unroll
+    for (int ti = 0; ti < 7; ++ti) {
+        const int tap = wave + 4 * ti;
+        if (tap < 27) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    part[((long)tap * a.ca16 + a0 + g * 4 + i) * a.cb16 + b0 + nb * 16 + n] = acc[ti][nb][i];
+        }
+    }
+}
+
+// dw[a][b][t] = sum_blk part[blk][t][a][b], fixed order
+__global__ void wgrad_finish_kernel(const float* __restrict__ part, int nblk, int ca, int cb, int ca16, int cb16,
+                                    float* __restrict__ dw, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = 27 * ca * cb;
+    if (i >= n) return;
+    const int t = i % 27, ab = i / 27;
+    const int b = ab % cb, aa = ab / cb;
+    const long off = ((long)t * ca16 + aa) * cb16 + b;
+    const long stride = 27L * ca16 * cb16;
+    float s0 = 0.f, s1 = 0.f;
+    int k = 0;
+    for (; k + 1 < nblk; k += 2) { s0 += part[off + k * stride]; s1 += part[off + (k + 1) * stride]; }
+    if (k < nblk) s0 += part[off + k * stride];
+    const float v = s0 + s1;
+    dw[i] = accumulate ? dw[i] + v : v;
+}
+
+static inline int wg_ceil(int a, int b) { return (a + b - 1) / b; }
+
+struct WgPlan { int tz, ty, nb, ntz, nty, ntx, ntiles, nblk, ny, ca16, cb16; };
+
+static WgPlan wgrad_plan(int B, int Dp, int Hp, int Wp, int ca, int cb, int stride) {
+    WgPlan p;
+    p.tz = 2; p.ty = stride == 1 ? 4 : 2;
+    p.ca16 = wg_ceil(ca, 16) * 16; p.cb16 = wg_ceil(cb, 16) * 16;
+    p.nb = (p.cb16 % 32 == 0) ? 2 : 1;
+    p.ntz = wg_ceil(Dp, p.tz); p.nty = wg_ceil(Hp, p.ty); p.ntx = wg_ceil(Wp, 16);
+    p.ntiles = B * p.ntz * p.nty * p.ntx;
+    p.ny = (p.ca16 / 16) * (p.cb16 / (16 * p.nb));
+    int want = 1024 / p.ny;            // ~4 workgroups per CU in total
+    if (want < 1) want = 1;
+    p.nblk = p.ntiles < want ? p.ntiles : want;
+    return p;
+}
+
+template <typename H, int S, int TZ, int TY, int NB>
+static int wgrad_launch(const WgradArgs& a, const WgPlan& p, hipStream_t st) {
+    using G = WgGeom<S, TZ, TY, NB>;
+    static_assert(G::LDS <= 160 * 1024, "wgrad tile does not fit the LDS");
+    auto kern = wgrad_kernel<H, S, TZ, TY, NB>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+        if (e != hipSuccess) { set_error("pscv_conv3d_wgrad: hipFuncSetAttribute(%d B LDS): %s", G::LDS, hipGetErrorString(e)); return -2; }
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.nblk, p.ny), dim3(256), G::LDS, st, a);
+    return 0;
+}
+
+}  // namespace pscv
+
+using namespace pscv;
+
+extern "C" long pscv_conv3d_wgrad_workspace(int B, int Dp, int Hp, int Wp, int ca, int cb, int stride) {
+    PSCV_CHECK_ARG(B > 0 && Dp > 0 && Hp > 0 && Wp > 0 && ca > 0 && cb > 0 && (stride == 1 || stride == 2),
+                   "pscv_conv3d_wgrad_workspace: bad arguments");
+    const WgPlan p = wgrad_plan(B, Dp, Hp, Wp, ca, cb, stride);
+    return (long)p.nblk * 27 * p.ca16 * p.cb16;
+}
+
+extern "C" int pscv_conv3d_wgrad(const void* p, int p_cstride, int p_coff, int ca, const void* q, int q_cstride, int q_coff,
+                                 int cb, int dtype, int B, int Dp, int Hp, int Wp, int stride, float* workspace, float* dw,
+                                 int accumulate, void* stream) {
+    PSCV_CHECK_ARG(p && q && workspace && dw, "pscv_conv3d_wgrad: null pointer argument");
+    PSCV_CHECK_ARG(B > 0 && Dp > 0 && Hp > 0 && Wp > 0, "pscv_conv3d_wgrad: bad sizes");
+    PSCV_CHECK_ARG(stride == 1 || stride == 2, "pscv_conv3d_wgrad: stride %d must be 1 or 2", stride);
+    PSCV_CHECK_ARG(ca % 8 == 0 && cb % 8 == 0 && ca >= 8 && cb >= 8 && ca <= 64 && cb <= 64,
+                   "pscv_conv3d_wgrad: channel counts %d x %d must be multiples of 8 in [8,64]", ca, cb);
+    PSCV_CHECK_ARG(p_cstride % 8 == 0 && p_coff % 8 == 0 && p_coff + ca <= p_cstride && q_cstride % 8 == 0 && q_coff % 8 == 0 &&
+                       q_coff + cb <= q_cstride, "pscv_conv3d_wgrad: channel slices must be 8-aligned and inside their strides");
+    PSCV_CHECK_ARG(dtype == PSCV_BF16 || dtype == PSCV_F16, "pscv_conv3d_wgrad: dtype %d must be bf16 or fp16", dtype);
+    const WgPlan pl = wgrad_plan(B, Dp, Hp, Wp, ca, cb, stride);
+    WgradArgs a;
+    a.p = reinterpret_cast<const uint16_t*>(p); a.q = reinterpret_cast<const uint16_t*>(q); a.part = workspace;
+    a.p_cs = p_cstride; a.p_co = p_coff; a.q_cs = q_cstride; a.q_co = q_coff;
+    a.ca = ca; a.cb = cb; a.ca16 = pl.ca16; a.cb16 = pl.cb16;
+    a.B = B; a.Dp = Dp; a.Hp = Hp; a.Wp = Wp;
+    a.Dq = stride * Dp; a.Hq = stride * Hp; a.Wq = stride * Wp;
+    a.ntz = pl.ntz; a.nty = pl.nty; a.ntx = pl.ntx; a.ntiles = pl.ntiles;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int rc;
+#define PSCV_WG(HT)                                                                       \
+    if (stride == 1) rc = pl.nb == 2 ? wgrad_launch<HT, 1, 2, 4, 2>(a, pl, st) : wgrad_launch<HT, 1, 2, 4, 1>(a, pl, st); \
+    else rc = pl.nb == 2 ? wgrad_launch<HT, 2, 2, 2, 2>(a, pl, st) : wgrad_launch<HT, 2, 2, 2, 1>(a, pl, st);
+    if (dtype == PSCV_BF16) { PSCV_WG(bf16_t) } else { PSCV_WG(f16_t) }
+#undef PSCV_WG
+    if (rc) return rc;
+    PSCV_CHECK_LAUNCH("pscv_conv3d_wgrad");
+    const int n = 27 * ca * cb;
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, st, workspace, pl.nblk, ca, cb, pl.ca16, pl.cb16, dw, accumulate);
+    PSCV_CHECK_LAUNCH("pscv_conv3d_wgrad(finish)");
+    return 0;
+}

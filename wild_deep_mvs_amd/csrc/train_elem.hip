@@ -1,0 +1,310 @@
+// Training-mode pieces of the 3-D regulariser that are byte work, not contractions (gfx950):
+//   - per-channel batch statistics of a channels-last 16-bit volume (BatchNorm3d in train(): the reference's
+//     ConvBnReLU3D / Sequential(ConvTranspose3d, BatchNorm3d, ReLU) blocks, models/MVSNet/module.py:41-58,
+//     models/MVSNet/model.py:57-70, normalise with the statistics of the current batch),
+//   - the normalise + ReLU + skip-add pass,
+//   - the two passes of the BatchNorm backward (reduce, then apply),
+//   - the backward of softmax-over-D + depth regression (models/MVSNet/model.py:207-209).
+// All are HBM-bound single passes: one 16-byte chunk (8 channels of a voxel) per lane per iteration, a lane keeps
+// the same channel group for its whole grid-stride walk so per-channel constants sit in registers and per-channel
+// sums need no cross-lane traffic until the end.  Reductions are two-phase (block partials in a caller-provided
+// workspace, then one small finishing block) so results are bit-reproducible run to run: no float atomics.
+#include "pscv_common.h"
+
+namespace pscv {
+
+constexpr int RED_BLOCKS = 1024;   // partial-sum blocks of the two-phase reductions (workspace = RED_BLOCKS * 2 * 64 floats)
+
+template <typename H> __device__ __forceinline__ void unpack8(const uint4& a, float (&v)[8]) {
+    v[0] = Half16<H>::lo(a.x); v[1] = Half16<H>::hi(a.x); v[2] = Half16<H>::lo(a.y); v[3] = Half16<H>::hi(a.y);
+    v[4] = Half16<H>::lo(a.z); v[5] = Half16<H>::hi(a.z); v[6] = Half16<H>::lo(a.w); v[7] = Half16<H>::hi(a.w);
+}
+template <typename H> __device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
+    return make_uint4(Half16<H>::pack(v[0], v[1]), Half16<H>::pack(v[2], v[3]), Half16<H>::pack(v[4], v[5]),
+                      Half16<H>::pack(v[6], v[7]));
+}
+
+// Block-level sum of two 8-channel register vectors into partials[blk][2][C]; lanes with the same channel group
+// (tid % CG) are combined through LDS in a fixed order.
+template <int CG>
+__device__ __forceinline__ void block_reduce2(const float (&s0)[8], const float (&s1)[8], float* partials, int C) {
+    __shared__ float red[256][17];
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[tid][j] = s0[j]; red[tid][8 + j] = s1[j]; }
+    __syncthreads();
+    // thread (cg, j16) sums the 256 / CG lanes of its channel group, in lane order
+    if (tid < CG * 16) {
+        const int cg = tid / 16, j = tid % 16;
+        float acc = 0.0f;
+        for (int l = cg; l < 256; l += CG) acc += red[l][j];
+        const int which = j >> 3, c = cg * 8 + (j & 7);
+        partials[((long)blockIdx.x * 2 + which) * C + c] = acc;
+    }
+}
+
+__global__ void finish_partials_kernel(const float* __restrict__ partials, int nblk, int n, float* __restrict__ out) {
+    // out[i] = sum_b partials[b][i], fixed order (pairwise over 4 accumulators)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int b = 0;
+    for (; b + 3 < nblk; b += 4) {
+        a0 += partials[(long)b * n + i]; a1 += partials[(long)(b + 1) * n + i];
+        a2 += partials[(long)(b + 2) * n + i]; a3 += partials[(long)(b + 3) * n + i];
+    }
+    for (; b < nblk; ++b) a0 += partials[(long)b * n + i];
+    out[i] = (a0 + a1) + (a2 + a3);
+}
+
+// ---- batch statistics: sum and sum of squares per channel ---------------------------------------------------------
+template <typename H, int CG>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const uint4* __restrict__ y, long nchunk, float* __restrict__ partials, int C) {
+    float s0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nchunk; i += stride) {
+        float v[8];
+        unpack8<H>(y[i], v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s0[j] += v[j]; s1[j] = fmaf(v[j], v[j], s1[j]); }
+    }
+    block_reduce2<CG>(s0, s1, partials, C);
+}
+
+// ---- forward: out = [relu](y * scale + bias) + skip -----------------------------------------------------------------
+template <typename H>
+__global__ __launch_bounds__(256) void bn_act_kernel(const uint4* __restrict__ y, const float* __restrict__ scale,
+                                                     const float* __restrict__ bias, const uint4* __restrict__ skip,
+                                                     uint4* __restrict__ out, long nchunk, int CG, int relu) {
+    const int cg = threadIdx.x % CG;   // 256 and the grid stride are multiples of CG
+    float sc[8], bi[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = scale[cg * 8 + j]; bi[j] = bias[cg * 8 + j]; }
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nchunk; i += stride) {
+        float v[8];
+        unpack8<H>(y[i], v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[j] = fmaf(v[j], sc[j], bi[j]);
+            if (relu) v[j] = fmaxf(v[j], 0.0f);
+        }
+        if (skip) {
+            float s[8];
+            unpack8<H>(skip[i], s);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += s[j];
+        }
+        out[i] = pack8<H>(v);
+    }
+}
+
+// ---- backward, pass 1: dz = dact * [z > 0];  sums of dz and dz * y per channel --------------------------------------
+template <typename H, int CG>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint4* __restrict__ dact, const uint4* __restrict__ y,
+                                                            const float* __restrict__ scale, const float* __restrict__ bias,
+                                                            long nchunk, float* __restrict__ partials, int C, int relu) {
+    const int cg = threadIdx.x % CG;
+    float sc[8], bi[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = scale[cg * 8 + j]; bi[j] = bias[cg * 8 + j]; }
+    float s0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nchunk; i += stride) {
+        float g[8], v[8];
+        unpack8<H>(dact[i], g);
+        unpack8<H>(y[i], v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float z = fmaf(v[j], sc[j], bi[j]);
+            const float dz = (relu && !(z > 0.0f)) ? 0.0f : g[j];
+            s0[j] += dz;
+            s1[j] = fmaf(dz, v[j], s1[j]);
+        }
+    }
+    block_reduce2<CG>(s0, s1, partials, C);
+}
+
+// ---- backward, pass 2: dy = ca * dz + cb * y + cc --------------------------------------------------------------------
+template <typename H>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint4* __restrict__ dact, const uint4* __restrict__ y,
+                                                           const float* __restrict__ scale, const float* __restrict__ bias,
+                                                           const float* __restrict__ ca, const float* __restrict__ cb,
+                                                           const float* __restrict__ cc, uint4* __restrict__ dy, long nchunk,
+                                                           int CG, int relu) {
+    const int cg = threadIdx.x % CG;
+    float sc[8], bi[8], a[8], b[8], c[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        sc[j] = scale[cg * 8 + j]; bi[j] = bias[cg * 8 + j];
+        a[j] = ca[cg * 8 + j]; b[j] = cb[cg * 8 + j]; c[j] = cc[cg * 8 + j];
+    }
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nchunk; i += stride) {
+        float g[8], v[8], o[8];
+        unpack8<H>(dact[i], g);
+        unpack8<H>(y[i], v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float z = fmaf(v[j], sc[j], bi[j]);
+            const float dz = (relu && !(z > 0.0f)) ? 0.0f : g[j];
+            o[j] = fmaf(a[j], dz, fmaf(b[j], v[j], c[j]));
+        }
+        dy[i] = pack8<H>(o);
+    }
+}
+
+// ---- softmax over D + depth regression, backward ---------------------------------------------------------------------
+// depth = sum_d p_d depth_d, p = softmax(logits):  d depth / d logit_d = p_d (depth_d - depth).
+// One lane per pixel walks D three times (max, sums, write); reads and writes are coalesced across the wave.
+// Output: the gradient volume in the conv engine's layout, [B,D,h,w,8] 16-bit with the value in channel 0 and
+// channels 1-7 zero (the 1-channel `prob` head's backward then runs on the 8-channel MFMA kernels).
+template <typename H>
+__global__ __launch_bounds__(256) void softargmin_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ depth,
+                                                             long depth_bstride, int depth_per_pixel,
+                                                             const float* __restrict__ gdepth, uint4* __restrict__ dl8, int B,
+                                                             int D, int hw) {
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= (long)B * hw) return;
+    const int b = (int)(p / hw);
+    const int pix = (int)(p - (long)b * hw);
+    const float* lp = logits + (long)b * D * hw + pix;
+    const float* dp = depth + (long)b * depth_bstride + (depth_per_pixel ? pix : 0);
+    const long dstep = depth_per_pixel ? hw : 1;
+    float m = -INFINITY;
+    for (int d = 0; d < D; ++d) m = fmaxf(m, lp[(long)d * hw]);
+    float z = 0.0f, zd = 0.0f;
+    for (int d = 0; d < D; ++d) {
+        const float e = __expf(lp[(long)d * hw] - m);
+        z += e;
+        zd = fmaf(e, dp[d * dstep], zd);
+    }
+    const float inv = 1.0f / z;
+    const float mean = zd * inv;
+    const float g = gdepth[p] * inv;
+    uint4* op = dl8 + (long)b * D * hw + pix;
+    for (int d = 0; d < D; ++d) {
+        const float e = __expf(lp[(long)d * hw] - m);
+        const float v = g * e * (dp[d * dstep] - mean);
+        op[(long)d * hw] = make_uint4(Half16<H>::pack(v, 0.0f), 0u, 0u, 0u);
+    }
+}
+
+static int grid_for(long nchunk) {
+    long nb = (nchunk + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+static int red_grid_for(long nchunk) {
+    long nb = (nchunk + 255) / 256;
+    if (nb > RED_BLOCKS) nb = RED_BLOCKS;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+}  // namespace pscv
+
+using namespace pscv;
+
+extern "C" long pscv_train_workspace_floats(void) { return (long)RED_BLOCKS * 2 * 64; }
+
+extern "C" int pscv_bn_stats(const void* y, int dtype, long nvox, int C, float* workspace, float* sums, void* stream) {
+    PSCV_CHECK_ARG(y && workspace && sums, "pscv_bn_stats: null pointer argument");
+    PSCV_CHECK_ARG(C == 8 || C == 16 || C == 32 || C == 64, "pscv_bn_stats: C=%d must be 8, 16, 32 or 64", C);
+    PSCV_CHECK_ARG(dtype == PSCV_BF16 || dtype == PSCV_F16, "pscv_bn_stats: dtype %d must be bf16 or fp16", dtype);
+    PSCV_CHECK_ARG(nvox > 0, "pscv_bn_stats: empty volume");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const long nchunk = nvox * (C / 8);
+    const int nb = red_grid_for(nchunk);
+    const uint4* yp = reinterpret_cast<const uint4*>(y);
+#define PSCV_STATS(HT)                                                                                     \
+    switch (C / 8) {                                                                                       \
+        case 1: hipLaunchKernelGGL((bn_stats_kernel<HT, 1>), dim3(nb), dim3(256), 0, st, yp, nchunk, workspace, C); break; \
+        case 2: hipLaunchKernelGGL((bn_stats_kernel<HT, 2>), dim3(nb), dim3(256), 0, st, yp, nchunk, workspace, C); break; \
+        case 4: hipLaunchKernelGGL((bn_stats_kernel<HT, 4>), dim3(nb), dim3(256), 0, st, yp, nchunk, workspace, C); break; \
+        default: hipLaunchKernelGGL((bn_stats_kernel<HT, 8>), dim3(nb), dim3(256), 0, st, yp, nchunk, workspace, C); break; \
+    }
+    if (dtype == PSCV_BF16) { PSCV_STATS(bf16_t) } else { PSCV_STATS(f16_t) }
+#undef PSCV_STATS
+    PSCV_CHECK_LAUNCH("pscv_bn_stats");
+    hipLaunchKernelGGL(finish_partials_kernel, dim3((2 * C + 63) / 64), dim3(64), 0, st, workspace, nb, 2 * C, sums);
+    PSCV_CHECK_LAUNCH("pscv_bn_stats(finish)");
+    return 0;
+}
+
+extern "C" int pscv_bn_act(const void* y, int dtype, long nvox, int C, const float* scale, const float* bias, int relu,
+                           const void* skip, void* out, void* stream) {
+    PSCV_CHECK_ARG(y && scale && bias && out, "pscv_bn_act: null pointer argument");
+    PSCV_CHECK_ARG(C == 8 || C == 16 || C == 32 || C == 64, "pscv_bn_act: C=%d must be 8, 16, 32 or 64", C);
+    PSCV_CHECK_ARG(dtype == PSCV_BF16 || dtype == PSCV_F16, "pscv_bn_act: dtype %d must be bf16 or fp16", dtype);
+    PSCV_CHECK_ARG(nvox > 0, "pscv_bn_act: empty volume");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const long nchunk = nvox * (C / 8);
+    const int nb = grid_for(nchunk);
+    if (dtype == PSCV_BF16)
+        hipLaunchKernelGGL(bn_act_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const uint4*)y, scale, bias, (const uint4*)skip, (uint4*)out, nchunk, C / 8, relu);
+    else
+        hipLaunchKernelGGL(bn_act_kernel<f16_t>, dim3(nb), dim3(256), 0, st, (const uint4*)y, scale, bias, (const uint4*)skip, (uint4*)out, nchunk, C / 8, relu);
+    PSCV_CHECK_LAUNCH("pscv_bn_act");
+    return 0;
+}
+
+extern "C" int pscv_bn_bwd_reduce(const void* dact, const void* y, int dtype, long nvox, int C, const float* scale,
+                                  const float* bias, int relu, float* workspace, float* sums, void* stream) {
+    PSCV_CHECK_ARG(dact && y && scale && bias && workspace && sums, "pscv_bn_bwd_reduce: null pointer argument");
+    PSCV_CHECK_ARG(C == 8 || C == 16 || C == 32 || C == 64, "pscv_bn_bwd_reduce: C=%d must be 8, 16, 32 or 64", C);
+    PSCV_CHECK_ARG(dtype == PSCV_BF16 || dtype == PSCV_F16, "pscv_bn_bwd_reduce: dtype %d must be bf16 or fp16", dtype);
+    PSCV_CHECK_ARG(nvox > 0, "pscv_bn_bwd_reduce: empty volume");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const long nchunk = nvox * (C / 8);
+    const int nb = red_grid_for(nchunk);
+    const uint4 *gp = (const uint4*)dact, *yp = (const uint4*)y;
+#define PSCV_RED(HT)                                                                                                              \
+    switch (C / 8) {                                                                                                              \
+        case 1: hipLaunchKernelGGL((bn_bwd_reduce_kernel<HT, 1>), dim3(nb), dim3(256), 0, st, gp, yp, scale, bias, nchunk, workspace, C, relu); break; \
+        case 2: hipLaunchKernelGGL((bn_bwd_reduce_kernel<HT, 2>), dim3(nb), dim3(256), 0, st, gp, yp, scale, bias, nchunk, workspace, C, relu); break; \
+        case 4: hipLaunchKernelGGL((bn_bwd_reduce_kernel<HT, 4>), dim3(nb), dim3(256), 0, st, gp, yp, scale, bias, nchunk, workspace, C, relu); break; \
+        default: hipLaunchKernelGGL((bn_bwd_reduce_kernel<HT, 8>), dim3(nb), dim3(256), 0, st, gp, yp, scale, bias, nchunk, workspace, C, relu); break; \
+    }
+    if (dtype == PSCV_BF16) { PSCV_RED(bf16_t) } else { PSCV_RED(f16_t) }
+#undef PSCV_RED
+    PSCV_CHECK_LAUNCH("pscv_bn_bwd_reduce");
+    hipLaunchKernelGGL(finish_partials_kernel, dim3((2 * C + 63) / 64), dim3(64), 0, st, workspace, nb, 2 * C, sums);
+    PSCV_CHECK_LAUNCH("pscv_bn_bwd_reduce(finish)");
+    return 0;
+}
+
+extern "C" int pscv_bn_bwd_apply(const void* dact, const void* y, int dtype, long nvox, int C, const float* scale,
+                                 const float* bias, int relu, const float* ca, const float* cb, const float* cc, void* dy,
+                                 void* stream) {
+    PSCV_CHECK_ARG(dact && y && scale && bias && ca && cb && cc && dy, "pscv_bn_bwd_apply: null pointer argument");
+    PSCV_CHECK_ARG(C == 8 || C == 16 || C == 32 || C == 64, "pscv_bn_bwd_apply: C=%d must be 8, 16, 32 or 64", C);
+    PSCV_CHECK_ARG(dtype == PSCV_BF16 || dtype == PSCV_F16, "pscv_bn_bwd_apply: dtype %d must be bf16 or fp16", dtype);
+    PSCV_CHECK_ARG(nvox > 0, "pscv_bn_bwd_apply: empty volume");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const long nchunk = nvox * (C / 8);
+    const int nb = grid_for(nchunk);
+    if (dtype == PSCV_BF16)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const uint4*)dact, (const uint4*)y, scale, bias, ca, cb, cc, (uint4*)dy, nchunk, C / 8, relu);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<f16_t>, dim3(nb), dim3(256), 0, st, (const uint4*)dact, (const uint4*)y, scale, bias, ca, cb, cc, (uint4*)dy, nchunk, C / 8, relu);
+    PSCV_CHECK_LAUNCH("pscv_bn_bwd_apply");
+    return 0;
+}
+
+extern "C" int pscv_softargmin_bwd(const float* logits, const float* depth, long depth_bstride, int depth_per_pixel,
+                                   const float* grad_depth, void* dlogits8, int dtype, int B, int D, int h, int w, void* stream) {
+    PSCV_CHECK_ARG(logits && depth && grad_depth && dlogits8, "pscv_softargmin_bwd: null pointer argument");
+    PSCV_CHECK_ARG(B > 0 && D > 0 && h > 0 && w > 0, "pscv_softargmin_bwd: bad sizes");
+    PSCV_CHECK_ARG(dtype == PSCV_BF16 || dtype == PSCV_F16, "pscv_softargmin_bwd: dtype %d must be bf16 or fp16", dtype);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const long npix = (long)B * h * w;
+    const int nb = (int)((npix + 255) / 256);
+    if (dtype == PSCV_BF16)
+        hipLaunchKernelGGL(softargmin_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, logits, depth, depth_bstride, depth_per_pixel, grad_depth, (uint4*)dlogits8, B, D, h * w);
+    else
+        hipLaunchKernelGGL(softargmin_bwd_kernel<f16_t>, dim3(nb), dim3(256), 0, st, logits, depth, depth_bstride, depth_per_pixel, grad_depth, (uint4*)dlogits8, B, D, h * w);
+    PSCV_CHECK_LAUNCH("pscv_softargmin_bwd");
+    return 0;
+}

@@ -1,0 +1,324 @@
+// Backward of the fused plane-sweep warp + cost aggregation (gfx950): gradient of the loss with respect to the
+// reference and source FEATURE MAPS given the gradient of the cost volume.
+//
+// Reference semantics (fdarmon/wild_deep_mvs): the sampling grid is built under torch.no_grad()
+// (models/MVSNet/module.py:127, models/CVP_MVSNet/models/modules.py:83, models/VisMVSNet/homography.py has no grad
+// path to the cameras in train.py either), so autograd reaches only `src_fea` through F.grid_sample (bilinear, zeros)
+// and the features through the cost statistic (models/MVSNet/model.py:109-176).  This kernel is that backward, fused:
+// the per-view warped volumes and their gradients (503 MB fp32 each at the headline size) never exist.
+//
+// Per voxel: pass 1 re-samples the sources to rebuild the statistic the forward kept only in registers (sum for the
+// variance, the soft-min numerator / weights), pass 2 re-samples each source, forms d cost / d warped in registers and
+// scatters it to the four taps of the fp32 gradient map with hardware float atomics (global_atomic_add_f32, no
+// return); the reference-feature gradient is accumulated over the block's depth planes in registers first.
+// Same block / lane mapping and XCD-banded block order as the forward (warp_cost.hip).
+#include "warp_common.h"
+
+namespace pscv {
+
+struct WarpBwdArgs {
+    WarpArgs w;                    // geometry, features (ref / src), depth planes; w.out unused
+    const void* g;                 // gradient of the forward's output, same layout as that output
+    long g_view_stride;
+    float* dref;                   // [B,h,w,C] fp32, accumulated (caller zero-fills), or NULL
+    float* dsrc[PSCV_MAX_SRC];     // [B,hs,ws,C] fp32 each, accumulated (caller zero-fills)
+    float* dtemp;                  // [1] fp32, accumulated (SOFTMIN), or NULL
+};
+
+__device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
+
+template <typename TIn, typename TG, int C, int LPV, int GEOM, int COST>
+__global__ __launch_bounds__(256) void warp_bwd_kernel(const WarpBwdArgs A) {
+    const WarpArgs& a = A.w;
+    constexpr int CPL = C / LPV;
+    constexpr int PPB = 256 / LPV;
+    constexpr int PIXB = C * (int)sizeof(TIn);
+    constexpr bool VAR = (COST == PSCV_COST_VARIANCE || COST == PSCV_COST_VARIANCE_CVP);
+
+    const int nwg = gridDim.x;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    const int pb = wg / a.n_dchunks;
+    const int dc = wg - pb * a.n_dchunks;
+    const int b = pb / a.npb_batch;
+    const int pbb = pb - b * a.npb_batch;
+
+    const int tid = threadIdx.x;
+    __shared__ float cam_lds[PSCV_MAX_SRC * PSCV_CAM_FLOATS];
+    __shared__ float red_lds[4];
+    for (int i = tid; i < a.n_src * PSCV_CAM_FLOATS; i += 256) {
+        const int v = i / PSCV_CAM_FLOATS, k = i - v * PSCV_CAM_FLOATS;
+        cam_lds[i] = a.cams[((long)v * a.B + b) * PSCV_CAM_FLOATS + k];
+    }
+    __syncthreads();
+
+    const int hw = a.h * a.w;
+    const int pl = tid / LPV;
+    int pflat = pbb * PPB + pl;
+    const bool active = pflat < hw;
+    pflat = active ? pflat : hw - 1;
+    const int choff = (tid % LPV) * CPL;
+    const unsigned chb = (unsigned)choff * (unsigned)sizeof(TIn);
+    const long pix = (long)b * hw + pflat;
+    const int y = pflat / a.w;
+    const int x = pflat - y * a.w;
+    const float off = (GEOM == PSCV_GEOM_HOMOG) ? 0.5f : 0.0f;
+    const float px = (float)x + off, py = (float)y + off;
+
+    VecF<CPL> rf, gref;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) { rf.v[j] = 0.0f; gref.v[j] = 0.0f; }
+    if (COST != PSCV_COST_WARP_ONLY) rf = load_chan<TIn, CPL>(reinterpret_cast<const TIn*>(a.ref) + pix * C + choff);
+
+    const int d0 = dc * a.ppd;
+    const int d1 = min(a.D, d0 + a.ppd);
+    const float N = (float)(a.n_src + 1);
+    const float invN = 1.0f / N;
+    const long img_elems = (long)b * a.hs * a.ws * C;
+    const TG* gp = reinterpret_cast<const TG*>(A.g);
+    float dtemp_acc = 0.0f;
+
+    // bilinear taps of (voxel, view) in the general (border-aware) form: invalid taps carry weight 0
+    auto sample = [&](int v, float dval, Taps& taps) -> VecF<CPL> {
+        float ix, iy;
+        sweep_index<GEOM>(cam_lds + v * PSCV_CAM_FLOATS, px, py, dval, a, ix, iy);
+        const float x0f = floorf(ix), y0f = floorf(iy);
+        make_taps<false, PIXB>(ix - x0f, iy - y0f, (int)x0f, (int)y0f, a.hs, a.ws, chb, taps);
+        const char* img = reinterpret_cast<const char*>(a.src[v]) + img_elems * (long)sizeof(TIn);
+        return blend_taps<TIn, CPL, false, PIXB>(img, taps);
+    };
+    auto scatter = [&](int v, const Taps& taps, const VecF<CPL>& gw) {
+        if (!active) return;
+        float* base = A.dsrc[v] + img_elems;
+        float* p00 = base + taps.o00 / sizeof(TIn);
+        float* p01 = base + taps.o01 / sizeof(TIn);
+        float* p10 = base + taps.o10 / sizeof(TIn);
+        float* p11 = base + taps.o11 / sizeof(TIn);
+        if (taps.w00 != 0.0f) {
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) atomic_add_f32(p00 + j, gw.v[j] * taps.w00);
+        }
+        if (taps.w01 != 0.0f) {
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) atomic_add_f32(p01 + j, gw.v[j] * taps.w01);
+        }
+        if (taps.w10 != 0.0f) {
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) atomic_add_f32(p10 + j, gw.v[j] * taps.w10);
+        }
+        if (taps.w11 != 0.0f) {
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) atomic_add_f32(p11 + j, gw.v[j] * taps.w11);
+        }
+    };
+    auto lane_sum = [&](float part) -> float {   // sum over the LPV lanes that share a voxel
+#pragma unroll
+        for (int m = 1; m < LPV; m <<= 1) part += __shfl_xor(part, m, 64);
+        return part;
+    };
+
+    for (int d = d0; d < d1; ++d) {
+        const float dval = a.depth_per_pixel ? a.depth[(long)b * a.depth_bstride + (long)d * hw + pflat]
+                                             : a.depth[(long)b * a.depth_bstride + d];
+        const long vox = ((long)b * a.D + d) * hw + pflat;
+        Taps taps;
+
+        if (VAR) {
+            // cost = S2 / N - S1^2 / N^2  ->  d cost / d f = (2 / N) (f - S1 / N)      model.py:134, net.py:148
+            VecF<CPL> s1 = rf;
+            for (int v = 0; v < a.n_src; ++v) {
+                const VecF<CPL> wv = sample(v, dval, taps);
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) s1.v[j] += wv.v[j];
+            }
+            VecF<CPL> G = load_chan<TG, CPL>(gp + vox * C + choff);
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) {
+                G.v[j] *= 2.0f * invN;
+                s1.v[j] *= invN;
+                gref.v[j] = fmaf(G.v[j], rf.v[j] - s1.v[j], gref.v[j]);
+            }
+            for (int v = 0; v < a.n_src; ++v) {
+                const VecF<CPL> wv = sample(v, dval, taps);
+                VecF<CPL> gw;
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) gw.v[j] = G.v[j] * (wv.v[j] - s1.v[j]);
+                scatter(v, taps, gw);
+            }
+        } else if (COST == PSCV_COST_SOFTMIN) {
+            // cost_c = num_c / Z, num_c = sum_v e_v diff_vc, Z = sum_v e_v + 1e-6, e_v = exp(-temp S_v), S_v = sum_c diff_vc
+            VecF<CPL> num;
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) num.v[j] = 0.0f;
+            float Z = 1e-6f;
+            for (int v = 0; v < a.n_src; ++v) {
+                const VecF<CPL> wv = sample(v, dval, taps);
+                VecF<CPL> diff;
+                float part = 0.0f;
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) { const float t = rf.v[j] - wv.v[j]; diff.v[j] = t * t; part += diff.v[j]; }
+                const float e = __expf(-a.temp * lane_sum(part));
+                Z += e;
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) num.v[j] = fmaf(e, diff.v[j], num.v[j]);
+            }
+            const float invZ = 1.0f / Z;
+            const VecF<CPL> G = load_chan<TG, CPL>(gp + vox * C + choff);
+            float gc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) gc = fmaf(G.v[j], num.v[j] * invZ, gc);
+            gc = lane_sum(gc);
+            for (int v = 0; v < a.n_src; ++v) {
+                const VecF<CPL> wv = sample(v, dval, taps);
+                VecF<CPL> t;
+                float part = 0.0f, gd = 0.0f;
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) {
+                    t.v[j] = rf.v[j] - wv.v[j];
+                    const float df = t.v[j] * t.v[j];
+                    part += df;
+                    gd = fmaf(G.v[j], df, gd);
+                }
+                const float S = lane_sum(part);
+                gd = lane_sum(gd);
+                const float e = __expf(-a.temp * S);
+                const float dLde = (gd - gc) * invZ;
+                if (active && (tid % LPV) == 0) dtemp_acc -= dLde * S * e;
+                VecF<CPL> gw;
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) {
+                    const float coef = 2.0f * e * (G.v[j] * invZ - a.temp * dLde) * t.v[j];   // d L / d diff * d diff / d r
+                    gref.v[j] += coef;
+                    gw.v[j] = -coef;
+                }
+                scatter(v, taps, gw);
+            }
+        } else if constexpr (COST == PSCV_COST_GROUPCORR) {
+            // corr_g = sum_{c in group g} ref_c warp_c                                    nn_utils.py:473-490
+            static_assert(C == 32, "group-wise correlation backward: 32 channels -> 8 groups (Vis-MVSNet)");
+            constexpr int GC = C / 4;
+            for (int v = 0; v < a.n_src; ++v) {
+                const VecF<CPL> wv = sample(v, dval, taps);
+                const TG* gv = gp + (long)v * A.g_view_stride + vox * GC + choff / 4;
+                VecF<CPL> gw;
+                const VecF<8> G8 = load_chan<TG, 8>(gv - (choff / 4) % 8);   // aligned 8-group chunk holding this lane's groups
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) {
+                    const float Gg = G8.v[(choff / 4) % 8 + j / 4];
+                    gw.v[j] = Gg * rf.v[j];
+                    gref.v[j] = fmaf(Gg, wv.v[j], gref.v[j]);
+                }
+                scatter(v, taps, gw);
+            }
+        } else {   // WARP_ONLY: the gradient of the warped volume goes straight to the taps
+            for (int v = 0; v < a.n_src; ++v) {
+                (void)sample(v, dval, taps);
+                const VecF<CPL> gw = load_chan<TG, CPL>(gp + (long)v * A.g_view_stride + vox * C + choff);
+                scatter(v, taps, gw);
+            }
+        }
+    }
+
+    if (COST != PSCV_COST_WARP_ONLY && A.dref && active) {
+        float* dr = A.dref + pix * C + choff;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) atomic_add_f32(dr + j, gref.v[j]);
+    }
+    if (COST == PSCV_COST_SOFTMIN && A.dtemp) {
+        float s = dtemp_acc;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) s += __shfl_xor(s, m, 64);
+        if ((tid & 63) == 0) red_lds[tid >> 6] = s;
+        __syncthreads();
+        if (tid == 0) atomic_add_f32(A.dtemp, (red_lds[0] + red_lds[1]) + (red_lds[2] + red_lds[3]));
+    }
+}
+
+template <typename TIn, typename TG, int C, int LPV>
+static int bwd_launch(WarpBwdArgs& A, int geom, int cost, hipStream_t st) {
+    WarpArgs& a = A.w;
+    constexpr int PPB = 256 / LPV;
+    a.npb_batch = (a.h * a.w + PPB - 1) / PPB;
+    const long n_pixblocks = (long)a.npb_batch * a.B;
+    int ppd = 8;
+    while (ppd > 1 && n_pixblocks * ((a.D + ppd - 1) / ppd) < 4096) ppd >>= 1;
+    a.ppd = ppd;
+    a.n_dchunks = (a.D + ppd - 1) / ppd;
+    const long nblk = n_pixblocks * a.n_dchunks;
+    if (nblk <= 0 || nblk > 0x7fffffffL) { set_error("pscv_warp_cost_bwd: bad grid size %ld", nblk); return -1; }
+#define PSCV_BWD(GEOMV, COSTV)                                                                                          \
+    if (geom == GEOMV && cost == COSTV) {                                                                               \
+        hipLaunchKernelGGL((warp_bwd_kernel<TIn, TG, C, LPV, GEOMV, COSTV>), dim3((unsigned)nblk), dim3(256), 0, st, A);  \
+        return 0;                                                                                                       \
+    }
+    PSCV_BWD(PSCV_GEOM_PROJ, PSCV_COST_VARIANCE)
+    PSCV_BWD(PSCV_GEOM_PROJ, PSCV_COST_VARIANCE_CVP)
+    PSCV_BWD(PSCV_GEOM_PROJ, PSCV_COST_SOFTMIN)
+    PSCV_BWD(PSCV_GEOM_PROJ, PSCV_COST_WARP_ONLY)
+    if constexpr (C == 32) {
+        PSCV_BWD(PSCV_GEOM_HOMOG, PSCV_COST_GROUPCORR)
+    }
+    PSCV_BWD(PSCV_GEOM_HOMOG, PSCV_COST_WARP_ONLY)
+#undef PSCV_BWD
+    set_error("pscv_warp_cost_bwd: cost mode %d is not available with geometry %d", cost, geom);
+    return -1;
+}
+
+template <typename TIn, typename TG>
+static int bwd_channels(WarpBwdArgs& A, int C, int geom, int cost, hipStream_t st) {
+    if (C == 32) return bwd_launch<TIn, TG, 32, 2>(A, geom, cost, st);
+    if (C == 16) return bwd_launch<TIn, TG, 16, 2>(A, geom, cost, st);
+    set_error("pscv_warp_cost_bwd: unsupported channel count C=%d (16 or 32)", C);
+    return -1;
+}
+
+}  // namespace pscv
+
+extern "C" int pscv_warp_cost_bwd(const void* ref, const void* const* srcs, int n_src, const float* cams, const float* depth,
+                                  long depth_bstride, int depth_per_pixel, int geom, int cost, float temp, const void* grad_out,
+                                  float* dref, float* const* dsrcs, float* dtemp, int B, int C, int h, int w, int hs, int ws,
+                                  int D, int in_dtype, int grad_dtype, void* stream) {
+    using namespace pscv;
+    PSCV_CHECK_ARG(n_src >= 1 && n_src <= PSCV_MAX_SRC, "pscv_warp_cost_bwd: n_src=%d outside [1,%d]", n_src, PSCV_MAX_SRC);
+    PSCV_CHECK_ARG(srcs && cams && depth && grad_out && dsrcs, "pscv_warp_cost_bwd: null pointer argument");
+    PSCV_CHECK_ARG(cost == PSCV_COST_WARP_ONLY || ref, "pscv_warp_cost_bwd: ref is required for cost mode %d", cost);
+    PSCV_CHECK_ARG(B > 0 && h > 0 && w > 0 && hs > 1 && ws > 1 && D > 0, "pscv_warp_cost_bwd: bad sizes");
+    PSCV_CHECK_ARG((long)hs * ws < (1L << 24) && (long)hs * ws * C * 4 < (1L << 32), "pscv_warp_cost_bwd: source map %dx%dx%d too large", hs, ws, C);
+    WarpBwdArgs A;
+    WarpArgs& a = A.w;
+    a.ref = ref;
+    for (int i = 0; i < PSCV_MAX_SRC; ++i) { a.src[i] = i < n_src ? srcs[i] : nullptr; A.dsrc[i] = i < n_src ? dsrcs[i] : nullptr; }
+    for (int i = 0; i < n_src; ++i) PSCV_CHECK_ARG(srcs[i] && dsrcs[i], "pscv_warp_cost_bwd: srcs[%d] / dsrcs[%d] is null", i, i);
+    a.cams = cams; a.depth = depth; a.out = nullptr;
+    a.depth_bstride = depth_bstride;
+    a.n_src = n_src; a.B = B; a.h = h; a.w = w; a.hs = hs; a.ws = ws; a.D = D;
+    a.depth_per_pixel = depth_per_pixel;
+    a.temp = temp;
+    const long vol = (long)B * D * h * w;
+    a.out_view_stride = 0;
+    A.g = grad_out;
+    A.g_view_stride = cost == PSCV_COST_GROUPCORR ? vol * (C / 4) : vol * C;
+    A.dref = dref; A.dtemp = dtemp;
+    if (geom == PSCV_GEOM_PROJ) {
+        a.sx = 1.0f; a.sy = 1.0f;
+        a.xlo = -4.5f * (ws - 1); a.xhi = 5.5f * (ws - 1);
+        a.ylo = -4.5f * (hs - 1); a.yhi = 5.5f * (hs - 1);
+    } else {
+        a.sx = (float)(ws - 1) / (float)ws; a.sy = (float)(hs - 1) / (float)hs;
+        a.xlo = -0.05f * (ws - 1); a.xhi = 1.05f * (ws - 1);
+        a.ylo = -0.05f * (hs - 1); a.yhi = 1.05f * (hs - 1);
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int rc;
+    if (in_dtype == PSCV_BF16 && grad_dtype == PSCV_BF16) rc = bwd_channels<bf16_t, bf16_t>(A, C, geom, cost, st);
+    else if (in_dtype == PSCV_F16 && grad_dtype == PSCV_F16) rc = bwd_channels<f16_t, f16_t>(A, C, geom, cost, st);
+    else if (in_dtype == PSCV_F32 && grad_dtype == PSCV_F32) rc = bwd_channels<float, float>(A, C, geom, cost, st);
+    else if (in_dtype == PSCV_BF16 && grad_dtype == PSCV_F32) rc = bwd_channels<bf16_t, float>(A, C, geom, cost, st);
+    else if (in_dtype == PSCV_F16 && grad_dtype == PSCV_F32) rc = bwd_channels<f16_t, float>(A, C, geom, cost, st);
+    else { set_error("pscv_warp_cost_bwd: unsupported dtype pair in=%d grad=%d", in_dtype, grad_dtype); return -1; }
+    if (rc) return rc;
+    PSCV_CHECK_LAUNCH("pscv_warp_cost_bwd");
+    return 0;
+}

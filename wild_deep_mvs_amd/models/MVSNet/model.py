@@ -16,6 +16,7 @@ import torch.nn as nn
 
 from ... import _lib as L
 from ... import ops
+from ... import training as T
 from .module import ConvBnReLU, ConvBnReLU3D, deconv_engine_layer, homo_warping, depth_regression  # noqa: F401
 
 
@@ -123,10 +124,25 @@ class CostRegNet(nn.Module):
             self._layers, self._layers_key = lay, key
         return self._layers
 
+    def train_blocks(self) -> List[T.Block]:
+        """The U-Net as the block list of the training executor (``training.RegressFn``): same dataflow as ``forward``
+        (reference models/MVSNet/model.py:74-84), BatchNorm with batch statistics."""
+        blocks, prev = [], "cost"
+        for i, stride in enumerate((1, 2, 1, 2, 1, 2, 1)):
+            m = getattr(self, f"conv{i}")
+            blocks.append(T.Block(f"conv{i}", prev, m.conv.weight, stride=stride, bn=m.bn, relu=True))
+            prev = f"conv{i}"
+        for name, skip in (("conv7", "conv4"), ("conv9", "conv2"), ("conv11", "conv0")):
+            seq = getattr(self, name)
+            blocks.append(T.Block(name, prev, seq[0].weight, stride=2, transposed=True, bn=seq[1], relu=True, skip=skip))
+            prev = name
+        blocks.append(T.Block("prob", prev, self.prob.weight, bn=None, relu=False, conv_bias=self.prob.bias))
+        return blocks
+
     def forward(self, cost: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
         if self.training:
-            raise NotImplementedError("pscv CostRegNet: training-mode BatchNorm / backward are not implemented yet "
-                                      "(SURVEY.md section 8f-1); call .eval()")
+            raise RuntimeError("pscv CostRegNet: in train() mode the U-Net runs inside training.RegressFn (MVSNet.forward "
+                               "routes there); this entry point is the eval-mode engine")
         B, D, h, w, _ = cost.shape
         if D % 8 or h % 8 or w % 8:
             raise ValueError(f"MVSNet CostRegNet needs D,h,w multiples of 8 (got {D},{h},{w}), as in the reference")
@@ -162,6 +178,8 @@ class MVSNet(nn.Module):
         # 2-D extractor: "pscv" = eight MFMA conv2d launches writing the warp kernel's layout directly (16-bit
         # activations between the layers); "torch" = PyTorch-ROCm in fp32, converted once at the end.
         self.feature_engine = "pscv"
+        # train() mode: gradients span many decades, so the stored activations / gradients default to bf16 there
+        self.train_storage_dtype = torch.bfloat16
 
     # -- upstream ---------------------------------------------------------------------------
     def extract_features(self, imgs: Sequence[torch.Tensor]) -> List[torch.Tensor]:
@@ -210,10 +228,26 @@ class MVSNet(nn.Module):
             taps.update(cost_volume=cost, logits=logits)
         return o["depth"], o["conf"]
 
+    def hot_path_train(self, features: Sequence[torch.Tensor], proj: torch.Tensor, depth_values: torch.Tensor,
+                       reference_frame: int = 0):
+        """train()-mode hot path with autograd: NCHW fp32 feature maps (requiring grad) -> depth, confidence.
+        Forward and backward are HIP launches (training.WarpCostFn / training.RegressFn); BatchNorm3d uses and
+        updates batch statistics like the reference's modules in train() (models/MVSNet/model.py:109-139,74-84)."""
+        V = len(features)
+        src_idx = [i for i in range(V) if i != reference_frame]
+        D, h, w = depth_values.shape[1], features[0].shape[2], features[0].shape[3]
+        if D % 8 or h % 8 or w % 8:
+            raise ValueError(f"MVSNet CostRegNet needs D,h,w multiples of 8 (got {D},{h},{w}), as in the reference")
+        dt = self.train_storage_dtype
+        cams = ops.proj_cams_device(proj.detach().to(torch.float32).contiguous(), reference_frame)
+        cost_mode = L.COST_VARIANCE if self.aggregation == "variance" else L.COST_SOFTMIN
+        temp = self.temp if self.aggregation == "softmin" else None
+        cost = T.WarpCostFn.apply(cams, depth_values, L.GEOM_PROJ, cost_mode, dt, temp, features[reference_frame],
+                                  *[features[i] for i in src_idx])
+        blocks = self.cost_regularization.train_blocks()
+        return T.RegressFn.apply(blocks, depth_values, dt, cost, *T.RegressFn.block_params(blocks))
+
     def forward(self, imgs, K, R, t, depth_min, depth_max, reference_frame=0, **kwargs):
-        if self.training:
-            raise NotImplementedError("pscv MVSNet: the HIP engine is inference-only for now; call .eval() "
-                                      "(backward kernels are the next scope row, SURVEY.md section 8f-1)")
         if isinstance(imgs, torch.Tensor):
             imgs = torch.unbind(imgs, 1)
         scaled_K = K.clone()
@@ -225,6 +259,13 @@ class MVSNet(nn.Module):
         steps = torch.arange(D, device=depth_min.device, dtype=torch.float32).view(1, 1, -1)
         depth_values = depth_min.unsqueeze(-1) + ((depth_max - depth_min) / (D - 1)).unsqueeze(-1) * steps  # model.py:187-189
         dv_ref = depth_values[:, reference_frame].to(torch.float32).contiguous()
+
+        if self.training:
+            # per-view extractor passes like the reference (model.py:101-107): each view normalises with its own batch
+            # statistics; the 2-D extractor is upstream of the path and stays on PyTorch-ROCm autograd in training
+            feats = [self.feature(img) for img in imgs]
+            depth, conf = self.hot_path_train(feats, proj, dv_ref, reference_frame)
+            return {"depth": depth, "depth_est_list": [depth, ], "depth_pair_list": [], "photometric_confidence": conf}
 
         with torch.no_grad():
             feats_cl = self.extract_features_cl(imgs)

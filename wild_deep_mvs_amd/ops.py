@@ -508,3 +508,146 @@ def softargmin(logits: torch.Tensor, depth: Optional[torch.Tensor] = None, *, wa
         index_offset, B, D, h, w, _stream()))
     L.check(rc, "pscv_softargmin")
     return {k: v for k, v in o.items() if v is not None}
+
+
+# --------------------------------------------------------------------------------------------
+# training path: batch-statistics BatchNorm pieces, weight gradients, backward of the sweep
+# --------------------------------------------------------------------------------------------
+_train_ws = {}
+
+
+def _workspace(device, nfloats: int) -> torch.Tensor:
+    """Per-device fp32 scratch for the two-phase reductions, grown on demand (stream-ordered reuse)."""
+    ws = _train_ws.get(device)
+    if ws is None or ws.numel() < nfloats:
+        ws = torch.empty(max(int(nfloats), int(L.lib().pscv_train_workspace_floats())), dtype=torch.float32, device=device)
+        _train_ws[device] = ws
+    return ws
+
+
+def _vol16(x: torch.Tensor, what: str):
+    if x.dtype not in HALF_DTYPES or x.dim() != 5 or x.shape[4] not in (8, 16, 32, 64):
+        raise TypeError(f"pscv.{what}: a 16-bit channels-last volume [B,D,h,w,C] with C in 8/16/32/64 is expected, got "
+                        f"{x.dtype} {tuple(x.shape)}")
+
+
+def bn_stats(y: torch.Tensor) -> torch.Tensor:
+    """y [B,D,h,w,C] 16-bit -> fp32 [2,C]: per-channel sum and sum of squares over all voxels (pscv_bn_stats)."""
+    _dev(y)
+    _vol16(y, "bn_stats")
+    Cc = y.shape[4]
+    sums = torch.empty((2, Cc), dtype=torch.float32, device=y.device)
+    ws = _workspace(y.device, 0)
+    rc = _launch("bn_stats", lambda: L.lib().pscv_bn_stats(_p(y), _dt(y), y.numel() // Cc, Cc, _p(ws), _p(sums), _stream()))
+    L.check(rc, "pscv_bn_stats")
+    return sums
+
+
+def bn_act(y: torch.Tensor, scale: torch.Tensor, bias: torch.Tensor, *, relu: bool, skip: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[relu](y * scale + bias) + skip on a 16-bit channels-last volume (pscv_bn_act)."""
+    _dev(y, scale, bias, skip)
+    _vol16(y, "bn_act")
+    if skip is not None and (skip.shape != y.shape or skip.dtype != y.dtype):
+        raise ValueError("pscv.bn_act: skip must match y")
+    Cc = y.shape[4]
+    out = torch.empty_like(y)
+    rc = _launch("bn_act", lambda: L.lib().pscv_bn_act(_p(y), _dt(y), y.numel() // Cc, Cc, _p(scale), _p(bias), int(relu), _p(skip),
+                                                      _p(out), _stream()))
+    L.check(rc, "pscv_bn_act")
+    return out
+
+
+def bn_bwd_reduce(dact: torch.Tensor, y: torch.Tensor, scale: torch.Tensor, bias: torch.Tensor, *, relu: bool) -> torch.Tensor:
+    """fp32 [2,C]: sum dz and sum dz*y with dz = dact * [y*scale+bias > 0] (pscv_bn_bwd_reduce)."""
+    _dev(dact, y, scale, bias)
+    _vol16(y, "bn_bwd_reduce")
+    if dact.shape != y.shape or dact.dtype != y.dtype:
+        raise ValueError("pscv.bn_bwd_reduce: dact must match y")
+    Cc = y.shape[4]
+    sums = torch.empty((2, Cc), dtype=torch.float32, device=y.device)
+    ws = _workspace(y.device, 0)
+    rc = _launch("bn_bwd_reduce", lambda: L.lib().pscv_bn_bwd_reduce(_p(dact), _p(y), _dt(y), y.numel() // Cc, Cc, _p(scale), _p(bias),
+                                                                    int(relu), _p(ws), _p(sums), _stream()))
+    L.check(rc, "pscv_bn_bwd_reduce")
+    return sums
+
+
+def bn_bwd_apply(dact: torch.Tensor, y: torch.Tensor, scale: torch.Tensor, bias: torch.Tensor, ca: torch.Tensor, cb: torch.Tensor,
+                 cc: torch.Tensor, *, relu: bool) -> torch.Tensor:
+    """dy = ca * dz + cb * y + cc per channel (pscv_bn_bwd_apply)."""
+    _dev(dact, y, scale, bias, ca, cb, cc)
+    _vol16(y, "bn_bwd_apply")
+    Cc = y.shape[4]
+    dy = torch.empty_like(y)
+    rc = _launch("bn_bwd_apply", lambda: L.lib().pscv_bn_bwd_apply(_p(dact), _p(y), _dt(y), y.numel() // Cc, Cc, _p(scale), _p(bias),
+                                                                  int(relu), _p(ca), _p(cb), _p(cc), _p(dy), _stream()))
+    L.check(rc, "pscv_bn_bwd_apply")
+    return dy
+
+
+def softargmin_bwd(logits: torch.Tensor, depth: torch.Tensor, grad_depth: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """logits fp32 [B,D,h,w], depth planes [B,D] / [B,D,h,w], grad_depth fp32 [B,h,w] -> [B,D,h,w,8] in ``dtype``
+    with d loss / d logit in channel 0 and zeros elsewhere (pscv_softargmin_bwd)."""
+    _dev(logits, depth, grad_depth)
+    if logits.dtype != torch.float32 or logits.dim() != 4 or depth.dtype != torch.float32 or grad_depth.dtype != torch.float32:
+        raise TypeError("pscv.softargmin_bwd: fp32 logits [B,D,h,w], fp32 depth planes and fp32 grad_depth expected")
+    B, D, h, w = logits.shape
+    if tuple(grad_depth.shape) != (B, h, w) or depth.shape[:2] != (B, D):
+        raise ValueError("pscv.softargmin_bwd: shape mismatch")
+    out = torch.empty((B, D, h, w, 8), dtype=dtype, device=logits.device)
+    rc = _launch("softargmin_bwd", lambda: L.lib().pscv_softargmin_bwd(_p(logits), _p(depth), depth.stride(0), int(depth.dim() == 4),
+                                                                      _p(grad_depth), _p(out), _TORCH2PSCV[dtype], B, D, h, w, _stream()))
+    L.check(rc, "pscv_softargmin_bwd")
+    return out
+
+
+def conv3d_wgrad(p: torch.Tensor, q: torch.Tensor, *, ca: int, cb: int, stride: int, p_coff: int = 0, q_coff: int = 0) -> torch.Tensor:
+    """dw[a][b][tz,ty,tx] = sum P[o,a] Q[stride*o + t - 1, b] -> fp32 [ca,cb,3,3,3] (pscv_conv3d_wgrad).
+    Conv3d: p = grad of the output, q = input; ConvTranspose3d: p = input, q = grad of the output."""
+    _dev(p, q)
+    _vol16(p, "conv3d_wgrad")
+    _vol16(q, "conv3d_wgrad")
+    B, Dp, Hp, Wp, pcs = p.shape
+    if q.dtype != p.dtype or tuple(q.shape[:4]) != (B, stride * Dp, stride * Hp, stride * Wp):
+        raise ValueError(f"pscv.conv3d_wgrad: q must be [B,{stride}*Dp,{stride}*Hp,{stride}*Wp,*] in p's dtype")
+    n = L.lib().pscv_conv3d_wgrad_workspace(B, Dp, Hp, Wp, ca, cb, stride)
+    if n < 0:
+        L.check(int(n), "pscv_conv3d_wgrad_workspace")
+    ws = _workspace(p.device, n)
+    dw = torch.empty((ca, cb, 3, 3, 3), dtype=torch.float32, device=p.device)
+    rc = _launch(f"conv3d_wgrad[{ca}x{cb},s{stride}]", lambda: L.lib().pscv_conv3d_wgrad(
+        _p(p), pcs, p_coff, ca, _p(q), q.shape[4], q_coff, cb, _dt(p), B, Dp, Hp, Wp, stride, _p(ws), _p(dw), 0, _stream()))
+    L.check(rc, "pscv_conv3d_wgrad")
+    return dw
+
+
+def warp_cost_bwd(ref: Optional[torch.Tensor], srcs: Sequence[torch.Tensor], cams: torch.Tensor, depth: torch.Tensor,
+                  grad_out: torch.Tensor, *, geom: int = L.GEOM_PROJ, cost: int = L.COST_VARIANCE, temp: float = 0.0,
+                  ref_hw: Optional[Sequence[int]] = None, want_dtemp: bool = False):
+    """Backward of ``warp_cost`` to the feature maps: returns (dref fp32 [B,h,w,C] or None, [dsrc fp32 [B,hs,ws,C]], dtemp
+    fp32 [1] or None).  ``grad_out`` has the layout of the forward's output (16-bit like the features, or fp32)."""
+    srcs = list(srcs)
+    _dev(ref, cams, depth, grad_out, *srcs)
+    B, hs, ws, Cc = srcs[0].shape
+    h, w = (ref.shape[1:3] if ref is not None else ((hs, ws) if ref_hw is None else (int(ref_hw[0]), int(ref_hw[1]))))
+    n = len(srcs)
+    D = depth.shape[1]
+    per_pixel = depth.dim() == 4
+    if cost == L.COST_GROUPCORR:
+        shape = (n, B, D, h, w, Cc // 4)
+    elif cost == L.COST_WARP_ONLY:
+        shape = (n, B, D, h, w, Cc)
+    else:
+        shape = (B, D, h, w, Cc)
+    if tuple(grad_out.shape) != shape:
+        raise ValueError(f"pscv.warp_cost_bwd: grad_out has shape {tuple(grad_out.shape)}, expected {shape}")
+    dref = torch.zeros((B, h, w, Cc), dtype=torch.float32, device=srcs[0].device) if ref is not None else None
+    dsrcs = [torch.zeros((B, hs, ws, Cc), dtype=torch.float32, device=srcs[0].device) for _ in srcs]
+    dtemp = torch.zeros((1,), dtype=torch.float32, device=srcs[0].device) if want_dtemp else None
+    sp = (C.c_void_p * n)(*[s.data_ptr() for s in srcs])
+    dp = (C.c_void_p * n)(*[s.data_ptr() for s in dsrcs])
+    rc = _launch(f"warp_cost_bwd[{cost}]", lambda: L.lib().pscv_warp_cost_bwd(
+        _p(ref), sp, n, _p(cams), _p(depth), depth.stride(0), int(per_pixel), geom, cost, float(temp), _p(grad_out), _p(dref), dp,
+        _p(dtemp), B, Cc, h, w, hs, ws, D, _dt(srcs[0]), _dt(grad_out), _stream()))
+    L.check(rc, "pscv_warp_cost_bwd")
+    return dref, dsrcs, dtemp

@@ -203,3 +203,31 @@ TRANSPOSED_KEYS = {
 def sharpened_state_dict(arch: str, template: Mapping[str, Tuple[int, ...]], seed: int = 0):
     """``arch`` in {"mvsnet", "vis", "cvp"}."""
     return make_state_dict(template, seed=seed, transposed_keys=TRANSPOSED_KEYS[arch], **SHARPEN[arch])
+
+
+# ---- training fixtures (shared by tests/golden/gen_golden.py, the oracle tests and the GPU tests) ------------------
+TRAIN_PROB_GAIN = 0.3   # keeps the softmax unsaturated under batch-statistics BatchNorm (mean max-prob ~0.5)
+
+
+def train_state_dict(arch: str, template: Mapping[str, Tuple[int, ...]], seed: int = 0):
+    """Sharpened weights for a train()-mode step: ``sharpened_state_dict`` with the `prob` head scaled down."""
+    sd = sharpened_state_dict(arch, template, seed=seed)
+    for k in list(sd.keys()):
+        if k.endswith("cost_regularization.prob.weight"):
+            sd[k] = sd[k] * TRAIN_PROB_GAIN
+    return sd
+
+
+def train_target(scene, h: int, w: int, seed: int = 11):
+    """Seeded ground-truth depth [B,h,w] and validity mask of the supervised loss (models/trainer.py:163-167)."""
+    g = torch.Generator().manual_seed(seed)
+    dmin, dmax = scene["depth_min"][:, 0].view(-1, 1, 1), scene["depth_max"][:, 0].view(-1, 1, 1)
+    gt = dmin + (dmax - dmin) * (0.2 + 0.6 * torch.rand(dmin.shape[0], h, w, generator=g))
+    mask = (torch.rand(dmin.shape[0], h, w, generator=g) > 0.1).float()
+    return gt, mask
+
+
+def supervised_loss(depth: torch.Tensor, gt: torch.Tensor, mask: torch.Tensor, depth_min: torch.Tensor, depth_max: torch.Tensor):
+    """sum(|d - gt| / interval * mask) / sum(mask), interval = (max - min) / 128 of view 0 (models/trainer.py:163-167)."""
+    interval = ((depth_max - depth_min) / 128)[:, 0].view(-1, 1, 1)
+    return torch.sum(torch.abs(depth - gt) / interval * mask) / torch.sum(mask)
