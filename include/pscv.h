@@ -79,6 +79,8 @@ int pscv_abi_version(void);
  *               direct-gather kernel, which measured faster on MI355X.  "warp_lpv" != 0 also selects the direct kernel.
  *   "sweep_dc"  depth planes per workgroup of the 32->8 depth-sweep conv (0 = default heuristic)
  *   "sweep_th16" 1: the 32->8 depth-sweep conv uses 16-row tiles / 512 threads; 0 (default): 8-row tiles / 256 threads
+ *   "warp_bwd_direct" 1: pscv_warp_cost_bwd issues one global float atomic per tap; 0 (default): accumulates per-workgroup
+ *               LDS patches and flushes them coalesced
  *   "conv_small_tiles"  1 (default): small volumes use 1x4x16 tiles with the output channels split over
  *               blockIdx.y; 0: always the large-tile variant */
 int pscv_set_tuning(const char* key, int value);

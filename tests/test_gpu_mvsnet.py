@@ -133,10 +133,14 @@ def test_list_input_and_reference_frame(env):
     assert s["rel_l1"] <= 1e-3
 
 
-def test_training_mode_fails_loudly(env):
+def test_training_mode_runs_on_the_engine(env):
+    """train() mode is the engine's autograd path (tests/test_gpu_train.py holds its parity); the eval-only entry point of
+    the U-Net refuses to be called in train() mode instead of silently folding stale running statistics."""
     L, ops, synthetic, MVSNet, O = env
     net, _ = _model(env, "variance", 0)
     net.train()
     scene = {k: v.cuda() for k, v in synthetic.make_scene(1, 3, 64, 96).items()}
-    with pytest.raises(NotImplementedError):
-        net(scene["imgs"], scene["K"], scene["R"], scene["t"], scene["depth_min"], scene["depth_max"])
+    out = net(scene["imgs"], scene["K"], scene["R"], scene["t"], scene["depth_min"], scene["depth_max"])
+    assert out["depth"].requires_grad
+    with pytest.raises(RuntimeError):
+        net.cost_regularization(torch.zeros(1, 16, 16, 24, 32, dtype=torch.float16, device="cuda"))

@@ -186,22 +186,33 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     }
 }
 
-// dw[a][b][t] = sum_blk part[blk][t][a][b], fixed order
-__global__ void wgrad_finish_kernel(const float* __restrict__ part, int nblk, int ca, int cb, int ca16, int cb16,
-                                    float* __restrict__ dw, int accumulate) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// dw[a][b][t] = sum_blk part[blk][t][a][b], fixed order.  Block = 16 outputs x 16 workgroup slices (each thread walks
+// nblk / 16 partials, then the slices are combined through LDS in slice order): the per-output chain of dependent L2 reads
+// is 16x shorter than one thread per output.
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restrict__ part, int nblk, int ca, int cb, int ca16, int cb16,
+                                                           float* __restrict__ dw, int accumulate) {
+    __shared__ float red[16][17];
+    const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + c;
     const int n = 27 * ca * cb;
-    if (i >= n) return;
-    const int t = i % 27, ab = i / 27;
-    const int b = ab % cb, aa = ab / cb;
-    const long off = ((long)t * ca16 + aa) * cb16 + b;
-    const long stride = 27L * ca16 * cb16;
     float s0 = 0.f, s1 = 0.f;
-    int k = 0;
-    for (; k + 1 < nblk; k += 2) { s0 += part[off + k * stride]; s1 += part[off + (k + 1) * stride]; }
-    if (k < nblk) s0 += part[off + k * stride];
-    const float v = s0 + s1;
-    dw[i] = accumulate ? dw[i] + v : v;
+    if (i < n) {
+        const int t = i % 27, ab = i / 27;
+        const int b = ab % cb, aa = ab / cb;
+        const long off = ((long)t * ca16 + aa) * cb16 + b;
+        const long stride = 27L * ca16 * cb16;
+        int k = g;
+        for (; k + 16 < nblk; k += 32) { s0 += part[off + k * stride]; s1 += part[off + (k + 16) * stride]; }
+        if (k < nblk) s0 += part[off + k * stride];
+    }
+    red[g][c] = s0 + s1;
+    __syncthreads();
+    if (g == 0 && i < n) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += red[k][c];
+        dw[i] = accumulate ? dw[i] + v : v;
+    }
 }
 
 static inline int wg_ceil(int a, int b) { return (a + b - 1) / b; }
@@ -277,7 +288,7 @@ extern "C" int pscv_conv3d_wgrad(const void* p, int p_cstride, int p_coff, int c
     if (rc) return rc;
     PSCV_CHECK_LAUNCH("pscv_conv3d_wgrad");
     const int n = 27 * ca * cb;
-    hipLaunchKernelGGL(wgrad_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, st, workspace, pl.nblk, ca, cb, pl.ca16, pl.cb16, dw, accumulate);
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3((n + 15) / 16), dim3(256), 0, st, workspace, pl.nblk, ca, cb, pl.ca16, pl.cb16, dw, accumulate);
     PSCV_CHECK_LAUNCH("pscv_conv3d_wgrad(finish)");
     return 0;
 }

@@ -243,6 +243,7 @@ extern int g_sweep_dc;
 }
 extern int g_c1_nb;
 namespace pscv {
+extern int g_warp_bwd_direct;    // warp_bwd.hip
 static int g_warp_q2 = 1;        // 1: 32-channel 16-bit sweeps use the quad-mapped kernel (warp_cost_q2.hip)
 int warp_cost_q2_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, int out_dtype, int ppd_override, hipStream_t st);
 int warp_cost_tiled_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, int out_dtype, int ppd_override, hipStream_t st);
@@ -334,6 +335,7 @@ extern "C" int pscv_set_tuning(const char* key, int value) {
     if (!strcmp(key, "c1_nb")) { g_c1_nb = value; return 0; }
     if (!strcmp(key, "sweep_th16")) { g_sweep_th16 = value; return 0; }
     if (!strcmp(key, "sweep_dc")) { g_sweep_dc = value; return 0; }
+    if (!strcmp(key, "warp_bwd_direct")) { g_warp_bwd_direct = value; return 0; }
     set_error("pscv_set_tuning: unknown key '%s'", key);
     return -1;
 }
