@@ -15,9 +15,19 @@ BN_EPS = 1e-5
 PYR = ("conv0aa", "conv0ba", "conv0bb", "conv0bc", "conv0bd", "conv0be", "conv0bf", "conv0bg", "conv0bh")
 
 
-def _bn(x, sd: SD, p: str):
-    return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"],
-                        training=False, eps=BN_EPS)
+def _bn(x, sd: SD, p: str, training: bool = False, new_stats: Optional[dict] = None):
+    """eval: running statistics; training: batch statistics of ``nn.BatchNorm3d.train()`` -- the running statistics the
+    module would hold afterwards go to ``new_stats`` (read from there first, so several passes through the same net chain
+    their updates like the reference's module does when it is called once per pyramid level)."""
+    if not training:
+        return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"],
+                            training=False, eps=BN_EPS)
+    src = new_stats if (new_stats is not None and p + ".running_mean" in new_stats) else sd
+    rm, rv = src[p + ".running_mean"].detach().clone(), src[p + ".running_var"].detach().clone()
+    y = F.batch_norm(x, rm, rv, sd[p + ".weight"], sd[p + ".bias"], training=True, momentum=0.1, eps=BN_EPS)
+    if new_stats is not None:
+        new_stats[p + ".running_mean"], new_stats[p + ".running_var"] = rm, rv
+    return y
 
 
 def feature_pyramid(img, sd: SD, scales: int, p: str = "model.featurePyramid"):
@@ -62,16 +72,18 @@ def homo_warping(src_feature, ref_in, src_in, ref_ex, src_ex, depth_hypos, ref_s
     B, C, hs, ws = src_feature.shape
     h, w = (hs, ws) if ref_shape is None else (int(ref_shape[0]), int(ref_shape[1]))
     D = depth_hypos.shape[1]
-    proj = torch.matmul(_proj(src_in, src_ex), torch.inverse(_proj(ref_in, ref_ex)))
-    rot, trans = proj[:, :3, :3], proj[:, :3, 3:4]
-    yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
-    pix = torch.stack((xx.reshape(-1), yy.reshape(-1), torch.ones(h * w))).unsqueeze(0).repeat(B, 1, 1)
-    q = torch.matmul(rot, pix).unsqueeze(2) * depth_hypos.reshape(B, 1, D, -1) + trans.view(B, 3, 1, 1)
-    uv = q[:, :2] / q[:, 2:3]
-    uv = torch.where((q[:, 2:3] <= 0).expand(-1, 2, -1, -1), torch.full_like(uv, -10.0), uv)
-    gx = uv[:, 0] / ((ws - 1) / 2) - 1
-    gy = uv[:, 1] / ((hs - 1) / 2) - 1
-    grid = torch.stack((gx, gy), dim=3).clamp(-10, 10)
+    with torch.no_grad():   # modules.py:83 / :241: the sampling grid carries no gradient (matters in train(): the refinement
+        # hypotheses depend on the coarse depth, and the reference lets that reach the depth only through the regression)
+        proj = torch.matmul(_proj(src_in, src_ex), torch.inverse(_proj(ref_in, ref_ex)))
+        rot, trans = proj[:, :3, :3], proj[:, :3, 3:4]
+        yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+        pix = torch.stack((xx.reshape(-1), yy.reshape(-1), torch.ones(h * w))).unsqueeze(0).repeat(B, 1, 1)
+        q = torch.matmul(rot, pix).unsqueeze(2) * depth_hypos.reshape(B, 1, D, -1) + trans.view(B, 3, 1, 1)
+        uv = q[:, :2] / q[:, 2:3]
+        uv = torch.where((q[:, 2:3] <= 0).expand(-1, 2, -1, -1), torch.full_like(uv, -10.0), uv)
+        gx = uv[:, 0] / ((ws - 1) / 2) - 1
+        gy = uv[:, 1] / ((hs - 1) / 2) - 1
+        grid = torch.stack((gx, gy), dim=3).clamp(-10, 10)
     out = F.grid_sample(src_feature, grid.view(B, D * h, w, 2), mode="bilinear", padding_mode="zeros", align_corners=True)
     return out.view(B, C, D, h, w)
 
@@ -88,18 +100,20 @@ def variance_cost(ref_fea, warped: Sequence[torch.Tensor]):
     return sq / N - (s / N) ** 2
 
 
-def cbr3(x, sd, p, stride=1):
-    return F.relu(_bn(F.conv3d(x, sd[p + ".conv.weight"], None, stride=stride, padding=1), sd, p + ".bn"))
+def cbr3(x, sd, p, stride=1, training=False, new_stats=None):
+    return F.relu(_bn(F.conv3d(x, sd[p + ".conv.weight"], None, stride=stride, padding=1), sd, p + ".bn", training, new_stats))
 
 
-def cost_reg_net(x, sd: SD, p: str = "model.cost_reg_refine", taps: Optional[dict] = None):
+def cost_reg_net(x, sd: SD, p: str = "model.cost_reg_refine", taps: Optional[dict] = None, training: bool = False,
+                 new_stats: Optional[dict] = None):
     """CVP ``CostRegNet`` net.py:50-85: conv0,0a 16->16; conv1 16->32 s2; conv2,2a; conv3 32->64 (stride 1); conv4,4a;
     conv5^T 64->32 (stride 1, op 0) + conv2; conv6^T 32->16 (s2, op 1) + conv0; prob0 16->1.  -> [B,D,h,w]."""
-    c0 = cbr3(cbr3(x, sd, p + ".conv0"), sd, p + ".conv0a")
-    c2 = cbr3(cbr3(cbr3(c0, sd, p + ".conv1", 2), sd, p + ".conv2"), sd, p + ".conv2a")
-    c4 = cbr3(cbr3(cbr3(c2, sd, p + ".conv3"), sd, p + ".conv4"), sd, p + ".conv4a")
-    c5 = c2 + F.relu(_bn(F.conv_transpose3d(c4, sd[p + ".conv5.0.weight"], None, stride=1, padding=1, output_padding=0), sd, p + ".conv5.1"))
-    c6 = c0 + F.relu(_bn(F.conv_transpose3d(c5, sd[p + ".conv6.0.weight"], None, stride=2, padding=1, output_padding=1), sd, p + ".conv6.1"))
+    kw = dict(training=training, new_stats=new_stats)
+    c0 = cbr3(cbr3(x, sd, p + ".conv0", **kw), sd, p + ".conv0a", **kw)
+    c2 = cbr3(cbr3(cbr3(c0, sd, p + ".conv1", 2, **kw), sd, p + ".conv2", **kw), sd, p + ".conv2a", **kw)
+    c4 = cbr3(cbr3(cbr3(c2, sd, p + ".conv3", **kw), sd, p + ".conv4", **kw), sd, p + ".conv4a", **kw)
+    c5 = c2 + F.relu(_bn(F.conv_transpose3d(c4, sd[p + ".conv5.0.weight"], None, stride=1, padding=1, output_padding=0), sd, p + ".conv5.1", **kw))
+    c6 = c0 + F.relu(_bn(F.conv_transpose3d(c5, sd[p + ".conv6.0.weight"], None, stride=2, padding=1, output_padding=1), sd, p + ".conv6.1", **kw))
     logits = F.conv3d(c6, sd[p + ".prob0.weight"], sd[p + ".prob0.bias"], padding=1).squeeze(1)
     if taps is not None:
         taps.update(conv0=c0, conv2=c2, conv4=c4, conv5=c5, conv6=c6, logits=logits)
@@ -152,10 +166,11 @@ def cal_depth_hypo(ref_depths, ref_in, src_in, ref_ex, src_ex, depth_min, depth_
 
 
 def forward(imgs, K, R, t, depth_min, depth_max, sd: SD, nscale: int = 2, training_hypos: bool = False,
-            reference_frame: int = 0, taps: Optional[dict] = None):
+            reference_frame: int = 0, taps: Optional[dict] = None, training: bool = False, new_stats: Optional[dict] = None):
     """``Frontend.forward`` frontend.py:10-38 + ``network.forward`` net.py:96-229.  ``training_hypos`` selects the
     train()-mode hypothesis rule (48 coarse planes, fixed halving intervals) instead of the eval() one (96 planes,
-    calDepthHypo); BatchNorm is eval-mode in both."""
+    calDepthHypo); ``training`` additionally switches BatchNorm to batch statistics (the module in ``train()``: pass both
+    for a training step; gradients then come from ATen autograd like in the reference)."""
     if isinstance(imgs, torch.Tensor):
         imgs = list(torch.unbind(imgs, 1))
     V = len(imgs)
@@ -179,7 +194,7 @@ def forward(imgs, K, R, t, depth_min, depth_max, sd: SD, nscale: int = 2, traini
                            ref_pyr[-1].shape[2:]) for i in range(len(src_idx))]
     cost = variance_cost(ref_pyr[-1], warped)
     level_taps = {} if taps is not None else None
-    logits = cost_reg_net(cost, sd, taps=level_taps)
+    logits = cost_reg_net(cost, sd, taps=level_taps, training=training, new_stats=new_stats)
     prob = F.softmax(logits, dim=1)
     depth = torch.sum(prob * hypos.view(*hypos.shape, 1, 1), 1)
     est = [depth]
@@ -196,7 +211,7 @@ def forward(imgs, K, R, t, depth_min, depth_max, sd: SD, nscale: int = 2, traini
                                ref_pyr[level].shape[2:]) for i in range(len(src_idx))]
         cost = variance_cost(ref_pyr[level], warped)
         lt = {} if taps is not None else None
-        logits = cost_reg_net(cost, sd, taps=lt)
+        logits = cost_reg_net(cost, sd, taps=lt, training=training, new_stats=new_stats)
         prob = F.softmax(logits, dim=1)
         depth = torch.sum(prob * hyp, 1)
         est.append(depth)

@@ -79,10 +79,11 @@ def homo_warping(src_fea, src_proj, ref_proj, depth_values, ref_shape: Optional[
     B, C, hs, ws = src_fea.shape
     h, w = (hs, ws) if ref_shape is None else (int(ref_shape[0]), int(ref_shape[1]))
     D = depth_values.shape[1]
-    u, v, _ = sweep_pixel_coords(src_proj, ref_proj, depth_values, (h, w))
-    gx = u / ((ws - 1) / 2) - 1
-    gy = v / ((hs - 1) / 2) - 1
-    grid = torch.stack((gx, gy), dim=3).clamp(-10, 10)  # [B,D,h*w,2]
+    with torch.no_grad():   # module.py:127: the sampling grid carries no gradient
+        u, v, _ = sweep_pixel_coords(src_proj, ref_proj, depth_values, (h, w))
+        gx = u / ((ws - 1) / 2) - 1
+        gy = v / ((hs - 1) / 2) - 1
+        grid = torch.stack((gx, gy), dim=3).clamp(-10, 10)  # [B,D,h*w,2]
     out = F.grid_sample(src_fea, grid.view(B, D * h, w, 2), mode="bilinear", padding_mode="zeros", align_corners=True)
     return out.view(B, C, D, h, w)
 

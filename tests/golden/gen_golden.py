@@ -292,6 +292,45 @@ def gen_cvp(tag, *, H=32, W=48, V=3, nscale=2, seed=0, scene_seed=0, baseline_sc
 PLANES96 = [0, 40, 95]
 
 
+def gen_cvp_train(tag, *, H=64, W=96, V=3, nscale=2, seed=0, scene_seed=0, baseline_scale=8, B=2):
+    """One training step of the reference's CVP-MVSNet in train() mode (48 coarse planes, fixed halving refinement
+    intervals, batch-statistics BatchNorm, the regulariser called once per pyramid level), supervised loss over
+    depth_est_list like models/trainer.py:118-167, backward."""
+    sys.path.insert(0, REPO)
+    from wild_deep_mvs_amd import synthetic
+    from models.CVP_MVSNet.frontend import Frontend  # reference
+
+    torch.manual_seed(0)
+    net = Frontend()
+    sd = synthetic.train_state_dict("cvp", synthetic.template_of(net), seed=seed)
+    net.load_state_dict(sd, strict=True)
+    net.train()
+    net.model.nscale = nscale
+    scene = synthetic.make_scene(B, V, H, W, seed=scene_seed)
+    scene["t"] = scene["t"] * baseline_scale
+    out = net(scene["imgs"], scene["K"], scene["R"], scene["t"], scene["depth_min"], scene["depth_max"], nscale=nscale)
+    gt, mask = synthetic.train_target(scene, H, W)
+    loss = synthetic.supervised_loss_list(out["depth_est_list"], gt, mask, scene["depth_min"], scene["depth_max"])
+    loss.backward()
+    grads = {k: p.grad for k, p in net.named_parameters()}
+    norms = {k: float(g.norm()) for k, g in grads.items()}
+    keep = [k for k in grads if "cost_reg_refine" in k and (".bn." in k or ".1." in k or "prob0" in k or "conv0." in k or "conv3." in k
+                                                             or "conv5." in k or "conv6." in k)]
+    keep += ["model.featurePyramid.conv0aa.0.weight", "model.featurePyramid.conv0bh.0.weight", "model.featurePyramid.conv0bh.0.bias"]
+    stats = {k: v for k, v in net.state_dict().items() if "running_" in k}
+    print(f"[{tag}] loss {float(loss):.5f}, depth range {out['depth'].min():.3f}..{out['depth'].max():.3f}, "
+          f"|g conv0| {norms['model.cost_reg_refine.conv0.conv.weight']:.3e}, |g pyramid conv0aa| {norms['model.featurePyramid.conv0aa.0.weight']:.3e}")
+    arrays = {"meta": np.array([H, W, V, nscale, seed, scene_seed, baseline_scale, B], dtype=np.int64), "loss": np.float32(float(loss)),
+              "norm_keys": np.array(list(norms.keys())), "norm_vals": np.array(list(norms.values()), dtype=np.float64)}
+    for i, d in enumerate(out["depth_est_list"]):
+        arrays[f"depth_est_{i}"] = np32(d)
+    for k in keep:
+        arrays["grad:" + k] = np32(grads[k])
+    for k, v in stats.items():
+        arrays["stat:" + k] = np32(v)
+    save(f"{tag}.npz", **arrays)
+
+
 def gen_state_dict_keys():
     """Key order, names and shapes of the reference's state dicts (the checkpoint-compat contract)."""
     import json
@@ -368,6 +407,7 @@ def main():
         "mvsnet_s_train": lambda: gen_mvsnet_train("softmin", "mvsnet_s_train", seed=1),
         "vis": lambda: gen_vis("vis_tiny"),
         "cvp": lambda: gen_cvp("cvp_tiny"),
+        "cvp_train": lambda: gen_cvp_train("cvp_train"),
         "keys": gen_state_dict_keys,
         "filter": lambda: (gen_filter("filter_tiny", V=6, behind_view=4, half_res_view=3, near_view=2),
                            gen_filter("filter_upsample", V=4, seed=3, upsample=True, downscale=2, num_consistent=2)),

@@ -23,7 +23,7 @@ def oracle_train_step(agg, H, W, V, D, seed, scene_seed, B, store=None):
     loss = synthetic.supervised_loss(depth, gt, mask, scene["depth_min"], scene["depth_max"])
     loss.backward()
     grads = {k: v.grad for k, v in sd.items() if isinstance(v, torch.Tensor) and v.requires_grad}
-    return depth.detach(), float(loss), grads, stats
+    return depth.detach(), float(loss.detach()), grads, stats
 
 
 @pytest.mark.parametrize("fname,agg", [("mvsnet_train.npz", "variance"), ("mvsnet_s_train.npz", "softmin")])
@@ -39,5 +39,42 @@ def test_oracle_train_step_matches_reference(fname, agg):
     for k in g:
         if k.startswith("grad:"):
             check_close(k, grads[k[5:]], t(g[k]), rel_l2=2e-3)
+        if k.startswith("stat:"):
+            check_close(k, stats[k[5:]], t(g[k]), rel_l2=1e-4)
+
+
+def cvp_oracle_train_step(H, W, V, nscale, seed, scene_seed, bscale, B):
+    import json, os
+    from collections import OrderedDict
+    from _util import GOLDEN
+    from oracle import cvpmvsnet as OC
+    keys = json.load(open(os.path.join(GOLDEN, "state_dict_keys.json")))["cvp"]
+    sd = synthetic.train_state_dict("cvp", OrderedDict((k, tuple(s)) for k, s in keys), seed=seed)
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v) for k, v in sd.items()}
+    scene = synthetic.make_scene(B, V, H, W, seed=scene_seed)
+    scene["t"] = scene["t"] * bscale
+    stats = {}
+    out = OC.forward(scene["imgs"], scene["K"], scene["R"], scene["t"], scene["depth_min"], scene["depth_max"], sd, nscale=nscale,
+                     training_hypos=True, training=True, new_stats=stats)
+    gt, mask = synthetic.train_target(scene, H, W)
+    loss = synthetic.supervised_loss_list(out["depth_est_list"], gt, mask, scene["depth_min"], scene["depth_max"])
+    loss.backward()
+    grads = {k: v.grad for k, v in sd.items() if isinstance(v, torch.Tensor) and v.requires_grad}
+    return [d.detach() for d in out["depth_est_list"]], float(loss.detach()), grads, stats
+
+
+def test_cvp_oracle_train_step_matches_reference():
+    g = load_golden("cvp_train.npz")
+    H, W, V, nscale, seed, scene_seed, bscale, B = [int(x) for x in g["meta"]]
+    depths, loss, grads, stats = cvp_oracle_train_step(H, W, V, nscale, seed, scene_seed, bscale, B)
+    for i, d in enumerate(depths):
+        check_close(f"depth_est_{i}", d, t(g[f"depth_est_{i}"]), max_abs=3e-4)
+    assert abs(loss - float(g["loss"])) <= 2e-4 * abs(float(g["loss"])), (loss, float(g["loss"]))
+    for k, ref in zip(g["norm_keys"], g["norm_vals"]):
+        got = float(grads[str(k)].norm())
+        assert abs(got - ref) <= 3e-3 * ref + 1e-6, (k, got, ref)
+    for k in g:
+        if k.startswith("grad:"):
+            check_close(k, grads[k[5:]], t(g[k]), rel_l2=3e-3)
         if k.startswith("stat:"):
             check_close(k, stats[k[5:]], t(g[k]), rel_l2=1e-4)

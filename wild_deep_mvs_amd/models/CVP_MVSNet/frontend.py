@@ -19,6 +19,14 @@ class Frontend(nn.Module):
         self.model.storage_dtype = dt
 
     @property
+    def train_storage_dtype(self):
+        return self.model.train_storage_dtype
+
+    @train_storage_dtype.setter
+    def train_storage_dtype(self, dt):
+        self.model.train_storage_dtype = dt
+
+    @property
     def feature_engine(self):
         return self.model.feature_engine
 

@@ -10,6 +10,7 @@ import torch.nn.functional as F
 
 from .... import _lib as L
 from .... import ops
+from .... import training as T
 from ...MVSNet.module import deconv_engine_layer
 from .modules import (ConvBnReLU3D, calDepthHypo, calSweepingDepthHypo, conditionIntrinsics, conv, proj_cost, _cams)
 
@@ -94,9 +95,24 @@ class CostRegNet(nn.Module):
             self._lay, self._key = lay, key
         return self._lay
 
+    def train_blocks(self):
+        """The regulariser as the block list of the training executor (``training.RegressFn``): the dataflow of ``forward``
+        (reference net.py:76-85) with batch-statistics BatchNorm."""
+        blocks, prev = [], "cost"
+        for name, stride in (("conv0", 1), ("conv0a", 1), ("conv1", 2), ("conv2", 1), ("conv2a", 1), ("conv3", 1), ("conv4", 1),
+                             ("conv4a", 1)):
+            m = getattr(self, name)
+            blocks.append(T.Block(name, prev, m.conv.weight, stride=stride, bn=m.bn, relu=True))
+            prev = name
+        blocks.append(T.Block("conv5", prev, self.conv5[0].weight, stride=1, transposed=True, bn=self.conv5[1], relu=True, skip="conv2a"))
+        blocks.append(T.Block("conv6", "conv5", self.conv6[0].weight, stride=2, transposed=True, bn=self.conv6[1], relu=True, skip="conv0a"))
+        blocks.append(T.Block("prob0", "conv6", self.prob0.weight, bn=None, relu=False, conv_bias=self.prob0.bias))
+        return blocks
+
     def forward(self, x: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
         if self.training:
-            raise NotImplementedError("pscv CVP CostRegNet: inference only for now; call .eval()")
+            raise RuntimeError("pscv CVP CostRegNet: in train() mode the regulariser runs inside training.RegressFn "
+                               "(network.forward routes there); this entry point is the eval-mode engine")
         B, D, h, w, _ = x.shape
         if D % 2 or h % 2 or w % 2:
             raise ValueError(f"CVP CostRegNet needs even D,h,w (got {D},{h},{w}), as in the reference")
@@ -122,10 +138,49 @@ class network(nn.Module):
         # 2-D pyramid tower: "pscv" = MFMA conv2d launches writing channels-last 16-bit maps (default);
         # "torch" = PyTorch-ROCm in fp32, converted where the warp kernel reads them
         self.feature_engine = "pscv"
+        self.train_storage_dtype = torch.bfloat16   # train(): bf16 activations / gradients by default (range), fp32 accumulation
+
+    def forward_train(self, ref_img, src_imgs, ref_in, src_in, ref_ex, src_ex, depth_min, depth_max, nscale):
+        """train()-mode forward with autograd (reference net.py:96-229 with ``self.training``): 48 coarse planes, fixed
+        halving refinement intervals, batch-statistics BatchNorm, the regulariser applied once per pyramid level.  The
+        pyramid tower stays on PyTorch-ROCm autograd (upstream of the path); warp + cost and the regulariser + regression are
+        the engine's autograd nodes.  The sampling grid carries no gradient (modules.py:83,241), so a refinement level's
+        depth depends on the upsampled coarse depth only through ``sum_d p_d (depth_up + off_d) = depth_up + sum_d p_d off_d``:
+        the engine regresses the per-batch offsets and the ``depth_up +`` stays an autograd add."""
+        nsrc = len(src_imgs)
+        dt = self.train_storage_dtype
+        ref_pyr = self.featurePyramid(ref_img, nscale)
+        src_pyrs = [self.featurePyramid(s, nscale) for s in src_imgs]
+        ref_in_ms = conditionIntrinsics(ref_in, ref_img.shape, [f.shape for f in ref_pyr])
+        src_in_ms = torch.stack([conditionIntrinsics(src_in[:, i], ref_img.shape, [f.shape for f in src_pyrs[i]])
+                                 for i in range(nsrc)]).permute(1, 0, 2, 3, 4)
+        blocks = self.cost_reg_refine.train_blocks()
+        params = T.RegressFn.block_params(blocks)
+
+        def level_cost(level, hypos):
+            cams = _cams(ref_in_ms[:, level], [src_in_ms[:, i, level] for i in range(nsrc)], ref_ex, [src_ex[:, i] for i in range(nsrc)])
+            return T.WarpCostFn.apply(cams, hypos, L.GEOM_PROJ, L.COST_VARIANCE_CVP, dt, None, ref_pyr[level],
+                                      *[p[level] for p in src_pyrs])
+
+        hypos = calSweepingDepthHypo(ref_in_ms[:, -1], src_in_ms[:, 0, -1], ref_ex, src_ex, depth_min, depth_max,
+                                     nhypothesis_init=48).to(torch.float32).contiguous()
+        depth, conf = T.RegressFn.apply(blocks, hypos, dt, level_cost(nscale - 1, hypos), *params)
+        depth_est_list = [depth]
+        for id_level, level in enumerate(range(nscale - 2, -1, -1)):
+            depth_up = F.interpolate(depth[None, :], size=None, scale_factor=2, mode='bicubic', align_corners=None).squeeze(0)
+            interval = ((depth_max - depth_min) / 48 / 2 ** (id_level + 1)).to(torch.float32)              # net.py:178-181
+            offs = torch.stack([i * interval for i in range(-4, 4)], dim=1).contiguous()                    # [B,8]
+            hyp = (depth_up.detach().unsqueeze(1) + offs.view(-1, 8, 1, 1)).contiguous()                    # [B,8,H,W] for the warp
+            resid, conf = T.RegressFn.apply(blocks, offs, dt, level_cost(level, hyp), *params)
+            depth = depth_up + resid
+            depth_est_list.append(depth)
+        depth_est_list.reverse()
+        return {"depth_est_list": depth_est_list, "prob_confidence": conf}
 
     def forward(self, ref_img, src_imgs, ref_in, src_in, ref_ex, src_ex, depth_min, depth_max, **kwargs):
         if self.training:
-            raise NotImplementedError("pscv CVP-MVSNet: inference only for now; call .eval()")
+            return self.forward_train(ref_img, src_imgs, ref_in, src_in, ref_ex, src_ex, depth_min, depth_max,
+                                      kwargs.get("nscale", self.nscale))
         nscale = kwargs.get("nscale", self.nscale)
         taps = kwargs.get("taps")
         nsrc = len(src_imgs)

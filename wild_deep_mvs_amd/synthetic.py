@@ -213,7 +213,7 @@ def train_state_dict(arch: str, template: Mapping[str, Tuple[int, ...]], seed: i
     """Sharpened weights for a train()-mode step: ``sharpened_state_dict`` with the `prob` head scaled down."""
     sd = sharpened_state_dict(arch, template, seed=seed)
     for k in list(sd.keys()):
-        if k.endswith("cost_regularization.prob.weight"):
+        if k.endswith("cost_regularization.prob.weight") or k.endswith("cost_reg_refine.prob0.weight"):
             sd[k] = sd[k] * TRAIN_PROB_GAIN
     return sd
 
@@ -231,3 +231,20 @@ def supervised_loss(depth: torch.Tensor, gt: torch.Tensor, mask: torch.Tensor, d
     """sum(|d - gt| / interval * mask) / sum(mask), interval = (max - min) / 128 of view 0 (models/trainer.py:163-167)."""
     interval = ((depth_max - depth_min) / 128)[:, 0].view(-1, 1, 1)
     return torch.sum(torch.abs(depth - gt) / interval * mask) / torch.sum(mask)
+
+
+def supervised_loss_list(depth_list: Sequence[torch.Tensor], gt: torch.Tensor, mask: torch.Tensor, depth_min: torch.Tensor,
+                         depth_max: torch.Tensor, reference_frame: int = 0):
+    """The supervised loss of models/trainer.py:118-167 over ``depth_est_list``: ground truth and mask are bilinearly
+    resized to each estimate (the mask keeps only pixels whose four neighbours are valid), every level has factor 1."""
+    import torch.nn.functional as F
+    interval = ((depth_max - depth_min) / 128)[:, reference_frame].view(-1, 1, 1)
+    loss = 0
+    for d in depth_list:
+        if d is None:
+            continue
+        hd, wd = d.shape[1:]
+        g = F.interpolate(gt.unsqueeze(1), size=(hd, wd), mode="bilinear", align_corners=False).squeeze(1)
+        m = (F.interpolate(mask.unsqueeze(1).float(), size=(hd, wd), mode="bilinear", align_corners=False).squeeze(1) == 1).float()
+        loss = loss + torch.sum(torch.abs(d - g) / interval * m) / torch.sum(m)
+    return loss
