@@ -303,6 +303,20 @@ int pscv_warp_cost_bwd(const void* ref, const void* const* srcs, int n_src, cons
                        float* dref, float* const* dsrcs, float* dtemp, int B, int C, int h, int w, int hs, int ws, int D,
                        int in_dtype, int grad_dtype, void* stream);
 
+/*
+ * CVP-MVSNet refinement hypotheses in eval mode without a host round trip.  Replaces calDepthHypo,
+ * models/CVP_MVSNet/models/modules.py:131-226 (a per-batch Python loop in fp64 with a median): per pixel the depth step
+ * that moves its projection into the FIRST source view by one pixel along the epipolar line (fp64), the lower median of
+ * |step| over the valid pixels (exact radix select), and the planes depth + k * median, k = -4..3.
+ *   depth    device fp32 [B,H,W]    the upsampled depth of the previous level
+ *   cams     device fp64 [B][39]:   K_ref^-1 (9), rows 0..2 of E_src E_ref^-1 (12), K_src (9),
+ *                                   A = (K_ref R_ref)(K_src R_src)^-1 (9); row-major, first source view
+ *   fallback device fp32 [B]        (depth_max - depth_min) / 128, the step used when no pixel is valid
+ *   keys     device uint64 workspace [B*H*W];  steps  device fp64 out [B];  hypos  device fp32 out [B,8,H,W]
+ */
+int pscv_cvp_depth_hypos(const float* depth, const double* cams, const float* fallback, unsigned long long* keys,
+                         double* steps, float* hypos, int B, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

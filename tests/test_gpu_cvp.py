@@ -71,3 +71,34 @@ def test_cvp_function_level_warp_and_proj_cost(env):
     cost = proj_cost(2, pyr[0].cuda(), [[pyr[1].cuda()], [pyr[2].cuda()]], 0, K[:, 0].cuda(), K[:, 1:].cuda(), ref_ex.cuda(),
                      src_ex.cuda(), hyp.cuda(), storage_dtype=torch.float16)
     check_close("cvp proj_cost vs reference golden", cost.float().permute(0, 4, 1, 2, 3).cpu(), t(g["refine1_cost"]), rel_l2=2e-3)
+
+
+@pytest.mark.parametrize("case", ["scene", "degenerate", "partly_invalid"])
+def test_cal_depth_hypo_kernel_vs_oracle(env, case):
+    """pscv_cvp_depth_hypos (per-pixel fp64 steps, exact radix-select median, planes; no host round trip) against the
+    oracle's restatement of calDepthHypo (modules.py:131-226; pinned to the reference by tests/test_oracle_cvp.py): batch of
+    two with different source cameras, the all-invalid fallback (identical cameras: zero epipolar motion) and a map where
+    part of the pixels project behind the source camera."""
+    L, ops, synthetic, Frontend = env
+    from oracle import cvpmvsnet as OC
+    from wild_deep_mvs_amd.models.CVP_MVSNet.models.modules import calDepthHypo
+    B, V, H, W = (1 if case == "degenerate" else 2), 3, 48, 64   # (the reference's fallback expression only broadcasts for B = 1)
+    scene = synthetic.make_scene(B, V, H, W, seed=4)
+    scene["t"] = scene["t"] * 8
+    scene["t"][B - 1] *= 0.5                                     # a different baseline in the last batch item
+    row = torch.tensor([0., 0., 0., 1.])
+    ref_ex = torch.cat((torch.cat((scene["R"][:, 0], scene["t"][:, 0]), 2), row.view(1, 1, 4).expand(B, 1, 4)), 1)
+    src_ex = torch.cat((torch.cat((scene["R"][:, 1:], scene["t"][:, 1:]), 3), row.view(1, 1, 1, 4).expand(B, V - 1, 1, 4)), 2)
+    K = scene["K"]
+    gen = torch.Generator().manual_seed(8)
+    depth = 2.5 + 3.0 * torch.rand(B, H, W, generator=gen)
+    if case == "degenerate":
+        src_ex = ref_ex.unsqueeze(1).repeat(1, V - 1, 1, 1)
+    if case == "partly_invalid":
+        src_ex[:, 0, 2, 3] -= 4.0                                # pushes the nearer half of the depth range behind the source camera
+    dmin, dmax = scene["depth_min"][:, 0], scene["depth_max"][:, 0]
+    want = OC.cal_depth_hypo(depth, K[:, 0], K[:, 1:], ref_ex, src_ex, dmin, dmax)
+    got = calDepthHypo(depth.cuda(), K[:, 0].cuda(), K[:, 1:].cuda(), ref_ex.cuda(), src_ex.cuda(), dmin.cuda(), dmax.cuda(), 0)
+    step_want = (want[:, 5] - want[:, 4]).reshape(B, -1)[:, 0]
+    print(f"[cal_depth_hypo] {case}: steps {step_want.tolist()}")
+    check_close(f"calDepthHypo {case}", got.cpu(), want, max_abs=2e-6)

@@ -31,7 +31,7 @@ EXPORTS = ("pscv_last_error", "pscv_abi_version", "pscv_set_tuning", "pscv_proj_
            "pscv_fuse_pairs", "pscv_fuse_finish", "pscv_geo_filter", "pscv_pack_conv2d_weights", "pscv_conv2d",
            "pscv_pack_conv3d_weights", "pscv_conv3d", "pscv_softargmin", "pscv_train_workspace_floats", "pscv_bn_stats",
            "pscv_bn_act", "pscv_bn_bwd_reduce", "pscv_bn_bwd_apply", "pscv_softargmin_bwd", "pscv_conv3d_wgrad_workspace",
-           "pscv_conv3d_wgrad", "pscv_warp_cost_bwd")
+           "pscv_conv3d_wgrad", "pscv_warp_cost_bwd", "pscv_cvp_depth_hypos")
 
 
 class PscvMissingError(RuntimeError):
@@ -104,6 +104,8 @@ def _declare(lib):
     lib.pscv_conv3d_wgrad_workspace.argtypes = [i, i, i, i, i, i, i]
     lib.pscv_conv3d_wgrad.restype = i
     lib.pscv_conv3d_wgrad.argtypes = [vp, i, i, i, vp, i, i, i, i, i, i, i, i, i, vp, vp, i, vp]
+    lib.pscv_cvp_depth_hypos.restype = i
+    lib.pscv_cvp_depth_hypos.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, vp]
     lib.pscv_warp_cost_bwd.restype = i
     lib.pscv_warp_cost_bwd.argtypes = [vp, C.POINTER(vp), i, vp, vp, l, i, i, i, f, vp, vp, C.POINTER(vp), vp, i, i, i, i, i,
                                        i, i, i, i, vp]

@@ -76,48 +76,20 @@ def proj_cost(nsrc, ref_feature, src_feature, level, ref_in, src_in, ref_ex, src
 
 
 def calDepthHypo(ref_depths, ref_intrinsics, src_intrinsics, ref_extrinsics, src_extrinsics, depth_min, depth_max, level):
-    """Eval-mode hypothesis maps (modules.py:131-226): per batch item, the MEDIAN over valid pixels of the depth step
-    that moves the projection into the first source view by one pixel along the epipolar line; 8 planes
-    ``depth + k * step``, k = -4..3.  fp64 like the reference; scalar / per-pixel algebra, stays tensor math
-    (scope row f-4).  ref_depths [B,H,W]; src_intrinsics [B,N,3,3]; src_extrinsics [B,N,4,4] -> [B,8,H,W] fp32."""
-    B, H, W = ref_depths.shape
-    dev = ref_depths.device
+    """Eval-mode hypothesis maps (modules.py:131-226): per batch item, the MEDIAN over valid pixels of the depth step that
+    moves the projection into the first source view by one pixel along the epipolar line; 8 planes ``depth + k * step``,
+    k = -4..3.  The reference loops over the batch in Python with fp64 tensors; here the per-pixel steps, the exact median
+    (radix select) and the planes are three HIP launches with no host round trip (``pscv_cvp_depth_hypos``, scope row
+    f-4); only the four 3x3 / 3x4 camera products per batch item are tensor math (fp64 like the reference).
+    ref_depths [B,H,W]; src_intrinsics [B,N,3,3]; src_extrinsics [B,N,4,4] -> [B,8,H,W] fp32."""
     Ki, Ks = ref_intrinsics.double(), src_intrinsics[:, 0].double()
     Ei, Es = ref_extrinsics.double(), src_extrinsics[:, 0].double()
-    # pixel order x-major (the reference builds meshgrid(x, y) and transposes the depth map to match)
-    xs = torch.arange(W, device=dev, dtype=torch.float64).repeat_interleave(H)
-    ys = torch.arange(H, device=dev, dtype=torch.float64).repeat(W)
-    X = torch.stack([xs, ys, torch.ones_like(xs)], 0)                                   # [3,HW]
-    out = ref_depths.unsqueeze(1).repeat(1, 8, 1, 1)
-    for b in range(B):
-        d1 = ref_depths[b].transpose(0, 1).reshape(-1).double()
-        to_src = Es[b] @ torch.linalg.inv(Ei[b])
-        Kinv = torch.linalg.inv(Ki[b])
-
-        def project(depth):
-            cam = Kinv @ (X * depth)
-            p = Ks[b] @ (to_src[:3, :3] @ cam + to_src[:3, 3:4])
-            return p / p[2:3], p[2]
-
-        x1, z1 = project(d1)
-        x2, z2 = project(d1 + 1)
-        direction = x2 - x1
-        norm = torch.linalg.norm(direction, dim=0)
-        x3 = x1 + direction / norm.clamp(min=1e-8)
-        A = (Ki[b] @ Ei[b][:3, :3]) @ torch.linalg.inv(Ks[b] @ Es[b][:3, :3])
-        rhs, col2 = z1 * (A @ x1), A @ x3
-        # rows 1..2 of [X | A x3] * (delta, .)^T = rows 1..2 of z1 A x1, solved with Cramer's rule
-        m00, m01, m10, m11 = X[1], col2[1], X[2], col2[2]
-        det = m00 * m11 - m01 * m10
-        valid = (norm > 1e-8) & (z1 > 1e-8) & (z2 > 1e-8) & (det.abs() > 1e-8)
-        if bool(valid.any()):
-            delta = ((m11 * rhs[1] - m01 * rhs[2]) / det)[valid]
-            step = delta.abs().median()
-        else:
-            step = ((depth_max - depth_min) / 128).double().reshape(-1)[0]
-        for k in range(-4, 4):
-            out[b, k + 4] = (ref_depths[b].double() + k * step).to(out.dtype)
-    return out.float()
+    to_src = Es @ torch.linalg.inv(Ei)                                                       # [B,4,4]
+    A = (Ki @ Ei[:, :3, :3]) @ torch.linalg.inv(Ks @ Es[:, :3, :3])
+    cams = torch.cat((torch.linalg.inv(Ki).reshape(-1, 9), to_src[:, :3, :].reshape(-1, 12), Ks.reshape(-1, 9), A.reshape(-1, 9)),
+                     dim=1).contiguous()
+    fallback = ((depth_max - depth_min) / 128).to(torch.float32).reshape(-1).contiguous()
+    return ops.cvp_depth_hypos(ref_depths.to(torch.float32).contiguous(), cams, fallback)
 
 
 def depth_regression(p, depth_values):

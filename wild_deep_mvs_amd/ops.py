@@ -511,6 +511,26 @@ def softargmin(logits: torch.Tensor, depth: Optional[torch.Tensor] = None, *, wa
 
 
 # --------------------------------------------------------------------------------------------
+# CVP refinement hypotheses
+# --------------------------------------------------------------------------------------------
+def cvp_depth_hypos(depth: torch.Tensor, cams: torch.Tensor, fallback: torch.Tensor, *, want_steps: bool = False):
+    """depth fp32 [B,H,W], cams fp64 [B,39] (K_ref^-1, rows 0..2 of E_src E_ref^-1, K_src, (K_ref R_ref)(K_src R_src)^-1),
+    fallback fp32 [B] -> hypotheses fp32 [B,8,H,W] = depth + k * median|step| (pscv_cvp_depth_hypos; no host sync)."""
+    _dev(depth, cams, fallback)
+    if depth.dtype != torch.float32 or depth.dim() != 3 or cams.dtype != torch.float64 or tuple(cams.shape) != (depth.shape[0], 39) \
+            or fallback.dtype != torch.float32 or fallback.numel() != depth.shape[0]:
+        raise ValueError("pscv.cvp_depth_hypos: depth fp32 [B,H,W], cams fp64 [B,39], fallback fp32 [B] expected")
+    B, H, W = depth.shape
+    keys = torch.empty((B * H * W,), dtype=torch.int64, device=depth.device)
+    steps = torch.empty((B,), dtype=torch.float64, device=depth.device)
+    hypos = torch.empty((B, 8, H, W), dtype=torch.float32, device=depth.device)
+    rc = _launch("cvp_depth_hypos", lambda: L.lib().pscv_cvp_depth_hypos(_p(depth), _p(cams), _p(fallback), _p(keys), _p(steps),
+                                                                        _p(hypos), B, H, W, _stream()))
+    L.check(rc, "pscv_cvp_depth_hypos")
+    return (hypos, steps) if want_steps else hypos
+
+
+# --------------------------------------------------------------------------------------------
 # training path (SURVEY 8f-1): batch-statistics BatchNorm pieces, weight gradients, backward of the sweep
 # --------------------------------------------------------------------------------------------
 _train_ws = {}
