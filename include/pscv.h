@@ -252,7 +252,8 @@ long pscv_train_workspace_floats(void);
 int pscv_bn_stats(const void* y, int dtype, long nvox, int C, float* workspace, float* sums, void* stream);
 
 /* out = [relu](y * scale + bias) + skip   (scale / bias fp32 [C] = the batch-statistics affine; skip may be NULL;
- * `skip + relu(bn(deconv(x)))` of models/MVSNet/model.py:79-81). */
+ * `skip + relu(bn(deconv(x)))` of models/MVSNet/model.py:79-81).  relu: 0 none, 1 before the skip add, 2 AFTER it
+ * (`relu(bn(conv(x)) + shortcut)` of the Vis BasicBlock, models/VisMVSNet/nn_utils.py:123-171). */
 int pscv_bn_act(const void* y, int dtype, long nvox, int C, const float* scale, const float* bias, int relu,
                 const void* skip, void* out, void* stream);
 
@@ -268,13 +269,29 @@ int pscv_bn_bwd_apply(const void* dact, const void* y, int dtype, long nvox, int
                       void* stream);
 
 /*
- * Backward of softmax over D + depth regression (models/MVSNet/model.py:207-209, module.py:174-178):
- * d depth / d logit_d = p_d (depth_d - depth).  logits fp32 [B,D,h,w], depth planes as in pscv_softargmin,
- * grad_depth fp32 [B,h,w]  ->  dlogits8 [B,D,h,w,8] in `dtype` with the gradient in channel 0 and zeros in
- * channels 1-7 (the layout the 8-channel MFMA kernels read: the 1-channel `prob` head's backward runs on them).
+ * Backward of softmax over D + the regression heads (models/MVSNet/model.py:207-209, module.py:174-178;
+ * models/VisMVSNet/nn_utils.py:453-470), p = softmax(logits); every upstream gradient is optional (NULL):
+ *   grad_depth    of depth   = sum_d p_d depth_d                       (needs the depth planes, as in pscv_softargmin)
+ *   grad_index    of index   = sum_d p_d d
+ *   grad_entropy  of entropy = -sum_d p_d log clamp(p_d, 1e-9, 1)
+ * logits fp32 [B,D,h,w], gradients fp32 [B,h,w]  ->  dlogits8 [B,D,h,w,8] in `dtype` with the gradient in channel 0
+ * and zeros in channels 1-7 (the layout the 8-channel MFMA kernels read: the 1-channel heads' backward runs on them).
  */
 int pscv_softargmin_bwd(const float* logits, const float* depth, long depth_bstride, int depth_per_pixel,
-                        const float* grad_depth, void* dlogits8, int dtype, int B, int D, int h, int w, void* stream);
+                        const float* grad_depth, const float* grad_index, const float* grad_entropy, void* dlogits8,
+                        int dtype, int B, int D, int h, int w, void* stream);
+
+/* dpre = dout * [out > 0]: backward of a ReLU applied AFTER a residual add (Vis BasicBlock, nn_utils.py:123-171; the
+ * forward is pscv_bn_act with relu = 2).  16-bit channels-last volumes, C a multiple of 8. */
+int pscv_relu_bwd(const void* dout, const void* out, int dtype, long nvox, int C, void* dpre, void* stream);
+
+/*
+ * Backward of pscv_fuse_pairs (normalise = 1): d interm_v = G w_v / W, d uncert_v = -w_v / W sum_{d,c} G (interm_v - fused)
+ * (models/VisMVSNet/model_cas.py:354-357,385-386 under autograd).  grad_fused [B,D,h,w,8] and dinterm[v] in `dtype`,
+ * duncert[v] fp32 [B,h,w]; host arrays of n_src device pointers.
+ */
+int pscv_fuse_pairs_bwd(const void* const* interm, const float* const* uncert, int n_src, int dtype, const void* grad_fused,
+                        void* const* dinterm, float* const* duncert, int B, int D, int h, int w, void* stream);
 
 /*
  * Weight gradient of a 3x3x3 convolution, an MFMA contraction over voxels:

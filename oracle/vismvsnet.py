@@ -15,9 +15,38 @@ SD = Mapping[str, torch.Tensor]
 BN_EPS = 1e-5
 
 
+# train() mode of the modules (the reference under train.py): BatchNorm uses batch statistics; the running statistics the
+# modules would hold afterwards are collected in MODE["new_stats"] (chained across repeated calls of the same module: the
+# pair U-Net runs once per source view).  Set through the ``train_mode`` context manager; gradients then come from ATen
+# autograd through these same functions, exactly as in the reference.
+MODE = {"training": False, "new_stats": None}
+
+
+class train_mode:
+    def __init__(self, new_stats: Optional[dict] = None):
+        self.new_stats = new_stats
+
+    def __enter__(self):
+        self.prev = dict(MODE)
+        MODE.update(training=True, new_stats=self.new_stats)
+        return self
+
+    def __exit__(self, *exc):
+        MODE.update(self.prev)
+        return False
+
+
 def _bn(x, sd: SD, p: str):
-    return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"],
-                        training=False, eps=BN_EPS)
+    if not MODE["training"]:
+        return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"],
+                            training=False, eps=BN_EPS)
+    ns = MODE["new_stats"]
+    src = ns if (ns is not None and p + ".running_mean" in ns) else sd
+    rm, rv = src[p + ".running_mean"].detach().clone(), src[p + ".running_var"].detach().clone()
+    y = F.batch_norm(x, rm, rv, sd[p + ".weight"], sd[p + ".bias"], training=True, momentum=0.1, eps=BN_EPS)
+    if ns is not None:
+        ns[p + ".running_mean"], ns[p + ".running_var"] = rm, rv
+    return y
 
 
 def _conv(x, w, stride=1, dim=2, padding=None):
@@ -125,24 +154,26 @@ def homography_warping(src, H, ref_shape):
     """homography.py:77-120: half-pixel centres, ``z <= 0`` -> (-10,-10), coordinates / size * 2 - 1 clamped to
     +-1.1, ``grid_sample(align_corners=True)``.  src [m,c,hs,ws], H [m,1|h,1|w,3,3] -> [m,c,h,w]."""
     h, w = ref_shape
-    xs = (torch.arange(w, dtype=torch.float32) + 0.5).repeat(h, 1)
-    ys = (torch.arange(h, dtype=torch.float32) + 0.5).repeat(w, 1).t()
-    grid = torch.stack([xs, ys, torch.ones_like(xs)], dim=-1).unsqueeze(-1).unsqueeze(0)   # [1,h,w,3,1]
-    hom = (H @ grid).squeeze(-1)                                                            # [m,h,w,3]
-    valid = hom[..., 2] > 0
-    coord = hom[..., :2] / hom[..., 2:3].clamp(min=1e-9)
-    coord = torch.where(valid.unsqueeze(-1), coord, torch.full_like(coord, -10.0))
-    norm = coord.clone()
-    norm[..., 0] /= src.shape[3]
-    norm[..., 1] /= src.shape[2]
-    norm = (norm * 2 - 1).clamp(-1.1, 1.1)
+    with torch.no_grad():   # homography.py:92,110
+        xs = (torch.arange(w, dtype=torch.float32) + 0.5).repeat(h, 1)
+        ys = (torch.arange(h, dtype=torch.float32) + 0.5).repeat(w, 1).t()
+        grid = torch.stack([xs, ys, torch.ones_like(xs)], dim=-1).unsqueeze(-1).unsqueeze(0)   # [1,h,w,3,1]
+        hom = (H @ grid).squeeze(-1)                                                            # [m,h,w,3]
+        valid = hom[..., 2] > 0
+        coord = hom[..., :2] / hom[..., 2:3].clamp(min=1e-9)
+        coord = torch.where(valid.unsqueeze(-1), coord, torch.full_like(coord, -10.0))
+        norm = coord.clone()
+        norm[..., 0] /= src.shape[3]
+        norm[..., 1] /= src.shape[2]
+        norm = (norm * 2 - 1).clamp(-1.1, 1.1)
     return F.grid_sample(src, norm, mode="bilinear", padding_mode="zeros", align_corners=True)
 
 
 def warp_volume(src_feat, ref_cam, src_cam, depth_num, depth_start, depth_interval, s_scale, ref_shape):
     """``SingleStage.build_cost_volume`` model_cas.py:176-186 -> warped source volume [n,c,d,h,w]."""
-    rc, sc = scale_camera(ref_cam, 1.0 / s_scale), scale_camera(src_cam, 1.0 / s_scale)
-    Hs = get_homographies(rc, sc, depth_num, depth_start, depth_interval)        # [n,d,1|h,1|w,3,3]
+    with torch.no_grad():   # homography.py:25: the homographies carry no gradient
+        rc, sc = scale_camera(ref_cam, 1.0 / s_scale), scale_camera(src_cam, 1.0 / s_scale)
+        Hs = get_homographies(rc, sc, depth_num, depth_start, depth_interval)        # [n,d,1|h,1|w,3,3]
     n, c = src_feat.shape[:2]
     src_rep = src_feat.unsqueeze(1).repeat(1, depth_num, 1, 1, 1).view(-1, *src_feat.shape[1:])
     warped = homography_warping(src_rep, Hs.reshape(-1, *Hs.shape[2:]), ref_shape)
@@ -242,12 +273,12 @@ def forward(imgs, K, R, t, depth_min, depth_max, sd: SD, depth_nums=(32, 16, 8),
     d1, p1, pr1 = single_stage(rf[0], ref_cam, [f[0] for f in sf], srcs_cam, sd, "model.stage1", depth_nums[0], ds1,
                                di * interval_scales[0], 8, stage_taps[0])
     p1_up = F.interpolate(p1, scale_factor=4, mode="bilinear", align_corners=False)
-    ds2 = F.interpolate(d1, size=rf[1].shape[2:], mode="bilinear", align_corners=False) \
+    ds2 = F.interpolate(d1.detach(), size=rf[1].shape[2:], mode="bilinear", align_corners=False) \
         - depth_nums[1] * di * attr_interval_scales[1] / 2
     d2, p2, pr2 = single_stage(rf[1], ref_cam, [f[1] for f in sf], srcs_cam, sd, "model.stage2", depth_nums[1], ds2,
                                di * interval_scales[1], 4, stage_taps[1])
     p2_up = F.interpolate(p2, scale_factor=2, mode="bilinear", align_corners=False)
-    ds3 = F.interpolate(d2, size=rf[2].shape[2:], mode="bilinear", align_corners=False) \
+    ds3 = F.interpolate(d2.detach(), size=rf[2].shape[2:], mode="bilinear", align_corners=False) \
         - depth_nums[2] * di * attr_interval_scales[2] / 2
     d3, p3, pr3 = single_stage(rf[2], ref_cam, [f[2] for f in sf], srcs_cam, sd, "model.stage3", depth_nums[2], ds3,
                                di * interval_scales[2], 2, stage_taps[2])

@@ -232,6 +232,59 @@ def gen_vis(tag, *, H=64, W=96, V=3, depth_nums=(16, 8, 4), interval_scales=(8.0
     save(f"{tag}.npz", **arrays)
 
 
+def gen_vis_train(tag, *, H=64, W=96, V=3, depth_nums=(16, 8, 4), interval_scales=(8.0, 4.0, 2.0), seed=0, scene_seed=0, B=2):
+    """One training step of the reference's Vis-MVSNet in train() mode (batch-statistics BatchNorm in the 2-D extractor, the
+    pair / fuse U-Nets and the uncertainty net; stages detached from each other), the supervised loss of models/trainer.py
+    (fused L1 per stage + the Bayesian pair loss with the predicted log-uncertainties), backward."""
+    sys.path.insert(0, REPO)
+    from wild_deep_mvs_amd import synthetic
+    from models.VisMVSNet.frontend import Frontend  # reference
+    import models.VisMVSNet.model_cas as MC
+
+    # UncertNet.forward (model_cas.py:93-98) does `out += x` on the output of a non-inplace ReLU.  torch 1.4 (the reference's
+    # pin) differentiates that ReLU from its INPUT, so the in-place add is harmless there; torch >= 1.7 differentiates it from
+    # its OUTPUT and refuses ("modified by an inplace operation").  Same values, out of place, for this process only:
+    def uncert_forward(self, x):
+        out = self.conv2(self.conv1(x))
+        out = out + x
+        return [conv(out) for conv in self.head_convs]
+    MC.UncertNet.forward = uncert_forward
+
+    torch.manual_seed(0)
+    net = Frontend()
+    sd = synthetic.sharpened_state_dict("vis", synthetic.template_of(net), seed=seed)
+    net.load_state_dict(sd, strict=True)
+    net.train()
+    net.depth_nums = list(depth_nums)
+    net.interval_scales = list(interval_scales)
+    scene = synthetic.make_scene(B, V, H, W, seed=scene_seed)
+    out = net(scene["imgs"], scene["K"], scene["R"], scene["t"], scene["depth_min"], scene["depth_max"])
+    gt, mask = synthetic.train_target(scene, H // 2, W // 2)
+    loss = synthetic.vis_supervised_loss(out, gt, mask, scene["depth_min"], scene["depth_max"], V)
+    loss.backward()
+    grads = {k: p.grad for k, p in net.named_parameters() if p.grad is not None}
+    norms = {k: float(g.norm()) for k, g in grads.items()}
+    keep = [k for k in grads if ("stage1.reg." in k or "stage3.reg_fuse." in k or "reg_pair" in k or "uncert_net.head" in k)]
+    keep += ["model.feat_ext.init_conv.0.weight", "model.feat_ext.final_conv_3.weight"]
+    stats = {k: v for k, v in net.state_dict().items() if "running_" in k and ".stage" in k}
+    print(f"[{tag}] loss {float(loss.detach()):.5f}, depth range {out['depth'].min():.3f}..{out['depth'].max():.3f}, params with grad "
+          f"{len(grads)}/{len(list(net.parameters()))}, |g stage1 reg conv1| {norms['model.stage1.reg.unet.enc_blocks.reg14_0.0.conv1.weight']:.3e}")
+    arrays = {"meta": np.array([H, W, V, seed, scene_seed, B], dtype=np.int64), "depth_nums": np.array(depth_nums, dtype=np.int64),
+              "interval_scales": np.array(interval_scales, dtype=np.float64), "loss": np.float32(float(loss.detach())),
+              "norm_keys": np.array(list(norms.keys())), "norm_vals": np.array(list(norms.values()), dtype=np.float64)}
+    for i, d in enumerate(out["depth_est_list"]):
+        arrays[f"depth_est_{i}"] = np32(d)
+    for i, prs in enumerate(out["depth_pair_list"]):
+        for j, (dp, (unc,)) in enumerate(prs):
+            arrays[f"pair_{i}_{j}_depth"] = np32(dp)
+            arrays[f"pair_{i}_{j}_uncert"] = np32(unc)
+    for k in keep:
+        arrays["grad:" + k] = np32(grads[k])
+    for k, v in stats.items():
+        arrays["stat:" + k] = np32(v)
+    save(f"{tag}.npz", **arrays)
+
+
 def gen_cvp(tag, *, H=32, W=48, V=3, nscale=2, seed=0, scene_seed=0, baseline_scale=8):
     sys.path.insert(0, REPO)
     from wild_deep_mvs_amd import synthetic
@@ -406,6 +459,7 @@ def main():
         "mvsnet_train": lambda: gen_mvsnet_train("variance", "mvsnet_train"),
         "mvsnet_s_train": lambda: gen_mvsnet_train("softmin", "mvsnet_s_train", seed=1),
         "vis": lambda: gen_vis("vis_tiny"),
+        "vis_train": lambda: gen_vis_train("vis_train"),
         "cvp": lambda: gen_cvp("cvp_tiny"),
         "cvp_train": lambda: gen_cvp_train("cvp_train"),
         "keys": gen_state_dict_keys,

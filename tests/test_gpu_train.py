@@ -409,3 +409,188 @@ def test_cvp_train_step(dtype):
     sd = net.state_dict()
     for k, ref in o_stats.items():
         check_close(f"stat {k}", sd[k].cpu(), ref, rel_l2=3e-2 if bf else 5e-3)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Vis-MVSNet training pieces
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DT)
+def test_vis_heads_and_fusion_backward(dtype):
+    """pscv_softargmin_bwd with the expected-index and entropy heads, pscv_relu_bwd, the post-add ReLU of pscv_bn_act and
+    pscv_fuse_pairs_bwd against ATen autograd on identical operands."""
+    from wild_deep_mvs_amd import ops
+    g = torch.Generator().manual_seed(21)
+    B, D, h, w = 2, 12, 10, 14
+    # softargmin heads (incl. a pixel whose softmax saturates so that clamp(p, 1e-9) is active)
+    logits = (torch.randn(B, D, h, w, generator=g) * 2)
+    logits[0, 3, 0, 0] = 60.0
+    logits.requires_grad_(True)
+    p = F.softmax(logits, 1)
+    idx = (p * torch.arange(D).view(1, D, 1, 1)).sum(1)
+    ent = (-p * p.clamp(1e-9, 1.0).log()).sum(1)
+    gi, ge = torch.randn(B, h, w, generator=g), torch.randn(B, h, w, generator=g)
+    (idx * gi + ent * ge).sum().backward()
+    got = ops.softargmin_bwd(logits.detach().cuda(), None, None, torch.float16, grad_index=gi.cuda(), grad_entropy=ge.cuda())
+    check_close("d logits (index + entropy)", got[..., 0].float().cpu(), logits.grad, rel_l2=1e-3)
+    # relu after the add, forward and backward
+    y = (torch.randn(B, 8, D, h, w, generator=g)).to(dtype).float()
+    skip = torch.randn(B, 8, D, h, w, generator=g).to(dtype).float()
+    sc, bi = torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g) * 0.2
+    out_ref = F.relu(y * sc.view(1, 8, 1, 1, 1) + bi.view(1, 8, 1, 1, 1) + skip)
+    out = ops.bn_act(_cl(y, dtype), sc.cuda(), bi.cuda(), relu="post", skip=_cl(skip, dtype))
+    check_close("bn_act post relu", _cf(out), out_ref.to(dtype).float(), rel_l2=4e-3 if dtype == torch.bfloat16 else 5e-4)
+    dout = torch.randn(B, 8, D, h, w, generator=g).to(dtype).float()
+    dpre = ops.relu_bwd(_cl(dout, dtype), out)
+    check_close("relu_bwd", _cf(dpre), dout * (_cf(out) > 0).float(), max_abs=0.0)
+    # fusion
+    n = 3
+    Is = [torch.randn(B, 8, D, h, w, generator=g).to(dtype).float().requires_grad_(True) for _ in range(n)]
+    us = [(torch.randn(B, h, w, generator=g) * 0.7).requires_grad_(True) for _ in range(n)]
+    ws = [(-u).exp().view(B, 1, 1, h, w) for u in us]
+    fused = sum(I * w_ for I, w_ in zip(Is, ws)) / sum(ws)
+    G = torch.randn(B, 8, D, h, w, generator=g).to(dtype).float()
+    fused.backward(G)
+    dI, dU = ops.fuse_pairs_bwd([_cl(I.detach(), dtype) for I in Is], [u.detach().cuda() for u in us], _cl(G, dtype))
+    for v in range(n):
+        check_close(f"d interm {v}", _cf(dI[v]), Is[v].grad, rel_l2=4e-3 if dtype == torch.bfloat16 else 5e-4)
+        check_close(f"d uncert {v}", dU[v].cpu(), us[v].grad, rel_l2=1e-4)
+
+
+def _cg(x, w, dy, *, stride=1, transposed=False, pad=1):
+    """(input gradient, weight gradient) of one (transposed) convolution from ATen autograd."""
+    x = x.clone().requires_grad_(True)
+    w = w.clone().requires_grad_(True)
+    y = F.conv_transpose3d(x, w, None, stride=stride, padding=pad, output_padding=stride - 1) if transposed else \
+        F.conv3d(x, w, None, stride=stride, padding=pad)
+    y.backward(dy)
+    return x.grad, w.grad
+
+
+def _bn_bwd_ref(y, gamma, beta, dz_src, relu, eps=1e-5):
+    y = y.clone().requires_grad_(True)
+    gamma, beta = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    z = F.batch_norm(y, None, None, gamma, beta, training=True, eps=eps)
+    (F.relu(z) if relu else z).backward(dz_src)
+    return y.grad, gamma.grad, beta.grad
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_vis_unet_fn_stepwise_against_autograd(dtype):
+    """training.VisUNetFn (the residual-block U-Net of Vis-MVSNet's Reg / RegFuse in train() mode, forward AND backward on
+    the engine) step by step on the tensors the engine recorded (training.TRACE): every convolution, batch-statistics
+    BatchNorm, post-add ReLU, the strided 1x1x1 shortcut, the linear decoder with its channel concatenation, and in the
+    backward every d weight / d gamma / d beta / d input incl. the three-way gradient sum at the first block's output."""
+    from wild_deep_mvs_amd import ops, synthetic, training as T
+    from wild_deep_mvs_amd.models.VisMVSNet.frontend import Frontend
+    net = Frontend()
+    net.load_state_dict(synthetic.sharpened_state_dict("vis", synthetic.template_of(net), seed=2))
+    holder = net.cuda().train().model.stage1.reg
+    gen = torch.Generator().manual_seed(6)
+    n, d, h, w = 2, 8, 12, 20
+    x = torch.randn(n, 8, d, h, w, generator=gen).to(dtype)
+    gout = torch.randn(n, 8, d, h, w, generator=gen).to(dtype)
+    x_cl = ops.to_channels_last(x.cuda(), dtype).requires_grad_(True)
+    params = T.VisUNetFn.params(holder)
+    T.TRACE = {}
+    try:
+        out = T.VisUNetFn.apply(holder, dtype, x_cl, *params)
+        out.backward(ops.to_channels_last(gout.cuda(), dtype))
+        torch.cuda.synchronize()
+        f, b = T.TRACE["vis_unet"][0], T.TRACE["vis_unet_bwd"][0]
+    finally:
+        T.TRACE = None
+    bf = dtype == torch.bfloat16
+    q = lambda v: v.to(dtype).float()
+    tol, btol = 2e-4, (2e-3 if bf else 3e-4)
+    b0, b1, dec = T.VisUNetFn.parts(holder)
+    W = lambda p_: q(p_.detach().cpu())
+    P = lambda p_: p_.detach().cpu().float()
+    R = {k: (_cf(v) if torch.is_tensor(v) and v.dim() == 5 else v) for k, v in {**f, **{"b_" + k: v for k, v in b.items() if v is not None}}.items()}
+    bn = lambda y, m: F.batch_norm(y, None, None, P(m.weight), P(m.bias), training=True, eps=m.eps)
+    # ---- forward ----
+    check_close("y1", R["y1"], q(F.conv3d(R["x"], W(b0.conv1.weight), padding=1)), rel_l2=tol)
+    check_close("t", R["t"], q(F.relu(bn(R["y1"], b0.bn1))), rel_l2=tol)
+    check_close("y2", R["y2"], q(F.conv3d(R["t"], W(b0.conv2.weight), padding=1)), rel_l2=tol)
+    check_close("enc0", R["enc0"], q(F.relu(bn(R["y2"], b0.bn2) + R["x"])), rel_l2=tol)
+    check_close("y3", R["y3"], q(F.conv3d(R["enc0"], W(b1.conv1.weight), stride=2, padding=1)), rel_l2=tol)
+    check_close("t1", R["t1"], q(F.relu(bn(R["y3"], b1.bn1))), rel_l2=tol)
+    check_close("y4 (1x1x1 stride-2 shortcut)", R["y4"], q(F.conv3d(R["enc0"], W(b1.downsample[0].weight), stride=2, padding=0)), rel_l2=tol)
+    check_close("ds", R["ds"], q(bn(R["y4"], b1.downsample[1])), rel_l2=tol)
+    check_close("y5", R["y5"], q(F.conv3d(R["t1"], W(b1.conv2.weight), padding=1)), rel_l2=tol)
+    check_close("e1", R["e1"], q(F.relu(bn(R["y5"], b1.bn2) + R["ds"])), rel_l2=tol)
+    check_close("up", R["up"], q(F.conv_transpose3d(R["e1"], W(dec[0].weight), stride=2, padding=1, output_padding=1)), rel_l2=tol)
+    check_close("cat", R["cat"], torch.cat([R["up"], R["enc0"]], 1), max_abs=0.0)
+    check_close("out", R["out"], q(F.conv3d(R["cat"], W(dec[1].weight), padding=1)), rel_l2=tol)
+    # ---- backward ----
+    G = {k: p_.grad.detach().cpu().float() for k, p_ in zip(
+        ["c1a", "g1", "b1", "c2a", "g2", "b2", "c1b", "g3", "b3", "ds", "g4", "b4", "c2b", "g5", "b5", "dec", "post"], params)}
+    dx_, dw_ = _cg(R["cat"], W(dec[1].weight), R["b_g"])
+    check_close("d cat", R["b_dcat"], q(dx_), rel_l2=btol); check_close("dW post", G["post"], dw_, rel_l2=tol)
+    dx_, dw_ = _cg(R["e1"], W(dec[0].weight), R["b_dcat"][:, :8], stride=2, transposed=True)
+    check_close("d e1", R["b_de1"], q(dx_), rel_l2=btol); check_close("dW deconv", G["dec"], dw_, rel_l2=tol)
+    check_close("d pre (post-add relu)", R["b_dpre"], R["b_de1"] * (R["e1"] > 0).float(), max_abs=0.0)
+    dy_, dg_, db_ = _bn_bwd_ref(R["y5"], P(b1.bn2.weight), P(b1.bn2.bias), R["b_dpre"], False, b1.bn2.eps)
+    check_close("dy5", R["b_dy5"], q(dy_), rel_l2=btol); check_close("d gamma5", G["g5"], dg_, rel_l2=tol); check_close("d beta5", G["b5"], db_, rel_l2=tol)
+    dx_, dw_ = _cg(R["t1"], W(b1.conv2.weight), R["b_dy5"])
+    check_close("d t1", R["b_dt1"], q(dx_), rel_l2=btol); check_close("dW conv2 (block 1)", G["c2b"], dw_, rel_l2=tol)
+    dy_, dg_, db_ = _bn_bwd_ref(R["y4"], P(b1.downsample[1].weight), P(b1.downsample[1].bias), R["b_dpre"], False, b1.downsample[1].eps)
+    check_close("dy4", R["b_dy4"], q(dy_), rel_l2=btol); check_close("d gamma4", G["g4"], dg_, rel_l2=tol); check_close("d beta4", G["b4"], db_, rel_l2=tol)
+    dx4, dw_ = _cg(R["enc0"], W(b1.downsample[0].weight), R["b_dy4"], stride=2, pad=0)
+    check_close("dW shortcut", G["ds"], dw_, rel_l2=tol)
+    dy_, dg_, db_ = _bn_bwd_ref(R["y3"], P(b1.bn1.weight), P(b1.bn1.bias), R["b_dt1"], True, b1.bn1.eps)
+    check_close("dy3", R["b_dy3"], q(dy_), rel_l2=btol); check_close("d gamma3", G["g3"], dg_, rel_l2=tol); check_close("d beta3", G["b3"], db_, rel_l2=tol)
+    dx3, dw_ = _cg(R["enc0"], W(b1.conv1.weight), R["b_dy3"], stride=2)
+    check_close("dW conv1 (block 1)", G["c1b"], dw_, rel_l2=tol)
+    check_close("d enc0 (concat slice + shortcut + strided conv)", R["b_denc0"], q(q(R["b_dcat"][:, 8:] + dx4) + dx3), rel_l2=btol)
+    check_close("d pre0", R["b_dpre0"], R["b_denc0"] * (R["enc0"] > 0).float(), max_abs=0.0)
+    dy_, dg_, db_ = _bn_bwd_ref(R["y2"], P(b0.bn2.weight), P(b0.bn2.bias), R["b_dpre0"], False, b0.bn2.eps)
+    check_close("dy2", R["b_dy2"], q(dy_), rel_l2=btol); check_close("d gamma2", G["g2"], dg_, rel_l2=tol); check_close("d beta2", G["b2"], db_, rel_l2=tol)
+    dx_, dw_ = _cg(R["t"], W(b0.conv2.weight), R["b_dy2"])
+    check_close("d t", R["b_dt"], q(dx_), rel_l2=btol); check_close("dW conv2 (block 0)", G["c2a"], dw_, rel_l2=tol)
+    dy_, dg_, db_ = _bn_bwd_ref(R["y1"], P(b0.bn1.weight), P(b0.bn1.bias), R["b_dt"], True, b0.bn1.eps)
+    check_close("dy1", R["b_dy1"], q(dy_), rel_l2=btol); check_close("d gamma1", G["g1"], dg_, rel_l2=tol); check_close("d beta1", G["b1"], db_, rel_l2=tol)
+    dx_, dw_ = _cg(R["x"], W(b0.conv1.weight), R["b_dy1"])
+    check_close("dW conv1 (block 0)", G["c1a"], dw_, rel_l2=tol)
+    check_close("d x (conv path + residual)", R["b_dx"], q(dx_ + R["b_dpre0"]), rel_l2=btol)
+    check_close("d x returned by autograd", _cf(x_cl.grad), R["b_dx"], max_abs=0.0)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_vis_train_step(dtype):
+    """One training step of the Vis-MVSNet mirror in train() mode (three detached cascade stages; per source view: fused warp
+    + group correlation, pair U-Net, score head with expected index + entropy, 2-D uncertainty net; visibility-weighted
+    fusion; fuse U-Net) with the reference trainer's loss (fused L1 + Bayesian pair loss) against the oracle's autograd and
+    the reference's own step (tests/golden/vis_train.npz; pinned by tests/test_oracle_train.py)."""
+    from test_oracle_train import vis_oracle_train_step
+    from wild_deep_mvs_amd import synthetic
+    from wild_deep_mvs_amd.models.VisMVSNet.frontend import Frontend
+    g = load_golden("vis_train.npz")
+    H, W, V, seed, scene_seed, B = [int(x) for x in g["meta"]]
+    depth_nums, scales = [int(x) for x in g["depth_nums"]], [float(x) for x in g["interval_scales"]]
+    net = Frontend()
+    net.load_state_dict(synthetic.sharpened_state_dict("vis", synthetic.template_of(net), seed=seed))
+    net = net.cuda().train()
+    net.depth_nums, net.interval_scales = depth_nums, scales
+    net.train_storage_dtype = dtype
+    scene = synthetic.make_scene(B, V, H, W, seed=scene_seed)
+    out = net(*[scene[k].cuda() for k in ("imgs", "K", "R", "t", "depth_min", "depth_max")])
+    gt, mask = synthetic.train_target(scene, H // 2, W // 2)
+    loss = synthetic.vis_supervised_loss(out, gt.cuda(), mask.cuda(), scene["depth_min"].cuda(), scene["depth_max"].cuda(), V)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert tuple(out["photometric_confidence"].shape) == (B, 3, H // 2, W // 2)
+    o_out, o_loss, o_grads, o_stats = vis_oracle_train_step(H, W, V, seed, scene_seed, B, tuple(depth_nums), tuple(scales))
+    bf = dtype == torch.bfloat16
+    for i, d in enumerate(out["depth_est_list"]):
+        check_close(f"depth_est_{i} vs oracle", d.detach().cpu(), o_out["depth_est_list"][i].detach(), rel_l1=6e-3 if bf else 1e-3)
+        check_close(f"depth_est_{i} vs reference golden", d.detach().cpu(), t(g[f"depth_est_{i}"]), rel_l1=6e-3 if bf else 1e-3)
+    for i, prs in enumerate(out["depth_pair_list"]):
+        for j, (dp, (unc,)) in enumerate(prs):
+            check_close(f"pair {i},{j} depth", dp.detach().cpu(), t(g[f"pair_{i}_{j}_depth"]), rel_l1=6e-3 if bf else 1e-3)
+            check_close(f"pair {i},{j} uncertainty", unc.detach().cpu(), t(g[f"pair_{i}_{j}_uncert"]), rel_l2=8e-2 if bf else 1.5e-2)
+    assert abs(float(loss) - o_loss) <= (3e-2 if bf else 5e-3) * abs(o_loss), (float(loss), o_loss)
+    worst, cos, rows = _grad_report(f"vis {dtype} vs fp32 oracle", net, o_grads)
+    assert cos >= (0.9 if bf else 0.98), (cos, rows)
+    sd = net.state_dict()
+    for k, ref in o_stats.items():
+        check_close(f"stat {k}", sd[k].cpu(), ref, rel_l2=5e-2 if bf else 8e-3)

@@ -78,3 +78,45 @@ def test_cvp_oracle_train_step_matches_reference():
             check_close(k, grads[k[5:]], t(g[k]), rel_l2=3e-3)
         if k.startswith("stat:"):
             check_close(k, stats[k[5:]], t(g[k]), rel_l2=1e-4)
+
+
+def vis_oracle_train_step(H, W, V, seed, scene_seed, B, depth_nums, interval_scales):
+    import json, os
+    from collections import OrderedDict
+    from _util import GOLDEN
+    from oracle import vismvsnet as OV
+    keys = json.load(open(os.path.join(GOLDEN, "state_dict_keys.json")))["vis"]
+    sd = synthetic.sharpened_state_dict("vis", OrderedDict((k, tuple(s)) for k, s in keys), seed=seed)
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v) for k, v in sd.items()}
+    scene = synthetic.make_scene(B, V, H, W, seed=scene_seed)
+    stats = {}
+    with OV.train_mode(stats):
+        out = OV.forward(scene["imgs"], scene["K"], scene["R"], scene["t"], scene["depth_min"], scene["depth_max"], sd,
+                         depth_nums=depth_nums, interval_scales=interval_scales, attr_interval_scales=interval_scales)
+    gt, mask = synthetic.train_target(scene, H // 2, W // 2)
+    loss = synthetic.vis_supervised_loss(out, gt, mask, scene["depth_min"], scene["depth_max"], V)
+    loss.backward()
+    grads = {k: v.grad for k, v in sd.items() if isinstance(v, torch.Tensor) and v.requires_grad and v.grad is not None}
+    return out, float(loss.detach()), grads, stats
+
+
+def test_vis_oracle_train_step_matches_reference():
+    g = load_golden("vis_train.npz")
+    H, W, V, seed, scene_seed, B = [int(x) for x in g["meta"]]
+    out, loss, grads, stats = vis_oracle_train_step(H, W, V, seed, scene_seed, B, tuple(int(x) for x in g["depth_nums"]),
+                                                    tuple(float(x) for x in g["interval_scales"]))
+    for i, d in enumerate(out["depth_est_list"]):
+        check_close(f"depth_est_{i}", d.detach(), t(g[f"depth_est_{i}"]), max_abs=3e-4)
+    for i, prs in enumerate(out["depth_pair_list"]):
+        for j, (dp, (unc,)) in enumerate(prs):
+            check_close(f"pair_{i}_{j}_depth", dp.detach(), t(g[f"pair_{i}_{j}_depth"]), max_abs=3e-4)
+            check_close(f"pair_{i}_{j}_uncert", unc.detach(), t(g[f"pair_{i}_{j}_uncert"]), max_abs=3e-4)
+    assert abs(loss - float(g["loss"])) <= 2e-4 * abs(float(g["loss"])), (loss, float(g["loss"]))
+    for k, ref in zip(g["norm_keys"], g["norm_vals"]):
+        got = float(grads[str(k)].norm())
+        assert abs(got - ref) <= 5e-3 * ref + 1e-5, (k, got, ref)
+    for k in g:
+        if k.startswith("grad:"):
+            check_close(k, grads[k[5:]], t(g[k]), rel_l2=5e-3)
+        if k.startswith("stat:"):
+            check_close(k, stats[k[5:]], t(g[k]), rel_l2=1e-4)

@@ -31,7 +31,7 @@ EXPORTS = ("pscv_last_error", "pscv_abi_version", "pscv_set_tuning", "pscv_proj_
            "pscv_fuse_pairs", "pscv_fuse_finish", "pscv_geo_filter", "pscv_pack_conv2d_weights", "pscv_conv2d",
            "pscv_pack_conv3d_weights", "pscv_conv3d", "pscv_softargmin", "pscv_train_workspace_floats", "pscv_bn_stats",
            "pscv_bn_act", "pscv_bn_bwd_reduce", "pscv_bn_bwd_apply", "pscv_softargmin_bwd", "pscv_conv3d_wgrad_workspace",
-           "pscv_conv3d_wgrad", "pscv_warp_cost_bwd", "pscv_cvp_depth_hypos")
+           "pscv_conv3d_wgrad", "pscv_warp_cost_bwd", "pscv_cvp_depth_hypos", "pscv_relu_bwd", "pscv_fuse_pairs_bwd")
 
 
 class PscvMissingError(RuntimeError):
@@ -99,7 +99,11 @@ def _declare(lib):
     lib.pscv_bn_bwd_apply.restype = i
     lib.pscv_bn_bwd_apply.argtypes = [vp, vp, i, l, i, vp, vp, i, vp, vp, vp, vp, vp]
     lib.pscv_softargmin_bwd.restype = i
-    lib.pscv_softargmin_bwd.argtypes = [vp, vp, l, i, vp, vp, i, i, i, i, i, vp]
+    lib.pscv_softargmin_bwd.argtypes = [vp, vp, l, i, vp, vp, vp, vp, i, i, i, i, i, vp]
+    lib.pscv_relu_bwd.restype = i
+    lib.pscv_relu_bwd.argtypes = [vp, vp, i, l, i, vp, vp]
+    lib.pscv_fuse_pairs_bwd.restype = i
+    lib.pscv_fuse_pairs_bwd.argtypes = [C.POINTER(vp), C.POINTER(vp), i, i, vp, C.POINTER(vp), C.POINTER(vp), i, i, i, i, vp]
     lib.pscv_conv3d_wgrad_workspace.restype = l
     lib.pscv_conv3d_wgrad_workspace.argtypes = [i, i, i, i, i, i, i]
     lib.pscv_conv3d_wgrad.restype = i

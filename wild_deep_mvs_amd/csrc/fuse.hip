@@ -64,7 +64,80 @@ __global__ __launch_bounds__(256) void fuse_finish_kernel(const float* __restric
     Elem<H>::store8(out + vox * 8, x);
 }
 
+// Backward of the fusion (training): with fused = sum_v w_v I_v / W, W = sum_v w_v, w_v = exp(-u_v) and G the
+// gradient of the fused volume,
+//     d I_v = G w_v / W            d u_v = -w_v / W * sum_{d,c} G (I_v - fused)
+// One lane per pixel walks the depth axis (coalesced 16-byte accesses across the wave), recomputes `fused` from the pair
+// volumes and keeps the per-view sums in registers: every volume is read once, every d I_v written once.
+struct FuseBwdArgs {
+    const void* interm[PSCV_MAX_SRC];
+    const float* uncert[PSCV_MAX_SRC];
+    const void* g;                      // [B,D,h,w,8] 16-bit
+    void* dinterm[PSCV_MAX_SRC];        // each [B,D,h,w,8] 16-bit
+    float* duncert[PSCV_MAX_SRC];       // each [B,h,w] fp32
+    int n_src, B, D, hw;
+};
+
+template <typename H>
+__global__ __launch_bounds__(256) void fuse_pairs_bwd_kernel(const FuseBwdArgs a) {
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= (long)a.B * a.hw) return;
+    const int b = (int)(p / a.hw);
+    const int pf = (int)(p - (long)b * a.hw);
+    float w[PSCV_MAX_SRC], acc[PSCV_MAX_SRC];
+    float wsum = 0.f;
+    for (int v = 0; v < a.n_src; ++v) { w[v] = expf(-a.uncert[v][p]); wsum += w[v]; acc[v] = 0.f; }
+    const float inv = 1.0f / wsum;
+    for (int d = 0; d < a.D; ++d) {
+        const long vox = ((long)b * a.D + d) * a.hw + pf;
+        const f32x8 G = Elem<H>::load8(reinterpret_cast<const H*>(a.g) + vox * 8);
+        float fused[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int v = 0; v < a.n_src; ++v) {
+            const f32x8 x = Elem<H>::load8(reinterpret_cast<const H*>(a.interm[v]) + vox * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fused[j] = fmaf(x.v[j], w[v], fused[j]);
+        }
+        float gf = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gf = fmaf(G.v[j], fused[j] * inv, gf);
+        for (int v = 0; v < a.n_src; ++v) {
+            const f32x8 x = Elem<H>::load8(reinterpret_cast<const H*>(a.interm[v]) + vox * 8);   // (L1/L2 hit: read just above)
+            float gi = 0.f;
+            f32x8 o;
+            const float s = w[v] * inv;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { gi = fmaf(G.v[j], x.v[j], gi); o.v[j] = G.v[j] * s; }
+            acc[v] += gi - gf;
+            Elem<H>::store8(reinterpret_cast<H*>(a.dinterm[v]) + vox * 8, o);
+        }
+    }
+    for (int v = 0; v < a.n_src; ++v) a.duncert[v][p] = -w[v] * inv * acc[v];
+}
+
 }  // namespace pscv
+
+extern "C" int pscv_fuse_pairs_bwd(const void* const* interm, const float* const* uncert, int n_src, int dtype, const void* grad_fused,
+                                   void* const* dinterm, float* const* duncert, int B, int D, int h, int w, void* stream) {
+    using namespace pscv;
+    PSCV_CHECK_ARG(interm && uncert && grad_fused && dinterm && duncert, "pscv_fuse_pairs_bwd: null pointer argument");
+    PSCV_CHECK_ARG(n_src >= 1 && n_src <= PSCV_MAX_SRC, "pscv_fuse_pairs_bwd: n_src=%d outside [1,%d]", n_src, PSCV_MAX_SRC);
+    PSCV_CHECK_ARG(dtype == PSCV_BF16 || dtype == PSCV_F16, "pscv_fuse_pairs_bwd: dtype %d must be bf16 or fp16", dtype);
+    PSCV_CHECK_ARG(B > 0 && D > 0 && h > 0 && w > 0, "pscv_fuse_pairs_bwd: bad sizes");
+    FuseBwdArgs a;
+    for (int i = 0; i < PSCV_MAX_SRC; ++i) {
+        a.interm[i] = i < n_src ? interm[i] : nullptr; a.uncert[i] = i < n_src ? uncert[i] : nullptr;
+        a.dinterm[i] = i < n_src ? dinterm[i] : nullptr; a.duncert[i] = i < n_src ? duncert[i] : nullptr;
+    }
+    for (int i = 0; i < n_src; ++i) PSCV_CHECK_ARG(interm[i] && uncert[i] && dinterm[i] && duncert[i], "pscv_fuse_pairs_bwd: null view %d", i);
+    a.g = grad_fused; a.n_src = n_src; a.B = B; a.D = D; a.hw = h * w;
+    const long npix = (long)B * h * w;
+    const unsigned nblk = (unsigned)((npix + 255) / 256);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == PSCV_BF16) hipLaunchKernelGGL(fuse_pairs_bwd_kernel<bf16_t>, dim3(nblk), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(fuse_pairs_bwd_kernel<f16_t>, dim3(nblk), dim3(256), 0, st, a);
+    PSCV_CHECK_LAUNCH("pscv_fuse_pairs_bwd");
+    return 0;
+}
 
 extern "C" int pscv_fuse_finish(const float* partial, const float* wsum, int dtype, void* out, int B, int D, int h, int w,
                                 void* stream) {

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const uint4* __restrict__ y
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             v[j] = fmaf(v[j], sc[j], bi[j]);
-            if (relu) v[j] = fmaxf(v[j], 0.0f);
+            if (relu == 1) v[j] = fmaxf(v[j], 0.0f);
         }
         if (skip) {
             float s[8];
@@ -107,7 +107,26 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const uint4* __restrict__ y
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] += s[j];
         }
+        if (relu == 2) {   // ReLU after the residual add (Vis BasicBlock, models/VisMVSNet/nn_utils.py:123-171)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.0f);
+        }
         out[i] = pack8<H>(v);
+    }
+}
+
+// ---- backward of a ReLU applied AFTER a residual add: dpre = dout * [out > 0] ------------------------------------------
+template <typename H>
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const uint4* __restrict__ dout, const uint4* __restrict__ out,
+                                                       uint4* __restrict__ dpre, long nchunk) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nchunk; i += stride) {
+        float g[8], o[8];
+        unpack8<H>(dout[i], g);
+        unpack8<H>(out[i], o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] = o[j] > 0.0f ? g[j] : 0.0f;
+        dpre[i] = pack8<H>(g);
     }
 }
 
@@ -166,39 +185,47 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint4* __restri
     }
 }
 
-// ---- softmax over D + depth regression, backward ---------------------------------------------------------------------
-// depth = sum_d p_d depth_d, p = softmax(logits):  d depth / d logit_d = p_d (depth_d - depth).
+// ---- softmax over D + regression heads, backward ----------------------------------------------------------------------
+// p = softmax(logits).  Heads (each optional) and their derivative w.r.t. logit_d:
+//   depth   = sum_d p_d depth_d            g_depth p_d (depth_d - depth)                 models/MVSNet/model.py:207-209
+//   index   = sum_d p_d d                  g_index p_d (d - index)                       models/VisMVSNet/nn_utils.py:453-466
+//   entropy = -sum_d p_d log clamp(p_d, 1e-9, 1)   g_ent p_d (a_d - sum_k p_k a_k), a_d = -(log clamp(p_d) + [p_d > 1e-9])   nn_utils.py:469-470
 // One lane per pixel walks D three times (max, sums, write); reads and writes are coalesced across the wave.
 // Output: the gradient volume in the conv engine's layout, [B,D,h,w,8] 16-bit with the value in channel 0 and
-// channels 1-7 zero (the 1-channel `prob` head's backward then runs on the 8-channel MFMA kernels).
+// channels 1-7 zero (the 1-channel heads' backward then runs on the 8-channel MFMA kernels).
 template <typename H>
 __global__ __launch_bounds__(256) void softargmin_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ depth,
                                                              long depth_bstride, int depth_per_pixel,
-                                                             const float* __restrict__ gdepth, uint4* __restrict__ dl8, int B,
+                                                             const float* __restrict__ gdepth, const float* __restrict__ gindex,
+                                                             const float* __restrict__ gentropy, uint4* __restrict__ dl8, int B,
                                                              int D, int hw) {
     const long p = (long)blockIdx.x * 256 + threadIdx.x;
     if (p >= (long)B * hw) return;
     const int b = (int)(p / hw);
     const int pix = (int)(p - (long)b * hw);
     const float* lp = logits + (long)b * D * hw + pix;
-    const float* dp = depth + (long)b * depth_bstride + (depth_per_pixel ? pix : 0);
+    const float* dp = gdepth ? depth + (long)b * depth_bstride + (depth_per_pixel ? pix : 0) : nullptr;
     const long dstep = depth_per_pixel ? hw : 1;
     float m = -INFINITY;
     for (int d = 0; d < D; ++d) m = fmaxf(m, lp[(long)d * hw]);
-    float z = 0.0f, zd = 0.0f;
-    for (int d = 0; d < D; ++d) {
-        const float e = __expf(lp[(long)d * hw] - m);
-        z += e;
-        zd = fmaf(e, dp[d * dstep], zd);
-    }
+    float z = 0.0f;
+    for (int d = 0; d < D; ++d) z += __expf(lp[(long)d * hw] - m);
     const float inv = 1.0f / z;
-    const float mean = zd * inv;
-    const float g = gdepth[p] * inv;
+    float e_depth = 0.0f, e_index = 0.0f, e_a = 0.0f;
+    for (int d = 0; d < D; ++d) {
+        const float pd = __expf(lp[(long)d * hw] - m) * inv;
+        if (gdepth) e_depth = fmaf(pd, dp[d * dstep], e_depth);
+        e_index = fmaf(pd, (float)d, e_index);
+        if (gentropy) e_a = fmaf(pd, -(__logf(fminf(fmaxf(pd, 1e-9f), 1.0f)) + (pd > 1e-9f ? 1.0f : 0.0f)), e_a);
+    }
+    const float gd = gdepth ? gdepth[p] : 0.0f, gi = gindex ? gindex[p] : 0.0f, ge = gentropy ? gentropy[p] : 0.0f;
     uint4* op = dl8 + (long)b * D * hw + pix;
     for (int d = 0; d < D; ++d) {
-        const float e = __expf(lp[(long)d * hw] - m);
-        const float v = g * e * (dp[d * dstep] - mean);
-        op[(long)d * hw] = make_uint4(Half16<H>::pack(v, 0.0f), 0u, 0u, 0u);
+        const float pd = __expf(lp[(long)d * hw] - m) * inv;
+        float v = gi * ((float)d - e_index);
+        if (gdepth) v = fmaf(gd, dp[d * dstep] - e_depth, v);
+        if (gentropy) v = fmaf(ge, -(__logf(fminf(fmaxf(pd, 1e-9f), 1.0f)) + (pd > 1e-9f ? 1.0f : 0.0f)) - e_a, v);
+        op[(long)d * hw] = make_uint4(Half16<H>::pack(v * pd, 0.0f), 0u, 0u, 0u);
     }
 }
 
@@ -306,17 +333,33 @@ extern "C" int pscv_bn_bwd_apply(const void* dact, const void* y, int dtype, lon
 }
 
 extern "C" int pscv_softargmin_bwd(const float* logits, const float* depth, long depth_bstride, int depth_per_pixel,
-                                   const float* grad_depth, void* dlogits8, int dtype, int B, int D, int h, int w, void* stream) {
-    PSCV_CHECK_ARG(logits && depth && grad_depth && dlogits8, "pscv_softargmin_bwd: null pointer argument");
+                                   const float* grad_depth, const float* grad_index, const float* grad_entropy, void* dlogits8,
+                                   int dtype, int B, int D, int h, int w, void* stream) {
+    PSCV_CHECK_ARG(logits && dlogits8, "pscv_softargmin_bwd: null pointer argument");
+    PSCV_CHECK_ARG(grad_depth || grad_index || grad_entropy, "pscv_softargmin_bwd: no upstream gradient given");
+    PSCV_CHECK_ARG(!grad_depth || depth, "pscv_softargmin_bwd: grad_depth needs the depth planes");
     PSCV_CHECK_ARG(B > 0 && D > 0 && h > 0 && w > 0, "pscv_softargmin_bwd: bad sizes");
     PSCV_CHECK_ARG(dtype == PSCV_BF16 || dtype == PSCV_F16, "pscv_softargmin_bwd: dtype %d must be bf16 or fp16", dtype);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const long npix = (long)B * h * w;
     const int nb = (int)((npix + 255) / 256);
     if (dtype == PSCV_BF16)
-        hipLaunchKernelGGL(softargmin_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, logits, depth, depth_bstride, depth_per_pixel, grad_depth, (uint4*)dlogits8, B, D, h * w);
+        hipLaunchKernelGGL(softargmin_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, logits, depth, depth_bstride, depth_per_pixel, grad_depth, grad_index, grad_entropy, (uint4*)dlogits8, B, D, h * w);
     else
-        hipLaunchKernelGGL(softargmin_bwd_kernel<f16_t>, dim3(nb), dim3(256), 0, st, logits, depth, depth_bstride, depth_per_pixel, grad_depth, (uint4*)dlogits8, B, D, h * w);
+        hipLaunchKernelGGL(softargmin_bwd_kernel<f16_t>, dim3(nb), dim3(256), 0, st, logits, depth, depth_bstride, depth_per_pixel, grad_depth, grad_index, grad_entropy, (uint4*)dlogits8, B, D, h * w);
     PSCV_CHECK_LAUNCH("pscv_softargmin_bwd");
+    return 0;
+}
+
+extern "C" int pscv_relu_bwd(const void* dout, const void* out, int dtype, long nvox, int C, void* dpre, void* stream) {
+    PSCV_CHECK_ARG(dout && out && dpre, "pscv_relu_bwd: null pointer argument");
+    PSCV_CHECK_ARG(C % 8 == 0 && C > 0 && nvox > 0, "pscv_relu_bwd: bad sizes");
+    PSCV_CHECK_ARG(dtype == PSCV_BF16 || dtype == PSCV_F16, "pscv_relu_bwd: dtype %d must be bf16 or fp16", dtype);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const long nchunk = nvox * (C / 8);
+    const int nb = grid_for(nchunk);
+    if (dtype == PSCV_BF16) hipLaunchKernelGGL(relu_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const uint4*)dout, (const uint4*)out, (uint4*)dpre, nchunk);
+    else hipLaunchKernelGGL(relu_bwd_kernel<f16_t>, dim3(nb), dim3(256), 0, st, (const uint4*)dout, (const uint4*)out, (uint4*)dpre, nchunk);
+    PSCV_CHECK_LAUNCH("pscv_relu_bwd");
     return 0;
 }

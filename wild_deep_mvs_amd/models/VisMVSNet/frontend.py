@@ -22,6 +22,15 @@ class Frontend(nn.Module):
         for st in (self.model.stage1, self.model.stage2, self.model.stage3):
             st.storage_dtype = dt
 
+    @property
+    def train_storage_dtype(self):
+        return self.model.stage1.train_storage_dtype
+
+    @train_storage_dtype.setter
+    def train_storage_dtype(self, dt):
+        for st in (self.model.stage1, self.model.stage2, self.model.stage3):
+            st.train_storage_dtype = dt
+
     def set_view_group(self, group):
         """Shard the source views of every stage over a torch.distributed group (None = no sharding)."""
         for st in (self.model.stage1, self.model.stage2, self.model.stage3):
@@ -47,9 +56,16 @@ class Frontend(nn.Module):
         ref_cam = self.fill_cam_array(K[:, reference_frame], R[:, reference_frame], t[:, reference_frame],
                                       depth_min[:, reference_frame], depth_interval[:, reference_frame])
         srcs_cam = [self.fill_cam_array(K[:, i], R[:, i], t[:, i], depth_min[:, i], depth_interval[:, i]) for i in src_idx]
-        with torch.no_grad():
+        with torch.set_grad_enabled(self.training):
             grp = self.model.stage1.view_group
-            if grp is None and len({tuple(i.shape) for i in imgs}) == 1:
+            if self.training:
+                # train(): per-view extractor passes like the reference (frontend.py:59-61: each view normalises with its own
+                # batch statistics), on PyTorch-ROCm autograd (upstream of the path); the stages are the engine's autograd nodes
+                if grp is not None:
+                    raise NotImplementedError("pscv Vis-MVSNet: the source-view shard is an inference path")
+                ref_feats = self.model.feat_ext(imgs[reference_frame])
+                src_feats = [self.model.feat_ext(imgs[i]) for i in src_idx]
+            elif grp is None and len({tuple(i.shape) for i in imgs}) == 1:
                 # all views through the 2-D extractor as one batch (same result as the per-view loop in eval mode)
                 packs = [torch.chunk(f, v, 0) for f in self.model.feat_ext(torch.cat([imgs[reference_frame]] + [imgs[i] for i in src_idx], 0))]
                 ref_feats = tuple(p[0] for p in packs)

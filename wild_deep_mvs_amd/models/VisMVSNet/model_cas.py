@@ -18,6 +18,7 @@ import torch.nn.functional as F
 
 from ... import _lib as L
 from ... import ops
+from ... import training as T
 from .nn_utils import UNet
 
 cpg = 8
@@ -77,7 +78,8 @@ class _RegUNet(nn.Module):
     def run_unet(self, x: torch.Tensor) -> torch.Tensor:
         """x [n,d,h,w,8] 16-bit channels-last -> [n,d,h,w,8]."""
         if self.training:
-            raise NotImplementedError("pscv Vis U-Net: inference only for now; call .eval()")
+            raise RuntimeError("pscv Vis U-Net: in train() mode the U-Net runs inside training.VisUNetFn (SingleStage.forward "
+                               "routes there); this entry point is the eval-mode engine")
         n, d, h, w, _ = x.shape
         if d % 2 or h % 2 or w % 2:
             raise ValueError(f"Vis U-Net needs even d,h,w (got {d},{h},{w}), as in the reference")
@@ -157,6 +159,7 @@ class SingleStage(nn.Module):
         self.reg_pair = RegPair()
         self.uncert_net = UncertNet(1)
         self.storage_dtype = torch.float16
+        self.train_storage_dtype = torch.bfloat16   # train(): bf16 activations / gradients by default (range), fp32 accumulation
         # source-view shard: with a torch.distributed group set here, rank r warps and
         # regularises source views r, r+G, ... only; the visibility-weighted sums are all-reduced (RCCL) and every rank
         # then runs RegFuse on the same fused volume.  The reference has no counterpart (it loops over all views).
@@ -175,16 +178,47 @@ class SingleStage(nn.Module):
         return ops.warp_cost(ref_cl, srcs_cl, cams, planes.contiguous(), geom=L.GEOM_HOMOG, cost=L.COST_GROUPCORR,
                              out_dtype=self.storage_dtype)
 
+    def forward_train(self, ref_feat, ref_cam, srcs_feat, srcs_cam, depth_num, depth_start, depth_interval, s_scale):
+        """One cascade stage in train() mode with autograd (reference model_cas.py:303-420 under ``loss.backward()``): the
+        fused warp + group correlation, the pair / fuse U-Nets (batch-statistics BatchNorm), the score heads with expected
+        index + entropy and the visibility-weighted fusion are the engine's autograd nodes (training.WarpCostFn / VisUNetFn /
+        ScoreHeadFn / FusePairsFn); the 2-D ``UncertNet`` on the entropy map stays on PyTorch-ROCm autograd.  The homographies
+        carry no gradient (homography.py:25,92,110)."""
+        n, _, h, w = ref_feat.shape
+        dt = self.train_storage_dtype
+        if depth_num % 2 or h % 2 or w % 2:
+            raise ValueError(f"Vis U-Net needs even d,h,w (got {depth_num},{h},{w}), as in the reference")
+        steps = torch.arange(depth_num, dtype=torch.float32, device=ref_feat.device).view(1, depth_num, 1, 1)
+        planes = (depth_start.detach() + depth_interval.detach() * steps).to(torch.float32)
+        planes = planes.reshape(n, depth_num) if planes.shape[2:] == (1, 1) else planes.expand(n, depth_num, h, w)
+        cams = ops.homog_cams_device(ref_cam.detach(), [c.detach() for c in srcs_cam], 1.0 / s_scale)
+        costs = T.WarpCostFn.apply(cams, planes.contiguous(), L.GEOM_HOMOG, L.COST_GROUPCORR, dt, None, ref_feat, *srcs_feat)
+        reg_params = T.VisUNetFn.params(self.reg)
+        interms, uncerts, pair_results = [], [], []
+        for i in range(len(srcs_feat)):
+            interm = T.VisUNetFn.apply(self.reg, dt, costs[i], *reg_params)
+            idx, ent, _ = T.ScoreHeadFn.apply(dt, None, interm, self.reg_pair.final_conv.weight)
+            est_depth = idx.unsqueeze(1) * depth_interval + depth_start                  # model_cas.py:348
+            heads = self.uncert_net(ent.unsqueeze(1))
+            pair_results.append([est_depth, heads])
+            interms.append(interm)
+            uncerts.append(heads[0].squeeze(1))
+        fused = T.FusePairsFn.apply(len(interms), *interms, *uncerts)                    # model_cas.py:354-357,385-386
+        fu = T.VisUNetFn.apply(self.reg_fuse, dt, fused, *T.VisUNetFn.params(self.reg_fuse))
+        idx, _, conf = T.ScoreHeadFn.apply(dt, 2.0, fu, self.reg_fuse.final_conv.weight)
+        est_depth = idx.unsqueeze(1) * depth_interval + depth_start                      # model_cas.py:404-405
+        return est_depth, conf.unsqueeze(1), pair_results
+
     def forward(self, sample, depth_num, upsample=False, mem=False, mode='soft', depth_start_override=None,
                 depth_interval_override=None, s_scale=1, taps: Optional[dict] = None):
         if mem or mode != 'soft' or upsample:
             raise NotImplementedError("pscv Vis-MVSNet implements the reference's live configuration: mode='soft', "
                                       "no mem, no upsample (frontend.py:28-30)")
-        if self.training:
-            raise NotImplementedError("pscv Vis-MVSNet: inference only for now; call .eval()")
         ref_feat, ref_cam, srcs_feat, srcs_cam = sample
         depth_start = ref_cam[:, 1:2, 3:4, 0:1] if depth_start_override is None else depth_start_override
         depth_interval = ref_cam[:, 1:2, 3:4, 1:2] if depth_interval_override is None else depth_interval_override
+        if self.training:
+            return self.forward_train(ref_feat, ref_cam, srcs_feat, srcs_cam, depth_num, depth_start, depth_interval, s_scale)
         n_views = len(srcs_feat)
         world, rank = 1, 0
         if self.view_group is not None:

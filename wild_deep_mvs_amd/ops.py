@@ -563,16 +563,17 @@ def bn_stats(y: torch.Tensor) -> torch.Tensor:
     return sums
 
 
-def bn_act(y: torch.Tensor, scale: torch.Tensor, bias: torch.Tensor, *, relu: bool, skip: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """[relu](y * scale + bias) + skip on a 16-bit channels-last volume (pscv_bn_act)."""
+def bn_act(y: torch.Tensor, scale: torch.Tensor, bias: torch.Tensor, *, relu, skip: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[relu](y * scale + bias) + skip on a 16-bit channels-last volume (pscv_bn_act).  ``relu``: False / True (before the
+    skip add) / "post" (after it: the Vis BasicBlock)."""
     _dev(y, scale, bias, skip)
     _vol16(y, "bn_act")
     if skip is not None and (skip.shape != y.shape or skip.dtype != y.dtype):
         raise ValueError("pscv.bn_act: skip must match y")
     Cc = y.shape[4]
     out = torch.empty_like(y)
-    rc = _launch("bn_act", lambda: L.lib().pscv_bn_act(_p(y), _dt(y), y.numel() // Cc, Cc, _p(scale), _p(bias), int(relu), _p(skip),
-                                                      _p(out), _stream()))
+    rc = _launch("bn_act", lambda: L.lib().pscv_bn_act(_p(y), _dt(y), y.numel() // Cc, Cc, _p(scale), _p(bias), 2 if relu == "post" else int(bool(relu)),
+                                                      _p(skip), _p(out), _stream()))
     L.check(rc, "pscv_bn_act")
     return out
 
@@ -605,20 +606,59 @@ def bn_bwd_apply(dact: torch.Tensor, y: torch.Tensor, scale: torch.Tensor, bias:
     return dy
 
 
-def softargmin_bwd(logits: torch.Tensor, depth: torch.Tensor, grad_depth: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
-    """logits fp32 [B,D,h,w], depth planes [B,D] / [B,D,h,w], grad_depth fp32 [B,h,w] -> [B,D,h,w,8] in ``dtype``
-    with d loss / d logit in channel 0 and zeros elsewhere (pscv_softargmin_bwd)."""
-    _dev(logits, depth, grad_depth)
-    if logits.dtype != torch.float32 or logits.dim() != 4 or depth.dtype != torch.float32 or grad_depth.dtype != torch.float32:
-        raise TypeError("pscv.softargmin_bwd: fp32 logits [B,D,h,w], fp32 depth planes and fp32 grad_depth expected")
+def softargmin_bwd(logits: torch.Tensor, depth: Optional[torch.Tensor], grad_depth: Optional[torch.Tensor], dtype: torch.dtype, *,
+                   grad_index: Optional[torch.Tensor] = None, grad_entropy: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """logits fp32 [B,D,h,w]; upstream gradients fp32 [B,h,w] of depth (needs the planes [B,D] / [B,D,h,w]), expected index
+    and entropy (each optional) -> [B,D,h,w,8] in ``dtype`` with d loss / d logit in channel 0 and zeros elsewhere
+    (pscv_softargmin_bwd)."""
+    _dev(logits, depth, grad_depth, grad_index, grad_entropy)
+    if logits.dtype != torch.float32 or logits.dim() != 4:
+        raise TypeError("pscv.softargmin_bwd: fp32 logits [B,D,h,w] expected")
     B, D, h, w = logits.shape
-    if tuple(grad_depth.shape) != (B, h, w) or depth.shape[:2] != (B, D):
-        raise ValueError("pscv.softargmin_bwd: shape mismatch")
+    for g in (grad_depth, grad_index, grad_entropy):
+        if g is not None and (g.dtype != torch.float32 or tuple(g.shape) != (B, h, w)):
+            raise ValueError("pscv.softargmin_bwd: upstream gradients must be fp32 [B,h,w]")
+    if grad_depth is not None and (depth is None or depth.dtype != torch.float32 or depth.shape[:2] != (B, D)):
+        raise ValueError("pscv.softargmin_bwd: grad_depth needs fp32 depth planes [B,D] or [B,D,h,w]")
     out = torch.empty((B, D, h, w, 8), dtype=dtype, device=logits.device)
-    rc = _launch("softargmin_bwd", lambda: L.lib().pscv_softargmin_bwd(_p(logits), _p(depth), depth.stride(0), int(depth.dim() == 4),
-                                                                      _p(grad_depth), _p(out), _TORCH2PSCV[dtype], B, D, h, w, _stream()))
+    rc = _launch("softargmin_bwd", lambda: L.lib().pscv_softargmin_bwd(
+        _p(logits), _p(depth), 0 if depth is None else depth.stride(0), int(depth is not None and depth.dim() == 4), _p(grad_depth),
+        _p(grad_index), _p(grad_entropy), _p(out), _TORCH2PSCV[dtype], B, D, h, w, _stream()))
     L.check(rc, "pscv_softargmin_bwd")
     return out
+
+
+def relu_bwd(dout: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """dout * [out > 0] on 16-bit channels-last volumes (pscv_relu_bwd): backward of a ReLU applied after a residual add."""
+    _dev(dout, out)
+    _vol16(out, "relu_bwd")
+    if dout.shape != out.shape or dout.dtype != out.dtype:
+        raise ValueError("pscv.relu_bwd: dout must match out")
+    Cc = out.shape[4]
+    dpre = torch.empty_like(out)
+    rc = _launch("relu_bwd", lambda: L.lib().pscv_relu_bwd(_p(dout), _p(out), _dt(out), out.numel() // Cc, Cc, _p(dpre), _stream()))
+    L.check(rc, "pscv_relu_bwd")
+    return dpre
+
+
+def fuse_pairs_bwd(interms: Sequence[torch.Tensor], uncerts: Sequence[torch.Tensor], grad_fused: torch.Tensor):
+    """Backward of ``fuse_pairs``: ([d interm_v] 16-bit, [d uncert_v] fp32 [B,h,w]) (pscv_fuse_pairs_bwd)."""
+    interms, uncerts = list(interms), list(uncerts)
+    _dev(grad_fused, *interms, *uncerts)
+    B, D, h, w, c = interms[0].shape
+    if grad_fused.shape != interms[0].shape or grad_fused.dtype != interms[0].dtype:
+        raise ValueError("pscv.fuse_pairs_bwd: grad_fused must match the pair volumes")
+    n = len(interms)
+    dI = [torch.empty_like(t) for t in interms]
+    dU = [torch.empty((B, h, w), dtype=torch.float32, device=grad_fused.device) for _ in range(n)]
+    ip = (C.c_void_p * n)(*[t.data_ptr() for t in interms])
+    up = (C.c_void_p * n)(*[t.data_ptr() for t in uncerts])
+    dip = (C.c_void_p * n)(*[t.data_ptr() for t in dI])
+    dup = (C.c_void_p * n)(*[t.data_ptr() for t in dU])
+    rc = _launch("fuse_pairs_bwd", lambda: L.lib().pscv_fuse_pairs_bwd(ip, up, n, _dt(interms[0]), _p(grad_fused), dip, dup, B, D, h, w,
+                                                                      _stream()))
+    L.check(rc, "pscv_fuse_pairs_bwd")
+    return dI, dU
 
 
 def conv3d_wgrad(p: torch.Tensor, q: torch.Tensor, *, ca: int, cb: int, stride: int, p_coff: int = 0, q_coff: int = 0) -> torch.Tensor:

@@ -248,3 +248,25 @@ def supervised_loss_list(depth_list: Sequence[torch.Tensor], gt: torch.Tensor, m
         m = (F.interpolate(mask.unsqueeze(1).float(), size=(hd, wd), mode="bilinear", align_corners=False).squeeze(1) == 1).float()
         loss = loss + torch.sum(torch.abs(d - g) / interval * m) / torch.sum(m)
     return loss
+
+
+VIS_LOSS_FACTORS = (2, 1, 0.5)   # models/trainer.py:33
+
+
+def vis_supervised_loss(out, gt: torch.Tensor, mask: torch.Tensor, depth_min: torch.Tensor, depth_max: torch.Tensor, n_views: int):
+    """The supervised Vis-MVSNet loss of models/trainer.py:118-206: per stage ``factor * masked L1`` on the fused depth plus
+    ``factor / (n - 1) * bayesian_version_loss`` (models/utils.py:110-119) on every pair depth with its log-uncertainty."""
+    import torch.nn.functional as F
+    interval = ((depth_max - depth_min) / 128)[:, 0].view(-1, 1, 1, 1)
+    loss = 0
+    for i, d in enumerate(out["depth_est_list"]):
+        hd, wd = d.shape[1:]
+        g = F.interpolate(gt.unsqueeze(1), size=(hd, wd), mode="bilinear", align_corners=False)
+        m = (F.interpolate(mask.unsqueeze(1).float(), size=(hd, wd), mode="bilinear", align_corners=False) == 1).float()
+        l1 = torch.abs(d.unsqueeze(1) - g) / interval
+        loss = loss + VIS_LOSS_FACTORS[i] * torch.sum(l1 * m) / torch.sum(m)
+        for dp, (unc,) in out["depth_pair_list"][i]:
+            l1p = torch.abs(dp.squeeze(1).unsqueeze(1) - g) / interval
+            loss = loss + VIS_LOSS_FACTORS[i] / (n_views - 1) * (torch.sum((l1p * torch.exp(-unc) + unc) * m) / torch.sum(m)
+                                                               + torch.sum(l1p * m) / torch.sum(m))
+    return loss

@@ -253,3 +253,184 @@ class RegressFn(torch.autograd.Function):
             out.append(pgrads.get(id(p)))
         ctx.t = ctx.saved_bn = None
         return tuple(out)
+
+
+# --------------------------------------------------------------------------------------------------
+# Vis-MVSNet: residual-block U-Net, score heads, visibility-weighted fusion
+# --------------------------------------------------------------------------------------------------
+def _bn_stats_affine(bn: nn.BatchNorm3d, y: torch.Tensor):
+    """Batch statistics of a stored conv output -> (scale, bias, mean, invstd, nvox); updates the running statistics."""
+    nvox = y.numel() // y.shape[4]
+    scale, bias, mean, invstd = _bn_affine(Block("", "", y, bn=bn), ops.bn_stats(y), nvox)
+    return scale, bias, mean, invstd, nvox
+
+
+def _bn_backward(bn: nn.BatchNorm3d, dz_src: torch.Tensor, y: torch.Tensor, saved, relu: bool):
+    """BatchNorm(+ReLU before any skip) backward on the engine: returns (dy, d gamma, d beta)."""
+    scale, bias, mean, invstd, nvox = saved
+    s = ops.bn_bwd_reduce(dz_src, y, scale, bias, relu=relu)
+    s1 = s[0]
+    s2 = invstd * (s[1] - mean * s[0])
+    k = bn.weight.detach().float() * invstd
+    ca = k.contiguous()
+    cb = (-k * invstd * s2 / nvox).contiguous()
+    cc = (-k * s1 / nvox + k * invstd * mean * s2 / nvox).contiguous()
+    dy = ops.bn_bwd_apply(dz_src, y, scale, bias, ca, cb, cc, relu=relu)
+    return dy, s2.to(bn.weight.dtype), s1.to(bn.bias.dtype)
+
+
+class VisUNetFn(torch.autograd.Function):
+    """``UNet(8, 1, 0, 4, [], [8, 16], [], tag, dim=3)`` of Vis-MVSNet (models/VisMVSNet/nn_utils.py:194-278, used by
+    ``Reg`` / ``RegFuse``, model_cas.py:38-74) in train() mode, forward and backward on the engine:
+
+        enc0 = relu(bn(conv(relu(bn(conv(x))))) + x)                         BasicBlock 8 -> 8
+        e1   = relu(bn(conv(relu(bn(conv_s2(enc0))))) + bn(conv1x1_s2(enc0)))  BasicBlock 8 -> 16, strided 1x1x1 shortcut
+        out  = conv(cat([deconv_s2(e1), enc0]))                              linear decoder (no BN / ReLU)
+
+    ``forward(ctx, holder, dtype, x, *params)`` with ``params = VisUNetFn.params(holder)``; x / out [n,d,h,w,8] 16-bit."""
+
+    @staticmethod
+    def parts(holder):
+        enc = list(holder.unet.enc_blocks.values())
+        return enc[0][0], enc[1][0], list(holder.unet.dec_blocks.values())[0]
+
+    @staticmethod
+    def params(holder) -> List[torch.Tensor]:
+        b0, b1, dec = VisUNetFn.parts(holder)
+        return [b0.conv1.weight, b0.bn1.weight, b0.bn1.bias, b0.conv2.weight, b0.bn2.weight, b0.bn2.bias,
+                b1.conv1.weight, b1.bn1.weight, b1.bn1.bias, b1.downsample[0].weight, b1.downsample[1].weight, b1.downsample[1].bias,
+                b1.conv2.weight, b1.bn2.weight, b1.bn2.bias, dec[0].weight, dec[1].weight]
+
+    @staticmethod
+    def _ds_weight(b1):
+        """The strided 1x1x1 shortcut conv as the centre tap of a 3x3x3 stride-2 conv (reads 2*o + 1 - 1 = 2*o)."""
+        w = b1.downsample[0].weight
+        w3 = torch.zeros((w.shape[0], w.shape[1], 3, 3, 3), dtype=torch.float32, device=w.device)
+        w3[:, :, 1, 1, 1] = w.detach().float().view(w.shape[0], w.shape[1])
+        return w3
+
+    @staticmethod
+    def forward(ctx, holder, dtype, x, *params):
+        b0, b1, dec = VisUNetFn.parts(holder)
+        dev = x.device
+        mk = lambda w, kind, tr=False: ops.Conv3dLayer.build(w, kind=kind, transposed=tr, device=dev, dtype=dtype)
+        y1 = ops.conv3d(x, mk(b0.conv1.weight, L.CONV_S1))
+        a1 = _bn_stats_affine(b0.bn1, y1)
+        t = ops.bn_act(y1, a1[0], a1[1], relu=True)
+        y2 = ops.conv3d(t, mk(b0.conv2.weight, L.CONV_S1))
+        a2 = _bn_stats_affine(b0.bn2, y2)
+        enc0 = ops.bn_act(y2, a2[0], a2[1], relu="post", skip=x)
+        y3 = ops.conv3d(enc0, mk(b1.conv1.weight, L.CONV_S2))
+        a3 = _bn_stats_affine(b1.bn1, y3)
+        t1 = ops.bn_act(y3, a3[0], a3[1], relu=True)
+        y4 = ops.conv3d(enc0, mk(VisUNetFn._ds_weight(b1), L.CONV_S2))
+        a4 = _bn_stats_affine(b1.downsample[1], y4)
+        ds = ops.bn_act(y4, a4[0], a4[1], relu=False)
+        y5 = ops.conv3d(t1, mk(b1.conv2.weight, L.CONV_S1))
+        a5 = _bn_stats_affine(b1.bn2, y5)
+        e1 = ops.bn_act(y5, a5[0], a5[1], relu="post", skip=ds)
+        up = ops.conv3d(e1, mk(dec[0].weight, L.CONV_T2, True))
+        cat = torch.cat([up, enc0], dim=4)                                   # deconv channels first (nn_utils.py:269-271)
+        out = ops.conv3d(cat, mk(dec[1].weight, L.CONV_S1))
+        ctx.holder, ctx.dtype = holder, dtype
+        ctx.t = dict(x=x, y1=y1, t=t, y2=y2, enc0=enc0, y3=y3, t1=t1, y4=y4, y5=y5, e1=e1, cat=cat)
+        ctx.a = (a1, a2, a3, a4, a5)
+        if TRACE is not None:
+            TRACE.setdefault("vis_unet", []).append(dict(ctx.t, ds=ds, up=up, out=out))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        b0, b1, dec = VisUNetFn.parts(ctx.holder)
+        T_, dtype = ctx.t, ctx.dtype
+        a1, a2, a3, a4, a5 = ctx.a
+        dev = g.device
+        g = g.contiguous()
+        mk = lambda w, kind, tr=False: ops.Conv3dLayer.build(w, kind=kind, transposed=tr, device=dev, dtype=dtype)
+        # post conv 16 -> 8 (linear): weight gradient, then d cat (16 channels) through the flipped-tap adjoint
+        dw_post = ops.conv3d_wgrad(g, T_["cat"], ca=8, cb=16, stride=1)
+        dcat = ops.conv3d(g, mk(dec[1].weight, L.CONV_S1, True))
+        # deconv 16 -> 8 s2 (linear): P = its input e1, Q = channels 0..7 of d cat
+        dw_dec = ops.conv3d_wgrad(T_["e1"], dcat, ca=16, cb=8, stride=2)
+        de1 = ops.conv3d(dcat, mk(dec[0].weight, L.CONV_S2, False), in_coff=0)
+        # block 1, second conv: e1 = relu(bn2(conv2(t1)) + ds)
+        dpre = ops.relu_bwd(de1, T_["e1"])
+        dy5, dg5, db5 = _bn_backward(b1.bn2, dpre, T_["y5"], a5, relu=False)
+        dw_c2b = ops.conv3d_wgrad(dy5, T_["t1"], ca=16, cb=16, stride=1)
+        dt1 = ops.conv3d(dy5, mk(b1.conv2.weight, L.CONV_S1, True))
+        # shortcut: ds = bn(conv1x1_s2(enc0)); its gradient is dpre
+        dy4, dg4, db4 = _bn_backward(b1.downsample[1], dpre, T_["y4"], a4, relu=False)
+        dw_ds = ops.conv3d_wgrad(dy4, T_["enc0"], ca=16, cb=8, stride=2)[:, :, 1, 1, 1].reshape(b1.downsample[0].weight.shape)
+        denc0 = ops.conv3d(dy4, mk(VisUNetFn._ds_weight(b1), L.CONV_T2, True), skip=dcat, skip_coff=8)   # + d cat[..., 8:16]
+        # block 1, first conv (stride 2)
+        dy3, dg3, db3 = _bn_backward(b1.bn1, dt1, T_["y3"], a3, relu=True)
+        dw_c1b = ops.conv3d_wgrad(dy3, T_["enc0"], ca=16, cb=8, stride=2)
+        denc0 = ops.conv3d(dy3, mk(b1.conv1.weight, L.CONV_T2, True), skip=denc0)
+        # block 0: enc0 = relu(bn2(conv2(t)) + x)
+        dpre0 = ops.relu_bwd(denc0, T_["enc0"])
+        dy2, dg2, db2 = _bn_backward(b0.bn2, dpre0, T_["y2"], a2, relu=False)
+        dw_c2a = ops.conv3d_wgrad(dy2, T_["t"], ca=8, cb=8, stride=1)
+        dt = ops.conv3d(dy2, mk(b0.conv2.weight, L.CONV_S1, True))
+        dy1, dg1, db1 = _bn_backward(b0.bn1, dt, T_["y1"], a1, relu=True)
+        dw_c1a = ops.conv3d_wgrad(dy1, T_["x"], ca=8, cb=8, stride=1)
+        dx = ops.conv3d(dy1, mk(b0.conv1.weight, L.CONV_S1, True), skip=dpre0) if ctx.needs_input_grad[2] else None
+        if TRACE is not None:
+            TRACE.setdefault("vis_unet_bwd", []).append(dict(g=g, dcat=dcat, de1=de1, dpre=dpre, dy5=dy5, dt1=dt1, dy4=dy4, dy3=dy3,
+                                                             denc0=denc0, dpre0=dpre0, dy2=dy2, dt=dt, dy1=dy1, dx=dx))
+        wd = lambda t_, p: t_.to(p.dtype)
+        grads = [wd(dw_c1a, b0.conv1.weight), dg1, db1, wd(dw_c2a, b0.conv2.weight), dg2, db2,
+                 wd(dw_c1b, b1.conv1.weight), dg3, db3, wd(dw_ds, b1.downsample[0].weight), dg4, db4,
+                 wd(dw_c2b, b1.conv2.weight), dg5, db5, wd(dw_dec, dec[0].weight), wd(dw_post, dec[1].weight)]
+        ctx.t = None
+        return (None, None, dx, *grads)
+
+
+class ScoreHeadFn(torch.autograd.Function):
+    """1-channel score head (``final_conv`` 8 -> 1, no bias: RegPair / RegFuse, model_cas.py:51-74) + softmax over the
+    planes + expected index, entropy and the +-window probability (nn_utils.py:453-470), forward and backward on the
+    engine.  Returns (index [n,h,w], entropy [n,h,w], window prob [n,h,w] or None-like zeros); the window probability is
+    not differentiated (the reference only reports it)."""
+
+    @staticmethod
+    def forward(ctx, dtype, window, interm, weight):
+        lay = ops.Conv3dLayer.build(weight, kind=L.CONV_S1, device=interm.device, dtype=dtype)
+        score = ops.conv3d(interm, lay, out_dtype=torch.float32).squeeze(-1)
+        o = ops.softargmin(score, None, want_index=True, want_entropy=True, want_conf=window is not None, conf_mode=1,
+                           window=float(window or 0))
+        ctx.dtype, ctx.score, ctx.interm, ctx.weight = dtype, score, interm, weight
+        conf = o["conf"] if window is not None else torch.zeros_like(o["index"])
+        ctx.mark_non_differentiable(conf)
+        if TRACE is not None:
+            TRACE.setdefault("vis_head", []).append(dict(interm=interm, score=score, index=o["index"], entropy=o["entropy"]))
+        return o["index"], o["entropy"], conf
+
+    @staticmethod
+    def backward(ctx, g_index, g_entropy, _g_conf):
+        dtype, score, interm, weight = ctx.dtype, ctx.score, ctx.interm, ctx.weight
+        gi = g_index.contiguous().float() if g_index is not None else None
+        ge = g_entropy.contiguous().float() if g_entropy is not None else None
+        dl8 = ops.softargmin_bwd(score, None, None, dtype, grad_index=gi, grad_entropy=ge)
+        dw = ops.conv3d_wgrad(dl8, interm, ca=8, cb=8, stride=1)[:1].to(weight.dtype)
+        w8 = torch.zeros((8,) + tuple(weight.shape[1:]), dtype=torch.float32, device=interm.device)
+        w8[:1] = weight.detach().float()
+        dinterm = ops.conv3d(dl8, ops.Conv3dLayer.build(w8, kind=L.CONV_S1, transposed=True, device=interm.device, dtype=dtype))
+        if TRACE is not None:
+            TRACE.setdefault("vis_head_bwd", []).append(dict(dl8=dl8, dw=dw, dinterm=dinterm))
+        return None, None, dinterm, dw
+
+
+class FusePairsFn(torch.autograd.Function):
+    """fused = sum_v exp(-u_v) I_v / sum_v exp(-u_v) (model_cas.py:354-357,385-386), forward and backward on the engine.
+    ``forward(ctx, n, I_0..I_{n-1}, u_0..u_{n-1})`` with I_v [B,D,h,w,8] 16-bit and u_v [B,h,w] fp32."""
+
+    @staticmethod
+    def forward(ctx, n, *tensors):
+        interms = [t.contiguous() for t in tensors[:n]]
+        uncerts = [t.contiguous().float() for t in tensors[n:]]
+        ctx.n, ctx.interms, ctx.uncerts = n, interms, uncerts
+        return ops.fuse_pairs(interms, uncerts)
+
+    @staticmethod
+    def backward(ctx, g):
+        dI, dU = ops.fuse_pairs_bwd(ctx.interms, ctx.uncerts, g.contiguous())
+        return (None, *dI, *dU)
