@@ -133,6 +133,10 @@ int pscv_warp_cost(const void* ref, const void* const* srcs, int n_src, const fl
  */
 long pscv_pack_conv3d_weights(const float* w /*host*/, int c_in, int c_out, int kind, int transposed, int dtype,
                               uint16_t* packed /*host, may be NULL*/);
+/* The same packing as one launch on device pointers (fp32 weights in, packed 16-bit out; the element count comes from
+ * pscv_pack_conv3d_weights(NULL ...)): no device -> host copy when the weights change every optimizer step. */
+int pscv_pack_conv3d_weights_device(const float* w /*device*/, int c_in, int c_out, int kind, int transposed, int dtype,
+                                    uint16_t* packed /*device*/, void* stream);
 
 /*
  * 3x3x3 convolution as an MFMA implicit GEMM with fused per-channel affine (folded eval-mode BatchNorm or bias),

@@ -246,3 +246,20 @@ def test_parity_pair_deconv_matches_generic_kernel_and_aten(env, shape, dtype):
     check_close("t2p8 slice output", buf[..., :8].float().permute(0, 4, 1, 2, 3).cpu(), want,
                 max_abs=(2 ** -8 if dtype == torch.bfloat16 else 2 ** -11) * float(want.abs().max()) + 1e-3)
     assert float((buf[..., 8:].float() - 3.0).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_device_weight_packing_equals_host_packing(dtype):
+    """pscv_pack_conv3d_weights_device (one launch, used when the weights live on the GPU: every training step) writes
+    exactly the bits of the host packer for every layout (dense S1 / S2 / T2 incl. flipped-tap transposed S1, and the
+    three special kernels' layouts)."""
+    from wild_deep_mvs_amd import _lib as L, ops
+    g = torch.Generator().manual_seed(5)
+    cases = [(8, 32, L.CONV_S1, False), (32, 8, L.CONV_S1, True), (64, 32, L.CONV_S1, True), (16, 8, L.CONV_S2, False),
+             (64, 32, L.CONV_S2, False), (64, 32, L.CONV_T2, True), (32, 16, L.CONV_T2, True), (8, 32, L.CONV_S1P8, False),
+             (16, 8, L.CONV_T2P8, True), (1, 8, L.CONV_S1C1, False), (1, 16, L.CONV_S1C1, False)]
+    for a, b, kind, tr in cases:
+        w = torch.randn(a, b, 3, 3, 3, generator=g)
+        host = torch.from_numpy(ops.pack_conv3d_weights(w, kind, tr, dtype).view(np.int16))
+        dev = ops.pack_conv3d_weights_device(w.cuda(), kind, tr, dtype).cpu()
+        assert torch.equal(host, dev), (a, b, kind, tr)

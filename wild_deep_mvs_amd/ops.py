@@ -395,6 +395,25 @@ def pack_conv3d_weights(weight: torch.Tensor, kind: int, transposed: bool,
     return packed
 
 
+def pack_conv3d_weights_device(weight: torch.Tensor, kind: int, transposed: bool, dtype: torch.dtype) -> torch.Tensor:
+    """Same repack as ``pack_conv3d_weights`` in one launch on the GPU (pscv_pack_conv3d_weights_device): weights that
+    change every optimizer step never travel to the host.  Returns the packed int16 tensor on the weight's device."""
+    w = weight.detach().to(torch.float32).contiguous()
+    _dev(w)
+    if w.dim() != 5 or tuple(w.shape[2:]) != (3, 3, 3):
+        raise ValueError(f"pscv: conv3d weights must be [*,*,3,3,3], got {tuple(w.shape)}")
+    c_in, c_out = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
+    code = _TORCH2PSCV.get(dtype, -1)
+    n = L.lib().pscv_pack_conv3d_weights(None, c_in, c_out, kind, int(transposed), code, None)
+    if n < 0:
+        L.check(int(n), "pscv_pack_conv3d_weights")
+    packed = torch.empty((n,), dtype=torch.int16, device=w.device)
+    rc = _launch("pack_conv3d_weights", lambda: L.lib().pscv_pack_conv3d_weights_device(_p(w), c_in, c_out, kind, int(transposed), code,
+                                                                                       _p(packed), _stream()))
+    L.check(rc, "pscv_pack_conv3d_weights_device")
+    return packed
+
+
 @dataclass
 class Conv3dLayer:
     """One 3x3x3 layer ready for the engine: packed 16-bit weights + fp32 epilogue vectors, on device."""
@@ -423,7 +442,10 @@ class Conv3dLayer:
             kind = L.CONV_T2P8     # same result, parity-pair packed MFMA rows + contiguous 32-byte stores
         if kind == L.CONV_S1 and not transposed and c_in in (8, 16) and c_out == 1 and USE_SWEEP_KERNEL:
             kind = L.CONV_S1C1     # same result, depth-in-rows MFMA kernel for the 1-channel heads
-        packed = torch.from_numpy(pack_conv3d_weights(weight, kind, transposed, dtype).view(np.int16)).to(device)
+        if weight.is_cuda and torch.device(device).type == "cuda":
+            packed = pack_conv3d_weights_device(weight, kind, transposed, dtype)
+        else:
+            packed = torch.from_numpy(pack_conv3d_weights(weight, kind, transposed, dtype).view(np.int16)).to(device)
         scale = bias = None
         if bn is not None:
             gamma, beta, mean, var = [t.detach().to(device, torch.float32) for t in bn]
