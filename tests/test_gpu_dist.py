@@ -74,3 +74,80 @@ def test_vis_source_view_shard_two_ranks_one_gpu():
                 r = g[f"pair_depth_s{3 - si}_v{vi}"]
                 assert np.abs(ed - r).mean() / np.abs(r).mean() <= 2e-3
     assert np.abs(res[0][1] - res[1][1]).max() <= 1e-5, "ranks must agree on the fused result"
+
+
+def _ddp_worker(rank, world, port, q):
+    """What train.py:52-59,136 does per process: gloo process group on localhost, DistributedDataParallel around the model
+    (device_ids=[0]: both ranks share cuda:0 here), one training step on this rank's own sample."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from torch.nn.parallel import DistributedDataParallel
+        from wild_deep_mvs_amd import synthetic
+        from wild_deep_mvs_amd.models.MVSNet.model import MVSNet
+        net = MVSNet("variance")
+        net.load_state_dict(synthetic.train_state_dict("mvsnet", synthetic.template_of(net), seed=0))
+        net.num_depth = 16
+        ddp = DistributedDataParallel(net.cuda(), device_ids=[0])
+        ddp.train()
+        scene = synthetic.make_scene(1, 3, 64, 96, seed=10 + rank)
+        out = ddp(*[scene[k].cuda() for k in ("imgs", "K", "R", "t", "depth_min", "depth_max")])
+        gt, mask = synthetic.train_target(scene, 16, 24, seed=20 + rank)
+        loss = synthetic.supervised_loss(out["depth"], gt.cuda(), mask.cuda(), scene["depth_min"].cuda(), scene["depth_max"].cuda())
+        loss.backward()
+        torch.cuda.synchronize()
+        grads = {k: p.grad.detach().cpu().numpy() for k, p in net.named_parameters()}
+        q.put((rank, float(loss.detach()), grads))
+    finally:
+        dist.destroy_process_group()
+
+
+def _single_worker(q):
+    """The same two samples in one process, gradients averaged by hand: what DDP's all-reduce must produce."""
+    from wild_deep_mvs_amd import synthetic
+    from wild_deep_mvs_amd.models.MVSNet.model import MVSNet
+    acc = None
+    for rank in range(2):
+        net = MVSNet("variance")
+        net.load_state_dict(synthetic.train_state_dict("mvsnet", synthetic.template_of(net), seed=0))
+        net.num_depth = 16
+        net = net.cuda().train()
+        scene = synthetic.make_scene(1, 3, 64, 96, seed=10 + rank)
+        out = net(*[scene[k].cuda() for k in ("imgs", "K", "R", "t", "depth_min", "depth_max")])
+        gt, mask = synthetic.train_target(scene, 16, 24, seed=20 + rank)
+        loss = synthetic.supervised_loss(out["depth"], gt.cuda(), mask.cuda(), scene["depth_min"].cuda(), scene["depth_max"].cuda())
+        loss.backward()
+        g = {k: p.grad.detach().cpu().numpy() / 2 for k, p in net.named_parameters()}
+        acc = g if acc is None else {k: acc[k] + g[k] for k in g}
+    q.put(acc)
+
+
+@pytest.mark.timeout(300)
+def test_mvsnet_training_under_ddp_two_ranks_one_gpu():
+    """train.py wraps the model in DistributedDataParallel over a gloo group (train.py:52-59,136).  The engine's autograd
+    nodes hand every parameter its gradient through autograd, so DDP's reducer averages them like any other module's: both
+    ranks end with the mean of the two per-sample gradients (the warp backward's float atomics leave ~1e-6 run-to-run noise)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    q2 = ctx.Queue()
+    p = ctx.Process(target=_single_worker, args=(q2,))
+    p.start()
+    want = q2.get(timeout=240)
+    p.join(timeout=60)
+    assert res[0][1] != res[1][1], "the two ranks train on different samples"
+    for k in want:
+        a, b = res[0][2][k], res[1][2][k]
+        assert np.abs(a - b).max() <= 1e-6 * max(1.0, np.abs(a).max()), f"ranks disagree on {k}"
+        err = np.linalg.norm(a - want[k]) / (np.linalg.norm(want[k]) + 1e-12)
+        assert err <= 2e-3, (k, err)

@@ -594,3 +594,53 @@ def test_vis_train_step(dtype):
     sd = net.state_dict()
     for k, ref in o_stats.items():
         check_close(f"stat {k}", sd[k].cpu(), ref, rel_l2=5e-2 if bf else 8e-3)
+
+
+def test_function_level_warps_are_differentiable():
+    """models.MVSNet.module.homo_warping, models.CVP_MVSNet.models.modules.homo_warping and
+    models.VisMVSNet.homography.homography_warping carry autograd to the source map (training.WarpOnlyFn), like the
+    reference's grid_sample-based functions: gradients against ATen autograd through the oracle's versions."""
+    from oracle import mvsnet as O, cvpmvsnet as OC, vismvsnet as OV
+    from wild_deep_mvs_amd.models.MVSNet.module import homo_warping as hw_mvs
+    from wild_deep_mvs_amd.models.CVP_MVSNet.models.modules import homo_warping as hw_cvp
+    from wild_deep_mvs_amd.models.VisMVSNet.homography import homography_warping as hw_vis
+    proj, dv, feats = _sweep_case(32, 3, 16, 24, 8, seed=4)
+    gen = torch.Generator().manual_seed(1)
+    # MVSNet
+    src = feats[1].clone().requires_grad_(True)
+    ref = O.homo_warping(src, proj[:, 1], proj[:, 0], dv, (16, 24))
+    gv = torch.randn(ref.shape, generator=gen)
+    ref.backward(gv)
+    s2 = feats[1].clone().cuda().requires_grad_(True)
+    got = hw_mvs(s2, proj[:, 1].cuda(), proj[:, 0].cuda(), dv.cuda(), (16, 24))
+    got.backward(gv.cuda())
+    check_close("mvsnet homo_warping", got.detach().cpu(), ref.detach(), max_abs=3e-4)
+    check_close("mvsnet homo_warping d src", s2.grad.cpu(), src.grad, rel_l2=2e-4)
+    # CVP (16 channels, per-pixel hypotheses)
+    from wild_deep_mvs_amd import synthetic
+    scene = synthetic.make_scene(1, 2, 64, 96, seed=4)
+    row = torch.tensor([0., 0., 0., 1.])
+    ex = [torch.cat((torch.cat((scene["R"][:, i], scene["t"][:, i] * 8), 2), row.view(1, 1, 4)), 1) for i in range(2)]
+    K = scene["K"].clone()
+    K[:, :, :2] /= 4
+    hyp = 3.0 + torch.rand(1, 4, 16, 24, generator=gen)
+    src = (torch.randn(1, 16, 16, 24, generator=gen) * 0.5).requires_grad_(True)
+    ref = OC.homo_warping(src, K[:, 0], K[:, 1], ex[0], ex[1], hyp, (16, 24))
+    gv = torch.randn(ref.shape, generator=gen)
+    ref.backward(gv)
+    s2 = src.detach().clone().cuda().requires_grad_(True)
+    got = hw_cvp(s2, K[:, 0].cuda(), K[:, 1].cuda(), ex[0].cuda(), ex[1].cuda(), hyp.cuda(), (16, 24))
+    got.backward(gv.cuda())
+    check_close("cvp homo_warping", got.detach().cpu(), ref.detach(), max_abs=3e-4)
+    check_close("cvp homo_warping d src", s2.grad.cpu(), src.grad, rel_l2=2e-4)
+    # Vis (one homography per batch item)
+    H = torch.eye(3).view(1, 3, 3) + 0.02 * torch.randn(1, 3, 3, generator=gen)
+    src = (torch.randn(1, 32, 16, 24, generator=gen) * 0.5).requires_grad_(True)
+    ref = OV.homography_warping(src, H.view(1, 1, 1, 3, 3), (16, 24))
+    gv = torch.randn(ref.shape, generator=gen)
+    ref.backward(gv)
+    s2 = src.detach().clone().cuda().requires_grad_(True)
+    got = hw_vis(s2, H.cuda(), (16, 24))
+    got.backward(gv.cuda())
+    check_close("vis homography_warping", got.detach().cpu(), ref.detach(), max_abs=3e-4)
+    check_close("vis homography_warping d src", s2.grad.cpu(), src.grad, rel_l2=2e-4)

@@ -52,9 +52,11 @@ def _cams(ref_in, src_ins, ref_ex, src_exs):
 def homo_warping(src_feature, ref_in, src_in, ref_ex, src_ex, depth_hypos, ref_shape=None):
     """Plane-sweep warp of one source feature map (modules.py:74-128) -> [B,C,D,h,w] fp32; depth_hypos [B,D] or
     [B,D,h,w]."""
-    if src_feature.requires_grad and torch.is_grad_enabled():
-        raise NotImplementedError("pscv homo_warping: backward is not implemented yet")
     hw = tuple(src_feature.shape[2:]) if ref_shape is None else tuple(int(s) for s in ref_shape)
+    if src_feature.requires_grad and torch.is_grad_enabled():
+        from .... import training as T
+        return T.WarpOnlyFn.apply(_cams(ref_in.detach(), [src_in.detach()], ref_ex.detach(), [src_ex.detach()]),
+                                  depth_hypos.detach().to(torch.float32).contiguous(), L.GEOM_PROJ, hw, src_feature)
     fea = ops.to_channels_last(src_feature.detach(), torch.float32)
     vol = ops.warp_cost(None, [fea], _cams(ref_in, [src_in], ref_ex, [src_ex]), depth_hypos.to(torch.float32).contiguous(),
                         geom=L.GEOM_PROJ, cost=L.COST_WARP_ONLY, ref_hw=hw, out_dtype=torch.float32)

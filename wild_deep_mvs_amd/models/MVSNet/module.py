@@ -69,12 +69,13 @@ def homo_warping(src_fea, src_proj, ref_proj, depth_values, ref_shape=None):
 
     src_fea [B,C,Hs,Ws]; src_proj, ref_proj [B,4,4]; depth_values [B,D] or [B,D,h,w]
     -> [B,C,D,h,w] fp32 (an NCDHW-indexed view of the engine's channels-last volume).
-    Inference only: the grid is built under no_grad in the reference and the engine has no backward yet."""
-    if src_fea.requires_grad and torch.is_grad_enabled():
-        raise NotImplementedError("pscv homo_warping: backward (d/d src_fea) is not implemented yet")
-    fea = ops.to_channels_last(src_fea.detach(), torch.float32)
-    cams = ops.proj_cams_device(torch.stack([ref_proj, src_proj], dim=1).to(torch.float32).contiguous(), 0)
+    Differentiable w.r.t. ``src_fea`` (the grid is built under no_grad in the reference too)."""
+    cams = ops.proj_cams_device(torch.stack([ref_proj, src_proj], dim=1).detach().to(torch.float32).contiguous(), 0)
     hw = src_fea.shape[-2:] if ref_shape is None else tuple(int(s) for s in ref_shape)
+    if src_fea.requires_grad and torch.is_grad_enabled():
+        from ... import training as T
+        return T.WarpOnlyFn.apply(cams, depth_values.detach().to(torch.float32).contiguous(), L.GEOM_PROJ, tuple(hw), src_fea)
+    fea = ops.to_channels_last(src_fea.detach(), torch.float32)
     vol = ops.warp_cost(None, [fea], cams, depth_values.to(torch.float32).contiguous(), geom=L.GEOM_PROJ,
                         cost=L.COST_WARP_ONLY, ref_hw=hw, out_dtype=torch.float32)
     return ops.to_channels_first(vol[0])

@@ -46,8 +46,11 @@ def homography_warping(input, H, ref_shape=None):
     hw = tuple(input.shape[2:]) if ref_shape is None else tuple(int(s) for s in ref_shape)
     cams = torch.zeros((1, m, L.CAM_FLOATS), dtype=torch.float32, device=input.device)
     cams[0, :, :9] = H.reshape(m, 9).to(torch.float32)            # hom = A p - 0 / (d + 1e-9) with d = 1
-    fea = ops.to_channels_last(input.detach(), torch.float32)
     one = torch.ones((m, 1), dtype=torch.float32, device=input.device)
+    if input.requires_grad and torch.is_grad_enabled():
+        from ... import training as T
+        return T.WarpOnlyFn.apply(cams, one, L.GEOM_HOMOG, hw, input)[:, :, 0]
+    fea = ops.to_channels_last(input.detach(), torch.float32)
     vol = ops.warp_cost(None, [fea], cams, one, geom=L.GEOM_HOMOG, cost=L.COST_WARP_ONLY, ref_hw=hw,
                         out_dtype=torch.float32)                   # [1,m,1,h,w,c]
     return vol[0, :, 0].permute(0, 3, 1, 2)

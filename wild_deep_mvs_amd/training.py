@@ -59,6 +59,30 @@ class WarpCostFn(torch.autograd.Function):
         return (None, None, None, None, None, dtemp if has_temp else None, gref, *gsrcs)
 
 
+class WarpOnlyFn(torch.autograd.Function):
+    """Function-level plane-sweep warp of ONE source map with autograd to the map (``homo_warping`` of
+    models/MVSNet/module.py:111-169 and models/CVP_MVSNet/models/modules.py:74-128, ``homography_warping`` of
+    models/VisMVSNet/homography.py:107-120): src NCHW fp32 -> [B,C,D,h,w] fp32; the grid carries no gradient."""
+
+    @staticmethod
+    def forward(ctx, cams, depth, geom, ref_hw, src):
+        fea = ops.to_channels_last(src.detach(), torch.float32)
+        vol = ops.warp_cost(None, [fea], cams, depth, geom=geom, cost=L.COST_WARP_ONLY, ref_hw=ref_hw, out_dtype=torch.float32)
+        ctx.save_for_backward(cams, depth, fea)
+        ctx.meta = (geom, tuple(ref_hw), src.dtype)
+        return ops.to_channels_first(vol[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        cams, depth, fea = ctx.saved_tensors
+        geom, ref_hw, dt = ctx.meta
+        if fea.shape[3] not in (16, 32):
+            raise NotImplementedError("pscv warp backward: 16 or 32 feature channels")
+        g_cl = g.permute(0, 2, 3, 4, 1).to(torch.float32).contiguous().unsqueeze(0)        # [1,B,D,h,w,C]
+        _, dsrcs, _ = ops.warp_cost_bwd(None, [fea], cams, depth, g_cl, geom=geom, cost=L.COST_WARP_ONLY, ref_hw=ref_hw)
+        return None, None, None, None, dsrcs[0].permute(0, 3, 1, 2).to(dt)
+
+
 # --------------------------------------------------------------------------------------------------
 # 3-D U-Net in train() mode
 # --------------------------------------------------------------------------------------------------
