@@ -333,7 +333,7 @@ int pscv_warp_cost_bwd(const void* ref, const void* const* srcs, int n_src, cons
  *   cams     device fp64 [B][39]:   K_ref^-1 (9), rows 0..2 of E_src E_ref^-1 (12), K_src (9),
  *                                   A = (K_ref R_ref)(K_src R_src)^-1 (9); row-major, first source view
  *   fallback device fp32 [B]        (depth_max - depth_min) / 128, the step used when no pixel is valid
- *   keys     device uint64 workspace [B*H*W];  steps  device fp64 out [B];  hypos  device fp32 out [B,8,H,W]
+ *   keys     device uint64 workspace [B*H*W + B*1040];  steps  device fp64 out [B];  hypos  device fp32 out [B,8,H,W]
  */
 int pscv_cvp_depth_hypos(const float* depth, const double* cams, const float* fallback, unsigned long long* keys,
                          double* steps, float* hypos, int B, int H, int W, void* stream);

@@ -4,8 +4,9 @@
 // step that moves a pixel's projection into the FIRST source view by one pixel along its epipolar line, the MEDIAN of
 // |step| over the valid pixels, then 8 hypothesis planes depth + k * median, k = -4..3.
 // Three launches: (1) per-pixel |step| in fp64 -> 64-bit keys (bit patterns of non-negative doubles order like the
-// values; invalid pixels get the all-ones key), (2) one workgroup per batch item finds the lower median by an 8-pass
-// MSB-first radix select with LDS integer histograms (exact, order-independent), (3) the hypothesis planes.
+// values; invalid pixels get the all-ones key), (2) the lower median by an 8-pass MSB-first radix select (one launch per
+// pass over many workgroups, integer histograms: exact and order-independent; a first single-workgroup version took 4.2 ms
+// at 1024x1280 -- every key shares its leading digits, so the LDS atomics serialised on one bin), (3) the planes.
 #include "pscv_common.h"
 
 namespace pscv {
@@ -59,49 +60,89 @@ __global__ __launch_bounds__(256) void hypo_keys_kernel(const float* __restrict_
     keys[(long)b * H * W + pix] = key;
 }
 
-// one workgroup per batch item: lower median (rank (n-1)/2) of the keys != ~0 by radix select, 8 bits per pass
-__global__ __launch_bounds__(1024) void hypo_median_kernel(const unsigned long long* __restrict__ keys, const float* __restrict__ fallback,
-                                                           double* __restrict__ steps, int n) {
-    __shared__ unsigned hist[256];
-    __shared__ unsigned long long prefix_s;
-    __shared__ unsigned rank_s;
-    __shared__ int empty_s;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const unsigned long long* k = keys + (long)b * n;
-    unsigned long long prefix = 0;
-    unsigned rank = 0;
-    for (int pass = 0; pass < 8; ++pass) {
-        const int shift = 56 - 8 * pass;
-        if (tid < 256) hist[tid] = 0;
-        __syncthreads();
-        for (int i = tid; i < n; i += 1024) {
-            const unsigned long long v = k[i];
-            if (v == ~0ull) continue;
-            if (pass == 0 || (v >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(v >> shift) & 255], 1u);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            if (pass == 0) {
-                unsigned total = 0;
-                for (int j = 0; j < 256; ++j) total += hist[j];
-                empty_s = total == 0;
-                rank = total ? (total - 1) / 2 : 0;
-            }
-            unsigned acc = 0;
-            int j = 0;
-            for (; j < 255; ++j) {
-                if (acc + hist[j] > rank) break;
-                acc += hist[j];
-            }
-            prefix_s = prefix | ((unsigned long long)j << shift);
-            rank_s = rank - acc;
-        }
-        __syncthreads();
-        prefix = prefix_s;
-        rank = rank_s;
-        if (empty_s) break;
+// Lower median (rank (n_valid - 1) / 2) of the keys != ~0 by an MSB-first radix select, 8 bits per pass, one launch per
+// pass over many workgroups.  Per batch item the workspace holds hist[8][256] (u32, zeroed by the key kernel's launch
+// companion) and state[8] = (prefix, rank) after each pass.  Launch p: every workgroup derives state[p-1] from state[p-2]
+// and hist[p-1] (256-entry scan, redundantly: cheaper than another launch), workgroup 0 publishes it, then each workgroup
+// histograms its slice of the keys that match the prefix into hist[p].  Lanes aggregate runs of equal digits before the
+// LDS atomic (in the first passes nearly all keys share the digit: sign / exponent bits), the LDS histogram goes to
+// global memory with one integer atomic per non-empty bin.
+struct SelState { unsigned long long prefix; unsigned long long rank; };   // rank == ~0: no valid key
+
+constexpr int SEL_WS_U64 = 8 * 256 / 2 + 8 * 2;   // u64 words per batch item: hist[8][256] u32 + state[8]
+
+__device__ __forceinline__ unsigned* sel_hist(unsigned long long* ws, int b, int pass) {
+    return reinterpret_cast<unsigned*>(ws + (long)b * SEL_WS_U64) + pass * 256;
+}
+__device__ __forceinline__ SelState* sel_state(unsigned long long* ws, int b) {
+    return reinterpret_cast<SelState*>(ws + (long)b * SEL_WS_U64 + 8 * 256 / 2);
+}
+
+// state after pass `done` (0-based) from the state before it and that pass's histogram; thread 0 of the block, result in LDS
+__device__ void sel_advance(const unsigned* __restrict__ hist, SelState prev, int done, SelState* out) {
+    const int shift = 56 - 8 * done;
+    unsigned long long rank = prev.rank;
+    if (done == 0) {
+        unsigned total = 0;
+        for (int j = 0; j < 256; ++j) total += hist[j];
+        rank = total ? (unsigned long long)((total - 1) / 2) : ~0ull;
     }
-    if (tid == 0) steps[b] = empty_s ? (double)fallback[b] : __longlong_as_double((long long)prefix);
+    if (rank == ~0ull) { out->prefix = 0; out->rank = ~0ull; return; }
+    unsigned long long acc = 0;
+    int j = 0;
+    for (; j < 255; ++j) {
+        if (acc + hist[j] > rank) break;
+        acc += hist[j];
+    }
+    out->prefix = prev.prefix | ((unsigned long long)j << shift);
+    out->rank = rank - acc;
+}
+
+__global__ __launch_bounds__(256) void hypo_select_pass_kernel(const unsigned long long* __restrict__ keys, unsigned long long* __restrict__ ws,
+                                                               int n, int pass) {
+    __shared__ unsigned hist[256];
+    __shared__ SelState st;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    hist[tid] = 0;
+    if (tid == 0) {
+        SelState prev{0, 0};
+        if (pass >= 2) prev = sel_state(ws, b)[pass - 2];
+        if (pass >= 1) {
+            sel_advance(sel_hist(ws, b, pass - 1), prev, pass - 1, &st);
+            if (blockIdx.x == 0) sel_state(ws, b)[pass - 1] = st;
+        } else {
+            st = prev;
+        }
+    }
+    __syncthreads();
+    if (st.rank == ~0ull) return;
+    const int shift = 56 - 8 * pass;
+    const unsigned long long prefix = st.prefix;
+    const unsigned long long* k = keys + (long)b * n;
+    int run_digit = -1;
+    unsigned run = 0;
+    for (long i = (long)blockIdx.x * 256 + tid; i < n; i += (long)gridDim.x * 256) {
+        const unsigned long long v = k[i];
+        if (v == ~0ull) continue;
+        if (pass > 0 && (v >> (shift + 8)) != (prefix >> (shift + 8))) continue;
+        const int dgt = (int)((v >> shift) & 255);
+        if (dgt != run_digit) {
+            if (run) atomicAdd(&hist[run_digit], run);
+            run_digit = dgt; run = 0;
+        }
+        ++run;
+    }
+    if (run) atomicAdd(&hist[run_digit], run);
+    __syncthreads();
+    if (hist[tid]) atomicAdd(sel_hist(ws, b, pass) + tid, hist[tid]);
+}
+
+__global__ void hypo_median_finish_kernel(unsigned long long* __restrict__ ws, const float* __restrict__ fallback, double* __restrict__ steps) {
+    const int b = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    SelState st;
+    sel_advance(sel_hist(ws, b, 7), sel_state(ws, b)[6], 7, &st);
+    steps[b] = st.rank == ~0ull ? (double)fallback[b] : __longlong_as_double((long long)st.prefix);
 }
 
 __global__ __launch_bounds__(256) void hypo_planes_kernel(const float* __restrict__ depth, const double* __restrict__ steps,
@@ -126,7 +167,15 @@ extern "C" int pscv_cvp_depth_hypos(const float* depth, const double* cams, cons
     const int hw = H * W;
     hipLaunchKernelGGL(hypo_keys_kernel, dim3((hw + 255) / 256, B), dim3(256), 0, st, depth, cams, keys, H, W);
     PSCV_CHECK_LAUNCH("pscv_cvp_depth_hypos(keys)");
-    hipLaunchKernelGGL(hypo_median_kernel, dim3(B), dim3(1024), 0, st, keys, fallback, steps, hw);
+    unsigned long long* ws = keys + (long)B * hw;
+    hipError_t me = hipMemsetAsync(ws, 0, (size_t)B * SEL_WS_U64 * 8, st);
+    if (me != hipSuccess) { set_error("pscv_cvp_depth_hypos: hipMemsetAsync: %s", hipGetErrorString(me)); return -2; }
+    int nsel = (hw + 256 * 16 - 1) / (256 * 16);
+    if (nsel > 1024) nsel = 1024;
+    for (int pass = 0; pass < 8; ++pass)
+        hipLaunchKernelGGL(hypo_select_pass_kernel, dim3(nsel, B), dim3(256), 0, st, keys, ws, hw, pass);
+    PSCV_CHECK_LAUNCH("pscv_cvp_depth_hypos(select)");
+    hipLaunchKernelGGL(hypo_median_finish_kernel, dim3(B), dim3(64), 0, st, ws, fallback, steps);
     PSCV_CHECK_LAUNCH("pscv_cvp_depth_hypos(median)");
     hipLaunchKernelGGL(hypo_planes_kernel, dim3((hw + 255) / 256, B), dim3(256), 0, st, depth, steps, hypos, hw);
     PSCV_CHECK_LAUNCH("pscv_cvp_depth_hypos(planes)");

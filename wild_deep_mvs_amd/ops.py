@@ -543,7 +543,7 @@ def cvp_depth_hypos(depth: torch.Tensor, cams: torch.Tensor, fallback: torch.Ten
             or fallback.dtype != torch.float32 or fallback.numel() != depth.shape[0]:
         raise ValueError("pscv.cvp_depth_hypos: depth fp32 [B,H,W], cams fp64 [B,39], fallback fp32 [B] expected")
     B, H, W = depth.shape
-    keys = torch.empty((B * H * W,), dtype=torch.int64, device=depth.device)
+    keys = torch.empty((B * H * W + B * 1040,), dtype=torch.int64, device=depth.device)
     steps = torch.empty((B,), dtype=torch.float64, device=depth.device)
     hypos = torch.empty((B, 8, H, W), dtype=torch.float32, device=depth.device)
     rc = _launch("cvp_depth_hypos", lambda: L.lib().pscv_cvp_depth_hypos(_p(depth), _p(cams), _p(fallback), _p(keys), _p(steps),
