@@ -194,6 +194,21 @@ int pscv_fuse_finish(const float* partial, const float* wsum, int dtype, void* o
 long pscv_pack_conv2d_weights(const float* w, int c_in, int c_in_padded, int c_out, int ks, int dtype, uint16_t* packed);
 int pscv_conv2d(const void* in, int dtype, const uint16_t* packed, const float* scale, const float* bias, void* out,
                 int out_dtype, int B, int Hi, int Wi, int c_in, int c_out, int ks, int stride, float neg_slope, void* stream);
+/*
+ * The general form, used by Vis-MVSNet's FeatExt (models/VisMVSNet/model_cas.py:18-35: a 2-D residual U-Net over
+ * nn_utils.py:123-278).  On top of pscv_conv2d:
+ *   layers   k3 s1|s2 p1, k5 s2 p2, k1 s1|s2 p0 (the BasicBlock shortcuts), and ks = 2: one of the four 2x2-tap parity
+ *            sub-convolutions of ConvTranspose2d(k3, s2, p1, op1) -- parity = 2 * (output row parity) + (output column parity),
+ *            weights [c_out, c_in, 2, 2] with tap (ty, tx) applied to input (i + ty, j + tx); output pixel (2 i + row parity,
+ *            2 j + column parity) of a [B, 2 Hi, 2 Wi, *] map.  parity = -1 for every other layer.
+ *   skip     NULL or [B,Ho,Wo,skip_cstride] read at channel offset skip_coff, added BEFORE the activation
+ *            (BasicBlock: relu(bn(conv(x)) + shortcut))
+ *   out      [B,Ho,Wo,out_cstride] written at channel offset out_coff (the decoder's cat([deconv, skip]) needs no copy)
+ *   c_in up to 128; c_out up to 64, or 128 (output tiles split over blockIdx.y).
+ */
+int pscv_conv2d_ex(const void* in, int dtype, const uint16_t* packed, const float* scale, const float* bias, const void* skip,
+                   int skip_cstride, int skip_coff, void* out, int out_cstride, int out_coff, int out_dtype, int B, int Hi, int Wi,
+                   int c_in, int c_out, int ks, int stride, int parity, float neg_slope, void* stream);
 
 /*
  * Geometric-consistency filter of one depth map against its source views (the step after the

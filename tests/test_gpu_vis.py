@@ -76,13 +76,37 @@ def test_fuse_pairs_matches_formula(env):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-def test_vis_forward_parity_with_reference(env, dtype):
+def test_feat_ext_engine_vs_reference_features(env, dtype):
+    """FeatExt (the 2-D residual U-Net: init k5 s2, BasicBlocks with 1x1 (strided) shortcuts, k3 s2 down-sampling, 128-channel
+    bottom level, two transposed convs as parity sub-convolutions, channel concat, three final convs) on pscv_conv2d_ex against
+    the reference's fp32 feature maps stored in the golden file, next to the PyTorch-ROCm modules."""
+    L, ops, synthetic, Frontend, OV = env
+    g = load_golden("vis_tiny.npz")
+    H, W, V, seed, scene_seed = [int(x) for x in g["meta"][:5]]
+    net, sd = _net(env, seed, dtype)
+    scene = synthetic.make_scene(1, V, H, W, seed=scene_seed)
+    x = torch.cat(list(torch.unbind(scene["imgs"], 1)), 0).cuda()                  # [V,3,H,W]
+    with torch.no_grad():
+        got = net.model.feat_ext.forward_engine(x, dtype)
+        base = net.model.feat_ext(x)
+    ulp = 2 ** -8 if dtype == torch.bfloat16 else 2 ** -11
+    for i, key in enumerate(("feat_s1", "feat_s2", "feat_s3")):
+        ref = t(g[key]).squeeze(1)                                                  # [V,32,h,w]
+        check_close(f"torch {key}", base[i].float().cpu(), ref, rel_l2=1e-5)
+        # ~37 stored layers instead of one final rounding: a few ulp of relative L2
+        check_close(f"pscv conv2d {key} {dtype}", got[i].float().permute(0, 3, 1, 2).cpu(), ref, rel_l2=12 * ulp)
+
+
+@pytest.mark.parametrize("feature_engine", ["pscv", "torch"])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_vis_forward_parity_with_reference(env, dtype, feature_engine):
     L, ops, synthetic, Frontend, OV = env
     g = load_golden("vis_tiny.npz")
     H, W, V, seed, scene_seed = [int(x) for x in g["meta"][:5]]
     depth_nums = [int(x) for x in g["meta"][5:8]]
     scales = [float(x) for x in g["interval_scales"]]
     net, sd = _net(env, seed, dtype)
+    net.feature_engine = feature_engine
     net.depth_nums, net.interval_scales = depth_nums, scales
     scene = {k: v.cuda() for k, v in synthetic.make_scene(1, V, H, W, seed=scene_seed).items()}
     taps = {}

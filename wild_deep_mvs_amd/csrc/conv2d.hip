@@ -1,4 +1,5 @@
-// 2-D convolution (3x3 stride 1, 5x5 stride 2) over channels-last 16-bit feature maps as an MFMA implicit GEMM.  gfx950.
+// 2-D convolution (k3 s1, k5 s2, k3 s2, k1 s1/s2, and the 2x2 parity sub-convolutions of a k3 s2 transposed convolution)
+// over channels-last 16-bit feature maps as an MFMA implicit GEMM.  gfx950.
 //
 // The step BEFORE the plane-sweep path: MVSNet's FeatureNet is eight small-channel layers
 // (3->8->8->16->16->16->32->32->32) on every view; at these widths a library convolution spends ~1 ms on 35 MB of
@@ -13,9 +14,16 @@
 // with its columns split by parity -- [even columns | odd columns] per row -- so that for a fixed tap the lanes read
 // consecutive voxels exactly like the stride-1 case.
 //
+// Vis-MVSNet's FeatExt (a 2-D residual U-Net, models/VisMVSNet/model_cas.py:18-35 over nn_utils.py:123-278) adds: a
+// residual input added BEFORE the activation (BasicBlock: relu(bn(conv) + shortcut)), 1x1 (strided) shortcut convs, k3 s2
+// convs, up to 128 channels (the output tiles of a wide layer are split over blockIdx.y), writes into a channel slice of a
+// wider map (the decoder's cat) and ConvTranspose2d(k3, s2, p1, op1) as four 2x2-tap parity sub-convolutions whose
+// outputs interleave (no zero insertion): out[2i+a] takes input i with kernel index a+1 and, for a = 1, input i+1 with
+// kernel index 0.
+//
 // Replaces (fdarmon/wild_deep_mvs): ConvBnReLU (models/MVSNet/module.py:23-38) inside FeatureNet
 // (models/MVSNet/model.py:21-41) and its final plain Conv2d; conv + LeakyReLU(0.1) of CVP-MVSNet's FeaturePyramid
-// (models/CVP_MVSNet/models/modules.py:24-28, net.py:21-47).
+// (models/CVP_MVSNet/models/modules.py:24-28, net.py:21-47); every layer of Vis-MVSNet's FeatExt.
 #include "pscv_common.h"
 
 namespace pscv {
@@ -41,9 +49,13 @@ struct Conv2dArgs {
     const uint4* wpk;        // [steps][NT][64 lanes] x 8 halves
     const float* scale;      // [c_out] or null
     const float* bias;
-    void* out;               // [B,Ho,Wo,c_out]
+    void* out;               // [B,Hof,Wof,out_cs], written at channel offset out_co, pixel (oy*oys + oyo, ox*oxs + oxo)
+    const uint16_t* skip;    // null or [B,Hof,Wof,skip_cs] read at skip_co: added before the activation
     int out_f32;
     int B, Hi, Wi, Ho, Wo, cout;
+    int out_cs, out_co, skip_cs, skip_co;
+    int oys, oxs, oyo, oxo, Hof, Wof;
+    int nt_total;            // 16-channel output tiles of the layer (blockIdx.y picks this block's first NT tiles)
     float neg_slope;         // activation y -> max(y, neg_slope * y): 0 = ReLU, 0.1 = LeakyReLU(0.1), 1 = none
     int nth, ntw;
 };
@@ -51,6 +63,8 @@ struct Conv2dArgs {
 __host__ __device__ constexpr int c2_ceil_div(int a, int b) { return (a + b - 1) / b; }
 __host__ __device__ constexpr int c2_vs(int cin) { return cin == 32 ? 96 : cin * 2 + 16; }   // LDS bytes per pixel (conv3d.hip)
 constexpr int C2_TW = 32;    // output columns per workgroup (two 16-pixel MFMA column tiles)
+
+__host__ __device__ constexpr int c2_pad(int ks) { return ks == 2 ? 0 : ks / 2; }   // the 2x2 parity sub-convs read (i, i+1)
 
 template <typename H, int CIN, int NT, int KS, int STRIDE>
 __global__ __launch_bounds__(256) void conv2d_kernel(const Conv2dArgs a) {
@@ -61,7 +75,7 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const Conv2dArgs a) {
     constexpr int VS = c2_vs(CIN), CCH = CIN / 8;
     constexpr int NTAPS = KS * KS, NSTEPS = c2_ceil_div(NTAPS * CIN, 32);
     constexpr int NMT = TH * 2, MB = NMT / 4;               // M-tiles per workgroup / per wave
-    constexpr int PAD = KS / 2;
+    constexpr int PAD = c2_pad(KS);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int nwg = gridDim.x, bid = blockIdx.x;
@@ -76,6 +90,7 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const Conv2dArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, g = lane >> 4;
+    const int nt0 = blockIdx.y * NT;
 
     // A fragments: the first PF k-steps (all of them for the small layers) are requested before the brick so that both
     // share one memory latency; wide layers (64 channels: 72 fragments) continue through a ring, step s + PF being
@@ -85,7 +100,7 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const Conv2dArgs a) {
 #pragma unroll
     for (int s = 0; s < PF; ++s)
 #pragma unroll
-        for (int m = 0; m < NT; ++m) wf[s][m] = a.wpk[(s * NT + m) * 64 + lane];
+        for (int m = 0; m < NT; ++m) wf[s][m] = a.wpk[(s * a.nt_total + nt0 + m) * 64 + lane];
 
     {   // ---- stage the brick: a wave takes whole rows (row arithmetic is scalar), a lane its chunk(s) of the row ----
         constexpr int ROWCH = BW * CCH, NPASS = c2_ceil_div(ROWCH, 64);
@@ -137,7 +152,7 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const Conv2dArgs a) {
     for (int m = 0; m < NT; ++m)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int c = m * 16 + g * 4 + k;
+            const int c = (nt0 + m) * 16 + g * 4 + k;
             sc[m][k] = (a.scale && c < a.cout) ? a.scale[c] : 1.0f;
             bi[m][k] = (a.bias && c < a.cout) ? a.bias[c] : 0.0f;
         }
@@ -170,7 +185,7 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const Conv2dArgs a) {
         }
         if (s + PF < NSTEPS) {
 #pragma unroll
-            for (int m = 0; m < NT; ++m) wf[s % PF][m] = a.wpk[((s + PF) * NT + m) * 64 + lane];
+            for (int m = 0; m < NT; ++m) wf[s % PF][m] = a.wpk[((s + PF) * a.nt_total + nt0 + m) * 64 + lane];
         }
     }
 
@@ -180,26 +195,29 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const Conv2dArgs a) {
         const int mt = wave * MB + i;
         const int oy = oy0 + (mt >> 1), ox = ox0 + (mt & 1) * 16 + n;
         if (oy >= a.Ho || ox >= a.Wo) continue;
-        const unsigned long pix = ((unsigned long)b * a.Ho + oy) * a.Wo + ox;
+        const unsigned long pix = ((unsigned long)b * a.Hof + (oy * a.oys + a.oyo)) * a.Wof + (ox * a.oxs + a.oxo);
 #pragma unroll
         for (int m = 0; m < NT; ++m) {
-            const int c0 = m * 16 + g * 4;
+            const int c0 = (nt0 + m) * 16 + g * 4;
             if (c0 >= a.cout) continue;
-            float y[4];
+            float v[4], y[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float v = fmaf(acc[i][m][k], sc[m][k], bi[m][k]);
-                y[k] = fmaxf(v, v * a.neg_slope);
+            for (int k = 0; k < 4; ++k) v[k] = fmaf(acc[i][m][k], sc[m][k], bi[m][k]);
+            if (a.skip) {
+                const uint2 sv = *reinterpret_cast<const uint2*>(a.skip + pix * a.skip_cs + a.skip_co + c0);
+                v[0] += Half16<H>::lo(sv.x); v[1] += Half16<H>::hi(sv.x); v[2] += Half16<H>::lo(sv.y); v[3] += Half16<H>::hi(sv.y);
             }
-            if (a.out_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + pix * a.cout + c0) = make_float4(y[0], y[1], y[2], y[3]);
-            else *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.out) + pix * a.cout + c0) =
+#pragma unroll
+            for (int k = 0; k < 4; ++k) y[k] = fmaxf(v[k], v[k] * a.neg_slope);
+            if (a.out_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + pix * a.out_cs + a.out_co + c0) = make_float4(y[0], y[1], y[2], y[3]);
+            else *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.out) + pix * a.out_cs + a.out_co + c0) =
                      make_uint2(Half16<H>::pack(y[0], y[1]), Half16<H>::pack(y[2], y[3]));
         }
     }
 }
 
 template <typename H, int CIN, int NT, int KS, int STRIDE>
-static int c2_launch(Conv2dArgs& a, hipStream_t st) {
+static int c2_launch(Conv2dArgs& a, int n_split, hipStream_t st) {
     constexpr int TH = STRIDE == 1 ? 8 : 4;
     constexpr int BH = STRIDE * (TH - 1) + KS, BW = STRIDE * (C2_TW - 1) + KS;
     constexpr int BWL = STRIDE == 1 ? BW : 2 * ((BW + 1) / 2);
@@ -217,17 +235,28 @@ static int c2_launch(Conv2dArgs& a, hipStream_t st) {
             done = true;
         }
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), LDS, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_split), dim3(256), LDS, st, a);
     return 0;
 }
 
 template <typename H>
 static int c2_dispatch(Conv2dArgs& a, int c_in, int c_out, int ks, int stride, hipStream_t st) {
     const int nt = (c_out + 15) / 16;
-#define PSCV_C2(CI, NTV, K, S) if (c_in == CI && nt == NTV && ks == K && stride == S) return c2_launch<H, CI, NTV, K, S>(a, st);
+    a.nt_total = nt;
+    // (c_in, output tiles per workgroup, kernel size, stride); layers wider than 4 tiles (64 channels) split their output
+    // tiles over blockIdx.y in groups of 4
+    const int ntw = nt > 4 ? 4 : nt;
+    const int split = (nt + ntw - 1) / ntw;
+    if (nt > 4 && nt % 4) { set_error("pscv_conv2d: c_out=%d above 64 must be a multiple of 64", c_out); return -1; }
+#define PSCV_C2(CI, NTV, K, S) if (c_in == CI && ntw == NTV && ks == K && stride == S) return c2_launch<H, CI, NTV, K, S>(a, split, st);
     PSCV_C2(8, 1, 3, 1) PSCV_C2(16, 1, 3, 1) PSCV_C2(32, 2, 3, 1) PSCV_C2(16, 2, 3, 1) PSCV_C2(32, 1, 3, 1)
     PSCV_C2(8, 4, 3, 1) PSCV_C2(64, 4, 3, 1) PSCV_C2(64, 2, 3, 1)                       // CVP pyramid: 3->64, 64->64, 64->32
     PSCV_C2(8, 1, 5, 2) PSCV_C2(16, 2, 5, 2) PSCV_C2(8, 2, 5, 2) PSCV_C2(16, 1, 5, 2)
+    // Vis FeatExt: 1x1 shortcuts, k3 s2 down-sampling convs, 128-channel layers, 2x2 parity sub-convs of the deconvs
+    PSCV_C2(16, 2, 1, 1) PSCV_C2(32, 4, 1, 2) PSCV_C2(64, 4, 1, 2)
+    PSCV_C2(32, 4, 3, 2) PSCV_C2(64, 4, 3, 2)
+    PSCV_C2(128, 4, 3, 1) PSCV_C2(128, 2, 3, 1)
+    PSCV_C2(128, 4, 2, 1) PSCV_C2(64, 2, 2, 1)
 #undef PSCV_C2
     set_error("pscv_conv2d: unsupported layer c_in=%d c_out=%d k=%d stride=%d", c_in, c_out, ks, stride);
     return -1;
@@ -237,7 +266,7 @@ static int c2_dispatch(Conv2dArgs& a, int c_in, int c_out, int ks, int stride, h
 
 extern "C" long pscv_pack_conv2d_weights(const float* w, int c_in, int c_in_padded, int c_out, int ks, int dtype, uint16_t* packed) {
     using namespace pscv;
-    PSCV_CHECK_ARG(c_in > 0 && c_in <= c_in_padded && c_in_padded % 8 == 0 && c_out > 0 && (ks == 3 || ks == 5),
+    PSCV_CHECK_ARG(c_in > 0 && c_in <= c_in_padded && c_in_padded % 8 == 0 && c_out > 0 && (ks == 1 || ks == 2 || ks == 3 || ks == 5),
                    "pscv_pack_conv2d_weights: bad layer %d(%d) -> %d, k=%d", c_in, c_in_padded, c_out, ks);
     PSCV_CHECK_ARG(dtype == PSCV_BF16 || dtype == PSCV_F16, "pscv_pack_conv2d_weights: dtype %d must be bf16 or fp16", dtype);
     const int nt = (c_out + 15) / 16, ntaps = ks * ks;
@@ -259,23 +288,36 @@ extern "C" long pscv_pack_conv2d_weights(const float* w, int c_in, int c_in_padd
     return n;
 }
 
-extern "C" int pscv_conv2d(const void* in, int dtype, const uint16_t* packed, const float* scale, const float* bias, void* out,
-                           int out_dtype, int B, int Hi, int Wi, int c_in, int c_out, int ks, int stride, float neg_slope, void* stream) {
+extern "C" int pscv_conv2d_ex(const void* in, int dtype, const uint16_t* packed, const float* scale, const float* bias,
+                              const void* skip, int skip_cstride, int skip_coff, void* out, int out_cstride, int out_coff,
+                              int out_dtype, int B, int Hi, int Wi, int c_in, int c_out, int ks, int stride, int parity,
+                              float neg_slope, void* stream) {
     using namespace pscv;
     PSCV_CHECK_ARG(in && packed && out, "pscv_conv2d: null pointer argument");
     PSCV_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0, "pscv_conv2d: bad sizes");
     PSCV_CHECK_ARG(dtype == PSCV_BF16 || dtype == PSCV_F16, "pscv_conv2d: storage dtype %d must be bf16 or fp16", dtype);
     PSCV_CHECK_ARG(out_dtype == dtype || out_dtype == PSCV_F32, "pscv_conv2d: out dtype %d must be the storage dtype or fp32", out_dtype);
     PSCV_CHECK_ARG(c_out % 4 == 0, "pscv_conv2d: c_out=%d must be a multiple of 4", c_out);
-    PSCV_CHECK_ARG((ks == 3 && stride == 1) || (ks == 5 && stride == 2), "pscv_conv2d: only k3 s1 p1 and k5 s2 p2 layers (got k%d s%d)", ks, stride);
+    PSCV_CHECK_ARG((ks == 3 && (stride == 1 || stride == 2)) || (ks == 5 && stride == 2) || (ks == 1 && (stride == 1 || stride == 2)) ||
+                       (ks == 2 && stride == 1),
+                   "pscv_conv2d: supported layers are k3 s1|s2 p1, k5 s2 p2, k1 s1|s2 p0 and the k2 parity sub-conv (got k%d s%d)", ks, stride);
+    PSCV_CHECK_ARG(ks == 2 || parity < 0, "pscv_conv2d: an output parity only applies to the k2 sub-convolutions of a transposed conv");
+    PSCV_CHECK_ARG(ks != 2 || (parity >= 0 && parity < 4), "pscv_conv2d: k2 sub-convolution needs parity 0..3 (2 * row parity + column parity)");
     PSCV_CHECK_ARG((long)Hi * Wi * c_in * 2 < (1L << 32), "pscv_conv2d: one input map must stay below 4 GiB");
+    PSCV_CHECK_ARG(out_cstride % 4 == 0 && out_coff % 4 == 0 && out_coff + c_out <= out_cstride, "pscv_conv2d: bad output channel slice");
+    PSCV_CHECK_ARG(!skip || (skip_cstride % 4 == 0 && skip_coff % 4 == 0 && skip_coff + c_out <= skip_cstride), "pscv_conv2d: bad skip channel slice");
     Conv2dArgs a;
     a.in = reinterpret_cast<const uint16_t*>(in);
     a.wpk = reinterpret_cast<const uint4*>(packed);
     a.scale = scale; a.bias = bias; a.out = out; a.out_f32 = out_dtype == PSCV_F32;
+    a.skip = reinterpret_cast<const uint16_t*>(skip);
+    a.out_cs = out_cstride; a.out_co = out_coff; a.skip_cs = skip_cstride; a.skip_co = skip_coff;
     a.B = B; a.Hi = Hi; a.Wi = Wi;
-    a.Ho = stride == 1 ? Hi : (Hi + 2 * 2 - 5) / 2 + 1;
-    a.Wo = stride == 1 ? Wi : (Wi + 2 * 2 - 5) / 2 + 1;
+    const int pad = ks == 2 ? 0 : ks / 2;
+    a.Ho = ks == 2 ? Hi : (Hi + 2 * pad - ks) / stride + 1;
+    a.Wo = ks == 2 ? Wi : (Wi + 2 * pad - ks) / stride + 1;
+    a.oys = a.oxs = 1; a.oyo = a.oxo = 0; a.Hof = a.Ho; a.Wof = a.Wo;
+    if (ks == 2) { a.oys = a.oxs = 2; a.oyo = parity >> 1; a.oxo = parity & 1; a.Hof = 2 * Hi; a.Wof = 2 * Wi; }
     PSCV_CHECK_ARG(neg_slope >= 0.0f && neg_slope <= 1.0f, "pscv_conv2d: neg_slope=%g outside [0,1]", (double)neg_slope);
     a.cout = c_out; a.neg_slope = neg_slope;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -283,4 +325,12 @@ extern "C" int pscv_conv2d(const void* in, int dtype, const uint16_t* packed, co
     if (rc) return rc;
     PSCV_CHECK_LAUNCH("pscv_conv2d");
     return 0;
+}
+
+extern "C" int pscv_conv2d(const void* in, int dtype, const uint16_t* packed, const float* scale, const float* bias, void* out,
+                           int out_dtype, int B, int Hi, int Wi, int c_in, int c_out, int ks, int stride, float neg_slope, void* stream) {
+    PSCV_CHECK_ARG((ks == 3 && stride == 1) || (ks == 5 && stride == 2), "pscv_conv2d: only k3 s1 p1 and k5 s2 p2 layers (got k%d s%d); "
+                   "see pscv_conv2d_ex", ks, stride);
+    return pscv_conv2d_ex(in, dtype, packed, scale, bias, nullptr, 0, 0, out, c_out, 0, out_dtype, B, Hi, Wi, c_in, c_out, ks, stride, -1,
+                          neg_slope, stream);
 }

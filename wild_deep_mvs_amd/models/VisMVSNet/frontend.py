@@ -12,6 +12,9 @@ class Frontend(nn.Module):
         self.model = Model()
         self.depth_nums = [32, 16, 8]
         self.interval_scales = [4, 2, 1]
+        # 2-D extractor: "pscv" = the residual U-Net on MFMA conv2d launches writing the warp kernel's channels-last 16-bit
+        # layout directly (default); "torch" = PyTorch-ROCm in fp32, converted where the warp kernel reads it
+        self.feature_engine = "pscv"
 
     @property
     def storage_dtype(self):
@@ -65,19 +68,25 @@ class Frontend(nn.Module):
                     raise NotImplementedError("pscv Vis-MVSNet: the source-view shard is an inference path")
                 ref_feats = self.model.feat_ext(imgs[reference_frame])
                 src_feats = [self.model.feat_ext(imgs[i]) for i in src_idx]
+            engine = self.feature_engine == "pscv" and not self.training
+            fe = (lambda x: self.model.feat_ext.forward_engine(x, self.storage_dtype)) if engine else self.model.feat_ext
+            for st in (self.model.stage1, self.model.stage2, self.model.stage3):
+                st._channels_last_features = engine
+            if self.training:
+                pass
             elif grp is None and len({tuple(i.shape) for i in imgs}) == 1:
                 # all views through the 2-D extractor as one batch (same result as the per-view loop in eval mode)
-                packs = [torch.chunk(f, v, 0) for f in self.model.feat_ext(torch.cat([imgs[reference_frame]] + [imgs[i] for i in src_idx], 0))]
+                packs = [torch.chunk(f, v, 0) for f in fe(torch.cat([imgs[reference_frame]] + [imgs[i] for i in src_idx], 0))]
                 ref_feats = tuple(p[0] for p in packs)
                 src_feats = [tuple(p[j + 1] for p in packs) for j in range(len(src_idx))]
             elif grp is None:
-                ref_feats = self.model.feat_ext(imgs[reference_frame])
-                src_feats = [self.model.feat_ext(imgs[i]) for i in src_idx]
+                ref_feats = fe(imgs[reference_frame])
+                src_feats = [fe(imgs[i]) for i in src_idx]
             else:   # view shard: a rank only extracts the features of the source views it will sweep
                 import torch.distributed as dist
-                ref_feats = self.model.feat_ext(imgs[reference_frame])
+                ref_feats = fe(imgs[reference_frame])
                 world, rank = dist.get_world_size(grp), dist.get_rank(grp)
-                src_feats = [self.model.feat_ext(imgs[i]) if j % world == rank else (None, None, None)
+                src_feats = [fe(imgs[i]) if j % world == rank else (None, None, None)
                              for j, i in enumerate(src_idx)]
             di = depth_interval[:, reference_frame].view(n, 1, 1, 1)
             stages = (self.model.stage1, self.model.stage2, self.model.stage3)
@@ -87,7 +96,8 @@ class Frontend(nn.Module):
                 if k > 0:
                     # NB: like the reference, the offset uses the ATTRIBUTE self.interval_scales, not the kwarg
                     # (frontend.py:76-78,89-91)
-                    start = F.interpolate(ests[-1].detach(), size=tuple(ref_feats[k].shape[2:]), mode='bilinear',
+                    fhw = tuple(ref_feats[k].shape[1:3]) if engine else tuple(ref_feats[k].shape[2:])
+                    start = F.interpolate(ests[-1].detach(), size=fhw, mode='bilinear',
                                           align_corners=False) - depth_nums[k] * di * self.interval_scales[k] / 2
                 stage_taps = {} if taps is not None else None
                 est, prob, pr = stage([ref_feats[k], ref_cam, [f[k] for f in src_feats], srcs_cam], depth_num=depth_nums[k],

@@ -39,6 +39,63 @@ class FeatExt(nn.Module):
         o1, o2, o3 = self.unet(self.init_conv(x), multi_scale=3)
         return self.final_conv_1(o1), self.final_conv_2(o2), self.final_conv_3(o3)
 
+    # -- HIP path: every layer of the 2-D residual U-Net on pscv_conv2d_ex, channels-last 16-bit maps ----------
+    def engine_layers(self, dtype: torch.dtype):
+        """Packed weights + folded eval-mode BatchNorm of all 37 layers (the two transposed convs as four parity
+        sub-convolutions each), rebuilt when a parameter / buffer changes."""
+        key = (dtype,) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        if getattr(self, "_lay", None) is not None and self._lay_key == key:
+            return self._lay
+        mk = ops.Conv2dLayer.build
+
+        def block(b):
+            d = dict(c1=mk(b.conv1.weight, stride=b.stride, bn=_bn_tuple(b.bn1), bn_eps=b.bn1.eps, relu=True, dtype=dtype),
+                     c2=mk(b.conv2.weight, stride=1, bn=_bn_tuple(b.bn2), bn_eps=b.bn2.eps, relu=True, dtype=dtype))   # relu after the add
+            if b.downsample is not None:
+                d["ds"] = mk(b.downsample[0].weight, stride=b.stride, bn=_bn_tuple(b.downsample[1]), bn_eps=b.downsample[1].eps,
+                             dtype=dtype)
+            return d
+        lay = dict(init=mk(self.init_conv[0].weight, stride=2, bn=_bn_tuple(self.init_conv[1]), bn_eps=self.init_conv[1].eps,
+                           relu=True, dtype=dtype),
+                   enc=[[block(b) for b in seq] for seq in self.unet.enc_blocks.values()], dec=[])
+        for parts in self.unet.dec_blocks.values():
+            lay["dec"].append(dict(up=[mk(w_, stride=1, dtype=dtype) for w_ in ops.deconv2d_parity_weights(parts[0].weight)],
+                                   conv=mk(parts[1].weight, stride=1, dtype=dtype), blocks=[block(b) for b in parts[2]]))
+        lay["final"] = [mk(c.weight, stride=1, dtype=dtype) for c in (self.final_conv_1, self.final_conv_2, self.final_conv_3)]
+        self._lay, self._lay_key = lay, key
+        return lay
+
+    def forward_engine(self, x: torch.Tensor, dtype: torch.dtype):
+        """[B,3,H,W] images on the GPU -> three channels-last feature maps [B,H/8,W/8,32], [B,H/4,W/4,32], [B,H/2,W/2,32] in
+        ``dtype`` (eval mode): the layout the warp kernel reads."""
+        if self.training:
+            raise NotImplementedError("pscv FeatExt: the HIP path is inference-only (eval-mode BatchNorm is folded)")
+        ly = self.engine_layers(dtype)
+
+        def run_block(y, d):
+            t = ops.conv2d(y, d["c1"])
+            sc = ops.conv2d(y, d["ds"]) if "ds" in d else y
+            return ops.conv2d(t, d["c2"], skip=sc)
+        y = ops.conv2d(ops.image_to_channels_last8(x, dtype), ly["init"])
+        skips = []
+        for blocks in ly["enc"]:
+            for d in blocks:
+                y = run_block(y, d)
+            skips.append(y)
+        outs = [y]
+        for i, d in enumerate(ly["dec"]):
+            skip = skips[-2 - i]
+            B, H, W, f = skip.shape
+            cat = torch.empty((B, H, W, 2 * f), dtype=dtype, device=x.device)       # [deconv | skip] (nn_utils.py:269-271)
+            for par, sub in enumerate(d["up"]):
+                ops.conv2d(y, sub, out=cat, out_coff=0, parity=par)
+            cat[..., f:] = skip
+            y = ops.conv2d(cat, d["conv"])
+            for bd in d["blocks"]:
+                y = run_block(y, bd)
+            outs.append(y)
+        return tuple(ops.conv2d(o, l) for o, l in zip(outs[-3:], ly["final"]))
+
 
 def _bn_tuple(bn):
     return (bn.weight, bn.bias, bn.running_mean, bn.running_var)
@@ -168,13 +225,14 @@ class SingleStage(nn.Module):
     def build_cost_volume(self, ref, ref_cam, srcs, srcs_cam, depth_num, depth_start, depth_interval, s_scale):
         """Pair-wise group-correlation volumes of ALL source views in one fused launch: [n_src,n,d,h,w,8]
         (reference model_cas.py:176-186 + groupwise_correlation at :340)."""
-        n, _, h, w = ref.shape
+        cl = getattr(self, "_channels_last_features", False)     # the HIP extractor already wrote [n,h,w,32] 16-bit maps
+        (n, h, w, _) = ref.shape if cl else (ref.shape[0], ref.shape[2], ref.shape[3], 0)
         steps = torch.arange(depth_num, dtype=torch.float32, device=ref.device).view(1, depth_num, 1, 1)
         planes = (depth_start + depth_interval * steps).to(torch.float32)            # homography.py:39-41
         planes = planes.reshape(n, depth_num) if planes.shape[2:] == (1, 1) else planes.expand(n, depth_num, h, w)
         cams = ops.homog_cams_device(ref_cam, srcs_cam, 1.0 / s_scale)
-        ref_cl = ops.to_channels_last(ref, self.storage_dtype)
-        srcs_cl = [ops.to_channels_last(s, self.storage_dtype) for s in srcs]
+        ref_cl = ref.contiguous() if cl else ops.to_channels_last(ref, self.storage_dtype)
+        srcs_cl = [s.contiguous() if cl else ops.to_channels_last(s, self.storage_dtype) for s in srcs]
         return ops.warp_cost(ref_cl, srcs_cl, cams, planes.contiguous(), geom=L.GEOM_HOMOG, cost=L.COST_GROUPCORR,
                              out_dtype=self.storage_dtype)
 

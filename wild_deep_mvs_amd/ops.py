@@ -257,20 +257,56 @@ class Conv2dLayer:
         return Conv2dLayer(packed, dtype, c_pad, c_out, ks, int(stride), slope, scale, bias)
 
 
-def conv2d(x: torch.Tensor, layer: Conv2dLayer, *, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
-    """x [B,H,W,C] in the layer's 16-bit format -> [B,Ho,Wo,c_out] in the same format or fp32 (pscv_conv2d)."""
-    _dev(x, layer.packed)
+def conv2d_out_hw(layer: "Conv2dLayer", H: int, W: int):
+    if layer.ks == 2:                      # parity sub-convolution of a k3 s2 transposed conv: full output map is 2x
+        return 2 * H, 2 * W
+    pad = layer.ks // 2
+    return (H + 2 * pad - layer.ks) // layer.stride + 1, (W + 2 * pad - layer.ks) // layer.stride + 1
+
+
+def conv2d(x: torch.Tensor, layer: Conv2dLayer, *, out_dtype: Optional[torch.dtype] = None, skip: Optional[torch.Tensor] = None,
+           skip_coff: int = 0, out: Optional[torch.Tensor] = None, out_coff: int = 0, parity: int = -1) -> torch.Tensor:
+    """x [B,H,W,C] in the layer's 16-bit format -> [B,Ho,Wo,c_out] in the same format or fp32 (pscv_conv2d_ex).
+    ``skip`` is added before the activation; ``out`` / ``out_coff`` write a channel slice of a wider map; ``parity``
+    (0..3) selects the output parity of a ks = 2 sub-convolution of a transposed conv (writes pixels (2i+py, 2j+px))."""
+    _dev(x, layer.packed, skip, out)
     if x.dtype != layer.dtype or x.dim() != 4 or x.shape[3] != layer.c_in:
         raise TypeError(f"pscv.conv2d: input must be a {layer.dtype} [B,H,W,{layer.c_in}] map, got {x.dtype} {tuple(x.shape)}")
     out_dtype = layer.dtype if out_dtype is None else out_dtype
     B, H, W, _ = x.shape
-    Ho, Wo = (H, W) if layer.stride == 1 else ((H - 1) // 2 + 1, (W - 1) // 2 + 1)
-    out = torch.empty((B, Ho, Wo, layer.c_out), dtype=out_dtype, device=x.device)
-    rc = _launch(f"conv2d[{layer.c_in}->{layer.c_out},k{layer.ks}s{layer.stride}]", lambda: L.lib().pscv_conv2d(
-        _p(x), _dt(x), _p(layer.packed), _p(layer.scale), _p(layer.bias), _p(out), _dt(out), B, H, W, layer.c_in,
-        layer.c_out, layer.ks, layer.stride, float(layer.neg_slope), _stream()))
+    Ho, Wo = conv2d_out_hw(layer, H, W)
+    if out is None:
+        out = torch.empty((B, Ho, Wo, layer.c_out), dtype=out_dtype, device=x.device)
+    if tuple(out.shape[:3]) != (B, Ho, Wo):
+        raise ValueError(f"pscv.conv2d: out has shape {tuple(out.shape)}, expected [B,{Ho},{Wo},*]")
+    if skip is not None and (skip.dtype != layer.dtype or tuple(skip.shape[:3]) != (B, Ho, Wo)):
+        raise ValueError("pscv.conv2d: skip must have the layer's dtype and the output's spatial shape")
+    rc = _launch(f"conv2d[{layer.c_in}->{layer.c_out},k{layer.ks}s{layer.stride}]", lambda: L.lib().pscv_conv2d_ex(
+        _p(x), _dt(x), _p(layer.packed), _p(layer.scale), _p(layer.bias), _p(skip), 0 if skip is None else skip.shape[3], skip_coff,
+        _p(out), out.shape[3], out_coff, _dt(out), B, H, W, layer.c_in, layer.c_out, layer.ks, layer.stride, int(parity),
+        float(layer.neg_slope), _stream()))
     L.check(rc, "pscv_conv2d")
     return out
+
+
+def deconv2d_parity_weights(weight: torch.Tensor):
+    """ConvTranspose2d(k3, s2, p1, op1) weight [Ci,Co,3,3] -> four Conv2d weights [Co,Ci,2,2], index 2*py+px: output pixel
+    (2i+py, 2j+px) = sum over taps (ty, tx) of W[py,px][:, :, ty, tx] x[i+ty, j+tx].  Along a dim, parity 0 takes input i with
+    kernel index 1; parity 1 takes input i with kernel index 2 and input i+1 with kernel index 0."""
+    w = weight.detach().float()
+    ci, co = w.shape[:2]
+    kidx = {0: (1, None), 1: (2, 0)}     # parity -> kernel index for tap 0 (input i), tap 1 (input i+1)
+    outs = []
+    for py in (0, 1):
+        for px in (0, 1):
+            sub = torch.zeros((co, ci, 2, 2), dtype=torch.float32, device=w.device)
+            for ty in (0, 1):
+                for tx in (0, 1):
+                    ky, kx = kidx[py][ty], kidx[px][tx]
+                    if ky is not None and kx is not None:
+                        sub[:, :, ty, tx] = w[:, :, ky, kx].t()
+            outs.append(sub)
+    return outs
 
 
 def image_to_channels_last8(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
