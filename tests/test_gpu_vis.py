@@ -134,3 +134,31 @@ def test_vis_forward_parity_with_reference(env, dtype, feature_engine):
             s = check_close(f"pair depth s{3 - si} v{vi} {dtype}", ed.cpu(), t(g[f"pair_depth_s{3 - si}_v{vi}"]))
             assert s["rel_l1"] <= 2 * dtol
             check_close(f"pair uncert s{3 - si} v{vi} {dtype}", unc[0].cpu(), t(g[f"pair_uncert_s{3 - si}_v{vi}"]), rel_l1=5e-2)
+
+
+def test_graphed_forward_equals_eager(env):
+    """graph.GraphedModel: the eval-mode forward captured into a HIP graph and replayed (new inputs copied into the static
+    buffers) returns what the eager module returns, for Vis-MVSNet (the launch-count-bound model) and MVSNet."""
+    L, ops, synthetic, Frontend, OV = env
+    from wild_deep_mvs_amd.graph import GraphedModel
+    from wild_deep_mvs_amd.models.MVSNet.model import MVSNet
+    net, _ = _net(env, 0)
+    net.depth_nums, net.interval_scales = [16, 8, 4], [8.0, 4.0, 2.0]
+    gnet = GraphedModel(net)
+    for seed in (0, 1, 2):                      # first call captures, the next two replay with different inputs
+        sc = {k: v.cuda() for k, v in synthetic.make_scene(1, 3, 64, 96, seed=seed).items()}
+        a = (sc["imgs"], sc["K"], sc["R"], sc["t"], sc["depth_min"], sc["depth_max"])
+        want, got = net(*a), gnet(*a)
+        check_close(f"vis graphed depth seed {seed}", got["depth"].cpu(), want["depth"].cpu(), max_abs=1e-5)
+        check_close(f"vis graphed pair uncert seed {seed}", got["depth_pair_list"][0][1][1][0].cpu(),
+                    want["depth_pair_list"][0][1][1][0].cpu(), max_abs=1e-4)
+    assert len(gnet._graphs) == 1
+    m = MVSNet("variance")
+    m.load_state_dict(synthetic.sharpened_state_dict("mvsnet", synthetic.template_of(m), seed=0))
+    m = m.cuda().eval()
+    m.num_depth = 16
+    gm = GraphedModel(m)
+    for seed in (3, 4):
+        sc = {k: v.cuda() for k, v in synthetic.make_scene(1, 3, 64, 96, seed=seed).items()}
+        a = (sc["imgs"], sc["K"], sc["R"], sc["t"], sc["depth_min"], sc["depth_max"])
+        check_close(f"mvsnet graphed depth seed {seed}", gm(*a)["depth"].cpu(), m(*a)["depth"].cpu(), max_abs=1e-5)
