@@ -200,7 +200,9 @@ int pscv_conv2d(const void* in, int dtype, const uint16_t* packed, const float* 
  *   layers   k3 s1|s2 p1, k5 s2 p2, k1 s1|s2 p0 (the BasicBlock shortcuts), and ks = 2: one of the four 2x2-tap parity
  *            sub-convolutions of ConvTranspose2d(k3, s2, p1, op1) -- parity = 2 * (output row parity) + (output column parity),
  *            weights [c_out, c_in, 2, 2] with tap (ty, tx) applied to input (i + ty, j + tx); output pixel (2 i + row parity,
- *            2 j + column parity) of a [B, 2 Hi, 2 Wi, *] map.  parity = -1 for every other layer.
+ *            2 j + column parity) of a [B, 2 Hi, 2 Wi, *] map.  A k3 s1 layer may carry a parity too (the sub-convolutions of
+ *            ConvTranspose2d(k5, s2, p2, op1) = the data gradient of a k5 s2 conv: taps at -1, 0, +1 around input (i, j)).
+ *            parity = -1 for every other layer.
  *   skip     NULL or [B,Ho,Wo,skip_cstride] read at channel offset skip_coff, added BEFORE the activation
  *            (BasicBlock: relu(bn(conv(x)) + shortcut))
  *   out      [B,Ho,Wo,out_cstride] written at channel offset out_coff (the decoder's cat([deconv, skip]) needs no copy)

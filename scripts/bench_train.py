@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--depth", type=int, default=192)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--aggregation", default="variance")
+    ap.add_argument("--feature-engine", default="torch", choices=["torch", "pscv"],
+                    help="2-D extractor in train(): PyTorch-ROCm autograd (fp32) or training.FeatureNetFn (engine, 16-bit activations)")
     a = ap.parse_args()
     dt = {"bf16": torch.bfloat16, "f16": torch.float16}[a.dtype]
     torch.cuda.set_device(0)
@@ -38,6 +40,7 @@ def main():
     net = net.cuda().train()
     net.num_depth = a.depth
     net.train_storage_dtype = dt
+    net.feature_engine_train = a.feature_engine
     opt = torch.optim.Adam(net.parameters(), lr=1e-4)
     scene = synthetic.make_scene(a.batch, a.views, a.height, a.width, seed=0)
     gt, mask = synthetic.train_target(scene, a.height // 4, a.width // 4)
@@ -70,7 +73,8 @@ def main():
     vox = a.batch * a.depth * (a.height // 4) * (a.width // 4)
     print(json.dumps({"metric": "MVSNet training step (forward train() + backward + Adam), cost-volume voxels/s", "value": vox / (ms * 1e-3),
                       "unit": "voxels/s", "ms_per_step": ms, "dtype": a.dtype, "loss": float(loss),
-                      "config": {"workload": f"MVSNet {a.aggregation}, {a.views} views, {a.height}x{a.width}, D={a.depth}, B={a.batch}"},
+                      "config": {"workload": f"MVSNet {a.aggregation}, {a.views} views, {a.height}x{a.width}, D={a.depth}, B={a.batch}",
+                                 "feature_engine_train": a.feature_engine},
                       "pscv_kernels_us_per_step": kern, "pscv_kernels_total_ms": round(sum(kern.values()) / 1e3, 3)}))
 
 

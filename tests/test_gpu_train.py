@@ -644,3 +644,95 @@ def test_function_level_warps_are_differentiable():
     got.backward(gv.cuda())
     check_close("vis homography_warping", got.detach().cpu(), ref.detach(), max_abs=3e-4)
     check_close("vis homography_warping d src", s2.grad.cpu(), src.grad, rel_l2=2e-4)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_conv2d_k5s2_gradients(dtype):
+    """The two decompositions FeatureNetFn uses for a k5 s2 p2 Conv2d: weight gradient from the four parity planes of the
+    input (four single-plane runs of the 3-D MFMA weight-gradient kernel) and data gradient as four parity sub-convolutions
+    on the forward conv2d kernel; plus the k3 s1 forms.  Against ATen autograd on identical operands."""
+    from wild_deep_mvs_amd import ops, training as T
+    g = torch.Generator().manual_seed(31)
+    B, H, W = 2, 24, 40
+    cl2 = lambda v: v.permute(0, 2, 3, 1).to(dtype).contiguous().cuda()
+    cf2 = lambda v: v.float().permute(0, 3, 1, 2).cpu()
+    for ci, co in ((8, 16), (16, 32)):
+        w = (torch.randn(co, ci, 5, 5, generator=g) * 0.1).to(dtype).float().requires_grad_(True)
+        x = torch.randn(B, ci, H, W, generator=g).to(dtype).float().requires_grad_(True)
+        y = F.conv2d(x, w, None, stride=2, padding=2)
+        dy = torch.randn(y.shape, generator=g).to(dtype).float()
+        y.backward(dy)
+        dw = T._wgrad2d_k5s2(cl2(dy), cl2(x.detach()), co, ci)
+        check_close(f"k5s2 dW {ci}->{co}", dw.cpu(), w.grad, rel_l2=2e-5)
+        dx = torch.empty((B, H, W, ci), dtype=torch.float32, device="cuda")
+        for par, sub in enumerate(T._dgrad2d_k5s2_layers(w.detach().cuda(), dtype)):
+            ops.conv2d(cl2(dy), sub, out=dx, parity=par, out_dtype=torch.float32)
+        check_close(f"k5s2 dX {ci}->{co}", cf2(dx), x.grad, rel_l2=2e-5)
+    for ci, co in ((8, 8), (16, 16), (32, 32)):
+        w = (torch.randn(co, ci, 3, 3, generator=g) * 0.1).to(dtype).float().requires_grad_(True)
+        x = torch.randn(B, ci, H, W, generator=g).to(dtype).float().requires_grad_(True)
+        y = F.conv2d(x, w, None, padding=1)
+        dy = torch.randn(y.shape, generator=g).to(dtype).float()
+        y.backward(dy)
+        check_close(f"k3 dW {ci}->{co}", T._wgrad2d_k3(cl2(dy), cl2(x.detach()), co, ci).cpu(), w.grad, rel_l2=2e-5)
+        dx = ops.conv2d(cl2(dy), T._dgrad2d_k3_layer(w.detach().cuda(), dtype), out_dtype=torch.float32)
+        check_close(f"k3 dX {ci}->{co}", cf2(dx), x.grad, rel_l2=2e-5)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_feature_net_fn_against_module_autograd(dtype):
+    """training.FeatureNetFn (MVSNet's 2-D extractor in train() mode, forward and backward on the engine) against the same
+    module under PyTorch-ROCm autograd (fp32): features, every parameter gradient (direction of the whole vector + per-tensor
+    errors reported) and the BatchNorm2d running statistics.  Eight stored 16-bit layers each way; the kernels themselves are
+    held tight by test_conv2d_k5s2_gradients / test_bn_backward / test_conv3d_wgrad_and_dgrad."""
+    from wild_deep_mvs_amd import synthetic, training as T
+    from wild_deep_mvs_amd.models.MVSNet.model import MVSNet
+    import copy
+    net = MVSNet("variance")
+    net.load_state_dict(synthetic.train_state_dict("mvsnet", synthetic.template_of(net), seed=0))
+    fa = net.feature.cuda().train()
+    fb = copy.deepcopy(fa)
+    gen = torch.Generator().manual_seed(4)
+    img = torch.rand(2, 3, 64, 96, generator=gen).cuda()
+    gout = torch.randn(2, 32, 16, 24, generator=gen).cuda()
+    out = T.FeatureNetFn.apply(fa, dtype, img, *T.FeatureNetFn.params(fa))
+    out.backward(gout.permute(0, 2, 3, 1).to(dtype).contiguous())
+    ref = fb(img)
+    ref.backward(gout)
+    torch.cuda.synchronize()
+    bf = dtype == torch.bfloat16
+    check_close("features", out.detach().float().permute(0, 3, 1, 2).cpu(), ref.detach().cpu(), rel_l2=3e-2 if bf else 4e-3)
+    o_grads = {k: p.grad.detach().cpu() for k, p in fb.named_parameters()}
+    worst, cos, rows = _grad_report(f"FeatureNetFn {dtype} vs module autograd", fa, o_grads)
+    assert cos >= (0.97 if bf else 0.995), (cos, rows)
+    for (k, a), (_, b_) in zip(fa.state_dict().items(), fb.state_dict().items()):
+        if "running_" in k:
+            check_close(f"stat {k}", a.cpu(), b_.cpu(), rel_l2=3e-2 if bf else 4e-3)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_mvsnet_train_step_with_engine_extractor(dtype):
+    """feature_engine_train = "pscv": the whole MVSNet training step (2-D extractor included) on the engine.  A mixed-precision
+    mode -- eight more stored 16-bit layers in front of the sweep -- so the bars against the fp32 oracle are those of the
+    storage format, not of the path: depth, loss, direction of the full gradient."""
+    from test_oracle_train import oracle_train_step
+    from wild_deep_mvs_amd import synthetic
+    from wild_deep_mvs_amd.models.MVSNet.model import MVSNet
+    g = load_golden("mvsnet_train.npz")
+    H, W, V, D, seed, scene_seed, B = [int(x) for x in g["meta"]]
+    net = MVSNet("variance")
+    net.load_state_dict(synthetic.train_state_dict("mvsnet", synthetic.template_of(net), seed=seed))
+    net = net.cuda().train()
+    net.num_depth, net.train_storage_dtype, net.feature_engine_train = D, dtype, "pscv"
+    scene = synthetic.make_scene(B, V, H, W, seed=scene_seed)
+    out = net(*[scene[k].cuda() for k in ("imgs", "K", "R", "t", "depth_min", "depth_max")])
+    gt, mask = synthetic.train_target(scene, H // 4, W // 4)
+    loss = synthetic.supervised_loss(out["depth"], gt.cuda(), mask.cuda(), scene["depth_min"].cuda(), scene["depth_max"].cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    o_depth, o_loss, o_grads, _ = oracle_train_step("variance", H, W, V, D, seed, scene_seed, B)
+    bf = dtype == torch.bfloat16
+    check_close("depth vs oracle", out["depth"].detach().cpu(), o_depth, rel_l1=4e-2 if bf else 6e-3)
+    assert abs(float(loss) - o_loss) <= (1e-1 if bf else 2e-2) * abs(o_loss), (float(loss), o_loss)
+    worst, cos, rows = _grad_report(f"mvsnet + FeatureNetFn {dtype} vs fp32 oracle", net, o_grads)
+    assert cos >= (0.8 if bf else 0.97), (cos, rows)

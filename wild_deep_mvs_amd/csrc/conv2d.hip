@@ -301,8 +301,9 @@ extern "C" int pscv_conv2d_ex(const void* in, int dtype, const uint16_t* packed,
     PSCV_CHECK_ARG((ks == 3 && (stride == 1 || stride == 2)) || (ks == 5 && stride == 2) || (ks == 1 && (stride == 1 || stride == 2)) ||
                        (ks == 2 && stride == 1),
                    "pscv_conv2d: supported layers are k3 s1|s2 p1, k5 s2 p2, k1 s1|s2 p0 and the k2 parity sub-conv (got k%d s%d)", ks, stride);
-    PSCV_CHECK_ARG(ks == 2 || parity < 0, "pscv_conv2d: an output parity only applies to the k2 sub-convolutions of a transposed conv");
-    PSCV_CHECK_ARG(ks != 2 || (parity >= 0 && parity < 4), "pscv_conv2d: k2 sub-convolution needs parity 0..3 (2 * row parity + column parity)");
+    PSCV_CHECK_ARG(parity < 0 || ((ks == 2 || ks == 3) && stride == 1 && parity < 4),
+                   "pscv_conv2d: an output parity (0..3) only applies to the stride-1 k2 / k3 sub-convolutions of a transposed conv");
+    PSCV_CHECK_ARG(ks != 2 || parity >= 0, "pscv_conv2d: a k2 sub-convolution needs parity 0..3 (2 * row parity + column parity)");
     PSCV_CHECK_ARG((long)Hi * Wi * c_in * 2 < (1L << 32), "pscv_conv2d: one input map must stay below 4 GiB");
     PSCV_CHECK_ARG(out_cstride % 4 == 0 && out_coff % 4 == 0 && out_coff + c_out <= out_cstride, "pscv_conv2d: bad output channel slice");
     PSCV_CHECK_ARG(!skip || (skip_cstride % 4 == 0 && skip_coff % 4 == 0 && skip_coff + c_out <= skip_cstride), "pscv_conv2d: bad skip channel slice");
@@ -317,7 +318,7 @@ extern "C" int pscv_conv2d_ex(const void* in, int dtype, const uint16_t* packed,
     a.Ho = ks == 2 ? Hi : (Hi + 2 * pad - ks) / stride + 1;
     a.Wo = ks == 2 ? Wi : (Wi + 2 * pad - ks) / stride + 1;
     a.oys = a.oxs = 1; a.oyo = a.oxo = 0; a.Hof = a.Ho; a.Wof = a.Wo;
-    if (ks == 2) { a.oys = a.oxs = 2; a.oyo = parity >> 1; a.oxo = parity & 1; a.Hof = 2 * Hi; a.Wof = 2 * Wi; }
+    if (parity >= 0) { a.oys = a.oxs = 2; a.oyo = parity >> 1; a.oxo = parity & 1; a.Hof = 2 * Hi; a.Wof = 2 * Wi; }
     PSCV_CHECK_ARG(neg_slope >= 0.0f && neg_slope <= 1.0f, "pscv_conv2d: neg_slope=%g outside [0,1]", (double)neg_slope);
     a.cout = c_out; a.neg_slope = neg_slope;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -180,6 +180,11 @@ class MVSNet(nn.Module):
         self.feature_engine = "pscv"
         # train() mode: gradients span many decades, so the stored activations / gradients default to bf16 there
         self.train_storage_dtype = torch.bfloat16
+        # 2-D extractor in train(): "torch" (default) = PyTorch-ROCm autograd in fp32, the reference's numerics for the step
+        # before the path; "pscv" = training.FeatureNetFn (forward and backward on the engine's conv2d / weight-gradient /
+        # BatchNorm kernels with 16-bit stored activations: a mixed-precision speed mode, eight more 16-bit roundings in front
+        # of the sweep -- depth moves by ~2e-3 (fp16) / ~2e-2 (bf16) relative on the training fixtures)
+        self.feature_engine_train = "torch"
 
     # -- upstream ---------------------------------------------------------------------------
     def extract_features(self, imgs: Sequence[torch.Tensor]) -> List[torch.Tensor]:
@@ -235,7 +240,8 @@ class MVSNet(nn.Module):
         updates batch statistics like the reference's modules in train() (models/MVSNet/model.py:109-139,74-84)."""
         V = len(features)
         src_idx = [i for i in range(V) if i != reference_frame]
-        D, h, w = depth_values.shape[1], features[0].shape[2], features[0].shape[3]
+        cl = features[0].dtype == self.train_storage_dtype   # channels-last 16-bit maps from FeatureNetFn (else NCHW fp32)
+        D, h, w = (depth_values.shape[1],) + (tuple(features[0].shape[1:3]) if cl else tuple(features[0].shape[2:4]))
         if D % 8 or h % 8 or w % 8:
             raise ValueError(f"MVSNet CostRegNet needs D,h,w multiples of 8 (got {D},{h},{w}), as in the reference")
         dt = self.train_storage_dtype
@@ -263,7 +269,11 @@ class MVSNet(nn.Module):
         if self.training:
             # per-view extractor passes like the reference (model.py:101-107): each view normalises with its own batch
             # statistics; the 2-D extractor is upstream of the path and stays on PyTorch-ROCm autograd in training
-            feats = [self.feature(img) for img in imgs]
+            if self.feature_engine_train == "pscv":
+                fparams = T.FeatureNetFn.params(self.feature)
+                feats = [T.FeatureNetFn.apply(self.feature, self.train_storage_dtype, img, *fparams) for img in imgs]
+            else:
+                feats = [self.feature(img) for img in imgs]
             depth, conf = self.hot_path_train(feats, proj, dv_ref, reference_frame)
             return {"depth": depth, "depth_est_list": [depth, ], "depth_pair_list": [], "photometric_confidence": conf}
 

@@ -257,8 +257,8 @@ class Conv2dLayer:
         return Conv2dLayer(packed, dtype, c_pad, c_out, ks, int(stride), slope, scale, bias)
 
 
-def conv2d_out_hw(layer: "Conv2dLayer", H: int, W: int):
-    if layer.ks == 2:                      # parity sub-convolution of a k3 s2 transposed conv: full output map is 2x
+def conv2d_out_hw(layer: "Conv2dLayer", H: int, W: int, parity: int = -1):
+    if layer.ks == 2 or parity >= 0:       # parity sub-convolution of a stride-2 transposed conv: full output map is 2x
         return 2 * H, 2 * W
     pad = layer.ks // 2
     return (H + 2 * pad - layer.ks) // layer.stride + 1, (W + 2 * pad - layer.ks) // layer.stride + 1
@@ -274,7 +274,7 @@ def conv2d(x: torch.Tensor, layer: Conv2dLayer, *, out_dtype: Optional[torch.dty
         raise TypeError(f"pscv.conv2d: input must be a {layer.dtype} [B,H,W,{layer.c_in}] map, got {x.dtype} {tuple(x.shape)}")
     out_dtype = layer.dtype if out_dtype is None else out_dtype
     B, H, W, _ = x.shape
-    Ho, Wo = conv2d_out_hw(layer, H, W)
+    Ho, Wo = conv2d_out_hw(layer, H, W, parity)
     if out is None:
         out = torch.empty((B, Ho, Wo, layer.c_out), dtype=out_dtype, device=x.device)
     if tuple(out.shape[:3]) != (B, Ho, Wo):

@@ -39,23 +39,32 @@ class WarpCostFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cams, depth, geom, cost, dtype, temp, ref, *srcs):
-        ref_cl = ops.to_channels_last(ref.detach(), dtype)
-        srcs_cl = [ops.to_channels_last(s.detach(), dtype) for s in srcs]
+        # NCHW fp32 maps (the PyTorch-ROCm extractor) are converted here; [B,h,w,C] maps already in the storage dtype (the
+        # engine's own extractor, FeatureNetFn) are taken as they are
+        cl_in = ref.dtype == dtype and dtype != torch.float32
+        if cl_in:
+            ref_cl, srcs_cl = ref.detach().contiguous(), [s.detach().contiguous() for s in srcs]
+        else:
+            ref_cl = ops.to_channels_last(ref.detach(), dtype)
+            srcs_cl = [ops.to_channels_last(s.detach(), dtype) for s in srcs]
         tval = float(temp.detach().float().item()) if temp is not None else 0.0
         out = ops.warp_cost(ref_cl, srcs_cl, cams, depth, geom=geom, cost=cost, temp=tval, out_dtype=dtype)
         ctx.save_for_backward(cams, depth, ref_cl, *srcs_cl)
-        ctx.meta = (geom, cost, tval, temp is not None, ref.dtype, [s.dtype for s in srcs])
+        ctx.meta = (geom, cost, tval, temp is not None, ref.dtype, [s.dtype for s in srcs], cl_in)
         return out
 
     @staticmethod
     def backward(ctx, g):
         cams, depth, ref_cl, *srcs_cl = ctx.saved_tensors
-        geom, cost, tval, has_temp, ref_dt, src_dts = ctx.meta
+        geom, cost, tval, has_temp, ref_dt, src_dts, cl_in = ctx.meta
         g = g.contiguous()
         dref, dsrcs, dtemp = ops.warp_cost_bwd(ref_cl, srcs_cl, cams, depth, g, geom=geom, cost=cost, temp=tval,
                                                want_dtemp=has_temp)
-        gref = dref.permute(0, 3, 1, 2).to(ref_dt)
-        gsrcs = [d.permute(0, 3, 1, 2).to(dt) for d, dt in zip(dsrcs, src_dts)]
+        if cl_in:
+            gref, gsrcs = dref.to(ref_dt), [d.to(dt) for d, dt in zip(dsrcs, src_dts)]
+        else:
+            gref = dref.permute(0, 3, 1, 2).to(ref_dt)
+            gsrcs = [d.permute(0, 3, 1, 2).to(dt) for d, dt in zip(dsrcs, src_dts)]
         return (None, None, None, None, None, dtemp if has_temp else None, gref, *gsrcs)
 
 
@@ -458,3 +467,134 @@ class FusePairsFn(torch.autograd.Function):
     def backward(ctx, g):
         dI, dU = ops.fuse_pairs_bwd(ctx.interms, ctx.uncerts, g.contiguous())
         return (None, *dI, *dU)
+
+
+# --------------------------------------------------------------------------------------------------
+# MVSNet's 2-D FeatureNet in train() mode on the engine (upstream of the path; optional)
+# --------------------------------------------------------------------------------------------------
+def _v5(x: torch.Tensor) -> torch.Tensor:
+    """[B,H,W,C] -> [B,1,H,W,C]: the 3-D kernels (batch statistics, weight gradient with a single plane) on 2-D maps."""
+    return x.unsqueeze(1)
+
+
+def _wgrad2d_k3(dy: torch.Tensor, x: torch.Tensor, co: int, ci: int) -> torch.Tensor:
+    """Weight gradient of a k3 s1 p1 Conv2d as the single-plane case of the 3-D MFMA kernel (its z taps 0 and 2 only meet
+    zero padding): [co,ci,3,3]."""
+    return ops.conv3d_wgrad(_v5(dy), _v5(x), ca=co, cb=ci, stride=1)[:, :, 1]
+
+
+def _wgrad2d_k5s2(dy: torch.Tensor, x: torch.Tensor, co: int, ci: int) -> torch.Tensor:
+    """Weight gradient of a k5 s2 p2 Conv2d: x[2o + k - 2] with k = 2 t + a is tap t - 1 of the input's parity plane
+    x_a[i] = x[2i + a], so the 5x5 gradient is assembled from four stride-1 3x3 weight gradients."""
+    dw = torch.zeros((co, ci, 5, 5), dtype=torch.float32, device=dy.device)
+    for a in (0, 1):
+        for b in (0, 1):
+            g = _wgrad2d_k3(dy, x[:, a::2, b::2, :].contiguous(), co, ci)
+            ty = [t for t in range(3) if 2 * t + a <= 4]
+            tx = [t for t in range(3) if 2 * t + b <= 4]
+            for t1 in ty:
+                for t2 in tx:
+                    dw[:, :, 2 * t1 + a, 2 * t2 + b] = g[:, :, t1, t2]
+    return dw
+
+
+def _dgrad2d_k3_layer(w: torch.Tensor, dtype) -> ops.Conv2dLayer:
+    """Adjoint of a k3 s1 p1 Conv2d [Co,Ci,3,3]: the same conv kernel on the channel-swapped, tap-flipped weight."""
+    return ops.Conv2dLayer.build(w.detach().float().flip(2, 3).transpose(0, 1).contiguous(), stride=1, dtype=dtype)
+
+
+def _dgrad2d_k5s2_layers(w: torch.Tensor, dtype) -> List[ops.Conv2dLayer]:
+    """Adjoint of a k5 s2 p2 Conv2d [Co,Ci,5,5] (= ConvTranspose2d k5 s2 p2 op1) as four stride-1 3x3 sub-convolutions, one per
+    output parity: dx[2i + a] = sum_m dy[i + m] w[k = a + 2 - 2m], m = -1, 0, +1 (k = 5 does not exist: zero)."""
+    wf = w.detach().float()
+    co, ci = wf.shape[:2]
+    subs = []
+    for a in (0, 1):
+        for b in (0, 1):
+            sub = torch.zeros((ci, co, 3, 3), dtype=torch.float32, device=wf.device)
+            for ty in range(3):
+                for tx in range(3):
+                    ky, kx = a + 2 - 2 * (ty - 1), b + 2 - 2 * (tx - 1)
+                    if 0 <= ky <= 4 and 0 <= kx <= 4:
+                        sub[:, :, ty, tx] = wf[:, :, ky, kx].t()
+            subs.append(ops.Conv2dLayer.build(sub, stride=1, dtype=dtype))
+    return subs
+
+
+def _cached_layer(net, tag, weight, dtype, make):
+    """Packed 2-D layers are built on the host (pscv_pack_conv2d_weights): keep them per (weight version, dtype) on the module so
+    that the views of one step -- same weights -- do not repack (and synchronise) once per view."""
+    cache = net.__dict__.setdefault("_pscv_train_layers", {})
+    key = (tag, weight.data_ptr(), weight._version, dtype)
+    if key not in cache:
+        for k in [k for k in cache if k[0] == tag]:
+            del cache[k]
+        cache[key] = make()
+    return cache[key]
+
+
+class FeatureNetFn(torch.autograd.Function):
+    """MVSNet's 2-D extractor (models/MVSNet/model.py:21-41: seven conv + BatchNorm2d + ReLU blocks, k3 s1 / k5 s2, and a
+    final k3 conv with bias) in train() mode, forward and backward on the engine: raw MFMA conv2d, batch statistics, one
+    normalise + ReLU pass; backward = BatchNorm backward, weight gradient on the 3-D MFMA kernel (single plane; k5 s2 from
+    the four parity planes of the input), data gradient as the adjoint conv on the forward kernel (k5 s2: four parity
+    sub-convolutions).  ``forward(ctx, net, dtype, img [B,3,H,W], *params)`` -> [B,H/4,W/4,32] in ``dtype``."""
+
+    @staticmethod
+    def params(net) -> List[torch.Tensor]:
+        ps = []
+        for i in range(7):
+            blk = getattr(net, f"conv{i}")
+            ps += [blk.conv.weight, blk.bn.weight, blk.bn.bias]
+        return ps + [net.feature.weight, net.feature.bias]
+
+    @staticmethod
+    def forward(ctx, net, dtype, img, *params):
+        B, _, H, W = img.shape
+        if H % 4 or W % 4:
+            raise ValueError("pscv FeatureNetFn: image height and width must be multiples of 4")
+        x = ops.image_to_channels_last8(img.detach(), dtype)
+        saved = []
+        for i, (ci, co, k, s_, p_) in enumerate(net.SPEC):
+            blk = getattr(net, f"conv{i}")
+            y = ops.conv2d(x, _cached_layer(net, f"f{i}", blk.conv.weight, dtype,
+                                            lambda: ops.Conv2dLayer.build(blk.conv.weight, stride=s_, dtype=dtype)))
+            nvox = y.numel() // y.shape[3]
+            aff = _bn_affine(Block("", "", y, bn=blk.bn), ops.bn_stats(_v5(y)), nvox)
+            act = ops.bn_act(_v5(y), aff[0], aff[1], relu=True).squeeze(1)
+            saved.append((x, y, aff, nvox))
+            x = act
+        out = ops.conv2d(x, ops.Conv2dLayer.build(net.feature.weight, stride=1, conv_bias=net.feature.bias, dtype=dtype))   # (bias may change alone)
+        ctx.net, ctx.dtype, ctx.saved, ctx.x_last = net, dtype, saved, x
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        net, dtype, saved = ctx.net, ctx.dtype, ctx.saved
+        g = g.contiguous().to(dtype)
+        grads = {}
+        # final conv (bias, no BatchNorm)
+        grads[id(net.feature.weight)] = _wgrad2d_k3(g, ctx.x_last, 32, 32).to(net.feature.weight.dtype)
+        grads[id(net.feature.bias)] = ops.bn_stats(_v5(g))[0].to(net.feature.bias.dtype)
+        dact = ops.conv2d(g, _cached_layer(net, "dfeat", net.feature.weight, dtype, lambda: _dgrad2d_k3_layer(net.feature.weight, dtype)))
+        for i in range(6, -1, -1):
+            ci, co, k, s_, p_ = net.SPEC[i]
+            blk = getattr(net, f"conv{i}")
+            x, y, (scale, bias, mean, invstd), nvox = saved[i]
+            dy, dg, db = _bn_backward(blk.bn, _v5(dact), _v5(y), (scale, bias, mean, invstd, nvox), relu=True)
+            dy = dy.squeeze(1)
+            cpad = x.shape[3]
+            dw = _wgrad2d_k3(dy, x, co, cpad) if k == 3 else _wgrad2d_k5s2(dy, x, co, cpad)
+            grads[id(blk.conv.weight)] = dw[:, :ci].to(blk.conv.weight.dtype)
+            grads[id(blk.bn.weight)], grads[id(blk.bn.bias)] = dg, db
+            if i > 0:
+                if k == 3:
+                    dact = ops.conv2d(dy, _cached_layer(net, f"d{i}", blk.conv.weight, dtype,
+                                                        lambda: _dgrad2d_k3_layer(blk.conv.weight, dtype)))
+                else:
+                    dact = torch.empty_like(x)
+                    subs = _cached_layer(net, f"d{i}", blk.conv.weight, dtype, lambda: _dgrad2d_k5s2_layers(blk.conv.weight, dtype))
+                    for par, sub in enumerate(subs):
+                        ops.conv2d(dy, sub, out=dact, parity=par)
+        ctx.saved = None
+        return (None, None, None, *[grads[id(p)] for p in FeatureNetFn.params(net)])
