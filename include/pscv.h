@@ -47,6 +47,9 @@ extern "C" {
 #define PSCV_COST_SOFTMIN 2      /* sum_v e diff/(sum_v e + 1e-6)      models/MVSNet/model.py:141-173 */
 #define PSCV_COST_GROUPCORR 3    /* per source, 4-channel group dot    models/VisMVSNet/nn_utils.py:473-490 (call model_cas.py:340) */
 #define PSCV_COST_WARP_ONLY 4    /* per source warped volume           homo_warping / homography_warping themselves */
+#define PSCV_COST_VARIANCE_PARTIAL 5 /* fp32 partial sums (sum f, sum f^2) over the GIVEN views for a source-view shard across GPUs:
+                                    out [2][B,D,h,w,C] fp32; ref may be NULL (only one rank adds the reference view).  The ranks'
+                                    outputs are all-reduced (RCCL) and pscv_variance_finish turns them into the cost volume */
 
 #define PSCV_MAX_SRC 16
 #define PSCV_CAM_FLOATS 18 /* per (source, batch): PROJ = rot[9] trans[3] pad[6]; HOMOG = A[9] Bm[9] */
@@ -120,6 +123,14 @@ int pscv_homog_cams(const float* ref_cam, const float* src_cams, int B, int n_sr
 int pscv_warp_cost(const void* ref, const void* const* srcs, int n_src, const float* cams, const float* depth,
                    long depth_bstride, int depth_per_pixel, int geom, int cost, float temp, void* out, int B, int C,
                    int h, int w, int hs, int ws, int D, int in_dtype, int out_dtype, void* stream);
+
+/*
+ * Second half of a source-view-sharded variance cost volume (MVSNet / CVP-MVSNet): after the all-reduce of the
+ * PSCV_COST_VARIANCE_PARTIAL outputs, out = sum2 / N - (sum / N)^2 in the rounding order of `cost`
+ * (PSCV_COST_VARIANCE: models/MVSNet/model.py:134, PSCV_COST_VARIANCE_CVP: models/CVP_MVSNet/models/net.py:148).
+ *   sums fp32 [2][n] (n = B*D*h*w*C, a multiple of 8), n_views = total number of views incl. the reference, out [n] in `dtype`.
+ */
+int pscv_variance_finish(const float* sums, long n, int n_views, int cost, int dtype, void* out, void* stream);
 
 /*
  * Weight packing for pscv_conv3d (host side, done once at model-load time).

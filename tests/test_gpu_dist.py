@@ -157,3 +157,52 @@ def test_mvsnet_training_under_ddp_two_ranks_one_gpu():
     cos = dot / (n1 ** 0.5 * n2 ** 0.5)
     print(f"[ddp] cosine between the DDP-averaged and the hand-averaged gradient: {cos:.6f}", flush=True)
     assert cos >= 0.99, cos
+
+
+def _mvs_shard_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from wild_deep_mvs_amd import synthetic
+        from wild_deep_mvs_amd.models.MVSNet.model import MVSNet
+        g = load_golden("mvsnet_behind.npz")
+        H, W, V, D, seed, scene_seed, behind = [int(x) for x in g["meta"]]
+        net = MVSNet("variance")
+        net.load_state_dict(synthetic.sharpened_state_dict("mvsnet", synthetic.template_of(net), seed=seed))
+        net = net.cuda().eval()
+        net.num_depth = D
+        net.set_view_group(dist.group.WORLD)
+        scene = {k: v.cuda() for k, v in synthetic.make_scene(1, V, H, W, seed=scene_seed, behind_view=behind).items()}
+        taps = {}
+        out = net(scene["imgs"], scene["K"], scene["R"], scene["t"], scene["depth_min"], scene["depth_max"], taps=taps)
+        q.put((rank, out["depth"].cpu().numpy(), taps["cost_volume"].float().cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_mvsnet_source_view_shard_variance_reduce_two_ranks_one_gpu():
+    """MVSNet variance cost volume with the source views spread over two ranks (rank 0: reference + sources 0, 2; rank 1:
+    source 1): fp32 partial sums (pscv_warp_cost PSCV_COST_VARIANCE_PARTIAL), one all-reduce, pscv_variance_finish -- against
+    the reference golden (a scene with a camera behind which nothing projects)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mvs_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = load_golden("mvsnet_behind.npz")
+    ref_cost = np.transpose(g["cost_volume"], (0, 2, 3, 4, 1))
+    for rank, depth, cost in res:
+        rel = np.abs(depth - g["depth"]).mean() / np.abs(g["depth"]).mean()
+        crel = np.linalg.norm(cost - ref_cost) / np.linalg.norm(ref_cost)
+        print(f"[parity] variance view-shard rank {rank}: depth rel-L1 {rel:.3e}, cost volume rel-L2 {crel:.3e}", flush=True)
+        assert rel <= 1e-3 and crel <= 1e-2
+    assert np.array_equal(res[0][2], res[1][2]), "ranks must hold the same cost volume"

@@ -19,7 +19,7 @@ CSRC = os.path.join(_HERE, "csrc")
 ABI_VERSION = 2
 F32, BF16, F16 = 0, 1, 2
 GEOM_PROJ, GEOM_HOMOG = 0, 1
-COST_VARIANCE, COST_VARIANCE_CVP, COST_SOFTMIN, COST_GROUPCORR, COST_WARP_ONLY = 0, 1, 2, 3, 4
+COST_VARIANCE, COST_VARIANCE_CVP, COST_SOFTMIN, COST_GROUPCORR, COST_WARP_ONLY, COST_VARIANCE_PARTIAL = 0, 1, 2, 3, 4, 5
 CONV_S1, CONV_S2, CONV_T2, CONV_S1P8, CONV_S1C1, CONV_T2P8 = 0, 1, 2, 3, 4, 5
 EPI_RELU_PRE, EPI_RELU_POST = 1, 2
 MAX_SRC = 16
@@ -31,7 +31,7 @@ EXPORTS = ("pscv_last_error", "pscv_abi_version", "pscv_set_tuning", "pscv_proj_
            "pscv_fuse_pairs", "pscv_fuse_finish", "pscv_geo_filter", "pscv_pack_conv2d_weights", "pscv_conv2d",
            "pscv_pack_conv3d_weights", "pscv_conv3d", "pscv_softargmin", "pscv_train_workspace_floats", "pscv_bn_stats",
            "pscv_bn_act", "pscv_bn_bwd_reduce", "pscv_bn_bwd_apply", "pscv_softargmin_bwd", "pscv_conv3d_wgrad_workspace",
-           "pscv_conv3d_wgrad", "pscv_warp_cost_bwd", "pscv_cvp_depth_hypos", "pscv_relu_bwd", "pscv_fuse_pairs_bwd", "pscv_pack_conv3d_weights_device", "pscv_conv2d_ex")
+           "pscv_conv3d_wgrad", "pscv_warp_cost_bwd", "pscv_cvp_depth_hypos", "pscv_relu_bwd", "pscv_fuse_pairs_bwd", "pscv_pack_conv3d_weights_device", "pscv_conv2d_ex", "pscv_variance_finish")
 
 
 class PscvMissingError(RuntimeError):
@@ -78,6 +78,8 @@ def _declare(lib):
     lib.pscv_pack_conv2d_weights.argtypes = [vp, i, i, i, i, i, vp]
     lib.pscv_conv2d.restype = i
     lib.pscv_conv2d.argtypes = [vp, i, vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, vp]
+    lib.pscv_variance_finish.restype = i
+    lib.pscv_variance_finish.argtypes = [vp, l, i, i, i, vp, vp]
     lib.pscv_conv2d_ex.restype = i
     lib.pscv_conv2d_ex.argtypes = [vp, i, vp, vp, vp, vp, i, i, vp, i, i, i, i, i, i, i, i, i, i, i, f, vp]
     lib.pscv_geo_filter.restype = i

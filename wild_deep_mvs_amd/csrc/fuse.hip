@@ -114,7 +114,39 @@ __global__ __launch_bounds__(256) void fuse_pairs_bwd_kernel(const FuseBwdArgs a
     for (int v = 0; v < a.n_src; ++v) a.duncert[v][p] = -w[v] * inv * acc[v];
 }
 
+// second half of a source-view-sharded variance: out = sum2 / N - mean^2 after the cross-rank all-reduce of the partial sums
+template <typename H>
+__global__ __launch_bounds__(256) void variance_finish_kernel(const float* __restrict__ s1, const float* __restrict__ s2, H* __restrict__ out,
+                                                             long nchunk, float invN, float invN2, int cvp) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nchunk) return;
+    const f32x8 a = Elem<float>::load8(s1 + i * 8), b = Elem<float>::load8(s2 + i * 8);
+    f32x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (cvp) { const float m = a.v[j] * invN; o.v[j] = b.v[j] * invN - m * m; }     // net.py:148
+        else o.v[j] = b.v[j] * invN - (a.v[j] * a.v[j]) * invN2;                         // model.py:134
+    }
+    Elem<H>::store8(out + i * 8, o);
+}
+
 }  // namespace pscv
+
+extern "C" int pscv_variance_finish(const float* sums, long n, int n_views, int cost, int dtype, void* out, void* stream) {
+    using namespace pscv;
+    PSCV_CHECK_ARG(sums && out, "pscv_variance_finish: null pointer argument");
+    PSCV_CHECK_ARG(n > 0 && n % 8 == 0 && n_views >= 2, "pscv_variance_finish: bad sizes");
+    PSCV_CHECK_ARG(cost == PSCV_COST_VARIANCE || cost == PSCV_COST_VARIANCE_CVP, "pscv_variance_finish: cost %d must be VARIANCE or VARIANCE_CVP", cost);
+    PSCV_CHECK_ARG(dtype == PSCV_BF16 || dtype == PSCV_F16, "pscv_variance_finish: dtype %d must be bf16 or fp16", dtype);
+    const long nchunk = n / 8;
+    const unsigned nblk = (unsigned)((nchunk + 255) / 256);
+    const float invN = 1.0f / (float)n_views, invN2 = 1.0f / ((float)n_views * (float)n_views);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == PSCV_BF16) hipLaunchKernelGGL(variance_finish_kernel<bf16_t>, dim3(nblk), dim3(256), 0, st, sums, sums + n, reinterpret_cast<bf16_t*>(out), nchunk, invN, invN2, cost == PSCV_COST_VARIANCE_CVP);
+    else hipLaunchKernelGGL(variance_finish_kernel<f16_t>, dim3(nblk), dim3(256), 0, st, sums, sums + n, reinterpret_cast<f16_t*>(out), nchunk, invN, invN2, cost == PSCV_COST_VARIANCE_CVP);
+    PSCV_CHECK_LAUNCH("pscv_variance_finish");
+    return 0;
+}
 
 extern "C" int pscv_fuse_pairs_bwd(const void* const* interm, const float* const* uncert, int n_src, int dtype, const void* grad_fused,
                                    void* const* dinterm, float* const* duncert, int B, int D, int h, int w, void* stream) {

@@ -96,7 +96,10 @@ __global__ __launch_bounds__(256, 4) void warp_cost_kernel(const WarpArgs a) {
 
     const TIn* ref = reinterpret_cast<const TIn*>(a.ref);
     VecF<CPL> rf;
-    if (COST != PSCV_COST_WARP_ONLY) {
+    if (COST == PSCV_COST_VARIANCE_PARTIAL && !a.ref) {
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) rf.v[j] = 0.0f;
+    } else if (COST != PSCV_COST_WARP_ONLY) {
         rf = load_chan<TIn, CPL>(ref + pix * C + choff);
     }
 
@@ -119,9 +122,9 @@ __global__ __launch_bounds__(256, 4) void warp_cost_kernel(const WarpArgs a) {
 
         VecF<CPL> acc0, acc1;   // variance: sum, sum of squares; softmin: sum e*diff
         float sum_e = 0.0f;
-        if (COST == PSCV_COST_VARIANCE || COST == PSCV_COST_VARIANCE_CVP) {
+        if (COST == PSCV_COST_VARIANCE || COST == PSCV_COST_VARIANCE_CVP || COST == PSCV_COST_VARIANCE_PARTIAL) {
 #pragma unroll
-            for (int j = 0; j < CPL; ++j) { acc0.v[j] = rf.v[j]; acc1.v[j] = rf.v[j] * rf.v[j]; }
+            for (int j = 0; j < CPL; ++j) { acc0.v[j] = rf.v[j]; acc1.v[j] = rf.v[j] * rf.v[j]; }   // (rf = 0 without a reference)
         } else {
 #pragma unroll
             for (int j = 0; j < CPL; ++j) { acc0.v[j] = 0.0f; acc1.v[j] = 0.0f; }
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(256, 4) void warp_cost_kernel(const WarpArgs a) {
                 make_taps<false, PIXB>(fx, fy, x0, y0, a.hs, a.ws, chb, taps);
                 wv = blend_taps<TIn, CPL, false, PIXB>(img, taps);
             }
-            if (COST == PSCV_COST_VARIANCE || COST == PSCV_COST_VARIANCE_CVP) {
+            if (COST == PSCV_COST_VARIANCE || COST == PSCV_COST_VARIANCE_CVP || COST == PSCV_COST_VARIANCE_PARTIAL) {
 #pragma unroll
                 for (int j = 0; j < CPL; ++j) {
                     acc0.v[j] += wv.v[j];
@@ -221,6 +224,11 @@ __global__ __launch_bounds__(256, 4) void warp_cost_kernel(const WarpArgs a) {
                 o.v[j] = acc1.v[j] * invN - m * m;
             }
             if (active) store_chan<TOut, CPL>(out + vox * C + choff, o);
+        } else if (COST == PSCV_COST_VARIANCE_PARTIAL) {
+            if (active) {
+                store_chan<TOut, CPL>(out + vox * C + choff, acc0);
+                store_chan<TOut, CPL>(out + a.out_view_stride + vox * C + choff, acc1);
+            }
         } else if (COST == PSCV_COST_SOFTMIN) {
             VecF<CPL> o;
             const float inv = 1.0f / (sum_e + 1e-6f);
@@ -273,6 +281,10 @@ static int launch_cost(const WarpArgs& a, int cost, int nblk, hipStream_t st) {
             PSCV_LAUNCH_COST(PSCV_COST_VARIANCE_CVP)
             PSCV_LAUNCH_COST(PSCV_COST_SOFTMIN)
             PSCV_LAUNCH_COST(PSCV_COST_WARP_ONLY)
+            case PSCV_COST_VARIANCE_PARTIAL:
+                if constexpr (sizeof(TOut) == 4)
+                    return launch_one(warp_cost_kernel<TIn, TOut, C, LPV, GEOM, PSCV_COST_VARIANCE_PARTIAL>, a, nblk, ray_bytes, st);
+                break;
         }
     } else {
         switch (cost) {
@@ -347,7 +359,8 @@ extern "C" int pscv_warp_cost(const void* ref, const void* const* srcs, int n_sr
     using namespace pscv;
     PSCV_CHECK_ARG(n_src >= 1 && n_src <= PSCV_MAX_SRC, "pscv_warp_cost: n_src=%d outside [1,%d]", n_src, PSCV_MAX_SRC);
     PSCV_CHECK_ARG(srcs && cams && depth && out, "pscv_warp_cost: null pointer argument");
-    PSCV_CHECK_ARG(cost == PSCV_COST_WARP_ONLY || ref, "pscv_warp_cost: ref is required for cost mode %d", cost);
+    PSCV_CHECK_ARG(cost == PSCV_COST_WARP_ONLY || cost == PSCV_COST_VARIANCE_PARTIAL || ref, "pscv_warp_cost: ref is required for cost mode %d", cost);
+    PSCV_CHECK_ARG(cost != PSCV_COST_VARIANCE_PARTIAL || out_dtype == PSCV_F32, "pscv_warp_cost: partial sums are written in fp32");
     PSCV_CHECK_ARG(B > 0 && h > 0 && w > 0 && hs > 1 && ws > 1 && D > 0, "pscv_warp_cost: bad sizes");
     PSCV_CHECK_ARG(C % 8 == 0, "pscv_warp_cost: C=%d must be a multiple of 8", C);
     // taps are addressed with 24-bit texel indices and 32-bit byte offsets inside one source image
@@ -364,7 +377,7 @@ extern "C" int pscv_warp_cost(const void* ref, const void* const* srcs, int n_sr
     a.depth_per_pixel = depth_per_pixel;
     a.temp = temp;
     const long vol = (long)B * D * h * w;
-    a.out_view_stride = cost == PSCV_COST_GROUPCORR ? vol * (C / 4) : vol * C;
+    a.out_view_stride = cost == PSCV_COST_GROUPCORR ? vol * (C / 4) : vol * C;   // (PARTIAL: offset of the sum-of-squares half)
     if (geom == PSCV_GEOM_PROJ) {
         // grid = u/((W-1)/2) - 1 clamped to +-10, index = (grid+1)/2*(W-1)  ->  index = u clamped to
         // [-4.5 (W-1), 5.5 (W-1)]                                            module.py:151-155
@@ -379,7 +392,7 @@ extern "C" int pscv_warp_cost(const void* ref, const void* const* srcs, int n_sr
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int rc;
-    if (g_warp_tiled && g_warp_lpv_override == 0) {
+    if (g_warp_tiled && g_warp_lpv_override == 0 && cost != PSCV_COST_VARIANCE_PARTIAL) {
         rc = warp_cost_tiled_try(a, C, geom, cost, in_dtype, out_dtype, g_warp_ppd_override, st);
         if (rc < 0) return rc;
         if (rc == 0) {

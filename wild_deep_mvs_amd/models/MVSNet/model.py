@@ -185,6 +185,12 @@ class MVSNet(nn.Module):
         # BatchNorm kernels with 16-bit stored activations: a mixed-precision speed mode, eight more 16-bit roundings in front
         # of the sweep -- depth moves by ~2e-3 (fp16) / ~2e-2 (bf16) relative on the training fixtures)
         self.feature_engine_train = "torch"
+        # source-view shard: with a torch.distributed group set here (``set_view_group``), rank r warps
+        # source views r, r+G, ... only and contributes fp32 partial sums (sum f, sum f^2; rank 0 adds the reference view);
+        # one all-reduce (RCCL) and pscv_variance_finish give every rank the full cost volume.  The reference has no
+        # counterpart.  (At the headline size the all-reduce of 2 x 503 MB costs more than warping all views locally --
+        # DESIGN.md section 7 -- it pays off only when the per-view work dominates: many views, large maps.)
+        self.view_group = None
 
     # -- upstream ---------------------------------------------------------------------------
     def extract_features(self, imgs: Sequence[torch.Tensor]) -> List[torch.Tensor]:
@@ -206,12 +212,33 @@ class MVSNet(nn.Module):
             return [self.feature.forward_engine(img, self.storage_dtype) for img in imgs]
         return [ops.to_channels_last(f, self.storage_dtype) for f in self.extract_features(imgs)]
 
+    def set_view_group(self, group):
+        """Shard the source views of the variance cost volume over a torch.distributed group (None = no sharding)."""
+        self.view_group = group
+
+    def _sharded_variance(self, ref_feature, src_features, cams, depth_values):
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(self.view_group), dist.get_rank(self.view_group)
+        mine = [i for i in range(len(src_features)) if i % world == rank]
+        B, h, w, C = ref_feature.shape
+        if mine:
+            sums = ops.warp_cost(ref_feature if rank == 0 else None, [src_features[i] for i in mine], cams[mine].contiguous(),
+                                 depth_values, geom=L.GEOM_PROJ, cost=L.COST_VARIANCE_PARTIAL, ref_hw=(h, w))
+        else:   # more ranks than source views: this rank only joins the collective
+            sums = torch.zeros((2, B, depth_values.shape[1], h, w, C), dtype=torch.float32, device=ref_feature.device)
+        dist.all_reduce(sums, group=self.view_group)
+        return ops.variance_finish(sums, len(src_features) + 1, cost=L.COST_VARIANCE, dtype=ref_feature.dtype)
+
     # -- hot path ---------------------------------------------------------------------------
     def build_cost_volume(self, ref_feature, src_features, ref_proj, src_projs, depth_values, cams=None):
         """Channels-last features [B,h,w,32] + [B,4,4] projections + planes [B,D] (or [B,D,h,w])
         -> channels-last cost volume [B,D,h,w,32] in one fused launch (reference model.py:109-176)."""
         if cams is None:
             cams = ops.proj_cams_device(torch.stack([ref_proj] + list(src_projs), dim=1).to(torch.float32).contiguous(), 0)
+        if self.view_group is not None:
+            if self.aggregation != "variance":
+                raise NotImplementedError("pscv MVSNet: the source-view shard reduces variance sums; soft-min weights need all views")
+            return self._sharded_variance(ref_feature, list(src_features), cams, depth_values)
         if self.aggregation == "variance":
             return ops.warp_cost(ref_feature, src_features, cams, depth_values, geom=L.GEOM_PROJ,
                                  cost=L.COST_VARIANCE, out_dtype=ref_feature.dtype)

@@ -393,6 +393,8 @@ def warp_cost(ref: Optional[torch.Tensor], srcs: Sequence[torch.Tensor], cams: t
         shape = (n, B, D, h, w, Cc // 4)
     elif cost == L.COST_WARP_ONLY:
         shape = (n, B, D, h, w, Cc)
+    elif cost == L.COST_VARIANCE_PARTIAL:
+        shape, out_dtype = (2, B, D, h, w, Cc), torch.float32     # (sum f, sum f^2) over the given views
     else:
         shape = (B, D, h, w, Cc)
     if out is None:
@@ -404,6 +406,19 @@ def warp_cost(ref: Optional[torch.Tensor], srcs: Sequence[torch.Tensor], cams: t
         _p(ref), ptrs, n, _p(cams), _p(depth), bstride, int(per_pixel), geom, cost, float(temp), _p(out), B, Cc, h, w,
         hs, ws, D, _dt(srcs[0]), _dt(out), _stream()))
     L.check(rc, "pscv_warp_cost")
+    return out
+
+
+def variance_finish(sums: torch.Tensor, n_views: int, *, cost: int = L.COST_VARIANCE, dtype: torch.dtype = torch.float16) -> torch.Tensor:
+    """(all-reduced) partial sums fp32 [2,B,D,h,w,C] of ``warp_cost(cost=COST_VARIANCE_PARTIAL)`` -> variance volume
+    [B,D,h,w,C] in ``dtype`` (pscv_variance_finish)."""
+    _dev(sums)
+    if sums.dtype != torch.float32 or sums.dim() != 6 or sums.shape[0] != 2 or not sums.is_contiguous():
+        raise ValueError("pscv.variance_finish: fp32 [2,B,D,h,w,C] partial sums expected")
+    out = torch.empty(tuple(sums.shape[1:]), dtype=dtype, device=sums.device)
+    rc = _launch("variance_finish", lambda: L.lib().pscv_variance_finish(_p(sums), out.numel(), int(n_views), cost, _TORCH2PSCV[dtype],
+                                                                        _p(out), _stream()))
+    L.check(rc, "pscv_variance_finish")
     return out
 
 
