@@ -45,7 +45,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", type=int, default=0)
     ap.add_argument("--reps", type=int, default=3)
-    ap.add_argument("--feature-engine", default="", help="pscv | torch: 2-D extractor of MVSNet / CVP (default: the model's)")
+    ap.add_argument("--feature-engine", default="", help="pscv | torch: 2-D extractor (default: the model's)")
+    ap.add_argument("--graph", action="store_true", help="also time hipGraph replay of the forward (wild_deep_mvs_amd.graph.GraphedModel)")
     args = ap.parse_args()
     for cid, cfg in CONFIGS.items():
         if args.only and cid != args.only:
@@ -70,11 +71,31 @@ def main():
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / args.reps
         gc.enable()
+        dt_graph = None
+        if args.graph:
+            from wild_deep_mvs_amd.graph import GraphedModel
+            try:
+                gnet = GraphedModel(net)
+                gcall = lambda: gnet(dev["imgs"], dev["K"], dev["R"], dev["t"], dev["depth_min"], dev["depth_max"], **cfg["kw"])
+                gcall(); gcall()
+                torch.cuda.synchronize()
+                gc.disable()
+                t0 = time.perf_counter()
+                for _ in range(args.reps):
+                    gcall()
+                torch.cuda.synchronize()
+                dt_graph = (time.perf_counter() - t0) / args.reps
+                gc.enable()
+                del gnet
+            except Exception as e:   # e.g. MVSNet-s reads its temperature on the host (a sync inside the capture)
+                print(f"   (config {cid}: hipGraph capture not possible: {type(e).__name__}: {str(e)[:120]})")
+                gc.enable()
         d = out["depth"]
         ok = bool(torch.isfinite(d).all()) and bool(torch.isfinite(out["photometric_confidence"]).all())
         print(f"config {cid} {cfg['arch']:8s} V={cfg['V']} {cfg['H']}x{cfg['W']}: {dt * 1e3:8.2f} ms / forward (with 2-D features), "
               f"{cfg['vox']() / dt / 1e9:6.3f} G cost-volume voxels/s, depth {tuple(d.shape)} range {float(d.min()):.3f}..{float(d.max()):.3f}, "
-              f"finite={ok}, peak mem {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB", flush=True)
+              f"finite={ok}, peak mem {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB"
+              + (f", hipGraph replay {dt_graph * 1e3:.2f} ms" if dt_graph is not None else ""), flush=True)
         del net, out
         torch.cuda.empty_cache()
         torch.cuda.reset_peak_memory_stats()

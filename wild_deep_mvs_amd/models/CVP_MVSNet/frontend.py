@@ -37,14 +37,18 @@ class Frontend(nn.Module):
     def forward(self, imgs, K, R, t, depth_min, depth_max, reference_frame=0, **kwargs):
         src_idx = [i for i in range(K.shape[1]) if i != reference_frame]
         if isinstance(imgs, torch.Tensor):
-            ref_img, src_imgs = imgs[:, reference_frame], list(torch.unbind(imgs[:, src_idx], dim=1))
+            ref_img, src_imgs = imgs[:, reference_frame], [imgs[:, i] for i in src_idx]
         else:
             ref_img, src_imgs = imgs[reference_frame], [imgs[i] for i in src_idx]
         b, n = ref_img.shape[0], len(src_imgs)
-        row = torch.tensor([0., 0., 0., 1.], device=K.device)
+        # (0,0,0,1) built on the device: a host list / scalar assignment is a synchronous copy, which a hipGraph capture of the
+        # forward does not permit
+        row = (torch.arange(4, device=K.device) == 3).to(K.dtype)
         ref_ex = torch.cat((torch.cat((R[:, reference_frame], t[:, reference_frame]), dim=2), row.view(1, 1, 4).expand(b, 1, 4)), dim=1)
-        src_ex = torch.cat((torch.cat((R[:, src_idx], t[:, src_idx]), dim=3), row.view(1, 1, 1, 4).expand(b, n, 1, 4)), dim=2)
-        out = self.model(ref_img, src_imgs, K[:, reference_frame], K[:, src_idx], ref_ex, src_ex,
+        # (views are picked with python slices, not index lists: an index list is a host tensor, i.e. a synchronous copy)
+        pick = lambda x: torch.stack([x[:, i] for i in src_idx], dim=1)
+        src_ex = torch.cat((torch.cat((pick(R), pick(t)), dim=3), row.view(1, 1, 1, 4).expand(b, n, 1, 4)), dim=2)
+        out = self.model(ref_img, src_imgs, K[:, reference_frame], pick(K), ref_ex, src_ex,
                          depth_min[:, reference_frame], depth_max[:, reference_frame], **kwargs)
         return {"depth": out["depth_est_list"][0], "depth_est_list": out["depth_est_list"], "depth_pair_list": [],
                 "photometric_confidence": out["prob_confidence"].unsqueeze(1)}

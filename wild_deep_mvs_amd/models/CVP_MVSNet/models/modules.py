@@ -86,9 +86,14 @@ def calDepthHypo(ref_depths, ref_intrinsics, src_intrinsics, ref_extrinsics, src
     ref_depths [B,H,W]; src_intrinsics [B,N,3,3]; src_extrinsics [B,N,4,4] -> [B,8,H,W] fp32."""
     Ki, Ks = ref_intrinsics.double(), src_intrinsics[:, 0].double()
     Ei, Es = ref_extrinsics.double(), src_extrinsics[:, 0].double()
-    to_src = Es @ torch.linalg.inv(Ei)                                                       # [B,4,4]
-    A = (Ki @ Ei[:, :3, :3]) @ torch.linalg.inv(Ks @ Es[:, :3, :3])
-    cams = torch.cat((torch.linalg.inv(Ki).reshape(-1, 9), to_src[:, :3, :].reshape(-1, 12), Ks.reshape(-1, 9), A.reshape(-1, 9)),
+    # closed-form fp64 inverses (adjugate of the 3x3 blocks; extrinsics have the last row (0,0,0,1)): no LAPACK call, so the
+    # whole forward stays capturable in a hipGraph
+    Ri_inv = ops.inv3x3(Ei[:, :3, :3])
+    Ei_inv = torch.zeros_like(Ei)
+    Ei_inv[:, :3, :3], Ei_inv[:, :3, 3:4], Ei_inv[:, 3, 3] = Ri_inv, -(Ri_inv @ Ei[:, :3, 3:4]), 1.0
+    to_src = Es @ Ei_inv                                                                     # [B,4,4]
+    A = (Ki @ Ei[:, :3, :3]) @ ops.inv3x3(Ks @ Es[:, :3, :3])
+    cams = torch.cat((ops.inv3x3(Ki).reshape(-1, 9), to_src[:, :3, :].reshape(-1, 12), Ks.reshape(-1, 9), A.reshape(-1, 9)),
                      dim=1).contiguous()
     fallback = ((depth_max - depth_min) / 128).to(torch.float32).reshape(-1).contiguous()
     return ops.cvp_depth_hypos(ref_depths.to(torch.float32).contiguous(), cams, fallback)

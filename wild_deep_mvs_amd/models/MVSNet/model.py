@@ -242,8 +242,13 @@ class MVSNet(nn.Module):
         if self.aggregation == "variance":
             return ops.warp_cost(ref_feature, src_features, cams, depth_values, geom=L.GEOM_PROJ,
                                  cost=L.COST_VARIANCE, out_dtype=ref_feature.dtype)
+        # the kernel takes the temperature by value: read it back once per parameter version (no host sync in steady state,
+        # and none inside a hipGraph capture of the forward)
+        key = (self.temp.data_ptr(), self.temp._version)
+        if getattr(self, "_temp_key", None) != key:
+            self._temp_val, self._temp_key = float(self.temp.detach().float().item()), key
         return ops.warp_cost(ref_feature, src_features, cams, depth_values, geom=L.GEOM_PROJ, cost=L.COST_SOFTMIN,
-                             temp=float(self.temp.detach().float().item()), out_dtype=ref_feature.dtype)
+                             temp=self._temp_val, out_dtype=ref_feature.dtype)
 
     def hot_path(self, features_cl: Sequence[torch.Tensor], proj: torch.Tensor, depth_values: torch.Tensor,
                  reference_frame: int = 0, taps: Optional[dict] = None):
