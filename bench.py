@@ -40,17 +40,20 @@ def algorithmic_bytes(name: str) -> float:
     """Algorithmic HBM bytes of one launch at the headline size."""
     if name.startswith("warp_cost"):
         return V * C * h * w * 2 + C * VOX * 2                      # read V feature maps + write the volume once
-    if name.startswith("conv3d[32->8,k0]"):
+    if name.startswith("conv3d[32->8,k"):
         return C * VOX * 2 + 8 * VOX * 2                            # read 32-ch volume, write 8-ch volume
-    if name.startswith("conv3d[16->8,k2]"):
+    if name.startswith("conv3d[16->8,k"):
         return 16 * (VOX // 8) * 2 + 2 * 8 * VOX * 2                # read half-res 16ch + skip, write 8ch
-    if name.startswith("conv3d[8->1,k0]"):
+    if name.startswith("conv3d[8->1,k"):
         return 8 * VOX * 2 + VOX * 4
     if name.startswith("conv3d[8->16,k1]"):
         return 8 * VOX * 2 + 16 * (VOX // 8) * 2
     if name.startswith("softargmin"):
         return VOX * 4 + 2 * h * w * 4
     return 0.0
+
+
+MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 / fp16 MFMA peak of one MI355X (MI355X_MICROARCH.md)
 
 
 DTYPES = {"f16": torch.float16, "bf16": torch.bfloat16}
@@ -198,6 +201,18 @@ def main():
                 "unit": "GB/s", "frac": (ab / avg_s / 1e9 / HBM_PEAK_GBS) if ab else None,
                 "traffic": pmc_traffic(name) if args.dtype == "f16" else None,
                 "avg_us": avg_s * 1e6, "algorithmic_bytes": ab, "share_of_gpu_time": ms / total_ms}
+        # the matrix-core side of the path (north_star: "MFMA utilisation on the 3D conv against gfx950 peak"): the layer with
+        # 68 % of the regulariser's FLOPs, conv0 32 -> 8 at full resolution (2 * 27 * 32 * 8 FLOP per voxel).  Per layer it is
+        # HBM-bound at these channel counts (arithmetic intensity 173 FLOP/B < ridge), so both fractions are given.
+        roof_mfma = None
+        c0 = [k for k in kern if k.startswith("conv3d[32->8,k")]
+        if c0:
+            n0, ms0 = kern[c0[0]]
+            t0s = ms0 / n0 * 1e-3
+            fl = 2.0 * 27 * 32 * 8 * VOX
+            roof_mfma = {"kernel": c0[0], "bound": "mfma", "achieved": fl / t0s / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": fl / t0s / 1e12 / MFMA_PEAK_TFLOPS, "avg_us": t0s * 1e6, "flops": fl,
+                         "hbm_frac": algorithmic_bytes(c0[0]) / t0s / 1e9 / HBM_PEAK_GBS}
         line = {
             "metric": "cost-volume voxels/sec (BxDxHxW), MVSNet hot path", "value": world * VOX * args.steps / elapsed,
             "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -210,6 +225,7 @@ def main():
                       f"; per-kernel HIP events from an eager pass of the same {args.steps} steps "
                       f"({elapsed_eager / args.steps * 1e3:.3f} ms/step eager)",
             "roofline": roof,
+            "roofline_mfma": roof_mfma,
             "kernels_us": {k: round(ms / n * 1e3, 2) for k, (n, ms) in sorted(kern.items(), key=lambda kv: -kv[1][1])},
         }
         if world == 1 and not args.no_cpu_baseline:
