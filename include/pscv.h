@@ -265,6 +265,14 @@ int pscv_softargmin(const void* logits, int logit_dtype, const float* depth, lon
                     float* out_depth, float* out_index, float* out_conf, float* out_entropy, float* out_prob,
                     float* out_partials, int conf_mode, float window, int index_offset, int B, int D, int h, int w,
                     void* stream);
+/*
+ * Depth-plane shard across GPUs, last step of the window probability (Vis soft_argmin(window=), nn_utils.py:464-465): this
+ * shard's part of sum_{|d - E[index]| <= window} p_d under the GLOBALLY merged softmax.  logits fp32 [B,D,h,w] = the shard's
+ * planes (global index = d + index_offset), stats fp32 [B,3,h,w] = (global max, global sum of exp, global expected index) from
+ * the merged out_partials; out fp32 [B,h,w]; the shards' outputs are summed by one all-reduce.
+ */
+int pscv_softargmin_window(const float* logits, const float* stats, float* out, float window, int index_offset, int B, int D,
+                           int h, int w, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Training path: what loss.backward() needs from the hot path when train.py drives the model

@@ -31,7 +31,7 @@ EXPORTS = ("pscv_last_error", "pscv_abi_version", "pscv_set_tuning", "pscv_proj_
            "pscv_fuse_pairs", "pscv_fuse_finish", "pscv_geo_filter", "pscv_pack_conv2d_weights", "pscv_conv2d",
            "pscv_pack_conv3d_weights", "pscv_conv3d", "pscv_softargmin", "pscv_train_workspace_floats", "pscv_bn_stats",
            "pscv_bn_act", "pscv_bn_bwd_reduce", "pscv_bn_bwd_apply", "pscv_softargmin_bwd", "pscv_conv3d_wgrad_workspace",
-           "pscv_conv3d_wgrad", "pscv_warp_cost_bwd", "pscv_cvp_depth_hypos", "pscv_relu_bwd", "pscv_fuse_pairs_bwd", "pscv_pack_conv3d_weights_device", "pscv_conv2d_ex", "pscv_variance_finish")
+           "pscv_conv3d_wgrad", "pscv_warp_cost_bwd", "pscv_cvp_depth_hypos", "pscv_relu_bwd", "pscv_fuse_pairs_bwd", "pscv_pack_conv3d_weights_device", "pscv_conv2d_ex", "pscv_variance_finish", "pscv_softargmin_window")
 
 
 class PscvMissingError(RuntimeError):
@@ -78,6 +78,8 @@ def _declare(lib):
     lib.pscv_pack_conv2d_weights.argtypes = [vp, i, i, i, i, i, vp]
     lib.pscv_conv2d.restype = i
     lib.pscv_conv2d.argtypes = [vp, i, vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, vp]
+    lib.pscv_softargmin_window.restype = i
+    lib.pscv_softargmin_window.argtypes = [vp, vp, vp, f, i, i, i, i, i, vp]
     lib.pscv_variance_finish.restype = i
     lib.pscv_variance_finish.argtypes = [vp, l, i, i, i, vp, vp]
     lib.pscv_conv2d_ex.restype = i

@@ -144,7 +144,38 @@ __global__ __launch_bounds__(256) void softargmin_kernel(const SoftArgs a) {
     }
 }
 
+// Window probability of ONE depth shard under the globally merged softmax statistics (depth-plane shard across GPUs):
+//     out[pix] = sum over this shard's planes d with |d + index_offset - E[index]| <= window of exp(l_d - M) / Z
+// stats [B,3,h,w] = (global max M, global sum Z, global expected index); the shards' outputs are summed by an all-reduce.
+__global__ __launch_bounds__(256) void softargmin_window_kernel(const float* __restrict__ logits, const float* __restrict__ stats,
+                                                                float* __restrict__ out, float window, int index_offset, int B, int D,
+                                                                long hw) {
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= (long)B * hw) return;
+    const int b = (int)(p / hw);
+    const long pf = p - (long)b * hw;
+    const float* sp = stats + (long)b * 3 * hw + pf;
+    const float M = sp[0], inv = 1.0f / sp[hw], eidx = sp[2 * hw];
+    const float* lp = logits + (long)b * D * hw + pf;
+    float c = 0.f;
+    for (int d = 0; d < D; ++d)
+        if (fabsf((float)(d + index_offset) - eidx) <= window) c += expf(lp[(long)d * hw] - M) * inv;
+    out[p] = c;
+}
+
 }  // namespace pscv
+
+extern "C" int pscv_softargmin_window(const float* logits, const float* stats, float* out, float window, int index_offset, int B,
+                                      int D, int h, int w, void* stream) {
+    using namespace pscv;
+    PSCV_CHECK_ARG(logits && stats && out, "pscv_softargmin_window: null pointer argument");
+    PSCV_CHECK_ARG(B > 0 && D > 0 && h > 0 && w > 0, "pscv_softargmin_window: bad sizes");
+    const long npix = (long)B * h * w;
+    hipLaunchKernelGGL(softargmin_window_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       logits, stats, out, window, index_offset, B, D, (long)h * w);
+    PSCV_CHECK_LAUNCH("pscv_softargmin_window");
+    return 0;
+}
 
 extern "C" int pscv_softargmin(const void* logits, int logit_dtype, const float* depth, long depth_bstride,
                                int depth_per_pixel, float* out_depth, float* out_index, float* out_conf,

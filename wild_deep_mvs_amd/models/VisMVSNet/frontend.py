@@ -39,6 +39,11 @@ class Frontend(nn.Module):
         for st in (self.model.stage1, self.model.stage2, self.model.stage3):
             st.view_group = group
 
+    def set_depth_group(self, group):
+        """Shard the depth planes of every stage over a torch.distributed group (None = no sharding)."""
+        for st in (self.model.stage1, self.model.stage2, self.model.stage3):
+            st.depth_group = group
+
     def fill_cam_array(self, K, R, t, start_depth, depth_interval):
         b = K.shape[0]
         cam = torch.zeros((b, 2, 4, 4), device=K.device)

@@ -221,6 +221,10 @@ class SingleStage(nn.Module):
         # regularises source views r, r+G, ... only; the visibility-weighted sums are all-reduced (RCCL) and every rank
         # then runs RegFuse on the same fused volume.  The reference has no counterpart (it loops over all views).
         self.view_group = None
+        # depth-plane shard: with a group set here, rank r sweeps, regularises and fuses only
+        # the planes it owns plus a 16-plane halo per side (the pair U-Net + head and the fuse U-Net + head each reach 8
+        # planes), and the softmax over D is merged from per-rank partials.  The reference has no counterpart.
+        self.depth_group = None
 
     def build_cost_volume(self, ref, ref_cam, srcs, srcs_cam, depth_num, depth_start, depth_interval, s_scale):
         """Pair-wise group-correlation volumes of ALL source views in one fused launch: [n_src,n,d,h,w,8]
@@ -267,6 +271,54 @@ class SingleStage(nn.Module):
         est_depth = idx.unsqueeze(1) * depth_interval + depth_start                      # model_cas.py:404-405
         return est_depth, conf.unsqueeze(1), pair_results
 
+    DEPTH_HALO = 16   # planes of redundant compute per side: 8 (pair U-Net + head) + 8 (fuse U-Net + head)
+
+    def forward_depth_shard(self, ref_feat, ref_cam, srcs_feat, srcs_cam, depth_num, depth_start, depth_interval, s_scale):
+        """Eval-mode stage with the depth planes sharded over ``self.depth_group``.  Per rank: warp + group correlation,
+        pair U-Nets, fusion and fuse U-Net on the owned planes [a, b) extended by the halo (no communication: the halo is
+        recomputed, and values more than 8 planes inside an artificial boundary equal the unsharded ones exactly); the
+        softmax statistics come from log-sum-exp partials of the OWNED planes -- (max, sum e, sum e*logit, sum e*index): one
+        small all-gather per head -- and the +-2 window probability from one more all-reduce of a [n,h,w] map."""
+        import torch.distributed as dist
+        from ... import dist as pdist
+        grp = self.depth_group
+        world, rank = dist.get_world_size(grp), dist.get_rank(grp)
+        a, b = pdist.plane_shard(depth_num, world, rank, multiple=2)
+        ea, eb = max(0, a - self.DEPTH_HALO), min(depth_num, b + self.DEPTH_HALO)
+        costs = self.build_cost_volume(ref_feat, ref_cam, srcs_feat, srcs_cam, eb - ea, depth_start + depth_interval * ea,
+                                       depth_interval, s_scale)
+
+        def merged(score_ext, window=None):
+            own = score_ext[:, a - ea:b - ea].contiguous()
+            part = ops.softargmin(own, own, want_partials=True, index_offset=a)["partials"]     # "depth" := the logits
+            bufs = [torch.empty_like(part) for _ in range(world)]
+            dist.all_gather(bufs, part, group=grp)
+            st = torch.stack(bufs)                                                          # [world,n,4,h,w]
+            m = st[:, :, 0].max(dim=0).values
+            f = torch.exp(st[:, :, 0] - m.unsqueeze(0))
+            Z, sl, si = (st[:, :, 1] * f).sum(0), (st[:, :, 2] * f).sum(0), (st[:, :, 3] * f).sum(0)
+            idx = si / Z
+            entropy = m + torch.log(Z) - sl / Z               # -sum p log p = log-sum-exp - E[logit]
+            conf = None
+            if window is not None:
+                conf = ops.softargmin_window(own, torch.stack([m, Z, idx], dim=1).contiguous(), window=window, index_offset=a)
+                dist.all_reduce(conf, group=grp)
+            return idx, entropy, conf
+
+        interms, uncerts, pair_results = [], [], []
+        for i in range(len(srcs_feat)):
+            interm = self.reg(costs[i])
+            idx, ent, _ = merged(self.reg_pair(interm))
+            est_depth = idx.unsqueeze(1) * depth_interval + depth_start
+            heads = self.uncert_net(ent.unsqueeze(1))
+            pair_results.append([est_depth, heads])
+            interms.append(interm)
+            uncerts.append(heads[0].squeeze(1).to(torch.float32).contiguous())
+        fused = ops.fuse_pairs(interms, uncerts)
+        idx, _, conf = merged(self.reg_fuse(fused), window=2.0)
+        est_depth = idx.unsqueeze(1) * depth_interval + depth_start
+        return est_depth, conf.unsqueeze(1), pair_results
+
     def forward(self, sample, depth_num, upsample=False, mem=False, mode='soft', depth_start_override=None,
                 depth_interval_override=None, s_scale=1, taps: Optional[dict] = None):
         if mem or mode != 'soft' or upsample:
@@ -277,6 +329,10 @@ class SingleStage(nn.Module):
         depth_interval = ref_cam[:, 1:2, 3:4, 1:2] if depth_interval_override is None else depth_interval_override
         if self.training:
             return self.forward_train(ref_feat, ref_cam, srcs_feat, srcs_cam, depth_num, depth_start, depth_interval, s_scale)
+        if self.depth_group is not None:
+            if self.view_group is not None:
+                raise NotImplementedError("pscv Vis-MVSNet: choose the depth-plane shard or the source-view shard, not both")
+            return self.forward_depth_shard(ref_feat, ref_cam, srcs_feat, srcs_cam, depth_num, depth_start, depth_interval, s_scale)
         n_views = len(srcs_feat)
         world, rank = 1, 0
         if self.view_group is not None:

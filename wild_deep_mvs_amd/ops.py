@@ -583,6 +583,20 @@ def softargmin(logits: torch.Tensor, depth: Optional[torch.Tensor] = None, *, wa
     return {k: v for k, v in o.items() if v is not None}
 
 
+def softargmin_window(logits: torch.Tensor, stats: torch.Tensor, *, window: float, index_offset: int) -> torch.Tensor:
+    """One depth shard's part of the +-window probability under globally merged softmax statistics: logits fp32 [B,D,h,w] (this
+    shard's planes), stats fp32 [B,3,h,w] = (max, sum exp, expected index) -> fp32 [B,h,w] (pscv_softargmin_window)."""
+    _dev(logits, stats)
+    B, D, h, w = logits.shape
+    if logits.dtype != torch.float32 or stats.dtype != torch.float32 or tuple(stats.shape) != (B, 3, h, w):
+        raise ValueError("pscv.softargmin_window: fp32 logits [B,D,h,w] and stats [B,3,h,w] expected")
+    out = torch.empty((B, h, w), dtype=torch.float32, device=logits.device)
+    rc = _launch("softargmin_window", lambda: L.lib().pscv_softargmin_window(_p(logits), _p(stats), _p(out), float(window),
+                                                                            int(index_offset), B, D, h, w, _stream()))
+    L.check(rc, "pscv_softargmin_window")
+    return out
+
+
 # --------------------------------------------------------------------------------------------
 # CVP refinement hypotheses (SURVEY 8f-4)
 # --------------------------------------------------------------------------------------------
