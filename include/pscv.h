@@ -374,6 +374,34 @@ int pscv_warp_cost_bwd(const void* ref, const void* const* srcs, int n_src, cons
 int pscv_cvp_depth_hypos(const float* depth, const double* cams, const float* fallback, unsigned long long* keys,
                          double* steps, float* hypos, int B, int H, int W, void* stream);
 
+/* ---- unsupervised photometric loss (replaces models/trainer.py:209-278 + utils/ssimLoss.py:27-60) ---------
+ *
+ * pscv_photo_warp: depth map -> flows -> warped source images, the body of Trainer.get_flow_from_depthmap /
+ * photometricloss / masked_photometricloss (trainer.py:209-236, 258-266; utils_3D.py:185-208, 243-272):
+ *   P3 = inv_ref (x d, y d, d, 1);  q = proj_src P3;  f = q_xy / max(q_z, 1e-6);  g = 2 f / (size - 1) - 1;
+ *   g = -10 where q_z <= 0; clamp to +-10; sample = grid_sample(bilinear, zeros, align_corners=False) (index g -> ((g+1) size - 1)/2,
+ *   the reference's (size-1)-normalised flows under align_corners=False, reproduced).
+ * src_imgs fp32 [B,S,C,h,w] (may be null with C = 0), depth [B,h,w], inv_ref [B,16] = inverse of the reference view's 4x4
+ * projection, proj_src [B,S,16]; optional src_depth [B,S,h,w].  Outputs, each optional: warped [B,S,C,h,w], mask [B,S,h,w]
+ * (1.0 where |g| < 1 in both axes), z_src [B,S,h,w] (depth in the source view), flows [B,S,h,w,2], warped_depth [B,S,h,w].
+ * pscv_photo_warp_bwd: grad_warped [B,S,C,h,w] -> grad_depth [B,h,w] through the sampling position (no gradient where the
+ * z <= 0 assignment or the clamp cuts the reference's graph); no atomics, deterministic.
+ */
+int pscv_photo_warp(const float* src_imgs, const float* depth, const float* inv_ref, const float* proj_src, const float* src_depth,
+                    float* warped, float* mask, float* z_src, float* flows, float* warped_depth, int B, int S, int C, int h, int w,
+                    void* stream);
+int pscv_photo_warp_bwd(const float* src_imgs, const float* depth, const float* inv_ref, const float* proj_src,
+                        const float* grad_warped, float* grad_depth, int B, int S, int C, int h, int w, void* stream);
+/*
+ * SSIM loss map of utils/ssimLoss.py:27-60: out = 1 - SSIM(img1, img2) per channel, 11x11 Gaussian window (sigma 1.5), zero
+ * padding.  img1 fp32 [n1,C,h,w], img2 [n1*rep,C,h,w] (item n of img2 is compared with item n / rep of img1: the reference
+ * image against its rep warped sources), out [n1*rep,C,h,w].  pscv_ssim_bwd: grad_out -> grad_img2 (img1 is data);
+ * workspace 3 * n1*rep*C*h*w floats.
+ */
+int pscv_ssim(const float* img1, const float* img2, float* out, int n1, int rep, int C, int h, int w, void* stream);
+int pscv_ssim_bwd(const float* img1, const float* img2, const float* grad_out, float* workspace, float* grad_img2, int n1, int rep,
+                  int C, int h, int w, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,7 +12,7 @@ be re-created from ``wild_deep_mvs_amd.synthetic`` (the fixture records the
 generator arguments instead); every stage boundary of the reference's hot path is
 stored as fp32 arrays (tiny problem sizes; per-view warped volumes keep 3 planes).
 
-Usage:  python tests/golden/gen_golden.py [--only mvsnet|mvsnet_s|mvsnet_train|mvsnet_s_train|vis|cvp|filter]
+Usage:  python tests/golden/gen_golden.py [--only mvsnet|mvsnet_s|mvsnet_train|mvsnet_s_train|vis|cvp|filter|photo]
 """
 from __future__ import annotations
 
@@ -446,6 +446,45 @@ def gen_filter(tag: str, *, V=5, H=48, W=64, seed=0, behind_view=-1, half_res_vi
     print({k: float(v.mean()) for k, v in masks.items()})
 
 
+def gen_photo(tag: str, *, B=2, V=3, H=48, W=64, seed=0, behind_view=-1, masked=False, i_ref=0, geom_clamping=0.05):
+    """Unsupervised photometric loss: the reference's own ``Trainer.photometricloss`` / ``masked_photometricloss``
+    (models/trainer.py:221-278) on a ``Trainer`` built without its ``__init__`` (which only adds logging state and a
+    ``.cuda()`` call); for the occlusion-masked variant ``dist.all_gather`` / ``dist.get_rank`` are replaced process-locally by
+    stand-ins that hand over the other views' depth maps.  Stores inputs, the loss map, the mask, the scalar loss of
+    trainer.py:169-174 and its gradient to the depth map."""
+    from argparse import Namespace
+    import torch.distributed as tdist
+    sys.path.insert(0, REPO)
+    from wild_deep_mvs_amd import synthetic
+    from models.trainer import Trainer             # reference
+    from utils.ssimLoss import SSIM                # reference
+    from utils.utils_3D import build_proj_matrices  # reference
+
+    sc = synthetic.make_photo_case(B, V, H, W, seed=seed, behind_view=behind_view)
+    proj = build_proj_matrices(sc["K"].clone(), sc["R"], sc["t"])
+    tr = Trainer.__new__(Trainer)
+    tr.ims, tr.ssim, tr.args = {}, SSIM(), Namespace(geom_clamping=geom_clamping, occ_masking=masked)
+    depth = sc["depths"][i_ref].clone().requires_grad_(True)
+    if masked:
+        saved = (tdist.all_gather, tdist.get_rank)
+        def fake_all_gather(out_list, tensor, **k):
+            for v in range(V):
+                out_list[v] = sc["depths"][v].clone() if v != i_ref else tensor.detach().clone()
+        tdist.all_gather, tdist.get_rank = fake_all_gather, (lambda *a, **k: i_ref)
+        try:
+            ssim, mask = tr.masked_photometricloss(sc["imgs"], depth, proj)
+        finally:
+            tdist.all_gather, tdist.get_rank = saved
+    else:
+        ssim, mask = tr.photometricloss(sc["imgs"], depth, proj)
+    maskf = mask.float()
+    loss = torch.sum(ssim * maskf) / torch.sum(maskf)
+    loss.backward()
+    save(f"{tag}.npz", meta=np.array([B, V, H, W, seed, behind_view, int(masked), i_ref]), geom_clamping=np.float32(geom_clamping),
+         proj=np32(proj), ssim=np32(ssim), mask=np32(maskf), loss=np32(loss), grad_depth=np32(depth.grad))
+    print(tag, "loss", float(loss), "mask mean", float(maskf.mean()), "grad abs mean", float(depth.grad.abs().mean()))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -466,6 +505,8 @@ def main():
         "filter": lambda: (gen_filter("filter_tiny", V=6, behind_view=4, half_res_view=3, near_view=2),
                            gen_filter("filter_upsample", V=4, seed=3, upsample=True, downscale=2, num_consistent=2)),
     }
+    todo["photo"] = lambda: (gen_photo("photo_tiny"), gen_photo("photo_behind", V=4, behind_view=2, seed=3),
+                             gen_photo("photo_masked", V=4, masked=True, i_ref=1, seed=5))
     for k, fn in todo.items():
         if args.only in (None, k):
             fn()

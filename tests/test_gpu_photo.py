@@ -1,0 +1,119 @@
+"""Unsupervised photometric loss on the HIP kernels against the reference's goldens and the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import photometric as P
+from wild_deep_mvs_amd import ops, synthetic
+from wild_deep_mvs_amd.models.trainer import Trainer
+from wild_deep_mvs_amd.utils.ssimLoss import SSIM
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load_case(tag):
+    g = np.load(os.path.join(GOLD, f"{tag}.npz"))
+    B, V, H, W, seed, behind, masked, i_ref = [int(v) for v in g["meta"]]
+    sc = synthetic.make_photo_case(B, V, H, W, seed=seed, behind_view=behind)
+    return g, sc, torch.from_numpy(g["proj"]), bool(masked), i_ref
+
+
+def masked_mean(ssim, mask):
+    mask = mask.float()
+    return torch.sum(ssim * mask) / torch.sum(mask)
+
+
+@pytest.mark.parametrize("tag", ["photo_tiny", "photo_behind"])
+def test_photometricloss_matches_reference_golden(tag):
+    g, sc, proj, _, _ = load_case(tag)
+    tr = Trainer()
+    depth = sc["depths"][0].cuda().requires_grad_(True)
+    ssim, mask = tr.photometricloss(sc["imgs"].cuda(), depth, proj.cuda())
+    loss = masked_mean(ssim, mask)
+    loss.backward()
+    moved = (mask.cpu().numpy() != g["mask"]).mean()
+    err = np.abs(ssim.detach().cpu().numpy() - g["ssim"])
+    rel = np.abs(depth.grad.cpu().numpy() - g["grad_depth"]).sum() / np.abs(g["grad_depth"]).sum()
+    print(f"[parity] {tag}: ssim max abs {err.max():.2e}, mask pixels differing {moved:.2e}, loss {float(loss):.6f} vs "
+          f"{float(g['loss']):.6f}, grad_depth rel-L1 {rel:.2e}", flush=True)
+    assert moved <= 1e-3                        # |g| < 1 is a threshold on an fp32 coordinate
+    assert np.quantile(err, 0.999) <= 1e-4 and abs(float(loss) - float(g["loss"])) <= 1e-5
+    assert rel <= 1e-4
+    assert sorted(tr.ims) == [f"warped{i}" for i in range(1, sc["imgs"].shape[1])]
+
+
+def test_ssim_module_matches_oracle_and_autograd():
+    g = torch.Generator().manual_seed(3)
+    a, b = torch.rand(2, 3, 37, 53, generator=g), torch.rand(6, 3, 37, 53, generator=g)
+    bc = b.clone().requires_grad_(True)
+    want = P.ssim_loss(a.repeat_interleave(3, dim=0), bc)
+    go = torch.rand(want.shape, generator=g)
+    want.backward(go)
+    bg = b.cuda().requires_grad_(True)
+    got = SSIM()(a.cuda(), bg)
+    got.backward(go.cuda())
+    assert (got.detach().cpu() - want.detach()).abs().max().item() <= 2e-5
+    rel = ((bg.grad.cpu() - bc.grad).abs().sum() / bc.grad.abs().sum()).item()
+    print(f"[parity] SSIM: value max abs {(got.detach().cpu() - want.detach()).abs().max().item():.2e}, grad rel-L1 {rel:.2e}", flush=True)
+    assert rel <= 1e-4
+
+
+def test_get_flow_from_depthmap_matches_oracle():
+    g, sc, proj, _, _ = load_case("photo_behind")
+    h, w = sc["depths"].shape[-2:]
+    want_f, want_z = P.get_flow_from_depthmap(sc["depths"][0], proj, (h, w), 0)
+    got_f, got_z = Trainer().get_flow_from_depthmap(sc["depths"][0].cuda(), proj.cuda(), (h, w), 0)
+    assert (got_z.cpu() - want_z).abs().max().item() <= 1e-4
+    assert ((got_f.cpu() - want_f).abs() > 1e-4).float().mean().item() <= 1e-4       # z ~ 0 pixels may flip to -10
+    assert (want_f == -10).float().mean().item() > 0.2
+
+
+def _masked_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from argparse import Namespace
+        g, sc, proj, _, i_ref = load_case("photo_masked")
+        tr = Trainer(args=Namespace(occ_masking=True, geom_clamping=float(g["geom_clamping"])))
+        depth = sc["depths"][rank].cuda().requires_grad_(True)            # rank r predicts view r
+        ssim, mask = tr.loss(sc["imgs"].cuda(), depth, proj.cuda(), None)
+        loss = masked_mean(ssim, mask)
+        loss.backward()
+        q.put((rank, ssim.detach().cpu().numpy(), mask.cpu().numpy(), float(loss), depth.grad.cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_masked_photometricloss_ranks_one_gpu():
+    """Occlusion masking needs one rank per view (rank r's reference view is r): four ranks on one GPU, gloo rendezvous; rank 1
+    is the one the reference golden was generated for."""
+    import torch.multiprocessing as mp
+    import socket
+    def free_port():
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            return s_.getsockname()[1]
+    g, sc, proj, _, i_ref = load_case("photo_masked")
+    world = sc["imgs"].shape[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_masked_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r[0]: r for r in [q.get(timeout=240) for _ in range(world)]}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    _, ssim, mask, loss, grad = res[i_ref]
+    moved = (mask.astype(np.float32) != g["mask"]).mean()
+    rel = np.abs(grad - g["grad_depth"]).sum() / np.abs(g["grad_depth"]).sum()
+    print(f"[parity] photo_masked rank {i_ref}: mask pixels differing {moved:.2e}, loss {loss:.6f} vs {float(g['loss']):.6f}, "
+          f"grad_depth rel-L1 {rel:.2e}", flush=True)
+    assert moved <= 2e-3 and np.quantile(np.abs(ssim - g["ssim"]), 0.999) <= 1e-4
+    assert abs(loss - float(g["loss"])) <= 1e-5 and rel <= 1e-4

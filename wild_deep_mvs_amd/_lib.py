@@ -31,7 +31,8 @@ EXPORTS = ("pscv_last_error", "pscv_abi_version", "pscv_set_tuning", "pscv_proj_
            "pscv_fuse_pairs", "pscv_fuse_finish", "pscv_geo_filter", "pscv_pack_conv2d_weights", "pscv_conv2d",
            "pscv_pack_conv3d_weights", "pscv_conv3d", "pscv_softargmin", "pscv_train_workspace_floats", "pscv_bn_stats",
            "pscv_bn_act", "pscv_bn_bwd_reduce", "pscv_bn_bwd_apply", "pscv_softargmin_bwd", "pscv_conv3d_wgrad_workspace",
-           "pscv_conv3d_wgrad", "pscv_warp_cost_bwd", "pscv_cvp_depth_hypos", "pscv_relu_bwd", "pscv_fuse_pairs_bwd", "pscv_pack_conv3d_weights_device", "pscv_conv2d_ex", "pscv_variance_finish", "pscv_softargmin_window")
+           "pscv_conv3d_wgrad", "pscv_warp_cost_bwd", "pscv_cvp_depth_hypos", "pscv_relu_bwd", "pscv_fuse_pairs_bwd", "pscv_pack_conv3d_weights_device", "pscv_conv2d_ex", "pscv_variance_finish", "pscv_softargmin_window",
+           "pscv_photo_warp", "pscv_photo_warp_bwd", "pscv_ssim", "pscv_ssim_bwd")
 
 
 class PscvMissingError(RuntimeError):
@@ -78,6 +79,14 @@ def _declare(lib):
     lib.pscv_pack_conv2d_weights.argtypes = [vp, i, i, i, i, i, vp]
     lib.pscv_conv2d.restype = i
     lib.pscv_conv2d.argtypes = [vp, i, vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, vp]
+    lib.pscv_photo_warp.restype = i
+    lib.pscv_photo_warp.argtypes = [vp] * 10 + [i, i, i, i, i, vp]
+    lib.pscv_photo_warp_bwd.restype = i
+    lib.pscv_photo_warp_bwd.argtypes = [vp] * 6 + [i, i, i, i, i, vp]
+    lib.pscv_ssim.restype = i
+    lib.pscv_ssim.argtypes = [vp, vp, vp, i, i, i, i, i, vp]
+    lib.pscv_ssim_bwd.restype = i
+    lib.pscv_ssim_bwd.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, vp]
     lib.pscv_softargmin_window.restype = i
     lib.pscv_softargmin_window.argtypes = [vp, vp, vp, f, i, i, i, i, i, vp]
     lib.pscv_variance_finish.restype = i

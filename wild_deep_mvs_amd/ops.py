@@ -598,6 +598,110 @@ def softargmin_window(logits: torch.Tensor, stats: torch.Tensor, *, window: floa
 
 
 # --------------------------------------------------------------------------------------------
+# unsupervised photometric loss: depth -> flows -> warped sources, SSIM
+# --------------------------------------------------------------------------------------------
+def inv_proj4x4(P: torch.Tensor) -> torch.Tensor:
+    """Inverse of projection matrices [...,4,4] with last row (0,0,0,1): [[A^-1, -A^-1 b], [0 0 0 1]], closed form in fp64
+    (the reference calls torch.inverse in fp32, utils_3D.py:196; no LAPACK call / host sync here)."""
+    Pd = P.double()
+    Ai = inv3x3(Pd[..., :3, :3])
+    out = torch.zeros_like(Pd)
+    out[..., :3, :3] = Ai
+    out[..., :3, 3:] = -(Ai @ Pd[..., :3, 3:])
+    out[..., 3, 3] = 1.0
+    return out.to(P.dtype)
+
+
+def _photo_args(src_imgs, depth, inv_ref, proj_src):
+    _dev(depth, inv_ref, proj_src)
+    B, h, w = depth.shape
+    S = proj_src.shape[1]
+    if depth.dtype != torch.float32 or inv_ref.dtype != torch.float32 or proj_src.dtype != torch.float32 \
+            or tuple(inv_ref.shape) != (B, 4, 4) or tuple(proj_src.shape) != (B, S, 4, 4):
+        raise ValueError("pscv.photo_warp: fp32 depth [B,h,w], inv_ref [B,4,4], proj_src [B,S,4,4] expected")
+    C = 0
+    if src_imgs is not None:
+        _dev(src_imgs)
+        C = src_imgs.shape[2]
+        if src_imgs.dtype != torch.float32 or tuple(src_imgs.shape) != (B, S, C, h, w):
+            raise ValueError(f"pscv.photo_warp: source images fp32 [B,S,C,h,w] at the depth map's resolution expected, got "
+                             f"{tuple(src_imgs.shape)} for depth {tuple(depth.shape)}")
+    return B, S, C, h, w
+
+
+def photo_warp(src_imgs: Optional[torch.Tensor], depth: torch.Tensor, inv_ref: torch.Tensor, proj_src: torch.Tensor, *,
+               src_depth: Optional[torch.Tensor] = None, want_mask: bool = True, want_z: bool = False, want_flows: bool = False) -> dict:
+    """Depth map -> flows -> warped sources (pscv_photo_warp; trainer.py:209-236).  Returns a dict with ``warped`` [B,S,C,h,w]
+    (if images are given), ``mask`` [B,S,h,w] fp32, ``z`` [B,S,h,w], ``flows`` [B,S,h,w,2], ``warped_depth`` [B,S,h,w]."""
+    B, S, C, h, w = _photo_args(src_imgs, depth, inv_ref, proj_src)
+    depth, inv_ref, proj_src = depth.contiguous(), inv_ref.contiguous(), proj_src.contiguous()
+    mk = lambda *sh: torch.empty(sh, dtype=torch.float32, device=depth.device)
+    o = {"warped": mk(B, S, C, h, w) if src_imgs is not None else None, "mask": mk(B, S, h, w) if want_mask else None,
+         "z": mk(B, S, h, w) if want_z else None, "flows": mk(B, S, h, w, 2) if want_flows else None,
+         "warped_depth": mk(B, S, h, w) if src_depth is not None else None}
+    if src_imgs is not None:
+        src_imgs = src_imgs.contiguous()
+    if src_depth is not None:
+        _dev(src_depth)
+        if src_depth.dtype != torch.float32 or tuple(src_depth.shape) != (B, S, h, w):
+            raise ValueError("pscv.photo_warp: src_depth fp32 [B,S,h,w] expected")
+        src_depth = src_depth.contiguous()
+    rc = _launch("photo_warp", lambda: L.lib().pscv_photo_warp(_p(src_imgs), _p(depth), _p(inv_ref), _p(proj_src), _p(src_depth),
+                                                              _p(o["warped"]), _p(o["mask"]), _p(o["z"]), _p(o["flows"]),
+                                                              _p(o["warped_depth"]), B, S, C, h, w, _stream()))
+    L.check(rc, "pscv_photo_warp")
+    return o
+
+
+def photo_warp_bwd(src_imgs: torch.Tensor, depth: torch.Tensor, inv_ref: torch.Tensor, proj_src: torch.Tensor,
+                   grad_warped: torch.Tensor) -> torch.Tensor:
+    """grad_warped [B,S,C,h,w] -> grad_depth [B,h,w] (pscv_photo_warp_bwd)."""
+    B, S, C, h, w = _photo_args(src_imgs, depth, inv_ref, proj_src)
+    _dev(grad_warped)
+    if grad_warped.dtype != torch.float32 or tuple(grad_warped.shape) != (B, S, C, h, w):
+        raise ValueError("pscv.photo_warp_bwd: grad_warped fp32 [B,S,C,h,w] expected")
+    gd = torch.empty((B, h, w), dtype=torch.float32, device=depth.device)
+    src_imgs, depth, inv_ref, proj_src, grad_warped = (t.contiguous() for t in (src_imgs, depth, inv_ref, proj_src, grad_warped))
+    rc = _launch("photo_warp_bwd", lambda: L.lib().pscv_photo_warp_bwd(_p(src_imgs), _p(depth), _p(inv_ref), _p(proj_src),
+                                                                      _p(grad_warped), _p(gd), B, S, C, h, w, _stream()))
+    L.check(rc, "pscv_photo_warp_bwd")
+    return gd
+
+
+def _ssim_args(img1, img2):
+    _dev(img1, img2)
+    if img1.dtype != torch.float32 or img2.dtype != torch.float32 or img1.dim() != 4 or img2.dim() != 4 \
+            or img1.shape[1:] != img2.shape[1:] or img2.shape[0] % img1.shape[0]:
+        raise ValueError(f"pscv.ssim: fp32 img1 [n1,C,h,w] and img2 [n1*rep,C,h,w] expected, got {tuple(img1.shape)} {tuple(img2.shape)}")
+    n1, C, h, w = img1.shape
+    return n1, img2.shape[0] // n1, C, h, w
+
+
+def ssim(img1: torch.Tensor, img2: torch.Tensor) -> torch.Tensor:
+    """1 - SSIM per channel (pscv_ssim; utils/ssimLoss.py:27-60): img1 [n1,C,h,w], img2 [n1*rep,C,h,w] -> [n1*rep,C,h,w]."""
+    n1, rep, C, h, w = _ssim_args(img1, img2)
+    img1, img2 = img1.contiguous(), img2.contiguous()
+    out = torch.empty_like(img2)
+    rc = _launch("ssim", lambda: L.lib().pscv_ssim(_p(img1), _p(img2), _p(out), n1, rep, C, h, w, _stream()))
+    L.check(rc, "pscv_ssim")
+    return out
+
+
+def ssim_bwd(img1: torch.Tensor, img2: torch.Tensor, grad_out: torch.Tensor) -> torch.Tensor:
+    """Gradient of ``ssim`` to img2 (pscv_ssim_bwd)."""
+    n1, rep, C, h, w = _ssim_args(img1, img2)
+    _dev(grad_out)
+    if grad_out.dtype != torch.float32 or grad_out.shape != img2.shape:
+        raise ValueError("pscv.ssim_bwd: grad_out must match img2")
+    img1, img2, grad_out = img1.contiguous(), img2.contiguous(), grad_out.contiguous()
+    ws = torch.empty((3 * img2.numel(),), dtype=torch.float32, device=img2.device)
+    g2 = torch.empty_like(img2)
+    rc = _launch("ssim_bwd", lambda: L.lib().pscv_ssim_bwd(_p(img1), _p(img2), _p(grad_out), _p(ws), _p(g2), n1, rep, C, h, w, _stream()))
+    L.check(rc, "pscv_ssim_bwd")
+    return g2
+
+
+# --------------------------------------------------------------------------------------------
 # CVP refinement hypotheses (SURVEY 8f-4)
 # --------------------------------------------------------------------------------------------
 def cvp_depth_hypos(depth: torch.Tensor, cams: torch.Tensor, fallback: torch.Tensor, *, want_steps: bool = False):

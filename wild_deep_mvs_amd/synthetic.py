@@ -116,6 +116,19 @@ def make_scene(B: int, V: int, H: int, W: int, *, seed: int = 0, depth_min: floa
     return out
 
 
+def make_photo_case(B: int, V: int, H: int, W: int, *, seed: int = 0, behind_view: int = -1) -> Dict[str, torch.Tensor]:
+    """Inputs of the unsupervised photometric loss at the loss resolution: the scene of ``make_scene`` plus one smooth depth
+    map per view ``depths`` [V,B,H,W] (a slanted surface with bumps inside [depth_min, depth_max]; view v's map is what the
+    network would predict with view v as the reference)."""
+    out = make_scene(B, V, H, W, seed=seed, behind_view=behind_view)
+    rng = np.random.default_rng(seed + 77)
+    coarse = torch.from_numpy(rng.random((V * B, 1, 4, 5), dtype=np.float32))
+    bumps = torch.nn.functional.interpolate(coarse, size=(H, W), mode="bicubic", align_corners=False).reshape(V, B, H, W)
+    ramp = torch.linspace(0.0, 1.0, W).view(1, 1, 1, W)
+    out["depths"] = (3.2 + 0.8 * ramp + 0.9 * (bumps - 0.5)).contiguous()
+    return out
+
+
 def make_features(B: int, V: int, C: int, h: int, w: int, *, seed: int = 1,
                   scale: float = 0.5) -> torch.Tensor:
     """Feature maps ~ N(0,1)*scale, [V,B,C,h,w] fp32 (hot-path-only timing input)."""

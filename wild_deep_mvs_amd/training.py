@@ -598,3 +598,39 @@ class FeatureNetFn(torch.autograd.Function):
                         ops.conv2d(dy, sub, out=dact, parity=par)
         ctx.saved = None
         return (None, None, None, *[grads[id(p)] for p in FeatureNetFn.params(net)])
+
+
+# --------------------------------------------------------------------------------------------
+# unsupervised photometric loss (models/trainer.py:209-278, utils/ssimLoss.py)
+# --------------------------------------------------------------------------------------------
+class PhotoWarpFn(torch.autograd.Function):
+    """depth [B,h,w] -> (warped sources [B,S,C,h,w], mask [B,S,h,w]); the gradient flows to the DEPTH through the sampling
+    position, as in the reference (the images are data).  Forward and backward are one HIP launch each."""
+
+    @staticmethod
+    def forward(ctx, depth, src_imgs, inv_ref, proj_src):
+        o = ops.photo_warp(src_imgs, depth.detach(), inv_ref, proj_src)
+        ctx.save_for_backward(depth.detach(), src_imgs, inv_ref, proj_src)
+        ctx.mark_non_differentiable(o["mask"])
+        return o["warped"], o["mask"]
+
+    @staticmethod
+    def backward(ctx, grad_warped, _grad_mask):
+        depth, src_imgs, inv_ref, proj_src = ctx.saved_tensors
+        return ops.photo_warp_bwd(src_imgs, depth, inv_ref, proj_src, grad_warped.contiguous()), None, None, None
+
+
+class SSIMFn(torch.autograd.Function):
+    """1 - SSIM(img1, img2) per channel; differentiable in img2 (the warped image), img1 is data."""
+
+    @staticmethod
+    def forward(ctx, img1, img2):
+        if img1.requires_grad:
+            raise NotImplementedError("pscv SSIM: the first image is treated as data (the reference image of the loss)")
+        ctx.save_for_backward(img1, img2.detach())
+        return ops.ssim(img1, img2.detach())
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        img1, img2 = ctx.saved_tensors
+        return None, ops.ssim_bwd(img1, img2, grad_out.contiguous())
