@@ -117,3 +117,49 @@ def test_masked_photometricloss_ranks_one_gpu():
           f"grad_depth rel-L1 {rel:.2e}", flush=True)
     assert moved <= 2e-3 and np.quantile(np.abs(ssim - g["ssim"]), 0.999) <= 1e-4
     assert abs(loss - float(g["loss"])) <= 1e-5 and rel <= 1e-4
+
+
+def test_unsupervised_mvsnet_train_step():
+    """The `--unsupervised` step of the reference's trainer (models/trainer.py:96-174) on the engine end to end: MVSNet in
+    train() mode -> depth at 1/4 resolution -> images resized to it, intrinsics divided by 4 -> photometric loss -> backward
+    into every weight.  Against the oracle (model restatement with the engine's fp16 storage emulated + loss restatement, both
+    pinned to the reference): loss value, and the cosine of the full weight-gradient vector (a random-weight BatchNorm net
+    amplifies one-ulp differences layer by layer, so the whole vector is compared, as in tests/test_gpu_train.py)."""
+    import torch.nn.functional as F
+    from oracle import mvsnet as O
+    from wild_deep_mvs_amd.models.MVSNet.model import MVSNet, build_proj_matrices
+    H, W, V, D, B, seed = 64, 96, 3, 16, 2, 0
+    scene = synthetic.make_scene(B, V, H, W, seed=4)
+
+    def loss_of(depth, imgs, K, R, t, photometricloss):
+        h, w = depth.shape[-2:]
+        img = F.interpolate(imgs.view(-1, 3, H, W), size=(h, w), mode="bilinear", align_corners=False).view(B, V, 3, h, w)
+        Ks = K.clone()
+        Ks[:, :, :2] /= 4
+        ssim, mask = photometricloss(img, depth, build_proj_matrices(Ks, R, t))[:2]
+        return torch.sum(ssim * mask) / torch.sum(mask)
+
+    net = MVSNet("variance")
+    net.load_state_dict(synthetic.train_state_dict("mvsnet", synthetic.template_of(net), seed=seed))
+    net = net.cuda().train()
+    net.num_depth, net.train_storage_dtype = D, torch.float16
+    dev = {k: scene[k].cuda() for k in ("imgs", "K", "R", "t", "depth_min", "depth_max")}
+    out = net(*[dev[k] for k in ("imgs", "K", "R", "t", "depth_min", "depth_max")])
+    loss = loss_of(out["depth"], dev["imgs"], dev["K"], dev["R"], dev["t"], Trainer().photometricloss)
+    loss.backward()
+
+    sd = synthetic.train_state_dict("mvsnet", synthetic.template_of(MVSNet("variance")), seed=seed)
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v) for k, v in sd.items()}
+    o_out = O.forward(scene["imgs"], scene["K"], scene["R"], scene["t"], scene["depth_min"], scene["depth_max"], sd, num_depth=D,
+                      aggregation="variance", training=True, new_stats={}, store=torch.float16)
+    o_loss = loss_of(o_out["depth"], scene["imgs"], scene["K"], scene["R"], scene["t"], P.photometricloss)
+    o_loss.backward()
+    dot = n1 = n2 = 0.0
+    for k, p in net.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+        a, b = p.grad.float().cpu(), sd[k].grad.float()
+        dot += float((a * b).sum()); n1 += float((a * a).sum()); n2 += float((b * b).sum())
+    cos = dot / (n1 ** 0.5 * n2 ** 0.5)
+    print(f"[parity] unsupervised MVSNet step: loss {float(loss):.6f} vs oracle {float(o_loss):.6f}, gradient cosine {cos:.5f}", flush=True)
+    assert abs(float(loss) - float(o_loss)) <= 1e-3 * abs(float(o_loss))
+    assert cos >= 0.98

@@ -54,6 +54,8 @@ def test_homo_warping_function_api(env):
     wpp = homo_warping(feats[1].cuda(), proj[:, 1].cuda(), proj[:, 0].cuda(), t(g["depth_per_pixel"]).cuda(),
                        feats[0].shape[-2:])
     check_close("homo_warping per-pixel planes", wpp[:, :, planes].cpu(), t(g["warped_per_pixel"]), max_abs=3e-4)
+    from wild_deep_mvs_amd.models import utils as mutils          # the name BASELINE.json gives the warp
+    assert mutils.homo_warp is homo_warping
 
 
 @pytest.mark.parametrize("fname,agg", [("mvsnet_tiny.npz", "variance"), ("mvsnet_behind.npz", "variance"),
