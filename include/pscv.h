@@ -58,8 +58,9 @@ extern "C" {
 #define PSCV_CONV_S1 0 /* Conv3d k3 s1 p1 (also ConvTranspose3d k3 s1 p1, packed flipped) */
 #define PSCV_CONV_S2 1 /* Conv3d k3 s2 p1 */
 #define PSCV_CONV_T2 2 /* ConvTranspose3d k3 s2 p1 output_padding 1 */
-#define PSCV_CONV_S1P8 3 /* Conv3d k3 s1 p1 with c_in = 32, c_out = 8 on the depth-sweep kernel (plane-pair packed
-                            MFMA rows, register-resident weights); same result as PSCV_CONV_S1, own packed layout */
+#define PSCV_CONV_S1P8 3 /* Conv3d k3 s1 p1 (or ConvTranspose3d k3 s1 p1) with c_in = 8, 16 or 32 and c_out = 8 on the depth-sweep
+                            kernels (plane-pair packed MFMA rows, register-resident weights); same result as PSCV_CONV_S1, own
+                            packed layout */
 #define PSCV_CONV_T2P8 5 /* ConvTranspose3d k3 s2 p1 op1 with c_in = 16, c_out = 8 on the parity-pair packed kernel; same
                             result as PSCV_CONV_T2, own packed layout */
 #define PSCV_CONV_S1C1 4 /* Conv3d k3 s1 p1 with c_out = 1, c_in = 8 or 16 (the `prob` heads) on the depth-in-rows MFMA
@@ -80,7 +81,9 @@ int pscv_abi_version(void);
  *   "warp_tiled" 1: pscv_warp_cost stages source patches in LDS where it applies (C = 32, 16-bit features,
  *               per-batch planes, PROJ geometry, 2-4 source views, variance / softmin); 0 (default): the
  *               direct-gather kernel, which measured faster on MI355X.  "warp_lpv" != 0 also selects the direct kernel.
- *   "sweep_dc"  depth planes per workgroup of the 32->8 depth-sweep conv (0 = default heuristic)
+ *   "sweep_dc"  depth planes per workgroup of the depth-sweep convs (0 = default heuristic)
+ *   "sweepc_slots" resident-workgroup target that sizes the depth chunks of the 8|16 -> 8 depth-sweep conv (0 = 768)
+ *   "sweepc_pd" prefetch distance in iterations (1..3) of the same kernel (0 = 1)
  *   "sweep_th16" 1: the 32->8 depth-sweep conv uses 16-row tiles / 512 threads; 0 (default): 8-row tiles / 256 threads
  *   "warp_bwd_direct" 1: pscv_warp_cost_bwd issues one global float atomic per tap; 0 (default): accumulates per-workgroup
  *               LDS patches and flushes them coalesced

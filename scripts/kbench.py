@@ -55,6 +55,37 @@ def main():
             print(f"conv0 sweep dc={dc:3d}: {us:8.1f} us")
         L.set_tuning("sweep_dc", 0)
         return
+    if args.only == "vis":
+        # the Vis-MVSNet U-Net's full-resolution layers (8 -> 8 with residual, 16 -> 8 after the concat): narrow depth-sweep
+        # kernel (default) against the generic brick kernel, at stage-1 sizes of BASELINE configurations 3 and 5
+        for (Dv, hv, wv) in ((192, 64, 80), (32, 128, 160), (16, 256, 320), (256, 144, 200), (32, 288, 400), (16, 576, 800)):
+            for ci in (8, 16):
+                x = (torch.randn(1, Dv, hv, wv, 16, generator=g) * 0.5).to(dt).to(dev)
+                sk = (torch.randn(1, Dv, hv, wv, 8, generator=g) * 0.5).to(dt).to(dev)
+                wt = torch.randn(8, ci, 3, 3, 3, generator=g) / (27 * ci) ** 0.5
+                out = torch.empty(1, Dv, hv, wv, 8, dtype=dt, device=dev)
+                vox = Dv * hv * wv
+                gb = vox * (ci + 8 + 8) * 2 / 1e9
+                res = {}
+                for use in (True, False):
+                    ops.USE_SWEEP_KERNEL = use
+                    layer = ops.Conv3dLayer.build(wt, kind=L.CONV_S1, device=dev, relu_post=True, dtype=dt)
+                    ops.USE_SWEEP_KERNEL = True
+                    res[use] = timeit(lambda: ops.conv3d(x, layer, skip=sk, out=out), args.reps)
+                print(f"vis {ci:2d}->8 + skip @ {Dv}x{hv}x{wv}: sweep {res[True]:8.1f} us ({gb / res[True] * 1e6:6.0f} GB/s)   "
+                      f"brick {res[False]:8.1f} us ({gb / res[False] * 1e6:6.0f} GB/s)")
+                if True:
+                    layer = ops.Conv3dLayer.build(wt, kind=L.CONV_S1, device=dev, relu_post=True, dtype=dt)
+                    for pd in ((1, 2, 3) if args.reps > 20 else ()):
+                        L.set_tuning("sweepc_pd", pd)
+                        row = []
+                        for slots in (512, 768, 1024, 2048):
+                            L.set_tuning("sweepc_slots", slots)
+                            row.append(f"{slots}: {timeit(lambda: ops.conv3d(x, layer, skip=sk, out=out), args.reps):6.1f}")
+                        print(f"    prefetch distance {pd}, us by resident-workgroup target  " + "  ".join(row))
+                    L.set_tuning("sweepc_slots", 0)
+                    L.set_tuning("sweepc_pd", 0)
+        return
     for name, ci, co, kind, s, skip in layers:
         if args.only and args.only not in name:
             continue

@@ -181,6 +181,52 @@ def test_sweep_kernel_matches_brick_kernel_and_aten(env, shape, th16, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("cin,shape,transposed,dc", [(8, (16, 16, 32), False, 0), (8, (13, 11, 21), False, 4), (8, (37, 9, 40), True, 0),
+                                                     (16, (16, 16, 32), False, 0), (16, (9, 37, 24), False, 6), (16, (2, 8, 16), True, 0),
+                                                     (8, (2, 3, 5), False, 0)])
+def test_narrow_sweep_kernel_matches_brick_kernel_and_aten(env, cin, shape, transposed, dc, dtype):
+    """The 8|16 -> 8 depth-sweep kernel (PSCV_CONV_S1P8, the Vis U-Net's full-resolution layers) against the generic brick kernel
+    and ATen: sizes off the 8x16 tile, odd D, forced depth-chunk seams, BN + skip + post-ReLU, input / skip / output channel
+    slices of wider tensors (the U-Net's concat buffer), and stride-1 ConvTranspose3d weights (the training path's adjoints)."""
+    L, ops = env
+    g = torch.Generator().manual_seed(cin + sum(shape))
+    D, H, W = shape
+    wide = bf16_round(torch.randn(2, 24, D, H, W, generator=g))               # the conv reads channels [8, 8 + cin)
+    x = wide[:, 8:8 + cin]
+    if transposed:
+        w = bf16_round(torch.randn(cin, 8, 3, 3, 3, generator=g) / np.sqrt(27 * cin))
+        conv = F.conv_transpose3d(x, w, padding=1)
+    else:
+        w = bf16_round(torch.randn(8, cin, 3, 3, 3, generator=g) / np.sqrt(27 * cin))
+        conv = F.conv3d(x, w, padding=1)
+    gamma, beta = torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g) * 0.3
+    mean, var = torch.randn(8, generator=g) * 0.2, torch.rand(8, generator=g) + 0.5
+    skip_wide = bf16_round(torch.randn(2, 16, D, H, W, generator=g))          # skip = channels [4, 12)
+    ref = F.relu(F.batch_norm(conv, mean, var, gamma, beta, training=False, eps=1e-5) + skip_wide[:, 4:12])
+    xcl, scl = ops.to_channels_last(wide.cuda(), dtype), ops.to_channels_last(skip_wide.cuda(), dtype)
+    outs = {}
+    for use in (True, False):
+        ops.USE_SWEEP_KERNEL = use
+        try:
+            layer = ops.Conv3dLayer.build(w, kind=L.CONV_S1, transposed=transposed, device="cuda", bn=(gamma, beta, mean, var),
+                                          relu_post=True, dtype=dtype)
+        finally:
+            ops.USE_SWEEP_KERNEL = True
+        assert layer.kind == (L.CONV_S1P8 if use else L.CONV_S1)
+        out = torch.full((2, D, H, W, 16), 7.0, dtype=dtype, device="cuda")     # the conv writes channels [8, 16)
+        L.set_tuning("sweep_dc", dc)
+        try:
+            ops.conv3d(xcl, layer, in_coff=8, skip=scl, skip_coff=4, out=out, out_coff=8)
+        finally:
+            L.set_tuning("sweep_dc", 0)
+        assert bool((out[..., :8] == 7.0).all())
+        outs[use] = out[..., 8:].float().permute(0, 4, 1, 2, 3).cpu()
+    ulp = 2 ** -8 if dtype == torch.bfloat16 else 2 ** -11
+    check_close(f"narrow sweep vs ATen cin={cin} {shape} {dtype}", outs[True], ref, max_abs=ulp * float(ref.abs().max()) + 2e-3)
+    check_close(f"narrow sweep vs brick cin={cin} {shape} {dtype}", outs[True], outs[False], max_abs=ulp * float(ref.abs().max()) + 1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("cin,shape,out_dtype", [(8, (16, 16, 32), torch.float32), (8, (13, 11, 45), torch.float32),
                                                  (16, (9, 8, 33), torch.float32), (8, (5, 17, 64), None)])
 def test_one_channel_dot2_kernel_matches_mfma_kernel_and_aten(env, cin, shape, out_dtype, dtype):
@@ -256,7 +302,7 @@ def test_device_weight_packing_equals_host_packing(dtype):
     from wild_deep_mvs_amd import _lib as L, ops
     g = torch.Generator().manual_seed(5)
     cases = [(8, 32, L.CONV_S1, False), (32, 8, L.CONV_S1, True), (64, 32, L.CONV_S1, True), (16, 8, L.CONV_S2, False),
-             (64, 32, L.CONV_S2, False), (64, 32, L.CONV_T2, True), (32, 16, L.CONV_T2, True), (8, 32, L.CONV_S1P8, False),
+             (64, 32, L.CONV_S2, False), (64, 32, L.CONV_T2, True), (32, 16, L.CONV_T2, True), (8, 32, L.CONV_S1P8, False), (8, 8, L.CONV_S1P8, False), (8, 16, L.CONV_S1P8, False), (8, 8, L.CONV_S1P8, True),
              (16, 8, L.CONV_T2P8, True), (1, 8, L.CONV_S1C1, False), (1, 16, L.CONV_S1C1, False)]
     for a, b, kind, tr in cases:
         w = torch.randn(a, b, 3, 3, 3, generator=g)

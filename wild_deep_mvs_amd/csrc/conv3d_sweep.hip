@@ -37,6 +37,8 @@ template <> struct SwMfma<f16_t> {
 };
 
 int g_sweep_dc = 0;     // pscv_set_tuning("sweep_dc", n): depth planes per workgroup sweep (0 = heuristic)
+int g_sweepc_pd = 0;    // pscv_set_tuning("sweepc_pd", 1..3): prefetch distance (iterations) of the narrow-input sweep (0 = 1)
+int g_sweepc_slots = 0; // pscv_set_tuning("sweepc_slots", n): resident-workgroup target of the narrow-input sweep (0 = 768)
 int g_sweep_th16 = 0;   // pscv_set_tuning("sweep_th16", 1) selects the 16-row / 512-thread tile variant (measured
                         // 116 us vs 107 us for 8-row tiles at the headline size: one workgroup per CU hides less latency)
 
@@ -236,7 +238,273 @@ __global__ __launch_bounds__(32 * SW_TH, 2) void conv3d_sweep8_kernel(const Swee
     }
 }
 
+// ---- narrow-input variant: C_in = 8 or 16, C_out = 8 (the Vis-MVSNet U-Net's full-resolution layers) ---------------------
+// Same sweep (8 x 16 pixel tile, 6-slot plane ring, two new planes per iteration prefetched under the MFMAs, plane-pair packed
+// rows), but with 16 / 32-byte voxels the 32-deep MFMA reduction spans PLANES instead of channels:
+//   C_in = 8:  k = 4 input planes (lane group g = plane d-1+g) x 8 channels; one MFMA per (kh,kw) tap -> 9 MFMAs give two
+//              output planes of a 16-pixel row (the generic brick kernel issues 7 per ONE plane with half its rows idle);
+//   C_in = 16: k = 2 planes (g >> 1) x 16 channels (chunk g & 1); 18 MFMAs per plane pair.
+// A lane's plane is fixed, so its ring-slot base is computed once per iteration.  ds_read_b128 lane groups pair g = 0 with 1
+// and g = 2 with 3: with the plane slot a multiple of 256 B (C_in = 8) the paired lanes read the same in-plane voxels of two
+// planes -> 16 distinct 16-byte slots; for C_in = 16 the pair reads the two chunks of the same voxels -> even / odd slots.
+// Conflict-free without a swizzle.  All weights stay in registers (36 / 72 VGPRs), 18 / 36 KiB of LDS: 4 / 3 workgroups per CU.
+// Input planes and the residual (skip) values travel through a register FIFO of PD iterations (template; 1 by default).
+// HBM-bound: 16 (32) B in + 16 B out per voxel; replaces BasicBlock.conv1 / conv2 (nn_utils.py:27-37) and the decoder's
+// post-concat conv (nn_utils.py:238-245, 269-272) of the reference's UNet.
+template <int CIN> struct ScGeom {
+    static constexpr int VB = CIN * 2, CCH = CIN / 8;
+    static constexpr int BH = 10, PV = 192;                  // 10 x 18 = 180 voxels per plane, padded to a multiple of 16
+    static constexpr int PB = PV * VB;
+    static constexpr int LDS = SW_NSLOT * PB;
+    static constexpr int CHUNKS = BH * SW_BW * CCH;
+    static constexpr int NLD = (CHUNKS + 255) / 256;
+    static constexpr int NM = 4 * 9 * CIN / 32;              // MFMAs per plane pair and pixel row
+};
+
+template <typename H, int CIN, int PD>
+__global__ __launch_bounds__(256, (CIN == 8 && PD <= 2) ? 4 : (CIN == 8 || PD == 1) ? 3 : 2) void conv3d_sweepc_kernel(const SweepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using G = ScGeom<CIN>;
+    constexpr int VB = G::VB, CCH = G::CCH, PB = G::PB, CHUNKS = G::CHUNKS, NLD = G::NLD, NM = G::NM;
+    constexpr int R = 2;
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, slot_ = bid >> 3, q = nwg >> 3, r_ = nwg & 7;
+    int wg = (xcd < r_ ? xcd * (q + 1) : r_ * (q + 1) + (xcd - r_) * q) + slot_;
+    const int dci = wg % a.ndc; wg /= a.ndc;
+    const int twi = wg % a.ntw; wg /= a.ntw;
+    const int thi = wg % a.nth; wg /= a.nth;
+    const int b = wg;
+    const int h0 = thi * 8, w0 = twi * 16;
+    const int dbeg = dci * a.dc, dend = min(a.D, dbeg + a.dc);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+
+    uint4 wf[NM];
+    {
+        const uint4* wp = reinterpret_cast<const uint4*>(a.wpk);
+#pragma unroll
+        for (int m = 0; m < NM; ++m) wf[m] = wp[m * 64 + lane];
+    }
+
+    const int row0 = wave * R;
+    int boff[R + 2][3];
+#pragma unroll
+    for (int rr = 0; rr < R + 2; ++rr)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) boff[rr][kw] = ((row0 + rr) * SW_BW + n + kw) * VB + (CIN == 16 ? (g & 1) * 16 : 0);
+    const int pl0 = CIN == 8 ? g : (g >> 1);      // this lane's plane (relative to d-1) in MFMA set 0; set 1 (C_in = 16) adds 2
+
+    int goff[NLD], loff[NLD];
+    bool gval[NLD], lval[NLD];
+    const long plane_stride = (long)a.Hh * a.W * a.in_cs;
+    const uint16_t* inb = a.in + (long)b * a.D * plane_stride + a.in_co;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int id = tid + 256 * i;
+        const int v = id / CCH, c = id - v * CCH;
+        const int bh = v / SW_BW, bw = v - bh * SW_BW;
+        const int gh = h0 - 1 + bh, gw = w0 - 1 + bw;
+        lval[i] = id < CHUNKS;
+        gval[i] = lval[i] && (unsigned)gh < (unsigned)a.Hh && (unsigned)gw < (unsigned)a.W;
+        goff[i] = gval[i] ? (gh * a.W + gw) * a.in_cs + c * 8 : 0;
+        loff[i] = v * VB + c * 16;
+    }
+    const int plane_hi = min(a.D - 1, dend);
+    auto fetch = [&](int plane, uint4 (&reg)[NLD]) {
+        const bool pv = plane >= 0 && plane <= plane_hi;
+        const uint16_t* pp = inb + (long)(pv ? plane : 0) * plane_stride;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            reg[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (gval[i] && pv) reg[i] = *reinterpret_cast<const uint4*>(pp + goff[i]);
+        }
+    };
+    auto stash = [&](int ring, const uint4 (&reg)[NLD]) {
+        unsigned char* sp = smem + ring * PB;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+            if (lval[i]) *reinterpret_cast<uint4*>(sp + loff[i]) = reg[i];
+    };
+
+    const int c0 = (g & 1) * 4;
+    float sc[4], bi[4], fl[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        sc[k] = a.scale ? a.scale[c0 + k] : 1.0f;
+        bi[k] = a.bias ? a.bias[c0 + k] : 0.0f;
+        fl[k] = a.floor ? a.floor[c0 + k] : 0.0f;
+    }
+    // this lane's output voxels: plane dd + (g >> 1), rows row0 + r, column n
+    const bool col_ok = w0 + n < a.W;
+    long vrow[R];
+    bool row_ok[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        row_ok[r] = col_ok && h0 + row0 + r < a.Hh;
+        vrow[r] = ((long)b * a.D * a.Hh + (h0 + row0 + r)) * a.W + w0 + n;
+    }
+    const long vplane = (long)a.Hh * a.W;
+    auto fetch_skip = [&](int dd, uint2 (&reg)[R]) {
+        const int od = dd + (g >> 1);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            reg[r] = make_uint2(0u, 0u);
+            if (a.skip && od < dend && row_ok[r])
+                reg[r] = *reinterpret_cast<const uint2*>(a.skip + (vrow[r] + od * vplane) * a.skip_cs + a.skip_co + c0);
+        }
+    };
+
+    // ---- prologue: planes dbeg-1 .. dbeg+2 into ring slots 0..3; the register FIFO holds the planes and skip values of the
+    // next PD iterations (loads issued 2 PD planes ahead of their use: the HBM latency spans several iterations) ----
+    {
+        uint4 ra[NLD], rb[NLD];
+        fetch(dbeg - 1, ra); fetch(dbeg, rb);
+        stash(0, ra); stash(1, rb);
+        fetch(dbeg + 1, ra); fetch(dbeg + 2, rb);
+        stash(2, ra); stash(3, rb);
+    }
+    uint4 pfa[PD][NLD], pfb[PD][NLD];
+    uint2 sk[PD][R];
+#pragma unroll
+    for (int s = 0; s < PD; ++s) {
+        fetch(dbeg + 3 + 2 * s, pfa[s]);
+        fetch(dbeg + 4 + 2 * s, pfb[s]);
+        fetch_skip(dbeg + 2 * s, sk[s]);
+    }
+    __syncthreads();
+
+    int ring = 0;   // slot holding plane dd-1
+    for (int d = dbeg; d < dend; d += 2 * PD) {
+#pragma unroll
+        for (int s = 0; s < PD; ++s) {
+            const int dd = d + 2 * s;
+            if (dd < dend) {                                         // workgroup-uniform
+                // planes dd+3, dd+4 replace dd-3, dd-2 (last read one iteration ago, fenced by that iteration's barrier); their
+                // registers are refilled at once with the planes of iteration dd + 2 PD
+                int s4 = ring + 4, s5 = ring + 5;
+                s4 = s4 >= SW_NSLOT ? s4 - SW_NSLOT : s4;
+                s5 = s5 >= SW_NSLOT ? s5 - SW_NSLOT : s5;
+                stash(s4, pfa[s]);
+                stash(s5, pfb[s]);
+                fetch(dd + 3 + 2 * PD, pfa[s]);
+                fetch(dd + 4 + 2 * PD, pfb[s]);
+
+                sw_f32x4 acc[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r] = sw_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int set = 0; set < NM / 9; ++set) {
+                    int sl = ring + pl0 + 2 * set;
+                    sl = sl >= SW_NSLOT ? sl - SW_NSLOT : sl;
+                    const unsigned char* sp = smem + sl * PB;
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                            for (int r = 0; r < R; ++r) {
+                                const uint4 xf = *reinterpret_cast<const uint4*>(sp + boff[r + kh][kw]);
+                                acc[r] = SwMfma<H>::run(wf[set * 9 + kh * 3 + kw], xf, acc[r]);
+                            }
+                }
+
+                const int od = dd + (g >> 1);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (od < dend && row_ok[r]) {
+                        const long vox = vrow[r] + od * vplane;
+                        float y[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            y[k] = fmaf(acc[r][k], sc[k], bi[k]);
+                            if (a.epi & PSCV_EPI_RELU_PRE) y[k] = fmaxf(y[k], fl[k]);
+                        }
+                        if (a.skip) {
+                            y[0] += Half16<H>::lo(sk[s][r].x); y[1] += Half16<H>::hi(sk[s][r].x);
+                            y[2] += Half16<H>::lo(sk[s][r].y); y[3] += Half16<H>::hi(sk[s][r].y);
+                        }
+                        if (a.epi & PSCV_EPI_RELU_POST) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) y[k] = fmaxf(y[k], 0.0f);
+                        }
+                        if (a.out_f32) {
+                            *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + vox * a.out_cs + a.out_co + c0) =
+                                make_float4(y[0], y[1], y[2], y[3]);
+                        } else {
+                            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.out) + vox * a.out_cs + a.out_co + c0) =
+                                make_uint2(Half16<H>::pack(y[0], y[1]), Half16<H>::pack(y[2], y[3]));
+                        }
+                    }
+                }
+                fetch_skip(dd + 2 * PD, sk[s]);
+                ring += 2;
+                ring = ring >= SW_NSLOT ? ring - SW_NSLOT : ring;
+                __syncthreads();
+            }
+        }
+    }
+}
+
 }  // namespace pscv
+
+template <typename H, int CIN, int PD>
+static int sweepc_launch_t(pscv::SweepArgs& a, long nblk, hipStream_t st) {
+    using namespace pscv;
+    static bool attr_done = false;
+    constexpr int lds = ScGeom<CIN>::LDS;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_sweepc_kernel<H, CIN, PD>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) { set_error("pscv_conv3d(sweep): hipFuncSetAttribute: %s", hipGetErrorString(e)); return -2; }
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv3d_sweepc_kernel<H, CIN, PD>), dim3((unsigned)nblk), dim3(256), lds, st, a);
+    return 0;
+}
+template <typename H, int CIN>
+static int sweepc_launch_pd(pscv::SweepArgs& a, long nblk, hipStream_t st) {
+    // measured on MI355X over the six Vis stage shapes of BASELINE configurations 3 and 5 (scripts/kbench.py --only vis): distance 1
+    // wins or ties everywhere -- deeper FIFOs cost a wave of occupancy (C_in = 16: 156 -> 182 VGPRs), and resident workgroups hide
+    // more latency than registers do
+    const int pd = pscv::g_sweepc_pd > 0 ? pscv::g_sweepc_pd : 1;
+    return pd == 1 ? sweepc_launch_t<H, CIN, 1>(a, nblk, st) : pd == 2 ? sweepc_launch_t<H, CIN, 2>(a, nblk, st)
+                                                                       : sweepc_launch_t<H, CIN, 3>(a, nblk, st);
+}
+
+// entry used by pscv_conv3d (conv3d.hip) for kind == PSCV_CONV_S1P8 with c_in = 8 or 16
+int pscv_conv3d_sweepc_launch(const void* in, int dtype, int c_in, int in_cstride, int in_coff, const uint16_t* packed,
+                              const float* scale, const float* bias, const float* floor, const void* skip, int skip_cstride,
+                              int skip_coff, void* out, int out_cstride, int out_coff, int out_dtype, int B, int D, int Hh, int W,
+                              int epi_flags, hipStream_t st) {
+    using namespace pscv;
+    SweepArgs a;
+    a.in = reinterpret_cast<const uint16_t*>(in);
+    a.wpk = packed; a.scale = scale; a.bias = bias; a.floor = floor;
+    a.skip = reinterpret_cast<const uint16_t*>(skip);
+    a.out = out;
+    a.in_cs = in_cstride; a.in_co = in_coff; a.skip_cs = skip_cstride; a.skip_co = skip_coff;
+    a.out_cs = out_cstride; a.out_co = out_coff; a.out_f32 = out_dtype == PSCV_F32;
+    a.B = B; a.D = D; a.Hh = Hh; a.W = W; a.epi = epi_flags;
+    a.nth = (Hh + 7) / 8;
+    a.ntw = (W + 15) / 16;
+    // one resident round of workgroups (4 per CU); each depth-chunk seam re-reads two halo planes
+    const long tiles = (long)B * a.nth * a.ntw;
+    const long slots = g_sweepc_slots > 0 ? g_sweepc_slots : 768;
+    const long ndc_want = tiles >= slots ? 1 : slots / tiles;
+    int dc = (int)((D + ndc_want - 1) / ndc_want);
+    dc = (dc + 1) & ~1;
+    dc = dc < 4 ? 4 : dc;
+    if (g_sweep_dc > 0) dc = g_sweep_dc & ~1;
+    dc = dc > D ? ((D + 1) & ~1) : dc;
+    a.dc = dc;
+    a.ndc = (D + dc - 1) / dc;
+    const long nblk = tiles * a.ndc;
+    if (nblk <= 0 || nblk > 0x7fffffffL) { set_error("pscv_conv3d(sweep): bad grid %ld", nblk); return -1; }
+    if (c_in == 8) return dtype == PSCV_BF16 ? sweepc_launch_pd<bf16_t, 8>(a, nblk, st) : sweepc_launch_pd<f16_t, 8>(a, nblk, st);
+    return dtype == PSCV_BF16 ? sweepc_launch_pd<bf16_t, 16>(a, nblk, st) : sweepc_launch_pd<f16_t, 16>(a, nblk, st);
+}
 
 // entry used by pscv_conv3d (conv3d.hip) for kind == PSCV_CONV_S1P8
 int pscv_conv3d_sweep8_launch(const void* in, int dtype, int in_cstride, int in_coff, const uint16_t* packed,

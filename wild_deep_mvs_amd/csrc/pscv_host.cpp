@@ -29,7 +29,8 @@ extern "C" int pscv_abi_version(void) { return PSCV_ABI_VERSION; }
 //
 // Special layouts:
 //   S1P8  depth-sweep [p_rel 0..3][tap (kh,kw) 0..8][lane][8]: rows 0-7 hold kernel slice kd = p_rel for output plane d,
-//         rows 8-15 hold kd = p_rel - 1 for output plane d+1 (zero where kd falls outside 0..2).
+//         rows 8-15 hold kd = p_rel - 1 for output plane d+1 (zero where kd falls outside 0..2).  c_in = 16: [pair 0..1][tap]
+//         with lane group g holding plane 2 pair + (g >> 1), channels 8 (g & 1) + j; c_in = 8: [tap] with group g = plane g.
 //   T2P8  parity-pair: 9 k-steps ordered (pd, ph, sub_d <= pd, sub_h <= ph); K = 32 = two W taps (input x, x+1) x 16
 //         channels; rows 0-7 = output x parity 0 (kernel index kw = 1 on tap 0), rows 8-15 = parity 1 (kw = 2 on tap 0,
 //         kw = 0 on tap 1).  Along D / H a parity-1 class takes kernel index 0 at input offset +1 (sub 0) and kernel
@@ -47,7 +48,7 @@ __host__ __device__ static int pk_ceil_div(int a, int b) { return (a + b - 1) / 
 __host__ __device__ static int pk_t2_ntaps(int pc) { return (1 + ((pc >> 2) & 1)) * (1 + ((pc >> 1) & 1)) * (1 + (pc & 1)); }
 
 __host__ __device__ static long pack_count(const PackDesc& d) {
-    if (d.kind == PSCV_CONV_S1P8) return 4L * 9 * 64 * 8;
+    if (d.kind == PSCV_CONV_S1P8) return (long)(4 * 9 * d.c_in / 32) * 64 * 8;
     if (d.kind == PSCV_CONV_T2P8) return 9L * 64 * 8;
     if (d.kind == PSCV_CONV_S1C1) return (long)(8 * 9 * d.c_in / 32) * 64 * 8;
     const int nt = pk_ceil_div(d.c_out, 16);
@@ -67,9 +68,16 @@ __host__ __device__ static float pack_value(const float* w, const PackDesc& d, l
     const long blk = idx >> 9;
     const int m = lane & 15, g = lane >> 4;
     if (d.kind == PSCV_CONV_S1P8) {
-        const int t = (int)(blk % 9), p = (int)(blk / 9);
-        const int ci = g * 8 + j, co = m & 7, kd = m < 8 ? p : p - 1;
-        return (kd >= 0 && kd <= 2) ? w[((long)co * c_in + ci) * 27 + kd * 9 + t] : 0.f;
+        // one MFMA reduces over 32 = (planes x channels): c_in 32: one plane; 16: planes 2 (blk / 9) + (g >> 1), channel half
+        // g & 1; 8: planes g (conv3d_sweep.hip)
+        const int t = (int)(blk % 9);
+        const int p = c_in == 32 ? (int)(blk / 9) : c_in == 16 ? 2 * (int)(blk / 9) + (g >> 1) : g;
+        const int ci = c_in == 32 ? g * 8 + j : c_in == 16 ? (g & 1) * 8 + j : j;
+        const int co = m & 7, kd = m < 8 ? p : p - 1;
+        if (kd < 0 || kd > 2) return 0.f;
+        if (d.transposed)    // stride-1 deconv == conv with flipped taps and swapped channel axes
+            return w[((long)ci * c_out + co) * 27 + (2 - kd) * 9 + (8 - t)];
+        return w[((long)co * c_in + ci) * 27 + kd * 9 + t];
     }
     if (d.kind == PSCV_CONV_T2P8) {
         const int step = (int)blk;
@@ -132,7 +140,8 @@ static int pack_check(const PackDesc& d, int dtype, const char* fn) {
     PSCV_CHECK_ARG(d.kind != PSCV_CONV_T2 || d.transposed, "%s: T2 needs a ConvTranspose3d weight", fn);
     PSCV_CHECK_ARG(d.kind != PSCV_CONV_S2 || !d.transposed, "%s: S2 takes a Conv3d weight", fn);
     PSCV_CHECK_ARG(dtype == PSCV_BF16 || dtype == PSCV_F16, "%s: dtype %d must be bf16 or fp16", fn, dtype);
-    PSCV_CHECK_ARG(d.kind != PSCV_CONV_S1P8 || (d.c_in == 32 && d.c_out == 8 && !d.transposed), "%s: S1P8 is Conv3d 32 -> 8 only", fn);
+    PSCV_CHECK_ARG(d.kind != PSCV_CONV_S1P8 || ((d.c_in == 8 || d.c_in == 16 || d.c_in == 32) && d.c_out == 8),
+                   "%s: S1P8 is 8|16|32 -> 8 only", fn);
     PSCV_CHECK_ARG(d.kind != PSCV_CONV_T2P8 || (d.c_in == 16 && d.c_out == 8 && d.transposed), "%s: T2P8 is ConvTranspose3d 16 -> 8 only", fn);
     PSCV_CHECK_ARG(d.kind != PSCV_CONV_S1C1 || (d.c_out == 1 && (d.c_in == 8 || d.c_in == 16) && !d.transposed),
                    "%s: S1C1 is Conv3d 8|16 -> 1 only", fn);

@@ -248,6 +248,8 @@ static int g_warp_tiled = 0;     // 1: use the LDS-staged kernel (warp_cost_tile
 extern int g_conv_small_tiles;   // conv3d.hip
 extern int g_sweep_th16;         // conv3d_sweep.hip
 extern int g_sweep_dc;
+extern int g_sweepc_slots;
+extern int g_sweepc_pd;
 }
 extern int g_c1_nb;
 namespace pscv {
@@ -347,6 +349,8 @@ extern "C" int pscv_set_tuning(const char* key, int value) {
     if (!strcmp(key, "c1_nb")) { g_c1_nb = value; return 0; }
     if (!strcmp(key, "sweep_th16")) { g_sweep_th16 = value; return 0; }
     if (!strcmp(key, "sweep_dc")) { g_sweep_dc = value; return 0; }
+    if (!strcmp(key, "sweepc_slots")) { g_sweepc_slots = value; return 0; }
+    if (!strcmp(key, "sweepc_pd")) { g_sweepc_pd = value; return 0; }
     if (!strcmp(key, "warp_bwd_direct")) { g_warp_bwd_direct = value; return 0; }
     set_error("pscv_set_tuning: unknown key '%s'", key);
     return -1;
