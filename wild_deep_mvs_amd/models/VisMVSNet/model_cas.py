@@ -117,14 +117,21 @@ class _RegUNet(nn.Module):
             dec = list(self.unet.dec_blocks.values())[0]
             dev = b0.conv1.weight.device
             mk = ops.Conv3dLayer.build
-            # the strided 1x1x1 shortcut conv is the centre tap of a 3x3x3 stride-2 conv (in = 2*out + 1 - 1)
+            # the strided 1x1x1 shortcut conv is the centre tap of a 3x3x3 stride-2 conv (in = 2*out + 1 - 1), so the block's
+            # conv1 and its shortcut are ONE 8 -> 32 stride-2 launch over the same input brick: channels 0-15 = relu(bn1(conv1)),
+            # channels 16-31 = bn_ds(shortcut) (per-channel ReLU floor: 0 / -inf); conv2 then reads [0,16) and adds [16,32)
             ds_w = torch.zeros(16, 8, 3, 3, 3, dtype=torch.float32, device=dev)
             ds_w[:, :, 1, 1, 1] = b1.downsample[0].weight.detach().float().view(16, 8)
+            bn_ds = b1.downsample[1]
+            if b1.bn1.eps != bn_ds.eps:
+                raise ValueError("pscv Vis U-Net: BasicBlock.bn1 and the shortcut's BatchNorm must share eps")
+            e1_w = torch.cat([b1.conv1.weight.detach().float(), ds_w], dim=0)
+            e1_bn = tuple(torch.cat([p_.detach().float(), q_.detach().float()]) for p_, q_ in zip(_bn_tuple(b1.bn1), _bn_tuple(bn_ds)))
+            e1_floor = torch.cat([torch.zeros(16), torch.full((16,), float("-inf"))])
             self._lay = {
                 "e0c1": mk(b0.conv1.weight, kind=L.CONV_S1, device=dev, bn=_bn_tuple(b0.bn1), bn_eps=b0.bn1.eps, relu=True, dtype=dtype),
                 "e0c2": mk(b0.conv2.weight, kind=L.CONV_S1, device=dev, bn=_bn_tuple(b0.bn2), bn_eps=b0.bn2.eps, relu_post=True, dtype=dtype),
-                "e1c1": mk(b1.conv1.weight, kind=L.CONV_S2, device=dev, bn=_bn_tuple(b1.bn1), bn_eps=b1.bn1.eps, relu=True, dtype=dtype),
-                "e1ds": mk(ds_w, kind=L.CONV_S2, device=dev, bn=_bn_tuple(b1.downsample[1]), bn_eps=b1.downsample[1].eps, dtype=dtype),
+                "e1c1ds": mk(e1_w, kind=L.CONV_S2, device=dev, bn=e1_bn, bn_eps=b1.bn1.eps, relu=True, floor=e1_floor, dtype=dtype),
                 "e1c2": mk(b1.conv2.weight, kind=L.CONV_S1, device=dev, bn=_bn_tuple(b1.bn2), bn_eps=b1.bn2.eps, relu_post=True, dtype=dtype),
                 "dec": mk(dec[0].weight, kind=L.CONV_T2, transposed=True, device=dev, dtype=dtype),
                 "post": mk(dec[1].weight, kind=L.CONV_S1, device=dev, dtype=dtype),
@@ -144,9 +151,8 @@ class _RegUNet(nn.Module):
         cat = torch.empty((n, d, h, w, 16), dtype=x.dtype, device=x.device)       # [deconv | enc0] (nn_utils.py:269-271)
         t = ops.conv3d(x, ly["e0c1"])
         ops.conv3d(t, ly["e0c2"], skip=x, out=cat, out_coff=8)                    # enc0 -> cat[..., 8:16]
-        t1 = ops.conv3d(cat, ly["e1c1"], in_coff=8)
-        ds = ops.conv3d(cat, ly["e1ds"], in_coff=8)
-        e1 = ops.conv3d(t1, ly["e1c2"], skip=ds)
+        t1ds = ops.conv3d(cat, ly["e1c1ds"], in_coff=8)                           # [relu(bn1(conv1)) | bn_ds(shortcut)]
+        e1 = ops.conv3d(t1ds, ly["e1c2"], skip=t1ds, skip_coff=16)
         ops.conv3d(e1, ly["dec"], out=cat, out_coff=0)                            # deconv -> cat[..., 0:8]
         return ops.conv3d(cat, ly["post"])
 
