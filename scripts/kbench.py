@@ -55,6 +55,22 @@ def main():
             print(f"conv0 sweep dc={dc:3d}: {us:8.1f} us")
         L.set_tuning("sweep_dc", 0)
         return
+    if args.only == "cvp":
+        # the 64-channel layers of CVP-MVSNet (config 4): FeaturePyramid 64 -> 64 at 5 x 1024 x 1280 and the refinement U-Net's
+        # 64 -> 64 3-D conv at 4 x 512 x 640
+        x2 = (torch.randn(5, 1024, 1280, 64, generator=g) * 0.5).to(dt).to(dev)
+        w2 = torch.randn(64, 64, 3, 3, generator=g) / (9 * 64) ** 0.5
+        l2 = ops.Conv2dLayer.build(w2, stride=1, device=dev, dtype=dt, leaky=0.1)
+        x3 = (torch.randn(1, 4, 512, 640, 64, generator=g) * 0.5).to(dt).to(dev)
+        w3 = torch.randn(64, 64, 3, 3, 3, generator=g) / (27 * 64) ** 0.5
+        l3 = ops.Conv3dLayer.build(w3, kind=L.CONV_S1, device=dev, relu=True, dtype=dt)
+        t2 = timeit(lambda: ops.conv2d(x2, l2), args.reps)
+        t3 = timeit(lambda: ops.conv3d(x3, l3), args.reps)
+        f2 = 5 * 1024 * 1280 * 64 * 64 * 9 * 2 / 1e12
+        f3 = 4 * 512 * 640 * 64 * 64 * 27 * 2 / 1e12
+        print(f"conv2d 64->64 @5x1024x1280 {t2:8.1f} us ({f2 / t2 * 1e6:6.0f} TFLOP/s)   "
+              f"conv3d 64->64 @4x512x640 {t3:8.1f} us ({f3 / t3 * 1e6:6.0f} TFLOP/s)")
+        return
     if args.only == "vis":
         # the Vis-MVSNet U-Net's full-resolution layers (8 -> 8 with residual, 16 -> 8 after the concat): narrow depth-sweep
         # kernel (default) against the generic brick kernel, at stage-1 sizes of BASELINE configurations 3 and 5

@@ -104,7 +104,10 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const Conv2dArgs a) {
 
     {   // ---- stage the brick: a wave takes whole rows (row arithmetic is scalar), a lane its chunk(s) of the row ----
         constexpr int ROWCH = BW * CCH, NPASS = c2_ceil_div(ROWCH, 64);
-        constexpr int RB = (8 / NPASS) < 1 ? 1 : 8 / NPASS;   // rows per load batch
+        // rows per load batch: every batch exposes one global-memory latency, so the wide layers (whose k-loop needs few other
+        // registers at this point) take all of a wave's rows in ONE batch (64 channels: 3 rows x 5 chunks = 60 VGPRs in flight)
+        constexpr int RB_CAP = CIN >= 64 ? 16 : 8;
+        constexpr int RB = (RB_CAP / NPASS) < 1 ? 1 : RB_CAP / NPASS;
         const unsigned row_bytes = (unsigned)a.Wi * CIN * 2u;
         const char* inb = reinterpret_cast<const char*>(a.in) + (unsigned long)b * a.Hi * row_bytes;
         unsigned goff[NPASS];
