@@ -58,7 +58,7 @@ extern "C" {
 #define PSCV_CONV_S1 0 /* Conv3d k3 s1 p1 (also ConvTranspose3d k3 s1 p1, packed flipped) */
 #define PSCV_CONV_S2 1 /* Conv3d k3 s2 p1 */
 #define PSCV_CONV_T2 2 /* ConvTranspose3d k3 s2 p1 output_padding 1 */
-#define PSCV_CONV_S1P8 3 /* Conv3d k3 s1 p1 (or ConvTranspose3d k3 s1 p1) with c_in = 8, 16 or 32 and c_out = 8 on the depth-sweep
+#define PSCV_CONV_S1P8 3 /* Conv3d k3 s1 p1 (or ConvTranspose3d k3 s1 p1) with c_in = 8, 16 or 32 and c_out = 8, or 16 -> 16, on the depth-sweep
                             kernels (plane-pair packed MFMA rows, register-resident weights); same result as PSCV_CONV_S1, own
                             packed layout */
 #define PSCV_CONV_T2P8 5 /* ConvTranspose3d k3 s2 p1 op1 with c_in = 16, c_out = 8 on the parity-pair packed kernel; same

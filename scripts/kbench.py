@@ -64,6 +64,28 @@ def main():
         x3 = (torch.randn(1, 4, 512, 640, 64, generator=g) * 0.5).to(dt).to(dev)
         w3 = torch.randn(64, 64, 3, 3, 3, generator=g) / (27 * 64) ** 0.5
         l3 = ops.Conv3dLayer.build(w3, kind=L.CONV_S1, device=dev, relu=True, dtype=dt)
+        for (Dv, hv, wv) in ((8, 1024, 1280), (8, 512, 640), (96, 64, 80), (48, 32, 40)):       # 16 -> 16: conv0 / conv0a, MVSNet conv2
+            x = (torch.randn(1, Dv, hv, wv, 16, generator=g) * 0.5).to(dt).to(dev)
+            wt = torch.randn(16, 16, 3, 3, 3, generator=g) / (27 * 16) ** 0.5
+            out = torch.empty(1, Dv, hv, wv, 16, dtype=dt, device=dev)
+            res = {}
+            for use in (True, False):
+                ops.USE_SWEEP_KERNEL = use
+                layer = ops.Conv3dLayer.build(wt, kind=L.CONV_S1, device=dev, relu=True, dtype=dt)
+                ops.USE_SWEEP_KERNEL = True
+                res[use] = timeit(lambda: ops.conv3d(x, layer, out=out), args.reps)
+            gb = Dv * hv * wv * 64 / 1e9
+            print(f"conv3d 16->16 @ {Dv}x{hv}x{wv}: sweep {res[True]:8.1f} us ({gb / res[True] * 1e6:6.0f} GB/s)   brick {res[False]:8.1f} us")
+            if args.reps > 20:
+                layer = ops.Conv3dLayer.build(wt, kind=L.CONV_S1, device=dev, relu=True, dtype=dt)
+                for pd in (1, 2, 3):
+                    L.set_tuning("sweepc_pd", pd)
+                    row = []
+                    for slots in (512, 768, 1024, 2048):
+                        L.set_tuning("sweepc_slots", slots)
+                        row.append(f"{slots}: {timeit(lambda: ops.conv3d(x, layer, out=out), args.reps):6.1f}")
+                    print(f"    prefetch distance {pd}  " + "  ".join(row))
+                L.set_tuning("sweepc_pd", 0); L.set_tuning("sweepc_slots", 0)
         t2 = timeit(lambda: ops.conv2d(x2, l2), args.reps)
         t3 = timeit(lambda: ops.conv3d(x3, l3), args.reps)
         f2 = 5 * 1024 * 1280 * 64 * 64 * 9 * 2 / 1e12

@@ -227,6 +227,50 @@ def test_narrow_sweep_kernel_matches_brick_kernel_and_aten(env, cin, shape, tran
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape,transposed,dc", [((16, 16, 32), False, 0), ((13, 11, 21), False, 4), ((37, 9, 40), True, 0), ((2, 3, 5), False, 0),
+                                                 ((9, 37, 24), False, 6)])
+def test_sweep16_kernel_matches_brick_kernel_and_aten(env, shape, transposed, dc, dtype):
+    """The 16 -> 16 depth-sweep variant (CVP-MVSNet's full-resolution conv0 / conv0a, MVSNet's conv2) against the brick kernel and
+    ATen: off-tile sizes, odd D, forced chunk seams, BN + ReLU + skip, channel slices, stride-1 ConvTranspose3d weights."""
+    L, ops = env
+    g = torch.Generator().manual_seed(16 + sum(shape))
+    D, H, W = shape
+    wide = bf16_round(torch.randn(2, 32, D, H, W, generator=g))
+    x = wide[:, 8:24]
+    if transposed:
+        w = bf16_round(torch.randn(16, 16, 3, 3, 3, generator=g) / np.sqrt(27 * 16))
+        conv = F.conv_transpose3d(x, w, padding=1)
+    else:
+        w = bf16_round(torch.randn(16, 16, 3, 3, 3, generator=g) / np.sqrt(27 * 16))
+        conv = F.conv3d(x, w, padding=1)
+    gamma, beta = torch.rand(16, generator=g) + 0.5, torch.randn(16, generator=g) * 0.3
+    mean, var = torch.randn(16, generator=g) * 0.2, torch.rand(16, generator=g) + 0.5
+    skip_wide = bf16_round(torch.randn(2, 24, D, H, W, generator=g))
+    ref = F.relu(F.batch_norm(conv, mean, var, gamma, beta, training=False, eps=1e-5)) + skip_wide[:, 4:20]
+    xcl, scl = ops.to_channels_last(wide.cuda(), dtype), ops.to_channels_last(skip_wide.cuda(), dtype)
+    outs = {}
+    for use in (True, False):
+        ops.USE_SWEEP_KERNEL = use
+        try:
+            layer = ops.Conv3dLayer.build(w, kind=L.CONV_S1, transposed=transposed, device="cuda", bn=(gamma, beta, mean, var), relu=True,
+                                          dtype=dtype)
+        finally:
+            ops.USE_SWEEP_KERNEL = True
+        assert layer.kind == (L.CONV_S1P8 if use else L.CONV_S1)
+        out = torch.full((2, D, H, W, 24), 7.0, dtype=dtype, device="cuda")
+        L.set_tuning("sweep_dc", dc)
+        try:
+            ops.conv3d(xcl, layer, in_coff=8, skip=scl, skip_coff=4, out=out, out_coff=4)
+        finally:
+            L.set_tuning("sweep_dc", 0)
+        assert bool((out[..., :4] == 7.0).all()) and bool((out[..., 20:] == 7.0).all())
+        outs[use] = out[..., 4:20].float().permute(0, 4, 1, 2, 3).cpu()
+    ulp = 2 ** -8 if dtype == torch.bfloat16 else 2 ** -11
+    check_close(f"sweep16 vs ATen {shape} {dtype}", outs[True], ref, max_abs=ulp * float(ref.abs().max()) + 2e-3)
+    check_close(f"sweep16 vs brick {shape} {dtype}", outs[True], outs[False], max_abs=ulp * float(ref.abs().max()) + 1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("cin,shape,out_dtype", [(8, (16, 16, 32), torch.float32), (8, (13, 11, 45), torch.float32),
                                                  (16, (9, 8, 33), torch.float32), (8, (5, 17, 64), None)])
 def test_one_channel_dot2_kernel_matches_mfma_kernel_and_aten(env, cin, shape, out_dtype, dtype):
@@ -302,7 +346,7 @@ def test_device_weight_packing_equals_host_packing(dtype):
     from wild_deep_mvs_amd import _lib as L, ops
     g = torch.Generator().manual_seed(5)
     cases = [(8, 32, L.CONV_S1, False), (32, 8, L.CONV_S1, True), (64, 32, L.CONV_S1, True), (16, 8, L.CONV_S2, False),
-             (64, 32, L.CONV_S2, False), (64, 32, L.CONV_T2, True), (32, 16, L.CONV_T2, True), (8, 32, L.CONV_S1P8, False), (8, 8, L.CONV_S1P8, False), (8, 16, L.CONV_S1P8, False), (8, 8, L.CONV_S1P8, True),
+             (64, 32, L.CONV_S2, False), (64, 32, L.CONV_T2, True), (32, 16, L.CONV_T2, True), (8, 32, L.CONV_S1P8, False), (8, 8, L.CONV_S1P8, False), (8, 16, L.CONV_S1P8, False), (8, 8, L.CONV_S1P8, True), (16, 16, L.CONV_S1P8, False), (16, 16, L.CONV_S1P8, True),
              (16, 8, L.CONV_T2P8, True), (1, 8, L.CONV_S1C1, False), (1, 16, L.CONV_S1C1, False)]
     for a, b, kind, tr in cases:
         w = torch.randn(a, b, 3, 3, 3, generator=g)

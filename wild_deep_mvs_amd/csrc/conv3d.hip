@@ -406,7 +406,7 @@ int pscv_conv3d_sweep8_launch(const void* in, int dtype, int in_cstride, int in_
                               int skip_cstride, int skip_coff, void* out, int out_cstride, int out_coff, int out_dtype,
                               int B, int D, int Hh, int W, int epi_flags, hipStream_t st);
 
-int pscv_conv3d_sweepc_launch(const void* in, int dtype, int c_in, int in_cstride, int in_coff, const uint16_t* packed,
+int pscv_conv3d_sweepc_launch(const void* in, int dtype, int c_in, int c_out, int in_cstride, int in_coff, const uint16_t* packed,
                               const float* scale, const float* bias, const float* floor, const void* skip, int skip_cstride,
                               int skip_coff, void* out, int out_cstride, int out_coff, int out_dtype, int B, int D, int Hh, int W,
                               int epi_flags, hipStream_t st);
@@ -436,12 +436,12 @@ extern "C" int pscv_conv3d(const void* in, int dtype, int in_cstride, int in_cof
     PSCV_CHECK_ARG(dtype == PSCV_BF16 || dtype == PSCV_F16, "pscv_conv3d: storage dtype %d must be bf16 or fp16", dtype);
     PSCV_CHECK_ARG(out_dtype == dtype || out_dtype == PSCV_F32, "pscv_conv3d: out dtype %d must be the storage dtype or fp32", out_dtype);
     if (kind == PSCV_CONV_S1P8) {
-        PSCV_CHECK_ARG((c_in == 8 || c_in == 16 || c_in == 32) && c_out == 8,
-                       "pscv_conv3d: the sweep kernels (S1P8) are for c_in=8|16|32, c_out=8 (got %d -> %d)", c_in, c_out);
+        PSCV_CHECK_ARG(((c_in == 8 || c_in == 16 || c_in == 32) && c_out == 8) || (c_in == 16 && c_out == 16),
+                       "pscv_conv3d: the sweep kernels (S1P8) are for 8|16|32 -> 8 and 16 -> 16 (got %d -> %d)", c_in, c_out);
         const int rc = c_in == 32
             ? pscv_conv3d_sweep8_launch(in, dtype, in_cstride, in_coff, packed, scale, bias, floor, skip, skip_cstride, skip_coff, out,
                                         out_cstride, out_coff, out_dtype, B, Di, Hi, Wi, epi_flags, reinterpret_cast<hipStream_t>(stream))
-            : pscv_conv3d_sweepc_launch(in, dtype, c_in, in_cstride, in_coff, packed, scale, bias, floor, skip, skip_cstride, skip_coff,
+            : pscv_conv3d_sweepc_launch(in, dtype, c_in, c_out, in_cstride, in_coff, packed, scale, bias, floor, skip, skip_cstride, skip_coff,
                                         out, out_cstride, out_coff, out_dtype, B, Di, Hi, Wi, epi_flags,
                                         reinterpret_cast<hipStream_t>(stream));
         if (rc) return rc;

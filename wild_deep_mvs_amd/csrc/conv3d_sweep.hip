@@ -261,8 +261,14 @@ template <int CIN> struct ScGeom {
     static constexpr int NM = 4 * 9 * CIN / 32;              // MFMAs per plane pair and pixel row
 };
 
-template <typename H, int CIN, int PD>
-__global__ __launch_bounds__(256, (CIN == 8 && PD <= 2) ? 4 : (CIN == 8 || PD == 1) ? 3 : 2) void conv3d_sweepc_kernel(const SweepArgs a) {
+// COUT = 16 (C_in = 16 only; CVP-MVSNet's full-resolution conv0 / conv0a, MVSNet's conv2): the 16 MFMA rows are the 16 output
+// channels of ONE plane, so an iteration runs the tap loop twice (output planes dd and dd+1, same A fragments); the reduction
+// pairs planes (o-1, o) and (o, o+1) -- the repeated plane o carries zero weights in the second set, which keeps every read inside
+// the four ring slots that are already synchronised (a plane o+2 with zero weights could still be uninitialised LDS: 0 x NaN).
+template <typename H, int CIN, int PD, int COUT = 8>
+__global__ __launch_bounds__(256, (CIN == 8 && PD <= 2) ? 4 : (CIN == 8 || (PD == 1 && COUT == 8)) ? 3 : 2) void conv3d_sweepc_kernel(const SweepArgs a) {
+    static_assert(COUT == 8 || (COUT == 16 && CIN == 16), "narrow sweep: 8|16 -> 8 or 16 -> 16");
+    constexpr int NOP = COUT == 16 ? 2 : 1;      // output planes a lane finishes per iteration
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using G = ScGeom<CIN>;
     constexpr int VB = G::VB, CCH = G::CCH, PB = G::PB, CHUNKS = G::CHUNKS, NLD = G::NLD, NM = G::NM;
@@ -328,7 +334,7 @@ __global__ __launch_bounds__(256, (CIN == 8 && PD <= 2) ? 4 : (CIN == 8 || PD ==
             if (lval[i]) *reinterpret_cast<uint4*>(sp + loff[i]) = reg[i];
     };
 
-    const int c0 = (g & 1) * 4;
+    const int c0 = COUT == 16 ? g * 4 : (g & 1) * 4;
     float sc[4], bi[4], fl[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -346,13 +352,16 @@ __global__ __launch_bounds__(256, (CIN == 8 && PD <= 2) ? 4 : (CIN == 8 || PD ==
         vrow[r] = ((long)b * a.D * a.Hh + (h0 + row0 + r)) * a.W + w0 + n;
     }
     const long vplane = (long)a.Hh * a.W;
-    auto fetch_skip = [&](int dd, uint2 (&reg)[R]) {
-        const int od = dd + (g >> 1);
+    auto fetch_skip = [&](int dd, uint2 (&reg)[NOP][R]) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            reg[r] = make_uint2(0u, 0u);
-            if (a.skip && od < dend && row_ok[r])
-                reg[r] = *reinterpret_cast<const uint2*>(a.skip + (vrow[r] + od * vplane) * a.skip_cs + a.skip_co + c0);
+        for (int op = 0; op < NOP; ++op) {
+            const int od = COUT == 16 ? dd + op : dd + (g >> 1);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                reg[op][r] = make_uint2(0u, 0u);
+                if (a.skip && od < dend && row_ok[r])
+                    reg[op][r] = *reinterpret_cast<const uint2*>(a.skip + (vrow[r] + od * vplane) * a.skip_cs + a.skip_co + c0);
+            }
         }
     };
 
@@ -366,7 +375,7 @@ __global__ __launch_bounds__(256, (CIN == 8 && PD <= 2) ? 4 : (CIN == 8 || PD ==
         stash(2, ra); stash(3, rb);
     }
     uint4 pfa[PD][NLD], pfb[PD][NLD];
-    uint2 sk[PD][R];
+    uint2 sk[PD][NOP][R];
 #pragma unroll
     for (int s = 0; s < PD; ++s) {
         fetch(dbeg + 3 + 2 * s, pfa[s]);
@@ -391,50 +400,62 @@ __global__ __launch_bounds__(256, (CIN == 8 && PD <= 2) ? 4 : (CIN == 8 || PD ==
                 fetch(dd + 3 + 2 * PD, pfa[s]);
                 fetch(dd + 4 + 2 * PD, pfb[s]);
 
-                sw_f32x4 acc[R];
+                sw_f32x4 acc[NOP][R];
 #pragma unroll
-                for (int r = 0; r < R; ++r) acc[r] = sw_f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int op = 0; op < NOP; ++op)
 #pragma unroll
-                for (int set = 0; set < NM / 9; ++set) {
-                    int sl = ring + pl0 + 2 * set;
-                    sl = sl >= SW_NSLOT ? sl - SW_NSLOT : sl;
-                    const unsigned char* sp = smem + sl * PB;
+                    for (int r = 0; r < R; ++r) acc[op][r] = sw_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int kh = 0; kh < 3; ++kh)
+                for (int op = 0; op < NOP; ++op)
 #pragma unroll
-                        for (int kw = 0; kw < 3; ++kw)
+                    for (int set = 0; set < NM / 9; ++set) {
+                        // COUT 8: planes dd-1 + pl0 (+2 for the second set); COUT 16: output dd+op reads (o-1, o) then (o, o+1)
+                        int sl = ring + pl0 + (COUT == 16 ? op + set : 2 * set);
+                        sl = sl >= SW_NSLOT ? sl - SW_NSLOT : sl;
+                        const unsigned char* sp = smem + sl * PB;
 #pragma unroll
-                            for (int r = 0; r < R; ++r) {
-                                const uint4 xf = *reinterpret_cast<const uint4*>(sp + boff[r + kh][kw]);
-                                acc[r] = SwMfma<H>::run(wf[set * 9 + kh * 3 + kw], xf, acc[r]);
-                            }
-                }
+                        for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+                            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                                for (int r = 0; r < R; ++r) {
+                                    const uint4 xf = *reinterpret_cast<const uint4*>(sp + boff[r + kh][kw]);
+                                    acc[op][r] = SwMfma<H>::run(wf[set * 9 + kh * 3 + kw], xf, acc[op][r]);
+                                }
+                            // 72 MFMAs per iteration: fence the scheduler per tap row, or it hoists the independent LDS reads of all
+                            // four (plane, set) blocks and spills ~150 registers
+                            if (COUT == 16) __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
 
-                const int od = dd + (g >> 1);
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    if (od < dend && row_ok[r]) {
-                        const long vox = vrow[r] + od * vplane;
-                        float y[4];
+                for (int op = 0; op < NOP; ++op) {
+                    const int od = COUT == 16 ? dd + op : dd + (g >> 1);
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            y[k] = fmaf(acc[r][k], sc[k], bi[k]);
-                            if (a.epi & PSCV_EPI_RELU_PRE) y[k] = fmaxf(y[k], fl[k]);
-                        }
-                        if (a.skip) {
-                            y[0] += Half16<H>::lo(sk[s][r].x); y[1] += Half16<H>::hi(sk[s][r].x);
-                            y[2] += Half16<H>::lo(sk[s][r].y); y[3] += Half16<H>::hi(sk[s][r].y);
-                        }
-                        if (a.epi & PSCV_EPI_RELU_POST) {
+                    for (int r = 0; r < R; ++r) {
+                        if (od < dend && row_ok[r]) {
+                            const long vox = vrow[r] + od * vplane;
+                            float y[4];
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) y[k] = fmaxf(y[k], 0.0f);
-                        }
-                        if (a.out_f32) {
-                            *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + vox * a.out_cs + a.out_co + c0) =
-                                make_float4(y[0], y[1], y[2], y[3]);
-                        } else {
-                            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.out) + vox * a.out_cs + a.out_co + c0) =
-                                make_uint2(Half16<H>::pack(y[0], y[1]), Half16<H>::pack(y[2], y[3]));
+                            for (int k = 0; k < 4; ++k) {
+                                y[k] = fmaf(acc[op][r][k], sc[k], bi[k]);
+                                if (a.epi & PSCV_EPI_RELU_PRE) y[k] = fmaxf(y[k], fl[k]);
+                            }
+                            if (a.skip) {
+                                y[0] += Half16<H>::lo(sk[s][op][r].x); y[1] += Half16<H>::hi(sk[s][op][r].x);
+                                y[2] += Half16<H>::lo(sk[s][op][r].y); y[3] += Half16<H>::hi(sk[s][op][r].y);
+                            }
+                            if (a.epi & PSCV_EPI_RELU_POST) {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) y[k] = fmaxf(y[k], 0.0f);
+                            }
+                            if (a.out_f32) {
+                                *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + vox * a.out_cs + a.out_co + c0) =
+                                    make_float4(y[0], y[1], y[2], y[3]);
+                            } else {
+                                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.out) + vox * a.out_cs + a.out_co + c0) =
+                                    make_uint2(Half16<H>::pack(y[0], y[1]), Half16<H>::pack(y[2], y[3]));
+                            }
                         }
                     }
                 }
@@ -449,32 +470,32 @@ __global__ __launch_bounds__(256, (CIN == 8 && PD <= 2) ? 4 : (CIN == 8 || PD ==
 
 }  // namespace pscv
 
-template <typename H, int CIN, int PD>
+template <typename H, int CIN, int PD, int COUT = 8>
 static int sweepc_launch_t(pscv::SweepArgs& a, long nblk, hipStream_t st) {
     using namespace pscv;
     static bool attr_done = false;
     constexpr int lds = ScGeom<CIN>::LDS;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_sweepc_kernel<H, CIN, PD>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_sweepc_kernel<H, CIN, PD, COUT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) { set_error("pscv_conv3d(sweep): hipFuncSetAttribute: %s", hipGetErrorString(e)); return -2; }
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv3d_sweepc_kernel<H, CIN, PD>), dim3((unsigned)nblk), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv3d_sweepc_kernel<H, CIN, PD, COUT>), dim3((unsigned)nblk), dim3(256), lds, st, a);
     return 0;
 }
-template <typename H, int CIN>
+template <typename H, int CIN, int COUT = 8>
 static int sweepc_launch_pd(pscv::SweepArgs& a, long nblk, hipStream_t st) {
     // measured on MI355X over the six Vis stage shapes of BASELINE configurations 3 and 5 (scripts/kbench.py --only vis): distance 1
     // wins or ties everywhere -- deeper FIFOs cost a wave of occupancy (C_in = 16: 156 -> 182 VGPRs), and resident workgroups hide
     // more latency than registers do
-    const int pd = pscv::g_sweepc_pd > 0 ? pscv::g_sweepc_pd : 1;
-    return pd == 1 ? sweepc_launch_t<H, CIN, 1>(a, nblk, st) : pd == 2 ? sweepc_launch_t<H, CIN, 2>(a, nblk, st)
-                                                                       : sweepc_launch_t<H, CIN, 3>(a, nblk, st);
+    const int pd = pscv::g_sweepc_pd > 0 ? pscv::g_sweepc_pd : (COUT == 16 ? 2 : 1);   // 16 -> 16 runs at two waves per SIMD anyway
+    return pd == 1 ? sweepc_launch_t<H, CIN, 1, COUT>(a, nblk, st) : pd == 2 ? sweepc_launch_t<H, CIN, 2, COUT>(a, nblk, st)
+                                                                             : sweepc_launch_t<H, CIN, 3, COUT>(a, nblk, st);
 }
 
-// entry used by pscv_conv3d (conv3d.hip) for kind == PSCV_CONV_S1P8 with c_in = 8 or 16
-int pscv_conv3d_sweepc_launch(const void* in, int dtype, int c_in, int in_cstride, int in_coff, const uint16_t* packed,
+// entry used by pscv_conv3d (conv3d.hip) for kind == PSCV_CONV_S1P8 with (c_in, c_out) = (8, 8), (16, 8) or (16, 16)
+int pscv_conv3d_sweepc_launch(const void* in, int dtype, int c_in, int c_out, int in_cstride, int in_coff, const uint16_t* packed,
                               const float* scale, const float* bias, const float* floor, const void* skip, int skip_cstride,
                               int skip_coff, void* out, int out_cstride, int out_coff, int out_dtype, int B, int D, int Hh, int W,
                               int epi_flags, hipStream_t st) {
@@ -491,7 +512,7 @@ int pscv_conv3d_sweepc_launch(const void* in, int dtype, int c_in, int in_cstrid
     a.ntw = (W + 15) / 16;
     // one resident round of workgroups (4 per CU); each depth-chunk seam re-reads two halo planes
     const long tiles = (long)B * a.nth * a.ntw;
-    const long slots = g_sweepc_slots > 0 ? g_sweepc_slots : 768;
+    const long slots = g_sweepc_slots > 0 ? g_sweepc_slots : (c_out == 16 ? 512 : 768);
     const long ndc_want = tiles >= slots ? 1 : slots / tiles;
     int dc = (int)((D + ndc_want - 1) / ndc_want);
     dc = (dc + 1) & ~1;
@@ -502,6 +523,7 @@ int pscv_conv3d_sweepc_launch(const void* in, int dtype, int c_in, int in_cstrid
     a.ndc = (D + dc - 1) / dc;
     const long nblk = tiles * a.ndc;
     if (nblk <= 0 || nblk > 0x7fffffffL) { set_error("pscv_conv3d(sweep): bad grid %ld", nblk); return -1; }
+    if (c_out == 16) return dtype == PSCV_BF16 ? sweepc_launch_pd<bf16_t, 16, 16>(a, nblk, st) : sweepc_launch_pd<f16_t, 16, 16>(a, nblk, st);
     if (c_in == 8) return dtype == PSCV_BF16 ? sweepc_launch_pd<bf16_t, 8>(a, nblk, st) : sweepc_launch_pd<f16_t, 8>(a, nblk, st);
     return dtype == PSCV_BF16 ? sweepc_launch_pd<bf16_t, 16>(a, nblk, st) : sweepc_launch_pd<f16_t, 16>(a, nblk, st);
 }

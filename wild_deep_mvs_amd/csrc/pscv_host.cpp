@@ -31,6 +31,7 @@ extern "C" int pscv_abi_version(void) { return PSCV_ABI_VERSION; }
 //   S1P8  depth-sweep [p_rel 0..3][tap (kh,kw) 0..8][lane][8]: rows 0-7 hold kernel slice kd = p_rel for output plane d,
 //         rows 8-15 hold kd = p_rel - 1 for output plane d+1 (zero where kd falls outside 0..2).  c_in = 16: [pair 0..1][tap]
 //         with lane group g holding plane 2 pair + (g >> 1), channels 8 (g & 1) + j; c_in = 8: [tap] with group g = plane g.
+//         16 -> 16: [set 0..1][tap], rows = output channels, set 0 = kernel slices kd = (g >> 1), set 1 = kd 2 for g >> 1 = 1, zero else.
 //   T2P8  parity-pair: 9 k-steps ordered (pd, ph, sub_d <= pd, sub_h <= ph); K = 32 = two W taps (input x, x+1) x 16
 //         channels; rows 0-7 = output x parity 0 (kernel index kw = 1 on tap 0), rows 8-15 = parity 1 (kw = 2 on tap 0,
 //         kw = 0 on tap 1).  Along D / H a parity-1 class takes kernel index 0 at input offset +1 (sub 0) and kernel
@@ -71,9 +72,18 @@ __host__ __device__ static float pack_value(const float* w, const PackDesc& d, l
         // one MFMA reduces over 32 = (planes x channels): c_in 32: one plane; 16: planes 2 (blk / 9) + (g >> 1), channel half
         // g & 1; 8: planes g (conv3d_sweep.hip)
         const int t = (int)(blk % 9);
-        const int p = c_in == 32 ? (int)(blk / 9) : c_in == 16 ? 2 * (int)(blk / 9) + (g >> 1) : g;
+        int p, co, kd;
         const int ci = c_in == 32 ? g * 8 + j : c_in == 16 ? (g & 1) * 8 + j : j;
-        const int co = m & 7, kd = m < 8 ? p : p - 1;
+        if (c_out == 16) {   // 16 -> 16: rows = the 16 channels of one output plane o; set 0 = planes (o-1, o), set 1 = (o, o+1) with
+            const int set = (int)(blk / 9);                      // zero weights on the repeated plane o
+            co = m;
+            kd = set + (g >> 1);
+            if (set == 1 && (g >> 1) == 0) return 0.f;
+        } else {
+            p = c_in == 32 ? (int)(blk / 9) : c_in == 16 ? 2 * (int)(blk / 9) + (g >> 1) : g;
+            co = m & 7;
+            kd = m < 8 ? p : p - 1;
+        }
         if (kd < 0 || kd > 2) return 0.f;
         if (d.transposed)    // stride-1 deconv == conv with flipped taps and swapped channel axes
             return w[((long)ci * c_out + co) * 27 + (2 - kd) * 9 + (8 - t)];
@@ -140,8 +150,8 @@ static int pack_check(const PackDesc& d, int dtype, const char* fn) {
     PSCV_CHECK_ARG(d.kind != PSCV_CONV_T2 || d.transposed, "%s: T2 needs a ConvTranspose3d weight", fn);
     PSCV_CHECK_ARG(d.kind != PSCV_CONV_S2 || !d.transposed, "%s: S2 takes a Conv3d weight", fn);
     PSCV_CHECK_ARG(dtype == PSCV_BF16 || dtype == PSCV_F16, "%s: dtype %d must be bf16 or fp16", fn, dtype);
-    PSCV_CHECK_ARG(d.kind != PSCV_CONV_S1P8 || ((d.c_in == 8 || d.c_in == 16 || d.c_in == 32) && d.c_out == 8),
-                   "%s: S1P8 is 8|16|32 -> 8 only", fn);
+    PSCV_CHECK_ARG(d.kind != PSCV_CONV_S1P8 || ((d.c_in == 8 || d.c_in == 16 || d.c_in == 32) && d.c_out == 8) || (d.c_in == 16 && d.c_out == 16),
+                   "%s: S1P8 is 8|16|32 -> 8 and 16 -> 16 only", fn);
     PSCV_CHECK_ARG(d.kind != PSCV_CONV_T2P8 || (d.c_in == 16 && d.c_out == 8 && d.transposed), "%s: T2P8 is ConvTranspose3d 16 -> 8 only", fn);
     PSCV_CHECK_ARG(d.kind != PSCV_CONV_S1C1 || (d.c_out == 1 && (d.c_in == 8 || d.c_in == 16) && !d.transposed),
                    "%s: S1C1 is Conv3d 8|16 -> 1 only", fn);

@@ -487,7 +487,7 @@ class Conv3dLayer:
         epilogue: scale = gamma / sqrt(var + eps), bias = beta - mean * scale (+ scale * conv_bias)."""
         device = device if device is not None else weight.device
         c_in, c_out = (weight.shape[0], weight.shape[1]) if transposed else (weight.shape[1], weight.shape[0])
-        if kind == L.CONV_S1 and c_in in (8, 16, 32) and c_out == 8 and USE_SWEEP_KERNEL:
+        if kind == L.CONV_S1 and ((c_in in (8, 16, 32) and c_out == 8) or (c_in, c_out) == (16, 16)) and USE_SWEEP_KERNEL:
             kind = L.CONV_S1P8     # same result, depth-sweep kernels with plane-pair packed MFMA rows (stride-1 deconvs too)
         if kind == L.CONV_T2 and transposed and c_in == 16 and c_out == 8 and USE_SWEEP_KERNEL:
             kind = L.CONV_T2P8     # same result, parity-pair packed MFMA rows + contiguous 32-byte stores
