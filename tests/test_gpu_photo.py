@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import photometric as P
-from wild_deep_mvs_amd import ops, synthetic
+from wild_deep_mvs_amd import synthetic
 from wild_deep_mvs_amd.models.trainer import Trainer
 from wild_deep_mvs_amd.utils.ssimLoss import SSIM
 

@@ -5,7 +5,6 @@ from __future__ import annotations
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .... import _lib as L
 from .... import ops

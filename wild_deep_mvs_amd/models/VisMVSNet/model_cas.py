@@ -10,11 +10,10 @@ Same module tree and state-dict keys as the reference (FeatExt / Reg / RegPair /
 Model), so released checkpoints load unchanged."""
 from __future__ import annotations
 
-from typing import Dict, List, Optional
+from typing import Dict, Optional
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from ... import _lib as L
 from ... import ops

@@ -4,13 +4,11 @@
 are parameter holders executed by ``model_cas.Reg*`` through MFMA conv launches."""
 from __future__ import annotations
 
-from typing import List, Sequence
+from typing import List
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
-from ... import _lib as L
 from ... import ops
 
 

@@ -18,8 +18,8 @@ Storage is 16-bit (bf16 by default in training: gradients span many decades), ac
 """
 from __future__ import annotations
 
-from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Sequence, Tuple
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
 
 import torch
 import torch.nn as nn
