@@ -91,17 +91,19 @@ def build_inputs(device, rank: int, dtype):
     return net, sd, feats, feats_cl, proj.to(device), dv.to(device).contiguous(), proj, dv
 
 
-def cpu_baseline(sd, feats, proj, dv):
-    """The oracle's hot path (same stages, fp32 ATen on the host cores) on the same workload, once."""
+def cpu_baseline(sd, feats, proj, dv, gpu_depth):
+    """The oracle's hot path (same stages, fp32 ATen on the host cores) on the same workload, once.  The pass also yields the
+    second half of BASELINE.json's metric at the full headline size: relative L1 of the engine's depth map against it."""
     from oracle import mvsnet as O          # cpu_baseline leg only
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
     with torch.no_grad():
         t0 = time.perf_counter()
-        O.hot_path([feats[i] for i in range(V)], proj, dv.unsqueeze(1).expand(-1, V, -1), sd)
+        o_depth, _ = O.hot_path([feats[i] for i in range(V)], proj, dv.unsqueeze(1).expand(-1, V, -1), sd)
         dt = time.perf_counter() - t0
+    rel_l1 = float((gpu_depth.float().cpu() - o_depth).abs().mean() / o_depth.abs().mean())
     return {"value": VOX / dt, "unit": "voxels/s", "cores": cores, "kind": "port",
-            "sample": f"1 pass of the same workload (5-view 128x160x32 features, D=192, fp32, {dt:.1f} s)"}
+            "sample": f"1 pass of the same workload (5-view 128x160x32 features, D=192, fp32, {dt:.1f} s)"}, rel_l1
 
 
 def main():
@@ -229,7 +231,7 @@ def main():
             "kernels_us": {k: round(ms / n * 1e3, 2) for k, (n, ms) in sorted(kern.items(), key=lambda kv: -kv[1][1])},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(sd, feats, proj, dv)
+            line["cpu_baseline"], line["depth_rel_l1_vs_oracle"] = cpu_baseline(sd, feats, proj, dv, depth)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
