@@ -220,6 +220,9 @@ def main():
             "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "dtype_note": "16-bit HBM storage and MFMA operands, fp32 accumulation.  BASELINE.json names bf16: same bytes and MFMA "
+                          "rate, selectable with --dtype bf16 (profiles/r01_bench_line_bf16.json); fp16 is the default because "
+                          "bf16 storage sits at the 1e-3 parity bar (DESIGN.md section 5)",
             "config": {"workload": "MVSNet variance, 1 ref + 4 src views, 512x640 images (128x160x32 features), D=192, "
                                    "features resident in HBM -> depth + confidence", "global_batch": world,
                        "voxels_per_step_per_gpu": VOX, "parallelism": f"reference-view shard x{world}, no collective"},
