@@ -164,6 +164,55 @@ def test_sweep_pair_packing_contracts_like_the_kernel():
     np.testing.assert_allclose(out[:D], ref.permute(1, 2, 3, 0).numpy(), atol=2e-4 * float(ref.abs().max()), rtol=0)
 
 
+@pytest.mark.parametrize("cin,cout,transposed", [(8, 8, False), (16, 8, False), (16, 16, False), (8, 8, True), (16, 16, True)])
+def test_narrow_sweep_packing_contracts_like_the_kernel(cin, cout, transposed):
+    """PSCV_CONV_S1P8 layouts of the narrow depth-sweep kernel (conv3d_sweepc_kernel): the 32-deep MFMA reduction spans planes.
+    c_in 8: lane group g = input plane d-1+g, one MFMA per tap; c_in 16 -> 8: two MFMA sets, plane 2 set + (g >> 1), channel half
+    g & 1; rows 0-7 = output plane d, rows 8-15 = plane d+1.  16 -> 16: rows = the 16 channels of ONE output plane o, set 0 =
+    planes (o-1, o), set 1 = (o, o+1) with zero weights on the repeated plane.  numpy emulation of the kernel's contraction
+    against ATen, also for stride-1 ConvTranspose3d weights (flipped taps, swapped channel axes)."""
+    rng = np.random.default_rng(cin + cout + transposed)
+    wshape = (cin, cout, 3, 3, 3) if transposed else (cout, cin, 3, 3, 3)
+    w = _bf16(rng.standard_normal(wshape).astype(np.float32))
+    D, H, W = 5, 3, 4
+    x = _bf16(rng.standard_normal((D, H, W, cin)).astype(np.float32))
+    packed = ops.pack_conv3d_weights(torch.from_numpy(w), L.CONV_S1P8, transposed, torch.float16)
+    nsets = 4 * cin // 32
+    wk = packed.view(np.float16).astype(np.float32).reshape(nsets, 9, 64, 8)       # [set][tap][lane][j]
+    out = np.zeros((D + 2, H, W, cout), np.float32)
+
+    def plane_and_channels(set_, g, o):
+        """input plane and channel slice lane group g of MFMA set `set_` reads while output plane(s) starting at o are computed"""
+        if cout == 16:
+            return o - 1 + set_ + (g >> 1), slice((g & 1) * 8, (g & 1) * 8 + 8)
+        if cin == 8:
+            return o - 1 + g, slice(0, 8)
+        return o - 1 + 2 * set_ + (g >> 1), slice((g & 1) * 8, (g & 1) * 8 + 8)
+
+    for o in range(0, D, 1 if cout == 16 else 2):
+        for h in range(H):
+            for x_ in range(W):
+                for set_ in range(nsets):
+                    for t_ in range(9):
+                        kh, kw = t_ // 3, t_ % 3
+                        ph, pw = h + kh - 1, x_ + kw - 1
+                        if not (0 <= ph < H and 0 <= pw < W):
+                            continue
+                        for g in range(4):
+                            pd, cs = plane_and_channels(set_, g, o)
+                            if not 0 <= pd < D:
+                                continue
+                            xv = x[pd, ph, pw, cs]
+                            for m in range(16):
+                                if cout == 16:
+                                    out[o, h, x_, m] += wk[set_, t_, m + 16 * g] @ xv
+                                else:
+                                    out[o + (m >> 3), h, x_, m & 7] += wk[set_, t_, m + 16 * g] @ xv
+    xt = torch.from_numpy(x).permute(3, 0, 1, 2).unsqueeze(0)
+    ref = (F.conv_transpose3d(xt, torch.from_numpy(w), padding=1) if transposed else F.conv3d(xt, torch.from_numpy(w), padding=1))[0]
+    np.testing.assert_allclose(out[:D], ref.permute(1, 2, 3, 0).numpy(), atol=2e-4 * float(ref.abs().max()), rtol=0)
+
+
 def test_parity_pair_deconv_packing_contracts_like_the_kernel():
     """PSCV_CONV_T2P8: numpy emulation of conv3d_t2p8.hip's contraction (9 k-steps, rows 0-7 / 8-15 = output x
     parity 0 / 1, K = two W taps x 16 channels) vs ATen's ConvTranspose3d(k3, s2, p1, op1)."""
@@ -333,6 +382,14 @@ def test_reference_import_paths_resolve():
     from models.VisMVSNet.homography import homography_warping, get_homographies   # noqa: F401
     from models.VisMVSNet.nn_utils import soft_argmin, entropy, groupwise_correlation   # noqa: F401
     from models.CVP_MVSNet.models.modules import proj_cost            # noqa: F401
+    from models.utils import homo_warp, rec_upsample, bayesian_version_loss   # noqa: F401  (BASELINE.json names models/utils.py homo_warp)
+    from models.trainer import Trainer                                # noqa: F401  (loss half of the reference's trainer)
+    assert homo_warp is homo_warping
+    l, u, m = torch.rand(2, 1, 4, 5), torch.randn(2, 1, 4, 5), (torch.rand(2, 1, 4, 5) > 0.3).float()
+    want = ((l * torch.exp(-u) + u) * m).sum() / m.sum() + (l * m).sum() / m.sum()          # models/utils.py:110-115
+    assert torch.allclose(bayesian_version_loss(l, u, m), want)
+    up = rec_upsample([torch.rand(2, 4, 5), (torch.rand(2, 1, 4, 5), None)], (8, 10))
+    assert tuple(up[0].shape) == (2, 8, 10) and tuple(up[1][0].shape) == (2, 1, 8, 10) and up[1][1] is None
     assert Vis().depth_nums == [32, 16, 8] and CVP().model.nscale == 2
     net = MVSNet("variance")
     assert net.num_depth == 192

@@ -19,7 +19,7 @@ def install_as_models() -> None:
     sys.modules["models"] = pkg
     for sub in ("MVSNet", "MVSNet.model", "MVSNet.module", "VisMVSNet", "VisMVSNet.frontend", "VisMVSNet.model_cas",
                 "VisMVSNet.nn_utils", "VisMVSNet.homography", "VisMVSNet.preproc", "CVP_MVSNet", "CVP_MVSNet.frontend",
-                "CVP_MVSNet.models", "CVP_MVSNet.models.net", "CVP_MVSNet.models.modules"):
+                "CVP_MVSNet.models", "CVP_MVSNet.models.net", "CVP_MVSNet.models.modules", "utils", "trainer"):
         try:
             sys.modules["models." + sub] = importlib.import_module(f"{__name__}.models.{sub}")
         except ImportError:
