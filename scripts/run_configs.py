@@ -46,8 +46,13 @@ def main():
     ap.add_argument("--only", type=int, default=0)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--feature-engine", default="", help="pscv | torch: 2-D extractor (default: the model's)")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="pscv_set_tuning knob (measurement runs)")
     ap.add_argument("--graph", action="store_true", help="also time hipGraph replay of the forward (wild_deep_mvs_amd.graph.GraphedModel)")
     args = ap.parse_args()
+    for kv in args.tune:
+        from wild_deep_mvs_amd import _lib
+        k, v = kv.split("=")
+        _lib.set_tuning(k, int(v))
     for cid, cfg in CONFIGS.items():
         if args.only and cid != args.only:
             continue
