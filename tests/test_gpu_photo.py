@@ -163,3 +163,67 @@ def test_unsupervised_mvsnet_train_step():
     print(f"[parity] unsupervised MVSNet step: loss {float(loss):.6f} vs oracle {float(o_loss):.6f}, gradient cosine {cos:.5f}", flush=True)
     assert abs(float(loss) - float(o_loss)) <= 1e-3 * abs(float(o_loss))
     assert cos >= 0.98
+
+
+def test_unsupervised_vis_train_step():
+    """The reference trainer's `--unsupervised` loss for Vis-MVSNet (models/trainer.py:154-200) on the engine end to end: three
+    cascade depth maps and every pair depth upsampled to 1/2 resolution, photometric loss per map (factors 2, 1, 0.5), Bayesian pair
+    loss `ssim exp(-u) + u` with the pair's uncertainty, backward into every weight.  Against the oracle pair (model restatement in
+    train mode + loss restatement): loss value and the cosine of the full weight gradient."""
+    import json
+    from collections import OrderedDict
+    import torch.nn.functional as F
+    from oracle import vismvsnet as OV
+    from wild_deep_mvs_amd.models.MVSNet.model import build_proj_matrices
+    from wild_deep_mvs_amd.models.VisMVSNet.frontend import Frontend
+    from wild_deep_mvs_amd.models.utils import rec_upsample, bayesian_version_loss
+    H, W, V, B, seed = 64, 96, 3, 2, 0
+    depth_nums, scales = [16, 8, 4], [8.0, 4.0, 2.0]
+    scene = synthetic.make_scene(B, V, H, W, seed=4)
+
+    def loss_of(out, imgs, K, R, t, photometricloss):
+        h, w = H // 2, W // 2
+        img = F.interpolate(imgs.view(-1, 3, H, W), size=(h, w), mode="bilinear", align_corners=False).view(B, V, 3, h, w)
+        Ks = K.clone()
+        Ks[:, :, :2] /= 2
+        proj = build_proj_matrices(Ks, R, t)
+        loss = 0
+        for i, d in enumerate(rec_upsample(list(out["depth_est_list"]), (h, w))):
+            ssim, mask = photometricloss(img, d, proj)[:2]
+            loss = loss + [2, 1, 0.5][i] * torch.sum(ssim * mask) / torch.sum(mask)
+        for i, pairs in enumerate(rec_upsample([[(d, u[0]) for d, u in st] for st in out["depth_pair_list"]], (h, w))):
+            for j, (d, unc) in enumerate(pairs):
+                idx = [0, j + 1]
+                ssim, mask = photometricloss(img[:, idx], d.squeeze(1), proj[:, idx])[:2]
+                loss = loss + [2, 1, 0.5][i] / (V - 1) * bayesian_version_loss(ssim, unc, mask)
+        return loss
+
+    net = Frontend()
+    net.load_state_dict(synthetic.sharpened_state_dict("vis", synthetic.template_of(net), seed=seed))
+    net = net.cuda().train()
+    net.depth_nums, net.interval_scales = depth_nums, scales
+    net.train_storage_dtype = torch.float16
+    dev = {k: scene[k].cuda() for k in ("imgs", "K", "R", "t", "depth_min", "depth_max")}
+    out = net(*[dev[k] for k in ("imgs", "K", "R", "t", "depth_min", "depth_max")])
+    loss = loss_of(out, dev["imgs"], dev["K"], dev["R"], dev["t"], Trainer().photometricloss)
+    loss.backward()
+
+    keys = json.load(open(os.path.join(GOLD, "state_dict_keys.json")))["vis"]
+    sd = synthetic.sharpened_state_dict("vis", OrderedDict((k, tuple(s)) for k, s in keys), seed=seed)
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v) for k, v in sd.items()}
+    with OV.train_mode({}):
+        o_out = OV.forward(scene["imgs"], scene["K"], scene["R"], scene["t"], scene["depth_min"], scene["depth_max"], sd,
+                           depth_nums=tuple(depth_nums), interval_scales=tuple(scales), attr_interval_scales=tuple(scales))
+    o_loss = loss_of(o_out, scene["imgs"], scene["K"], scene["R"], scene["t"], P.photometricloss)
+    o_loss.backward()
+    dot = n1 = n2 = 0.0
+    for k, p in net.named_parameters():
+        if sd[k].grad is None:
+            continue
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+        a, b = p.grad.float().cpu(), sd[k].grad.float()
+        dot += float((a * b).sum()); n1 += float((a * a).sum()); n2 += float((b * b).sum())
+    cos = dot / (n1 ** 0.5 * n2 ** 0.5)
+    print(f"[parity] unsupervised Vis step: loss {float(loss):.6f} vs oracle {float(o_loss):.6f}, gradient cosine {cos:.5f}", flush=True)
+    assert abs(float(loss) - float(o_loss)) <= 2e-3 * abs(float(o_loss))
+    assert cos >= 0.97
