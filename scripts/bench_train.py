@@ -19,6 +19,59 @@ from wild_deep_mvs_amd import ops, synthetic  # noqa: E402
 from wild_deep_mvs_amd.models.MVSNet.model import MVSNet  # noqa: E402
 
 
+def other_arch(a, dt):
+    """Vis-MVSNet / CVP-MVSNet training step (train() forward on the engine's autograd nodes + the trainer's supervised loss +
+    backward + Adam), same timing protocol as the MVSNet line."""
+    if a.arch == "vis":
+        from wild_deep_mvs_amd.models.VisMVSNet.frontend import Frontend
+        net = Frontend()
+        key, down, kw = "vis", 2, dict(depth_nums=[64, 32, 16], interval_scales=[2.0, 1.0, 0.5])
+        net.depth_nums, net.interval_scales = kw["depth_nums"], kw["interval_scales"]
+    else:
+        from wild_deep_mvs_amd.models.CVP_MVSNet.frontend import Frontend
+        net = Frontend()
+        key, down, kw = "cvp", 1, dict(nscale=2)
+    net.load_state_dict(synthetic.train_state_dict(key, synthetic.template_of(net), seed=0))
+    net = net.cuda().train()
+    net.train_storage_dtype = dt
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    scene = synthetic.make_scene(a.batch, a.views, a.height, a.width, seed=0)
+    if a.arch == "cvp":
+        scene["t"] = scene["t"] * 8          # CVP's hypothesis spacing follows the baseline (as in the test fixtures)
+    gt, mask = synthetic.train_target(scene, a.height // down, a.width // down)
+    dev = {k: v.cuda() for k, v in scene.items() if isinstance(v, torch.Tensor)}
+    gt, mask = gt.cuda(), mask.cuda()
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = net(dev["imgs"], dev["K"], dev["R"], dev["t"], dev["depth_min"], dev["depth_max"], **kw)
+        if a.arch == "vis":
+            loss = synthetic.vis_supervised_loss(out, gt, mask, dev["depth_min"], dev["depth_max"], a.views)
+        else:
+            loss = synthetic.supervised_loss_list(out["depth_est_list"], gt, mask, dev["depth_min"], dev["depth_max"])
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    gc.disable()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / a.steps
+    with ops.EventTimer() as tm:
+        for _ in range(a.steps):
+            step()
+    gc.enable()
+    kern = {k: round(v[1] * 1e3 / a.steps, 1) for k, v in sorted(tm.summary().items(), key=lambda kv: -kv[1][1])}
+    print(json.dumps({"metric": f"{a.arch} training step (forward train() + backward + Adam)", "ms_per_step": ms, "dtype": a.dtype,
+                      "loss": float(loss), "config": {"workload": f"{a.arch}, {a.views} views, {a.height}x{a.width}, B={a.batch}", **{k: str(v) for k, v in kw.items()}},
+                      "pscv_kernels_us_per_step": dict(list(kern.items())[:12]), "pscv_kernels_total_ms": round(sum(kern.values()) / 1e3, 3)}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=5)
@@ -30,11 +83,16 @@ def main():
     ap.add_argument("--depth", type=int, default=192)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--aggregation", default="variance")
+    ap.add_argument("--arch", default="mvsnet", choices=["mvsnet", "vis", "cvp"],
+                    help="vis: Vis-MVSNet (cascade depth_nums 64,32,16, the reference trainer's supervised loss incl. Bayesian pair terms); "
+                         "cvp: CVP-MVSNet (nscale 2 as in training, supervised L1 on every level)")
     ap.add_argument("--feature-engine", default="torch", choices=["torch", "pscv"],
                     help="2-D extractor in train(): PyTorch-ROCm autograd (fp32) or training.FeatureNetFn (engine, 16-bit activations)")
     a = ap.parse_args()
     dt = {"bf16": torch.bfloat16, "f16": torch.float16}[a.dtype]
     torch.cuda.set_device(0)
+    if a.arch != "mvsnet":
+        return other_arch(a, dt)
     net = MVSNet(a.aggregation)
     net.load_state_dict(synthetic.train_state_dict("mvsnet", synthetic.template_of(net), seed=0))
     net = net.cuda().train()
