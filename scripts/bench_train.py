@@ -86,11 +86,13 @@ def main():
     ap.add_argument("--arch", default="mvsnet", choices=["mvsnet", "vis", "cvp"],
                     help="vis: Vis-MVSNet (cascade depth_nums 64,32,16, the reference trainer's supervised loss incl. Bayesian pair terms); "
                          "cvp: CVP-MVSNet (nscale 2 as in training, supervised L1 on every level)")
+    ap.add_argument("--no-pack-cache", action="store_true", help="rebuild every packed layer on every use (A/B of ops.PACK_CACHE)")
     ap.add_argument("--feature-engine", default="torch", choices=["torch", "pscv"],
                     help="2-D extractor in train(): PyTorch-ROCm autograd (fp32) or training.FeatureNetFn (engine, 16-bit activations)")
     a = ap.parse_args()
     dt = {"bf16": torch.bfloat16, "f16": torch.float16}[a.dtype]
     torch.cuda.set_device(0)
+    ops.PACK_CACHE = not a.no_pack_cache
     if a.arch != "mvsnet":
         return other_arch(a, dt)
     net = MVSNet(a.aggregation)

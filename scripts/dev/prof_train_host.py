@@ -8,5 +8,7 @@ pr.enable()
 runpy.run_path(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench_train.py"), run_name="__main__")
 pr.disable()
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(45)
-print("\n".join(l[:170] for l in s.getvalue().splitlines()[:70]))
+pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(400)
+lines = s.getvalue().splitlines()
+print("\n".join(l[:170] for l in lines[:12]))
+print("\n".join(l[:170] for l in lines if any(k in l for k in ("ops.py", "training.py", "_lib.py", "run_backward", "frontend.py", "model_cas.py", "adam", "bench_train.py"))))

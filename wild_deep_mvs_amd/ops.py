@@ -9,6 +9,7 @@ Layouts: feature maps ``[B,h,w,C]`` and volumes ``[B,D,h,w,C]`` (channels-last),
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from dataclasses import dataclass
 from typing import Optional, Sequence
 
@@ -493,6 +494,15 @@ class Conv3dLayer:
             kind = L.CONV_T2P8     # same result, parity-pair packed MFMA rows + contiguous 32-byte stores
         if kind == L.CONV_S1 and not transposed and c_in in (8, 16) and c_out == 1 and USE_SWEEP_KERNEL:
             kind = L.CONV_S1C1     # same result, depth-in-rows MFMA kernel for the 1-channel heads
+        # A training step applies the same Parameter many times (Vis-MVSNet: one pair U-Net per source view and stage, forward and
+        # adjoint): raw-weight layers of live Parameters are memoised per parameter VERSION (the optimiser's in-place update bumps
+        # it), guarded by a weak reference so that a recycled id() can never alias another tensor.
+        ckey = None
+        if PACK_CACHE and isinstance(weight, torch.nn.Parameter) and weight.is_cuda and bn is None and conv_bias is None and floor is None:
+            ckey = (id(weight), kind, bool(transposed), dtype, str(device), bool(relu), bool(relu_post))
+            ent = _layer_cache.get(ckey)
+            if ent is not None and ent[0]() is weight and ent[1] == weight._version:
+                return ent[2]
         if weight.is_cuda and torch.device(device).type == "cuda":
             packed = pack_conv3d_weights_device(weight, kind, transposed, dtype)
         else:
@@ -510,10 +520,17 @@ class Conv3dLayer:
         epi = (L.EPI_RELU_PRE if relu else 0) | (L.EPI_RELU_POST if relu_post else 0)
         if floor is not None:
             floor = floor.detach().to(device, torch.float32).contiguous()
-        return Conv3dLayer(packed, dtype, int(c_in), int(c_out), kind, epi, scale, bias, floor)
+        layer = Conv3dLayer(packed, dtype, int(c_in), int(c_out), kind, epi, scale, bias, floor)
+        if ckey is not None:
+            if len(_layer_cache) > 4096:
+                _layer_cache.clear()
+            _layer_cache[ckey] = (weakref.ref(weight), weight._version, layer)
+        return layer
 
 
 USE_SWEEP_KERNEL = True   # tests flip this to compare the two stride-1 kernels
+PACK_CACHE = True         # memoise raw-weight layers of live Parameters per parameter version (Conv3dLayer.build)
+_layer_cache: dict = {}
 
 
 def conv_out_shape(kind: int, D: int, H: int, W: int):
