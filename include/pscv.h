@@ -294,6 +294,21 @@ long pscv_train_workspace_floats(void);
  */
 int pscv_bn_stats(const void* y, int dtype, long nvox, int C, float* workspace, float* sums, void* stream);
 
+/*
+ * The per-channel bookkeeping between pscv_bn_stats and pscv_bn_act, one launch (nn.BatchNorm3d.train() semantics): from sums
+ * [2][C]: mean = s0 / nvox, var = max(s1 / nvox - mean^2, 0), invstd = 1 / sqrt(var + eps); out fp32 [4][C] = (scale = gamma invstd,
+ * bias = beta - mean scale, mean, invstd).  gamma / beta may be NULL (1 / 0).  When running_mean / running_var are given they are
+ * updated in place with `momentum` and the unbiased variance, and *num_batches_tracked (int64, may be NULL) is incremented.
+ */
+int pscv_bn_finalize(const float* sums, long nvox, int C, const float* gamma, const float* beta, float eps, float momentum,
+                     float* running_mean, float* running_var, long long* num_batches_tracked, float* out, void* stream);
+/*
+ * The bookkeeping between pscv_bn_bwd_reduce and pscv_bn_bwd_apply: from sums [2][C] = (sum dz, sum dz y): out fp32 [5][C] =
+ * (ca, cb, cc, d gamma, d beta) with dy = ca dz + cb y + cc the BatchNorm input gradient.
+ */
+int pscv_bn_bwd_coeffs(const float* sums, const float* mean, const float* invstd, const float* gamma, long nvox, int C, float* out,
+                       void* stream);
+
 /* out = [relu](y * scale + bias) + skip   (scale / bias fp32 [C] = the batch-statistics affine; skip may be NULL;
  * `skip + relu(bn(deconv(x)))` of models/MVSNet/model.py:79-81).  relu: 0 none, 1 before the skip add, 2 AFTER it
  * (`relu(bn(conv(x)) + shortcut)` of the Vis BasicBlock, models/VisMVSNet/nn_utils.py:123-171). */

@@ -242,6 +242,42 @@ static int red_grid_for(long nchunk) {
     return (int)nb;
 }
 
+// ---- per-channel BatchNorm bookkeeping: the dozen C-element tensor ops between the reductions and the apply passes, one launch each
+// (a Vis-MVSNet training step has 75 BatchNorm applications: ~2000 launches of 8-64-element ATen kernels were 10 % of its wall time) ----
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, float nvox, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float eps, float momentum, float* __restrict__ run_mean, float* __restrict__ run_var,
+                                   long long* __restrict__ batches, float* __restrict__ out, int C) {
+    const int c = threadIdx.x;
+    if (c == 0 && batches) *batches += 1;
+    if (c >= C) return;
+    const float mean = sums[c] / nvox;
+    const float var = fmaxf(sums[C + c] / nvox - mean * mean, 0.0f);
+    const float invstd = 1.0f / sqrtf(var + eps);
+    const float scale = (gamma ? gamma[c] : 1.0f) * invstd;
+    out[c] = scale;
+    out[C + c] = (beta ? beta[c] : 0.0f) - mean * scale;
+    out[2 * C + c] = mean;
+    out[3 * C + c] = invstd;
+    if (run_mean) {      // nn.BatchNorm3d in train(): running = (1 - m) running + m batch, unbiased variance
+        run_mean[c] = run_mean[c] * (1.0f - momentum) + mean * momentum;
+        run_var[c] = run_var[c] * (1.0f - momentum) + var * (nvox / fmaxf(nvox - 1.0f, 1.0f)) * momentum;
+    }
+}
+
+__global__ void bn_bwd_coeffs_kernel(const float* __restrict__ s, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                     const float* __restrict__ gamma, float nvox, float* __restrict__ out, int C) {
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    const float s1 = s[c];                                        // sum dz       = d beta
+    const float s2 = invstd[c] * (s[C + c] - mean[c] * s1);       // sum dz xhat  = d gamma
+    const float k = (gamma ? gamma[c] : 1.0f) * invstd[c];
+    out[c] = k;                                                   // dy = ca dz + cb y + cc
+    out[C + c] = -k * invstd[c] * s2 / nvox;
+    out[2 * C + c] = -k * s1 / nvox + k * invstd[c] * mean[c] * s2 / nvox;
+    out[3 * C + c] = s2;
+    out[4 * C + c] = s1;
+}
+
 }  // namespace pscv
 
 using namespace pscv;
@@ -361,5 +397,26 @@ extern "C" int pscv_relu_bwd(const void* dout, const void* out, int dtype, long 
     if (dtype == PSCV_BF16) hipLaunchKernelGGL(relu_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const uint4*)dout, (const uint4*)out, (uint4*)dpre, nchunk);
     else hipLaunchKernelGGL(relu_bwd_kernel<f16_t>, dim3(nb), dim3(256), 0, st, (const uint4*)dout, (const uint4*)out, (uint4*)dpre, nchunk);
     PSCV_CHECK_LAUNCH("pscv_relu_bwd");
+    return 0;
+}
+
+extern "C" int pscv_bn_finalize(const float* sums, long nvox, int C, const float* gamma, const float* beta, float eps, float momentum,
+                                float* running_mean, float* running_var, long long* num_batches_tracked, float* out, void* stream) {
+    using namespace pscv;
+    PSCV_CHECK_ARG(sums && out && nvox > 0 && C > 0 && C <= 1024, "pscv_bn_finalize: bad arguments");
+    PSCV_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "pscv_bn_finalize: running_mean and running_var go together");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3((C + 63) / 64 * 64), 0, reinterpret_cast<hipStream_t>(stream), sums, (float)nvox,
+                       gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, out, C);
+    PSCV_CHECK_LAUNCH("pscv_bn_finalize");
+    return 0;
+}
+
+extern "C" int pscv_bn_bwd_coeffs(const float* sums, const float* mean, const float* invstd, const float* gamma, long nvox, int C,
+                                  float* out, void* stream) {
+    using namespace pscv;
+    PSCV_CHECK_ARG(sums && mean && invstd && out && nvox > 0 && C > 0 && C <= 1024, "pscv_bn_bwd_coeffs: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3(1), dim3((C + 63) / 64 * 64), 0, reinterpret_cast<hipStream_t>(stream), sums, mean, invstd,
+                       gamma, (float)nvox, out, C);
+    PSCV_CHECK_LAUNCH("pscv_bn_bwd_coeffs");
     return 0;
 }

@@ -771,6 +771,39 @@ def bn_stats(y: torch.Tensor) -> torch.Tensor:
     return sums
 
 
+def bn_finalize(sums: torch.Tensor, nvox: int, bn) -> torch.Tensor:
+    """sums fp32 [2,C] of ``bn_stats`` -> fp32 [4,C] = (scale, bias, mean, invstd) of a BatchNorm module in train(); updates its
+    running statistics and ``num_batches_tracked`` like nn.BatchNorm3d (pscv_bn_finalize, one launch)."""
+    _dev(sums)
+    Cc = sums.shape[1]
+    out = torch.empty((4, Cc), dtype=torch.float32, device=sums.device)
+    track = bn.track_running_stats and bn.running_mean is not None
+    if track and bn.momentum is None:
+        raise NotImplementedError("pscv BatchNorm training: cumulative moving average (momentum=None) is not used by the reference")
+    f32 = lambda t_: None if t_ is None else (t_ if t_.dtype == torch.float32 else t_.detach().float())
+    gamma, beta = f32(bn.weight), f32(bn.bias)
+    rm, rv = (bn.running_mean, bn.running_var) if track else (None, None)
+    if track and (rm.dtype != torch.float32 or rv.dtype != torch.float32):
+        raise TypeError("pscv BatchNorm training: fp32 running statistics expected")
+    nbt = bn.num_batches_tracked if track else None
+    rc = _launch("bn_finalize", lambda: L.lib().pscv_bn_finalize(_p(sums), int(nvox), Cc, _p(gamma), _p(beta), float(bn.eps),
+                                                                float(bn.momentum if track else 0.0), _p(rm), _p(rv), _p(nbt), _p(out),
+                                                                _stream()))
+    L.check(rc, "pscv_bn_finalize")
+    return out
+
+
+def bn_bwd_coeffs(sums: torch.Tensor, mean: torch.Tensor, invstd: torch.Tensor, gamma: Optional[torch.Tensor], nvox: int) -> torch.Tensor:
+    """sums fp32 [2,C] of ``bn_bwd_reduce`` -> fp32 [5,C] = (ca, cb, cc, d gamma, d beta) (pscv_bn_bwd_coeffs, one launch)."""
+    _dev(sums, mean, invstd, gamma)
+    Cc = sums.shape[1]
+    out = torch.empty((5, Cc), dtype=torch.float32, device=sums.device)
+    g = None if gamma is None else (gamma.detach() if gamma.dtype == torch.float32 else gamma.detach().float())
+    rc = _launch("bn_bwd_coeffs", lambda: L.lib().pscv_bn_bwd_coeffs(_p(sums), _p(mean), _p(invstd), _p(g), int(nvox), Cc, _p(out), _stream()))
+    L.check(rc, "pscv_bn_bwd_coeffs")
+    return out
+
+
 def bn_act(y: torch.Tensor, scale: torch.Tensor, bias: torch.Tensor, *, relu, skip: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[relu](y * scale + bias) + skip on a 16-bit channels-last volume (pscv_bn_act).  ``relu``: False / True (before the
     skip add) / "post" (after it: the Vis BasicBlock)."""

@@ -148,24 +148,10 @@ def _dgrad_layer(b: Block, dtype, dev) -> ops.Conv3dLayer:
 
 
 def _bn_affine(b: Block, sums: torch.Tensor, nvox: int):
-    """Batch statistics -> (scale, bias, mean, invstd); updates the running statistics like nn.BatchNorm3d.train()."""
-    bn = b.bn
-    mean = sums[0] / nvox
-    var = (sums[1] / nvox - mean * mean).clamp_min_(0.0)
-    invstd = torch.rsqrt(var + bn.eps)
-    gamma = bn.weight.detach().float() if bn.weight is not None else torch.ones_like(mean)
-    beta = bn.bias.detach().float() if bn.bias is not None else torch.zeros_like(mean)
-    scale = (gamma * invstd).contiguous()
-    bias = (beta - mean * scale).contiguous()
-    if bn.track_running_stats and bn.running_mean is not None:
-        with torch.no_grad():
-            if bn.num_batches_tracked is not None:
-                bn.num_batches_tracked += 1
-            m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked.item())
-            bn.running_mean.mul_(1.0 - m).add_(mean.to(bn.running_mean.dtype), alpha=m)
-            unbiased = var * (nvox / max(nvox - 1, 1))
-            bn.running_var.mul_(1.0 - m).add_(unbiased.to(bn.running_var.dtype), alpha=m)
-    return scale, bias, mean, invstd
+    """Batch statistics -> (scale, bias, mean, invstd); updates the running statistics like nn.BatchNorm3d.train().  One launch
+    (pscv_bn_finalize): the dozen C-element tensor ops this used to be were a tenth of a Vis-MVSNet training step's wall time."""
+    out = ops.bn_finalize(sums, nvox, b.bn)
+    return out[0], out[1], out[2], out[3]
 
 
 # Test hook: when set to a dict, RegressFn records every block's forward and backward tensors in it (the parity tests
@@ -263,13 +249,7 @@ class RegressFn(torch.autograd.Function):
             y, scale, bias, mean, invstd = saved[b.name]
             nvox = y.numel() // y.shape[4]
             s = ops.bn_bwd_reduce(dact, y, scale, bias, relu=b.relu)
-            s1 = s[0]
-            s2 = invstd * (s[1] - mean * s[0])                      # sum dz * xhat
-            gamma = b.bn.weight.detach().float()
-            k = gamma * invstd
-            ca = k.contiguous()
-            cb = (-k * invstd * s2 / nvox).contiguous()
-            cc = (-k * s1 / nvox + k * invstd * mean * s2 / nvox).contiguous()
+            ca, cb, cc, s2, s1 = ops.bn_bwd_coeffs(s, mean, invstd, b.bn.weight, nvox)     # s2 = sum dz * xhat, s1 = sum dz
             dy = ops.bn_bwd_apply(dact, y, scale, bias, ca, cb, cc, relu=b.relu)
             pgrads[id(b.bn.weight)] = s2.to(b.bn.weight.dtype)
             pgrads[id(b.bn.bias)] = s1.to(b.bn.bias.dtype)
@@ -302,12 +282,7 @@ def _bn_backward(bn: nn.BatchNorm3d, dz_src: torch.Tensor, y: torch.Tensor, save
     """BatchNorm(+ReLU before any skip) backward on the engine: returns (dy, d gamma, d beta)."""
     scale, bias, mean, invstd, nvox = saved
     s = ops.bn_bwd_reduce(dz_src, y, scale, bias, relu=relu)
-    s1 = s[0]
-    s2 = invstd * (s[1] - mean * s[0])
-    k = bn.weight.detach().float() * invstd
-    ca = k.contiguous()
-    cb = (-k * invstd * s2 / nvox).contiguous()
-    cc = (-k * s1 / nvox + k * invstd * mean * s2 / nvox).contiguous()
+    ca, cb, cc, s2, s1 = ops.bn_bwd_coeffs(s, mean, invstd, bn.weight, nvox)
     dy = ops.bn_bwd_apply(dz_src, y, scale, bias, ca, cb, cc, relu=relu)
     return dy, s2.to(bn.weight.dtype), s1.to(bn.bias.dtype)
 
