@@ -34,5 +34,10 @@ with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
 ev = [e for e in prof.key_averages() if e.device_time_total > 0]
 tot = sum(e.device_time_total for e in ev) / 3e3
 print(f"{arch}: GPU kernel time per step {tot:.2f} ms")
-for e in sorted(ev, key=lambda e: -e.device_time_total)[:22]:
-    print(f"  {e.device_time_total / 3e3:8.3f} ms  x{e.count // 3:4d}  {e.key[:110]}")
+kern = [e for e in ev if not e.key.startswith(("aten::", "autograd::")) and "Backward" not in e.key and "Fn" not in e.key[-4:]]
+print(f"  kernels only: {sum(e.device_time_total for e in kern) / 3e3:.2f} ms in {sum(e.count for e in kern) // 3} launches per step")
+for e in sorted(kern, key=lambda e: -e.count)[:14]:
+    print(f"  x{e.count // 3:5d}  {e.device_time_total / 3e3:8.3f} ms  {e.key[:120]}")
+cpu = sorted(prof.key_averages(), key=lambda e: -e.count)[:14]
+for e in cpu:
+    print(f"  cpu x{e.count // 3:5d} {e.self_cpu_time_total / 3e3:8.3f} ms  {e.key[:80]}")
