@@ -45,6 +45,48 @@ def test_bn_stats_and_act(C, dtype):
         check_close(f"bn_act relu={relu}", _cf(got), ref.to(dtype).float(), rel_l2=3e-3 if dtype == torch.bfloat16 else 4e-4)
 
 
+@pytest.mark.parametrize("C,affine", [(8, True), (16, True), (64, True), (32, False)])
+def test_bn_bookkeeping_kernels_match_batchnorm_module(C, affine):
+    """pscv_bn_finalize / pscv_bn_bwd_coeffs (the [C]-vector bookkeeping around the reductions, one launch each) against
+    nn.BatchNorm3d in train(): affine, saved mean / invstd, running statistics with the unbiased variance, num_batches_tracked; and
+    the input-gradient coefficients + d gamma / d beta against autograd of the same module."""
+    import torch.nn as nn
+    from wild_deep_mvs_amd import ops
+    g = torch.Generator().manual_seed(11 + C)
+    y = (torch.randn(2, C, 4, 6, 16, generator=g) * 1.5 + 0.3).requires_grad_(True)
+    ref_bn = nn.BatchNorm3d(C, affine=affine).train()
+    if affine:
+        with torch.no_grad():
+            ref_bn.weight.copy_(torch.rand(C, generator=g) + 0.5); ref_bn.bias.copy_(torch.randn(C, generator=g) * 0.3)
+            ref_bn.running_mean.copy_(torch.randn(C, generator=g)); ref_bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+    import copy
+    bn = copy.deepcopy(ref_bn).cuda()
+    z = ref_bn(y)
+    dz = torch.randn(z.shape, generator=g)
+    z.backward(dz)
+    n = y.numel() // C
+    yd = y.detach()
+    sums = torch.stack([yd.sum((0, 2, 3, 4)), (yd * yd).sum((0, 2, 3, 4))]).cuda()
+    out = ops.bn_finalize(sums, n, bn).cpu()
+    mean, var = yd.mean((0, 2, 3, 4)), yd.var((0, 2, 3, 4), unbiased=False)
+    gamma = ref_bn.weight.detach() if affine else torch.ones(C)
+    beta = ref_bn.bias.detach() if affine else torch.zeros(C)
+    check_close("scale", out[0], gamma * torch.rsqrt(var + 1e-5), rel_l2=1e-5)
+    check_close("bias", out[1], beta - mean * gamma * torch.rsqrt(var + 1e-5), rel_l2=1e-5)
+    check_close("mean", out[2], mean, rel_l2=1e-5)
+    check_close("invstd", out[3], torch.rsqrt(var + 1e-5), rel_l2=1e-5)
+    check_close("running_mean", bn.running_mean.cpu(), ref_bn.running_mean, rel_l2=1e-5)
+    check_close("running_var", bn.running_var.cpu(), ref_bn.running_var, rel_l2=1e-5)
+    assert int(bn.num_batches_tracked) == int(ref_bn.num_batches_tracked) == 1
+    bsum = torch.stack([dz.sum((0, 2, 3, 4)), (dz * yd).sum((0, 2, 3, 4))]).cuda()
+    co = ops.bn_bwd_coeffs(bsum, out[2].cuda(), out[3].cuda(), bn.weight, n).cpu()
+    dy = co[0].view(1, C, 1, 1, 1) * dz + co[1].view(1, C, 1, 1, 1) * yd + co[2].view(1, C, 1, 1, 1)
+    check_close("dy from the coefficients", dy, y.grad, rel_l2=2e-4)
+    if affine:
+        check_close("d gamma", co[3], ref_bn.weight.grad, rel_l2=1e-4)
+        check_close("d beta", co[4], ref_bn.bias.grad, rel_l2=1e-5)
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("C,relu", [(8, True), (16, True), (32, False), (64, True)])
 def test_bn_backward(C, relu, dtype):
