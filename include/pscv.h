@@ -77,10 +77,11 @@ int pscv_abi_version(void);
  *   "warp_q2"   1 (default): 32-channel 16-bit sweeps run on the quad-mapped kernel (one texel per lane quad, two depth
  *               planes per quad); 0: always the generic kernel.  "warp_lpv" != 0 also selects the generic kernel.
  *   "warp_lpv"  lanes sharing one voxel in the generic pscv_warp_cost kernel (1, 2 or 4 for C=32; 0 = default)
- *   "warp_ppd"  depth planes per workgroup in pscv_warp_cost (0 = default 8)
- *   "warp_tiled" 1: pscv_warp_cost stages source patches in LDS where it applies (C = 32, 16-bit features,
- *               per-batch planes, PROJ geometry, 2-4 source views, variance / softmin); 0 (default): the
- *               direct-gather kernel, which measured faster on MI355X.  "warp_lpv" != 0 also selects the direct kernel.
+ *   "warp_ppd"  depth planes per workgroup in pscv_warp_cost (0 = default: 8 direct kernels, 24 LDS-staged kernel)
+ *   "warp_tiled" 1 (default; -1 restores it): pscv_warp_cost stages the source patches of a reference tile in LDS as fp32
+ *               where it applies (C = 32, 16-bit features, per-batch planes, PROJ geometry, 1-4 source views, variance /
+ *               softmin) -- same bits as the direct-gather kernels; 0: always the direct-gather kernels.  "warp_lpv" != 0
+ *               also selects the direct kernel.
  *   "sweep_dc"  depth planes per workgroup of the depth-sweep convs (0 = default heuristic)
  *   "sweepc_slots" resident-workgroup target that sizes the depth chunks of the 8|16 -> 8 depth-sweep conv (0 = 768)
  *   "sweepc_pd" prefetch distance in iterations (1..3) of the same kernel (0 = 1)

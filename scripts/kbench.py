@@ -158,7 +158,7 @@ def main():
             L.set_tuning("warp_lpv", 0); L.set_tuning("warp_tiled", 1); L.set_tuning("warp_ppd", ppd)
             us = timeit(lambda: ops.warp_cost(fcl[0], fcl[1:], cm, dv, cost=L.COST_VARIANCE, out=out), args.reps)
             rows.append((f"warp_cost variance TILED ppd={ppd}", us, nbytes / us / 1e3, 0))
-            L.set_tuning("warp_tiled", 0)
+            L.set_tuning("warp_tiled", -1)
         for lpv in (4, 2, 1):
             for ppd in (4, 8, 16):
                 L.set_tuning("warp_lpv", lpv); L.set_tuning("warp_ppd", ppd)

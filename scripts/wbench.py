@@ -9,7 +9,10 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from wild_deep_mvs_amd import _lib as L, ops, synthetic  # noqa: E402
+from wild_deep_mvs_amd import _lib as L  # noqa: E402
+if os.environ.get("PSCV_LIB"):
+    L.LIB_PATH = os.environ["PSCV_LIB"]      # A/B runs against another build of the library
+from wild_deep_mvs_amd import ops, synthetic  # noqa: E402
 from wild_deep_mvs_amd.models.MVSNet.model import build_proj_matrices  # noqa: E402
 
 
@@ -57,7 +60,7 @@ def main():
             try:
                 us = timeit(lambda: ops.warp_cost(fcl[0], fcl[1:], cm, dv, cost=L.COST_VARIANCE, out=out), args.reps)
             finally:
-                L.set_tuning("warp_tiled", 0); L.set_tuning("warp_ppd", 0)
+                L.set_tuning("warp_tiled", -1); L.set_tuning("warp_ppd", 0)
             outs[name] = out
             print(f"warp_cost variance {args.dtype} {name:6s} ppd={ppd:2d}: {us:8.1f} us  {nbytes / us / 1e3:7.1f} GB/s (algorithmic)"
                   f"  = {nbytes / us / 1e3 / 8000:.3f} of 8 TB/s")

@@ -242,9 +242,8 @@ __global__ __launch_bounds__(256, 4) void warp_cost_kernel(const WarpArgs a) {
 // ---- host side ---------------------------------------------------------------------------------
 static int g_warp_lpv_override = 0;  // 0 = default heuristic; set through pscv_set_tuning("warp_lpv", n)
 static int g_warp_ppd_override = 0;
-static int g_warp_tiled = 0;     // 1: use the LDS-staged kernel (warp_cost_tiled.hip) where it applies.  Off by default:
-                                 // measured 252-275 us vs 218-228 us for the direct kernel at the headline size
-                                 // (profiles/README.md) -- the sweep is VALU-issue / latency limited, not L1-limited
+static int g_warp_tiled = 1;     // 1 (default): use the LDS-staged kernel (warp_cost_tiled.hip) where it applies: fp32 patches,
+                                 // full-rate fp32 blend; 129 us vs 166 us for the quad kernel inside the headline step, same bits
 extern int g_conv_small_tiles;   // conv3d.hip
 extern int g_sweep_th16;         // conv3d_sweep.hip
 extern int g_sweep_dc;
@@ -344,7 +343,7 @@ extern "C" int pscv_set_tuning(const char* key, int value) {
     if (!strcmp(key, "warp_lpv")) { g_warp_lpv_override = value; return 0; }
     if (!strcmp(key, "warp_ppd")) { g_warp_ppd_override = value; return 0; }
     if (!strcmp(key, "conv_small_tiles")) { g_conv_small_tiles = value; return 0; }
-    if (!strcmp(key, "warp_tiled")) { g_warp_tiled = value; return 0; }
+    if (!strcmp(key, "warp_tiled")) { g_warp_tiled = value < 0 ? 1 : value; return 0; }   // -1: back to the default
     if (!strcmp(key, "warp_q2")) { g_warp_q2 = value; return 0; }
     if (!strcmp(key, "c1_nb")) { g_c1_nb = value; return 0; }
     if (!strcmp(key, "sweep_th16")) { g_sweep_th16 = value; return 0; }

@@ -1,27 +1,38 @@
-// LDS-staged plane-sweep warp + cost for 32-channel 16-bit feature maps (gfx950), second design.
+// LDS-staged plane-sweep warp + cost for 32-channel 16-bit feature maps (gfx950), second design (round 2).
 //
 // What bounds the sweep (profiles/README.md, scripts/ubench/valu_rate2.hip): the direct-gather kernels are limited by
-// vector-ALU issue and by the per-CU L1 tap rate, not by HBM.  Measured issue rates on MI355X: plain fp32 `v_fma_f32` /
-// `v_add_f32` / `v_and_b32` are full rate; EVERY 16-bit form (`v_fma_mix_f32`, `v_pk_fma_f16`, `v_dot2_f32_f16|bf16`,
-// `v_cvt_f32_f16`, `v_lshlrev_b32`, `v_perm_b32`) and every DPP move is half rate; `ds_read_b128` moves 256 B/clk/CU and
-// overlaps fully with the vector ALU.  So:
+// vector-ALU issue and by the per-CU L1 tap rate, not by HBM (their traffic is already the algorithmic minimum).
+// Measured issue rates on MI355X: plain fp32 `v_fma_f32` / `v_add_f32` / `v_and_b32` are full rate; EVERY 16-bit form
+// (`v_fma_mix_f32`, `v_pk_fma_f16`, `v_dot2_f32_f16|bf16`, `v_cvt_f32_f16`, `v_lshlrev_b32`, `v_perm_b32`) and every DPP
+// move is half rate; `ds_read_b128` moves 256 B/clk/CU and overlaps with the vector ALU.  So:
 //
-//   * the source patches a tile of reference pixels can touch are staged in LDS ONCE per (tile, depth chunk, view) and
-//     are CONVERTED TO FP32 while they are staged (conversion cost is paid per staged texel, ~14x fewer than taps);
-//   * every bilinear tap is then two `ds_read_b128` (8 channels per lane) and the blend is four full-rate fp32 FMAs
-//     per channel -- the same fp32 operation chain as the direct kernels (`fmaf(float(h), w, acc)` == `v_fma_mix_f32`),
-//     so the results are bit-identical to theirs;
-//   * a quad of lanes owns a voxel (lane l: channels 8l..8l+7) and each lane of the quad computes the sample position
-//     of a DIFFERENT (plane, view) combination -- two planes x two source views per step -- so the coordinate
-//     arithmetic runs once per four voxel-views; weights and the texel index travel through the quad with DPP;
-//   * a view whose texel box lies strictly inside the source image needs no validity masks, clamps or behind-camera
-//     test at all (block-uniform decision from the 8 corner projections of the tile at the chunk's depth extremes);
-//     other views use direct global taps with the general (zero-padding) arithmetic for that block only.
+//   * the source patches a tile of 8 x 8 reference pixels can touch on a chunk of depth planes are staged in LDS ONCE per
+//     (tile, chunk, view) and CONVERTED TO FP32 while they are staged (conversion cost per staged texel, ~14x fewer than
+//     taps; boxes from the 8 corner projections of the tile at the chunk's depth extremes);
+//   * every bilinear tap is then two `ds_read_b128` (8 channels per lane) and the blend is four fp32 FMAs per channel --
+//     the same fp32 operation chain as the direct kernels (`fmaf(float(h), w, acc)` == `v_fma_mix_f32`), so the results are
+//     bit-identical to theirs (tests/test_gpu_warp_cost.py::test_tiled_kernel_equals_direct_kernel);
+//   * a quad of lanes owns a voxel (lane l: channels 8l..8l+7) and lane l computes the sample position in source view l,
+//     so the coordinate arithmetic runs once per four voxel-views; weights and the tap address travel through the quad
+//     with DPP `quad_perm` broadcasts; the ray terms rot (x, y, 1) of (pixel, view l) are lane constants of the sweep;
+//   * per (block, view) staging mode: box strictly inside the source image -> no validity masks, clamps or behind-camera
+//     test at all; box clipped at the border -> general zero-padding weights, taps clamped into the staged box; box
+//     entirely outside -> the view contributes f = 0 and is skipped (variance) -- 19 % of the voxel-views of the bench
+//     scene; a corner at / behind the camera or a box that does not fit -> direct global taps for that view;
+//   * one wave computes the boxes (cameras through the scalar cache) and publishes them through a 128-byte LDS table;
+//     the staging loads of a wave are one branch-free batch; this short phase runs at raised wave priority because the
+//     older workgroup of the CU, in its vector-ALU-bound sweep, would otherwise win every issue slot.
 //
-// Occupancy: 512 threads = 8 x 8 reference pixels x PD planes (8), all source views resident: 592 texels x 128 B fp32
-// + ray terms = 79 KiB -> two blocks (16 waves) per CU.  LDS layout of a texel: "lo" plane holds channels
-// {8l..8l+3 : l = 0..3} (64 B), "hi" plane {8l+4..8l+7}; a quad reads 64 contiguous bytes per instruction and the four
-// quads of a `ds_read_b128` lane group hit four texels of one row, conflict-free when the box pitch is a multiple of 4.
+// Occupancy: 512 threads = 8 x 8 pixels x 24 planes, all (<= 4) source views resident: 638 texels x 128 B fp32 = 80 KiB
+// -> two workgroups (16 waves) per CU.  LDS layout of a texel: "lo" plane holds channels {8l..8l+3 : l = 0..3} (64 B),
+// "hi" plane {8l+4..8l+7}; a quad reads 64 contiguous bytes per instruction; the quads of one `ds_read_b128` lane group
+// are four x-adjacent pixels and the box pitch is a multiple of 4, so a group hits four distinct 64-byte bank groups.
+//
+// Measured (profiles/README.md): 129 us against 166 us for the quad kernel inside the headline step (f16; bf16 alike),
+// 48 M vector-ALU instructions against 81 M, L1 tap traffic 8.8 M accesses against 67.9 M.  The sweep is now bound by
+// vector-ALU issue (~70 % busy; ~165 instructions per 16 voxels x 4 views, 77 of them the blend and the two sums).
+// Tried and not kept: software-pipelining the views inside a wave (next view's LDS reads issued between the channel
+// halves of the current blend: 0.71x the quad kernel's time against 0.63x), per-wave redundant box computation.
 //
 // Semantics and citations are those of warp_cost.hip.
 #include <type_traits>
@@ -32,19 +43,51 @@ namespace pscv {
 
 constexpr int WL_THREADS = 512;
 constexpr int WL_T = 8;                      // tile = WL_T x WL_T reference pixels
-constexpr int WL_ARENA = 640;                // staged texels per block (all views): 80 KiB of fp32 -> two blocks per CU
+constexpr int WL_ARENA = 638;                // staged texels per block (all views): 80 KiB of fp32 -> two blocks per CU
 constexpr int WL_HI = WL_ARENA * 64;         // byte offset of the "hi" channel plane
 constexpr int WL_MAX_SRC = 4;                // source views of this kernel = lanes of a quad (others: quad kernel)
-constexpr int WL_LDS = 2 * WL_HI;
+constexpr int WL_TABLE = 2 * WL_HI;          // per-view box records written by wave 0: 4 x {X0, Y0, X1, Y1, base, pitch, mode, -}
+constexpr int WL_LDS = WL_TABLE + WL_MAX_SRC * 32 + 32;
 static_assert(WL_LDS <= 81920, "two blocks per CU");
 
 typedef float wl_f2 __attribute__((ext_vector_type(2)));
+
+#ifdef WL_PROFILE
+// phase stamps kept in registers and written once per wave at the end (atomics per stamp perturbed the phases they timed)
+constexpr int WL_PROF_BLOCKS = 8192;
+__device__ unsigned int wl_prof[WL_PROF_BLOCKS * 16];
+#define WL_STAMP(i) { const unsigned long long t_ = __builtin_readcyclecounter(); t_acc[i] = (unsigned)(t_ - t_prev); t_prev = t_; }
+#else
+#define WL_STAMP(i)
+#endif
 
 // quad broadcast: every lane of a quad reads quad lane CTRL & 3.  (bound_ctrl with full row / bank masks: no lane keeps its
 // old value, so the compiler needs no copy of the source in front of the move.)
 template <int CTRL> __device__ __forceinline__ int wl_dpp_i(int x) { return __builtin_amdgcn_mov_dpp(x, CTRL, 0xf, 0xf, true); }
 template <int CTRL> __device__ __forceinline__ float wl_dpp_f(float x) {
     return __builtin_bit_cast(float, wl_dpp_i<CTRL>(__builtin_bit_cast(int, x)));
+}
+
+
+// min / max over groups of 8 lanes (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror) and over the whole wave (+ row_mirror,
+// row_bcast15, row_bcast31; the result is read from lane 63): vector-ALU DPP modifiers instead of LDS-crossbar shuffles
+template <bool MAX> __device__ __forceinline__ float wl_mm(float a, float b) { return MAX ? fmaxf(a, b) : fminf(a, b); }
+template <bool MAX, int CTRL, int ROWMASK = 0xf> __device__ __forceinline__ float wl_red_step(float x) {
+    const int xi = __builtin_bit_cast(int, x);
+    const float y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(xi, xi, CTRL, ROWMASK, 0xf, false));
+    return wl_mm<MAX>(x, y);
+}
+template <bool MAX> __device__ __forceinline__ float wl_reduce8(float x) {
+    x = wl_red_step<MAX, 0xB1>(x);     // quad_perm [1,0,3,2]
+    x = wl_red_step<MAX, 0x4E>(x);     // quad_perm [2,3,0,1]
+    return wl_red_step<MAX, 0x141>(x); // row_half_mirror
+}
+template <bool MAX> __device__ __forceinline__ float wl_wave_reduce(float x) {
+    x = wl_reduce8<MAX>(x);
+    x = wl_red_step<MAX, 0x140>(x);          // row_mirror: all 16 lanes of a row
+    x = wl_red_step<MAX, 0x142, 0xa>(x);     // row_bcast15 into rows 1 and 3
+    x = wl_red_step<MAX, 0x143, 0xc>(x);     // row_bcast31 into rows 2 and 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
 }
 
 // eight fp32 channels x four taps -> eight blended channels; t = {00lo, 00hi, 01lo, 01hi, 10lo, 10hi, 11lo, 11hi}
@@ -84,128 +127,47 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
     static_assert(GEOM == PSCV_GEOM_PROJ, "PROJ geometry (three depth-independent ray terms per (view, pixel))");
     extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
 
-    // ---- work decode: XCD-banded, tile-major, depth-chunk minor (the chunks of a tile re-read nearly the same texels: L2) ----
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int xcd = bid & 7, slot = bid >> 3, q_ = nwg >> 3, r_ = nwg & 7;
-    int wg = (xcd < r_ ? xcd * (q_ + 1) : r_ * (q_ + 1) + (xcd - r_) * q_) + slot;
-    wg = __builtin_amdgcn_readfirstlane(wg);
-    const int dc = wg % a.n_dchunks; wg /= a.n_dchunks;
+    // ---- work decode: grid = (8 x tiles-per-XCD, depth chunks).  Hardware places consecutive workgroups on consecutive XCDs,
+    //      so blockIdx.x & 7 is the XCD: give XCD k a contiguous run of tiles (its source footprint stays inside that XCD's
+    //      4 MiB L2; the depth chunks of a tile re-read nearly the same texels).  Float reciprocals replace integer division. ----
+    const int dc = blockIdx.y;
+    const int tpx = gridDim.x >> 3;
     const int ntx = (a.w + WL_T - 1) / WL_T, nty = (a.h + WL_T - 1) / WL_T;
-    const int txi = wg % ntx; wg /= ntx;
-    const int tyi = wg % nty;
-    const int b = wg / nty;
+    const int tile = ((int)blockIdx.x & 7) * tpx + ((int)blockIdx.x >> 3);
+    if (tile >= a.B * nty * ntx) return;
+    const int trow = (int)(((float)tile + 0.5f) * (1.0f / (float)ntx));     // exact: tile < 2^22
+    const int txi = tile - trow * ntx;
+    const int b = (int)(((float)trow + 0.5f) * (1.0f / (float)nty));
+    const int tyi = trow - b * nty;
 
+    // the box / staging phase of a new workgroup runs at raised priority: the (older) waves of the CU's other workgroup are in
+    // their vector-ALU-bound sweep and would otherwise win every issue slot (arbitration is priority, then age), stretching
+    // this short phase -- and with it the time the CU runs on one workgroup's waves only -- to ~25 000 cycles
+    __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int x0t = txi * WL_T, y0t = tyi * WL_T;
     const int d0 = dc * a.ppd, d1 = min(a.D, d0 + a.ppd);
     const float* const depth_b = a.depth + (long)b * a.depth_bstride;
     const int n_src = a.n_src;
+    int* const table = reinterpret_cast<int*>(lsm + WL_TABLE);
+#ifdef WL_PROFILE
+    unsigned long long t_prev = __builtin_readcyclecounter();
+    const unsigned long long t_begin = t_prev;
+    unsigned t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 
-    // ---- 1. depth planes of the chunk: lane i holds plane d0 + i (<= 64 planes per chunk); extremes by a wave reduction
-    //         (planes need not be monotone) ----
+    // depth planes of the chunk: lane i holds plane d0 + i (<= 64 planes per chunk)
     const float dlane = depth_b[min(d0 + lane, d1 - 1)];
-    float dmin = dlane, dmax = dlane;
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        dmin = fminf(dmin, __shfl_xor(dmin, m, 64)); dmax = fmaxf(dmax, __shfl_xor(dmax, m, 64));
-    }
 
-    // ---- 2. texel box per view from the 8 corner projections (tile corners x depth extremes): for a fixed plane the warp
-    //         is a homography (convex sets stay convex while z > 0), for a fixed pixel the sample moves monotonically along
-    //         its epipolar line, so every sample of the (tile, chunk) lies in the bounding box of these 8 points.  Every
-    //         wave computes this for itself (lanes 0..31 = 4 views x 8 corners) into scalar registers: no LDS, no barrier. ----
-    int bX0[WL_MAX_SRC], bY0[WL_MAX_SRC], bX1[WL_MAX_SRC], bY1[WL_MAX_SRC], bBase[WL_MAX_SRC], bPitch[WL_MAX_SRC], bMode[WL_MAX_SRC];
-    bool any_gen = false;
-    {
-        const int view = min((lane >> 3) & 3, n_src - 1), corner = lane & 7;
-        const float cxl = (float)x0t, cxh = (float)min(x0t + WL_T - 1, a.w - 1);
-        const float cyl = (float)y0t, cyh = (float)min(y0t + WL_T - 1, a.h - 1);
-        const float* cam = a.cams + ((long)view * a.B + b) * PSCV_CAM_FLOATS;
-        const float px = (corner & 1) ? cxh : cxl, py = (corner & 2) ? cyh : cyl, d = (corner & 4) ? dmax : dmin;
-        const float ax = fmaf(cam[1], py, cam[0] * px) + cam[2];
-        const float ay = fmaf(cam[4], py, cam[3] * px) + cam[5];
-        const float az = fmaf(cam[7], py, cam[6] * px) + cam[8];
-        const float hx = fmaf(ax, d, cam[9]), hy = fmaf(ay, d, cam[10]), hz = fmaf(az, d, cam[11]);
-        const float inv_z = 1.0f / hz;
-        const float u = hx * inv_z, v = hy * inv_z;
-        bool ok = hz > 1e-6f && fabsf(u) < 1e6f && fabsf(v) < 1e6f;   // also rejects NaN
-        float umin = u, umax = u, vmin = v, vmax = v;
-#pragma unroll
-        for (int m = 1; m < 8; m <<= 1) {
-            umin = fminf(umin, __shfl_xor(umin, m, 64)); umax = fmaxf(umax, __shfl_xor(umax, m, 64));
-            vmin = fminf(vmin, __shfl_xor(vmin, m, 64)); vmax = fmaxf(vmax, __shfl_xor(vmax, m, 64));
-            ok = ok && (__shfl_xor((int)ok, m, 64) != 0);
-        }
-        // slack of 1/64 texel: the per-pixel fp32 evaluation (1-ulp rcp, different rounding) differs from the corners' by
-        // < 1e-6 relative, i.e. < 1/64 for maps up to 16384 texels wide (warp_cost_tiled_try refuses larger ones)
-        const float sl = 1.0f / 64.0f;
-        const int X0 = ok ? (int)floorf(umin - sl) : 0, X1 = ok ? (int)floorf(umax + sl) + 1 : -1;
-        const int Y0 = ok ? (int)floorf(vmin - sl) : 0, Y1 = ok ? (int)floorf(vmax + sl) + 1 : -1;
-        int used = 0;
-#pragma unroll
-        for (int k = 0; k < WL_MAX_SRC; ++k) {
-            const int rX0 = __builtin_amdgcn_readlane(X0, 8 * k), rX1 = __builtin_amdgcn_readlane(X1, 8 * k);
-            const int rY0 = __builtin_amdgcn_readlane(Y0, 8 * k), rY1 = __builtin_amdgcn_readlane(Y1, 8 * k);
-            const bool okk = __builtin_amdgcn_readlane((int)ok, 8 * k) != 0;
-            const bool outside = rX1 < 0 || rY1 < 0 || rX0 > a.ws - 1 || rY0 > a.hs - 1;
-            const bool inside = rX0 >= 0 && rY0 >= 0 && rX1 <= a.ws - 1 && rY1 <= a.hs - 1;
-            bX0[k] = max(rX0, 0); bX1[k] = min(rX1, a.ws - 1);
-            bY0[k] = max(rY0, 0); bY1[k] = min(rY1, a.hs - 1);
-            const int bw = bX1[k] - bX0[k] + 1, bh = bY1[k] - bY0[k] + 1;
-            bPitch[k] = (bw + 3) & ~3;   // a multiple of 4: the four quads of a ds_read_b128 lane group stay conflict-free across rows
-            int mode = WL_DIRECT;
-            if (k < n_src && okk) {
-                if (outside) mode = WL_ZERO;
-                else if (bw <= 16 && used + bPitch[k] * bh <= WL_ARENA) mode = inside ? WL_FAST : WL_GEN;
-            }
-            bMode[k] = mode;
-            bBase[k] = used;
-            if (mode == WL_FAST || mode == WL_GEN) used += bPitch[k] * bh;
-            any_gen = any_gen || mode == WL_GEN;
-        }
-    }
-
-    // ---- 3. stage the boxes, 16-bit -> fp32 on the way: waves 2k, 2k+1 take the even / odd rows of view k's box ----
-    {
-        const int k = wave >> 1;
-        int X0 = bX0[0], Y0 = bY0[0], X1 = bX1[0], Y1 = bY1[0], vbase = bBase[0], pitch = bPitch[0], mode = bMode[0];
-        const void* srcp = a.src[0];
-#pragma unroll
-        for (int t = 1; t < WL_MAX_SRC; ++t)
-            if (k == t) { X0 = bX0[t]; Y0 = bY0[t]; X1 = bX1[t]; Y1 = bY1[t]; vbase = bBase[t]; pitch = bPitch[t]; mode = bMode[t]; srcp = a.src[t]; }
-        if (mode == WL_FAST || mode == WL_GEN) {
-            const int bw = X1 - X0 + 1, bh = Y1 - Y0 + 1;
-            constexpr int RU = 8;     // rows in flight per wave (boxes are <= 16 rows in practice; the loop covers any height)
-            const bool mine = lane < bw * 4;          // 16-byte chunk of a row (bw <= 16 texels)
-            const TIn* col = reinterpret_cast<const TIn*>(srcp) + (((long)b * a.hs + Y0) * a.ws + X0) * C + lane * 8;
-            const int dst0 = (vbase + (lane >> 2)) * 64 + (lane & 3) * 16;
-            for (int r0 = wave & 1; r0 < bh; r0 += 2 * RU) {
-                uint4 val[RU];
-#pragma unroll
-                for (int i = 0; i < RU; ++i) {
-                    const int ty = r0 + 2 * i;
-                    if (mine && ty < bh) val[i] = *reinterpret_cast<const uint4*>(col + (long)ty * a.ws * C);
-                }
-#pragma unroll
-                for (int i = 0; i < RU; ++i) {
-                    const int ty = r0 + 2 * i;
-                    if (mine && ty < bh) {
-                        const uint4 u = val[i];
-                        const float4 lo = make_float4(Half16<TIn>::lo(u.x), Half16<TIn>::hi(u.x), Half16<TIn>::lo(u.y), Half16<TIn>::hi(u.y));
-                        const float4 hi = make_float4(Half16<TIn>::lo(u.z), Half16<TIn>::hi(u.z), Half16<TIn>::lo(u.w), Half16<TIn>::hi(u.w));
-                        *reinterpret_cast<float4*>(lsm + dst0 + ty * pitch * 64) = lo;
-                        *reinterpret_cast<float4*>(lsm + dst0 + ty * pitch * 64 + WL_HI) = hi;
-                    }
-                }
-            }
-        }
-    }
-
-    // ---- 4. per-lane constants of the sweep: lane l of a quad owns channels 8l..8l+7 of the quad's voxel and computes the
-    //         sample position in source view l ----
+    // per-lane constants of the sweep (loads issued before the box phase): lane l of a quad owns channels 8l..8l+7 of the
+    // quad's voxel and computes the sample position in source view l
     const int quad = lane >> 2, l = lane & 3;
-    const int pl = (2 * (wave & 3) + (quad >> 3)) * 8 + (quad & 7);     // pixel of the tile
+    // pixel of the tile.  A ds_read_b128 is served in groups of 16 lanes = the quads {0,3,5,6} / {1,2,4,7} (+8) of a wave:
+    // give each group four x-ADJACENT pixels, whose samples fall on at most four consecutive (or identical) texels of a
+    // row = four distinct 64-byte bank groups, for any source scale <= 4/3 (quads of a tile row in natural order collide
+    // as soon as the scale is below 1: columns 0 3 5 6 -> texels 0 2 4 5)
+    const int pl = (2 * (wave & 3) + (quad >> 3)) * 8 + ((0x73261540u >> (4 * (quad & 7))) & 7);
     int x = x0t + (pl & 7), y = y0t + (pl >> 3);
     const bool active = x < a.w && y < a.h;
     x = min(x, a.w - 1); y = min(y, a.h - 1);
@@ -213,9 +175,7 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
     const int pflat = y * a.w + x;
     const float px = (float)x, py = (float)y;
     const unsigned chb = (unsigned)l * 16u;
-
-    // view l: depth-independent ray terms rot (x, y, 1), translation, and its (clipped) box
-    float rx, ry, rz, tx, ty_, tz;
+    float rx, ry, rz, tx, ty_, tz;     // view l: depth-independent ray terms rot (x, y, 1) and the translation
     {
         const float* cam = a.cams + ((long)min(l, n_src - 1) * a.B + b) * PSCV_CAM_FLOATS;
         rx = fmaf(cam[1], py, cam[0] * px) + cam[2];
@@ -223,18 +183,128 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
         rz = fmaf(cam[7], py, cam[6] * px) + cam[8];
         tx = cam[9]; ty_ = cam[10]; tz = cam[11];
     }
-    int mX0 = bX0[0], mX1 = bX1[0], mY0 = bY0[0], mY1 = bY1[0], mpitch = bPitch[0], mbase = bBase[0];
-#pragma unroll
-    for (int k = 1; k < WL_MAX_SRC; ++k)
-        if (l == k) { mX0 = bX0[k]; mX1 = bX1[k]; mY0 = bY0[k]; mY1 = bY1[k]; mpitch = bPitch[k]; mbase = bBase[k]; }
-    const int meb = mbase - mY0 * mpitch - mX0;    // texel index = y * pitch + x + meb
-
     float rf[8];
     {
         const f32x8 t = Elem<TIn>::load8(reinterpret_cast<const TIn*>(a.ref) + ((long)b * hw + pflat) * C + l * 8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) rf[j] = t.v[j];
     }
+
+    WL_STAMP(0)
+    // ---- 1. wave 0: texel box per view from the 8 corner projections (tile corners x depth extremes of the chunk): for a
+    //         fixed plane the warp is a homography (convex sets stay convex while z > 0), for a fixed pixel the sample moves
+    //         monotonically along its epipolar line, so every sample of the (tile, chunk) lies in the bounding box of these
+    //         8 points.  The camera blocks come through the SCALAR cache (constant address space: the vector memory path is
+    //         busy with the cost-volume stores of the other waves and answers in thousands of cycles); lanes = corners;
+    //         min / max by DPP; arena allocation greedy in view order, all in scalar registers. ----
+    if (wave == 0) {
+        const float dmin = wl_wave_reduce<false>(dlane), dmax = wl_wave_reduce<true>(dlane);   // (planes need not be monotone)
+        const int corner = lane & 7;
+        const float cx = (corner & 1) ? (float)min(x0t + WL_T - 1, a.w - 1) : (float)x0t;
+        const float cy = (corner & 2) ? (float)min(y0t + WL_T - 1, a.h - 1) : (float)y0t;
+        const float d = (corner & 4) ? dmax : dmin;
+        int used = 0;
+#pragma unroll
+        for (int k = 0; k < WL_MAX_SRC; ++k) {
+            int cX0 = 0, cY0 = 0, cX1 = -1, cY1 = -1, pitch = 4, mode = WL_ZERO;
+            if (k < n_src) {
+                typedef const __attribute__((address_space(4))) float* wl_cf;
+                wl_cf cam = (wl_cf)(a.cams + ((long)k * a.B + b) * PSCV_CAM_FLOATS);
+                const float ax = fmaf(cam[1], cy, cam[0] * cx) + cam[2];
+                const float ay = fmaf(cam[4], cy, cam[3] * cx) + cam[5];
+                const float az = fmaf(cam[7], cy, cam[6] * cx) + cam[8];
+                const float hx = fmaf(ax, d, cam[9]), hy = fmaf(ay, d, cam[10]), hz = fmaf(az, d, cam[11]);
+                const float inv_z = __builtin_amdgcn_rcpf(hz);
+                const float u = hx * inv_z, v = hy * inv_z;
+                const float okf = (hz > 1e-6f && fabsf(u) < 1e6f && fabsf(v) < 1e6f) ? 1.0f : 0.0f;   // also rejects NaN
+                const float umin = wl_reduce8<false>(u), umax = wl_reduce8<true>(u);
+                const float vmin = wl_reduce8<false>(v), vmax = wl_reduce8<true>(v);
+                const bool ok = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wl_reduce8<false>(okf))) != 0;
+                // slack of 1/32 texel: the per-pixel fp32 evaluation (different rounding, 1-ulp rcp on both sides) differs
+                // from the corners' by < 2e-6 relative, i.e. < 1/32 for maps up to 16384 texels wide (larger ones are refused)
+                const float sl = 1.0f / 32.0f;
+                const int X0 = __builtin_amdgcn_readfirstlane((int)floorf(umin - sl)), X1 = __builtin_amdgcn_readfirstlane((int)floorf(umax + sl)) + 1;
+                const int Y0 = __builtin_amdgcn_readfirstlane((int)floorf(vmin - sl)), Y1 = __builtin_amdgcn_readfirstlane((int)floorf(vmax + sl)) + 1;
+                mode = WL_DIRECT;
+                if (ok) {
+                    const bool outside = X1 < 0 || Y1 < 0 || X0 > a.ws - 1 || Y0 > a.hs - 1;
+                    const bool inside = X0 >= 0 && Y0 >= 0 && X1 <= a.ws - 1 && Y1 <= a.hs - 1;
+                    cX0 = max(X0, 0); cX1 = min(X1, a.ws - 1); cY0 = max(Y0, 0); cY1 = min(Y1, a.hs - 1);
+                    const int bw = cX1 - cX0 + 1, bh = cY1 - cY0 + 1;
+                    pitch = (bw + 3) & ~3;   // a multiple of 4: the quads of a ds_read_b128 lane group stay conflict-free across rows
+                    if (outside) mode = WL_ZERO;
+                    else if (bw <= 16 && bh <= 16 && used + pitch * bh <= WL_ARENA) mode = inside ? WL_FAST : WL_GEN;
+                }
+            }
+            if (lane == 0) {
+                int4* row = reinterpret_cast<int4*>(table + k * 8);
+                row[0] = make_int4(cX0, cY0, cX1, cY1);
+                row[1] = make_int4(used, pitch, mode, 0);
+            }
+            if (mode == WL_FAST || mode == WL_GEN) used += pitch * (cY1 - cY0 + 1);
+        }
+    }
+    WL_STAMP(1)
+    __syncthreads();
+    WL_STAMP(2)
+
+    // ---- 2. every wave: modes / pitches of the four views -> scalar registers; this lane's view -> vector registers ----
+    int bPitch[WL_MAX_SRC], bMode[WL_MAX_SRC];
+    bool any_gen = false;
+#pragma unroll
+    for (int k = 0; k < WL_MAX_SRC; ++k) {
+        const int4 r1 = *reinterpret_cast<const int4*>(table + k * 8 + 4);
+        bPitch[k] = __builtin_amdgcn_readfirstlane(r1.y);
+        bMode[k] = __builtin_amdgcn_readfirstlane(r1.z);
+        any_gen = any_gen || bMode[k] == WL_GEN;
+    }
+    const int4 mr0 = *reinterpret_cast<const int4*>(table + l * 8), mr1 = *reinterpret_cast<const int4*>(table + l * 8 + 4);
+    const int mX0 = mr0.x, mY0 = mr0.y, mX1 = mr0.z, mY1 = mr0.w, mpitch = mr1.y;
+    const int meb = mr1.x - mY0 * mpitch - mX0;    // texel index = y * pitch + x + meb
+
+    // ---- 3. stage the boxes, 16-bit -> fp32 on the way: waves 2k, 2k+1 take the even / odd rows of view k's box ----
+    {
+        const int k = wave >> 1;
+        const int4 f0 = *reinterpret_cast<const int4*>(table + k * 8), f1 = *reinterpret_cast<const int4*>(table + k * 8 + 4);
+        const int X0 = __builtin_amdgcn_readfirstlane(f0.x), Y0 = __builtin_amdgcn_readfirstlane(f0.y);
+        const int X1 = __builtin_amdgcn_readfirstlane(f0.z), Y1 = __builtin_amdgcn_readfirstlane(f0.w);
+        const int vbase = __builtin_amdgcn_readfirstlane(f1.x), pitch = __builtin_amdgcn_readfirstlane(f1.y);
+        const int mode = __builtin_amdgcn_readfirstlane(f1.z);
+        const void* srcp = a.src[0];
+#pragma unroll
+        for (int t = 1; t < WL_MAX_SRC; ++t)
+            if (k == t) srcp = a.src[t];
+        if (mode == WL_FAST || mode == WL_GEN) {
+            const int bw = X1 - X0 + 1, bh = Y1 - Y0 + 1;      // both <= 16
+            // eight row loads per wave, issued as one branch-free batch (clamped addresses; only the LDS writes are
+            // predicated): a per-row `if` in front of each load costs a full memory round trip per row
+            constexpr int RU = 8;
+            const int cl = min(lane, bw * 4 - 1);          // 16-byte chunk of a row
+            const bool mine = lane < bw * 4;
+            const TIn* col = reinterpret_cast<const TIn*>(srcp) + (((long)b * a.hs + Y0) * a.ws + X0) * C + cl * 8;
+            const int dst0 = (vbase + (cl >> 2)) * 64 + (cl & 3) * 16;
+            const long rstride = (long)a.ws * C;
+            uint4 val[RU];
+#pragma unroll
+            for (int i = 0; i < RU; ++i) {
+                const int ty = min((wave & 1) + 2 * i, bh - 1);
+                val[i] = *reinterpret_cast<const uint4*>(col + ty * rstride);
+            }
+#pragma unroll
+            for (int i = 0; i < RU; ++i) {
+                const int ty = (wave & 1) + 2 * i;
+                if (mine && ty < bh) {
+                    const uint4 u = val[i];
+                    const float4 lo = make_float4(Half16<TIn>::lo(u.x), Half16<TIn>::hi(u.x), Half16<TIn>::lo(u.y), Half16<TIn>::hi(u.y));
+                    const float4 hi = make_float4(Half16<TIn>::lo(u.z), Half16<TIn>::hi(u.z), Half16<TIn>::lo(u.w), Half16<TIn>::hi(u.w));
+                    *reinterpret_cast<float4*>(lsm + dst0 + ty * pitch * 64) = lo;
+                    *reinterpret_cast<float4*>(lsm + dst0 + ty * pitch * 64 + WL_HI) = hi;
+                }
+            }
+        }
+    }
+
+    WL_STAMP(3)
     const float invN = 1.0f / (float)(n_src + 1);
     const float invN2 = 1.0f / ((float)(n_src + 1) * (float)(n_src + 1));
     char* const out = reinterpret_cast<char*>(a.out);
@@ -242,9 +312,16 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
     const unsigned lane_out = (unsigned)pflat * (C * OB) + (unsigned)l * (8 * OB);
     const unsigned long img_bytes = (unsigned long)b * a.hs * a.ws * PIXB;
     __syncthreads();
+    __builtin_amdgcn_s_setprio(0);
+    WL_STAMP(4)
 
     // ---- 5. sweep: one voxel per quad and step, all source views ----
-    for (int d = d0 + (wave >> 2); d < d1; d += 2) {
+    int d1_eff = d1;
+#ifdef WL_PROFILE
+    const bool wl_skip = a.temp == -12345.0f;   // (phase timing of the staging alone)
+    if (wl_skip) d1_eff = d0;
+#endif
+    for (int d = d0 + (wave >> 2); d < d1_eff; d += 2) {
         const float dval = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dlane), d - d0));
         float s[8], q[8];          // variance: sum, sum of squares; softmin: sum e*diff (s only)
         float sum_e = 0.0f;
@@ -295,11 +372,11 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
                 w10 = (vx0 && vy1) ? w10 : 0.0f; w11 = (vx1 && vy1) ? w11 : 0.0f;
                 const int xc0 = med3_i32(x0, mX0, mX1), xc1 = med3_i32(x1, mX0, mX1);
                 const int yc0 = med3_i32(y0, mY0, mY1), yc1 = med3_i32(y1, mY0, mY1);
-                E = (yc0 * mpitch + xc0 + meb) << 6;
+                E = (__mul24(yc0, mpitch) + xc0 + meb) << 6;
                 DX = (xc1 - xc0) << 6;
-                DY = ((yc1 - yc0) * mpitch) << 6;
+                DY = __mul24(yc1 - yc0, mpitch) << 6;
             } else {
-                E = (y0 * mpitch + x0 + meb) << 6;
+                E = (__mul24(y0, mpitch) + x0 + meb) << 6;
             }
         }
 
@@ -397,6 +474,23 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
         }
         if (active) wl_store8<TOut>(out + ((unsigned long)b * a.D + d) * plane_bytes + lane_out, o);
     }
+    WL_STAMP(5)
+#ifdef WL_PROFILE
+    if (lane == 0 && (wave == 0 || wave == 7)) {
+        const int blk = blockIdx.x + gridDim.x * blockIdx.y;
+        if (blk < WL_PROF_BLOCKS)
+            for (int i = 0; i < 6; ++i) wl_prof[blk * 16 + (wave ? 8 : 0) + i] = t_acc[i];
+        if (blk < WL_PROF_BLOCKS) {   // absolute begin / end stamps (low 32 bits) and the hardware slot of this wave
+            unsigned hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            wl_prof[blk * 16 + (wave ? 8 : 0) + 6] = (unsigned)t_begin;
+            wl_prof[blk * 16 + (wave ? 8 : 0) + 7] = (unsigned)t_prev;
+            if (wave == 0) { wl_prof[blk * 16 + 0] = hwid; } else { wl_prof[blk * 16 + 8] = xcc; }
+        }
+    }
+#endif
 }
 
 template <typename TIn, typename TOut, int COST>
@@ -408,7 +502,8 @@ static int wl_launch(const WarpArgs& a, int nblk, hipStream_t st) {
         if (e != hipSuccess) { set_error("pscv_warp_cost(lds): hipFuncSetAttribute: %s", hipGetErrorString(e)); return -2; }
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(nblk), dim3(WL_THREADS), WL_LDS, st, a);
+    const int tiles = a.B * ((a.h + WL_T - 1) / WL_T) * ((a.w + WL_T - 1) / WL_T);
+    hipLaunchKernelGGL(kern, dim3(8 * ((tiles + 7) / 8), a.n_dchunks), dim3(WL_THREADS), WL_LDS, st, a);
     return 0;
 }
 
@@ -427,6 +522,7 @@ int warp_cost_tiled_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, in
     if (out_dtype != in_dtype && out_dtype != PSCV_F32) return 1;
     if (a.n_src < 1 || a.n_src > WL_MAX_SRC) return 1;
     if (a.ws > 16384 || a.hs > 16384) return 1;
+    if ((long)((a.h + WL_T - 1) / WL_T) * ((a.w + WL_T - 1) / WL_T) * a.B >= (1L << 22)) return 1;   // tile index decode is exact below 2^22
     const long tiles = (long)a.B * ((a.h + WL_T - 1) / WL_T) * ((a.w + WL_T - 1) / WL_T);
     int ppd = ppd_override > 0 ? min((ppd_override + 1) & ~1, 64) : 16;   // planes per block: amortises the patch staging
     while (ppd > 4 && tiles * ((a.D + ppd - 1) / ppd) < 1024) ppd >>= 1;
@@ -441,3 +537,20 @@ int warp_cost_tiled_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, in
 }
 
 }  // namespace pscv
+
+#ifdef WL_PROFILE
+// sums over the first n_blocks blocks of the last launch
+extern "C" int pscv_debug_wl_raw(unsigned int* out, int n_blocks) {
+    if (n_blocks > pscv::WL_PROF_BLOCKS) n_blocks = pscv::WL_PROF_BLOCKS;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pscv::wl_prof), (size_t)n_blocks * 16 * sizeof(unsigned int));
+}
+extern "C" int pscv_debug_wl_prof(unsigned long long* out16, int n_blocks) {
+    static unsigned int host[pscv::WL_PROF_BLOCKS * 16];
+    if (n_blocks > pscv::WL_PROF_BLOCKS) n_blocks = pscv::WL_PROF_BLOCKS;
+    hipMemcpyFromSymbol(host, HIP_SYMBOL(pscv::wl_prof), (size_t)n_blocks * 16 * sizeof(unsigned int));
+    for (int i = 0; i < 16; ++i) out16[i] = 0;
+    for (int b = 0; b < n_blocks; ++b)
+        for (int i = 0; i < 16; ++i) out16[i] += host[b * 16 + i];
+    return 0;
+}
+#endif
