@@ -91,19 +91,46 @@ def build_inputs(device, rank: int, dtype):
     return net, sd, feats, feats_cl, proj.to(device), dv.to(device).contiguous(), proj, dv
 
 
-def cpu_baseline(sd, feats, proj, dv, gpu_depth):
-    """The oracle's hot path (same stages, fp32 ATen on the host cores) on the same workload, once.  The pass also yields the
-    second half of BASELINE.json's metric at the full headline size: relative L1 of the engine's depth map against it."""
+REF_CONTAINER = {"seconds": 3.47, "voxels_per_s": VOX / 3.47, "threads": 8,
+                 "what": "the reference's own eval path (/root/reference models/MVSNet/model.py:109-139,74-84,207-209) on the same "
+                         "inputs in the build container (8 vCPU), median of 3; the oracle's streaming path took 2.95 s there with "
+                         "identical depth (scripts/time_reference_cpu.py)"}
+
+
+def physical_cores() -> int:
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
+
+
+def cpu_baseline(sd, feats, proj, dv, gpu_depths: dict):
+    """The oracle's hot path in the reference's eval-mode order (view by view, in-place sums: oracle.mvsnet.hot_path(streaming=True),
+    same stages, fp32 ATen) on the same workload: one warm-up pass, then the median of three, on the physical host cores.
+    The depth map of the pass also yields the second half of BASELINE.json's metric at the full headline size: relative L1 of the
+    engine's depth maps (one per storage format) against it."""
     from oracle import mvsnet as O          # cpu_baseline leg only
-    cores = os.cpu_count() or 1
+    cores = physical_cores()
     torch.set_num_threads(cores)
+    dvv = dv.unsqueeze(1).expand(-1, V, -1)
+    fl = [feats[i] for i in range(V)]
+    times = []
     with torch.no_grad():
-        t0 = time.perf_counter()
-        o_depth, _ = O.hot_path([feats[i] for i in range(V)], proj, dv.unsqueeze(1).expand(-1, V, -1), sd)
-        dt = time.perf_counter() - t0
-    rel_l1 = float((gpu_depth.float().cpu() - o_depth).abs().mean() / o_depth.abs().mean())
+        o_depth, _ = O.hot_path(fl, proj, dvv, sd, streaming=True)     # warm-up: thread pool, allocator
+        for _ in range(3):
+            t0 = time.perf_counter()
+            o_depth, _ = O.hot_path(fl, proj, dvv, sd, streaming=True)
+            times.append(time.perf_counter() - t0)
+    dt = sorted(times)[1]
+    rel = {k: float((d.float().cpu() - o_depth).abs().mean() / o_depth.abs().mean()) for k, d in gpu_depths.items()}
     return {"value": VOX / dt, "unit": "voxels/s", "cores": cores, "kind": "port",
-            "sample": f"1 pass of the same workload (5-view 128x160x32 features, D=192, fp32, {dt:.1f} s)"}, rel_l1
+            "sample": f"the same workload (5-view 128x160x32 features, D=192, fp32), eval-mode order of the reference; warm-up + median of "
+                      f"3 passes ({dt:.2f} s; all: {', '.join(f'{t:.2f}' for t in times)})",
+            "ref_container_s": REF_CONTAINER["seconds"], "ref_container": REF_CONTAINER}, rel
 
 
 def main():
@@ -112,6 +139,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the forward() timings of BASELINE configurations 3-5")
     ap.add_argument("--dtype", choices=sorted(DTYPES), default="f16",
                     help="16-bit HBM storage format (arithmetic is fp32); f16 is the engine default, see DESIGN.md section 5")
     ap.add_argument("--dump-events", default=None, help="write every per-launch event duration to this file")
@@ -137,62 +165,73 @@ def main():
         _lib.set_tuning(k, int(v))
     net, sd, feats, feats_cl, proj_d, dv_d, proj, dv = build_inputs(device, rank, DTYPES[args.dtype])
 
-    def step():
-        return net.hot_path(feats_cl, proj_d, dv_d)
+    def timed_region(dtype_name, feats_cl_, steps):
+        """W warm-up steps, then exactly `steps` steps between barrier + synchronize on both sides; then the same steps once
+        more eagerly with a HIP event pair around every launch (per-kernel durations)."""
+        net.storage_dtype = DTYPES[dtype_name]
 
-    with torch.no_grad():
-        for _ in range(max(args.warmup, 1)):
-            depth, conf = step()
-        torch.cuda.synchronize()
-        graph = None
-        if not args.eager:
-            # the 15-launch step is launch-gap bound between its small kernels: capture it once, replay it
-            try:
-                graph = torch.cuda.CUDAGraph()
-                # thread_local: the RCCL watchdog thread of a multi-GPU run must not invalidate the capture
-                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                    depth, conf = step()
-                for _ in range(2):
-                    graph.replay()
-                torch.cuda.synchronize()
-            except Exception as e:   # pragma: no cover  (never seen on 1 GPU; keeps an N-GPU run alive)
-                print(f"[bench] hipGraph capture failed ({e}); timing eager launches", file=sys.stderr)
-                graph = None
-                torch.cuda.synchronize()
-        run = graph.replay if graph is not None else step
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        # no cyclic-GC pause inside a timed region (a gen-2 collection with torch loaded costs ~40 ms)
-        gc.collect()
-        gc.disable()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            run()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        # per-kernel durations: the same K steps launched eagerly with a HIP event pair around every launch
-        with ops.EventTimer() as tm:
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
+        def step():
+            return net.hot_path(feats_cl_, proj_d, dv_d)
+
+        with torch.no_grad():
+            for _ in range(max(args.warmup, 1)):
                 depth, conf = step()
             torch.cuda.synchronize()
-            elapsed_eager = time.perf_counter() - t1
-        gc.enable()
-        kern = {k: v for k, v in tm.summary().items() if k != "proj_cams"}
-        if args.dump_events and rank == 0:
-            with open(args.dump_events, "w") as f:
-                for name, e0, e1 in tm.records:
-                    f.write(f"{name}\t{e0.elapsed_time(e1) * 1e3:.1f}\n")
-    assert torch.isfinite(depth).all()
+            graph = None
+            if not args.eager:
+                # the 13-launch step is launch-gap bound between its small kernels: capture it once, replay it
+                try:
+                    graph = torch.cuda.CUDAGraph()
+                    # thread_local: the RCCL watchdog thread of a multi-GPU run must not invalidate the capture
+                    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                        depth, conf = step()
+                    for _ in range(2):
+                        graph.replay()
+                    torch.cuda.synchronize()
+                except Exception as e:   # pragma: no cover  (never seen on 1 GPU; keeps an N-GPU run alive)
+                    print(f"[bench] hipGraph capture failed ({e}); timing eager launches", file=sys.stderr)
+                    graph = None
+                    torch.cuda.synchronize()
+            run = graph.replay if graph is not None else step
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            # no cyclic-GC pause inside a timed region (a gen-2 collection with torch loaded costs ~40 ms)
+            gc.collect()
+            gc.disable()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                run()
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+            with ops.EventTimer() as tm:
+                t1 = time.perf_counter()
+                for _ in range(steps):
+                    depth, conf = step()
+                torch.cuda.synchronize()
+                elapsed_eager = time.perf_counter() - t1
+            gc.enable()
+        assert torch.isfinite(depth).all()
+        t_max = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        return float(t_max.item()), tm, depth.clone(), graph is not None, elapsed_eager
 
-    t_max = torch.tensor([elapsed], device=device, dtype=torch.float64)
-    if dist is not None:
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-    elapsed = float(t_max.item())
+    elapsed, tm, depth, graphed, elapsed_eager = timed_region(args.dtype, feats_cl, args.steps)
+    kern = {k: v for k, v in tm.summary().items() if k != "proj_cams"}
+    if args.dump_events and rank == 0:
+        with open(args.dump_events, "w") as f:
+            for name, e0, e1 in tm.records:
+                f.write(f"{name}\t{e0.elapsed_time(e1) * 1e3:.1f}\n")
+    # the other 16-bit storage format on the same workload (BASELINE.json names bf16; same bytes, same MFMA rate)
+    alt_name = "bf16" if args.dtype == "f16" else "f16"
+    feats_alt = [ops.to_channels_last(feats[i].to(device), DTYPES[alt_name]) for i in range(V)]
+    alt_elapsed, alt_tm, alt_depth, _, _ = timed_region(alt_name, feats_alt, args.steps)
+    net.storage_dtype = DTYPES[args.dtype]
+    graph = graphed
 
     if rank == 0:
         total_ms = sum(ms for _, ms in kern.values())
@@ -221,22 +260,38 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "dtype_note": "16-bit HBM storage and MFMA operands, fp32 accumulation.  BASELINE.json names bf16: same bytes and MFMA "
-                          "rate, selectable with --dtype bf16 (profiles/r01_bench_line_bf16.json); fp16 is the default because "
-                          "bf16 storage sits at the 1e-3 parity bar (DESIGN.md section 5)",
+                          "rate; its driver-timed line and full-size depth error are under \"alt\" (and vice versa with --dtype bf16). "
+                          "fp16 is the headline because bf16 storage sits at the 1e-3 parity bar (DESIGN.md section 3)",
             "config": {"workload": "MVSNet variance, 1 ref + 4 src views, 512x640 images (128x160x32 features), D=192, "
                                    "features resident in HBM -> depth + confidence", "global_batch": world,
                        "voxels_per_step_per_gpu": VOX, "parallelism": f"reference-view shard x{world}, no collective"},
-            "timing": ("hipGraph replay of the step" if graph is not None else "eager launches") +
+            "timing": ("hipGraph replay of the step" if graph else "eager launches") +
                       f"; per-kernel HIP events from an eager pass of the same {args.steps} steps "
                       f"({elapsed_eager / args.steps * 1e3:.3f} ms/step eager)",
             "roofline": roof,
             "roofline_mfma": roof_mfma,
             "kernels_us": {k: round(ms / n * 1e3, 2) for k, (n, ms) in sorted(kern.items(), key=lambda kv: -kv[1][1])},
         }
+        alt_kern = {k: v for k, v in alt_tm.summary().items() if k != "proj_cams"}
+        line["alt"] = {"dtype": alt_name, "value": world * VOX * args.steps / alt_elapsed, "unit": "voxels/s",
+                       "ms_per_step": alt_elapsed / args.steps * 1e3,
+                       "kernels_us": {k: round(ms / n * 1e3, 2) for k, (n, ms) in sorted(alt_kern.items(), key=lambda kv: -kv[1][1])}}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"], line["depth_rel_l1_vs_oracle"] = cpu_baseline(sd, feats, proj, dv, depth)
+            line["cpu_baseline"], rel = cpu_baseline(sd, feats, proj, dv, {args.dtype: depth, alt_name: alt_depth})
+            line["depth_rel_l1_vs_oracle"] = rel[args.dtype]
+            line["alt"]["depth_rel_l1_vs_oracle"] = rel[alt_name]
         else:
             line["cpu_baseline"] = None
+        # BASELINE configurations 3, 4, 5 in their single-GPU forms (parity cases of tests/test_gpu_fullsize.py, not bench lines):
+        # driver-timed ms of the full forward(), after the headline region
+        line["other_configs"] = None
+        if world == 1 and not args.no_other_configs:
+            try:
+                sys.path.insert(0, os.path.join(REPO, "scripts"))
+                import run_configs
+                line["other_configs"] = [run_configs.time_config(c) for c in (3, 4, 5)]
+            except Exception as e:   # pragma: no cover  (never lose the headline line to a side measurement)
+                line["other_configs"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

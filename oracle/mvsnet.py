@@ -120,7 +120,29 @@ def softmin_cost(ref_fea, warped: Sequence[torch.Tensor], temp: torch.Tensor) ->
     return sum_v / (sum_e + 1e-6)
 
 
-def build_cost_volume(ref_fea, src_feas, ref_proj, src_projs, depth_values, aggregation="variance", temp=None):
+def variance_cost_streaming(ref_fea, src_feas, ref_proj, src_projs, depth_values) -> torch.Tensor:
+    """The same statistic in the reference's EVAL-mode order (``models/MVSNet/model.py:118-137`` with
+    ``self.training == False``): one source view at a time, the warped volume folded into the two running sums in
+    place and dropped, the final ``sq / N - s^2 / N^2`` in place as well.  Identical values to ``variance_cost`` (same
+    operations in the same order per element); it exists because it is what the reference's CPU inference path costs:
+    one 503 MB warped volume alive at a time instead of V - 1 of them plus out-of-place sums (bench.py's
+    ``cpu_baseline`` leg times this form)."""
+    D = depth_values.shape[1]
+    N = len(src_feas) + 1
+    s = ref_fea.unsqueeze(2).repeat(1, 1, D, 1, 1)
+    sq = s ** 2
+    for sf, sp in zip(src_feas, src_projs):
+        wv = homo_warping(sf, sp, ref_proj, depth_values, ref_fea.shape[-2:])
+        s += wv
+        sq += wv.pow_(2)
+        del wv
+    return sq.div_(N).sub_(s.pow_(2).div_(N ** 2))
+
+
+def build_cost_volume(ref_fea, src_feas, ref_proj, src_projs, depth_values, aggregation="variance", temp=None,
+                      streaming: bool = False):
+    if aggregation == "variance" and streaming:
+        return variance_cost_streaming(ref_fea, src_feas, ref_proj, src_projs, depth_values)
     warped = [homo_warping(sf, sp, ref_proj, depth_values, ref_fea.shape[-2:]) for sf, sp in zip(src_feas, src_projs)]
     if aggregation == "variance":
         return variance_cost(ref_fea, warped)
@@ -228,22 +250,24 @@ def cost_reg_net(cost: torch.Tensor, sd: SD, prefix: str = "cost_regularization"
     return logits
 
 
-def conv_bn_relu_2d(x, sd: SD, prefix: str, stride: int, pad: int, training: bool = False):
-    return F.relu(_bn(F.conv2d(x, sd[prefix + ".conv.weight"], None, stride=stride, padding=pad), sd, prefix + ".bn", training))
+def conv_bn_relu_2d(x, sd: SD, prefix: str, stride: int, pad: int, training: bool = False, store=None):
+    y = F.relu(_bn(F.conv2d(x, _w(sd, prefix + ".conv.weight", store), None, stride=stride, padding=pad), sd, prefix + ".bn", training))
+    return stored(y, store, round_grad=False)
 
 
-def feature_net(img: torch.Tensor, sd: SD, prefix: str = "feature", training: bool = False) -> torch.Tensor:
+def feature_net(img: torch.Tensor, sd: SD, prefix: str = "feature", training: bool = False, store=None) -> torch.Tensor:
     """2-D ``FeatureNet`` reference ``models/MVSNet/model.py:21-41`` (upstream of the hot
-    path; restated so that the full ``forward()`` can be checked).  [B,3,H,W] -> [B,32,H/4,W/4]."""
+    path; restated so that the full ``forward()`` can be checked).  [B,3,H,W] -> [B,32,H/4,W/4].
+    ``store``: emulate the engine's 2-D extractor, which keeps every layer's output (and the weights) in 16-bit storage."""
     p = prefix + "."
-    x = conv_bn_relu_2d(img, sd, p + "conv0", 1, 1, training)
-    x = conv_bn_relu_2d(x, sd, p + "conv1", 1, 1, training)
-    x = conv_bn_relu_2d(x, sd, p + "conv2", 2, 2, training)
-    x = conv_bn_relu_2d(x, sd, p + "conv3", 1, 1, training)
-    x = conv_bn_relu_2d(x, sd, p + "conv4", 1, 1, training)
-    x = conv_bn_relu_2d(x, sd, p + "conv5", 2, 2, training)
-    x = conv_bn_relu_2d(x, sd, p + "conv6", 1, 1, training)
-    return F.conv2d(x, sd[p + "feature.weight"], sd[p + "feature.bias"], stride=1, padding=1)
+    x = conv_bn_relu_2d(img, sd, p + "conv0", 1, 1, training, store)
+    x = conv_bn_relu_2d(x, sd, p + "conv1", 1, 1, training, store)
+    x = conv_bn_relu_2d(x, sd, p + "conv2", 2, 2, training, store)
+    x = conv_bn_relu_2d(x, sd, p + "conv3", 1, 1, training, store)
+    x = conv_bn_relu_2d(x, sd, p + "conv4", 1, 1, training, store)
+    x = conv_bn_relu_2d(x, sd, p + "conv5", 2, 2, training, store)
+    x = conv_bn_relu_2d(x, sd, p + "conv6", 1, 1, training, store)
+    return F.conv2d(x, _w(sd, p + "feature.weight", store), sd[p + "feature.bias"], stride=1, padding=1)
 
 
 # --------------------------------------------------------------------------
@@ -279,8 +303,9 @@ def regress(logits: torch.Tensor, depth_values: torch.Tensor):
 # --------------------------------------------------------------------------
 def hot_path(features: Sequence[torch.Tensor], proj: torch.Tensor, depth_values: torch.Tensor, sd: SD,
              aggregation: str = "variance", reference_frame: int = 0, taps: Optional[dict] = None, training: bool = False,
-             new_stats: Optional[dict] = None, store=None):
-    """Features + cameras -> depth, confidence (the timed region of bench.py).
+             new_stats: Optional[dict] = None, store=None, streaming: bool = False):
+    """Features + cameras -> depth, confidence (the timed region of bench.py).  ``streaming``: build the variance volume
+    in the reference's eval-mode order (view by view, in place; same values).
 
     ``features``: V tensors [B,32,h,w]; ``proj`` [B,V,4,4]; ``depth_values`` [B,V,D].
     Reference ``models/MVSNet/model.py:197-215``."""
@@ -290,7 +315,7 @@ def hot_path(features: Sequence[torch.Tensor], proj: torch.Tensor, depth_values:
     ref_proj = proj[:, reference_frame]
     src_projs = [proj[:, i] for i in range(V) if i != reference_frame]
     dv = depth_values[:, reference_frame]
-    cost = build_cost_volume(ref_fea, src_feas, ref_proj, src_projs, dv, aggregation, sd.get("temp"))
+    cost = build_cost_volume(ref_fea, src_feas, ref_proj, src_projs, dv, aggregation, sd.get("temp"), streaming=streaming)
     cost = stored(cost, store)
     logits = cost_reg_net(cost, sd, taps=taps, training=training, new_stats=new_stats, store=store).squeeze(1)
     prob, depth, conf = regress(logits, dv)
@@ -301,12 +326,15 @@ def hot_path(features: Sequence[torch.Tensor], proj: torch.Tensor, depth_values:
 
 def forward(imgs, K, R, t, depth_min, depth_max, sd: SD, num_depth: int = 192, aggregation: str = "variance",
             reference_frame: int = 0, taps: Optional[dict] = None, training: bool = False,
-            new_stats: Optional[dict] = None, store=None) -> Dict[str, object]:
-    """Full ``MVSNet.forward`` reference ``models/MVSNet/model.py:178-218``."""
+            new_stats: Optional[dict] = None, store=None, store_feature_layers: bool = False) -> Dict[str, object]:
+    """Full ``MVSNet.forward`` reference ``models/MVSNet/model.py:178-218``.  ``store`` (a 16-bit dtype) emulates the engine's
+    storage: every tensor it keeps in HBM is rounded once, arithmetic stays fp32; ``store_feature_layers`` extends that to the
+    eight layers of the 2-D extractor (the engine's own extractor; the PyTorch-ROCm one rounds the final map only)."""
     if isinstance(imgs, torch.Tensor):
         imgs = list(torch.unbind(imgs, 1))
     proj, depth_values = mvsnet_cameras(K, R, t, depth_min, depth_max, num_depth)
-    feats = [stored(feature_net(im, sd, training=training), store, round_grad=False) for im in imgs]   # per view, model.py:101-107
+    feats = [stored(feature_net(im, sd, training=training, store=store if store_feature_layers else None), store, round_grad=False)
+             for im in imgs]   # per view, model.py:101-107
     if taps is not None:
         taps.update(features=feats, proj=proj, depth_values=depth_values)
     depth, conf = hot_path(feats, proj, depth_values, sd, aggregation, reference_frame, taps, training, new_stats, store)

@@ -41,6 +41,40 @@ CONFIGS = {
 }
 
 
+def time_config(cid: int, reps: int = 3) -> dict:
+    """One BASELINE configuration through the engine's full forward() (2-D features included): ms per forward (eager launches,
+    wall clock between synchronisations, after two warm-up calls), cost-volume voxels and output sanity.  Used by bench.py's
+    "other_configs" and by this script."""
+    import gc
+    cfg = CONFIGS[cid]
+    net = build(cfg["arch"])
+    cfg["setup"](net)
+    scene = synthetic.make_scene(1, cfg["V"], cfg["H"], cfg["W"], seed=cid)
+    if "bscale" in cfg:
+        scene["t"] = scene["t"] * cfg["bscale"]
+    dev = {k: v.cuda() for k, v in scene.items()}
+    with torch.no_grad():
+        call = lambda: net(dev["imgs"], dev["K"], dev["R"], dev["t"], dev["depth_min"], dev["depth_max"], **cfg["kw"])
+        out = call()
+        out = call()
+        torch.cuda.synchronize()
+        gc.collect(); gc.disable()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            out = call()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        gc.enable()
+    d = out["depth"]
+    res = {"config": cid, "model": cfg["arch"], "views": cfg["V"], "image": [cfg["H"], cfg["W"]], "kwargs": {k: v for k, v in cfg["kw"].items()},
+           "ms_per_forward": dt * 1e3, "voxels": cfg["vox"](), "voxels_per_s": cfg["vox"]() / dt,
+           "finite": bool(torch.isfinite(d).all()) and bool(torch.isfinite(out["photometric_confidence"]).all()),
+           "timed": "full forward() incl. 2-D feature nets, eager launches, fp16 storage"}
+    del net, out, dev
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", type=int, default=0)

@@ -27,11 +27,22 @@ def _model(env, agg, seed, dtype=torch.float16):
     return net.cuda().eval(), sd
 
 
-# Depth tolerance per storage format.  fp16 storage (the default) meets the north-star 1e-3 relative L1 with
-# ~5x margin.  bf16 storage carries an 8-bit significand through 13 stored tensors; on these deliberately
-# unsaturated softmaxes (mean max-prob 0.2-0.8) the IDEAL bf16 pipeline -- the fp32 oracle with every stored
-# tensor rounded to bf16, see DESIGN.md section 5 -- already sits at 0.8-1.3e-3, and the kernels reproduce that.
-DEPTH_TOL = {torch.float16: 1e-3, torch.bfloat16: 2.5e-3}
+# Depth tolerance per storage format.  fp16 storage (the default) meets the north-star 1e-3 relative L1 with ~5x margin.
+# bf16 storage carries an 8-bit significand through 13 stored tensors; on these deliberately unsaturated softmaxes (mean
+# max-prob 0.2-0.8) the IDEAL bf16 pipeline -- the fp32 oracle with every stored tensor rounded to bf16, DESIGN.md section 3 --
+# already sits at 0.8-1.3e-3.  So the bf16 bar is NOT a loose constant: the engine may exceed the error of that storage-emulated
+# oracle (computed in the test, same inputs) by at most 15 %, which a kernel regression cannot hide under.
+DEPTH_TOL = {torch.float16: 1e-3}
+EMUL_SLACK = 1.15
+
+
+def emulated_depth_error(O, scene, sd, D, agg, dtype, ref_depth, feature_layers):
+    """relative L1 of the storage-emulated oracle (fp32 arithmetic, every HBM-resident tensor rounded to `dtype`) against the
+    reference golden: what an ideal pipeline with this storage format does."""
+    with torch.no_grad():
+        emul = O.forward(scene["imgs"], scene["K"], scene["R"], scene["t"], scene["depth_min"], scene["depth_max"], sd,
+                         num_depth=D, aggregation=agg, store=dtype, store_feature_layers=feature_layers)["depth"]
+    return float((emul - ref_depth).abs().mean() / ref_depth.abs().mean())
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
@@ -101,7 +112,12 @@ def test_forward_depth_parity_with_reference(env, fname, agg, dtype, feature_eng
     check_close(f"{fname} logits ({dtype})", taps["logits"].cpu(), t(g["logits"]).squeeze(1), rel_l2=6e-2 if loose else 3e-2)
     ref = t(g["depth"])
     s = check_close(f"{fname} depth ({dtype})", out["depth"].cpu(), ref)
-    assert s["rel_l1"] <= DEPTH_TOL[dtype], s
+    if dtype in DEPTH_TOL:
+        assert s["rel_l1"] <= DEPTH_TOL[dtype], s
+    else:
+        e_emul = emulated_depth_error(O, scene, sd, D, agg, dtype, ref, feature_layers=feature_engine == "pscv")
+        print(f"[parity] {fname} {dtype} {feature_engine}: engine {s['rel_l1']:.3e} vs storage-emulated oracle {e_emul:.3e}", flush=True)
+        assert s["rel_l1"] <= EMUL_SLACK * e_emul + 2e-5, (s, e_emul)
     # the confidence window is anchored at trunc(E[index]) (model.py:213), so it jumps where E[index] crosses an
     # integer: compare in the mean, and point-wise only away from those crossings
     conf, conf_ref = out["photometric_confidence"].cpu(), t(g["photometric_confidence"])

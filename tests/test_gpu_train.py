@@ -373,19 +373,30 @@ def test_mvsnet_train_step(fname, agg, dtype):
     # (1) storage-emulated oracle
     e_depth, e_loss, e_grads, e_stats = oracle_train_step(agg, H, W, V, D, seed, scene_seed, B, store=dtype)
     check_close("depth vs storage-emulated oracle", depth, e_depth, rel_l1=4e-3 if bf else 6e-4)
-    worst, cos, rows = _grad_report(f"{agg} {dtype} vs storage-emulated oracle", net, e_grads)
-    assert cos >= (0.93 if bf else 0.99), (cos, rows)
+    worst, cos_e, rows_e = _grad_report(f"{agg} {dtype} vs storage-emulated oracle", net, e_grads)
     sd = net.state_dict()
     for k, ref in e_stats.items():
         check_close(f"stat {k}", sd[k].cpu(), ref, rel_l2=2e-2 if bf else 3e-3)
     assert int(sd["cost_regularization.conv0.bn.num_batches_tracked"]) == 2   # the fixture starts at 1
     # (2) fp32 oracle / reference golden
     o_depth, o_loss, o_grads, o_stats = oracle_train_step(agg, H, W, V, D, seed, scene_seed, B)
-    check_close("depth vs oracle", depth, o_depth, rel_l1=4e-3 if bf else 6e-4)
-    check_close("depth vs reference golden", depth, t(g["depth"]), rel_l1=4e-3 if bf else 6e-4)
+    # the yardstick is what the storage format itself costs: the storage-emulated oracle's own distance from the fp32 oracle
+    # (depth: relative L1; gradient: 1 - cosine of the full vector).  The engine may exceed it by 15 % (depth) / 50 % (the
+    # gradient: two independent realisations of the same rounding noise) -- a kernel regression cannot hide under a constant.
+    emul_depth = float((e_depth - o_depth).abs().mean() / o_depth.abs().mean())
+    dot = sum(float((e_grads[k].float() * o_grads[k].float()).sum()) for k in o_grads)
+    n1 = sum(float((e_grads[k].float() ** 2).sum()) for k in o_grads) ** 0.5
+    n2 = sum(float((o_grads[k].float() ** 2).sum()) for k in o_grads) ** 0.5
+    emul_gap = 1.0 - dot / (n1 * n2)
+    s = check_close("depth vs oracle", depth, o_depth)
+    print(f"[train parity] {agg} {dtype}: depth rel-L1 engine {s['rel_l1']:.3e} / storage-emulated oracle {emul_depth:.3e}; "
+          f"1 - cos(gradient) storage-emulated oracle {emul_gap:.3e}", flush=True)
+    assert s["rel_l1"] <= 1.15 * emul_depth + 5e-5, (s, emul_depth)
+    check_close("depth vs reference golden", depth, t(g["depth"]), rel_l1=1.15 * emul_depth + 2.5e-4)
     assert abs(loss - o_loss) <= (2e-2 if bf else 3e-3) * abs(o_loss), (loss, o_loss)
     worst, cos, rows = _grad_report(f"{agg} {dtype} vs fp32 oracle", net, o_grads)
-    assert cos >= (0.93 if bf else 0.99), (cos, rows)
+    assert 1.0 - cos <= 1.5 * emul_gap + 2e-3, (cos, emul_gap, rows)
+    assert 1.0 - cos_e <= 1.0 * emul_gap + 2e-3, (cos_e, emul_gap, rows_e)     # (1): engine vs the storage-emulated oracle itself
 
 
 def test_train_step_then_eval_and_optimizer():
