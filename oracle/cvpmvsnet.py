@@ -13,6 +13,29 @@ import torch.nn.functional as F
 SD = Mapping[str, torch.Tensor]
 BN_EPS = 1e-5
 PYR = ("conv0aa", "conv0ba", "conv0bb", "conv0bc", "conv0bd", "conv0be", "conv0bf", "conv0bg", "conv0bh")
+STORE = {"dtype": None}
+
+
+class storage:
+    """Emulates the engine's 16-bit HBM storage inside this oracle (tests only): pyramid layers, conv weights, cost volumes
+    and every U-Net layer output are rounded once to ``dtype``; arithmetic and the 1-channel logits stay fp32.  The yardstick
+    for the engine's bf16 / fp16 parity bars (what an ideal pipeline with that storage format computes)."""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        self.prev = STORE["dtype"]
+        STORE["dtype"] = self.dtype
+        return self
+
+    def __exit__(self, *exc):
+        STORE["dtype"] = self.prev
+        return False
+
+
+def _q(x):
+    return x if STORE["dtype"] is None else x.to(STORE["dtype"]).to(x.dtype)
 
 
 def _bn(x, sd: SD, p: str, training: bool = False, new_stats: Optional[dict] = None):
@@ -35,7 +58,7 @@ def feature_pyramid(img, sd: SD, scales: int, p: str = "model.featurePyramid"):
     copies; 16 channels at EVERY level, finest first (upstream of the hot path)."""
     def tower(x):
         for name in PYR:
-            x = F.leaky_relu(F.conv2d(x, sd[f"{p}.{name}.0.weight"], sd[f"{p}.{name}.0.bias"], padding=1), 0.1)
+            x = _q(F.leaky_relu(F.conv2d(x, _q(sd[f"{p}.{name}.0.weight"]), sd[f"{p}.{name}.0.bias"], padding=1), 0.1))
         return x
     out = [tower(img)]
     for _ in range(scales - 1):
@@ -97,11 +120,11 @@ def variance_cost(ref_fea, warped: Sequence[torch.Tensor]):
     for wv in warped:
         s = s + wv
         sq = sq + wv ** 2
-    return sq / N - (s / N) ** 2
+    return _q(sq / N - (s / N) ** 2)
 
 
 def cbr3(x, sd, p, stride=1, training=False, new_stats=None):
-    return F.relu(_bn(F.conv3d(x, sd[p + ".conv.weight"], None, stride=stride, padding=1), sd, p + ".bn", training, new_stats))
+    return _q(F.relu(_bn(F.conv3d(x, _q(sd[p + ".conv.weight"]), None, stride=stride, padding=1), sd, p + ".bn", training, new_stats)))
 
 
 def cost_reg_net(x, sd: SD, p: str = "model.cost_reg_refine", taps: Optional[dict] = None, training: bool = False,
@@ -112,9 +135,9 @@ def cost_reg_net(x, sd: SD, p: str = "model.cost_reg_refine", taps: Optional[dic
     c0 = cbr3(cbr3(x, sd, p + ".conv0", **kw), sd, p + ".conv0a", **kw)
     c2 = cbr3(cbr3(cbr3(c0, sd, p + ".conv1", 2, **kw), sd, p + ".conv2", **kw), sd, p + ".conv2a", **kw)
     c4 = cbr3(cbr3(cbr3(c2, sd, p + ".conv3", **kw), sd, p + ".conv4", **kw), sd, p + ".conv4a", **kw)
-    c5 = c2 + F.relu(_bn(F.conv_transpose3d(c4, sd[p + ".conv5.0.weight"], None, stride=1, padding=1, output_padding=0), sd, p + ".conv5.1", **kw))
-    c6 = c0 + F.relu(_bn(F.conv_transpose3d(c5, sd[p + ".conv6.0.weight"], None, stride=2, padding=1, output_padding=1), sd, p + ".conv6.1", **kw))
-    logits = F.conv3d(c6, sd[p + ".prob0.weight"], sd[p + ".prob0.bias"], padding=1).squeeze(1)
+    c5 = _q(c2 + F.relu(_bn(F.conv_transpose3d(c4, _q(sd[p + ".conv5.0.weight"]), None, stride=1, padding=1, output_padding=0), sd, p + ".conv5.1", **kw)))
+    c6 = _q(c0 + F.relu(_bn(F.conv_transpose3d(c5, _q(sd[p + ".conv6.0.weight"]), None, stride=2, padding=1, output_padding=1), sd, p + ".conv6.1", **kw)))
+    logits = F.conv3d(c6, _q(sd[p + ".prob0.weight"]), sd[p + ".prob0.bias"], padding=1).squeeze(1)
     if taps is not None:
         taps.update(conv0=c0, conv2=c2, conv4=c4, conv5=c5, conv6=c6, logits=logits)
     return logits

@@ -19,7 +19,30 @@ BN_EPS = 1e-5
 # modules would hold afterwards are collected in MODE["new_stats"] (chained across repeated calls of the same module: the
 # pair U-Net runs once per source view).  Set through the ``train_mode`` context manager; gradients then come from ATen
 # autograd through these same functions, exactly as in the reference.
-MODE = {"training": False, "new_stats": None}
+MODE = {"training": False, "new_stats": None, "store": None}
+
+
+class storage:
+    """Emulates the engine's 16-bit HBM storage inside this oracle (tests only): every tensor the engine keeps in 16-bit form
+    -- feature maps, conv weights, the correlation volume, every U-Net layer output, the fused volume -- is rounded once to
+    ``dtype``; arithmetic stays fp32 and the 1-channel score heads stay fp32 (as in the engine).  The result is what an ideal
+    pipeline with that storage format computes: the yardstick for the engine's bf16 / fp16 parity bars."""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        self.prev = MODE["store"]
+        MODE["store"] = self.dtype
+        return self
+
+    def __exit__(self, *exc):
+        MODE["store"] = self.prev
+        return False
+
+
+def _q(x):
+    return x if MODE["store"] is None else x.to(MODE["store"]).to(x.dtype)
 
 
 class train_mode:
@@ -51,11 +74,11 @@ def _bn(x, sd: SD, p: str):
 
 def _conv(x, w, stride=1, dim=2, padding=None):
     pad = (w.shape[-1] // 2) if padding is None else padding
-    return (F.conv2d if dim == 2 else F.conv3d)(x, w, None, stride=stride, padding=pad)
+    return (F.conv2d if dim == 2 else F.conv3d)(x, _q(w), None, stride=stride, padding=pad)
 
 
 def _deconv(x, w, dim=2):
-    return (F.conv_transpose2d if dim == 2 else F.conv_transpose3d)(x, w, None, stride=2, padding=1, output_padding=1)
+    return (F.conv_transpose2d if dim == 2 else F.conv_transpose3d)(x, _q(w), None, stride=2, padding=1, output_padding=1)
 
 
 # --------------------------------------------------------------------------
@@ -63,11 +86,11 @@ def _deconv(x, w, dim=2):
 # --------------------------------------------------------------------------
 def basic_block(x, sd: SD, p: str, stride: int, dim: int):
     """``BasicBlock`` nn_utils.py:123-171: conv-bn-relu-conv-bn (+ 1x1 strided conv-bn shortcut when present), relu."""
-    out = F.relu(_bn(_conv(x, sd[p + ".conv1.weight"], stride, dim), sd, p + ".bn1"))
+    out = _q(F.relu(_bn(_conv(x, sd[p + ".conv1.weight"], stride, dim), sd, p + ".bn1")))
     out = _bn(_conv(out, sd[p + ".conv2.weight"], 1, dim), sd, p + ".bn2")
     if (p + ".downsample.0.weight") in sd:
-        x = _bn(_conv(x, sd[p + ".downsample.0.weight"], stride, dim, padding=0), sd, p + ".downsample.1")
-    return F.relu(out + x)
+        x = _q(_bn(_conv(x, sd[p + ".downsample.0.weight"], stride, dim, padding=0), sd, p + ".downsample.1"))
+    return _q(F.relu(out + x))
 
 
 def layer(x, sd: SD, p: str, blocks: int, stride: int, dim: int):
@@ -88,9 +111,9 @@ def unet(x, sd: SD, p: str, enc_names: Sequence[str], dec_names: Sequence[str], 
     dec_out = [x]
     for i, name in enumerate(dec_names):
         q = f"{p}.dec_blocks.{name}"
-        x = _deconv(x, sd[q + ".0.weight"], dim)
+        x = _q(_deconv(x, sd[q + ".0.weight"], dim))
         x = torch.cat([x, enc_out[-2 - i]], 1)            # deconv channels first, nn_utils.py:269-271
-        x = _conv(x, sd[q + ".1.weight"], 1, dim)
+        x = _q(_conv(x, sd[q + ".1.weight"], 1, dim))
         if dec_blocks > 0:
             x = layer(x, sd, q + ".2", dec_blocks, 1, dim)
         dec_out.append(x)
@@ -99,10 +122,10 @@ def unet(x, sd: SD, p: str, enc_names: Sequence[str], dec_names: Sequence[str], 
 
 def feat_ext(img, sd: SD, p: str = "model.feat_ext"):
     """``FeatExt`` model_cas.py:18-35: three 32-channel maps at 1/8, 1/4, 1/2 resolution (upstream of the hot path)."""
-    x = F.relu(_bn(_conv(img, sd[p + ".init_conv.0.weight"], 2, 2), sd, p + ".init_conv.1"))
+    x = _q(F.relu(_bn(_conv(img, sd[p + ".init_conv.0.weight"], 2, 2), sd, p + ".init_conv.1")))
     o1, o2, o3 = unet(x, sd, p + ".unet", ["2d2_0", "2d4_1", "2d8_2"], ["2d16_3", "2d8_4"], 2, 1, 2, multi_scale=3)
-    return (_conv(o1, sd[p + ".final_conv_1.weight"]), _conv(o2, sd[p + ".final_conv_2.weight"]),
-            _conv(o3, sd[p + ".final_conv_3.weight"]))
+    return (_q(_conv(o1, sd[p + ".final_conv_1.weight"])), _q(_conv(o2, sd[p + ".final_conv_2.weight"])),
+            _q(_conv(o3, sd[p + ".final_conv_3.weight"])))
 
 
 def reg_unet(x, sd: SD, p: str, tag: str):
@@ -217,7 +240,7 @@ def single_stage(ref_feat, ref_cam, srcs_feat, srcs_cam, sd: SD, p: str, depth_n
     pair_results = []
     for i, (sf, sc) in enumerate(zip(srcs_feat, srcs_cam)):
         warped = warp_volume(sf, ref_cam, sc, depth_num, depth_start, depth_interval, s_scale, (h, w))
-        cost = groupwise_correlation(ref_vol, warped, 8)
+        cost = _q(groupwise_correlation(ref_vol, warped, 8))
         interm = reg_unet(cost, sd, p + ".reg", "reg1")
         score = _conv(interm, sd[p + ".reg_pair.final_conv.weight"], 1, 3).squeeze(1)
         prob, est_class = soft_argmin(score)
@@ -230,7 +253,7 @@ def single_stage(ref_feat, ref_cam, srcs_feat, srcs_cam, sd: SD, p: str, depth_n
         fused = fused + interm * weight
         if taps is not None and i == 0:
             taps.update(warped0=warped, cost0=cost, interm0=interm, score0=score, entropy0=ent, uncert0=uncert)
-    fused = fused / weight_sum
+    fused = _q(fused / weight_sum)
     score = _conv(reg_unet(fused, sd, p + ".reg_fuse", "reg2"), sd[p + ".reg_fuse.final_conv.weight"], 1, 3).squeeze(1)
     prob, est_class, prob_map = soft_argmin(score, window=2)
     est_depth = est_class * depth_interval + depth_start

@@ -44,10 +44,22 @@ def test_cvp_forward_parity_with_reference(env, dtype, feature_engine):
     for i, lt in enumerate(taps["refine"], start=1):
         check_close(f"refine{i} hypotheses {dtype}", lt["hypos"].cpu(), t(g[f"refine{i}_hypos"]), max_abs=0.02 if dtype == torch.float16 else 0.1)
         check_close(f"refine{i} logits {dtype}", lt["logits"].cpu(), t(g[f"refine{i}_logits"]), rel_l2=10 * tol)
-    dtol = 1e-3 if dtype == torch.float16 else 5e-3
+    # fp16: the north-star bar.  bf16: at most 15 % above what the storage format itself costs -- the fp32 oracle with every
+    # HBM-resident tensor rounded to bf16 (oracle.cvpmvsnet.storage), computed here on the same inputs.
+    if dtype == torch.float16:
+        dtols = [1e-3] * nscale
+    else:
+        from oracle import cvpmvsnet as OC
+        from test_oracle_cvp import cvp_template
+        with torch.no_grad(), OC.storage(dtype):
+            emul = OC.forward(scene["imgs"], scene["K"], scene["R"], scene["t"], scene["depth_min"], scene["depth_max"],
+                              synthetic.sharpened_state_dict("cvp", cvp_template(), seed=seed), nscale=nscale)["depth_est_list"]
+        e_emul = [float((emul[i] - t(g[f"depth_est_{i}"])).abs().mean() / t(g[f"depth_est_{i}"]).abs().mean()) for i in range(nscale)]
+        print(f"[parity] cvp {dtype} {feature_engine}: storage-emulated oracle depth rel-L1 per level {['%.3e' % e for e in e_emul]}", flush=True)
+        dtols = [1.15 * e + 5e-5 for e in e_emul]
     for i in range(nscale):
         s = check_close(f"depth_est_list[{i}] {dtype}", out["depth_est_list"][i].cpu(), t(g[f"depth_est_{i}"]))
-        assert s["rel_l1"] <= dtol, s
+        assert s["rel_l1"] <= dtols[i], (s, dtols[i])
     check_close(f"confidence {dtype}", out["photometric_confidence"].cpu(), t(g["photometric_confidence"]), rel_l1=3e-2)
 
 

@@ -122,12 +122,23 @@ def test_vis_forward_parity_with_reference(env, dtype, feature_engine):
     check_close(f"s1 interm v0 {dtype}", s1["interm0"].float().permute(0, 4, 1, 2, 3).cpu(), t(g["s1_interm_v0"]), rel_l2=tol)
     check_close(f"s1 fused {dtype}", s1["fused"].float().permute(0, 4, 1, 2, 3).cpu(), t(g["s1_fused"]), rel_l2=tol)
     check_close(f"s1 score {dtype}", s1["score"].unsqueeze(1).cpu(), t(g["s1_score"]), rel_l2=tol)
-    dtol = 1e-3 if dtype == torch.float16 else 4e-3
+    # fp16: the north-star bar.  bf16: at most 15 % above what the storage format itself costs -- the fp32 oracle with every
+    # HBM-resident tensor rounded to bf16 (oracle.vismvsnet.storage), computed here on the same inputs.
+    dtol = 1e-3
+    if dtype != torch.float16:
+        cpu = synthetic.make_scene(1, V, H, W, seed=scene_seed)
+        with torch.no_grad(), OV.storage(dtype):
+            emul = OV.forward(cpu["imgs"], cpu["K"], cpu["R"], cpu["t"], cpu["depth_min"], cpu["depth_max"], sd,
+                              depth_nums=depth_nums, interval_scales=scales, attr_interval_scales=scales)
+        e_emul = max(float((emul["depth_est_list"][i] - t(g[f"depth_est_{i}"])).abs().mean() / t(g[f"depth_est_{i}"]).abs().mean())
+                     for i in range(3))
+        print(f"[parity] vis {dtype} {feature_engine}: storage-emulated oracle depth rel-L1 (worst stage) {e_emul:.3e}", flush=True)
+        dtol = 1.15 * e_emul + 5e-5
     for i in range(3):
         s = check_close(f"depth_est_list[{i}] {dtype}", out["depth_est_list"][i].cpu(), t(g[f"depth_est_{i}"]))
-        assert s["rel_l1"] <= dtol, s
+        assert s["rel_l1"] <= dtol, (s, dtol)
     s = check_close(f"depth {dtype}", out["depth"].cpu(), t(g["depth"]))
-    assert s["rel_l1"] <= dtol
+    assert s["rel_l1"] <= dtol, (s, dtol)
     check_close(f"prob maps {dtype}", out["photometric_confidence"].cpu(), t(g["photometric_confidence"]), rel_l1=3e-2)
     for si, pr in enumerate(out["depth_pair_list"]):
         for vi, (ed, unc) in enumerate(pr):
