@@ -12,7 +12,7 @@ be re-created from ``wild_deep_mvs_amd.synthetic`` (the fixture records the
 generator arguments instead); every stage boundary of the reference's hot path is
 stored as fp32 arrays (tiny problem sizes; per-view warped volumes keep 3 planes).
 
-Usage:  python tests/golden/gen_golden.py [--only mvsnet|mvsnet_s|mvsnet_train|mvsnet_s_train|vis|cvp|filter|photo]
+Usage:  python tests/golden/gen_golden.py [--only mvsnet|mvsnet_s|mvsnet_train|mvsnet_s_train|vis|cvp|filter|photo|api]
 """
 from __future__ import annotations
 
@@ -485,6 +485,24 @@ def gen_photo(tag: str, *, B=2, V=3, H=48, W=64, seed=0, behind_view=-1, masked=
     print(tag, "loss", float(loss), "mask mean", float(maskf.mean()), "grad abs mean", float(depth.grad.abs().mean()))
 
 
+def gen_api_names():
+    """Public names of the reference's ``models/utils.py`` and ``models/trainer.py`` (data only: a list of identifiers), so a
+    CPU test can hold the drop-in to "every name the reference's callers can import exists" without the reference present."""
+    import inspect
+    import json
+    import models.utils as RU          # reference
+    import models.trainer as RT        # reference
+    def public(mod):
+        return sorted(n for n, v in vars(mod).items() if not n.startswith("_") and not inspect.ismodule(v))
+    names = {"models.utils": public(RU),
+             "models.trainer": public(RT),
+             "models.trainer.Trainer": sorted(n for n in dir(RT.Trainer) if not n.startswith("__"))}
+    path = os.path.join(HERE, "api_names.json")
+    with open(path, "w") as f:
+        json.dump(names, f, indent=1, sort_keys=True)
+    print(f"wrote {path}: " + ", ".join(f"{k} {len(v)}" for k, v in names.items()))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -505,6 +523,7 @@ def main():
         "filter": lambda: (gen_filter("filter_tiny", V=6, behind_view=4, half_res_view=3, near_view=2),
                            gen_filter("filter_upsample", V=4, seed=3, upsample=True, downscale=2, num_consistent=2)),
     }
+    todo["api"] = gen_api_names
     todo["photo"] = lambda: (gen_photo("photo_tiny"), gen_photo("photo_behind", V=4, behind_view=2, seed=3),
                              gen_photo("photo_masked", V=4, masked=True, i_ref=1, seed=5))
     for k, fn in todo.items():

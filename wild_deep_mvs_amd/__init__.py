@@ -24,3 +24,5 @@ def install_as_models() -> None:
             sys.modules["models." + sub] = importlib.import_module(f"{__name__}.models.{sub}")
         except ImportError:
             pass
+    # (``utils.trainer`` / ``utils.utils_3D`` / ``utils.ssimLoss`` are the caller's own harness modules; their counterparts live
+    #  in ``wild_deep_mvs_amd.utils`` and are what the mirrors above import, so nothing is registered under ``utils``.)
