@@ -122,6 +122,40 @@ def gen_mvsnet(aggregation: str, tag: str, *, H=64, W=96, V=3, D=16, seed=0, beh
          depth_per_pixel=np32(dpp), warped_per_pixel=np32(warped_pp[:, :, PLANES]))
 
 
+def gen_mvsnet_cfg1(tag: str = "mvsnet_s_cfg1", *, H=128, W=160, V=3, D=48, seed=1, scene_seed=4, prob_gain=4):
+    """BASELINE.json configuration (1) at its real size: MVSNet-s (soft-min aggregation), 1 ref + 2 src views, 128x160 images,
+    D = 48 -- the reference's own CPU-runnable case.  Stores the outputs and the logits whole (245 KB) and the cost volume on
+    three planes only (it is 7.8 MB)."""
+    sys.path.insert(0, REPO)
+    from wild_deep_mvs_amd import synthetic
+    from models.MVSNet.model import MVSNet  # reference
+    torch.manual_seed(0)
+    net = MVSNet("softmin")
+    net.num_depth = D
+    sd = synthetic.sharpened_state_dict("mvsnet", synthetic.template_of(net), seed=seed)
+    sd["cost_regularization.prob.weight"] = sd["cost_regularization.prob.weight"] * prob_gain   # 48 planes: keep the softmax peaked
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    scene = synthetic.make_scene(1, V, H, W, seed=scene_seed)
+    with torch.no_grad():
+        out = net(scene["imgs"], scene["K"], scene["R"], scene["t"], scene["depth_min"], scene["depth_max"])
+        feats = net.extract_features(torch.unbind(scene["imgs"], 1))
+        from utils.utils_3D import build_proj_matrices
+        Ks = scene["K"].clone()
+        Ks[:, :, :2] /= 4
+        proj = build_proj_matrices(Ks, scene["R"], scene["t"])
+        step = (scene["depth_max"] - scene["depth_min"]) / (D - 1)
+        dv = (scene["depth_min"].unsqueeze(-1) + step.unsqueeze(-1) * torch.arange(D).view(1, 1, -1))[:, 0]
+        cost = net.build_cost_volume(feats[0], feats[1:], proj[:, 0], [proj[:, i] for i in range(1, V)], dv)
+        logits = net.cost_regularization(cost).squeeze(1)
+        prob = torch.softmax(logits, dim=1)
+    planes = [0, 17, 47]
+    print(f"[{tag}] max prob mean {prob.max(1)[0].mean():.3f}, depth range {out['depth'].min():.3f}..{out['depth'].max():.3f}")
+    save(f"{tag}.npz", meta=np.array([H, W, V, D, seed, scene_seed, prob_gain], dtype=np.int64), cost_planes=np.array(planes, dtype=np.int64),
+         cost_volume=np32(cost[:, :, planes]), logits=np32(logits), depth=np32(out["depth"]),
+         photometric_confidence=np32(out["photometric_confidence"]))
+
+
 def gen_mvsnet_train(aggregation: str, tag: str, *, H=64, W=96, V=3, D=16, seed=0, scene_seed=0, B=2):
     """One training step of the reference in train() mode: forward with batch-statistics BatchNorm, the supervised L1 loss
     of models/trainer.py:163-167, backward.  Stores depth, loss, every parameter gradient's norm, full gradients of a
@@ -513,6 +547,7 @@ def main():
         "mvsnet": lambda: gen_mvsnet("variance", "mvsnet_tiny"),
         "mvsnet_behind": lambda: gen_mvsnet("variance", "mvsnet_behind", V=4, behind_view=2, scene_seed=5),
         "mvsnet_s": lambda: gen_mvsnet("softmin", "mvsnet_s_tiny", seed=1),
+        "mvsnet_cfg1": gen_mvsnet_cfg1,
         "mvsnet_train": lambda: gen_mvsnet_train("variance", "mvsnet_train"),
         "mvsnet_s_train": lambda: gen_mvsnet_train("softmin", "mvsnet_s_train", seed=1),
         "vis": lambda: gen_vis("vis_tiny"),
