@@ -133,6 +133,66 @@ def cpu_baseline(sd, feats, proj, dv, gpu_depths: dict):
             "ref_container_s": REF_CONTAINER["seconds"], "ref_container": REF_CONTAINER}, rel
 
 
+SHARDED = {
+    # BASELINE configuration 3: Vis-MVSNet 5-view 512x640, depth planes [192,32,16] sharded over the ranks (LSE-merged heads)
+    "depth": dict(config=3, V=5, H=512, W=640, kw=dict(depth_nums=[192, 32, 16], interval_scales=[128 / 192, 1, 0.5]),
+                  vox=192 * 64 * 80 + 32 * 128 * 160 + 16 * 256 * 320),
+    # BASELINE configuration 5: Vis-MVSNet 9-view 1152x1600 [256,32,16], the 8 source views sharded over the ranks (all-reduce of
+    # the visibility-weighted partial sums, the "RCCL variance reduce" of that model)
+    "view": dict(config=5, V=9, H=1152, W=1600, kw=dict(depth_nums=[256, 32, 16], interval_scales=[0.5, 1, 0.5]),
+                 vox=256 * 144 * 200 + 32 * 288 * 400 + 16 * 576 * 800),
+}
+
+
+def sharded_legs(dist, device, world, rank, reps=5):
+    """N > 1 only, after the headline region: ONE reference view computed cooperatively by all ranks (strong scaling) through the
+    two shardings of the path that need a collective -- ``Frontend.set_depth_group`` and ``Frontend.set_view_group`` -- over
+    RCCL.  Every rank runs the forward; times are the max over ranks; a second, traced pass attributes time and bytes to each
+    collective (wild_deep_mvs_amd.dist.CollectiveTrace).  Returns a dict for rank 0's JSON line (None elsewhere)."""
+    from wild_deep_mvs_amd.dist import CollectiveTrace
+    from wild_deep_mvs_amd.models.VisMVSNet.frontend import Frontend
+    out = {}
+    for mode, cfg in SHARDED.items():
+        try:
+            net = Frontend()
+            net.load_state_dict(synthetic.sharpened_state_dict("vis", synthetic.template_of(net), seed=0))
+            net = net.to(device).eval()
+            scene = {k: v.to(device) for k, v in synthetic.make_scene(1, cfg["V"], cfg["H"], cfg["W"], seed=cfg["config"]).items()}
+            call = lambda: net(scene["imgs"], scene["K"], scene["R"], scene["t"], scene["depth_min"], scene["depth_max"], **cfg["kw"])
+            times = {}
+            for label, group in (("unsharded_replicated", None), ("sharded", dist.group.WORLD)):
+                (net.set_depth_group if mode == "depth" else net.set_view_group)(group)
+                with torch.no_grad():
+                    call(); call()
+                    dist.barrier(); torch.cuda.synchronize()
+                    gc.collect(); gc.disable()
+                    t0 = time.perf_counter()
+                    for _ in range(reps):
+                        depth = call()["depth"]
+                    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+                    dt = (time.perf_counter() - t0) / reps
+                    gc.enable()
+                tm = torch.tensor([dt], device=device, dtype=torch.float64)
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                times[label] = float(tm.item())
+                if label == "unsharded_replicated":
+                    ref_depth = depth.clone()
+            with torch.no_grad(), CollectiveTrace() as tr:
+                call()
+            rel = float((depth - ref_depth).abs().mean() / ref_depth.abs().mean())
+            out[mode] = {"config": cfg["config"], "model": "vis", "views": cfg["V"], "image": [cfg["H"], cfg["W"]], "kwargs": cfg["kw"],
+                         "scaling": "strong", "ms_per_forward_1gpu": times["unsharded_replicated"] * 1e3,
+                         "ms_per_forward_sharded": times["sharded"] * 1e3, "n_gpus": world,
+                         "voxels_per_s": cfg["vox"] / times["sharded"], "speedup_vs_1gpu": times["unsharded_replicated"] / times["sharded"],
+                         "depth_rel_l1_vs_unsharded": rel, "collectives": tr.summary(),
+                         "timed": "full forward() incl. 2-D feature nets, eager launches, max over ranks"}
+            del net, scene
+            torch.cuda.empty_cache()
+        except Exception as e:   # pragma: no cover  (never lose the headline line to a side measurement)
+            out[mode] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    return out if rank == 0 else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -140,6 +200,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the forward() timings of BASELINE configurations 3-5")
+    ap.add_argument("--no-sharded", action="store_true", help="N > 1: skip the depth-plane / source-view sharded legs (configurations 3 and 5)")
     ap.add_argument("--dtype", choices=sorted(DTYPES), default="f16",
                     help="16-bit HBM storage format (arithmetic is fp32); f16 is the engine default, see DESIGN.md section 5")
     ap.add_argument("--dump-events", default=None, help="write every per-launch event duration to this file")
@@ -233,6 +294,10 @@ def main():
     net.storage_dtype = DTYPES[args.dtype]
     graph = graphed
 
+    sharded = None
+    if world > 1 and not args.no_sharded:
+        sharded = sharded_legs(dist, device, world, rank)
+
     if rank == 0:
         total_ms = sum(ms for _, ms in kern.values())
         name, (n, ms) = max(kern.items(), key=lambda kv: kv[1][1])
@@ -284,6 +349,7 @@ def main():
             line["cpu_baseline"] = None
         # BASELINE configurations 3, 4, 5 in their single-GPU forms (parity cases of tests/test_gpu_fullsize.py, not bench lines):
         # driver-timed ms of the full forward(), after the headline region
+        line["sharded"] = sharded
         line["other_configs"] = None
         if world == 1 and not args.no_other_configs:
             try:

@@ -14,6 +14,18 @@ from _util import load_golden, t
 pytestmark = pytest.mark.gpu
 
 
+def _init(rank, world, port):
+    """gloo with both ranks on cuda:0 (default: one-GPU boxes), or RCCL with one GPU per rank when PSCV_TEST_BACKEND=nccl."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    backend = os.environ.get("PSCV_TEST_BACKEND", "gloo")
+    if backend == "nccl":
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -23,9 +35,7 @@ def _free_port():
 
 
 def _worker(rank, world, port, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _init(rank, world, port)
     try:
         from wild_deep_mvs_amd import synthetic
         from wild_deep_mvs_amd.models.VisMVSNet.frontend import Frontend
@@ -160,9 +170,7 @@ def test_mvsnet_training_under_ddp_two_ranks_one_gpu():
 
 
 def _mvs_shard_worker(rank, world, port, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _init(rank, world, port)
     try:
         from wild_deep_mvs_amd import synthetic
         from wild_deep_mvs_amd.models.MVSNet.model import MVSNet
@@ -209,9 +217,7 @@ def test_mvsnet_source_view_shard_variance_reduce_two_ranks_one_gpu():
 
 
 def _vis_depth_shard_worker(rank, world, port, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _init(rank, world, port)
     try:
         from wild_deep_mvs_amd import synthetic
         from wild_deep_mvs_amd.models.VisMVSNet.frontend import Frontend
@@ -283,3 +289,73 @@ def test_vis_depth_plane_shard_two_ranks_one_gpu():
             assert max(errs[3:]) <= 1e-4
         print(f"[parity] depth-plane shard rank {rank}: cascade depth rel-L1 vs unsharded {rel:.3e}", flush=True)
         assert rel <= 1e-3
+
+
+# ---- the same three shardings over RCCL: one GPU per rank, backend "nccl" (skipped on one-GPU boxes) --------------------------
+needs_two_gpus = pytest.mark.skipif(not torch.cuda.is_available() or torch.cuda.device_count() < 2,
+                                    reason="RCCL needs one GPU per rank: 2+ MI355X")
+
+
+@pytest.fixture
+def rccl(monkeypatch):
+    monkeypatch.setenv("PSCV_TEST_BACKEND", "nccl")      # inherited by the spawned ranks
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+@needs_two_gpus
+@pytest.mark.timeout(300)
+def test_vis_source_view_shard_two_ranks_nccl(rccl):
+    test_vis_source_view_shard_two_ranks_one_gpu()
+
+
+@needs_two_gpus
+@pytest.mark.timeout(300)
+def test_mvsnet_source_view_shard_variance_reduce_two_ranks_nccl(rccl):
+    test_mvsnet_source_view_shard_variance_reduce_two_ranks_one_gpu()
+
+
+@needs_two_gpus
+@pytest.mark.timeout(300)
+def test_vis_depth_plane_shard_two_ranks_nccl(rccl):
+    test_vis_depth_plane_shard_two_ranks_one_gpu()
+
+
+# ---- bench.py's sharded legs (what the driver's N > 1 runs report under "sharded"), here over gloo on one GPU ----------------
+def _bench_sharded_worker(rank, world, port, q):
+    _init(rank, world, port)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        dev = torch.device("cuda", rank if os.environ.get("PSCV_TEST_BACKEND") == "nccl" else 0)
+        res = bench.sharded_legs(dist, dev, world, rank, reps=1)
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_bench_sharded_legs_two_ranks_one_gpu():
+    """``bench.py --gpus N``'s ``sharded`` object: configuration 3 through the depth-plane shard and configuration 5 through the
+    source-view shard, each against the unsharded run on the same rank, with the per-collective trace."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=500) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[1] is None and set(res[0]) == {"depth", "view"}
+    for mode, r in res[0].items():
+        assert "error" not in r, r
+        print(f"[bench sharded] {mode}: 1 GPU {r['ms_per_forward_1gpu']:.2f} ms, 2 ranks {r['ms_per_forward_sharded']:.2f} ms, "
+              f"depth rel-L1 vs unsharded {r['depth_rel_l1_vs_unsharded']:.2e}, collectives {r['collectives']}", flush=True)
+        assert r["depth_rel_l1_vs_unsharded"] <= 3e-4 and r["n_gpus"] == 2 and r["scaling"] == "strong"
+        assert len(r["collectives"]) >= 1 and all(c["calls"] >= 1 and c["bytes_per_rank"] > 0 for c in r["collectives"])
+    names = {c["collective"] for c in res[0]["view"]["collectives"]}
+    assert "all_reduce" in names                  # the visibility-weighted partial sums of the source-view shard

@@ -54,3 +54,51 @@ def merge_partials(partials: torch.Tensor, group: Optional[dist.ProcessGroup] = 
     bufs = [torch.empty_like(partials) for _ in range(world)]
     dist.all_gather(bufs, partials.contiguous(), group=group)
     return merge_partials_local(bufs)
+
+
+class CollectiveTrace:
+    """Measurement aid (bench.py ``sharded`` legs): while active, every ``torch.distributed`` collective the sharded models issue
+    (``all_reduce``, ``all_gather``, ``broadcast``) is bracketed by CUDA events on the current stream and recorded as
+    ``(name, payload bytes of this rank, milliseconds)``.  ``summary()`` groups the records by (name, bytes).  The events add a
+    few microseconds per call; the traced pass is therefore separate from the timed one."""
+
+    NAMES = ("all_reduce", "all_gather", "broadcast", "reduce_scatter_tensor", "all_gather_into_tensor")
+
+    def __init__(self):
+        self.records = []
+        self._saved = {}
+
+    def _wrap(self, name, fn):
+        def traced(*args, **kwargs):
+            tensors = [a for a in args if torch.is_tensor(a)] + [x for a in args if isinstance(a, (list, tuple)) for x in a if torch.is_tensor(x)]
+            payload = max((x.numel() * x.element_size() for x in tensors), default=0)
+            if not tensors or not tensors[0].is_cuda:
+                return fn(*args, **kwargs)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*args, **kwargs)
+            e1.record()
+            self.records.append((name, payload, e0, e1))
+            return out
+        return traced
+
+    def __enter__(self):
+        for name in self.NAMES:
+            if hasattr(dist, name):
+                self._saved[name] = getattr(dist, name)
+                setattr(dist, name, self._wrap(name, self._saved[name]))
+        return self
+
+    def __exit__(self, *exc):
+        for name, fn in self._saved.items():
+            setattr(dist, name, fn)
+        return False
+
+    def summary(self):
+        torch.cuda.synchronize()
+        groups = {}
+        for name, payload, e0, e1 in self.records:
+            g = groups.setdefault((name, payload), [0, 0.0])
+            g[0] += 1
+            g[1] += e0.elapsed_time(e1)
+        return [{"collective": k[0], "bytes_per_rank": k[1], "calls": v[0], "avg_us": v[1] / v[0] * 1e3} for k, v in sorted(groups.items())]
