@@ -94,3 +94,51 @@ def test_trainer_test_metrics_and_log_epoch(env):
         if created:
             dist.destroy_process_group()
     assert res["epoch"] == 7 and abs(float(res["EPE"]) - float(want)) < 1e-5 * max(1.0, float(want)) and tr.nb_iter == 0
+
+
+@pytest.mark.parametrize("architecture", ["mvsnet", "mvsnet-s", "vis_mvsnet", "cvp_mvsnet"])
+def test_load_network_flow_dataparallel_module_prefix_strict_false(env, architecture, tmp_path):
+    """The reference's evaluation loader, step by step (evaluation/pipeline_utils.py:127-160): ``torch.load`` of a train.py
+    checkpoint (``{'epoch','model','optimizer','architecture'}``, DDP-prefixed ``module.`` keys, train.py:205-210) -> the model
+    class by architecture name through the ``models.*`` import paths -> attribute overrides -> ``nn.DataParallel`` -> ``.to(device)``
+    -> ``load_state_dict(strict=False)`` -> ``eval()`` -> ``net(...)``.  Every tensor of the checkpoint must land (strict=False
+    would silently drop a misnamed key) and the wrapped forward must equal the bare model's."""
+    import torch.nn as nn
+    synthetic, MT, MVSNet = env
+    from models.VisMVSNet.frontend import Frontend as Vis_MVSNet          # the reference's names (pipeline_utils.py:22-24)
+    from models.CVP_MVSNet.frontend import Frontend as CVP_MVSNet
+    key = {"mvsnet": "mvsnet", "mvsnet-s": "mvsnet", "vis_mvsnet": "vis", "cvp_mvsnet": "cvp"}[architecture]
+    make = {"mvsnet": lambda: MVSNet(aggregation="variance"), "mvsnet-s": lambda: MVSNet(aggregation="softmin"),
+            "vis_mvsnet": Vis_MVSNet, "cvp_mvsnet": CVP_MVSNet}[architecture]
+    # --- what train.py wrote
+    trained = make()
+    sd = synthetic.sharpened_state_dict(key, synthetic.template_of(trained), seed=3)
+    if architecture == "mvsnet-s":
+        sd["temp"] = torch.tensor([1.7])
+    ckpt = tmp_path / "model_000005.ckpt"
+    torch.save({"epoch": 5, "model": {"module." + k: v for k, v in sd.items()}, "optimizer": {}, "architecture": architecture}, ckpt)
+    # --- load_network
+    loaded = torch.load(ckpt)
+    net = make()
+    if architecture == "cvp_mvsnet":
+        net.model.nscale = 2
+    elif architecture == "vis_mvsnet":
+        net.depth_nums, net.interval_scales = [16, 8, 4], [2, 1, 0.5]
+    net = nn.DataParallel(net)
+    net.to(torch.device("cuda"))
+    res = net.load_state_dict(loaded["model"], strict=False)
+    assert list(res.missing_keys) == [] and list(res.unexpected_keys) == [], res
+    net.eval()
+    for k, v in net.module.state_dict().items():
+        assert torch.equal(v.cpu(), sd[k]), k
+    scene = synthetic.make_scene(1, 3, 64, 96, seed=6)
+    if architecture.startswith("mvsnet"):
+        net.module.num_depth = 16
+    args = [scene[k].cuda() for k in ("imgs", "K", "R", "t", "depth_min", "depth_max")]
+    with torch.no_grad():
+        out = net(*args)
+        bare = net.module(*args)
+    assert set(out) == {"depth", "depth_est_list", "depth_pair_list", "photometric_confidence"}
+    assert torch.isfinite(out["depth"]).all() and torch.equal(out["depth"], bare["depth"])
+    down = {"mvsnet": 4, "mvsnet-s": 4, "vis_mvsnet": 2, "cvp_mvsnet": 1}[architecture]           # pipeline_utils.py:140-154
+    assert tuple(out["depth"].shape) == (1, 64 // down, 96 // down)
