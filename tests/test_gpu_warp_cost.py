@@ -242,3 +242,29 @@ def test_quad_kernel_equals_generic_kernel(env, baseline_scale, shape, D, per_pi
     assert float(outs[1].abs().max()) > 0
     check_close(f"quad vs generic {cost_name} {dtype} baseline x{baseline_scale} {shape} D={D}", outs[0], outs[1],
                 max_abs=ulp * float(outs[1].abs().max()), rel_l2=ulp / 16)
+
+
+def test_staged_kernel_fp16_stores_saturate(env):
+    """fp16 cost volumes saturate at +-65504 instead of becoming inf (every kernel of the engine does; the LDS-staged warp
+    kernel gets it from the MODE.FP16_OVFL bit instead of a per-element clamp): features of magnitude ~300 give variances up
+    to ~9e4.  Same stored bits as the direct kernel (which clamps explicitly)."""
+    L, ops, O = env
+    from wild_deep_mvs_amd import synthetic
+    from oracle.mvsnet import mvsnet_cameras
+    B, V, C, h, w, D = 1, 3, 32, 40, 48, 8
+    feats = synthetic.make_features(B, V, C, h, w, seed=2) * 600.0
+    cam = synthetic.make_cameras(B, V, 4 * h, 4 * w)
+    proj, dvals = mvsnet_cameras(cam["K"], cam["R"], cam["t"], cam["depth_min"], cam["depth_max"], D)
+    cams = ops.proj_cams_device(proj.cuda().contiguous(), 0)
+    fcl = [ops.to_channels_last(feats[i].cuda(), torch.float16) for i in range(V)]
+    dv = dvals[:, 0].contiguous().cuda()
+    outs = []
+    for tiled in (1, 0):
+        L.set_tuning("warp_tiled", tiled)
+        try:
+            outs.append(ops.warp_cost(fcl[0], fcl[1:], cams, dv, cost=L.COST_VARIANCE, out_dtype=torch.float16))
+        finally:
+            L.set_tuning("warp_tiled", -1)
+    assert torch.isfinite(outs[0]).all() and float(outs[0].max()) == 65504.0
+    assert (outs[0] == 65504.0).float().mean() > 1e-3            # the case really overflows
+    assert torch.equal(outs[0], outs[1])

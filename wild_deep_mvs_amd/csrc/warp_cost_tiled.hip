@@ -103,13 +103,26 @@ __device__ __forceinline__ void wl_blend8(const float4 (&t)[8], const float (&w)
     }
 }
 
+// fp16 stores saturate at +-65504 like every other kernel of the engine (pscv_common.h), but through the MODE.FP16_OVFL bit the
+// kernel sets at its start ("an overflowed FP16 result is clamped to +-MAX_FP16 ... preserving true INF"): the per-element
+// v_med3_f32 clamp of pack_f16x2 costs 8 vector-ALU instructions per voxel here, 5 % of the sweep
+template <typename TOut> __device__ __forceinline__ uint32_t wl_pack2(float lo, float hi) {
+    if constexpr (Half16<TOut>::dtype == PSCV_F16) {
+        h2_t v;
+        v[0] = (_Float16)lo;
+        v[1] = (_Float16)hi;
+        return __builtin_bit_cast(uint32_t, v);
+    } else {
+        return Half16<TOut>::pack(lo, hi);
+    }
+}
 template <typename TOut> __device__ __forceinline__ void wl_store8(char* p, const float (&o)[8]) {
     if constexpr (sizeof(TOut) == 4) {
         *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
         *reinterpret_cast<float4*>(p + 16) = make_float4(o[4], o[5], o[6], o[7]);
     } else {
-        *reinterpret_cast<uint4*>(p) = make_uint4(Half16<TOut>::pack(o[0], o[1]), Half16<TOut>::pack(o[2], o[3]),
-                                                   Half16<TOut>::pack(o[4], o[5]), Half16<TOut>::pack(o[6], o[7]));
+        *reinterpret_cast<uint4*>(p) = make_uint4(wl_pack2<TOut>(o[0], o[1]), wl_pack2<TOut>(o[2], o[3]),
+                                                   wl_pack2<TOut>(o[4], o[5]), wl_pack2<TOut>(o[6], o[7]));
     }
 }
 
@@ -144,6 +157,7 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
     // their vector-ALU-bound sweep and would otherwise win every issue slot (arbitration is priority, then age), stretching
     // this short phase -- and with it the time the CU runs on one workgroup's waves only -- to ~25 000 cycles
     __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setreg((1 - 1) << 11 | 23 << 6 | 1, 1);     // hwreg(HW_REG_MODE, 23, 1) = FP16_OVFL: saturating f32 -> f16 stores
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int x0t = txi * WL_T, y0t = tyi * WL_T;
