@@ -60,9 +60,9 @@ DTYPES = {"f16": torch.float16, "bf16": torch.bfloat16}
 
 
 def pmc_traffic(name: str):
-    """HBM bytes per launch of `name` from the committed rocprofv3 PMC capture (profiles/r01_traffic.json, made by
-    scripts/profile.sh + scripts/prof_summary.py on the same command), or None."""
-    path = os.path.join(REPO, "profiles", "r01_traffic.json")
+    """HBM bytes per launch of `name` from the committed rocprofv3 PMC capture (profiles/r02_traffic.json, made by
+    scripts/profile.sh + scripts/prof_summary.py on the same command; regenerate it whenever the dominant kernel changes), or None."""
+    path = os.path.join(REPO, "profiles", "r02_traffic.json")
     try:
         table = json.load(open(path))
     except Exception:
