@@ -23,12 +23,13 @@
 //     the staging loads of a wave are one branch-free batch; this short phase runs at raised wave priority because the
 //     older workgroup of the CU, in its vector-ALU-bound sweep, would otherwise win every issue slot.
 //
-// Occupancy: 512 threads = 8 x 8 pixels x 24 planes, all (<= 4) source views resident: 638 texels x 128 B fp32 = 80 KiB
-// -> two workgroups (16 waves) per CU.  LDS layout of a texel: "lo" plane holds channels {8l..8l+3 : l = 0..3} (64 B),
+// Occupancy: 256 threads = 8 x 4 pixels x 32 planes, all (<= 4) source views resident: 318 texels x 128 B fp32 = 40 KiB
+// -> four workgroups (16 waves) per CU, so three sweep while one computes its boxes and stages (WL_TILE_H = 8: 512 threads,
+// 8 x 8 pixels, 80 KiB, two per CU -- 3-6 % slower: fewer staged texels per voxel but the staging phase is covered worse).  LDS layout of a texel: "lo" plane holds channels {8l..8l+3 : l = 0..3} (64 B),
 // "hi" plane {8l+4..8l+7}; a quad reads 64 contiguous bytes per instruction; the quads of one `ds_read_b128` lane group
 // are four x-adjacent pixels and the box pitch is a multiple of 4, so a group hits four distinct 64-byte bank groups.
 //
-// Measured (profiles/README.md): 129 us against 166 us for the quad kernel inside the headline step (f16; bf16 alike),
+// Measured (profiles/README.md): 115 us against 166 us for the quad kernel inside the headline step (f16; bf16 alike),
 // 48 M vector-ALU instructions against 81 M, L1 tap traffic 8.8 M accesses against 67.9 M.  The sweep is now bound by
 // vector-ALU issue (~70 % busy; ~165 instructions per 16 voxels x 4 views, 77 of them the blend and the two sums).
 // Tried and not kept: software-pipelining the views inside a wave (next view's LDS reads issued between the channel
@@ -41,14 +42,19 @@
 
 namespace pscv {
 
-constexpr int WL_THREADS = 512;
-constexpr int WL_T = 8;                      // tile = WL_T x WL_T reference pixels
-constexpr int WL_ARENA = 638;                // staged texels per block (all views): 80 KiB of fp32 -> two blocks per CU
+#ifndef WL_TILE_H
+#define WL_TILE_H 4
+#endif
+constexpr int WL_T = 8;                      // tile width in reference pixels
+constexpr int WL_TH = WL_TILE_H;             // tile height: 8 (512 threads, two workgroups per CU) or 4 (256 threads, four per CU)
+constexpr int WL_THREADS = 64 * WL_TH;       // a wave = 2 tile rows x 8 pixels; (WL_TH / 2) pixel groups x 2 plane parities
+constexpr int WL_PG = WL_TH / 2;             // pixel groups (waves per plane parity)
+constexpr int WL_ARENA = WL_TH == 8 ? 638 : 318;   // staged texels per block (all views): 80 / 40 KiB of fp32
 constexpr int WL_HI = WL_ARENA * 64;         // byte offset of the "hi" channel plane
 constexpr int WL_MAX_SRC = 4;                // source views of this kernel = lanes of a quad (others: quad kernel)
 constexpr int WL_TABLE = 2 * WL_HI;          // per-view box records written by wave 0: 4 x {X0, Y0, X1, Y1, base, pitch, mode, -}
 constexpr int WL_LDS = WL_TABLE + WL_MAX_SRC * 32 + 32;
-static_assert(WL_LDS <= 81920, "two blocks per CU");
+static_assert(WL_LDS <= (WL_TH == 8 ? 81920 : 40960), "two / four blocks per CU");
 
 typedef float wl_f2 __attribute__((ext_vector_type(2)));
 
@@ -145,7 +151,7 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
     //      4 MiB L2; the depth chunks of a tile re-read nearly the same texels).  Float reciprocals replace integer division. ----
     const int dc = blockIdx.y;
     const int tpx = gridDim.x >> 3;
-    const int ntx = (a.w + WL_T - 1) / WL_T, nty = (a.h + WL_T - 1) / WL_T;
+    const int ntx = (a.w + WL_T - 1) / WL_T, nty = (a.h + WL_TH - 1) / WL_TH;
     const int tile = ((int)blockIdx.x & 7) * tpx + ((int)blockIdx.x >> 3);
     if (tile >= a.B * nty * ntx) return;
     const int trow = (int)(((float)tile + 0.5f) * (1.0f / (float)ntx));     // exact: tile < 2^22
@@ -160,7 +166,7 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
     __builtin_amdgcn_s_setreg((1 - 1) << 11 | 23 << 6 | 1, 1);     // hwreg(HW_REG_MODE, 23, 1) = FP16_OVFL: saturating f32 -> f16 stores
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int x0t = txi * WL_T, y0t = tyi * WL_T;
+    const int x0t = txi * WL_T, y0t = tyi * WL_TH;
     const int d0 = dc * a.ppd, d1 = min(a.D, d0 + a.ppd);
     const float* const depth_b = a.depth + (long)b * a.depth_bstride;
     const int n_src = a.n_src;
@@ -181,7 +187,7 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
     // give each group four x-ADJACENT pixels, whose samples fall on at most four consecutive (or identical) texels of a
     // row = four distinct 64-byte bank groups, for any source scale <= 4/3 (quads of a tile row in natural order collide
     // as soon as the scale is below 1: columns 0 3 5 6 -> texels 0 2 4 5)
-    const int pl = (2 * (wave & 3) + (quad >> 3)) * 8 + ((0x73261540u >> (4 * (quad & 7))) & 7);
+    const int pl = (2 * (wave % WL_PG) + (quad >> 3)) * 8 + ((0x73261540u >> (4 * (quad & 7))) & 7);
     int x = x0t + (pl & 7), y = y0t + (pl >> 3);
     const bool active = x < a.w && y < a.h;
     x = min(x, a.w - 1); y = min(y, a.h - 1);
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
         const float dmin = wl_wave_reduce<false>(dlane), dmax = wl_wave_reduce<true>(dlane);   // (planes need not be monotone)
         const int corner = lane & 7;
         const float cx = (corner & 1) ? (float)min(x0t + WL_T - 1, a.w - 1) : (float)x0t;
-        const float cy = (corner & 2) ? (float)min(y0t + WL_T - 1, a.h - 1) : (float)y0t;
+        const float cy = (corner & 2) ? (float)min(y0t + WL_TH - 1, a.h - 1) : (float)y0t;
         const float d = (corner & 4) ? dmax : dmin;
         int used = 0;
 #pragma unroll
@@ -278,7 +284,8 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
 
     // ---- 3. stage the boxes, 16-bit -> fp32 on the way: waves 2k, 2k+1 take the even / odd rows of view k's box ----
     {
-        const int k = wave >> 1;
+        constexpr int WPV = WL_THREADS / 64 / WL_MAX_SRC;   // waves per view: 2 (even / odd rows) or 1
+        const int k = wave / WPV;
         const int4 f0 = *reinterpret_cast<const int4*>(table + k * 8), f1 = *reinterpret_cast<const int4*>(table + k * 8 + 4);
         const int X0 = __builtin_amdgcn_readfirstlane(f0.x), Y0 = __builtin_amdgcn_readfirstlane(f0.y);
         const int X1 = __builtin_amdgcn_readfirstlane(f0.z), Y1 = __builtin_amdgcn_readfirstlane(f0.w);
@@ -301,12 +308,12 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
             uint4 val[RU];
 #pragma unroll
             for (int i = 0; i < RU; ++i) {
-                const int ty = min((wave & 1) + 2 * i, bh - 1);
+                const int ty = min((wave % WPV) + WPV * i, bh - 1);
                 val[i] = *reinterpret_cast<const uint4*>(col + ty * rstride);
             }
 #pragma unroll
             for (int i = 0; i < RU; ++i) {
-                const int ty = (wave & 1) + 2 * i;
+                const int ty = (wave % WPV) + WPV * i;
                 if (mine && ty < bh) {
                     const uint4 u = val[i];
                     const float4 lo = make_float4(Half16<TIn>::lo(u.x), Half16<TIn>::hi(u.x), Half16<TIn>::lo(u.y), Half16<TIn>::hi(u.y));
@@ -335,7 +342,7 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
     const bool wl_skip = a.temp == -12345.0f;   // (phase timing of the staging alone)
     if (wl_skip) d1_eff = d0;
 #endif
-    for (int d = d0 + (wave >> 2); d < d1_eff; d += 2) {
+    for (int d = d0 + wave / WL_PG; d < d1_eff; d += 2) {
         const float dval = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dlane), d - d0));
         float s[8], q[8];          // variance: sum, sum of squares; softmin: sum e*diff (s only)
         float sum_e = 0.0f;
@@ -516,7 +523,7 @@ static int wl_launch(const WarpArgs& a, int nblk, hipStream_t st) {
         if (e != hipSuccess) { set_error("pscv_warp_cost(lds): hipFuncSetAttribute: %s", hipGetErrorString(e)); return -2; }
         attr_done = true;
     }
-    const int tiles = a.B * ((a.h + WL_T - 1) / WL_T) * ((a.w + WL_T - 1) / WL_T);
+    const int tiles = a.B * ((a.h + WL_TH - 1) / WL_TH) * ((a.w + WL_T - 1) / WL_T);
     hipLaunchKernelGGL(kern, dim3(8 * ((tiles + 7) / 8), a.n_dchunks), dim3(WL_THREADS), WL_LDS, st, a);
     return 0;
 }
@@ -536,9 +543,9 @@ int warp_cost_tiled_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, in
     if (out_dtype != in_dtype && out_dtype != PSCV_F32) return 1;
     if (a.n_src < 1 || a.n_src > WL_MAX_SRC) return 1;
     if (a.ws > 16384 || a.hs > 16384) return 1;
-    if ((long)((a.h + WL_T - 1) / WL_T) * ((a.w + WL_T - 1) / WL_T) * a.B >= (1L << 22)) return 1;   // tile index decode is exact below 2^22
-    const long tiles = (long)a.B * ((a.h + WL_T - 1) / WL_T) * ((a.w + WL_T - 1) / WL_T);
-    int ppd = ppd_override > 0 ? min((ppd_override + 1) & ~1, 64) : 16;   // planes per block: amortises the patch staging
+    if ((long)((a.h + WL_TH - 1) / WL_TH) * ((a.w + WL_T - 1) / WL_T) * a.B >= (1L << 22)) return 1;   // tile index decode is exact below 2^22
+    const long tiles = (long)a.B * ((a.h + WL_TH - 1) / WL_TH) * ((a.w + WL_T - 1) / WL_T);
+    int ppd = ppd_override > 0 ? min((ppd_override + 1) & ~1, 64) : 32;   // planes per block: amortises the patch staging
     while (ppd > 4 && tiles * ((a.D + ppd - 1) / ppd) < 1024) ppd >>= 1;
     a.ppd = ppd;
     a.n_dchunks = (a.D + ppd - 1) / ppd;
