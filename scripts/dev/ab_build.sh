@@ -1,10 +1,16 @@
 #!/bin/bash
-# A/B builds of libpscv with the CURRENT csrc/warp_cost_tiled.hip under another name: scripts/dev/libpscv_<name>.so
-# (gitignored; travels to the GPU box).  Compare with: PSCV_LIB=$PWD/scripts/dev/libpscv_<name>.so python scripts/wbench.py
+# A/B builds of libpscv under another name: scripts/dev/libpscv_<name>.so (gitignored; travels to the GPU box), rebuilding the
+# listed sources with extra flags and linking them with the regular objects of the others.
+#   bash scripts/dev/ab_build.sh <name> "<file1.hip file2.hip ...>" [extra hipcc flags]
+# Compare with: PSCV_LIB=$PWD/scripts/dev/libpscv_<name>.so python scripts/wbench.py / kbench.py / dev/phase_prof.py
 set -e
 cd "$(dirname "$0")/../../wild_deep_mvs_amd/csrc"
-name=$1; shift
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 "$@" -c warp_cost_tiled.hip -o /tmp/wt_$name.o
-OBJS=$(grep "^OBJS" Makefile | sed "s/OBJS *:= *//; s#warp_cost_tiled.o#/tmp/wt_$name.o#")
+name=$1; files=$2; shift; shift
+OBJS=$(grep "^OBJS" Makefile | sed "s/OBJS *:= *//")
+for f in $files; do
+    o=/tmp/ab_${name}_${f%.hip}.o
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -w "$@" -c $f -o $o
+    OBJS=$(echo "$OBJS" | sed "s#\b${f%.hip}.o#$o#")
+done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-rpath,/opt/rocm/lib -o ../../scripts/dev/libpscv_$name.so $OBJS
 echo built scripts/dev/libpscv_$name.so

@@ -8,7 +8,10 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from wild_deep_mvs_amd import _lib as L, ops, synthetic  # noqa: E402
+from wild_deep_mvs_amd import _lib as L  # noqa: E402
+if os.environ.get("PSCV_LIB"):
+    L.LIB_PATH = os.environ["PSCV_LIB"]      # A/B runs against another build of the library
+from wild_deep_mvs_amd import ops, synthetic  # noqa: E402
 
 
 def timeit(fn, reps):

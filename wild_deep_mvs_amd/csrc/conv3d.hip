@@ -17,6 +17,7 @@
 // Sequential(ConvTranspose3d, BatchNorm3d, ReLU) blocks and `prob` of models/MVSNet/model.py:43-84,
 // models/CVP_MVSNet/models/net.py:50-85 and the 3-D members of models/VisMVSNet/nn_utils.py:194-278.
 #include "pscv_common.h"
+#include <type_traits>
 
 namespace pscv {
 
@@ -37,6 +38,7 @@ template <> struct Mfma<f16_t> {
     }
 };
 
+PSCV_PROF_BUFFER(conv)
 int g_conv_small_tiles = 1;   // pscv_set_tuning("conv_small_tiles", 0) forces the large-tile variant
 
 struct ConvArgs {
@@ -53,7 +55,6 @@ struct ConvArgs {
     int cout, epi;
     int ntd, nth, ntw;   // tile counts along d, h, w
     int nt_total;        // 16-channel output tiles of the layer (blockIdx.y picks this block's first tile)
-    int wlds;            // 1: stage this block's weight fragments in LDS (small grids only)
 };
 
 // ---- compile-time geometry ----------------------------------------------------------------------
@@ -80,6 +81,17 @@ __host__ __device__ constexpr int conv_total_steps(int kind, int cin) {
 // 64 / 80 / 112 are 2-way); the other widths keep one 16-byte pad.
 __host__ __device__ constexpr int conv_vs(int cin) { return cin == 32 ? 96 : cin * 2 + 16; }
 __host__ __device__ constexpr int conv_epi_bytes(int nt) { return 3 * nt * 16 * 4; }
+
+// first LDS region: the input brick; workgroups with one M-tile per wave of a dense kind reuse it for the k-split
+// reduction (4 waves x 4 M-tiles x NT N-tiles x 64 lanes x 16 B), so it is at least that large
+__host__ __device__ constexpr int conv_region0(int kind, int cin, int nt, int td, int th) {
+    const int bd = kind == PSCV_CONV_S1 ? td + 2 : kind == PSCV_CONV_S2 ? 2 * td + 1 : td + 1;
+    const int bh = kind == PSCV_CONV_S1 ? th + 2 : kind == PSCV_CONV_S2 ? 2 * th + 1 : th + 1;
+    const int bw = kind == PSCV_CONV_S1 ? 18 : kind == PSCV_CONV_S2 ? 33 : 17;
+    const int brick = (bd * bh * bw * conv_vs(cin) + 15) & ~15;
+    const int red = (td * th == 4 && kind != PSCV_CONV_T2) ? 16 * 1024 * nt : 0;
+    return brick > red ? brick : red;
+}
 
 // LDS byte offset (relative to the lane's output-voxel anchor) of tap `tap` for the dense kinds
 template <int KIND, int BH, int BW, int VS> __device__ __forceinline__ int tap_off_dense(int tap) {
@@ -111,6 +123,7 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
     constexpr int SXY = (KIND == PSCV_CONV_S2) ? 2 : 1;   // input step per output voxel
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    PSCV_PROF_BEGIN
 
     // ---- which tile (XCD-aware bijective remap: each XCD gets a contiguous run of tiles) ----
     const int nwg = gridDim.x;
@@ -130,79 +143,140 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
     const int o_h = (KIND == PSCV_CONV_S1) ? t0h - 1 : (KIND == PSCV_CONV_S2) ? 2 * t0h - 1 : t0h;
     const int o_w = (KIND == PSCV_CONV_S1) ? t0w - 1 : (KIND == PSCV_CONV_S2) ? 2 * t0w - 1 : t0w;
 
-    // ---- weight prefetch ring (dense kinds): the A fragments of the first PF k-steps are requested BEFORE the brick is
-    // staged, so their L2 latency overlaps the brick's; inside the k-loop step s+PF is requested as soon as step s has
-    // been consumed.  (Left to the compiler, weight loads were issued 1-2 steps ahead and every k-step waited on L2.)
+    // ---- weight fragments ----
+    // Workgroups with one M-tile per wave (the 1x4x16 small-volume tiles and the 2x2x16 stride-2 tiles) would have all four
+    // waves fetch the SAME A fragments: four times the layer's weights through the CU's 64 B/clk vector-memory path per 64
+    // output voxels -- 4x more bytes than the input brick, and what these workgroups waited on (scripts/dev/phase_prof.py).
+    // There the waves split the REDUCTION instead of the rows:
+    //   dense kinds (KSPLIT): wave w runs k-steps w, w+4, ... over all four M-tiles; the four partial accumulators are summed
+    //     through LDS in a fixed order (0+1+2+3) before the epilogue of the wave's own M-tile;
+    //   transposed kind (CSPLIT): wave w owns the output-parity classes w and 7-w (9/6/6/6 of the 27 taps) of all four
+    //     M-tiles -- no reduction at all.
+    // Either way a wave fetches a quarter of the weights, all of them up front (<= 24 fragments in flight), together with
+    // the skip values of its outputs, so the only memory latency of the workgroup is the one it shares with the brick.
+    // Larger tiles (MB > 1) keep the row split with a prefetch ring of the next 24/NT k-steps.
     const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;
     const int nt0 = blockIdx.y * NT;
     const uint4* wpk = reinterpret_cast<const uint4*>(a.wpk);
-    const bool WLDS = (TD == 1) && a.wlds;   // small-tile variant on small grids only (wave-uniform)
-    constexpr int PF_WANT = 24 / NT;
-    // (dense kinds only: in the transposed kind the step index depends on the parity class and the ring index would not
-    //  be a compile-time constant everywhere -- the ring then lands in scratch memory)
     constexpr int NSTEPS_ALL = conv_total_steps(KIND, CIN);
-    constexpr int PF = (KIND == PSCV_CONV_T2) ? 1 : (NSTEPS_ALL < PF_WANT ? NSTEPS_ALL : PF_WANT);
+    constexpr bool KSPLIT = MB == 1 && KIND != PSCV_CONV_T2;
+    constexpr bool CSPLIT = MB == 1 && KIND == PSCV_CONV_T2;
+    constexpr int SPW = (NSTEPS_ALL + 3) / 4;    // k-steps per wave under the k-split
+    constexpr int PF_WANT = 24 / NT;
+    constexpr int PF_SRC = KSPLIT ? SPW : NSTEPS_ALL;
+    constexpr int PF = (KIND == PSCV_CONV_T2) ? 1 : (PF_SRC < PF_WANT ? PF_SRC : PF_WANT);
     uint4 wring[PF][NT];
-    if (KIND != PSCV_CONV_T2 && !WLDS) {
+    if (KIND != PSCV_CONV_T2) {
 #pragma unroll
-        for (int s = 0; s < PF; ++s)
+        for (int s = 0; s < PF; ++s) {
+            int st = KSPLIT ? wave + 4 * s : s;
+            st = st < NSTEPS_ALL ? st : NSTEPS_ALL - 1;   // (a wave with one step less re-reads its last one; never used)
 #pragma unroll
-            for (int m = 0; m < NT; ++m) wring[s][m] = wpk[(s * a.nt_total + nt0 + m) * 64 + (tid & 63)];
+            for (int m = 0; m < NT; ++m) wring[s][m] = wpk[(st * a.nt_total + nt0 + m) * 64 + lane];
+        }
+    }
+    // class split: all fragments of classes `wave` and `7 - wave`, and the skip values of their outputs
+    constexpr int CS_MAXW = CSPLIT ? t2_nsteps(0, CIN) + t2_nsteps(7, CIN) : 1;
+    uint4 wcls[CS_MAXW][NT];
+    uint2 skc[CSPLIT ? 8 : 1][NT];
+    // skip tensor addressing shared by the prefetches and the epilogue
+    auto skip_fetch = [&](int od, int oh, int ow, int m) -> uint2 {
+        const int c0 = (nt0 + m) * 16 + g * 4;
+        uint2 sv = make_uint2(0u, 0u);
+        if (a.skip && od < a.Do && oh < a.Ho && ow < a.Wo && a.cout - c0 >= 4) {
+            const long vox = (((long)b * a.Do + od) * a.Ho + oh) * a.Wo + ow;
+            sv = *reinterpret_cast<const uint2*>(a.skip + vox * a.skip_cs + a.skip_co + c0);
+        }
+        return sv;
+    };
+    auto cls_fetch = [&](auto pcc, auto woffc, auto soffc) {
+        constexpr int pc = decltype(pcc)::value, WOFF = decltype(woffc)::value, SOFF = decltype(soffc)::value;
+        constexpr int nsteps = t2_nsteps(pc, CIN), sbase = t2_stepbase(pc, CIN);
+#pragma unroll
+        for (int s = 0; s < nsteps; ++s)
+#pragma unroll
+            for (int m = 0; m < NT; ++m) wcls[WOFF + s][m] = wpk[((sbase + s) * a.nt_total + nt0 + m) * 64 + lane];
+        constexpr int pd = (pc >> 2) & 1, ph = (pc >> 1) & 1, pw = pc & 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = t0d + i / TH, ih = t0h + i % TH, iw = t0w + n;
+            const bool in_ok = id < a.Di && ih < a.Hi && iw < a.Wi;
+#pragma unroll
+            for (int m = 0; m < NT; ++m)
+                skc[SOFF + i][m] = in_ok ? skip_fetch(2 * id + pd, 2 * ih + ph, 2 * iw + pw, m) : make_uint2(0u, 0u);
+        }
+    };
+    if constexpr (CSPLIT) {
+        using std::integral_constant;
+#define PSCV_CLS_PAIR(W) case W: cls_fetch(integral_constant<int, W>{}, integral_constant<int, 0>{}, integral_constant<int, 0>{}); \
+                             cls_fetch(integral_constant<int, 7 - W>{}, integral_constant<int, t2_nsteps(W, CIN)>{}, integral_constant<int, 4>{}); break;
+        switch (wave) { PSCV_CLS_PAIR(0) PSCV_CLS_PAIR(1) PSCV_CLS_PAIR(2) default: PSCV_CLS_PAIR(3) }
+#undef PSCV_CLS_PAIR
+    }
+    // k-split: skip values of the wave's own M-tile
+    uint2 skk[NT];
+    if constexpr (KSPLIT) {
+#pragma unroll
+        for (int m = 0; m < NT; ++m) skk[m] = skip_fetch(t0d + wave / TH, t0h + wave % TH, t0w + n, m);
     }
 
     // ---- stage the input brick into LDS (zero fill outside the volume = the conv's padding) ----
-    // Loads are issued in batches of up to 8 per thread before any of them is written to LDS, so the batch shares
-    // one memory latency (a load -> wait -> ds_write loop exposed the L2/HBM latency once per 16-byte chunk).
+    // A thread owns the same in-plane positions (row, column, 16-byte channel chunk) in EVERY plane of the brick: their
+    // decomposition, bounds test, 32-bit global offset and LDS offset are computed once per slot, and the plane advances through
+    // a wave-uniform base pointer and an immediate LDS offset.  (A flat chunk id decomposed per load cost ~45 vector-ALU
+    // instructions per 16-byte chunk: the stride-2 8 -> 16 layer at full resolution and every small-volume layer spent more
+    // cycles on that arithmetic than on anything else -- scripts/dev/phase_prof.py.)  Loads are issued in groups of planes that
+    // keep <= 16 chunks per thread in flight before any of them is written to LDS, so a group shares one memory latency.
     {
-        const uint16_t* inb = a.in + (long)b * a.Di * a.Hi * a.Wi * a.in_cs + a.in_co;
-        constexpr int NCHUNK = NVOX * CCH;
-        constexpr int BATCH = 8;
-        for (int c0 = 0; c0 < NCHUNK; c0 += 256 * BATCH) {
-            uint4 val[BATCH];
-            int dst[BATCH];
+        constexpr int PC = BH * BW * CCH;                 // chunks per brick plane
+        constexpr int NS = (PC + 255) / 256;              // in-plane slots per thread
+        constexpr int PG = (16 / NS) < 1 ? 1 : ((16 / NS) > BD ? BD : (16 / NS));   // planes per group
+        const unsigned long plane_bytes = (unsigned long)a.Hi * a.Wi * a.in_cs * 2;
+        const char* inb = reinterpret_cast<const char*>(a.in + (long)b * a.Di * a.Hi * a.Wi * a.in_cs + a.in_co);
+        unsigned goff[NS];
+        int lds_off[NS];
+        bool ok[NS];
 #pragma unroll
-            for (int k = 0; k < BATCH; ++k) {
-                const int c = c0 + k * 256 + tid;
-                const int v = c / CCH, cc = c - v * CCH;
-                const int bw = v % BW, t = v / BW;
-                const int bh = t % BH, bd = t / BH;
-                const int gd = o_d + bd, gh = o_h + bh, gw = o_w + bw;
-                val[k] = make_uint4(0u, 0u, 0u, 0u);
-                dst[k] = c < NCHUNK ? v * VS + cc * 16 : -1;
-                if (c < NCHUNK && (unsigned)gd < (unsigned)a.Di && (unsigned)gh < (unsigned)a.Hi && (unsigned)gw < (unsigned)a.Wi)
-                    val[k] = *reinterpret_cast<const uint4*>(inb + (((long)gd * a.Hi + gh) * a.Wi + gw) * a.in_cs + cc * 8);
+        for (int sl = 0; sl < NS; ++sl) {
+            const int c = sl * 256 + tid;
+            const int v = c / CCH, cc = c - v * CCH;
+            const int bh = v / BW, bw = v - bh * BW;
+            const int gh = o_h + bh, gw = o_w + bw;
+            ok[sl] = c < PC && (unsigned)gh < (unsigned)a.Hi && (unsigned)gw < (unsigned)a.Wi;
+            goff[sl] = ok[sl] ? (unsigned)(gh * a.Wi + gw) * (unsigned)(a.in_cs * 2) + (unsigned)(cc * 16) : 0u;
+            lds_off[sl] = c < PC ? v * VS + cc * 16 : -1;
+        }
+#pragma unroll
+        for (int p0 = 0; p0 < BD; p0 += PG) {
+            uint4 val[PG][NS];
+#pragma unroll
+            for (int pp = 0; pp < PG; ++pp) {
+                const int gd = o_d + p0 + pp;                                   // wave-uniform
+                const bool pv = p0 + pp < BD && (unsigned)gd < (unsigned)a.Di;
+                const char* pb = inb + (unsigned long)(pv ? gd : 0) * plane_bytes;
+#pragma unroll
+                for (int sl = 0; sl < NS; ++sl) {
+                    val[pp][sl] = make_uint4(0u, 0u, 0u, 0u);
+                    if (pv && ok[sl]) val[pp][sl] = *reinterpret_cast<const uint4*>(pb + goff[sl]);
+                }
             }
+            PSCV_STAMP(0)
+            PSCV_STAMP_WAIT(1)
 #pragma unroll
-            for (int k = 0; k < BATCH; ++k)
-                if (dst[k] >= 0) *reinterpret_cast<uint4*>(smem + dst[k]) = val[k];
+            for (int pp = 0; pp < PG; ++pp)
+#pragma unroll
+                for (int sl = 0; sl < NS; ++sl)
+                    if (p0 + pp < BD && lds_off[sl] >= 0)
+                        *reinterpret_cast<uint4*>(smem + (p0 + pp) * (BH * BW * VS) + lds_off[sl]) = val[pp][sl];
         }
     }
     // per-channel epilogue constants of this block's NT output tiles -> LDS (one global read per block)
-    float* epi_sc = reinterpret_cast<float*>(smem + ((NVOX * VS + 15) & ~15));
+    constexpr int REGION0 = conv_region0(KIND, CIN, NT, TD, TH);   // brick, later reused by the k-split reduction
+    float* epi_sc = reinterpret_cast<float*>(smem + REGION0);
     float* epi_bi = epi_sc + NT * 16;
     float* epi_fl = epi_bi + NT * 16;
-    // small-tile variant: this block's A fragments are copied to LDS together with the brick (one exposed memory
-    // latency for both) instead of being fetched from L2 step by step inside the short, latency-bound k-loop
-    constexpr int WSTEPS = conv_total_steps(KIND, CIN);
-    uint4* wlds = reinterpret_cast<uint4*>(epi_fl + NT * 16);
-    if (WLDS) {
-        const uint4* wsrc = reinterpret_cast<const uint4*>(a.wpk);
-        constexpr int NW = WSTEPS * NT * 64;
-        for (int i0 = 0; i0 < NW; i0 += 256 * 8) {
-            uint4 wv[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int i = min(i0 + k * 256 + tid, NW - 1);   // clamped: unconditional load keeps wv[] in registers
-                const int l = i & 63, sm = i >> 6, m = sm % NT, st = sm / NT;
-                wv[k] = wsrc[(st * a.nt_total + nt0 + m) * 64 + l];
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int i = i0 + k * 256 + tid;
-                if (i < NW) wlds[i] = wv[k];
-            }
-        }
-    }
     if (tid < NT * 16) {
         const int c = nt0 * 16 + tid;
         const bool cv = c < a.cout;
@@ -211,21 +285,20 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
         epi_fl[tid] = (a.floor && cv) ? a.floor[c] : 0.0f;
     }
     __syncthreads();
+    PSCV_STAMP(2)
 
-    const int lane = tid & 63, wave = tid >> 6;
-    const int n = lane & 15, g = lane >> 4;
-
-    // per-M-tile LDS anchors of this lane's voxel column
-    int anchor[MB];
+    // per-M-tile LDS anchors of this lane's voxel column (row split: the wave's MB tiles; k / class split: all four)
+    constexpr int NA = MB == 1 ? 4 : MB;
+    int anchor[NA];
 #pragma unroll
-    for (int i = 0; i < MB; ++i) {
-        const int mt = wave * MB + i;
+    for (int i = 0; i < NA; ++i) {
+        const int mt = MB == 1 ? i : wave * MB + i;
         const int td = mt / TH, th = mt % TH;
         anchor[i] = ((td * SXY * BH + th * SXY) * BW + n * SXY) * VS;
     }
 
     // ---- epilogue (shared by all kinds) ----
-    auto epilogue = [&](const f32x4 (&acc)[NT], int od, int oh, int ow) {
+    auto epilogue = [&](const f32x4 (&acc)[NT], int od, int oh, int ow, const uint2* pre = nullptr) {
         if (od >= a.Do || oh >= a.Ho || ow >= a.Wo) return;
         const long vox = (((long)b * a.Do + od) * a.Ho + oh) * a.Wo + ow;
 #pragma unroll
@@ -243,7 +316,7 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
             if (a.skip) {
                 const uint16_t* sp = a.skip + vox * a.skip_cs + a.skip_co + c0;
                 if (a.cout - c0 >= 4) {
-                    const uint2 sv = *reinterpret_cast<const uint2*>(sp);
+                    const uint2 sv = pre ? pre[m] : *reinterpret_cast<const uint2*>(sp);
                     y[0] += Half16<H>::lo(sv.x); y[1] += Half16<H>::hi(sv.x);
                     y[2] += Half16<H>::lo(sv.y); y[3] += Half16<H>::hi(sv.y);
                 } else {
@@ -266,8 +339,94 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
         }
     };
 
-    if (KIND != PSCV_CONV_T2) {
-        constexpr int NSTEPS = ceil_div(27 * CIN, 32);
+    if constexpr (KSPLIT) {
+        // ---- dense kinds, k-split: wave w contracts k-steps w, w+4, ... for all four M-tiles ----
+        constexpr int NSTEPS = NSTEPS_ALL;
+        f32x4 acc[4][NT];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int m = 0; m < NT; ++m) acc[i][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < SPW; ++j) {
+            const int s = wave + 4 * j;              // wave-uniform
+            if (s < NSTEPS) {
+                const int kk0 = s * 32 + g * 8;
+                const int koff = tap_off_dense<KIND, BH, BW, VS>(kk0 / CIN) + (kk0 % CIN) * 2;
+                uint4 wf[NT];
+#pragma unroll
+                for (int m = 0; m < NT; ++m) wf[m] = wring[j % PF][m];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint4 xf = *reinterpret_cast<const uint4*>(smem + anchor[i] + koff);
+#pragma unroll
+                    for (int m = 0; m < NT; ++m) acc[i][m] = Mfma<H>::run(wf[m], xf, acc[i][m]);
+                }
+                if (j + PF < SPW) {
+                    int st = s + 4 * PF;
+                    st = st < NSTEPS ? st : NSTEPS - 1;
+#pragma unroll
+                    for (int m = 0; m < NT; ++m) wring[j % PF][m] = wpk[(st * a.nt_total + nt0 + m) * 64 + lane];
+                }
+            }
+        }
+        PSCV_STAMP(3)
+        // partial sums -> LDS (over the brick, which every wave has finished reading), summed in wave order 0..3
+        __syncthreads();
+        f32x4* red = reinterpret_cast<f32x4*>(smem);       // [source wave][M-tile][N-tile][lane]
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int m = 0; m < NT; ++m) red[((wave * 4 + i) * NT + m) * 64 + lane] = acc[i][m];
+        __syncthreads();
+        f32x4 fin[NT];
+#pragma unroll
+        for (int m = 0; m < NT; ++m) {
+            f32x4 f = red[((0 * 4 + wave) * NT + m) * 64 + lane];
+            f += red[((1 * 4 + wave) * NT + m) * 64 + lane];
+            f += red[((2 * 4 + wave) * NT + m) * 64 + lane];
+            f += red[((3 * 4 + wave) * NT + m) * 64 + lane];
+            fin[m] = f;
+        }
+        epilogue(fin, t0d + wave / TH, t0h + wave % TH, t0w + n, skk);
+        PSCV_STAMP(4)
+    } else if constexpr (CSPLIT) {
+        // ---- transposed kind, class split: wave w computes parity classes w and 7-w of all four M-tiles ----
+        auto cls_run = [&](auto pcc, auto woffc, auto soffc) {
+            constexpr int pc = decltype(pcc)::value, WOFF = decltype(woffc)::value, SOFF = decltype(soffc)::value;
+            constexpr int nsteps = t2_nsteps(pc, CIN);
+            constexpr int pd = (pc >> 2) & 1, ph = (pc >> 1) & 1, pw = pc & 1;
+            f32x4 acc[4][NT];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int m = 0; m < NT; ++m) acc[i][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < nsteps; ++s) {
+                const int kk0 = s * 32 + g * 8;
+                const int koff = tap_off_t2<BH, BW, VS>(pc, kk0 / CIN) + (kk0 % CIN) * 2;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint4 xf = *reinterpret_cast<const uint4*>(smem + anchor[i] + koff);
+#pragma unroll
+                    for (int m = 0; m < NT; ++m) acc[i][m] = Mfma<H>::run(wcls[WOFF + s][m], xf, acc[i][m]);
+                }
+            }
+            PSCV_STAMP(3)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int id = t0d + i / TH, ih = t0h + i % TH, iw = t0w + n;
+                if (id < a.Di && ih < a.Hi && iw < a.Wi) epilogue(acc[i], 2 * id + pd, 2 * ih + ph, 2 * iw + pw, skc[SOFF + i]);
+            }
+            PSCV_STAMP(4)
+        };
+        using std::integral_constant;
+#define PSCV_CLS_PAIR(W) case W: cls_run(integral_constant<int, W>{}, integral_constant<int, 0>{}, integral_constant<int, 0>{}); \
+                             cls_run(integral_constant<int, 7 - W>{}, integral_constant<int, t2_nsteps(W, CIN)>{}, integral_constant<int, 4>{}); break;
+        switch (wave) { PSCV_CLS_PAIR(0) PSCV_CLS_PAIR(1) PSCV_CLS_PAIR(2) default: PSCV_CLS_PAIR(3) }
+#undef PSCV_CLS_PAIR
+    } else if constexpr (KIND != PSCV_CONV_T2) {
+        constexpr int NSTEPS = NSTEPS_ALL;
         f32x4 acc[MB][NT];
 #pragma unroll
         for (int i = 0; i < MB; ++i)
@@ -280,23 +439,26 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
             const int koff = tap_off_dense<KIND, BH, BW, VS>(kk0 / CIN) + (kk0 % CIN) * 2;
             uint4 wf[NT];
 #pragma unroll
-            for (int m = 0; m < NT; ++m) wf[m] = WLDS ? wlds[(s * NT + m) * 64 + lane] : wring[s % PF][m];
+            for (int m = 0; m < NT; ++m) wf[m] = wring[s % PF][m];
 #pragma unroll
             for (int i = 0; i < MB; ++i) {
                 const uint4 xf = *reinterpret_cast<const uint4*>(smem + anchor[i] + koff);
 #pragma unroll
                 for (int m = 0; m < NT; ++m) acc[i][m] = Mfma<H>::run(wf[m], xf, acc[i][m]);
             }
-            if (!WLDS && s + PF < NSTEPS) {
+            if (s + PF < NSTEPS) {
 #pragma unroll
-                for (int m = 0; m < NT; ++m) wring[s % PF][m] = wpk[((s + PF) * a.nt_total + nt0 + m) * 64 + lane];
+                for (int m = 0; m < NT; ++m)
+                    wring[s % PF][m] = wpk[((s + PF) * a.nt_total + nt0 + m) * 64 + lane];
             }
         }
+        PSCV_STAMP(3)
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
             const int mt = wave * MB + i;
             epilogue(acc[i], t0d + mt / TH, t0h + mt % TH, t0w + n);
         }
+        PSCV_STAMP(4)
     } else {
 #pragma unroll
         for (int pc = 0; pc < 8; ++pc) {
@@ -315,34 +477,34 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
                     const int fs = sbase + s;   // flat step index over all classes (compile-time after unrolling)
                     uint4 wf[NT];
 #pragma unroll
-                    for (int m = 0; m < NT; ++m) wf[m] = WLDS ? wlds[(fs * NT + m) * 64 + lane] : wpk[(fs * a.nt_total + nt0 + m) * 64 + lane];
+                    for (int m = 0; m < NT; ++m) wf[m] = wpk[(fs * a.nt_total + nt0 + m) * 64 + lane];
 #pragma unroll
                     for (int i = 0; i < MB; ++i) {
                         const uint4 xf = *reinterpret_cast<const uint4*>(smem + anchor[i] + koff);
 #pragma unroll
                         for (int m = 0; m < NT; ++m) acc[i][m] = Mfma<H>::run(wf[m], xf, acc[i][m]);
                     }
-
                 }
             }
             const int pd = (pc >> 2) & 1, ph = (pc >> 1) & 1, pw = pc & 1;
+            PSCV_STAMP(3)
 #pragma unroll
             for (int i = 0; i < MB; ++i) {
                 const int mt = wave * MB + i;
                 const int id = t0d + mt / TH, ih = t0h + mt % TH, iw = t0w + n;
                 if (id < a.Di && ih < a.Hi && iw < a.Wi) epilogue(acc[i], 2 * id + pd, 2 * ih + ph, 2 * iw + pw);
             }
+            PSCV_STAMP(4)
         }
     }
+    PSCV_STAMP_WAIT(5)
+    PSCV_PROF_END(conv, blockIdx.x + gridDim.x * blockIdx.y)
 }
 
 // ---- host side ---------------------------------------------------------------------------------
 template <typename H, int CIN, int NT, int KIND, int TD, int TH>
 static int launch_conv(ConvArgs& a, int n_split, hipStream_t st) {
-    using BR = Brick<KIND, TD, TH>;
-    constexpr int VS = conv_vs(CIN);
-    constexpr int LDS_BASE = ((BR::BD * BR::BH * BR::BW * VS + 15) & ~15) + conv_epi_bytes(NT);
-    constexpr int LDS = LDS_BASE + (TD == 1 ? conv_total_steps(KIND, CIN) * NT * 1024 : 0);
+    constexpr int LDS = conv_region0(KIND, CIN, NT, TD, TH) + conv_epi_bytes(NT);
     static_assert(LDS <= 160 * 1024, "brick does not fit the 160 KiB LDS");
     const int rd = KIND == PSCV_CONV_T2 ? a.Di : a.Do, rh = KIND == PSCV_CONV_T2 ? a.Hi : a.Ho,
               rw = KIND == PSCV_CONV_T2 ? a.Wi : a.Wo;
@@ -356,10 +518,7 @@ static int launch_conv(ConvArgs& a, int n_split, hipStream_t st) {
         if (e != hipSuccess) { set_error("pscv_conv3d: hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e)); return -2; }
         attr_done = true;
     }
-    // weights through LDS pay off only when the grid is a round or two of workgroups (latency-bound); on larger
-    // grids the extra 27-54 KB per workgroup costs more than the per-step L2 fetches it hides
-    a.wlds = (TD == 1 && nblk * n_split <= 512) ? 1 : 0;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_split), dim3(256), a.wlds ? LDS : LDS_BASE, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_split), dim3(256), LDS, st, a);
     return 0;
 }
 
@@ -400,6 +559,8 @@ static int launch_channels(ConvArgs& a, int c_in, int c_out, int kind, hipStream
 }
 
 }  // namespace pscv
+
+PSCV_PROF_EXPORT(conv)
 
 int pscv_conv3d_sweep8_launch(const void* in, int dtype, int in_cstride, int in_coff, const uint16_t* packed,
                               const float* scale, const float* bias, const float* floor, const void* skip,

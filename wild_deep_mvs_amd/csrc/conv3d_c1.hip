@@ -57,6 +57,7 @@ constexpr int C1_P = 6;                        // output planes per block (MFMA 
 constexpr int C1_TH = 4, C1_TW = 32, C1_BH = C1_TH + 2, C1_BW = C1_TW + 2;
 constexpr int C1_PS = 208;                     // plane stride in voxels: 6 x 34 = 204 padded to 0 mod 16
 constexpr int C1_NB_MAX = 2;
+PSCV_PROF_BUFFER(c1)
 
 template <typename H, int CIN>
 __global__ __launch_bounds__(256) void conv3d_c1_kernel(const C1Args a) {
@@ -81,6 +82,7 @@ __global__ __launch_bounds__(256) void conv3d_c1_kernel(const C1Args a) {
     const bool interior = dbeg >= 1 && dbeg + brick_planes < a.D && a.nb == C1_NB_MAX;   // all staged planes exist
 
     const int tid = threadIdx.x;
+    PSCV_PROF_BEGIN
     {   // ---- stage the brick: every load of the workgroup is in flight before the first LDS write.  Thread t < 204
         // owns brick voxel t of EVERY plane: its offset inside a plane and its LDS offset are computed once, the plane
         // advances through an immediate / scalar offset -- no per-load vector arithmetic, and for an interior brick
@@ -115,6 +117,8 @@ __global__ __launch_bounds__(256) void conv3d_c1_kernel(const C1Args a) {
                     if (pv && vox_ok) reg[p][c] = *reinterpret_cast<const uint4*>(pp + goff + c * 16);
             }
         }
+        PSCV_STAMP(0)
+        PSCV_STAMP_WAIT(1)
         unsigned char* sp = smem + tid * VB;
         if (tid < PV) {
 #pragma unroll
@@ -130,13 +134,15 @@ __global__ __launch_bounds__(256) void conv3d_c1_kernel(const C1Args a) {
     const int n = lane & 15, g = lane >> 4;
     uint4 wf[NSTEPS];
 #pragma unroll
-    for (int s = 0; s < NSTEPS; ++s) wf[s] = a.wpk[s * 64 + lane];
+    for (int s = 0; s < NSTEPS; ++s)
+        wf[s] = a.wpk[s * 64 + lane];
     const float e_scale = a.scale ? a.scale[0] : 1.0f, e_bias = a.bias ? a.bias[0] : 0.0f,
                 e_floor = a.floor ? a.floor[0] : 0.0f;
     // ReLU switches as clamps against -inf (no branches in the epilogue)
     const float lo_pre = (a.epi & PSCV_EPI_RELU_PRE) ? e_floor : -__builtin_inff();
     const float lo_post = (a.epi & PSCV_EPI_RELU_POST) ? 0.0f : -__builtin_inff();
     __syncthreads();
+    PSCV_STAMP(2)
 
     // byte offset of this lane's B operand at step (q = 0, tap 0) of column tile 0: voxel (row = wave, col = n) of the
     // lane group's first plane
@@ -170,6 +176,7 @@ __global__ __launch_bounds__(256) void conv3d_c1_kernel(const C1Args a) {
             acc0 = C1Mfma<H>::run(wf[s], x0, acc0);
             acc1 = C1Mfma<H>::run(wf[s], x1, acc1);
         }
+        PSCV_STAMP(3)
         // ---- epilogue: lane (n, g) holds rows 4g..4g+3 = output planes d0 + 4g + r of pixel n ----
         if (full) {
             // interior brick without a skip tensor (the common case): straight-line code, two predicates in total
@@ -222,7 +229,10 @@ __global__ __launch_bounds__(256) void conv3d_c1_kernel(const C1Args a) {
                 }
             }
         }
+        PSCV_STAMP(4)
     }
+    PSCV_STAMP_WAIT(5)
+    PSCV_PROF_END(c1, blockIdx.x)
 }
 
 template <typename H, int CIN>
@@ -240,6 +250,7 @@ static int c1_launch(const C1Args& a, long nblk, hipStream_t st) {
 }  // namespace pscv
 
 int g_c1_nb = 0;
+PSCV_PROF_EXPORT(c1)
 
 int pscv_conv3d_c1_launch(const void* in, int dtype, int in_cstride, int in_coff, const uint16_t* packed,
                           const float* scale, const float* bias, const float* floor, const void* skip, int skip_cstride, int skip_coff, void* out,

@@ -47,6 +47,7 @@ struct Tp8Args {
 
 constexpr int TP_TD = 2, TP_TH = 4, TP_BD = TP_TD + 1, TP_BH = TP_TH + 1, TP_BW = 17;
 constexpr int TP_VS = 48;   // 16 ch x 2 B + 16 B pad
+PSCV_PROF_BUFFER(t2p8)
 
 template <typename H>
 __global__ __launch_bounds__(256) void conv3d_t2p8_kernel(const Tp8Args a) {
@@ -63,6 +64,7 @@ __global__ __launch_bounds__(256) void conv3d_t2p8_kernel(const Tp8Args a) {
     const int t0d = td_i * TP_TD, t0h = th_i * TP_TH, t0w = tw_i * 16;
 
     const int tid = threadIdx.x;
+    PSCV_PROF_BEGIN
     {
         const uint16_t* inb = a.in + (long)b * a.Di * a.Hi * a.Wi * a.in_cs + a.in_co;
         for (int c = tid; c < NVOX * 2; c += 256) {
@@ -76,13 +78,15 @@ __global__ __launch_bounds__(256) void conv3d_t2p8_kernel(const Tp8Args a) {
             *reinterpret_cast<uint4*>(smem + v * TP_VS + cc * 16) = val;
         }
     }
+    PSCV_STAMP(0)
     const int lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
     uint4 wf[9];
     {
         const uint4* wp = reinterpret_cast<const uint4*>(a.wpk);
 #pragma unroll
-        for (int s = 0; s < 9; ++s) wf[s] = wp[s * 64 + lane];
+        for (int s = 0; s < 9; ++s)
+            wf[s] = wp[s * 64 + lane];
     }
     const int c0 = (g & 1) * 4;
     float sc[4], bi[4], fl[4];
@@ -92,7 +96,9 @@ __global__ __launch_bounds__(256) void conv3d_t2p8_kernel(const Tp8Args a) {
         bi[k] = a.bias ? a.bias[c0 + k] : 0.0f;
         fl[k] = a.floor ? a.floor[c0 + k] : 0.0f;
     }
+    PSCV_STAMP_WAIT(1)
     __syncthreads();
+    PSCV_STAMP(2)
 
     const int Do = 2 * a.Di, Ho = 2 * a.Hi, Wo = 2 * a.Wi;
     // B operand of lane (n, g): input voxel column n + (g >> 1), channel half g & 1
@@ -118,6 +124,7 @@ __global__ __launch_bounds__(256) void conv3d_t2p8_kernel(const Tp8Args a) {
                         acc = TpMfma<H>::run(wf[step], xf, acc);
                         ++step;
                     }
+                PSCV_STAMP(3)
                 if (in_ok) {
                     const int ox = 2 * iw + (g >> 1);
                     const long vox = (((long)b * Do + 2 * id + pd) * Ho + 2 * ih + ph) * Wo + ox;
@@ -142,11 +149,16 @@ __global__ __launch_bounds__(256) void conv3d_t2p8_kernel(const Tp8Args a) {
                         *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.out) + vox * a.out_cs + a.out_co + c0) =
                             make_uint2(Half16<H>::pack(y[0], y[1]), Half16<H>::pack(y[2], y[3]));
                 }
+                PSCV_STAMP(4)
             }
     }
+    PSCV_STAMP_WAIT(5)
+    PSCV_PROF_END(t2p8, blockIdx.x)
 }
 
 }  // namespace pscv
+
+PSCV_PROF_EXPORT(t2p8)
 
 int pscv_conv3d_t2p8_launch(const void* in, int dtype, int in_cstride, int in_coff, const uint16_t* packed,
                             const float* scale, const float* bias, const float* floor, const void* skip, int skip_cstride,

@@ -29,6 +29,35 @@ void set_error(const char* fmt, ...);
         }                                                                              \
     } while (0)
 
+// ---- phase timing (development builds only: -DPSCV_PROFILE) ---------------------------------------------------------
+// Cycle stamps are kept in registers and written once per workgroup (wave 0) at the end: slots 0..5 = cycles of phases 0..5,
+// 6 / 7 = absolute begin / end (low 32 bits), 8 = HW_ID, 9 = XCC_ID.  Each translation unit owns its buffer and exports a getter
+// (PSCV_PROF_EXPORT); scripts/dev/phase_prof.py reads them.
+#ifdef PSCV_PROFILE
+constexpr int PSCV_PROF_BLOCKS = 16384;
+#define PSCV_PROF_BUFFER(tag) __device__ unsigned int pscv_prof_##tag[pscv::PSCV_PROF_BLOCKS * 16];
+#define PSCV_PROF_BEGIN unsigned long long pt_prev = __builtin_readcyclecounter(); const unsigned long long pt_begin = pt_prev; \
+    unsigned pt_acc[6] = {0, 0, 0, 0, 0, 0};
+#define PSCV_STAMP(i) { const unsigned long long t_ = __builtin_readcyclecounter(); pt_acc[i] += (unsigned)(t_ - pt_prev); pt_prev = t_; }
+#define PSCV_STAMP_WAIT(i) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); PSCV_STAMP(i) }
+#define PSCV_PROF_END(tag, blk) if (threadIdx.x == 0 && (blk) < pscv::PSCV_PROF_BLOCKS) { \
+        unsigned hwid_, xcc_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid_)); \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_)); \
+        unsigned int* o_ = pscv_prof_##tag + (blk) * 16; \
+        for (int i_ = 0; i_ < 6; ++i_) o_[i_] = pt_acc[i_]; \
+        o_[6] = (unsigned)pt_begin; o_[7] = (unsigned)pt_prev; o_[8] = hwid_; o_[9] = xcc_; }
+#define PSCV_PROF_EXPORT(tag) extern "C" int pscv_debug_prof_##tag(unsigned int* out, int n_blocks) { \
+        if (n_blocks > pscv::PSCV_PROF_BLOCKS) n_blocks = pscv::PSCV_PROF_BLOCKS; \
+        return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pscv::pscv_prof_##tag), (size_t)n_blocks * 16 * sizeof(unsigned int)); }
+#else
+#define PSCV_PROF_BUFFER(tag)
+#define PSCV_PROF_BEGIN
+#define PSCV_STAMP(i)
+#define PSCV_STAMP_WAIT(i)
+#define PSCV_PROF_END(tag, blk)
+#define PSCV_PROF_EXPORT(tag)
+#endif
+
 // ---- bf16 <-> fp32 (round to nearest even, same as torch's .to(bfloat16)) ----
 __host__ __device__ __forceinline__ float bf16_to_f32(uint16_t v) {
     union { uint32_t u; float f; } c;
