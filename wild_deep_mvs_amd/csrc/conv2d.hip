@@ -58,6 +58,7 @@ struct Conv2dArgs {
     int nt_total;            // 16-channel output tiles of the layer (blockIdx.y picks this block's first NT tiles)
     float neg_slope;         // activation y -> max(y, neg_slope * y): 0 = ReLU, 0.1 = LeakyReLU(0.1), 1 = none
     int nth, ntw;
+    unsigned mg_th, mg_tw;
 };
 
 __host__ __device__ constexpr int c2_ceil_div(int a, int b) { return (a + b - 1) / b; }
@@ -81,8 +82,8 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const Conv2dArgs a) {
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, slot = bid >> 3, q_ = nwg >> 3, r_ = nwg & 7;
     int wg = (xcd < r_ ? xcd * (q_ + 1) : r_ * (q_ + 1) + (xcd - r_) * q_) + slot;
-    const int tw_i = wg % a.ntw; wg /= a.ntw;
-    const int th_i = wg % a.nth; wg /= a.nth;
+    const int tw_i = fast_divmod(wg, a.ntw, a.mg_tw);
+    const int th_i = fast_divmod(wg, a.nth, a.mg_th);
     const int b = wg;
     const int oy0 = th_i * TH, ox0 = tw_i * C2_TW;
     const int iy0 = oy0 * STRIDE - PAD, ix0 = ox0 * STRIDE - PAD;
@@ -227,6 +228,7 @@ static int c2_launch(Conv2dArgs& a, int n_split, hipStream_t st) {
     constexpr int LDS = BH * BWL * c2_vs(CIN) + 64;
     static_assert(LDS <= 160 * 1024, "brick does not fit the LDS");
     a.nth = c2_ceil_div(a.Ho, TH); a.ntw = c2_ceil_div(a.Wo, C2_TW);
+    a.mg_th = fast_div_magic(a.nth); a.mg_tw = fast_div_magic(a.ntw);
     const long nblk = (long)a.B * a.nth * a.ntw;
     if (nblk <= 0 || nblk > 0x7fffffffL) { set_error("pscv_conv2d: bad grid %ld", nblk); return -1; }
     auto kern = conv2d_kernel<H, CIN, NT, KS, STRIDE>;

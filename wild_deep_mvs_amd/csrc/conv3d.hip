@@ -54,6 +54,7 @@ struct ConvArgs {
     int B, Di, Hi, Wi, Do, Ho, Wo;
     int cout, epi;
     int ntd, nth, ntw;   // tile counts along d, h, w
+    unsigned mg_td, mg_th, mg_tw;   // fast_div_magic of the tile counts
     int nt_total;        // 16-channel output tiles of the layer (blockIdx.y picks this block's first tile)
 };
 
@@ -110,6 +111,20 @@ template <int BH, int BW, int VS> __device__ __forceinline__ int tap_off_t2(int 
     return ((od * BH + oh) * BW + ow) * VS;
 }
 
+// channel group that is cut by c_out (c_out not a multiple of 4): element-wise skip add and stores, out of line
+template <typename H>
+__device__ __noinline__ void epi_ragged(float y0, float y1, float y2, float y3, const uint16_t* sp, void* op, int cnt, int out_f32,
+                                        float lo_post) {
+    float y[4] = {y0, y1, y2, y3};
+    for (int k = 0; k < cnt; ++k) {
+        float v = y[k];
+        if (sp) v += Half16<H>::one(sp[k]);
+        v = fmaxf(v, lo_post);
+        if (out_f32) reinterpret_cast<float*>(op)[k] = v;
+        else reinterpret_cast<uint16_t*>(op)[k] = Half16<H>::bits(v);
+    }
+}
+
 template <typename H, int CIN, int NT, int KIND, int TD, int TH>
 __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
     using BR = Brick<KIND, TD, TH>;
@@ -131,9 +146,9 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
     const int xcd = bid & 7, slot = bid >> 3;
     const int q = nwg >> 3, r = nwg & 7;
     int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    const int tw_i = wg % a.ntw; wg /= a.ntw;
-    const int th_i = wg % a.nth; wg /= a.nth;
-    const int td_i = wg % a.ntd; wg /= a.ntd;
+    const int tw_i = fast_divmod(wg, a.ntw, a.mg_tw);
+    const int th_i = fast_divmod(wg, a.nth, a.mg_th);
+    const int td_i = fast_divmod(wg, a.ntd, a.mg_td);
     const int b = wg;
 
     // tile anchor in "row space": output coords for S1/S2, input coords for T2
@@ -181,16 +196,32 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
     constexpr int CS_MAXW = CSPLIT ? t2_nsteps(0, CIN) + t2_nsteps(7, CIN) : 1;
     uint4 wcls[CS_MAXW][NT];
     uint2 skc[CSPLIT ? 8 : 1][NT];
-    // skip tensor addressing shared by the prefetches and the epilogue
-    auto skip_fetch = [&](int od, int oh, int ow, int m) -> uint2 {
-        const int c0 = (nt0 + m) * 16 + g * 4;
+    // Output / skip addressing shared by the prefetches and the epilogue.  A row of 16 x-adjacent output voxels has
+    // wave-uniform (od, oh): its base is scalar 64-bit arithmetic from per-workgroup constants, and a lane adds one 32-bit
+    // element offset computed ONCE here (x position of the lane's voxel * channel stride + its 4-channel group; the
+    // transposed kind adds pw * channel stride).  (Per-call 64-bit voxel arithmetic made the prologue and the epilogue of
+    // the small-tile kernels instruction-issue bound: ~70 instructions per 8-byte skip load.)
+    constexpr int XS = KIND == PSCV_CONV_T2 ? 2 : 1;
+    const int ox0 = XS * (t0w + n);                                 // lane's output x (pw = 0)
+    const int cg = nt0 * 16 + g * 4;                                // lane's first channel in N-tile 0
+    const unsigned lane_out = (unsigned)(ox0 * a.out_cs + cg), lane_skip = (unsigned)(ox0 * a.skip_cs + cg);
+    const bool lane_ok = t0w + n < (KIND == PSCV_CONV_T2 ? a.Wi : a.Wo);
+    const long plane_out = (long)a.Ho * a.Wo * a.out_cs, plane_skip = (long)a.Ho * a.Wo * a.skip_cs;
+    const int row_out = a.Wo * a.out_cs, row_skip = a.Wo * a.skip_cs;
+    const int bDo = b * a.Do;
+    const bool cout4 = (a.cout & 3) == 0;
+    auto out_row = [&](int od, int oh) -> long { return (long)(bDo + od) * plane_out + (long)oh * row_out + a.out_co; };
+    auto skip_row = [&](int od, int oh) -> long { return (long)(bDo + od) * plane_skip + (long)oh * row_skip + a.skip_co; };
+    auto skip_fetch = [&](long srow, int pw, int m) -> uint2 {           // srow: wave-uniform row inside the volume
         uint2 sv = make_uint2(0u, 0u);
-        if (a.skip && od < a.Do && oh < a.Ho && ow < a.Wo && a.cout - c0 >= 4) {
-            const long vox = (((long)b * a.Do + od) * a.Ho + oh) * a.Wo + ow;
-            sv = *reinterpret_cast<const uint2*>(a.skip + vox * a.skip_cs + a.skip_co + c0);
+        if (a.skip && cout4) {
+            if (lane_ok && cg + m * 16 < a.cout)
+                sv = *reinterpret_cast<const uint2*>(a.skip + srow + (lane_skip + (unsigned)(pw * a.skip_cs + m * 16)));
         }
         return sv;
     };
+    // class split: rows of the wave's outputs relative to the tile origin (od = 2 t0d + pd, oh = 2 (t0h + i) + ph)
+    const long cs_orow0 = CSPLIT ? out_row(2 * t0d, 2 * t0h) : 0, cs_srow0 = CSPLIT ? skip_row(2 * t0d, 2 * t0h) : 0;
     auto cls_fetch = [&](auto pcc, auto woffc, auto soffc) {
         constexpr int pc = decltype(pcc)::value, WOFF = decltype(woffc)::value, SOFF = decltype(soffc)::value;
         constexpr int nsteps = t2_nsteps(pc, CIN), sbase = t2_stepbase(pc, CIN);
@@ -201,11 +232,11 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
         constexpr int pd = (pc >> 2) & 1, ph = (pc >> 1) & 1, pw = pc & 1;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int id = t0d + i / TH, ih = t0h + i % TH, iw = t0w + n;
-            const bool in_ok = id < a.Di && ih < a.Hi && iw < a.Wi;
+            const int id = t0d + i / TH, ih = t0h + i % TH;
+            const bool in_ok = id < a.Di && ih < a.Hi;     // wave-uniform
 #pragma unroll
             for (int m = 0; m < NT; ++m)
-                skc[SOFF + i][m] = in_ok ? skip_fetch(2 * id + pd, 2 * ih + ph, 2 * iw + pw, m) : make_uint2(0u, 0u);
+                skc[SOFF + i][m] = in_ok ? skip_fetch(cs_srow0 + (pd ? plane_skip : 0) + (2 * i + ph) * row_skip, pw, m) : make_uint2(0u, 0u);
         }
     };
     if constexpr (CSPLIT) {
@@ -219,8 +250,12 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
     uint2 skk[NT];
     if constexpr (KSPLIT) {
 #pragma unroll
-        for (int m = 0; m < NT; ++m) skk[m] = skip_fetch(t0d + wave / TH, t0h + wave % TH, t0w + n, m);
+        for (int m = 0; m < NT; ++m) {
+            const int od = t0d + wave / TH, oh = t0h + wave % TH;
+            skk[m] = (od < a.Do && oh < a.Ho) ? skip_fetch(skip_row(od, oh), 0, m) : make_uint2(0u, 0u);
+        }
     }
+    PSCV_STAMP(5)   // (profile builds: slot 5 = weight / skip fetches issued + the final drain)
 
     // ---- stage the input brick into LDS (zero fill outside the volume = the conv's padding) ----
     // A thread owns the same in-plane positions (row, column, 16-byte channel chunk) in EVERY plane of the brick: their
@@ -282,7 +317,7 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
         const bool cv = c < a.cout;
         epi_sc[tid] = (a.scale && cv) ? a.scale[c] : 1.0f;
         epi_bi[tid] = (a.bias && cv) ? a.bias[c] : 0.0f;
-        epi_fl[tid] = (a.floor && cv) ? a.floor[c] : 0.0f;
+        epi_fl[tid] = (a.epi & PSCV_EPI_RELU_PRE) ? ((a.floor && cv) ? a.floor[c] : 0.0f) : -__builtin_inff();
     }
     __syncthreads();
     PSCV_STAMP(2)
@@ -298,45 +333,42 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
     }
 
     // ---- epilogue (shared by all kinds) ----
-    auto epilogue = [&](const f32x4 (&acc)[NT], int od, int oh, int ow, const uint2* pre = nullptr) {
-        if (od >= a.Do || oh >= a.Ho || ow >= a.Wo) return;
-        const long vox = (((long)b * a.Do + od) * a.Ho + oh) * a.Wo + ow;
+    // od, oh are wave-uniform (a row of 16 x-adjacent voxels per M-tile): the row base is scalar arithmetic and a lane adds a
+    // 32-bit offset.  The ReLU switches are folded into clamp constants (epi_fl holds -inf without RELU_PRE, lo_post is -inf
+    // without RELU_POST) and a missing skip tensor adds +0, so the common case -- a channel count that is a multiple of 4 --
+    // is straight-line code: the epilogue is inlined up to 32 times per kernel and its branches used to dominate the code size.
+    const float lo_post = (a.epi & PSCV_EPI_RELU_POST) ? 0.0f : -__builtin_inff();
+    auto epilogue_row = [&](const f32x4 (&acc)[NT], long orow, long srow, int pw, const uint2* pre) {
 #pragma unroll
         for (int m = 0; m < NT; ++m) {
-            const int c0 = (nt0 + m) * 16 + g * 4;
-            if (c0 >= a.cout) continue;
             const float4 sc = *reinterpret_cast<const float4*>(epi_sc + m * 16 + g * 4);
             const float4 bi = *reinterpret_cast<const float4*>(epi_bi + m * 16 + g * 4);
             const float4 fl = *reinterpret_cast<const float4*>(epi_fl + m * 16 + g * 4);
-            float y[4] = {fmaf(acc[m][0], sc.x, bi.x), fmaf(acc[m][1], sc.y, bi.y), fmaf(acc[m][2], sc.z, bi.z),
-                          fmaf(acc[m][3], sc.w, bi.w)};
-            if (a.epi & PSCV_EPI_RELU_PRE) {
-                y[0] = fmaxf(y[0], fl.x); y[1] = fmaxf(y[1], fl.y); y[2] = fmaxf(y[2], fl.z); y[3] = fmaxf(y[3], fl.w);
-            }
-            if (a.skip) {
-                const uint16_t* sp = a.skip + vox * a.skip_cs + a.skip_co + c0;
-                if (a.cout - c0 >= 4) {
-                    const uint2 sv = pre ? pre[m] : *reinterpret_cast<const uint2*>(sp);
-                    y[0] += Half16<H>::lo(sv.x); y[1] += Half16<H>::hi(sv.x);
-                    y[2] += Half16<H>::lo(sv.y); y[3] += Half16<H>::hi(sv.y);
+            float y[4] = {fmaxf(fmaf(acc[m][0], sc.x, bi.x), fl.x), fmaxf(fmaf(acc[m][1], sc.y, bi.y), fl.y),
+                          fmaxf(fmaf(acc[m][2], sc.z, bi.z), fl.z), fmaxf(fmaf(acc[m][3], sc.w, bi.w), fl.w)};
+            const unsigned lo = lane_out + (unsigned)(pw * a.out_cs + m * 16), ls = lane_skip + (unsigned)(pw * a.skip_cs + m * 16);
+            if (lane_ok && cg + m * 16 < a.cout) {
+                if (cout4) {
+                    uint2 sv = make_uint2(0u, 0u);
+                    if (pre) sv = pre[m];
+                    else if (a.skip) sv = *reinterpret_cast<const uint2*>(a.skip + srow + ls);
+                    y[0] = fmaxf(y[0] + Half16<H>::lo(sv.x), lo_post); y[1] = fmaxf(y[1] + Half16<H>::hi(sv.x), lo_post);
+                    y[2] = fmaxf(y[2] + Half16<H>::lo(sv.y), lo_post); y[3] = fmaxf(y[3] + Half16<H>::hi(sv.y), lo_post);
+                    if (a.out_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + orow + lo) = make_float4(y[0], y[1], y[2], y[3]);
+                    else *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.out) + orow + lo) =
+                             make_uint2(Half16<H>::pack(y[0], y[1]), Half16<H>::pack(y[2], y[3]));
                 } else {
-                    for (int k = 0; k < a.cout - c0; ++k) y[k] += Half16<H>::one(sp[k]);
+                    void* op = a.out_f32 ? static_cast<void*>(reinterpret_cast<float*>(a.out) + orow + lo)
+                                         : static_cast<void*>(reinterpret_cast<uint16_t*>(a.out) + orow + lo);
+                    epi_ragged<H>(y[0], y[1], y[2], y[3], a.skip ? a.skip + srow + ls : nullptr, op, min(4, a.cout - (cg + m * 16)),
+                                  a.out_f32, lo_post);
                 }
             }
-            if (a.epi & PSCV_EPI_RELU_POST) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) y[k] = fmaxf(y[k], 0.0f);
-            }
-            if (a.out_f32) {
-                float* op = reinterpret_cast<float*>(a.out) + vox * a.out_cs + a.out_co + c0;
-                if (a.cout - c0 >= 4) *reinterpret_cast<float4*>(op) = make_float4(y[0], y[1], y[2], y[3]);
-                else for (int k = 0; k < a.cout - c0; ++k) op[k] = y[k];
-            } else {
-                uint16_t* op = reinterpret_cast<uint16_t*>(a.out) + vox * a.out_cs + a.out_co + c0;
-                if (a.cout - c0 >= 4) *reinterpret_cast<uint2*>(op) = make_uint2(Half16<H>::pack(y[0], y[1]), Half16<H>::pack(y[2], y[3]));
-                else for (int k = 0; k < a.cout - c0; ++k) op[k] = Half16<H>::bits(y[k]);
-            }
         }
+    };
+    auto epilogue = [&](const f32x4 (&acc)[NT], int od, int oh, int pw, const uint2* pre = nullptr) {
+        if (od >= a.Do || oh >= a.Ho) return;                      // wave-uniform
+        epilogue_row(acc, out_row(od, oh), skip_row(od, oh), pw, pre);
     };
 
     if constexpr (KSPLIT) {
@@ -388,7 +420,7 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
             f += red[((3 * 4 + wave) * NT + m) * 64 + lane];
             fin[m] = f;
         }
-        epilogue(fin, t0d + wave / TH, t0h + wave % TH, t0w + n, skk);
+        epilogue(fin, t0d + wave / TH, t0h + wave % TH, 0, skk);
         PSCV_STAMP(4)
     } else if constexpr (CSPLIT) {
         // ---- transposed kind, class split: wave w computes parity classes w and 7-w of all four M-tiles ----
@@ -415,8 +447,10 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
             PSCV_STAMP(3)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int id = t0d + i / TH, ih = t0h + i % TH, iw = t0w + n;
-                if (id < a.Di && ih < a.Hi && iw < a.Wi) epilogue(acc[i], 2 * id + pd, 2 * ih + ph, 2 * iw + pw, skc[SOFF + i]);
+                const int id = t0d + i / TH, ih = t0h + i % TH;
+                if (id < a.Di && ih < a.Hi)
+                    epilogue_row(acc[i], cs_orow0 + (pd ? plane_out : 0) + (2 * i + ph) * row_out,
+                                 cs_srow0 + (pd ? plane_skip : 0) + (2 * i + ph) * row_skip, pw, skc[SOFF + i]);
             }
             PSCV_STAMP(4)
         };
@@ -456,7 +490,7 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
             const int mt = wave * MB + i;
-            epilogue(acc[i], t0d + mt / TH, t0h + mt % TH, t0w + n);
+            epilogue(acc[i], t0d + mt / TH, t0h + mt % TH, 0);
         }
         PSCV_STAMP(4)
     } else {
@@ -491,8 +525,8 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < MB; ++i) {
                 const int mt = wave * MB + i;
-                const int id = t0d + mt / TH, ih = t0h + mt % TH, iw = t0w + n;
-                if (id < a.Di && ih < a.Hi && iw < a.Wi) epilogue(acc[i], 2 * id + pd, 2 * ih + ph, 2 * iw + pw);
+                const int id = t0d + mt / TH, ih = t0h + mt % TH;
+                if (id < a.Di && ih < a.Hi) epilogue(acc[i], 2 * id + pd, 2 * ih + ph, pw);
             }
             PSCV_STAMP(4)
         }
@@ -509,6 +543,7 @@ static int launch_conv(ConvArgs& a, int n_split, hipStream_t st) {
     const int rd = KIND == PSCV_CONV_T2 ? a.Di : a.Do, rh = KIND == PSCV_CONV_T2 ? a.Hi : a.Ho,
               rw = KIND == PSCV_CONV_T2 ? a.Wi : a.Wo;
     a.ntd = ceil_div(rd, TD); a.nth = ceil_div(rh, TH); a.ntw = ceil_div(rw, 16);
+    a.mg_td = fast_div_magic(a.ntd); a.mg_th = fast_div_magic(a.nth); a.mg_tw = fast_div_magic(a.ntw);
     const long nblk = (long)a.B * a.ntd * a.nth * a.ntw;
     if (nblk <= 0 || nblk > 0x7fffffffL) { set_error("pscv_conv3d: bad grid %ld", nblk); return -1; }
     auto kern = conv3d_kernel<H, CIN, NT, KIND, TD, TH>;

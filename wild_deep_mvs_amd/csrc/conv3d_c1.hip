@@ -51,6 +51,7 @@ struct C1Args {
     int B, D, Hh, W;
     int epi;
     int nth, ntw, ndc, nb;   // tiles, depth chunks, 6-plane blocks per workgroup
+    unsigned mg_th, mg_tw, mg_dc;
 };
 
 constexpr int C1_P = 6;                        // output planes per block (MFMA rows 0..5)
@@ -71,9 +72,9 @@ __global__ __launch_bounds__(256) void conv3d_c1_kernel(const C1Args a) {
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, slot_ = bid >> 3, q_ = nwg >> 3, r_ = nwg & 7;
     int wg = (xcd < r_ ? xcd * (q_ + 1) : r_ * (q_ + 1) + (xcd - r_) * q_) + slot_;
-    const int dci = wg % a.ndc; wg /= a.ndc;
-    const int twi = wg % a.ntw; wg /= a.ntw;
-    const int thi = wg % a.nth; wg /= a.nth;
+    const int dci = fast_divmod(wg, a.ndc, a.mg_dc);
+    const int twi = fast_divmod(wg, a.ntw, a.mg_tw);
+    const int thi = fast_divmod(wg, a.nth, a.mg_th);
     const int b = wg;
     const int h0 = thi * C1_TH, w0 = twi * C1_TW;
     const int brick_planes = a.nb * C1_P;              // output planes of this workgroup
@@ -276,6 +277,7 @@ int pscv_conv3d_c1_launch(const void* in, int dtype, int in_cstride, int in_coff
     if (g_c1_nb) a.nb = g_c1_nb;
     a.ndc = (nblocks + a.nb - 1) / a.nb;
     const long nblk = tiles * a.ndc;
+    a.mg_th = fast_div_magic(a.nth); a.mg_tw = fast_div_magic(a.ntw); a.mg_dc = fast_div_magic(a.ndc);
     if (nblk <= 0 || nblk > 0x7fffffffL) { set_error("pscv_conv3d(c1): bad grid %ld", nblk); return -1; }
     if (dtype == PSCV_BF16 && c_in == 8) return c1_launch<bf16_t, 8>(a, nblk, st);
     if (dtype == PSCV_BF16 && c_in == 16) return c1_launch<bf16_t, 16>(a, nblk, st);

@@ -55,6 +55,7 @@ struct SweepArgs {
     int B, D, Hh, W;
     int epi;
     int nth, ntw, ndc, dc;   // tiles along h, w; depth chunks and planes per chunk (even)
+    unsigned mg_th, mg_tw, mg_dc;
 };
 
 constexpr int SW_BW = 18;
@@ -87,9 +88,9 @@ __global__ __launch_bounds__(32 * SW_TH, 2) void conv3d_sweep8_kernel(const Swee
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, slot_ = bid >> 3, q = nwg >> 3, r_ = nwg & 7;
     int wg = (xcd < r_ ? xcd * (q + 1) : r_ * (q + 1) + (xcd - r_) * q) + slot_;
-    const int dci = wg % a.ndc; wg /= a.ndc;
-    const int twi = wg % a.ntw; wg /= a.ntw;
-    const int thi = wg % a.nth; wg /= a.nth;
+    const int dci = fast_divmod(wg, a.ndc, a.mg_dc);
+    const int twi = fast_divmod(wg, a.ntw, a.mg_tw);
+    const int thi = fast_divmod(wg, a.nth, a.mg_th);
     const int b = wg;
     const int h0 = thi * SW_TH, w0 = twi * 16;
     const int dbeg = dci * a.dc, dend = min(a.D, dbeg + a.dc);
@@ -277,9 +278,9 @@ __global__ __launch_bounds__(256, (CIN == 8 && PD <= 2) ? 4 : (CIN == 8 || (PD =
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, slot_ = bid >> 3, q = nwg >> 3, r_ = nwg & 7;
     int wg = (xcd < r_ ? xcd * (q + 1) : r_ * (q + 1) + (xcd - r_) * q) + slot_;
-    const int dci = wg % a.ndc; wg /= a.ndc;
-    const int twi = wg % a.ntw; wg /= a.ntw;
-    const int thi = wg % a.nth; wg /= a.nth;
+    const int dci = fast_divmod(wg, a.ndc, a.mg_dc);
+    const int twi = fast_divmod(wg, a.ntw, a.mg_tw);
+    const int thi = fast_divmod(wg, a.nth, a.mg_th);
     const int b = wg;
     const int h0 = thi * 8, w0 = twi * 16;
     const int dbeg = dci * a.dc, dend = min(a.D, dbeg + a.dc);
@@ -522,6 +523,7 @@ int pscv_conv3d_sweepc_launch(const void* in, int dtype, int c_in, int c_out, in
     a.dc = dc;
     a.ndc = (D + dc - 1) / dc;
     const long nblk = tiles * a.ndc;
+    a.mg_th = fast_div_magic(a.nth); a.mg_tw = fast_div_magic(a.ntw); a.mg_dc = fast_div_magic(a.ndc);
     if (nblk <= 0 || nblk > 0x7fffffffL) { set_error("pscv_conv3d(sweep): bad grid %ld", nblk); return -1; }
     if (c_out == 16) return dtype == PSCV_BF16 ? sweepc_launch_pd<bf16_t, 16, 16>(a, nblk, st) : sweepc_launch_pd<f16_t, 16, 16>(a, nblk, st);
     if (c_in == 8) return dtype == PSCV_BF16 ? sweepc_launch_pd<bf16_t, 8>(a, nblk, st) : sweepc_launch_pd<f16_t, 8>(a, nblk, st);
@@ -560,6 +562,7 @@ int pscv_conv3d_sweep8_launch(const void* in, int dtype, int in_cstride, int in_
     a.dc = dc;
     a.ndc = (D + dc - 1) / dc;
     const long nblk = tiles * a.ndc;
+    a.mg_th = fast_div_magic(a.nth); a.mg_tw = fast_div_magic(a.ntw); a.mg_dc = fast_div_magic(a.ndc);
     if (nblk <= 0 || nblk > 0x7fffffffL) { set_error("pscv_conv3d(sweep): bad grid %ld", nblk); return -1; }
     static bool attr_done[4] = {false, false, false, false};
     const int ti = (dtype == PSCV_BF16 ? 0 : 1) + (tall ? 2 : 0);

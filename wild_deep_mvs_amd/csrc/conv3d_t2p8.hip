@@ -43,6 +43,7 @@ struct Tp8Args {
     int B, Di, Hi, Wi;
     int epi;
     int ntd, nth, ntw;
+    unsigned mg_td, mg_th, mg_tw;
 };
 
 constexpr int TP_TD = 2, TP_TH = 4, TP_BD = TP_TD + 1, TP_BH = TP_TH + 1, TP_BW = 17;
@@ -57,9 +58,9 @@ __global__ __launch_bounds__(256) void conv3d_t2p8_kernel(const Tp8Args a) {
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, slot = bid >> 3, q = nwg >> 3, r_ = nwg & 7;
     int wg = (xcd < r_ ? xcd * (q + 1) : r_ * (q + 1) + (xcd - r_) * q) + slot;
-    const int tw_i = wg % a.ntw; wg /= a.ntw;
-    const int th_i = wg % a.nth; wg /= a.nth;
-    const int td_i = wg % a.ntd; wg /= a.ntd;
+    const int tw_i = fast_divmod(wg, a.ntw, a.mg_tw);
+    const int th_i = fast_divmod(wg, a.nth, a.mg_th);
+    const int td_i = fast_divmod(wg, a.ntd, a.mg_td);
     const int b = wg;
     const int t0d = td_i * TP_TD, t0h = th_i * TP_TH, t0w = tw_i * 16;
 
@@ -174,6 +175,7 @@ int pscv_conv3d_t2p8_launch(const void* in, int dtype, int in_cstride, int in_co
     a.out_cs = out_cstride; a.out_co = out_coff; a.out_f32 = out_dtype == PSCV_F32;
     a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.epi = epi_flags;
     a.ntd = (Di + TP_TD - 1) / TP_TD; a.nth = (Hi + TP_TH - 1) / TP_TH; a.ntw = (Wi + 15) / 16;
+    a.mg_td = fast_div_magic(a.ntd); a.mg_th = fast_div_magic(a.nth); a.mg_tw = fast_div_magic(a.ntw);
     const long nblk = (long)B * a.ntd * a.nth * a.ntw;
     if (nblk <= 0 || nblk > 0x7fffffffL) { set_error("pscv_conv3d(t2p8): bad grid %ld", nblk); return -1; }
     if (dtype == PSCV_BF16) hipLaunchKernelGGL(conv3d_t2p8_kernel<bf16_t>, dim3((unsigned)nblk), dim3(256), 0, st, a);

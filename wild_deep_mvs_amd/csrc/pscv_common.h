@@ -58,6 +58,19 @@ constexpr int PSCV_PROF_BLOCKS = 16384;
 #define PSCV_PROF_EXPORT(tag)
 #endif
 
+// ---- workgroup-id decode ----------------------------------------------------------------------------------------------
+// x % d and x /= d for a launch constant d through a host-made reciprocal (mg = floor(2^32 / d) + 1: the quotient estimate is
+// exact or one too large for any 32-bit x; one correction step).  The compiler's own sequence for a run-time divisor is ~25
+// dependent scalar / transcendental instructions per division, three of them at the top of every conv workgroup.
+__host__ __device__ __forceinline__ unsigned fast_div_magic(int d) { return d <= 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)d) + 1u; }
+__device__ __forceinline__ int fast_divmod(int& x, int d, unsigned mg) {
+    unsigned q = d <= 1 ? (unsigned)x : __umulhi((unsigned)x, mg);
+    int r = x - (int)(q * (unsigned)d);
+    if (r < 0) { --q; r += d; }
+    x = (int)q;
+    return r;
+}
+
 // ---- bf16 <-> fp32 (round to nearest even, same as torch's .to(bfloat16)) ----
 __host__ __device__ __forceinline__ float bf16_to_f32(uint16_t v) {
     union { uint32_t u; float f; } c;
