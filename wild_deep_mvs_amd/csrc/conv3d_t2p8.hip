@@ -66,50 +66,86 @@ __global__ __launch_bounds__(256) void conv3d_t2p8_kernel(const Tp8Args a) {
 
     const int tid = threadIdx.x;
     PSCV_PROF_BEGIN
-    {
-        const uint16_t* inb = a.in + (long)b * a.Di * a.Hi * a.Wi * a.in_cs + a.in_co;
-        for (int c = tid; c < NVOX * 2; c += 256) {
-            const int v = c >> 1, cc = c & 1;
-            const int bw = v % TP_BW, t = v / TP_BW;
-            const int bh = t % TP_BH, bd = t / TP_BH;
-            const int gd = t0d + bd, gh = t0h + bh, gw = t0w + bw;
-            uint4 val = make_uint4(0u, 0u, 0u, 0u);
-            if (gd < a.Di && gh < a.Hi && gw < a.Wi)
-                val = *reinterpret_cast<const uint4*>(inb + (((long)gd * a.Hi + gh) * a.Wi + gw) * a.in_cs + cc * 8);
-            *reinterpret_cast<uint4*>(smem + v * TP_VS + cc * 16) = val;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    const int Do = 2 * a.Di, Ho = 2 * a.Hi, Wo = 2 * a.Wi;
+
+    // ---- output / skip addressing: rows of 16 input voxels have wave-uniform (od, oh); a lane adds one precomputed 32-bit
+    // element offset (its output x = 2 iw + (g >> 1), channel group (g & 1) * 4).  The skip values of the wave's 8 output rows
+    // are requested before the brick, so the workgroup waits for memory once.
+    const int c0 = (g & 1) * 4;
+    const int ox = 2 * (t0w + n) + (g >> 1);
+    const bool lane_ok = t0w + n < a.Wi;
+    const unsigned lane_out = (unsigned)(ox * a.out_cs + c0), lane_skip = (unsigned)(ox * a.skip_cs + c0);
+    const long plane_out = (long)Ho * Wo * a.out_cs, plane_skip = (long)Ho * Wo * a.skip_cs;
+    const int row_out = Wo * a.out_cs, row_skip = Wo * a.skip_cs;
+    const int bDo = b * Do;
+    uint2 skv[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int mt = wave * 2 + i;
+        const int id = t0d + mt / TP_TH, ih = t0h + mt % TP_TH;
+        const bool in_ok = id < a.Di && ih < a.Hi;     // wave-uniform
+#pragma unroll
+        for (int cl = 0; cl < 4; ++cl) {
+            skv[i][cl] = make_uint2(0u, 0u);
+            if (a.skip && in_ok) {
+                const uint16_t* row = a.skip + ((long)(bDo + 2 * id + (cl >> 1)) * plane_skip + (long)(2 * ih + (cl & 1)) * row_skip + a.skip_co);
+                if (lane_ok) skv[i][cl] = *reinterpret_cast<const uint2*>(row + lane_skip);
+            }
         }
     }
-    PSCV_STAMP(0)
-    const int lane = tid & 63, wave = tid >> 6;
-    const int n = lane & 15, g = lane >> 4;
+
+    // ---- stage the 3 x 5 x 17 input brick: a thread owns one (row, column, channel half) position of every plane ----
+    {
+        constexpr int PC = TP_BH * TP_BW * 2;     // 170 chunks per plane
+        const int v = tid >> 1, cc = tid & 1;
+        const int bh = v / TP_BW, bw = v - bh * TP_BW;
+        const int gh = t0h + bh, gw = t0w + bw;
+        const bool ok = tid < PC && gh < a.Hi && gw < a.Wi;
+        const unsigned goff = ok ? (unsigned)(gh * a.Wi + gw) * (unsigned)(a.in_cs * 2) + (unsigned)(cc * 16) : 0u;
+        const unsigned long plane_bytes = (unsigned long)a.Hi * a.Wi * a.in_cs * 2;
+        const char* inb = reinterpret_cast<const char*>(a.in + (long)b * a.Di * a.Hi * a.Wi * a.in_cs + a.in_co);
+        uint4 val[TP_BD];
+#pragma unroll
+        for (int p = 0; p < TP_BD; ++p) {
+            const int gd = t0d + p;                                    // wave-uniform
+            val[p] = make_uint4(0u, 0u, 0u, 0u);
+            if (gd < a.Di && ok) val[p] = *reinterpret_cast<const uint4*>(inb + (unsigned long)gd * plane_bytes + goff);
+        }
+        PSCV_STAMP(0)
+        if (tid < PC) {
+#pragma unroll
+            for (int p = 0; p < TP_BD; ++p)
+                *reinterpret_cast<uint4*>(smem + (p * (TP_BH * TP_BW) + v) * TP_VS + cc * 16) = val[p];
+        }
+    }
     uint4 wf[9];
     {
         const uint4* wp = reinterpret_cast<const uint4*>(a.wpk);
 #pragma unroll
-        for (int s = 0; s < 9; ++s)
-            wf[s] = wp[s * 64 + lane];
+        for (int s = 0; s < 9; ++s) wf[s] = wp[s * 64 + lane];
     }
-    const int c0 = (g & 1) * 4;
     float sc[4], bi[4], fl[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         sc[k] = a.scale ? a.scale[c0 + k] : 1.0f;
         bi[k] = a.bias ? a.bias[c0 + k] : 0.0f;
-        fl[k] = a.floor ? a.floor[c0 + k] : 0.0f;
+        fl[k] = (a.epi & PSCV_EPI_RELU_PRE) ? (a.floor ? a.floor[c0 + k] : 0.0f) : -__builtin_inff();   // ReLU switches as clamps
     }
+    const float lo_post = (a.epi & PSCV_EPI_RELU_POST) ? 0.0f : -__builtin_inff();
     PSCV_STAMP_WAIT(1)
     __syncthreads();
     PSCV_STAMP(2)
 
-    const int Do = 2 * a.Di, Ho = 2 * a.Hi, Wo = 2 * a.Wi;
     // B operand of lane (n, g): input voxel column n + (g >> 1), channel half g & 1
     const int lane_off = (n + (g >> 1)) * TP_VS + (g & 1) * 16;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int mt = wave * 2 + i;
         const int td = mt / TP_TH, th = mt % TP_TH;
-        const int id = t0d + td, ih = t0h + th, iw = t0w + n;
-        const bool in_ok = id < a.Di && ih < a.Hi && iw < a.Wi;
+        const int id = t0d + td, ih = t0h + th;
+        const bool in_ok = id < a.Di && ih < a.Hi;                    // wave-uniform
         int step = 0;
 #pragma unroll
         for (int pd = 0; pd < 2; ++pd)
@@ -127,28 +163,20 @@ __global__ __launch_bounds__(256) void conv3d_t2p8_kernel(const Tp8Args a) {
                     }
                 PSCV_STAMP(3)
                 if (in_ok) {
-                    const int ox = 2 * iw + (g >> 1);
-                    const long vox = (((long)b * Do + 2 * id + pd) * Ho + 2 * ih + ph) * Wo + ox;
+                    const long orow = (long)(bDo + 2 * id + pd) * plane_out + (long)(2 * ih + ph) * row_out + a.out_co;
+                    const uint2 sv = skv[i][pd * 2 + ph];
                     float y[4];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        y[k] = fmaf(acc[k], sc[k], bi[k]);
-                        if (a.epi & PSCV_EPI_RELU_PRE) y[k] = fmaxf(y[k], fl[k]);
+                    for (int k = 0; k < 4; ++k) y[k] = fmaxf(fmaf(acc[k], sc[k], bi[k]), fl[k]);
+                    y[0] = fmaxf(y[0] + Half16<H>::lo(sv.x), lo_post); y[1] = fmaxf(y[1] + Half16<H>::hi(sv.x), lo_post);
+                    y[2] = fmaxf(y[2] + Half16<H>::lo(sv.y), lo_post); y[3] = fmaxf(y[3] + Half16<H>::hi(sv.y), lo_post);
+                    if (lane_ok) {
+                        if (a.out_f32)
+                            *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + orow + lane_out) = make_float4(y[0], y[1], y[2], y[3]);
+                        else
+                            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.out) + orow + lane_out) =
+                                make_uint2(Half16<H>::pack(y[0], y[1]), Half16<H>::pack(y[2], y[3]));
                     }
-                    if (a.skip) {
-                        const uint2 sv = *reinterpret_cast<const uint2*>(a.skip + vox * a.skip_cs + a.skip_co + c0);
-                        y[0] += Half16<H>::lo(sv.x); y[1] += Half16<H>::hi(sv.x);
-                        y[2] += Half16<H>::lo(sv.y); y[3] += Half16<H>::hi(sv.y);
-                    }
-                    if (a.epi & PSCV_EPI_RELU_POST) {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) y[k] = fmaxf(y[k], 0.0f);
-                    }
-                    if (a.out_f32)
-                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + vox * a.out_cs + a.out_co + c0) = make_float4(y[0], y[1], y[2], y[3]);
-                    else
-                        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.out) + vox * a.out_cs + a.out_co + c0) =
-                            make_uint2(Half16<H>::pack(y[0], y[1]), Half16<H>::pack(y[2], y[3]));
                 }
                 PSCV_STAMP(4)
             }
