@@ -393,6 +393,19 @@ int pscv_warp_cost_bwd(const void* ref, const void* const* srcs, int n_src, cons
 int pscv_cvp_depth_hypos(const float* depth, const double* cams, const float* fallback, unsigned long long* keys,
                          double* steps, float* hypos, int B, int H, int W, void* stream);
 
+/*
+ * Every camera block of a CVP-MVSNet forward pass in one launch.  Replaces conditionIntrinsics, the per-level projection
+ * stacks of homo_warping / proj_cost and the camera products of calDepthHypo (models/CVP_MVSNet/models/modules.py:31-50,
+ * 89-98, 229-293, 131-226), which are hundreds of 3x3 tensor ops per forward.
+ *   ref_in   device fp32 [B,3,3], src_in [B,N,3,3]      intrinsics at image resolution
+ *   ref_ex   device fp32 [B,4,4], src_ex [B,N,4,4]      extrinsics (last row 0 0 0 1)
+ *   level_scale HOST fp32 [L]                           image_height / level_height of each pyramid level (L <= 8)
+ *   warp_cams device fp32 out [L][N][B][PSCV_CAM_FLOATS]  the pscv_proj_cams block of each level (input of pscv_warp_cost)
+ *   hypo_cams device fp64 out [L][B][39] or null          the `cams` of pscv_cvp_depth_hypos of each level (first source view)
+ */
+int pscv_cvp_cams(const float* ref_in, const float* src_in, const float* ref_ex, const float* src_ex, const float* level_scale,
+                  int B, int N, int L, float* warp_cams, double* hypo_cams, void* stream);
+
 /* ---- unsupervised photometric loss (replaces models/trainer.py:209-278 + utils/ssimLoss.py:27-60) ---------
  *
  * pscv_photo_warp: depth map -> flows -> warped source images, the body of Trainer.get_flow_from_depthmap /

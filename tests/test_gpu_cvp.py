@@ -114,3 +114,32 @@ def test_cal_depth_hypo_kernel_vs_oracle(env, case):
     step_want = (want[:, 5] - want[:, 4]).reshape(B, -1)[:, 0]
     print(f"[cal_depth_hypo] {case}: steps {step_want.tolist()}")
     check_close(f"calDepthHypo {case}", got.cpu(), want, max_abs=2e-6)
+
+
+def test_cvp_cams_one_launch_equals_tensor_level_camera_algebra(env):
+    """pscv_cvp_cams (every per-level camera block of a forward in one launch) against the tensor-level drop-ins it replaces in
+    the model's forward: conditionIntrinsics + the projection stack of proj_cost (modules.py:31-50, 89-98) for the warp blocks,
+    and the fp64 constants of calDepthHypo (modules.py:131-226) -- batch of two, three source views, a non-power-of-two level."""
+    L, ops, synthetic, Frontend = env
+    from wild_deep_mvs_amd.models.CVP_MVSNet.models.modules import conditionIntrinsics, _cams, hypo_cams
+    B, V, H, W = 2, 4, 96, 120
+    scene = synthetic.make_scene(B, V, H, W, seed=11)
+    scene["t"][1] *= 0.5
+    row = torch.tensor([0., 0., 0., 1.])
+    ref_ex = torch.cat((torch.cat((scene["R"][:, 0], scene["t"][:, 0]), 2), row.view(1, 1, 4).expand(B, 1, 4)), 1).cuda()
+    src_ex = torch.cat((torch.cat((scene["R"][:, 1:], scene["t"][:, 1:]), 3), row.view(1, 1, 1, 4).expand(B, V - 1, 1, 4)), 2).cuda()
+    K = scene["K"].cuda()
+    heights = [96, 48, 32, 12]                                   # 96 / 32 = 3: the scaling multiplies by an inexact fp32 reciprocal
+    shapes = [(B, 16, h, h * W // H) for h in heights]
+    warp, hypo = ops.cvp_cams(K[:, 0], K[:, 1:], ref_ex, src_ex, [H / h for h in heights])
+    assert tuple(warp.shape) == (len(heights), V - 1, B, L.CAM_FLOATS) and tuple(hypo.shape) == (len(heights), B, 39)
+    ref_ms = conditionIntrinsics(K[:, 0], (B, 3, H, W), shapes)
+    src_ms = torch.stack([conditionIntrinsics(K[:, 1 + i], (B, 3, H, W), shapes) for i in range(V - 1)]).permute(1, 0, 2, 3, 4)
+    for lv in range(len(heights)):
+        want = _cams(ref_ms[:, lv], [src_ms[:, i, lv] for i in range(V - 1)], ref_ex, [src_ex[:, i] for i in range(V - 1)])
+        # fp32 projections in both; the 3x3 products may contract in a different order (one fp32 ulp of the entries)
+        check_close(f"cvp_cams warp level {lv}", warp[lv].cpu(), want.cpu(), rel_l2=2e-6)
+        hw = hypo_cams(ref_ms[:, lv], src_ms[:, 0, lv], ref_ex, src_ex[:, 0])
+        rel = float((hypo[lv] - hw).norm() / hw.norm())          # fp64 on both sides
+        print(f"[parity] cvp_cams hypo level {lv}: rel_l2={rel:.3e}")
+        assert rel <= 1e-12, rel

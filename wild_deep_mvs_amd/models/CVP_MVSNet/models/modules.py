@@ -76,15 +76,11 @@ def proj_cost(nsrc, ref_feature, src_feature, level, ref_in, src_in, ref_ex, src
                          out_dtype=storage_dtype)
 
 
-def calDepthHypo(ref_depths, ref_intrinsics, src_intrinsics, ref_extrinsics, src_extrinsics, depth_min, depth_max, level):
-    """Eval-mode hypothesis maps (modules.py:131-226): per batch item, the MEDIAN over valid pixels of the depth step that
-    moves the projection into the first source view by one pixel along the epipolar line; 8 planes ``depth + k * step``,
-    k = -4..3.  The reference loops over the batch in Python with fp64 tensors; here the per-pixel steps, the exact median
-    (radix select) and the planes are three HIP launches with no host round trip (``pscv_cvp_depth_hypos``, scope row
-    f-4); only the four 3x3 / 3x4 camera products per batch item are tensor math (fp64 like the reference).
-    ref_depths [B,H,W]; src_intrinsics [B,N,3,3]; src_extrinsics [B,N,4,4] -> [B,8,H,W] fp32."""
-    Ki, Ks = ref_intrinsics.double(), src_intrinsics[:, 0].double()
-    Ei, Es = ref_extrinsics.double(), src_extrinsics[:, 0].double()
+def hypo_cams(ref_intrinsics, src_intrinsics, ref_extrinsics, src_extrinsics):
+    """fp64 [B,39] camera constants of ``pscv_cvp_depth_hypos`` for ONE source view (tensor-level form; the model's forward gets
+    the same block for every level from ``ops.cvp_cams``): K_ref^-1, rows 0..2 of E_src E_ref^-1, K_src, (K_ref R_ref)(K_src R_src)^-1."""
+    Ki, Ks = ref_intrinsics.double(), src_intrinsics.double()
+    Ei, Es = ref_extrinsics.double(), src_extrinsics.double()
     # closed-form fp64 inverses (adjugate of the 3x3 blocks; extrinsics have the last row (0,0,0,1)): no LAPACK call, so the
     # whole forward stays capturable in a hipGraph
     Ri_inv = ops.inv3x3(Ei[:, :3, :3])
@@ -92,8 +88,18 @@ def calDepthHypo(ref_depths, ref_intrinsics, src_intrinsics, ref_extrinsics, src
     Ei_inv[:, :3, :3], Ei_inv[:, :3, 3:4], Ei_inv[:, 3, 3] = Ri_inv, -(Ri_inv @ Ei[:, :3, 3:4]), 1.0
     to_src = Es @ Ei_inv                                                                     # [B,4,4]
     A = (Ki @ Ei[:, :3, :3]) @ ops.inv3x3(Ks @ Es[:, :3, :3])
-    cams = torch.cat((ops.inv3x3(Ki).reshape(-1, 9), to_src[:, :3, :].reshape(-1, 12), Ks.reshape(-1, 9), A.reshape(-1, 9)),
+    return torch.cat((ops.inv3x3(Ki).reshape(-1, 9), to_src[:, :3, :].reshape(-1, 12), Ks.reshape(-1, 9), A.reshape(-1, 9)),
                      dim=1).contiguous()
+
+
+def calDepthHypo(ref_depths, ref_intrinsics, src_intrinsics, ref_extrinsics, src_extrinsics, depth_min, depth_max, level):
+    """Eval-mode hypothesis maps (modules.py:131-226): per batch item, the MEDIAN over valid pixels of the depth step that
+    moves the projection into the first source view by one pixel along the epipolar line; 8 planes ``depth + k * step``,
+    k = -4..3.  The reference loops over the batch in Python with fp64 tensors; here the per-pixel steps, the exact median
+    (radix select) and the planes are three HIP launches with no host round trip (``pscv_cvp_depth_hypos``, scope row
+    f-4); only the four 3x3 / 3x4 camera products per batch item are tensor math (fp64 like the reference).
+    ref_depths [B,H,W]; src_intrinsics [B,N,3,3]; src_extrinsics [B,N,4,4] -> [B,8,H,W] fp32."""
+    cams = hypo_cams(ref_intrinsics, src_intrinsics[:, 0], ref_extrinsics, src_extrinsics[:, 0])
     fallback = ((depth_max - depth_min) / 128).to(torch.float32).reshape(-1).contiguous()
     return ops.cvp_depth_hypos(ref_depths.to(torch.float32).contiguous(), cams, fallback)
 

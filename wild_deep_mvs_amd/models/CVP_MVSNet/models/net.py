@@ -199,14 +199,24 @@ class network(nn.Module):
             # NCHW-style shapes of the levels (the engine's maps are [B,h,w,16])
             shp = (lambda f: (f.shape[0], f.shape[3], f.shape[1], f.shape[2])) if engine else (lambda f: tuple(f.shape))
             cl = (lambda f: f.contiguous()) if engine else (lambda f: ops.to_channels_last(f, dt))
-            ref_in_ms = conditionIntrinsics(ref_in, ref_img.shape, [shp(f) for f in ref_pyr])
-            src_in_ms = torch.stack([conditionIntrinsics(src_in[:, i], ref_img.shape, [shp(f) for f in src_pyrs[i]])
-                                     for i in range(nsrc)]).permute(1, 0, 2, 3, 4)
+            # Camera algebra: when all views share the image size, every per-level block (conditioned intrinsics, projection
+            # stacks, the constants of calDepthHypo) comes from ONE launch (ops.cvp_cams); the tensor-level functions of
+            # modules.py remain for direct callers and for views of different sizes.
+            fast_cams = all(s.shape == ref_img.shape for s in src_imgs)
+            if fast_cams:
+                warp_cams, hypo_cams = ops.cvp_cams(ref_in, src_in, ref_ex, src_ex, [ref_img.shape[2] / shp(f)[2] for f in ref_pyr])
+                fallback = ((depth_max - depth_min) / 128).to(torch.float32).reshape(-1).contiguous()
+                ref_in_ms = src_in_ms = None
+            else:
+                ref_in_ms = conditionIntrinsics(ref_in, ref_img.shape, [shp(f) for f in ref_pyr])
+                src_in_ms = torch.stack([conditionIntrinsics(src_in[:, i], ref_img.shape, [shp(f) for f in src_pyrs[i]])
+                                         for i in range(nsrc)]).permute(1, 0, 2, 3, 4)
 
             # coarsest level: fronto-parallel sweep, 96 planes in eval mode (net.py:126-127)
-            hypos = calSweepingDepthHypo(ref_in_ms[:, -1], src_in_ms[:, 0, -1], ref_ex, src_ex, depth_min, depth_max,
-                                         nhypothesis_init=96).to(torch.float32).contiguous()
-            cams = _cams(ref_in_ms[:, -1], [src_in_ms[:, i, -1] for i in range(nsrc)], ref_ex, [src_ex[:, i] for i in range(nsrc)])
+            hypos = calSweepingDepthHypo(None if fast_cams else ref_in_ms[:, -1], None if fast_cams else src_in_ms[:, 0, -1], ref_ex, src_ex,
+                                         depth_min, depth_max, nhypothesis_init=96).to(torch.float32).contiguous()
+            cams = warp_cams[-1] if fast_cams else _cams(ref_in_ms[:, -1], [src_in_ms[:, i, -1] for i in range(nsrc)], ref_ex,
+                                                         [src_ex[:, i] for i in range(nsrc)])
             cost = ops.warp_cost(cl(ref_pyr[-1]), [cl(p[-1]) for p in src_pyrs],
                                  cams, hypos, geom=L.GEOM_PROJ, cost=L.COST_VARIANCE_CVP, out_dtype=dt)
             lt = {} if taps is not None else None
@@ -221,10 +231,15 @@ class network(nn.Module):
 
             for id_level, level in enumerate(range(nscale - 2, -1, -1)):
                 depth_up = F.interpolate(depth[None, :], size=None, scale_factor=2, mode='bicubic', align_corners=None).squeeze(0)
-                hyp = calDepthHypo(depth_up, ref_in_ms[:, level], src_in_ms[:, :, level], ref_ex, src_ex, depth_min,
-                                   depth_max, level).contiguous()
-                cost = proj_cost(nsrc, ref_pyr[level], src_pyrs, level, ref_in_ms[:, level], src_in_ms[:, :, level],
-                                 ref_ex, src_ex, hyp, storage_dtype=dt, channels_last=engine)
+                if fast_cams:
+                    hyp = ops.cvp_depth_hypos(depth_up.to(torch.float32).contiguous(), hypo_cams[level], fallback)
+                    cost = ops.warp_cost(cl(ref_pyr[level]), [cl(p[level]) for p in src_pyrs], warp_cams[level], hyp,
+                                         geom=L.GEOM_PROJ, cost=L.COST_VARIANCE_CVP, out_dtype=dt)
+                else:
+                    hyp = calDepthHypo(depth_up, ref_in_ms[:, level], src_in_ms[:, :, level], ref_ex, src_ex, depth_min,
+                                       depth_max, level).contiguous()
+                    cost = proj_cost(nsrc, ref_pyr[level], src_pyrs, level, ref_in_ms[:, level], src_in_ms[:, :, level],
+                                     ref_ex, src_ex, hyp, storage_dtype=dt, channels_last=engine)
                 lt = {} if taps is not None else None
                 logits = self.cost_reg_refine(cost, lt)
                 is_last = level == 0

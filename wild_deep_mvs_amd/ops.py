@@ -738,6 +738,28 @@ def cvp_depth_hypos(depth: torch.Tensor, cams: torch.Tensor, fallback: torch.Ten
     return (hypos, steps) if want_steps else hypos
 
 
+def cvp_cams(ref_in: torch.Tensor, src_in: torch.Tensor, ref_ex: torch.Tensor, src_ex: torch.Tensor, level_scales: Sequence[float],
+             *, want_hypo: bool = True):
+    """All camera blocks of a CVP-MVSNet forward in one launch (pscv_cvp_cams): ref_in [B,3,3], src_in [B,N,3,3], ref_ex [B,4,4],
+    src_ex [B,N,4,4]; ``level_scales[l]`` = image_height / level_height.  Returns (warp cams fp32 [L,N,B,18] -- ``warp[l]`` is the
+    ``cams`` of ``warp_cost`` at level l --, hypothesis cams fp64 [L,B,39] for ``cvp_depth_hypos`` or None)."""
+    f32 = lambda t: t.detach().to(torch.float32).contiguous()
+    ref_in, src_in, ref_ex, src_ex = f32(ref_in), f32(src_in), f32(ref_ex), f32(src_ex)
+    _dev(ref_in, src_in, ref_ex, src_ex)
+    B, N = src_in.shape[:2]
+    if tuple(ref_in.shape) != (B, 3, 3) or tuple(src_in.shape) != (B, N, 3, 3) or tuple(ref_ex.shape) != (B, 4, 4) \
+            or tuple(src_ex.shape) != (B, N, 4, 4):
+        raise ValueError("pscv.cvp_cams: ref_in [B,3,3], src_in [B,N,3,3], ref_ex [B,4,4], src_ex [B,N,4,4] expected")
+    nl = len(level_scales)
+    sc = (C.c_float * nl)(*[float(v) for v in level_scales])
+    warp = torch.empty((nl, N, B, L.CAM_FLOATS), dtype=torch.float32, device=ref_in.device)
+    hypo = torch.empty((nl, B, 39), dtype=torch.float64, device=ref_in.device) if want_hypo else None
+    rc = _launch("cvp_cams", lambda: L.lib().pscv_cvp_cams(_p(ref_in), _p(src_in), _p(ref_ex), _p(src_ex), sc, B, N, nl, _p(warp),
+                                                         _p(hypo), _stream()))
+    L.check(rc, "pscv_cvp_cams")
+    return warp, hypo
+
+
 # --------------------------------------------------------------------------------------------
 # training path (SURVEY 8f-1): batch-statistics BatchNorm pieces, weight gradients, backward of the sweep
 # --------------------------------------------------------------------------------------------
