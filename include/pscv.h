@@ -73,11 +73,13 @@ extern "C" {
 const char* pscv_last_error(void);
 int pscv_abi_version(void);
 
-/* Tuning knobs for measurement runs (not part of the reference's surface). Keys:
+/* Tuning knobs for measurement runs (not part of the reference's surface).  Every knob is THREAD-LOCAL: a value set by one host
+ * thread steers only the launches that thread issues afterwards (one stream / one DataParallel replica per thread), other threads
+ * keep the defaults, and there is no shared mutable state between launching threads.  Keys:
  *   "warp_q2"   1 (default): 32-channel 16-bit sweeps run on the quad-mapped kernel (one texel per lane quad, two depth
  *               planes per quad); 0: always the generic kernel.  "warp_lpv" != 0 also selects the generic kernel.
  *   "warp_lpv"  lanes sharing one voxel in the generic pscv_warp_cost kernel (1, 2 or 4 for C=32; 0 = default)
- *   "warp_ppd"  depth planes per workgroup in pscv_warp_cost (0 = default: 8 direct kernels, 24 LDS-staged kernel)
+ *   "warp_ppd"  depth planes per workgroup in pscv_warp_cost (0 = default: 8 direct kernels, 32 LDS-staged kernel)
  *   "warp_tiled" 1 (default; -1 restores it): pscv_warp_cost stages the source patches of a reference tile in LDS as fp32
  *               where it applies (C = 32, 16-bit features, per-batch planes, PROJ geometry, 1-4 source views, variance /
  *               softmin) -- same bits as the direct-gather kernels; 0: always the direct-gather kernels.  "warp_lpv" != 0
@@ -392,6 +394,17 @@ int pscv_warp_cost_bwd(const void* ref, const void* const* srcs, int n_src, cons
  */
 int pscv_cvp_depth_hypos(const float* depth, const double* cams, const float* fallback, unsigned long long* keys,
                          double* steps, float* hypos, int B, int H, int W, void* stream);
+
+/*
+ * Function-level homography warp: one 3x3 matrix per batch item or per reference pixel.  Replaces homography_warping +
+ * interpolate of models/VisMVSNet/homography.py:84-120 for direct callers (inside the model the homographies are built in the
+ * fused sweep and never materialised).  Pixel centres at +0.5, z <= 0 -> zero sample, divisor clamped at 1e-9,
+ * normalise -> clamp(+-1.1) -> align_corners=True bilinear, zero padding.
+ *   image device fp32 [m,hs,ws,c] (channels last);  H device fp32 [m,9] (per_pixel = 0) or [m,h,w,9] (per_pixel = 1), row-major
+ *   out   device fp32 [m,h,w,c]
+ */
+int pscv_homography_warp(const float* image, const float* H, int per_pixel, float* out, int m, int c, int h, int w, int hs, int ws,
+                         void* stream);
 
 /*
  * Every camera block of a CVP-MVSNet forward pass in one launch.  Replaces conditionIntrinsics, the per-level projection

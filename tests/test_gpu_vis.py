@@ -173,3 +173,33 @@ def test_graphed_forward_equals_eager(env):
         sc = {k: v.cuda() for k, v in synthetic.make_scene(1, 3, 64, 96, seed=seed).items()}
         a = (sc["imgs"], sc["K"], sc["R"], sc["t"], sc["depth_min"], sc["depth_max"])
         check_close(f"mvsnet graphed depth seed {seed}", gm(*a)["depth"].cpu(), m(*a)["depth"].cpu(), max_abs=1e-5)
+
+
+def test_function_level_homography_warping_with_per_pixel_matrices(env):
+    """models.VisMVSNet.homography.homography_warping with H [m,h,w,3,3] (homography.py:107-120: the form the reference's later
+    stages use with per-pixel depth planes) against the oracle: per-pixel homographies from get_homographies with a depth map, a
+    different source size, and some matrices flipped behind the camera (z <= 0 -> zero sample)."""
+    L, ops, synthetic, Frontend, OV = env
+    from wild_deep_mvs_amd.models.VisMVSNet.homography import homography_warping
+    n, V, h, w, hs, ws, c = 2, 2, 20, 28, 24, 36, 8
+    scene = synthetic.make_scene(n, V, h * 4, w * 4, seed=21)
+    row = torch.tensor([0., 0., 0., 1.])
+
+    def cam(v):
+        ext = torch.cat((torch.cat((scene["R"][:, v], scene["t"][:, v]), 2), row.view(1, 1, 4).expand(n, 1, 4)), 1)
+        intr = torch.zeros(n, 4, 4)
+        intr[:, :3, :3] = scene["K"][:, v]
+        intr[:, :2, :3] /= 4
+        return torch.stack((ext, intr), 1)
+    gen = torch.Generator().manual_seed(5)
+    depth = 2.5 + 3.0 * torch.rand(n, 1, h, w, generator=gen)
+    Hs = OV.get_homographies(cam(0), cam(1), 1, depth, torch.zeros(n, 1, 1, 1))[:, 0]          # [n,h,w,3,3]
+    assert tuple(Hs.shape) == (n, h, w, 3, 3)
+    Hs[:, :4, :6] *= -1.0                                                                       # behind the source camera
+    src = torch.randn(n, c, hs, ws, generator=gen)
+    want = OV.homography_warping(src, Hs, (h, w))
+    got = homography_warping(src.cuda(), Hs.cuda(), (h, w))
+    assert float(want[:, :, :4, :6].abs().max()) == 0.0
+    check_close("vis homography_warping per-pixel H", got.cpu(), want, max_abs=3e-4)
+    with pytest.raises(ValueError):
+        homography_warping(src.cuda(), Hs.cuda(), (h + 1, w))

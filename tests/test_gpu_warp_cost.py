@@ -268,3 +268,38 @@ def test_staged_kernel_fp16_stores_saturate(env):
     assert torch.isfinite(outs[0]).all() and float(outs[0].max()) == 65504.0
     assert (outs[0] == 65504.0).float().mean() > 1e-3            # the case really overflows
     assert torch.equal(outs[0], outs[1])
+
+
+def test_tuning_knobs_are_thread_local(env):
+    """pscv_set_tuning steers only the launches of the calling host thread (include/pscv.h): with an unsupported lanes-per-voxel
+    value set in this thread its own launch fails loudly, while the same call from another thread (one stream / DataParallel
+    replica per thread) runs with the defaults and gives the default result."""
+    import threading
+    L, ops, O = env
+    g = load_golden("mvsnet_tiny.npz")
+    feats, proj, dv = t(g["features"]), t(g["proj"]), t(g["depth_values"])[:, 0].contiguous()
+    V = feats.shape[0]
+    cams = ops.proj_cams([proj[:, i].cuda() for i in range(1, V)], proj[:, 0].cuda())
+    fcl = [_cl(feats[i], torch.float16) for i in range(V)]
+    run = lambda: ops.warp_cost(fcl[0], fcl[1:], cams, dv.cuda(), cost=L.COST_VARIANCE, out_dtype=torch.float16)
+    want = run()
+    torch.cuda.synchronize()
+    L.set_tuning("warp_lpv", 3)
+    try:
+        with pytest.raises(L.PscvError):
+            run()
+        res = {}
+
+        def other():
+            try:
+                res["out"] = run()
+                torch.cuda.synchronize()
+            except Exception as e:     # noqa: BLE001
+                res["err"] = e
+        th = threading.Thread(target=other)
+        th.start(); th.join()
+        assert "err" not in res, res.get("err")
+        assert torch.equal(res["out"], want)
+    finally:
+        L.set_tuning("warp_lpv", 0)
+    assert torch.equal(run(), want)

@@ -39,7 +39,7 @@ template <> struct Mfma<f16_t> {
 };
 
 PSCV_PROF_BUFFER(conv)
-int g_conv_small_tiles = 1;   // pscv_set_tuning("conv_small_tiles", 0) forces the large-tile variant
+thread_local int g_conv_small_tiles = 1;   // pscv_set_tuning("conv_small_tiles", 0) forces the large-tile variant
 
 struct ConvArgs {
     const uint16_t* in;

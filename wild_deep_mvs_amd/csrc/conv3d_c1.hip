@@ -250,7 +250,7 @@ static int c1_launch(const C1Args& a, long nblk, hipStream_t st) {
 
 }  // namespace pscv
 
-int g_c1_nb = 0;
+thread_local int g_c1_nb = 0;
 PSCV_PROF_EXPORT(c1)
 
 int pscv_conv3d_c1_launch(const void* in, int dtype, int in_cstride, int in_coff, const uint16_t* packed,

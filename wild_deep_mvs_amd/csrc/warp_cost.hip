@@ -240,20 +240,20 @@ __global__ __launch_bounds__(256, 4) void warp_cost_kernel(const WarpArgs a) {
 }
 
 // ---- host side ---------------------------------------------------------------------------------
-static int g_warp_lpv_override = 0;  // 0 = default heuristic; set through pscv_set_tuning("warp_lpv", n)
-static int g_warp_ppd_override = 0;
-static int g_warp_tiled = 1;     // 1 (default): use the LDS-staged kernel (warp_cost_tiled.hip) where it applies: fp32 patches,
+static thread_local int g_warp_lpv_override = 0;  // 0 = default heuristic; set through pscv_set_tuning("warp_lpv", n)
+static thread_local int g_warp_ppd_override = 0;
+static thread_local int g_warp_tiled = 1;     // 1 (default): use the LDS-staged kernel (warp_cost_tiled.hip) where it applies: fp32 patches,
                                  // full-rate fp32 blend; 129 us vs 166 us for the quad kernel inside the headline step, same bits
-extern int g_conv_small_tiles;   // conv3d.hip
-extern int g_sweep_th16;         // conv3d_sweep.hip
-extern int g_sweep_dc;
-extern int g_sweepc_slots;
-extern int g_sweepc_pd;
+extern thread_local int g_conv_small_tiles;   // conv3d.hip
+extern thread_local int g_sweep_th16;         // conv3d_sweep.hip
+extern thread_local int g_sweep_dc;
+extern thread_local int g_sweepc_slots;
+extern thread_local int g_sweepc_pd;
 }
-extern int g_c1_nb;
+extern thread_local int g_c1_nb;
 namespace pscv {
-extern int g_warp_bwd_direct;    // warp_bwd.hip
-static int g_warp_q2 = 1;        // 1: 32-channel 16-bit sweeps use the quad-mapped kernel (warp_cost_q2.hip)
+extern thread_local int g_warp_bwd_direct;    // warp_bwd.hip
+static thread_local int g_warp_q2 = 1;        // 1: 32-channel 16-bit sweeps use the quad-mapped kernel (warp_cost_q2.hip)
 int warp_cost_q2_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, int out_dtype, int ppd_override, hipStream_t st);
 int warp_cost_tiled_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, int out_dtype, int ppd_override, hipStream_t st);
 

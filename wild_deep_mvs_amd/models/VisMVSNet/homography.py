@@ -33,14 +33,20 @@ def get_homographies(left_cam, right_cam, depth_num, depth_start, depth_interval
 
 
 def homography_warping(input, H, ref_shape=None):
-    """Warp ``input`` [m,c,hs,ws] with one homography per batch item, H [m,3,3] or [m,1,1,3,3] (the shapes the
-    reference's model passes, homography.py:107-120) -> [m,c,h,w] fp32.  Half-pixel centres, ``z <= 0`` -> zero
-    sample, index ``u (W-1)/W``.  Per-pixel homographies [m,h,w,3,3] are only reachable through the fused
-    model path (``SingleStage``), which takes per-pixel depth planes instead."""
+    """Warp ``input`` [m,c,hs,ws] with H [m,3,3] / [m,1,1,3,3] (one homography per batch item) or [m,h,w,3,3] (one per
+    reference pixel) -- the shapes of homography.py:107-120 -- -> [m,c,h,w] fp32.  Half-pixel centres, ``z <= 0`` -> zero sample,
+    index ``u (W-1)/W``.  Inside the model per-pixel homographies never exist (``SingleStage`` hands per-pixel depth planes to the
+    fused sweep); this function-level form runs the small ``pscv_homography_warp`` kernel and is forward-only for per-pixel H."""
+    if H.dim() == 5 and not (H.shape[1] == 1 and H.shape[2] == 1):
+        hw = tuple(input.shape[2:]) if ref_shape is None else tuple(int(s) for s in ref_shape)
+        if tuple(H.shape[1:3]) != hw:
+            raise ValueError(f"pscv homography_warping: per-pixel H {tuple(H.shape)} does not match the reference shape {hw}")
+        if input.requires_grad and torch.is_grad_enabled():
+            raise NotImplementedError("pscv homography_warping: the per-pixel form is forward-only (training goes through the "
+                                      "fused sweep with per-pixel depth planes)")
+        out = ops.homography_warp(ops.to_channels_last(input.detach(), torch.float32), H.detach().to(torch.float32).contiguous(), hw)
+        return out.permute(0, 3, 1, 2)
     if H.dim() == 5:
-        if H.shape[1] != 1 or H.shape[2] != 1:
-            raise NotImplementedError("pscv homography_warping: per-pixel homographies are handled inside the fused "
-                                      "warp kernel (per-pixel depth planes); pass [m,3,3] here")
         H = H.view(-1, 3, 3)
     m = input.shape[0]
     hw = tuple(input.shape[2:]) if ref_shape is None else tuple(int(s) for s in ref_shape)

@@ -738,6 +738,24 @@ def cvp_depth_hypos(depth: torch.Tensor, cams: torch.Tensor, fallback: torch.Ten
     return (hypos, steps) if want_steps else hypos
 
 
+def homography_warp(image_cl: torch.Tensor, H: torch.Tensor, ref_hw: Sequence[int]) -> torch.Tensor:
+    """image fp32 channels-last [m,hs,ws,c]; H fp32 [m,3,3] (one per batch item) or [m,h,w,3,3] (one per reference pixel)
+    -> warped fp32 [m,h,w,c] (pscv_homography_warp)."""
+    _dev(image_cl, H)
+    if image_cl.dtype != torch.float32 or image_cl.dim() != 4 or H.dtype != torch.float32:
+        raise TypeError("pscv.homography_warp: fp32 channels-last image [m,hs,ws,c] and fp32 homographies expected")
+    m, hs, ws, c = image_cl.shape
+    h, w = int(ref_hw[0]), int(ref_hw[1])
+    per_pixel = H.dim() == 5
+    if tuple(H.shape) not in ((m, 3, 3), (m, h, w, 3, 3)):
+        raise ValueError(f"pscv.homography_warp: H must be [{m},3,3] or [{m},{h},{w},3,3], got {tuple(H.shape)}")
+    out = torch.empty((m, h, w, c), dtype=torch.float32, device=image_cl.device)
+    rc = _launch("homography_warp", lambda: L.lib().pscv_homography_warp(_p(image_cl), _p(H), int(per_pixel), _p(out), m, c, h, w, hs,
+                                                                       ws, _stream()))
+    L.check(rc, "pscv_homography_warp")
+    return out
+
+
 def cvp_cams(ref_in: torch.Tensor, src_in: torch.Tensor, ref_ex: torch.Tensor, src_ex: torch.Tensor, level_scales: Sequence[float],
              *, want_hypo: bool = True):
     """All camera blocks of a CVP-MVSNet forward in one launch (pscv_cvp_cams): ref_in [B,3,3], src_in [B,N,3,3], ref_ex [B,4,4],
