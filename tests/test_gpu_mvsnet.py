@@ -160,3 +160,28 @@ def test_training_mode_runs_on_the_engine(env):
     assert out["depth"].requires_grad
     with pytest.raises(RuntimeError):
         net.cost_regularization(torch.zeros(1, 16, 16, 24, 32, dtype=torch.float16, device="cuda"))
+
+
+def test_invalidate_after_a_write_through_dot_data(env):
+    """The packed-weight caches key on (address, tensor._version).  A write through ``.data`` does not bump the version, so the
+    engine keeps the packed copy until ``wild_deep_mvs_amd.invalidate()`` is called (documented in ops.invalidate_weight_caches);
+    in-place ops on the Parameter itself are picked up without it."""
+    import wild_deep_mvs_amd
+    L, ops, synthetic, MVSNet, O = env
+    net, sd = _model(env, "variance", 0)
+    net.num_depth = 16
+    scene = synthetic.make_scene(1, 3, 64, 96, seed=2)
+    dev = {k: v.cuda() for k, v in scene.items()}
+    run = lambda: net(dev["imgs"], dev["K"], dev["R"], dev["t"], dev["depth_min"], dev["depth_max"])["depth"].clone()
+    d0 = run()
+    w = net.cost_regularization.prob.weight
+    v0 = w._version
+    w.data.mul_(-1.0)                                   # flips the sign of every logit: the soft-argmin must change
+    assert w._version == v0                             # ... but the version counter did not move
+    assert torch.equal(run(), d0)                       # stale packed weights: the documented hazard
+    wild_deep_mvs_amd.invalidate()
+    d1 = run()
+    assert float((d1 - d0).abs().mean()) > 1e-3 * float(d0.abs().mean())
+    with torch.no_grad():
+        w.mul_(-1.0)                                    # in-place op on the Parameter: version bump, no invalidate needed
+    assert torch.equal(run(), d0)

@@ -608,6 +608,53 @@ def test_vis_unet_fn_stepwise_against_autograd(dtype):
     check_close("d x returned by autograd", _cf(x_cl.grad), R["b_dx"], max_abs=0.0)
 
 
+def test_frozen_batchnorm_submodule_in_a_training_step():
+    """A BatchNorm submodule put in eval() inside a train()-mode network (frozen-BN fine-tuning) is honoured per module like
+    nn.BatchNorm: it normalises with its running statistics, they and num_batches_tracked stay untouched, and its backward is
+    the eval-mode one (dy = gamma * invstd * dz; d gamma / d beta against the running statistics) -- while its train()-mode
+    sibling in the same block keeps using and updating batch statistics."""
+    from wild_deep_mvs_amd import ops, synthetic, training as T
+    from wild_deep_mvs_amd.models.VisMVSNet.frontend import Frontend
+    dtype = torch.float16
+    net = Frontend()
+    net.load_state_dict(synthetic.sharpened_state_dict("vis", synthetic.template_of(net), seed=2))
+    holder = net.cuda().train().model.stage1.reg
+    b0, b1, dec = T.VisUNetFn.parts(holder)
+    gen = torch.Generator().manual_seed(9)
+    with torch.no_grad():
+        b0.bn1.running_mean.copy_(0.1 * torch.randn(8, generator=gen))
+        b0.bn1.running_var.copy_(0.5 + torch.rand(8, generator=gen))
+    b0.bn1.eval()
+    rm0, rv0, nb0 = b0.bn1.running_mean.clone(), b0.bn1.running_var.clone(), int(b0.bn1.num_batches_tracked)
+    nb2 = int(b0.bn2.num_batches_tracked)
+    n, d, h, w = 2, 8, 12, 20
+    x = torch.randn(n, 8, d, h, w, generator=gen).to(dtype)
+    gout = torch.randn(n, 8, d, h, w, generator=gen).to(dtype)
+    x_cl = ops.to_channels_last(x.cuda(), dtype).requires_grad_(True)
+    params = T.VisUNetFn.params(holder)
+    T.TRACE = {}
+    try:
+        out = T.VisUNetFn.apply(holder, dtype, x_cl, *params)
+        out.backward(ops.to_channels_last(gout.cuda(), dtype))
+        torch.cuda.synchronize()
+        f, b = T.TRACE["vis_unet"][0], T.TRACE["vis_unet_bwd"][0]
+    finally:
+        T.TRACE = None
+    assert torch.equal(b0.bn1.running_mean, rm0) and torch.equal(b0.bn1.running_var, rv0) and int(b0.bn1.num_batches_tracked) == nb0
+    assert int(b0.bn2.num_batches_tracked) == nb2 + 1
+    q = lambda v: v.to(dtype).float()
+    P = lambda p_: p_.detach().cpu().float()
+    y1, t_, dt = _cf(f["y1"]), _cf(f["t"]), _cf(b["dt"])
+    y = y1.clone().requires_grad_(True)
+    gamma, beta = P(b0.bn1.weight).requires_grad_(True), P(b0.bn1.bias).requires_grad_(True)
+    z = F.relu(F.batch_norm(y, rm0.cpu(), rv0.cpu(), gamma, beta, training=False, eps=b0.bn1.eps))
+    check_close("frozen BN forward", t_, q(z.detach()), rel_l2=2e-4)
+    z.backward(dt)
+    check_close("frozen BN dy", _cf(b["dy1"]), q(y.grad), rel_l2=3e-4)
+    check_close("frozen BN d gamma", b0.bn1.weight.grad.cpu().float(), gamma.grad, rel_l2=2e-4)
+    check_close("frozen BN d beta", b0.bn1.bias.grad.cpu().float(), beta.grad, rel_l2=2e-4)
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_vis_train_step(dtype):
     """One training step of the Vis-MVSNet mirror in train() mode (three detached cascade stages; per source view: fused warp

@@ -173,6 +173,19 @@ def test_graphed_forward_equals_eager(env):
         sc = {k: v.cuda() for k, v in synthetic.make_scene(1, 3, 64, 96, seed=seed).items()}
         a = (sc["imgs"], sc["K"], sc["R"], sc["t"], sc["depth_min"], sc["depth_max"])
         check_close(f"mvsnet graphed depth seed {seed}", gm(*a)["depth"].cpu(), m(*a)["depth"].cpu(), max_abs=1e-5)
+    # tensors passed by KEYWORD live in static buffers too: a replay must see the new call's cameras, not the captured ones
+    gk = GraphedModel(m)
+    for seed in (5, 6):
+        sc = {k: v.cuda() for k, v in synthetic.make_scene(1, 3, 64, 96, seed=seed).items()}
+        kw = dict(K=sc["K"], R=sc["R"], t=sc["t"], depth_min=sc["depth_min"], depth_max=sc["depth_max"])
+        check_close(f"mvsnet graphed depth, keyword tensors, seed {seed}", gk(sc["imgs"], **kw)["depth"].cpu(),
+                    m(sc["imgs"], **kw)["depth"].cpu(), max_abs=1e-5)
+    assert len(gk._graphs) == 1
+    # a weight update re-captures instead of replaying the old weights
+    with torch.no_grad():
+        m.cost_regularization.prob.weight.mul_(-1.0)
+    check_close("mvsnet graphed depth after a weight update", gk(sc["imgs"], **kw)["depth"].cpu(), m(sc["imgs"], **kw)["depth"].cpu(),
+                max_abs=1e-5)
 
 
 def test_function_level_homography_warping_with_per_pixel_matrices(env):

@@ -9,7 +9,14 @@
 import importlib
 import sys
 
-__all__ = ["install_as_models"]
+__all__ = ["install_as_models", "invalidate"]
+
+
+def invalidate() -> None:
+    """Drop every packed-weight / folded-BatchNorm cache (see ``ops.invalidate_weight_caches``): required after a write through
+    ``parameter.data`` (EMA copies, clamps, old-style optimisers), which does not bump the tensor version the caches key on."""
+    from . import ops
+    ops.invalidate_weight_caches()
 
 
 def install_as_models() -> None:

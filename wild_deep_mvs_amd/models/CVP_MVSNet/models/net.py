@@ -39,7 +39,7 @@ class FeaturePyramid(nn.Module):
 
     # -- HIP path: nine MFMA conv2d launches per level (bias + LeakyReLU(0.1) fused), channels-last 16-bit maps --
     def engine_layers(self, dtype: torch.dtype):
-        key = (dtype,) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        key = (ops.weights_epoch(), dtype) + tuple((p.data_ptr(), p._version) for p in self.parameters())
         if getattr(self, "_layers", None) is None or self._layers_key != key:
             self._layers = [ops.Conv2dLayer.build(getattr(self, n)[0].weight, stride=1, conv_bias=getattr(self, n)[0].bias,
                                                   leaky=0.1, dtype=dtype) for n in self._names]
@@ -84,7 +84,7 @@ class CostRegNet(nn.Module):
         self._lay, self._key = None, None
 
     def engine_layers(self, dtype) -> Dict[str, ops.Conv3dLayer]:
-        key = (dtype,) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        key = (ops.weights_epoch(), dtype) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
         if self._lay is None or key != self._key:
             dev = self.prob0.weight.device
             lay = {n: getattr(self, n).engine_layer(dev, dtype)

@@ -55,7 +55,7 @@ class FeatureNet(nn.Module):
 
     def engine_layers(self, dtype: torch.dtype):
         """Packed weights + folded BatchNorm of the eight layers, rebuilt when a parameter / buffer changes."""
-        key = (dtype,) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        key = (ops.weights_epoch(), dtype) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
         if self._layers is None or self._layers_key != key:
             dev = self.feature.weight.device
             layers = []
@@ -108,7 +108,7 @@ class CostRegNet(nn.Module):
 
     # -- weight residency ------------------------------------------------------------------
     def _param_key(self):
-        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        return (ops.weights_epoch(),) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
 
     def engine_layers(self, dtype: torch.dtype) -> Dict[str, ops.Conv3dLayer]:
         """Packed 16-bit weights + folded eval-mode BN, rebuilt whenever a parameter changed
@@ -244,7 +244,7 @@ class MVSNet(nn.Module):
                                  cost=L.COST_VARIANCE, out_dtype=ref_feature.dtype)
         # the kernel takes the temperature by value: read it back once per parameter version (no host sync in steady state,
         # and none inside a hipGraph capture of the forward)
-        key = (self.temp.data_ptr(), self.temp._version)
+        key = (ops.weights_epoch(), self.temp.data_ptr(), self.temp._version)
         if getattr(self, "_temp_key", None) != key:
             self._temp_val, self._temp_key = float(self.temp.detach().float().item()), key
         return ops.warp_cost(ref_feature, src_features, cams, depth_values, geom=L.GEOM_PROJ, cost=L.COST_SOFTMIN,

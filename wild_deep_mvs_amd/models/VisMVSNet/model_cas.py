@@ -42,7 +42,7 @@ class FeatExt(nn.Module):
     def engine_layers(self, dtype: torch.dtype):
         """Packed weights + folded eval-mode BatchNorm of all 37 layers (the two transposed convs as four parity
         sub-convolutions each), rebuilt when a parameter / buffer changes."""
-        key = (dtype,) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        key = (ops.weights_epoch(), dtype) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
         if getattr(self, "_lay", None) is not None and self._lay_key == key:
             return self._lay
         mk = ops.Conv2dLayer.build
@@ -109,7 +109,7 @@ class _RegUNet(nn.Module):
         self._lay, self._key = None, None
 
     def _layers(self, dtype) -> Dict[str, ops.Conv3dLayer]:
-        key = (dtype,) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        key = (ops.weights_epoch(), dtype) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
         if self._lay is None or key != self._key:
             enc = list(self.unet.enc_blocks.values())
             b0, b1 = enc[0][0], enc[1][0]
@@ -174,7 +174,7 @@ class _Head(nn.Module):
     def head(self, x: torch.Tensor) -> torch.Tensor:
         """[n,d,h,w,8] -> fp32 scores [n,d,h,w]."""
         w = self.final_conv.weight
-        key = (x.dtype, w.data_ptr(), w._version)
+        key = (ops.weights_epoch(), x.dtype, w.data_ptr(), w._version)
         if self._hl is None or key != self._hk:
             self._hl, self._hk = ops.Conv3dLayer.build(w, kind=L.CONV_S1, device=w.device, dtype=x.dtype), key
         return ops.conv3d(x, self._hl, out_dtype=torch.float32).squeeze(-1)

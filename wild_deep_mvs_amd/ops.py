@@ -499,7 +499,7 @@ class Conv3dLayer:
         # it), guarded by a weak reference so that a recycled id() can never alias another tensor.
         ckey = None
         if PACK_CACHE and isinstance(weight, torch.nn.Parameter) and weight.is_cuda and bn is None and conv_bias is None and floor is None:
-            ckey = (id(weight), kind, bool(transposed), dtype, str(device), bool(relu), bool(relu_post))
+            ckey = (_weights_epoch, id(weight), kind, bool(transposed), dtype, str(device), bool(relu), bool(relu_post))
             ent = _layer_cache.get(ckey)
             if ent is not None and ent[0]() is weight and ent[1] == weight._version:
                 return ent[2]
@@ -529,6 +529,25 @@ class Conv3dLayer:
 
 
 USE_SWEEP_KERNEL = True   # tests flip this to compare the two stride-1 kernels
+_weights_epoch = 0
+
+
+def weights_epoch() -> int:
+    """Generation counter folded into every packed-weight / folded-BatchNorm cache key of the package."""
+    return _weights_epoch
+
+
+def invalidate_weight_caches() -> None:
+    """Drop every packed-weight, folded-BatchNorm and soft-min temperature cache of the process.
+
+    The caches are keyed on (storage address, ``tensor._version``): in-place tensor ops, optimiser steps and
+    ``load_state_dict`` bump the version and are picked up automatically.  Writes THROUGH ``.data`` (``p.data.copy_(ema)``,
+    ``p.data.clamp_()``, old-style optimisers) do not bump it -- call this function (also exported as
+    ``wild_deep_mvs_amd.invalidate()``) after such a write, or the engine keeps running the previously packed weights."""
+    global _weights_epoch
+    _weights_epoch += 1
+    _layer_cache.clear()
+
 PACK_CACHE = True         # memoise raw-weight layers of live Parameters per parameter version (Conv3dLayer.build)
 _layer_cache: dict = {}
 

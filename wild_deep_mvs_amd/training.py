@@ -150,8 +150,33 @@ def _dgrad_layer(b: Block, dtype, dev) -> ops.Conv3dLayer:
 def _bn_affine(b: Block, sums: torch.Tensor, nvox: int):
     """Batch statistics -> (scale, bias, mean, invstd); updates the running statistics like nn.BatchNorm3d.train().  One launch
     (pscv_bn_finalize): the dozen C-element tensor ops this used to be were a tenth of a Vis-MVSNet training step's wall time."""
+    if not b.bn.training:
+        return _bn_frozen_affine(b.bn)
     out = ops.bn_finalize(sums, nvox, b.bn)
     return out[0], out[1], out[2], out[3]
+
+
+def _bn_frozen_affine(bn):
+    """A BatchNorm submodule in eval() inside a training step (frozen-BN fine-tuning; nn.BatchNorm honours the flag per module):
+    normalise with the running statistics, leave them and ``num_batches_tracked`` untouched.  The backward is then the eval-mode
+    one, ``dy = gamma * invstd * dz`` (see ``_bn_coeffs``)."""
+    if bn.running_mean is None or bn.running_var is None:
+        raise NotImplementedError("pscv BatchNorm training: a BatchNorm in eval() without running statistics normalises with batch "
+                                  "statistics in PyTorch; put it in train() instead")
+    mean = bn.running_mean.detach().float()
+    invstd = torch.rsqrt(bn.running_var.detach().float() + bn.eps)
+    scale = invstd if bn.weight is None else bn.weight.detach().float() * invstd
+    bias = -mean * scale if bn.bias is None else bn.bias.detach().float() - mean * scale
+    return scale.contiguous(), bias.contiguous(), mean.contiguous(), invstd.contiguous()
+
+
+def _bn_coeffs(bn, s, mean, invstd, nvox):
+    """(ca, cb, cc, d gamma, d beta) of ``dy = ca dz + cb y + cc``: the batch-statistics backward, or for a frozen BatchNorm
+    (eval() inside a training step) the eval-mode one, where the statistics are constants: cb = cc = 0."""
+    co = ops.bn_bwd_coeffs(s, mean, invstd, bn.weight, nvox)
+    if not bn.training:
+        co[1:3].zero_()
+    return co
 
 
 # Test hook: when set to a dict, RegressFn records every block's forward and backward tensors in it (the parity tests
@@ -249,7 +274,7 @@ class RegressFn(torch.autograd.Function):
             y, scale, bias, mean, invstd = saved[b.name]
             nvox = y.numel() // y.shape[4]
             s = ops.bn_bwd_reduce(dact, y, scale, bias, relu=b.relu)
-            ca, cb, cc, s2, s1 = ops.bn_bwd_coeffs(s, mean, invstd, b.bn.weight, nvox)     # s2 = sum dz * xhat, s1 = sum dz
+            ca, cb, cc, s2, s1 = _bn_coeffs(b.bn, s, mean, invstd, nvox)     # s2 = sum dz * xhat, s1 = sum dz
             dy = ops.bn_bwd_apply(dact, y, scale, bias, ca, cb, cc, relu=b.relu)
             pgrads[id(b.bn.weight)] = s2.to(b.bn.weight.dtype)
             pgrads[id(b.bn.bias)] = s1.to(b.bn.bias.dtype)
@@ -282,7 +307,7 @@ def _bn_backward(bn: nn.BatchNorm3d, dz_src: torch.Tensor, y: torch.Tensor, save
     """BatchNorm(+ReLU before any skip) backward on the engine: returns (dy, d gamma, d beta)."""
     scale, bias, mean, invstd, nvox = saved
     s = ops.bn_bwd_reduce(dz_src, y, scale, bias, relu=relu)
-    ca, cb, cc, s2, s1 = ops.bn_bwd_coeffs(s, mean, invstd, bn.weight, nvox)
+    ca, cb, cc, s2, s1 = _bn_coeffs(bn, s, mean, invstd, nvox)
     dy = ops.bn_bwd_apply(dz_src, y, scale, bias, ca, cb, cc, relu=relu)
     return dy, s2.to(bn.weight.dtype), s1.to(bn.bias.dtype)
 
@@ -500,7 +525,7 @@ def _cached_layer(net, tag, weight, dtype, make):
     """Packed 2-D layers are built on the host (pscv_pack_conv2d_weights): keep them per (weight version, dtype) on the module so
     that the views of one step -- same weights -- do not repack (and synchronise) once per view."""
     cache = net.__dict__.setdefault("_pscv_train_layers", {})
-    key = (tag, weight.data_ptr(), weight._version, dtype)
+    key = (ops.weights_epoch(), tag, weight.data_ptr(), weight._version, dtype)
     if key not in cache:
         for k in [k for k in cache if k[0] == tag]:
             del cache[k]
