@@ -73,14 +73,16 @@ def main():
             out = torch.empty(1, Dv, hv, wv, 16, dtype=dt, device=dev)
             res = {}
             for use in (True, False):
-                ops.USE_SWEEP_KERNEL = use
+                ops.USE_SWEEP_KERNEL, ops.SWEEP16 = use, True
                 layer = ops.Conv3dLayer.build(wt, kind=L.CONV_S1, device=dev, relu=True, dtype=dt)
-                ops.USE_SWEEP_KERNEL = True
+                ops.USE_SWEEP_KERNEL, ops.SWEEP16 = True, False
                 res[use] = timeit(lambda: ops.conv3d(x, layer, out=out), args.reps)
             gb = Dv * hv * wv * 64 / 1e9
             print(f"conv3d 16->16 @ {Dv}x{hv}x{wv}: sweep {res[True]:8.1f} us ({gb / res[True] * 1e6:6.0f} GB/s)   brick {res[False]:8.1f} us")
             if args.reps > 20:
+                ops.SWEEP16 = True
                 layer = ops.Conv3dLayer.build(wt, kind=L.CONV_S1, device=dev, relu=True, dtype=dt)
+                ops.SWEEP16 = False
                 for pd in (1, 2, 3):
                     L.set_tuning("sweepc_pd", pd)
                     row = []

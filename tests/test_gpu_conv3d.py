@@ -250,12 +250,12 @@ def test_sweep16_kernel_matches_brick_kernel_and_aten(env, shape, transposed, dc
     xcl, scl = ops.to_channels_last(wide.cuda(), dtype), ops.to_channels_last(skip_wide.cuda(), dtype)
     outs = {}
     for use in (True, False):
-        ops.USE_SWEEP_KERNEL = use
+        ops.USE_SWEEP_KERNEL, ops.SWEEP16 = use, True      # (the brick kernel is the default for 16 -> 16; SWEEP16 selects the sweep)
         try:
             layer = ops.Conv3dLayer.build(w, kind=L.CONV_S1, transposed=transposed, device="cuda", bn=(gamma, beta, mean, var), relu=True,
                                           dtype=dtype)
         finally:
-            ops.USE_SWEEP_KERNEL = True
+            ops.USE_SWEEP_KERNEL, ops.SWEEP16 = True, False
         assert layer.kind == (L.CONV_S1P8 if use else L.CONV_S1)
         out = torch.full((2, D, H, W, 24), 7.0, dtype=dtype, device="cuda")
         L.set_tuning("sweep_dc", dc)

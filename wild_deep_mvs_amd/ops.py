@@ -488,8 +488,10 @@ class Conv3dLayer:
         epilogue: scale = gamma / sqrt(var + eps), bias = beta - mean * scale (+ scale * conv_bias)."""
         device = device if device is not None else weight.device
         c_in, c_out = (weight.shape[0], weight.shape[1]) if transposed else (weight.shape[1], weight.shape[0])
-        if kind == L.CONV_S1 and ((c_in in (8, 16, 32) and c_out == 8) or (c_in, c_out) == (16, 16)) and USE_SWEEP_KERNEL:
+        if kind == L.CONV_S1 and ((c_in in (8, 16, 32) and c_out == 8) or (SWEEP16 and (c_in, c_out) == (16, 16))) and USE_SWEEP_KERNEL:
             kind = L.CONV_S1P8     # same result, depth-sweep kernels with plane-pair packed MFMA rows (stride-1 deconvs too)
+        # (16 -> 16 has a sweep variant too (kind S1P8 through the C ABI; ``SWEEP16 = True`` selects it), but since the brick kernel's staging / decode rewrite
+        #  the brick kernel is faster at every measured size: 295 vs 337 us at 8x1024x1280, 16.6 vs 18.7 us at 96x64x80)
         if kind == L.CONV_T2 and transposed and c_in == 16 and c_out == 8 and USE_SWEEP_KERNEL:
             kind = L.CONV_T2P8     # same result, parity-pair packed MFMA rows + contiguous 32-byte stores
         if kind == L.CONV_S1 and not transposed and c_in in (8, 16) and c_out == 1 and USE_SWEEP_KERNEL:
@@ -529,6 +531,7 @@ class Conv3dLayer:
 
 
 USE_SWEEP_KERNEL = True   # tests flip this to compare the two stride-1 kernels
+SWEEP16 = False           # 16 -> 16 layers on the depth-sweep kernel (tests / measurements; the brick kernel is the faster one)
 _weights_epoch = 0
 
 
