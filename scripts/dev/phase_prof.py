@@ -26,6 +26,7 @@ LAYERS = {
     "conv6": (64, 64, 0, 8, False, False, "conv"), "conv7": (64, 32, 2, 8, True, True, "conv"),
     "conv9": (32, 16, 2, 4, True, True, "conv"), "conv11": (16, 8, 2, 2, True, True, "t2p8"),
     "prob": (8, 1, 0, 1, False, False, "c1"),
+    "conv0": (32, 8, 0, 1, False, False, "sweep"),     # slots: prologue | fetch issue | MFMA loop | epilogue | stash (waits for the planes) | barrier
 }
 NAMES = ["loads issued", "loads landed", "LDS write+sync", "MFMA loop", "epilogue", "drain"]
 lib = L.lib()

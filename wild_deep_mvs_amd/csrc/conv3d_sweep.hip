@@ -58,6 +58,7 @@ struct SweepArgs {
     unsigned mg_th, mg_tw, mg_dc;
 };
 
+PSCV_PROF_BUFFER(sweep)
 constexpr int SW_BW = 18;
 constexpr int SW_VB = 64;                  // bytes per voxel (32 ch x 2 B)
 constexpr int SW_NSLOT = 6;
@@ -97,6 +98,7 @@ __global__ __launch_bounds__(32 * SW_TH, 2) void conv3d_sweep8_kernel(const Swee
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
+    PSCV_PROF_BEGIN   // (profile builds: slots = prologue | fetch issue | MFMA loop | epilogue | stash incl. the wait for the planes | barrier)
 
     // ---- A fragments: all weights of the layer, resident for the whole sweep ----
     uint4 wf[4][9];
@@ -168,13 +170,17 @@ __global__ __launch_bounds__(32 * SW_TH, 2) void conv3d_sweep8_kernel(const Swee
         stash(2, ra); stash(3, rb);
     }
     __syncthreads();
+    PSCV_STAMP(0)
 
     int ring = 0;   // slot holding plane d-1
     for (int d = dbeg; d < dend; d += 2) {
-        // issue the next two planes (d+3, d+4) early; they land in LDS after this iteration's MFMAs
+        // issue the next two planes (d+3, d+4) early; they land in LDS after this iteration's MFMAs.  (The per-load predicate
+        // + zero fill also pins the loads here: an unpredicated fast path for interior tiles let the scheduler sink them to
+        // the stash below and cost 40 us.)
         uint4 na[NLD], nb[NLD];
         fetch(d + 3, na);
         fetch(d + 4, nb);
+        PSCV_STAMP(1)
 
         sw_f32x4 acc[R];
 #pragma unroll
@@ -195,6 +201,7 @@ __global__ __launch_bounds__(32 * SW_TH, 2) void conv3d_sweep8_kernel(const Swee
                     }
         }
 
+        PSCV_STAMP(2)
         // epilogue: rows g*4.. of D = channels c0.. of plane d + (g >> 1)
         const int od = d + (g >> 1);
 #pragma unroll
@@ -227,16 +234,20 @@ __global__ __launch_bounds__(32 * SW_TH, 2) void conv3d_sweep8_kernel(const Swee
             }
         }
 
+        PSCV_STAMP(3)
         // planes d+3, d+4 replace d-3, d-2 (last read one iteration ago, fenced by that iteration's barrier)
         int s4 = ring + 4, s5 = ring + 5;
         s4 = s4 >= SW_NSLOT ? s4 - SW_NSLOT : s4;
         s5 = s5 >= SW_NSLOT ? s5 - SW_NSLOT : s5;
         stash(s4, na);
         stash(s5, nb);
+        PSCV_STAMP(4)
         ring += 2;
         ring = ring >= SW_NSLOT ? ring - SW_NSLOT : ring;
         __syncthreads();
+        PSCV_STAMP(5)
     }
+    PSCV_PROF_END(sweep, blockIdx.x)
 }
 
 // ---- narrow-input variant: C_in = 8 or 16, C_out = 8 (the Vis-MVSNet U-Net's full-resolution layers) ---------------------
@@ -531,6 +542,8 @@ int pscv_conv3d_sweepc_launch(const void* in, int dtype, int c_in, int c_out, in
 }
 
 // entry used by pscv_conv3d (conv3d.hip) for kind == PSCV_CONV_S1P8
+PSCV_PROF_EXPORT(sweep)
+
 int pscv_conv3d_sweep8_launch(const void* in, int dtype, int in_cstride, int in_coff, const uint16_t* packed,
                               const float* scale, const float* bias, const float* floor, const void* skip,
                               int skip_cstride, int skip_coff, void* out, int out_cstride, int out_coff, int out_dtype,
