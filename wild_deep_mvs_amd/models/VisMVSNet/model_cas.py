@@ -348,18 +348,26 @@ class SingleStage(nn.Module):
         if not mine:
             raise ValueError("view shard: more ranks than source views")
         costs = self.build_cost_volume(ref_feat, ref_cam, srcs_feat, srcs_cam, depth_num, depth_start, depth_interval, s_scale)
-        interms, uncerts, pair_results = [], [], []
+        interms, uncerts, pair_results, est_depths, entropies = [], [], [], [], []
         for i in range(len(srcs_feat)):
             interm = self.reg(costs[i])
             score = self.reg_pair(interm)                                              # fp32 [n,d,h,w]
             o = ops.softargmin(score, None, want_index=True, want_entropy=True)
-            est_depth = o["index"].unsqueeze(1) * depth_interval + depth_start         # model_cas.py:348
-            heads = self.uncert_net(o["entropy"].unsqueeze(1))
-            pair_results.append([est_depth, heads])
+            est_depths.append(o["index"].unsqueeze(1) * depth_interval + depth_start)  # model_cas.py:348
+            entropies.append(o["entropy"].unsqueeze(1))
             interms.append(interm)
+            if taps is not None and i == 0:
+                taps.update(cost0=costs[0], interm0=interm, score0=score, entropy0=o["entropy"])
+        # the 2-D UncertNet (eval-mode BatchNorm: per-sample) runs ONCE on the entropy maps of all pairs stacked along the batch
+        # axis -- 3 convolutions per stage instead of 3 per source view (72 -> 9 launches of ~23 us at 9 views); same values
+        n_b = entropies[0].shape[0]
+        heads_all = self.uncert_net(torch.cat(entropies, 0))
+        for i in range(len(srcs_feat)):
+            heads = [hd[i * n_b:(i + 1) * n_b] for hd in heads_all]
+            pair_results.append([est_depths[i], heads])
             uncerts.append(heads[0].squeeze(1).to(torch.float32).contiguous())
             if taps is not None and i == 0:
-                taps.update(cost0=costs[0], interm0=interm, score0=score, entropy0=o["entropy"], uncert0=heads[0])
+                taps.update(uncert0=heads[0])
         if world == 1:
             fused = ops.fuse_pairs(interms, uncerts)                                   # model_cas.py:354-357,385-386
         else:
