@@ -143,3 +143,25 @@ def test_cvp_cams_one_launch_equals_tensor_level_camera_algebra(env):
         rel = float((hypo[lv] - hw).norm() / hw.norm())          # fp64 on both sides
         print(f"[parity] cvp_cams hypo level {lv}: rel_l2={rel:.3e}")
         assert rel <= 1e-12, rel
+
+
+def test_cvp_graphed_forward_replays_equal_eager(env):
+    """graph.GraphedModel on the CVP-MVSNet mirror: the capture and FOUR replays return the eager result bit for bit.  The radix
+    select of pscv_cvp_depth_hypos used to clear its histograms with a hipMemsetAsync node, which a replayed hipGraph did not
+    re-execute correctly (first replay right, later ones with the previous counters: refinement depths off by 0.3)."""
+    L, ops, synthetic, Frontend = env
+    from wild_deep_mvs_amd.graph import GraphedModel
+    g = load_golden("cvp_tiny.npz")
+    scene, nscale, seed = cvp_scene(g)
+    net = Frontend()
+    net.load_state_dict(synthetic.sharpened_state_dict("cvp", synthetic.template_of(net), seed=seed), strict=True)
+    net = net.cuda().eval()
+    dev = {k: v.cuda() for k, v in scene.items()}
+    a = (dev["imgs"], dev["K"], dev["R"], dev["t"], dev["depth_min"], dev["depth_max"])
+    want = net(*a, nscale=nscale)
+    gnet = GraphedModel(net)
+    for r in range(5):
+        got = gnet(*a, nscale=nscale)
+        for i in range(nscale):
+            assert torch.equal(got["depth_est_list"][i], want["depth_est_list"][i]), (r, i)
+    assert len(gnet._graphs) == 1

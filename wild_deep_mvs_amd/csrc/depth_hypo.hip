@@ -20,8 +20,14 @@ __device__ __forceinline__ void mat3(const double* m, double x, double y, double
 }
 
 __global__ __launch_bounds__(256) void hypo_keys_kernel(const float* __restrict__ depth, const double* __restrict__ cams,
-                                                        unsigned long long* __restrict__ keys, int H, int W) {
+                                                        unsigned long long* __restrict__ keys, unsigned long long* __restrict__ ws,
+                                                        int ws_u64, int H, int W) {
     const int b = blockIdx.y;
+    // the select's histograms and state start from zero: cleared here (this launch completes before the first select pass).
+    // A hipMemsetAsync node did this before; replayed from a captured hipGraph it left the previous replay's counters in place
+    // (ROCm 7.2; first replay right, later ones wrong), so the kernels no longer rely on a memset.
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < ws_u64; i += 256) ws[(long)b * ws_u64 + i] = 0ull;
     const int pix = blockIdx.x * 256 + threadIdx.x;
     if (pix >= H * W) return;
     const double* c = cams + (long)b * HC;
@@ -165,11 +171,9 @@ extern "C" int pscv_cvp_depth_hypos(const float* depth, const double* cams, cons
     PSCV_CHECK_ARG(B > 0 && H > 0 && W > 0 && (long)H * W < (1L << 30), "pscv_cvp_depth_hypos: bad sizes");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int hw = H * W;
-    hipLaunchKernelGGL(hypo_keys_kernel, dim3((hw + 255) / 256, B), dim3(256), 0, st, depth, cams, keys, H, W);
-    PSCV_CHECK_LAUNCH("pscv_cvp_depth_hypos(keys)");
     unsigned long long* ws = keys + (long)B * hw;
-    hipError_t me = hipMemsetAsync(ws, 0, (size_t)B * SEL_WS_U64 * 8, st);
-    if (me != hipSuccess) { set_error("pscv_cvp_depth_hypos: hipMemsetAsync: %s", hipGetErrorString(me)); return -2; }
+    hipLaunchKernelGGL(hypo_keys_kernel, dim3((hw + 255) / 256, B), dim3(256), 0, st, depth, cams, keys, ws, SEL_WS_U64, H, W);
+    PSCV_CHECK_LAUNCH("pscv_cvp_depth_hypos(keys)");
     int nsel = (hw + 256 * 16 - 1) / (256 * 16);
     if (nsel > 1024) nsel = 1024;
     for (int pass = 0; pass < 8; ++pass)
