@@ -26,13 +26,15 @@ LAYERS = {
     "conv6": (64, 64, 0, 8, False, False, "conv"), "conv7": (64, 32, 2, 8, True, True, "conv"),
     "conv9": (32, 16, 2, 4, True, True, "conv"), "conv11": (16, 8, 2, 2, True, True, "t2p8"),
     "prob": (8, 1, 0, 1, False, False, "c1"),
-    "conv0": (32, 8, 0, 1, False, False, "sweep"),     # slots: prologue | fetch issue | MFMA loop | epilogue | stash (waits for the planes) | barrier
+    "conv0": (32, 8, 0, 1, False, False, "sweep"),
+    "cvp64": (64, 64, 0, (4, 512, 640), False, False, "conv"),   # CVP refinement 64 -> 64 at 4 x 512 x 640 (4x4x16 tiles, all 4 N-tiles)     # slots: prologue | fetch issue | MFMA loop | epilogue | stash (waits for the planes) | barrier
 }
 NAMES = ["loads issued", "loads landed", "LDS write+sync", "MFMA loop", "epilogue", "drain"]
 lib = L.lib()
 for name in sys.argv[1:] or list(LAYERS):
     ci, co, kind, s, tr, sk, tag = LAYERS[name]
-    x = (torch.randn(1, D // s, h // s, w // s, ci, generator=g) * 0.5).to(dt).to(dev)
+    shp = s if isinstance(s, tuple) else (D // s, h // s, w // s)
+    x = (torch.randn(1, *shp, ci, generator=g) * 0.5).to(dt).to(dev)
     wt = torch.randn(*((ci, co) if tr else (co, ci)), 3, 3, 3, generator=g) / (27 * ci) ** 0.5
     layer = ops.Conv3dLayer.build(wt, kind=kind, transposed=tr, device=dev, relu=co > 1, dtype=dt)
     Do, Ho, Wo = ops.conv_out_shape(kind, *x.shape[1:4])
