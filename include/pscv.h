@@ -90,6 +90,9 @@ int pscv_abi_version(void);
  *   "sweep_th16" 1: the 32->8 depth-sweep conv uses 16-row tiles / 512 threads; 0 (default): 8-row tiles / 256 threads
  *   "warp_bwd_direct" 1: pscv_warp_cost_bwd issues one global float atomic per tap; 0 (default): accumulates per-workgroup
  *               LDS patches and flushes them coalesced
+ *   "conv_s2_sweep"  1 (default): stride-2 layers with 8 input channels and <= 32 output channels on volumes of >= 64 Ki output
+ *               voxels run the stride-2 depth-sweep kernel; 0: always the brick kernel; 2: the sweep at any size (same packed weights, same result up to
+ *               fp32 summation order).  "s2s_slots": resident-workgroup target that sizes its depth chunks (0 = 768)
  *   "conv_small_tiles"  1 (default): small volumes use 1x4x16 tiles with the output channels split over
  *               blockIdx.y; 0: always the large-tile variant */
 int pscv_set_tuning(const char* key, int value);

@@ -21,13 +21,14 @@ D, h, w = 192, 128, 160
 g = torch.Generator().manual_seed(0)
 # name, c_in, c_out, kind, input scale, transposed, skip?, getter tag
 LAYERS = {
-    "conv1": (8, 16, 1, 1, False, False, "conv"), "conv3": (16, 32, 1, 2, False, False, "conv"),
+    "conv1": (8, 16, 1, 1, False, False, "s2s"),       # slots: prologue | stash + fetch issue | MFMA | epilogue | barrier
+    "conv3": (16, 32, 1, 2, False, False, "conv"),
     "conv4": (32, 32, 0, 4, False, False, "conv"), "conv5": (32, 64, 1, 4, False, False, "conv"),
     "conv6": (64, 64, 0, 8, False, False, "conv"), "conv7": (64, 32, 2, 8, True, True, "conv"),
     "conv9": (32, 16, 2, 4, True, True, "conv"), "conv11": (16, 8, 2, 2, True, True, "t2p8"),
     "prob": (8, 1, 0, 1, False, False, "c1"),
-    "conv0": (32, 8, 0, 1, False, False, "sweep"),
-    "cvp64": (64, 64, 0, (4, 512, 640), False, False, "conv"),   # CVP refinement 64 -> 64 at 4 x 512 x 640 (4x4x16 tiles, all 4 N-tiles)     # slots: prologue | fetch issue | MFMA loop | epilogue | stash (waits for the planes) | barrier
+    "conv0": (32, 8, 0, 1, False, False, "sweep"),     # slots: prologue | fetch issue | MFMA loop | epilogue | stash (waits for the planes) | barrier
+    "cvp64": (64, 64, 0, (4, 512, 640), False, False, "conv"),   # CVP refinement 64 -> 64 at 4 x 512 x 640 (4x4x16 tiles, all 4 N-tiles)
 }
 NAMES = ["loads issued", "loads landed", "LDS write+sync", "MFMA loop", "epilogue", "drain"]
 lib = L.lib()

@@ -353,3 +353,41 @@ def test_device_weight_packing_equals_host_packing(dtype):
         host = torch.from_numpy(ops.pack_conv3d_weights(w, kind, tr, dtype).view(np.int16))
         dev = ops.pack_conv3d_weights_device(w.cuda(), kind, tr, dtype).cpu()
         assert torch.equal(host, dev), (a, b, kind, tr)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("cout,shape,dc_slots,out_f32", [(16, (16, 16, 32), 0, False), (16, (13, 11, 21), 0, True), (32, (9, 37, 40), 0, False),
+                                                          (16, (37, 9, 70), 4, False), (24, (7, 33, 35), 0, False), (32, (2, 3, 5), 0, False),
+                                                          (16, (30, 20, 34), 6, False)])
+def test_stride2_sweep_kernel_matches_brick_kernel_and_aten(env, cout, shape, dc_slots, out_f32, dtype):
+    """The stride-2 depth-sweep kernel (csrc/conv3d_sweep_s2.hip: MVSNet's conv1 8 -> 16, the Vis U-Net's fused strided conv 8 -> 32)
+    against the brick kernel (same packed weights) and ATen: odd sizes in every dimension (output = ceil(size / 2)), forced chunk seams
+    ("s2s_slots" sizes the depth chunks), BN + ReLU + skip, channel slices in and out, a ragged last N-tile (24 channels), fp32 out."""
+    L, ops = env
+    g = torch.Generator().manual_seed(80 + cout + sum(shape))
+    D, H, W = shape
+    wide = bf16_round(torch.randn(2, 24, D, H, W, generator=g))
+    x = wide[:, 8:16]
+    w = bf16_round(torch.randn(cout, 8, 3, 3, 3, generator=g) / np.sqrt(27 * 8))
+    conv = F.conv3d(x, w, stride=2, padding=1)
+    Do, Ho, Wo = conv.shape[2:]
+    gamma, beta = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.3
+    mean, var = torch.randn(cout, generator=g) * 0.2, torch.rand(cout, generator=g) + 0.5
+    skip_wide = bf16_round(torch.randn(2, cout + 8, Do, Ho, Wo, generator=g))
+    ref = F.relu(F.batch_norm(conv, mean, var, gamma, beta, training=False, eps=1e-5)) + skip_wide[:, 4:4 + cout]
+    xcl, scl = ops.to_channels_last(wide.cuda(), dtype), ops.to_channels_last(skip_wide.cuda(), dtype)
+    layer = ops.Conv3dLayer.build(w, kind=L.CONV_S2, device="cuda", bn=(gamma, beta, mean, var), relu=True, dtype=dtype)
+    odt = torch.float32 if out_f32 else dtype
+    outs = {}
+    for sweep in (2, 0):                 # 2: the sweep at any size; 0: the brick kernel
+        out = torch.full((2, Do, Ho, Wo, cout + 8), 7.0, dtype=odt, device="cuda")
+        L.set_tuning("conv_s2_sweep", sweep); L.set_tuning("s2s_slots", dc_slots * 2 * ((Ho + 7) // 8) * ((Wo + 15) // 16))
+        try:
+            ops.conv3d(xcl, layer, in_coff=8, skip=scl, skip_coff=4, out=out, out_coff=4, out_dtype=odt)
+        finally:
+            L.set_tuning("conv_s2_sweep", 1); L.set_tuning("s2s_slots", 0)
+        assert bool((out[..., :4] == 7.0).all()) and bool((out[..., 4 + cout:] == 7.0).all())
+        outs[sweep] = out[..., 4:4 + cout].float().permute(0, 4, 1, 2, 3).cpu()
+    ulp = 0.0 if out_f32 else (2 ** -8 if dtype == torch.bfloat16 else 2 ** -11)
+    check_close(f"s2 sweep vs ATen {shape} -> {cout} {dtype}", outs[2], ref, max_abs=ulp * float(ref.abs().max()) + 2e-3)
+    check_close(f"s2 sweep vs brick {shape} -> {cout} {dtype}", outs[2], outs[0], max_abs=ulp * float(ref.abs().max()) + 1e-4)

@@ -296,7 +296,14 @@ def test_regress_fn_blockwise_against_autograd(arch, dtype):
             y = F.conv_transpose3d(x, wq, None, stride=b.stride, padding=1, output_padding=b.stride - 1)
         else:
             y = F.conv3d(x, wq, None, stride=b.stride, padding=1)
-        check_close(f"{b.name} raw conv", _cf(r["y"]), q(y.detach()), rel_l2=1e-4)
+        # fp32 accumulation in another order (k-steps split over the waves, MFMA internal order) can flip a 16-bit rounding where
+        # the exact value sits on a rounding boundary: on the tiny coarse levels one flip is already rel-L2 1e-4.  So: either the
+        # norm bar, or at most 0.2 % of the values differ and none by more than one ulp of the format.
+        got_y, ref_y = _cf(r["y"]), q(y.detach())
+        s_ = check_close(f"{b.name} raw conv", got_y, ref_y)
+        ulp1 = (2.0 ** -7 if bf else 2.0 ** -10) * ref_y.abs().clamp(min=2.0 ** -14)
+        flips = ((got_y - ref_y).abs() > 0).float().mean()
+        assert s_["rel_l2"] <= 1e-4 or (bool(((got_y - ref_y).abs() <= ulp1).all()) and float(flips) <= 2e-3), (s_, float(flips))
         # BN + ReLU (+ skip) on the ENGINE's stored y, so that the mask and the statistics are shared
         ye = _cf(r["y"]).requires_grad_(True)
         z = F.relu(F.batch_norm(ye, None, None, gamma, beta, training=True, eps=b.bn.eps))

@@ -607,6 +607,11 @@ int pscv_conv3d_sweepc_launch(const void* in, int dtype, int c_in, int c_out, in
                               int skip_coff, void* out, int out_cstride, int out_coff, int out_dtype, int B, int D, int Hh, int W,
                               int epi_flags, hipStream_t st);
 
+int pscv_conv3d_sweep_s2_launch(const void* in, int dtype, int in_cstride, int in_coff, const uint16_t* packed, const float* scale,
+                                const float* bias, const float* floor, const void* skip, int skip_cstride, int skip_coff, void* out,
+                                int out_cstride, int out_coff, int out_dtype, int B, int Di, int Hi, int Wi, int c_in, int c_out,
+                                int epi_flags, hipStream_t st);
+
 int pscv_conv3d_c1_launch(const void* in, int dtype, int in_cstride, int in_coff, const uint16_t* packed,
                           const float* scale, const float* bias, const float* floor, const void* skip,
                           int skip_cstride, int skip_coff, void* out, int out_cstride, int out_coff, int out_dtype,
@@ -661,6 +666,13 @@ extern "C" int pscv_conv3d(const void* in, int dtype, int in_cstride, int in_cof
         if (rc) return rc;
         PSCV_CHECK_LAUNCH("pscv_conv3d(c1)");
         return 0;
+    }
+    if (kind == PSCV_CONV_S2) {      // 8-channel inputs on large volumes: the stride-2 depth sweep (conv3d_sweep_s2.hip), same packing
+        const int rc = pscv_conv3d_sweep_s2_launch(in, dtype, in_cstride, in_coff, packed, scale, bias, floor, skip, skip_cstride, skip_coff,
+                                                   out, out_cstride, out_coff, out_dtype, B, Di, Hi, Wi, c_in, c_out, epi_flags,
+                                                   reinterpret_cast<hipStream_t>(stream));
+        if (rc < 0) return rc;
+        if (rc == 0) { PSCV_CHECK_LAUNCH("pscv_conv3d(s2 sweep)"); return 0; }
     }
     ConvArgs a;
     a.in = reinterpret_cast<const uint16_t*>(in);

@@ -129,6 +129,19 @@ __device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, v);
 }
 
+// Saturating fp32 -> fp16 stores without the two v_med3 clamps per pair: with MODE.FP16_OVFL set (once per wave, at kernel entry)
+// the hardware conversion clamps an overflowing result to +-65504 itself.  Kernels that call fp16_ovfl_mode() may pack with
+// pack_f16x2_ovfl(); everything else keeps pack_f16x2().
+__device__ __forceinline__ void fp16_ovfl_mode() { __builtin_amdgcn_s_setreg((1 - 1) << 11 | 23 << 6 | 1, 1); }   // hwreg(HW_REG_MODE, 23, 1)
+__device__ __forceinline__ uint32_t pack_f16x2_ovfl(float lo, float hi) {
+    h2_t v;
+    v[0] = (_Float16)lo;
+    v[1] = (_Float16)hi;
+    return __builtin_bit_cast(uint32_t, v);
+}
+// max(x, lo) as ONE instruction (fmaxf canonicalises a possibly-signalling operand with an extra v_max first)
+__device__ __forceinline__ float clamp_lo(float x, float lo) { return __builtin_amdgcn_fmed3f(x, lo, __builtin_inff()); }
+
 // 16-bit storage type tags (both are raw uint16 in memory)
 struct bf16_t { uint16_t bits; };
 struct f16_t { uint16_t bits; };
@@ -162,6 +175,7 @@ template <> struct Half16<bf16_t> {
     __device__ static __forceinline__ float lo(uint32_t x) { return bf16lo(x); }
     __device__ static __forceinline__ float hi(uint32_t x) { return bf16hi(x); }
     __device__ static __forceinline__ uint32_t pack(float a, float b) { return pack_bf16x2(a, b); }
+    __device__ static __forceinline__ uint32_t pack_ovfl(float a, float b) { return pack_bf16x2(a, b); }
     __device__ static __forceinline__ float one(uint16_t v) { return bf16_to_f32(v); }
     __host__ __device__ static __forceinline__ uint16_t bits(float f) { return f32_to_bf16(f); }
 };
@@ -170,6 +184,7 @@ template <> struct Half16<f16_t> {
     __device__ static __forceinline__ float lo(uint32_t x) { return f16lo(x); }
     __device__ static __forceinline__ float hi(uint32_t x) { return f16hi(x); }
     __device__ static __forceinline__ uint32_t pack(float a, float b) { return pack_f16x2(a, b); }
+    __device__ static __forceinline__ uint32_t pack_ovfl(float a, float b) { return pack_f16x2_ovfl(a, b); }   // needs fp16_ovfl_mode()
     __device__ static __forceinline__ float one(uint16_t v) { return f16lo((uint32_t)v); }
     __host__ __device__ static __forceinline__ uint16_t bits(float f) { return f32_to_f16_bits(f); }
 };

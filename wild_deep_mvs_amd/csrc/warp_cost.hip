@@ -253,6 +253,8 @@ extern thread_local int g_sweepc_pd;
 extern thread_local int g_c1_nb;
 namespace pscv {
 extern thread_local int g_warp_bwd_direct;    // warp_bwd.hip
+extern thread_local int g_conv_s2_sweep;      // conv3d_sweep_s2.hip
+extern thread_local int g_s2s_slots;
 static thread_local int g_warp_q2 = 1;        // 1: 32-channel 16-bit sweeps use the quad-mapped kernel (warp_cost_q2.hip)
 int warp_cost_q2_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, int out_dtype, int ppd_override, hipStream_t st);
 int warp_cost_tiled_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, int out_dtype, int ppd_override, hipStream_t st);
@@ -351,6 +353,8 @@ extern "C" int pscv_set_tuning(const char* key, int value) {
     if (!strcmp(key, "sweepc_slots")) { g_sweepc_slots = value; return 0; }
     if (!strcmp(key, "sweepc_pd")) { g_sweepc_pd = value; return 0; }
     if (!strcmp(key, "warp_bwd_direct")) { g_warp_bwd_direct = value; return 0; }
+    if (!strcmp(key, "conv_s2_sweep")) { g_conv_s2_sweep = value; return 0; }
+    if (!strcmp(key, "s2s_slots")) { g_s2s_slots = value; return 0; }
     set_error("pscv_set_tuning: unknown key '%s'", key);
     return -1;
 }
