@@ -119,9 +119,14 @@ __global__ __launch_bounds__(32 * SW_TH, 2) void conv3d_sweep8_kernel(const Swee
         for (int kw = 0; kw < 3; ++kw) boff[rr][kw] = sw_lds_off((row0 + rr) * SW_BW + n + kw, g);
 
     // ---- staging descriptors: 3 chunks per thread per plane ----
-    int goff[NLD], loff[NLD];
-    bool gval[NLD], lval[NLD];
+    // Planes are fetched with raw buffer loads: the descriptor covers one input plane, a chunk outside the image carries an
+    // out-of-range offset and a plane outside the volume an empty descriptor -- the hardware returns zeros (= the conv's
+    // padding): NLD load instructions per plane, no predicate, zero fill or 64-bit address arithmetic per chunk.
+    unsigned goff[NLD];
+    int loff[NLD];
+    bool lval[NLD];
     const long plane_stride = (long)a.Hh * a.W * a.in_cs;
+    const unsigned plane_bytes = (unsigned)(plane_stride * 2 - a.in_co * 2);
     const uint16_t* inb = a.in + (long)b * a.D * plane_stride + a.in_co;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
@@ -130,19 +135,18 @@ __global__ __launch_bounds__(32 * SW_TH, 2) void conv3d_sweep8_kernel(const Swee
         const int bh = v / SW_BW, bw = v - bh * SW_BW;
         const int gh = h0 - 1 + bh, gw = w0 - 1 + bw;
         lval[i] = id < SW_CHUNKS;
-        gval[i] = lval[i] && (unsigned)gh < (unsigned)a.Hh && (unsigned)gw < (unsigned)a.W;
-        goff[i] = gval[i] ? (gh * a.W + gw) * a.in_cs + c * 8 : 0;
+        const bool gval = lval[i] && (unsigned)gh < (unsigned)a.Hh && (unsigned)gw < (unsigned)a.W;
+        goff[i] = gval ? ((unsigned)(gh * a.W + gw) * (unsigned)a.in_cs + (unsigned)(c * 8)) * 2u : 0x7ffffff0u;
         loff[i] = sw_lds_off(v, c);
     }
     const int plane_hi = min(a.D - 1, dend);   // last input plane this sweep can use
     auto fetch = [&](int plane, uint4 (&reg)[NLD]) {
-        const bool pv = plane >= 0 && plane <= plane_hi;
-        const uint16_t* pp = inb + (long)(pv ? plane : 0) * plane_stride;
+        const bool pv = plane >= 0 && plane <= plane_hi;                                         // wave-uniform
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint16_t*>(inb + (long)(pv ? plane : 0) * plane_stride), (short)0, pv ? (int)plane_bytes : 0, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            reg[i] = make_uint4(0u, 0u, 0u, 0u);
-            if (gval[i] && pv) reg[i] = *reinterpret_cast<const uint4*>(pp + goff[i]);
-        }
+        for (int i = 0; i < NLD; ++i)
+            reg[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)goff[i], 0, 0));
     };
     auto stash = [&](int ring, const uint4 (&reg)[NLD]) {
         unsigned char* sp = smem + ring * SW_PB;
@@ -174,12 +178,11 @@ __global__ __launch_bounds__(32 * SW_TH, 2) void conv3d_sweep8_kernel(const Swee
 
     int ring = 0;   // slot holding plane d-1
     for (int d = dbeg; d < dend; d += 2) {
-        // issue the next two planes (d+3, d+4) early; they land in LDS after this iteration's MFMAs.  (The per-load predicate
-        // + zero fill also pins the loads here: an unpredicated fast path for interior tiles let the scheduler sink them to
-        // the stash below and cost 40 us.)
+        // issue the next two planes (d+3, d+4) early; they land in LDS after this iteration's MFMAs
         uint4 na[NLD], nb[NLD];
         fetch(d + 3, na);
         fetch(d + 4, nb);
+        __builtin_amdgcn_sched_barrier(0);      // both planes are requested HERE (the scheduler otherwise sinks the second below the MFMAs)
         PSCV_STAMP(1)
 
         sw_f32x4 acc[R];
@@ -314,9 +317,12 @@ __global__ __launch_bounds__(256, (CIN == 8 && PD <= 2) ? 4 : (CIN == 8 || (PD =
         for (int kw = 0; kw < 3; ++kw) boff[rr][kw] = ((row0 + rr) * SW_BW + n + kw) * VB + (CIN == 16 ? (g & 1) * 16 : 0);
     const int pl0 = CIN == 8 ? g : (g >> 1);      // this lane's plane (relative to d-1) in MFMA set 0; set 1 (C_in = 16) adds 2
 
-    int goff[NLD], loff[NLD];
-    bool gval[NLD], lval[NLD];
+    // (raw buffer loads as in the 32 -> 8 sweep: out-of-image chunks and out-of-volume planes come back as zeros from the hardware)
+    unsigned goff[NLD];
+    int loff[NLD];
+    bool lval[NLD];
     const long plane_stride = (long)a.Hh * a.W * a.in_cs;
+    const unsigned plane_bytes = (unsigned)(plane_stride * 2 - a.in_co * 2);
     const uint16_t* inb = a.in + (long)b * a.D * plane_stride + a.in_co;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
@@ -325,19 +331,18 @@ __global__ __launch_bounds__(256, (CIN == 8 && PD <= 2) ? 4 : (CIN == 8 || (PD =
         const int bh = v / SW_BW, bw = v - bh * SW_BW;
         const int gh = h0 - 1 + bh, gw = w0 - 1 + bw;
         lval[i] = id < CHUNKS;
-        gval[i] = lval[i] && (unsigned)gh < (unsigned)a.Hh && (unsigned)gw < (unsigned)a.W;
-        goff[i] = gval[i] ? (gh * a.W + gw) * a.in_cs + c * 8 : 0;
+        const bool gval = lval[i] && (unsigned)gh < (unsigned)a.Hh && (unsigned)gw < (unsigned)a.W;
+        goff[i] = gval ? ((unsigned)(gh * a.W + gw) * (unsigned)a.in_cs + (unsigned)(c * 8)) * 2u : 0x7ffffff0u;
         loff[i] = v * VB + c * 16;
     }
     const int plane_hi = min(a.D - 1, dend);
     auto fetch = [&](int plane, uint4 (&reg)[NLD]) {
-        const bool pv = plane >= 0 && plane <= plane_hi;
-        const uint16_t* pp = inb + (long)(pv ? plane : 0) * plane_stride;
+        const bool pv = plane >= 0 && plane <= plane_hi;                                         // wave-uniform
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint16_t*>(inb + (long)(pv ? plane : 0) * plane_stride), (short)0, pv ? (int)plane_bytes : 0, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            reg[i] = make_uint4(0u, 0u, 0u, 0u);
-            if (gval[i] && pv) reg[i] = *reinterpret_cast<const uint4*>(pp + goff[i]);
-        }
+        for (int i = 0; i < NLD; ++i)
+            reg[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)goff[i], 0, 0));
     };
     auto stash = [&](int ring, const uint4 (&reg)[NLD]) {
         unsigned char* sp = smem + ring * PB;
@@ -512,6 +517,7 @@ int pscv_conv3d_sweepc_launch(const void* in, int dtype, int c_in, int c_out, in
                               int skip_coff, void* out, int out_cstride, int out_coff, int out_dtype, int B, int D, int Hh, int W,
                               int epi_flags, hipStream_t st) {
     using namespace pscv;
+    PSCV_CHECK_ARG((long)Hh * W * in_cstride * 2 < 0x7fffffffL, "pscv_conv3d(sweep): an input plane of %d x %d x %d channels exceeds 2 GiB", Hh, W, in_cstride);
     SweepArgs a;
     a.in = reinterpret_cast<const uint16_t*>(in);
     a.wpk = packed; a.scale = scale; a.bias = bias; a.floor = floor;
@@ -557,6 +563,7 @@ int pscv_conv3d_sweep8_launch(const void* in, int dtype, int in_cstride, int in_
     a.in_cs = in_cstride; a.in_co = in_coff; a.skip_cs = skip_cstride; a.skip_co = skip_coff;
     a.out_cs = out_cstride; a.out_co = out_coff; a.out_f32 = out_dtype == PSCV_F32;
     a.B = B; a.D = D; a.Hh = Hh; a.W = W; a.epi = epi_flags;
+    PSCV_CHECK_ARG((long)Hh * W * in_cstride * 2 < 0x7fffffffL, "pscv_conv3d(sweep): an input plane of %d x %d x %d channels exceeds 2 GiB", Hh, W, in_cstride);
     const bool tall = g_sweep_th16 && Hh >= 16;
     const int TH = tall ? 16 : 8;
     a.nth = (Hh + TH - 1) / TH;
