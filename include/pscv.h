@@ -90,6 +90,8 @@ int pscv_abi_version(void);
  *   "sweep_th16" 1: the 32->8 depth-sweep conv uses 16-row tiles / 512 threads; 0 (default): 8-row tiles / 256 threads
  *   "warp_bwd_direct" 1: pscv_warp_cost_bwd issues one global float atomic per tap; 0 (default): accumulates per-workgroup
  *               LDS patches and flushes them coalesced
+ *   "c1_sweep"  1 (default): 1-channel heads with 8 input channels and at least three 6-plane blocks per depth chunk run the
+ *               depth-sweep variant; 0: always the brick variant; 2: the sweep at any depth
  *   "conv_s2_sweep"  1 (default): stride-2 layers with 8 input channels and <= 32 output channels on volumes of >= 64 Ki output
  *               voxels run the stride-2 depth-sweep kernel; 0: always the brick kernel; 2: the sweep at any size (same packed weights, same result up to
  *               fp32 summation order).  "s2s_slots": resident-workgroup target that sizes its depth chunks (0 = 768)

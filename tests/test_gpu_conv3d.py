@@ -391,3 +391,37 @@ def test_stride2_sweep_kernel_matches_brick_kernel_and_aten(env, cout, shape, dc
     ulp = 0.0 if out_f32 else (2 ** -8 if dtype == torch.bfloat16 else 2 ** -11)
     check_close(f"s2 sweep vs ATen {shape} -> {cout} {dtype}", outs[2], ref, max_abs=ulp * float(ref.abs().max()) + 2e-3)
     check_close(f"s2 sweep vs brick {shape} -> {cout} {dtype}", outs[2], outs[0], max_abs=ulp * float(ref.abs().max()) + 1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape,out_dtype,with_skip", [((16, 16, 32), torch.float32, False), ((13, 11, 45), torch.float32, False),
+                                                       ((37, 9, 40), torch.float32, False), ((5, 17, 64), None, False),
+                                                       ((48, 6, 70), torch.float32, True), ((25, 12, 33), None, True)])
+def test_one_channel_head_depth_sweep_matches_brick_variant_and_aten(env, shape, out_dtype, with_skip, dtype):
+    """The depth-sweep variant of the 1-channel head kernel (csrc/conv3d_c1.hip: 16-slot plane ring, planes requested one 6-plane block
+    ahead with raw buffer loads; what MVSNet's `prob` runs at D = 192) against the brick variant (pscv_set_tuning("c1_sweep", 0)) and
+    ATen: depths that are not multiples of 6, tiles off the 4 x 32 grid, a channel-slice input, bias, 16-bit and fp32 outputs, skip."""
+    L, ops = env
+    g = torch.Generator().manual_seed(31 + sum(shape))
+    D, H, W = shape
+    wide = bf16_round(torch.randn(2, 16, D, H, W, generator=g))
+    x = wide[:, 8:16]
+    w = bf16_round(torch.randn(1, 8, 3, 3, 3, generator=g) / np.sqrt(27 * 8))
+    bias = torch.randn(1, generator=g)
+    skip = bf16_round(torch.randn(2, 1, D, H, W, generator=g)) if with_skip else None
+    ref = F.conv3d(x, w, bias, padding=1) + (skip if with_skip else 0.0)
+    xcl = ops.to_channels_last(wide.cuda(), dtype)
+    scl = ops.to_channels_last(skip.cuda(), dtype) if with_skip else None
+    layer = ops.Conv3dLayer.build(w, kind=L.CONV_S1, device="cuda", conv_bias=bias, dtype=dtype)
+    assert layer.kind == L.CONV_S1C1
+    outs = {}
+    for sweep in (2, 0):                # 2: the sweep at any depth; 0: the brick variant
+        L.set_tuning("c1_sweep", sweep)
+        try:
+            y = ops.conv3d(xcl, layer, in_coff=8, skip=scl, out_dtype=out_dtype)
+        finally:
+            L.set_tuning("c1_sweep", 1)
+        outs[sweep] = y.float().permute(0, 4, 1, 2, 3).cpu()
+    tol = 3e-3 if out_dtype is not None else (2 ** -8 if dtype == torch.bfloat16 else 2 ** -11) * float(ref.abs().max()) + 1e-3
+    check_close(f"c1 sweep vs ATen {shape} {dtype}", outs[2], ref, max_abs=tol)
+    check_close(f"c1 sweep vs brick variant {shape} {dtype}", outs[2], outs[0], max_abs=tol if out_dtype is None else 1e-5)

@@ -236,6 +236,175 @@ __global__ __launch_bounds__(256) void conv3d_c1_kernel(const C1Args a) {
     PSCV_PROF_END(c1, blockIdx.x)
 }
 
+// ---- depth-sweep variant (C_in = 8, long depth axes: MVSNet's prob head at D = 192) ---------------------------------------
+// The kernel above stages 14 planes, waits, computes 12, stores, and leaves: its workgroup lifetime (13 K cycles, three resident per
+// CU) is a chain of exposed phases.  Here a workgroup keeps its 4 x 32 pixel tile and walks a depth chunk in 6-plane blocks over a
+// 16-slot LDS plane ring (slot = plane & 15, 53 KB): block k reads planes 6k .. 6k+7 (relative to the chunk's first halo plane) while
+// the six planes of block k+1 -- requested one block earlier with raw buffer loads (hardware zero fill outside the image / volume)
+// -- are written into slots nobody reads; every input plane is fetched once per chunk (14/12 before), the A fragments once per chunk.
+// A lane group reads two planes per block (4 (g >> 1) + (g & 1) and + 2): two ring addresses per block, taps as immediates.
+constexpr int C1S_NSLOT = 16;
+
+template <typename H>
+__global__ __launch_bounds__(256) void conv3d_c1_sweep_kernel(const C1Args a) {
+    constexpr int VB = 16, NSTEPS = 18, PV = C1_BH * C1_BW, PSB = C1_PS * VB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [16 slots][C1_PS][16 B]
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, slot_ = bid >> 3, q_ = nwg >> 3, r_ = nwg & 7;
+    int wg = (xcd < r_ ? xcd * (q_ + 1) : r_ * (q_ + 1) + (xcd - r_) * q_) + slot_;
+    const int dci = fast_divmod(wg, a.ndc, a.mg_dc);
+    const int twi = fast_divmod(wg, a.ntw, a.mg_tw);
+    const int thi = fast_divmod(wg, a.nth, a.mg_th);
+    const int b = wg;
+    const int h0 = thi * C1_TH, w0 = twi * C1_TW;
+    const int nbk = a.nb;                                // 6-plane blocks per chunk
+    const int dbeg = dci * nbk * C1_P;
+
+    const int tid = threadIdx.x;
+    PSCV_PROF_BEGIN   // (profile builds: slots = prologue | MFMA + LDS reads | epilogue | stash + fetch | barrier)
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;
+
+    // ---- staging: thread t < 204 owns voxel t of every plane ----
+    const unsigned long plane_stride_b = (unsigned long)a.Hh * a.W * a.in_cs * 2;
+    const unsigned plane_bytes = (unsigned)(plane_stride_b - (unsigned long)a.in_co * 2);
+    const char* inb = reinterpret_cast<const char*>(a.in) + ((unsigned long)b * a.D * plane_stride_b + (unsigned long)a.in_co * 2);
+    const int sbh = tid / C1_BW, sbw = tid - sbh * C1_BW;
+    const int sgh = h0 - 1 + sbh, sgw = w0 - 1 + sbw;
+    const bool vox_ok = tid < PV && (unsigned)sgh < (unsigned)a.Hh && (unsigned)sgw < (unsigned)a.W;
+    const unsigned goff = vox_ok ? (unsigned)(sgh * a.W + sgw) * (unsigned)(a.in_cs * 2) : 0x7ffffff0u;
+    auto fetch = [&](int plane) -> uint4 {
+        const bool pv = plane >= 0 && plane < a.D;                                               // wave-uniform
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(inb + (unsigned long)(pv ? plane : 0) * plane_stride_b), (short)0, pv ? (int)plane_bytes : 0, 0x00020000);
+        return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)goff, 0, 0));
+    };
+    auto stash = [&](int prel, const uint4& v) {          // prel = plane - (dbeg - 1)
+        if (tid < PV) *reinterpret_cast<uint4*>(smem + (prel & (C1S_NSLOT - 1)) * PSB + tid * VB) = v;
+    };
+
+    uint4 wf[NSTEPS];
+#pragma unroll
+    for (int s = 0; s < NSTEPS; ++s) wf[s] = a.wpk[s * 64 + lane];
+    {
+        uint4 r8[C1_P + 2];
+#pragma unroll
+        for (int p = 0; p < C1_P + 2; ++p) r8[p] = fetch(dbeg - 1 + p);
+#pragma unroll
+        for (int p = 0; p < C1_P + 2; ++p) stash(p, r8[p]);
+    }
+    uint4 nx[C1_P];
+#pragma unroll
+    for (int p = 0; p < C1_P; ++p) nx[p] = fetch(dbeg + C1_P + 1 + p);        // planes of block 1 (prel 8 .. 13)
+
+    const float e_scale = a.scale ? a.scale[0] : 1.0f, e_bias = a.bias ? a.bias[0] : 0.0f, e_floor = a.floor ? a.floor[0] : 0.0f;
+    const float lo_pre = (a.epi & PSCV_EPI_RELU_PRE) ? e_floor : -__builtin_inff();
+    const float lo_post = (a.epi & PSCV_EPI_RELU_POST) ? 0.0f : -__builtin_inff();
+    __syncthreads();
+    PSCV_STAMP(0)
+
+    const int inplane = (wave * C1_BW + n) * VB;
+    const int pA = 4 * (g >> 1) + (g & 1);
+    const int oh = h0 + wave;
+    const int OB = a.out_f32 ? 4 : 2;
+    const unsigned long out_plane = (unsigned long)a.Hh * a.W * a.out_cs * OB;
+    const unsigned long skip_plane = (unsigned long)a.Hh * a.W * a.skip_cs * 2;
+    const unsigned pix0 = (unsigned)(oh * a.W + w0 + n);
+    const bool row_ok = g < 2 && oh < a.Hh;
+    const unsigned ostep = (unsigned)a.out_cs * (unsigned)OB;
+    const unsigned ooff_g = (pix0 * (unsigned)a.out_cs + (unsigned)a.out_co) * (unsigned)OB + (unsigned)(4 * g) * (unsigned)out_plane;
+    const bool tile_full = w0 + C1_TW <= a.W && !a.skip && oh < a.Hh;
+
+    for (int k = 0; k < nbk; ++k) {
+        const int d0 = dbeg + k * C1_P;
+        if (d0 >= a.D) break;
+        const unsigned char* spA = smem + ((C1_P * k + pA) & (C1S_NSLOT - 1)) * PSB + inplane;
+        const unsigned char* spB = smem + ((C1_P * k + pA + 2) & (C1S_NSLOT - 1)) * PSB + inplane;
+        // four accumulation chains of 9 dependent MFMAs (two column tiles x the two plane sets) instead of two of 18: the block is a
+        // latency chain (one workgroup per CU still needs ~3.5 K cycles per block), so the chain length counts
+        c1_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc0b = {0.f, 0.f, 0.f, 0.f}, acc1b = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int off = ((t / 3) * C1_BW + (t % 3)) * VB;
+            const uint4 x0 = *reinterpret_cast<const uint4*>(spA + off);
+            const uint4 x1 = *reinterpret_cast<const uint4*>(spA + off + 16 * VB);
+            const uint4 x2 = *reinterpret_cast<const uint4*>(spB + off);
+            const uint4 x3 = *reinterpret_cast<const uint4*>(spB + off + 16 * VB);
+            acc0 = C1Mfma<H>::run(wf[t], x0, acc0);
+            acc1 = C1Mfma<H>::run(wf[t], x1, acc1);
+            acc0b = C1Mfma<H>::run(wf[9 + t], x2, acc0b);
+            acc1b = C1Mfma<H>::run(wf[9 + t], x3, acc1b);
+        }
+        acc0 += acc0b;
+        acc1 += acc1b;
+        PSCV_STAMP(1)
+        // ---- epilogue: lane (n, g) holds rows 4g..4g+3 = output planes d0 + 4g + r of pixel n ----
+        if (tile_full && d0 + C1_P <= a.D) {
+            char* ob = reinterpret_cast<char*>(a.out) + ((unsigned long)b * a.D + d0) * out_plane;
+            float y[2][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                y[0][r] = clamp_lo(clamp_lo(fmaf(acc0[r], e_scale, e_bias), lo_pre), lo_post);
+                y[1][r] = clamp_lo(clamp_lo(fmaf(acc1[r], e_scale, e_bias), lo_pre), lo_post);
+            }
+            if (g < 2) {          // rows 0,1 (g = 0) and 4,5 (g = 1)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        char* o = ob + (unsigned long)r * out_plane + (ooff_g + ct * 16 * ostep);
+                        if (a.out_f32) *reinterpret_cast<float*>(o) = y[ct][r];
+                        else *reinterpret_cast<uint16_t*>(o) = Half16<H>::bits(y[ct][r]);
+                    }
+            }
+            if (g == 0) {         // rows 2,3
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 2; r < 4; ++r) {
+                        char* o = ob + (unsigned long)r * out_plane + (ooff_g + ct * 16 * ostep);
+                        if (a.out_f32) *reinterpret_cast<float*>(o) = y[ct][r];
+                        else *reinterpret_cast<uint16_t*>(o) = Half16<H>::bits(y[ct][r]);
+                    }
+            }
+        } else if (row_ok) {
+            char* ob = reinterpret_cast<char*>(a.out) + ((unsigned long)b * a.D + d0 + 4 * g) * out_plane;
+            const char* sb = reinterpret_cast<const char*>(a.skip) + ((unsigned long)b * a.D + d0 + 4 * g) * skip_plane;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                if (w0 + ct * 16 + n >= a.W) continue;
+                const unsigned pix = pix0 + ct * 16;
+                const unsigned ooff = (pix * (unsigned)a.out_cs + (unsigned)a.out_co) * (unsigned)OB;
+                const unsigned soff = (pix * (unsigned)a.skip_cs + (unsigned)a.skip_co) * 2u;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = 4 * g + r;
+                    if (m >= C1_P || d0 + m >= a.D) continue;
+                    float y = fmaxf(fmaf(ct ? acc1[r] : acc0[r], e_scale, e_bias), lo_pre);
+                    if (a.skip) y += Half16<H>::one(*reinterpret_cast<const uint16_t*>(sb + r * skip_plane + soff));
+                    y = fmaxf(y, lo_post);
+                    if (a.out_f32) *reinterpret_cast<float*>(ob + r * out_plane + ooff) = y;
+                    else *reinterpret_cast<uint16_t*>(ob + r * out_plane + ooff) = Half16<H>::bits(y);
+                }
+            }
+        }
+        PSCV_STAMP(2)
+        // the planes of block k + 1 into the slots nobody reads now; their registers are refilled with the planes of block k + 2
+        if (k + 1 < nbk) {
+#pragma unroll
+            for (int p = 0; p < C1_P; ++p) stash(C1_P * k + C1_P + 2 + p, nx[p]);
+#pragma unroll
+            for (int p = 0; p < C1_P; ++p) nx[p] = fetch(dbeg + C1_P * (k + 2) + 1 + p);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        PSCV_STAMP(3)
+        __syncthreads();
+        PSCV_STAMP(4)
+    }
+    PSCV_PROF_END(c1, blockIdx.x)
+}
+
 template <typename H, int CIN>
 static int c1_launch(const C1Args& a, long nblk, hipStream_t st) {
     auto kern = conv3d_c1_kernel<H, CIN>;
@@ -251,6 +420,7 @@ static int c1_launch(const C1Args& a, long nblk, hipStream_t st) {
 }  // namespace pscv
 
 thread_local int g_c1_nb = 0;
+thread_local int g_c1_sweep = 1;   // pscv_set_tuning("c1_sweep", 0): always the brick variant; 2: the depth sweep at any depth
 PSCV_PROF_EXPORT(c1)
 
 int pscv_conv3d_c1_launch(const void* in, int dtype, int in_cstride, int in_coff, const uint16_t* packed,
@@ -275,10 +445,25 @@ int pscv_conv3d_c1_launch(const void* in, int dtype, int in_cstride, int in_coff
     // the chip a few rounds of workgroups; C_in = 16 keeps one (LDS: 53 KB per workgroup instead of 93)
     a.nb = (c_in == 8 && tiles * ((nblocks + 1) / 2) >= 1024) ? 2 : 1;
     if (g_c1_nb) a.nb = g_c1_nb;
+    // long depth axes with 8 input channels: the depth-sweep variant, chunks sized for about one resident round (3 per CU)
+    bool sweep = false;
+    if (c_in == 8 && g_c1_sweep && (long)Hh * W * in_cstride * 2 < 0x7fffffffL) {
+        const long want = tiles >= 768 ? 1 : 768 / tiles;
+        const int ndc = (int)(want < nblocks ? want : nblocks);
+        int nbk = (nblocks + ndc - 1) / ndc;
+        if (g_c1_nb > 2) nbk = g_c1_nb < nblocks ? g_c1_nb : nblocks;     // (measurement override: blocks per chunk)
+        if (nbk >= 3 || g_c1_sweep == 2) { sweep = true; a.nb = nbk; }
+    }
     a.ndc = (nblocks + a.nb - 1) / a.nb;
     const long nblk = tiles * a.ndc;
     a.mg_th = fast_div_magic(a.nth); a.mg_tw = fast_div_magic(a.ntw); a.mg_dc = fast_div_magic(a.ndc);
     if (nblk <= 0 || nblk > 0x7fffffffL) { set_error("pscv_conv3d(c1): bad grid %ld", nblk); return -1; }
+    if (sweep) {
+        const size_t lds = (size_t)C1S_NSLOT * C1_PS * 16;
+        if (dtype == PSCV_BF16) hipLaunchKernelGGL(conv3d_c1_sweep_kernel<bf16_t>, dim3((unsigned)nblk), dim3(256), lds, st, a);
+        else hipLaunchKernelGGL(conv3d_c1_sweep_kernel<f16_t>, dim3((unsigned)nblk), dim3(256), lds, st, a);
+        return 0;
+    }
     if (dtype == PSCV_BF16 && c_in == 8) return c1_launch<bf16_t, 8>(a, nblk, st);
     if (dtype == PSCV_BF16 && c_in == 16) return c1_launch<bf16_t, 16>(a, nblk, st);
     if (dtype == PSCV_F16 && c_in == 8) return c1_launch<f16_t, 8>(a, nblk, st);

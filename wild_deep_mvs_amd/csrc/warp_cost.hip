@@ -251,6 +251,7 @@ extern thread_local int g_sweepc_slots;
 extern thread_local int g_sweepc_pd;
 }
 extern thread_local int g_c1_nb;
+extern thread_local int g_c1_sweep;
 namespace pscv {
 extern thread_local int g_warp_bwd_direct;    // warp_bwd.hip
 extern thread_local int g_conv_s2_sweep;      // conv3d_sweep_s2.hip
@@ -348,6 +349,7 @@ extern "C" int pscv_set_tuning(const char* key, int value) {
     if (!strcmp(key, "warp_tiled")) { g_warp_tiled = value < 0 ? 1 : value; return 0; }   // -1: back to the default
     if (!strcmp(key, "warp_q2")) { g_warp_q2 = value; return 0; }
     if (!strcmp(key, "c1_nb")) { g_c1_nb = value; return 0; }
+    if (!strcmp(key, "c1_sweep")) { g_c1_sweep = value; return 0; }
     if (!strcmp(key, "sweep_th16")) { g_sweep_th16 = value; return 0; }
     if (!strcmp(key, "sweep_dc")) { g_sweep_dc = value; return 0; }
     if (!strcmp(key, "sweepc_slots")) { g_sweepc_slots = value; return 0; }
