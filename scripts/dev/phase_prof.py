@@ -22,6 +22,7 @@ g = torch.Generator().manual_seed(0)
 # name, c_in, c_out, kind, input scale, transposed, skip?, getter tag
 LAYERS = {
     "conv1": (8, 16, 1, 1, False, False, "s2s"),       # slots: prologue | stash + fetch issue | MFMA | epilogue | barrier
+    "conv2": (16, 16, 0, 2, False, False, "conv"),
     "conv3": (16, 32, 1, 2, False, False, "conv"),
     "conv4": (32, 32, 0, 4, False, False, "conv"), "conv5": (32, 64, 1, 4, False, False, "conv"),
     "conv6": (64, 64, 0, 8, False, False, "conv"), "conv7": (64, 32, 2, 8, True, True, "conv"),
