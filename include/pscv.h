@@ -401,6 +401,22 @@ int pscv_cvp_depth_hypos(const float* depth, const double* cams, const float* fa
                          double* steps, float* hypos, int B, int H, int W, void* stream);
 
 /*
+ * Fused tail of the MVSNet regulariser: the 1-channel `prob` head (kind S1C1 packing, 8 input channels, depth-sweep variant) writes
+ * the fp32 logits AND per-depth-chunk softmax partials; a merge launch gives depth and photometric confidence.  Replaces
+ * CostRegNet.prob + F.softmax + depth_regression + the 4-plane confidence (models/MVSNet/model.py:72,82,207-215) -- the separate
+ * pscv_softargmin pass over the 15.7 MB logit volume disappears.  Returns -3 (with pscv_last_error) when the layer / size does not
+ * qualify (then call pscv_conv3d and pscv_softargmin).
+ *   in      device 16-bit [B,D,H,W,in_cstride] (channel slice [in_coff, in_coff + c_in)), packed = S1C1 weights, scale/bias/floor [1]
+ *   depth   device fp32 planes, row b at depth + b * depth_bstride, D entries;  logits device fp32 out [B,D,H,W]
+ *   workspace device fp32, pscv_prob_softargmin_workspace(B,D,H,W) floats;  out_depth / out_conf device fp32 [B,H,W] (conf may be null)
+ */
+long pscv_prob_softargmin_workspace(int B, int D, int H, int W);
+int pscv_prob_softargmin(const void* in, int dtype, int in_cstride, int in_coff, const uint16_t* packed, const float* scale,
+                         const float* bias, const float* floor, int c_in, int epi_flags, const float* depth, long depth_bstride,
+                         float* logits, float* workspace, long workspace_floats, float* out_depth, float* out_conf, int B, int D,
+                         int H, int W, void* stream);
+
+/*
  * Function-level homography warp: one 3x3 matrix per batch item or per reference pixel.  Replaces homography_warping +
  * interpolate of models/VisMVSNet/homography.py:84-120 for direct callers (inside the model the homographies are built in the
  * fused sweep and never materialised).  Pixel centres at +0.5, z <= 0 -> zero sample, divisor clamped at 1e-9,

@@ -425,3 +425,35 @@ def test_one_channel_head_depth_sweep_matches_brick_variant_and_aten(env, shape,
     tol = 3e-3 if out_dtype is not None else (2 ** -8 if dtype == torch.bfloat16 else 2 ** -11) * float(ref.abs().max()) + 1e-3
     check_close(f"c1 sweep vs ATen {shape} {dtype}", outs[2], ref, max_abs=tol)
     check_close(f"c1 sweep vs brick variant {shape} {dtype}", outs[2], outs[0], max_abs=tol if out_dtype is None else 1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(24, 8, 32), (37, 9, 40), (48, 6, 70), (192, 16, 32)])
+def test_fused_prob_softargmin_tail_equals_separate_launches(env, shape, dtype):
+    """pscv_prob_softargmin (the 1-channel head's depth sweep emits per-chunk softmax partials, one merge launch gives depth and the
+    4-plane confidence) against pscv_conv3d + pscv_softargmin on the same input: identical logits, depth within 2e-6 of the depth
+    range, confidence within 2e-5; depths that are not multiples of 6, ragged tiles, several chunks, batch of two with different
+    depth planes.  Reference semantics: models/MVSNet/model.py:72,82,207-215."""
+    L, ops = env
+    g = torch.Generator().manual_seed(61 + sum(shape))
+    D, H, W = shape
+    x = bf16_round(torch.randn(2, 8, D, H, W, generator=g))
+    w = bf16_round(torch.randn(1, 8, 3, 3, 3, generator=g) * 1.5 / np.sqrt(27 * 8))     # (logit spread of a few units: a peaked softmax)
+    bias = torch.randn(1, generator=g)
+    dv = torch.stack([torch.linspace(2.0, 6.0, D), torch.linspace(1.0, 9.0, D)]).cuda().contiguous()
+    xcl = ops.to_channels_last(x.cuda(), dtype)
+    layer = ops.Conv3dLayer.build(w, kind=L.CONV_S1, device="cuda", conv_bias=bias, dtype=dtype)
+    L.set_tuning("c1_sweep", 2)
+    try:
+        fused = ops.prob_softargmin(xcl, layer, dv)
+        logits = ops.conv3d(xcl, layer, out_dtype=torch.float32).view(2, D, H, W)
+    finally:
+        L.set_tuning("c1_sweep", 1)
+    assert fused is not None
+    sep = ops.softargmin(logits, dv, want_conf=True, conf_mode=0)
+    assert torch.equal(fused["logits"], logits)
+    check_close(f"fused tail depth {shape} {dtype}", fused["depth"].cpu(), sep["depth"].cpu(), max_abs=2e-6 * 9.0)
+    check_close(f"fused tail confidence {shape} {dtype}", fused["conf"].cpu(), sep["conf"].cpu(), max_abs=2e-5)
+    # and against the definition
+    p = torch.softmax(logits.double(), 1)
+    check_close(f"fused tail depth vs softmax {shape}", fused["depth"].cpu(), (p * dv.double().view(2, D, 1, 1)).sum(1).float().cpu(), max_abs=2e-5 * 9.0)

@@ -185,3 +185,25 @@ def test_invalidate_after_a_write_through_dot_data(env):
     with torch.no_grad():
         w.mul_(-1.0)                                    # in-place op on the Parameter: version bump, no invalidate needed
     assert torch.equal(run(), d0)
+
+
+def test_fused_tail_option_equals_default_path(env):
+    """models.MVSNet.model.FUSED_TAIL (prob head + softmax regression through pscv_prob_softargmin; off by default because it measured
+    slower) gives the depth and confidence of the default path on a full forward."""
+    L, ops, synthetic, MVSNet, O = env
+    from wild_deep_mvs_amd.models.MVSNet import model as M
+    net, sd = _model(env, "variance", 0)
+    net.num_depth = 48
+    scene = synthetic.make_scene(1, 3, 64, 96, seed=2)
+    dev = {k: v.cuda() for k, v in scene.items()}
+    run = lambda: net(dev["imgs"], dev["K"], dev["R"], dev["t"], dev["depth_min"], dev["depth_max"])
+    want = run()
+    M.FUSED_TAIL = True
+    L.set_tuning("c1_sweep", 2)
+    try:
+        got = run()
+    finally:
+        M.FUSED_TAIL = False
+        L.set_tuning("c1_sweep", 1)
+    check_close("fused tail depth", got["depth"].cpu(), want["depth"].cpu(), max_abs=2e-5)
+    check_close("fused tail confidence", got["photometric_confidence"].cpu(), want["photometric_confidence"].cpu(), max_abs=5e-5)

@@ -32,7 +32,7 @@ EXPORTS = ("pscv_last_error", "pscv_abi_version", "pscv_set_tuning", "pscv_proj_
            "pscv_pack_conv3d_weights", "pscv_conv3d", "pscv_softargmin", "pscv_train_workspace_floats", "pscv_bn_stats",
            "pscv_bn_act", "pscv_bn_bwd_reduce", "pscv_bn_bwd_apply", "pscv_softargmin_bwd", "pscv_conv3d_wgrad_workspace",
            "pscv_conv3d_wgrad", "pscv_warp_cost_bwd", "pscv_cvp_depth_hypos", "pscv_relu_bwd", "pscv_fuse_pairs_bwd", "pscv_pack_conv3d_weights_device", "pscv_conv2d_ex", "pscv_variance_finish", "pscv_softargmin_window",
-           "pscv_photo_warp", "pscv_photo_warp_bwd", "pscv_ssim", "pscv_ssim_bwd", "pscv_bn_finalize", "pscv_bn_bwd_coeffs", "pscv_cvp_cams", "pscv_homography_warp")
+           "pscv_photo_warp", "pscv_photo_warp_bwd", "pscv_ssim", "pscv_ssim_bwd", "pscv_bn_finalize", "pscv_bn_bwd_coeffs", "pscv_cvp_cams", "pscv_homography_warp", "pscv_prob_softargmin", "pscv_prob_softargmin_workspace")
 
 
 class PscvMissingError(RuntimeError):
@@ -129,6 +129,10 @@ def _declare(lib):
     lib.pscv_conv3d_wgrad_workspace.argtypes = [i, i, i, i, i, i, i]
     lib.pscv_conv3d_wgrad.restype = i
     lib.pscv_conv3d_wgrad.argtypes = [vp, i, i, i, vp, i, i, i, i, i, i, i, i, i, vp, vp, i, vp]
+    lib.pscv_prob_softargmin_workspace.restype = C.c_long
+    lib.pscv_prob_softargmin_workspace.argtypes = [i, i, i, i]
+    lib.pscv_prob_softargmin.restype = i
+    lib.pscv_prob_softargmin.argtypes = [vp, i, i, i, vp, vp, vp, vp, i, i, vp, C.c_long, vp, vp, C.c_long, vp, vp, i, i, i, i, vp]
     lib.pscv_homography_warp.restype = i
     lib.pscv_homography_warp.argtypes = [vp, vp, i, vp, i, i, i, i, i, i, vp]
     lib.pscv_cvp_cams.restype = i

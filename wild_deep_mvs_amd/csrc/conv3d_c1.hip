@@ -52,6 +52,11 @@ struct C1Args {
     int epi;
     int nth, ntw, ndc, nb;   // tiles, depth chunks, 6-plane blocks per workgroup
     unsigned mg_th, mg_tw, mg_dc;
+    // fused softmax partials (depth-sweep variant only; null = off): per (batch, depth chunk, pixel) the running max, sum of
+    // exponentials, sum exp * depth plane and sum exp * plane index of the chunk's logits -- merged by softargmin_merge_kernel
+    const float* depth;      // [B][D] planes, row stride depth_bstride
+    long depth_bstride;
+    float* part;             // [B][ndc][4][Hh][W]
 };
 
 constexpr int C1_P = 6;                        // output planes per block (MFMA rows 0..5)
@@ -245,8 +250,8 @@ __global__ __launch_bounds__(256) void conv3d_c1_kernel(const C1Args a) {
 // A lane group reads two planes per block (4 (g >> 1) + (g & 1) and + 2): two ring addresses per block, taps as immediates.
 constexpr int C1S_NSLOT = 16;
 
-template <typename H>
-__global__ __launch_bounds__(256) void conv3d_c1_sweep_kernel(const C1Args a) {
+template <typename H, bool FUSE>      // FUSE: also keep the softmax statistics of the fused tail (its registers cost the plain head a wave per SIMD)
+__global__ __launch_bounds__(256, 3) void conv3d_c1_sweep_kernel(const C1Args a) {
     constexpr int VB = 16, NSTEPS = 18, PV = C1_BH * C1_BW, PSB = C1_PS * VB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [16 slots][C1_PS][16 B]
 
@@ -301,6 +306,10 @@ __global__ __launch_bounds__(256) void conv3d_c1_sweep_kernel(const C1Args a) {
     const float e_scale = a.scale ? a.scale[0] : 1.0f, e_bias = a.bias ? a.bias[0] : 0.0f, e_floor = a.floor ? a.floor[0] : 0.0f;
     const float lo_pre = (a.epi & PSCV_EPI_RELU_PRE) ? e_floor : -__builtin_inff();
     const float lo_post = (a.epi & PSCV_EPI_RELU_POST) ? 0.0f : -__builtin_inff();
+    // fused tail: the chunk's depth planes in LDS (a global load per block sat in the block's dependency chain: 59 us fused
+    // against 40 us for the two separate launches)
+    __shared__ float sdep[256];
+    if (FUSE && tid < 256) sdep[tid] = a.depth[(long)b * a.depth_bstride + min(dbeg + tid, a.D - 1)];
     __syncthreads();
     PSCV_STAMP(0)
 
@@ -315,6 +324,9 @@ __global__ __launch_bounds__(256) void conv3d_c1_sweep_kernel(const C1Args a) {
     const unsigned ostep = (unsigned)a.out_cs * (unsigned)OB;
     const unsigned ooff_g = (pix0 * (unsigned)a.out_cs + (unsigned)a.out_co) * (unsigned)OB + (unsigned)(4 * g) * (unsigned)out_plane;
     const bool tile_full = w0 + C1_TW <= a.W && !a.skip && oh < a.Hh;
+    // running softmax statistics of this lane's own logits (planes d0 + 4 g + r of pixels (oh, w0 + ct * 16 + n)), merged across the two
+    // lane groups once per chunk
+    float sM[2] = {-__builtin_inff(), -__builtin_inff()}, sZ[2] = {0.f, 0.f}, sD[2] = {0.f, 0.f}, sI[2] = {0.f, 0.f};
 
     for (int k = 0; k < nbk; ++k) {
         const int d0 = dbeg + k * C1_P;
@@ -389,6 +401,40 @@ __global__ __launch_bounds__(256) void conv3d_c1_sweep_kernel(const C1Args a) {
                 }
             }
         }
+        if (FUSE && g < 2) {
+            // fused tail: fold the block's logits (fp32, before any store rounding) into the lane's softmax statistics
+            float dpl[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dpl[r] = sdep[min(k * C1_P + 4 * g + r, 255)];
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                float yv[4];
+                bool ok[4];
+                float lmax = -__builtin_inff();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = 4 * g + r;
+                    ok[r] = m < C1_P && d0 + m < a.D;
+                    yv[r] = clamp_lo(clamp_lo(fmaf(ct ? acc1[r] : acc0[r], e_scale, e_bias), lo_pre), lo_post);
+                    if (ok[r]) lmax = fmaxf(lmax, yv[r]);
+                }
+                if (lmax > -__builtin_inff()) {
+                    const float mn = fmaxf(sM[ct], lmax);
+                    const float sc = sM[ct] > -__builtin_inff() ? __expf(sM[ct] - mn) : 0.0f;
+                    float z = sZ[ct] * sc, sd = sD[ct] * sc, si = sI[ct] * sc;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (ok[r]) {
+                            const float e = __expf(yv[r] - mn);
+                            z += e;
+                            sd = fmaf(e, dpl[r], sd);
+                            si = fmaf(e, (float)(d0 + 4 * g + r), si);
+                        }
+                    }
+                    sM[ct] = mn; sZ[ct] = z; sD[ct] = sd; sI[ct] = si;
+                }
+            }
+        }
         PSCV_STAMP(2)
         // the planes of block k + 1 into the slots nobody reads now; their registers are refilled with the planes of block k + 2
         if (k + 1 < nbk) {
@@ -402,8 +448,60 @@ __global__ __launch_bounds__(256) void conv3d_c1_sweep_kernel(const C1Args a) {
         __syncthreads();
         PSCV_STAMP(4)
     }
+    if (FUSE) {
+        // merge the lane groups g = 0 (rows 0..3) and g = 1 (rows 4, 5) of every pixel: lane n + 16 -> lane n; lanes g = 0 write
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const float m1 = __shfl_down(sM[ct], 16, 64), z1 = __shfl_down(sZ[ct], 16, 64);
+            const float d1 = __shfl_down(sD[ct], 16, 64), i1 = __shfl_down(sI[ct], 16, 64);
+            const float mn = fmaxf(sM[ct], m1);
+            const float f0 = sM[ct] > -__builtin_inff() ? __expf(sM[ct] - mn) : 0.0f, f1 = m1 > -__builtin_inff() ? __expf(m1 - mn) : 0.0f;
+            const int ow = w0 + ct * 16 + n;
+            if (g == 0 && oh < a.Hh && ow < a.W) {
+                const long hw = (long)a.Hh * a.W;
+                float* pp = a.part + (((long)b * a.ndc + dci) * 4) * hw + (long)oh * a.W + ow;
+                pp[0] = mn;
+                pp[hw] = sZ[ct] * f0 + z1 * f1;
+                pp[2 * hw] = sD[ct] * f0 + d1 * f1;
+                pp[3 * hw] = sI[ct] * f0 + i1 * f1;
+            }
+        }
+    }
     PSCV_PROF_END(c1, blockIdx.x)
 }
+
+// Merge of the per-chunk softmax partials written by the sweep above + the 4-plane photometric confidence from the fp32 logits:
+// depth = sum p_d depth_d, confidence = sum of p over planes i-1 .. i+2 around i = trunc(E[index]) (zero padded).
+// Replaces (fdarmon/wild_deep_mvs): F.softmax + depth_regression + confidence, models/MVSNet/model.py:207-215.
+__global__ __launch_bounds__(256) void softargmin_merge_kernel(const float* __restrict__ part, const float* __restrict__ logits, int ndc, int B,
+                                                                int D, long hw, float* __restrict__ o_depth, float* __restrict__ o_conf) {
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= (long)B * hw) return;
+    const int b = (int)(p / hw);
+    const long pf = p - (long)b * hw;
+    const float* pp = part + ((long)b * ndc * 4) * hw + pf;
+    float M = -__builtin_inff();
+    for (int c = 0; c < ndc; ++c) M = fmaxf(M, pp[(long)c * 4 * hw]);
+    float Z = 0.f, SD = 0.f, SI = 0.f;
+    for (int c = 0; c < ndc; ++c) {
+        const float* q = pp + (long)c * 4 * hw;
+        const float f = expf(q[0] - M);
+        Z = fmaf(q[hw], f, Z); SD = fmaf(q[2 * hw], f, SD); SI = fmaf(q[3 * hw], f, SI);
+    }
+    const float inv = 1.0f / Z;
+    if (o_depth) o_depth[p] = SD * inv;
+    if (o_conf) {
+        const int i = (int)(SI * inv);
+        const float* lp = logits + (long)b * D * hw + pf;
+        float c = 0.f;
+        for (int k = -1; k <= 2; ++k) {
+            const int d = i + k;
+            if (d >= 0 && d < D) c += expf(lp[(long)d * hw] - M) * inv;
+        }
+        o_conf[p] = c;
+    }
+}
+
 
 template <typename H, int CIN>
 static int c1_launch(const C1Args& a, long nblk, hipStream_t st) {
@@ -423,12 +521,16 @@ thread_local int g_c1_nb = 0;
 thread_local int g_c1_sweep = 1;   // pscv_set_tuning("c1_sweep", 0): always the brick variant; 2: the depth sweep at any depth
 PSCV_PROF_EXPORT(c1)
 
-int pscv_conv3d_c1_launch(const void* in, int dtype, int in_cstride, int in_coff, const uint16_t* packed,
-                          const float* scale, const float* bias, const float* floor, const void* skip, int skip_cstride, int skip_coff, void* out,
-                          int out_cstride, int out_coff, int out_dtype, int B, int D, int Hh, int W, int c_in,
-                          int epi_flags, hipStream_t st) {
+// depth / part / merged outputs non-null: the fused tail (pscv_prob_softargmin); returns 1 when the layer does not get the depth-sweep
+// variant (the caller then runs the two separate entry points), 0 on success, < 0 on error
+static int c1_dispatch(const void* in, int dtype, int in_cstride, int in_coff, const uint16_t* packed,
+                       const float* scale, const float* bias, const float* floor, const void* skip, int skip_cstride, int skip_coff, void* out,
+                       int out_cstride, int out_coff, int out_dtype, int B, int D, int Hh, int W, int c_in,
+                       int epi_flags, hipStream_t st, const float* depth, long depth_bstride, float* part, long part_floats,
+                       float* o_depth, float* o_conf) {
     using namespace pscv;
     C1Args a;
+    a.depth = depth; a.depth_bstride = depth_bstride; a.part = nullptr;
     a.in = reinterpret_cast<const uint16_t*>(in);
     a.wpk = reinterpret_cast<const uint4*>(packed);
     a.skip = reinterpret_cast<const uint16_t*>(skip);
@@ -458,10 +560,25 @@ int pscv_conv3d_c1_launch(const void* in, int dtype, int in_cstride, int in_coff
     const long nblk = tiles * a.ndc;
     a.mg_th = fast_div_magic(a.nth); a.mg_tw = fast_div_magic(a.ntw); a.mg_dc = fast_div_magic(a.ndc);
     if (nblk <= 0 || nblk > 0x7fffffffL) { set_error("pscv_conv3d(c1): bad grid %ld", nblk); return -1; }
+    if (part) {
+        if (!sweep || skip || out_dtype != PSCV_F32 || out_cstride != 1 || a.nb * C1_P > 256) return 1;
+        if ((long)B * a.ndc * 4 * Hh * W > part_floats) { set_error("pscv_prob_softargmin: workspace of %ld floats is too small", part_floats); return -1; }
+        a.part = part;
+    }
     if (sweep) {
         const size_t lds = (size_t)C1S_NSLOT * C1_PS * 16;
-        if (dtype == PSCV_BF16) hipLaunchKernelGGL(conv3d_c1_sweep_kernel<bf16_t>, dim3((unsigned)nblk), dim3(256), lds, st, a);
-        else hipLaunchKernelGGL(conv3d_c1_sweep_kernel<f16_t>, dim3((unsigned)nblk), dim3(256), lds, st, a);
+        if (part) {
+            if (dtype == PSCV_BF16) hipLaunchKernelGGL((conv3d_c1_sweep_kernel<bf16_t, true>), dim3((unsigned)nblk), dim3(256), lds, st, a);
+            else hipLaunchKernelGGL((conv3d_c1_sweep_kernel<f16_t, true>), dim3((unsigned)nblk), dim3(256), lds, st, a);
+        } else {
+            if (dtype == PSCV_BF16) hipLaunchKernelGGL((conv3d_c1_sweep_kernel<bf16_t, false>), dim3((unsigned)nblk), dim3(256), lds, st, a);
+            else hipLaunchKernelGGL((conv3d_c1_sweep_kernel<f16_t, false>), dim3((unsigned)nblk), dim3(256), lds, st, a);
+        }
+        if (part) {
+            const long npix = (long)B * Hh * W;
+            hipLaunchKernelGGL(softargmin_merge_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, part, reinterpret_cast<const float*>(out),
+                               a.ndc, B, D, (long)Hh * W, o_depth, o_conf);
+        }
         return 0;
     }
     if (dtype == PSCV_BF16 && c_in == 8) return c1_launch<bf16_t, 8>(a, nblk, st);
@@ -470,4 +587,34 @@ int pscv_conv3d_c1_launch(const void* in, int dtype, int in_cstride, int in_coff
     if (dtype == PSCV_F16 && c_in == 16) return c1_launch<f16_t, 16>(a, nblk, st);
     set_error("pscv_conv3d(c1): c_in=%d dtype=%d not supported (c_in 8 or 16)", c_in, dtype);
     return -1;
+}
+
+int pscv_conv3d_c1_launch(const void* in, int dtype, int in_cstride, int in_coff, const uint16_t* packed,
+                          const float* scale, const float* bias, const float* floor, const void* skip, int skip_cstride, int skip_coff, void* out,
+                          int out_cstride, int out_coff, int out_dtype, int B, int D, int Hh, int W, int c_in,
+                          int epi_flags, hipStream_t st) {
+    return c1_dispatch(in, dtype, in_cstride, in_coff, packed, scale, bias, floor, skip, skip_cstride, skip_coff, out, out_cstride, out_coff,
+                       out_dtype, B, D, Hh, W, c_in, epi_flags, st, nullptr, 0, nullptr, 0, nullptr, nullptr);
+}
+
+extern "C" long pscv_prob_softargmin_workspace(int B, int D, int H, int W) {
+    return (long)B * ((D + pscv::C1_P - 1) / pscv::C1_P) * 4 * H * W;     // floats: one partial set per 6-plane block at most
+}
+
+extern "C" int pscv_prob_softargmin(const void* in, int dtype, int in_cstride, int in_coff, const uint16_t* packed, const float* scale,
+                                    const float* bias, const float* floor, int c_in, int epi_flags, const float* depth, long depth_bstride,
+                                    float* logits, float* workspace, long workspace_floats, float* out_depth, float* out_conf, int B, int D,
+                                    int H, int W, void* stream) {
+    using namespace pscv;
+    PSCV_CHECK_ARG(in && packed && depth && logits && workspace && out_depth, "pscv_prob_softargmin: null pointer argument");
+    PSCV_CHECK_ARG(B > 0 && D > 0 && H > 0 && W > 0, "pscv_prob_softargmin: bad sizes");
+    PSCV_CHECK_ARG(dtype == PSCV_BF16 || dtype == PSCV_F16, "pscv_prob_softargmin: storage dtype %d must be bf16 or fp16", dtype);
+    PSCV_CHECK_ARG(in_cstride % 8 == 0 && in_coff % 8 == 0 && in_coff + c_in <= in_cstride, "pscv_prob_softargmin: input channel slice must be 8-aligned");
+    const int rc = c1_dispatch(in, dtype, in_cstride, in_coff, packed, scale, bias, floor, nullptr, 0, 0, logits, 1, 0, PSCV_F32, B, D, H, W, c_in,
+                               epi_flags, reinterpret_cast<hipStream_t>(stream), depth, depth_bstride, workspace, workspace_floats, out_depth,
+                               out_conf);
+    if (rc < 0) return rc;
+    if (rc == 1) { set_error("pscv_prob_softargmin: this layer does not run the depth-sweep head (needs c_in = 8 and a depth axis of >= 3 six-plane blocks per chunk); use pscv_conv3d + pscv_softargmin"); return -3; }
+    PSCV_CHECK_LAUNCH("pscv_prob_softargmin");
+    return 0;
 }

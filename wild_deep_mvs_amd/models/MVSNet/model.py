@@ -84,6 +84,15 @@ def _deconv_block(ci: int, co: int) -> nn.Sequential:
                          nn.BatchNorm3d(co), nn.ReLU(inplace=True))
 
 
+# prob head + softmax regression as ONE fused tail (ops.prob_softargmin: the head's depth sweep keeps running softmax statistics and a
+# merge launch finishes them).  Built, parity-tested (tests/test_gpu_conv3d.py, tests/test_gpu_mvsnet.py) and measured SLOWER than the two
+# separate launches at the headline size: 52.5 us against 26.0 + 13.5 us (same box, both at three waves per SIMD).  The head's sweep is instruction-issue bound (three resident
+# workgroups per CU, ~250 instructions per 6-plane block in one dependency chain); the ~100 extra vector instructions per block of
+# the online softmax lengthen exactly that chain, while the stand-alone softargmin pass is latency bound with an idle vector ALU.
+# So the default stays off.
+FUSED_TAIL = False
+
+
 class CostRegNet(nn.Module):
     """3-D U-Net regulariser (reference models/MVSNet/model.py:43-84) on MFMA conv3d launches.
 
@@ -139,7 +148,10 @@ class CostRegNet(nn.Module):
         blocks.append(T.Block("prob", prev, self.prob.weight, bn=None, relu=False, conv_bias=self.prob.bias))
         return blocks
 
-    def forward(self, cost: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
+    def forward(self, cost: torch.Tensor, taps: Optional[dict] = None, regress: Optional[torch.Tensor] = None):
+        """cost [B,D,h,w,32] -> fp32 logits [B,D,h,w].  With ``regress`` = the per-batch depth planes [B,D], the tail runs fused
+        (``ops.prob_softargmin``: the prob head emits softmax partials, one merge launch gives depth and confidence) and the
+        return value is (logits, {"depth", "conf"}); sizes the fused head does not take fall back to the two separate launches."""
         if self.training:
             raise RuntimeError("pscv CostRegNet: in train() mode the U-Net runs inside training.RegressFn (MVSNet.forward "
                                "routes there); this entry point is the eval-mode engine")
@@ -154,10 +166,15 @@ class CostRegNet(nn.Module):
         u7 = ops.conv3d(c6, ly["conv7"], skip=c4)      # conv4 + relu(bn(deconv))     model.py:79
         u9 = ops.conv3d(u7, ly["conv9"], skip=c2)      # model.py:80
         u11 = ops.conv3d(u9, ly["conv11"], skip=c0)    # model.py:81
-        logits = ops.conv3d(u11, ly["prob"], out_dtype=torch.float32)
+        fused = ops.prob_softargmin(u11, ly["prob"], regress) if regress is not None and FUSED_TAIL else None
+        logits = fused["logits"] if fused is not None else ops.conv3d(u11, ly["prob"], out_dtype=torch.float32).view(B, D, h, w)
         if taps is not None:
             taps.update(conv0=c0, conv2=c2, conv4=c4, conv6=c6, up7=u7, up9=u9, up11=u11)
-        return logits.view(B, D, h, w)
+        if regress is None:
+            return logits
+        if fused is None:
+            fused = ops.softargmin(logits, regress, want_conf=True, conf_mode=0)
+        return logits, {"depth": fused["depth"], "conf": fused["conf"]}
 
 
 class MVSNet(nn.Module):
@@ -259,8 +276,7 @@ class MVSNet(nn.Module):
         cams = ops.proj_cams_device(proj.to(torch.float32).contiguous(), reference_frame)
         cost = self.build_cost_volume(features_cl[reference_frame], [features_cl[i] for i in src_idx],
                                       proj[:, reference_frame], [proj[:, i] for i in src_idx], depth_values, cams)
-        logits = self.cost_regularization(cost, taps)
-        o = ops.softargmin(logits, depth_values, want_conf=True, conf_mode=0)
+        logits, o = self.cost_regularization(cost, taps, regress=depth_values.to(torch.float32).contiguous())
         if taps is not None:
             taps.update(cost_volume=cost, logits=logits)
         return o["depth"], o["conf"]

@@ -622,6 +622,40 @@ def softargmin(logits: torch.Tensor, depth: Optional[torch.Tensor] = None, *, wa
     return {k: v for k, v in o.items() if v is not None}
 
 
+_tail_ws: dict = {}
+
+
+def prob_softargmin(x: torch.Tensor, layer: "Conv3dLayer", depth: torch.Tensor, *, in_coff: int = 0, want_conf: bool = True):
+    """Fused tail of the MVSNet regulariser (pscv_prob_softargmin): x [B,D,h,w,Cs] 16-bit -> the 1-channel head ``layer`` (kind
+    S1C1, c_in 8) -> fp32 logits [B,D,h,w] + depth [B,h,w] (+ 4-plane confidence), with per-batch depth planes ``depth`` [B,D].
+    Returns None when the layer / size does not run the depth-sweep head (call ``conv3d`` + ``softargmin`` then)."""
+    _dev(x, depth, layer.packed)
+    if layer.kind != L.CONV_S1C1 or layer.c_in != 8 or x.dtype != layer.dtype or x.dim() != 5 or depth.dim() != 2 \
+            or depth.dtype != torch.float32:
+        return None
+    B, D, H, W, cs = x.shape
+    if tuple(depth.shape) != (B, D) or D < 18:
+        return None
+    n = int(L.lib().pscv_prob_softargmin_workspace(B, D, H, W))
+    ws = _tail_ws.get(x.device)
+    if ws is None or ws.numel() < n:
+        ws = torch.empty(n, dtype=torch.float32, device=x.device)
+        _tail_ws[x.device] = ws
+    logits = torch.empty((B, D, H, W), dtype=torch.float32, device=x.device)
+    o_depth = torch.empty((B, H, W), dtype=torch.float32, device=x.device)
+    o_conf = torch.empty((B, H, W), dtype=torch.float32, device=x.device) if want_conf else None
+    rc = _launch("prob_softargmin", lambda: L.lib().pscv_prob_softargmin(
+        _p(x), _dt(x), cs, in_coff, _p(layer.packed), _p(layer.scale), _p(layer.bias), _p(layer.floor), layer.c_in, layer.epi,
+        _p(depth), depth.stride(0), _p(logits), _p(ws), ws.numel(), _p(o_depth), _p(o_conf), B, D, H, W, _stream()))
+    if rc == -3:
+        return None
+    L.check(rc, "pscv_prob_softargmin")
+    out = {"logits": logits, "depth": o_depth}
+    if want_conf:
+        out["conf"] = o_conf
+    return out
+
+
 def softargmin_window(logits: torch.Tensor, stats: torch.Tensor, *, window: float, index_offset: int) -> torch.Tensor:
     """One depth shard's part of the +-window probability under globally merged softmax statistics: logits fp32 [B,D,h,w] (this
     shard's planes), stats fp32 [B,3,h,w] = (max, sum exp, expected index) -> fp32 [B,h,w] (pscv_softargmin_window)."""
