@@ -391,6 +391,18 @@ def test_stride2_sweep_kernel_matches_brick_kernel_and_aten(env, cout, shape, dc
     ulp = 0.0 if out_f32 else (2 ** -8 if dtype == torch.bfloat16 else 2 ** -11)
     check_close(f"s2 sweep vs ATen {shape} -> {cout} {dtype}", outs[2], ref, max_abs=ulp * float(ref.abs().max()) + 2e-3)
     check_close(f"s2 sweep vs brick {shape} -> {cout} {dtype}", outs[2], outs[0], max_abs=ulp * float(ref.abs().max()) + 1e-4)
+    # the models' call: no skip tensor, 16-bit output (the kernel's straight-line epilogue instantiation)
+    plain = {}
+    ref_plain = F.relu(F.batch_norm(conv, mean, var, gamma, beta, training=False, eps=1e-5))
+    for sweep in (2, 0):
+        L.set_tuning("conv_s2_sweep", sweep)
+        try:
+            plain[sweep] = ops.conv3d(xcl, layer, in_coff=8).float().permute(0, 4, 1, 2, 3).cpu()
+        finally:
+            L.set_tuning("conv_s2_sweep", 1)
+    u16 = 2 ** -8 if dtype == torch.bfloat16 else 2 ** -11
+    check_close(f"s2 sweep (plain) vs ATen {shape} -> {cout} {dtype}", plain[2], ref_plain, max_abs=u16 * float(ref_plain.abs().max()) + 2e-3)
+    check_close(f"s2 sweep (plain) vs brick {shape} -> {cout} {dtype}", plain[2], plain[0], max_abs=u16 * float(ref_plain.abs().max()) + 1e-4)
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])

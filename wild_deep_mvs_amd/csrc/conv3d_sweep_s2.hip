@@ -65,7 +65,8 @@ constexpr int S2S_STEPS = 7;                         // ceil(27 taps x 8 ch / 32
 constexpr long S2S_MIN_VOXELS = 65536;
 PSCV_PROF_BUFFER(s2s)
 
-template <typename H, int NT>
+// PLAIN: no skip tensor and 16-bit output (every call of the models): the epilogue is straight-line code without the two branches
+template <typename H, int NT, bool PLAIN>
 __global__ __launch_bounds__(256) void conv3d_sweep_s2_kernel(const S2sArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nwg = gridDim.x, bid = blockIdx.x;
@@ -224,6 +225,13 @@ __global__ __launch_bounds__(256) void conv3d_sweep_s2_kernel(const S2sArgs a) {
                         float y[4];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) y[k] = clamp_lo(fmaf(acc[r][m][k], sc[m][k], bi[m][k]), fl[m][k]);
+                        if constexpr (PLAIN) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) y[k] = clamp_lo(y[k], lo_post);
+                            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.out) + obase + lane_out[r] + m * 16) =
+                                make_uint2(Half16<H>::pack_ovfl(y[0], y[1]), Half16<H>::pack_ovfl(y[2], y[3]));
+                            continue;
+                        }
                         uint2 sv = make_uint2(0u, 0u);
                         if (a.skip) sv = *reinterpret_cast<const uint2*>(a.skip + sbase + lane_skip[r] + m * 16);
                         y[0] = clamp_lo(y[0] + Half16<H>::lo(sv.x), lo_post); y[1] = clamp_lo(y[1] + Half16<H>::hi(sv.x), lo_post);
@@ -247,8 +255,8 @@ __global__ __launch_bounds__(256) void conv3d_sweep_s2_kernel(const S2sArgs a) {
 
 template <typename H, int NT>
 static int s2s_launch(const S2sArgs& a, long nblk, hipStream_t st) {
-    auto kern = conv3d_sweep_s2_kernel<H, NT>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), S2S_NSLOT * S2S_PB, st, a);
+    if (!a.skip && !a.out_f32) hipLaunchKernelGGL((conv3d_sweep_s2_kernel<H, NT, true>), dim3((unsigned)nblk), dim3(256), S2S_NSLOT * S2S_PB, st, a);
+    else hipLaunchKernelGGL((conv3d_sweep_s2_kernel<H, NT, false>), dim3((unsigned)nblk), dim3(256), S2S_NSLOT * S2S_PB, st, a);
     return 0;
 }
 
