@@ -41,11 +41,22 @@ def _dev(*ts: Optional[torch.Tensor]):
 
 
 def _p(t: Optional[torch.Tensor]):
-    return C.c_void_p(0 if t is None else t.data_ptr())
+    """Device address for a ``c_void_p`` parameter (every entry point declares its argtypes): the plain integer / None -- ctypes
+    converts it at the call; building a ``c_void_p`` object per pointer cost ~2 us per launch."""
+    return None if t is None else t.data_ptr()
+
+
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """Raw handle of the current HIP stream.  ``torch.cuda.current_stream()`` builds a Stream object through several Python layers
+    (~4-7 us per call -- more than the ctypes launch itself, and a forward of Vis-MVSNet makes ~300 launches); the C-level accessor
+    is the same query without the object."""
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
+    return torch.cuda.current_stream().cuda_stream
 
 
 class EventTimer:
