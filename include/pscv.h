@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PSCV_ABI_VERSION 2
+#define PSCV_ABI_VERSION 3
 
 /* storage dtypes */
 #define PSCV_F32 0

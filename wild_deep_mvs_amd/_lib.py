@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libpscv.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 # mirror of include/pscv.h
-ABI_VERSION = 2
+ABI_VERSION = 3
 F32, BF16, F16 = 0, 1, 2
 GEOM_PROJ, GEOM_HOMOG = 0, 1
 COST_VARIANCE, COST_VARIANCE_CVP, COST_SOFTMIN, COST_GROUPCORR, COST_WARP_ONLY, COST_VARIANCE_PARTIAL = 0, 1, 2, 3, 4, 5
