@@ -6,8 +6,11 @@ softmax / depth regression / confidence) over one batch of synthetic input that 
 HBM: BASELINE.json configs[1] = MVSNet, 1 ref + 4 src views, 512x640 images (128x160x32 feature maps),
 D = 192 planes, bf16 storage / fp32 accumulation.  3 932 160 cost-volume voxels per reference view.
 
-Multi-GPU (--gpus N, one process per GPU via torch.distributed.run): reference views are independent
-objects, so each rank sweeps its own view (global batch = N) with no data-path collective -> weak scaling.
+Multi-GPU (--gpus N, one process per GPU): reference views are independent objects, so each rank sweeps its own
+view (global batch = N) with no data-path collective -> weak scaling.  Ranks come either from a launcher
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`: RANK / WORLD_SIZE / MASTER_* in the
+environment) or, when WORLD_SIZE is unset, from bench.py itself (`python bench.py --gpus N` spawns its N ranks the
+way the reference's train.py / depthmap_eval.py do with mp.spawn).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     the dominant kernel's achieved algorithmic GB/s vs the HBM peak (HIP events on the launch stream)
@@ -144,21 +147,42 @@ SHARDED = {
 }
 
 
+def _all_ok(dist, device, ok: bool) -> bool:
+    """True iff every rank reports ``ok`` (one MIN all-reduce of a flag): ranks agree to skip a leg together instead of one of them
+    raising while the others wait inside the next collective."""
+    flag = torch.tensor([1 if ok else 0], device=device, dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item())
+
+
 def sharded_legs(dist, device, world, rank, reps=5):
     """N > 1 only, after the headline region: ONE reference view computed cooperatively by all ranks (strong scaling) through the
     two shardings of the path that need a collective -- ``Frontend.set_depth_group`` and ``Frontend.set_view_group`` -- over
     RCCL.  Every rank runs the forward; times are the max over ranks; a second, traced pass attributes time and bytes to each
-    collective (wild_deep_mvs_amd.dist.CollectiveTrace).  Returns a dict for rank 0's JSON line (None elsewhere)."""
+    collective (wild_deep_mvs_amd.dist.CollectiveTrace).  Returns a dict for rank 0's JSON line (None elsewhere).
+
+    Failure handling: the set-up of a leg (model, scene: where an out-of-memory would strike) is agreed on across the ranks before
+    the first collective of the leg; a failure INSIDE a collective is bounded by the process group's timeout (``rendezvous``)."""
     from wild_deep_mvs_amd.dist import CollectiveTrace
     from wild_deep_mvs_amd.models.VisMVSNet.frontend import Frontend
     out = {}
     for mode, cfg in SHARDED.items():
+        net = scene = None
+        err = None
         try:
             net = Frontend()
             net.load_state_dict(synthetic.sharpened_state_dict("vis", synthetic.template_of(net), seed=0))
             net = net.to(device).eval()
             scene = {k: v.to(device) for k, v in synthetic.make_scene(1, cfg["V"], cfg["H"], cfg["W"], seed=cfg["config"]).items()}
-            call = lambda: net(scene["imgs"], scene["K"], scene["R"], scene["t"], scene["depth_min"], scene["depth_max"], **cfg["kw"])
+        except Exception as e:   # pragma: no cover
+            err = f"setup: {type(e).__name__}: {e}"[:300]
+        if not _all_ok(dist, device, err is None):
+            out[mode] = {"error": err or "setup failed on another rank"}
+            del net, scene
+            torch.cuda.empty_cache()
+            continue
+        call = lambda: net(scene["imgs"], scene["K"], scene["R"], scene["t"], scene["depth_min"], scene["depth_max"], **cfg["kw"])
+        try:
             times = {}
             for label, group in (("unsharded_replicated", None), ("sharded", dist.group.WORLD)):
                 (net.set_depth_group if mode == "depth" else net.set_view_group)(group)
@@ -166,12 +190,14 @@ def sharded_legs(dist, device, world, rank, reps=5):
                     call(); call()
                     dist.barrier(); torch.cuda.synchronize()
                     gc.collect(); gc.disable()
-                    t0 = time.perf_counter()
-                    for _ in range(reps):
-                        depth = call()["depth"]
-                    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-                    dt = (time.perf_counter() - t0) / reps
-                    gc.enable()
+                    try:
+                        t0 = time.perf_counter()
+                        for _ in range(reps):
+                            depth = call()["depth"]
+                        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+                        dt = (time.perf_counter() - t0) / reps
+                    finally:
+                        gc.enable()
                 tm = torch.tensor([dt], device=device, dtype=torch.float64)
                 dist.all_reduce(tm, op=dist.ReduceOp.MAX)
                 times[label] = float(tm.item())
@@ -180,20 +206,23 @@ def sharded_legs(dist, device, world, rank, reps=5):
             with torch.no_grad(), CollectiveTrace() as tr:
                 call()
             rel = float((depth - ref_depth).abs().mean() / ref_depth.abs().mean())
+            coll = tr.summary()
             out[mode] = {"config": cfg["config"], "model": "vis", "views": cfg["V"], "image": [cfg["H"], cfg["W"]], "kwargs": cfg["kw"],
                          "scaling": "strong", "ms_per_forward_1gpu": times["unsharded_replicated"] * 1e3,
                          "ms_per_forward_sharded": times["sharded"] * 1e3, "n_gpus": world,
                          "voxels_per_s": cfg["vox"] / times["sharded"], "speedup_vs_1gpu": times["unsharded_replicated"] / times["sharded"],
-                         "depth_rel_l1_vs_unsharded": rel, "collectives": tr.summary(),
+                         "depth_rel_l1_vs_unsharded": rel, "collectives": coll,
+                         "collective_bytes_per_rank_per_forward": sum(c["bytes_per_rank"] * c["calls"] for c in coll),
+                         "collective_ms_per_forward": sum(c["avg_us"] * c["calls"] for c in coll) * 1e-3,
                          "timed": "full forward() incl. 2-D feature nets, eager launches, max over ranks"}
-            del net, scene
-            torch.cuda.empty_cache()
         except Exception as e:   # pragma: no cover  (never lose the headline line to a side measurement)
             out[mode] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        del net, scene
+        torch.cuda.empty_cache()
     return out if rank == 0 else None
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -206,17 +235,82 @@ def main():
     ap.add_argument("--dump-events", default=None, help="write every per-launch event duration to this file")
     ap.add_argument("--eager", action="store_true", help="time eager launches instead of hipGraph replays")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="pscv_set_tuning knob (measurement runs)")
-    args = ap.parse_args()
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend of an N > 1 run (nccl = RCCL over xGMI; gloo only "
+                                                      "for the CPU rendezvous test)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="N > 1: start the ranks, join the process group, run one all-reduce, print a one-line report and exit "
+                         "(tests/test_dist_cpu.py drives this with --backend gloo on CPU)")
+    return ap.parse_args(argv)
 
+
+def _free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _spawned_rank(local_rank: int, args, port: int):
+    """Entry point of one self-spawned rank: the environment torch.distributed.run would have set, then the same ``run``."""
+    os.environ.update(RANK=str(local_rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(args.gpus),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
+    run(args)
+
+
+def spawn_ranks(args):
+    """``python bench.py --gpus N`` without a launcher: start the N ranks here, one process per GPU, the way the reference
+    starts its own (train.py:52-59,315 and depthmap_eval.py:200: ``mp.spawn(main, nprocs=world_size)`` + a localhost TCP
+    rendezvous).  Under ``python -m torch.distributed.run`` WORLD_SIZE is already set and this is skipped."""
+    import torch.multiprocessing as mp
+    mp.spawn(_spawned_rank, args=(args, _free_port()), nprocs=args.gpus, join=True)
+
+
+def rendezvous(args):
+    """(dist module or None, world, rank, local_rank) from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launcher and flag disagree)")
+    if world == 1:
+        return None, 1, 0, local_rank
+    import datetime
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    kw = {"device_id": torch.device("cuda", local_rank)} if args.backend == "nccl" else {}
+    # bounded: a rank that dies inside a collective must not leave the others waiting forever
+    dist.init_process_group(args.backend, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=10), **kw)
+    return dist, world, rank, local_rank
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
+        return
+    run(args)
+
+
+def run(args):
+    dist, world, rank, local_rank = rendezvous(args)
+    if args.rendezvous_only:
+        on_gpu = args.backend == "nccl"
+        if on_gpu:
+            torch.cuda.set_device(local_rank)
+        x = torch.full((4,), float(rank + 1), device=torch.device("cuda", local_rank) if on_gpu else "cpu")
+        if dist is not None:
+            dist.all_reduce(x)
+        if rank == 0:
+            print(json.dumps({"rendezvous": "ok", "world": world, "backend": args.backend if dist is not None else None,
+                              "allreduce": float(x[0]), "launcher": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ
+                              else ("self-spawned" if world > 1 else "none")}), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 

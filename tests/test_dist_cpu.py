@@ -86,3 +86,45 @@ def test_merge_is_exact_for_unequal_maxima():
     d, i = pdist.merge_partials_local(parts)
     p = torch.softmax(logits, 1)
     np.testing.assert_allclose(d.numpy(), (p * depth.view(1, -1, 1, 1)).sum(1).numpy(), atol=1e-6)
+
+
+# ---- bench.py's N > 1 entry point: it must start by itself (the reference spawns its own ranks: train.py:52-59,315) ----------
+def _run_bench(cmd, env_extra=None, timeout=240):
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable] + cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=timeout)
+    return p
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus2_spawns_its_own_ranks_and_joins_the_process_group():
+    """``python bench.py --gpus 2`` with NO launcher: bench.py spawns two ranks, they rendezvous on 127.0.0.1 (gloo here,
+    RCCL on a GPU node) and one all-reduce goes round; rank 0 prints one JSON line.  Round 2's bench.py aborted here."""
+    import json
+    p = _run_bench(["bench.py", "--gpus", "2", "--backend", "gloo", "--rendezvous-only"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    rec = json.loads(lines[0])
+    assert rec == {"rendezvous": "ok", "world": 2, "backend": "gloo", "allreduce": 3.0, "launcher": "self-spawned"}
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus2_under_torch_distributed_run():
+    """The driver's form: ``python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`` keeps working."""
+    import json
+    p = _run_bench(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                    "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--backend", "gloo", "--rendezvous-only"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    rec = json.loads(lines[0])
+    assert rec["world"] == 2 and rec["allreduce"] == 3.0 and rec["launcher"] == "torch.distributed.run"
+
+
+def test_bench_refuses_a_launcher_that_disagrees_with_gpus_flag():
+    p = _run_bench(["bench.py", "--gpus", "2", "--backend", "gloo", "--rendezvous-only"], env_extra={"WORLD_SIZE": "1", "RANK": "0"})
+    assert p.returncode != 0 and "WORLD_SIZE=1" in (p.stderr + p.stdout)
