@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PSCV_ABI_VERSION 3
+#define PSCV_ABI_VERSION 4
 
 /* storage dtypes */
 #define PSCV_F32 0
@@ -73,9 +73,9 @@ extern "C" {
 const char* pscv_last_error(void);
 int pscv_abi_version(void);
 
-/* Tuning knobs for measurement runs (not part of the reference's surface).  Every knob is THREAD-LOCAL: a value set by one host
- * thread steers only the launches that thread issues afterwards (one stream / one DataParallel replica per thread), other threads
- * keep the defaults, and there is no shared mutable state between launching threads.  Keys:
+/* Tuning knobs for measurement runs (not part of the reference's surface).  A knob holds ONE process-wide value (a relaxed
+ * atomic; every launching host thread reads it, including PyTorch's autograd thread and DataParallel's replica threads) and an
+ * optional per-thread override (pscv_set_tuning_thread).  Kernel selection never depends on anything else that is mutable.  Keys:
  *   "warp_q2"   1 (default): 32-channel 16-bit sweeps run on the quad-mapped kernel (one texel per lane quad, two depth
  *               planes per quad); 0: always the generic kernel.  "warp_lpv" != 0 also selects the generic kernel.
  *   "warp_lpv"  lanes sharing one voxel in the generic pscv_warp_cost kernel (1, 2 or 4 for C=32; 0 = default)
@@ -98,6 +98,13 @@ int pscv_abi_version(void);
  *   "conv_small_tiles"  1 (default): small volumes use 1x4x16 tiles with the output channels split over
  *               blockIdx.y; 0: always the large-tile variant */
 int pscv_set_tuning(const char* key, int value);
+
+/* The same knobs for the CALLING host thread only (enable = 1: this thread reads `value` instead of the process-wide one;
+ * enable = 0: drop the override).  pscv_set_tuning itself is process-wide: launches issued from other host threads -- PyTorch
+ * runs autograd's backward on its own thread, nn.DataParallel runs replicas on worker threads -- see it too. */
+int pscv_set_tuning_thread(const char* key, int value, int enable);
+/* The value the CALLING thread's next launch would use (its override if set, else the process-wide value). */
+int pscv_get_tuning(const char* key, int* value);
 
 /*
  * Camera blocks of the PROJ geometry in one launch: for every source view v != reference_frame,

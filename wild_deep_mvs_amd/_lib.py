@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libpscv.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 # mirror of include/pscv.h
-ABI_VERSION = 3
+ABI_VERSION = 4
 F32, BF16, F16 = 0, 1, 2
 GEOM_PROJ, GEOM_HOMOG = 0, 1
 COST_VARIANCE, COST_VARIANCE_CVP, COST_SOFTMIN, COST_GROUPCORR, COST_WARP_ONLY, COST_VARIANCE_PARTIAL = 0, 1, 2, 3, 4, 5
@@ -32,7 +32,8 @@ EXPORTS = ("pscv_last_error", "pscv_abi_version", "pscv_set_tuning", "pscv_proj_
            "pscv_pack_conv3d_weights", "pscv_conv3d", "pscv_softargmin", "pscv_train_workspace_floats", "pscv_bn_stats",
            "pscv_bn_act", "pscv_bn_bwd_reduce", "pscv_bn_bwd_apply", "pscv_softargmin_bwd", "pscv_conv3d_wgrad_workspace",
            "pscv_conv3d_wgrad", "pscv_warp_cost_bwd", "pscv_cvp_depth_hypos", "pscv_relu_bwd", "pscv_fuse_pairs_bwd", "pscv_pack_conv3d_weights_device", "pscv_conv2d_ex", "pscv_variance_finish", "pscv_softargmin_window",
-           "pscv_photo_warp", "pscv_photo_warp_bwd", "pscv_ssim", "pscv_ssim_bwd", "pscv_bn_finalize", "pscv_bn_bwd_coeffs", "pscv_cvp_cams", "pscv_homography_warp", "pscv_prob_softargmin", "pscv_prob_softargmin_workspace")
+           "pscv_photo_warp", "pscv_photo_warp_bwd", "pscv_ssim", "pscv_ssim_bwd", "pscv_bn_finalize", "pscv_bn_bwd_coeffs", "pscv_cvp_cams", "pscv_homography_warp", "pscv_prob_softargmin", "pscv_prob_softargmin_workspace",
+           "pscv_set_tuning_thread", "pscv_get_tuning")
 
 
 class PscvMissingError(RuntimeError):
@@ -67,6 +68,10 @@ def _declare(lib):
     lib.pscv_abi_version.argtypes = []
     lib.pscv_set_tuning.restype = i
     lib.pscv_set_tuning.argtypes = [C.c_char_p, i]
+    lib.pscv_set_tuning_thread.restype = i
+    lib.pscv_set_tuning_thread.argtypes = [C.c_char_p, i, i]
+    lib.pscv_get_tuning.restype = i
+    lib.pscv_get_tuning.argtypes = [C.c_char_p, C.POINTER(i)]
     lib.pscv_proj_cams.restype = i
     lib.pscv_proj_cams.argtypes = [vp, i, i, i, vp, vp]
     lib.pscv_homog_cams.restype = i
@@ -173,7 +178,20 @@ def lib():
 
 
 def set_tuning(key: str, value: int) -> None:
+    """Process-wide: also seen by launches from other host threads (autograd's backward thread, DataParallel replicas)."""
     check(lib().pscv_set_tuning(key.encode(), int(value)), "pscv_set_tuning")
+
+
+def get_tuning(key: str) -> int:
+    """The value the calling thread's next launch would use."""
+    v = C.c_int(0)
+    check(lib().pscv_get_tuning(key.encode(), C.byref(v)), "pscv_get_tuning")
+    return int(v.value)
+
+
+def set_tuning_thread(key: str, value: int, enable: bool = True) -> None:
+    """Override (or, enable=False, stop overriding) a knob for the calling host thread only."""
+    check(lib().pscv_set_tuning_thread(key.encode(), int(value), 1 if enable else 0), "pscv_set_tuning_thread")
 
 
 def check(rc: int, what: str):

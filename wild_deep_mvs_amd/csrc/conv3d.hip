@@ -39,7 +39,7 @@ template <> struct Mfma<f16_t> {
 };
 
 PSCV_PROF_BUFFER(conv)
-thread_local int g_conv_small_tiles = 1;   // pscv_set_tuning("conv_small_tiles", 0) forces the large-tile variant
+Knob g_conv_small_tiles = {1, KNOB_CONV_SMALL_TILES};   // pscv_set_tuning("conv_small_tiles", 0) forces the large-tile variant
 
 struct ConvArgs {
     const uint16_t* in;

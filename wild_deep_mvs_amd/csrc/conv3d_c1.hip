@@ -517,8 +517,8 @@ static int c1_launch(const C1Args& a, long nblk, hipStream_t st) {
 
 }  // namespace pscv
 
-thread_local int g_c1_nb = 0;
-thread_local int g_c1_sweep = 1;   // pscv_set_tuning("c1_sweep", 0): always the brick variant; 2: the depth sweep at any depth
+pscv::Knob g_c1_nb = {0, pscv::KNOB_C1_NB};
+pscv::Knob g_c1_sweep = {1, pscv::KNOB_C1_SWEEP};   // pscv_set_tuning("c1_sweep", 0): always the brick variant; 2: the depth sweep at any depth
 PSCV_PROF_EXPORT(c1)
 
 // depth / part / merged outputs non-null: the fused tail (pscv_prob_softargmin); returns 1 when the layer does not get the depth-sweep

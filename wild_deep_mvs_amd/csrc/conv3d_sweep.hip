@@ -36,10 +36,10 @@ template <> struct SwMfma<f16_t> {
     }
 };
 
-thread_local int g_sweep_dc = 0;     // pscv_set_tuning("sweep_dc", n): depth planes per workgroup sweep (0 = heuristic)
-thread_local int g_sweepc_pd = 0;    // pscv_set_tuning("sweepc_pd", 1..3): prefetch distance (iterations) of the narrow-input sweep (0 = 1)
-thread_local int g_sweepc_slots = 0; // pscv_set_tuning("sweepc_slots", n): resident-workgroup target of the narrow-input sweep (0 = 768)
-thread_local int g_sweep_th16 = 0;   // pscv_set_tuning("sweep_th16", 1) selects the 16-row / 512-thread tile variant (measured
+Knob g_sweep_dc = {0, KNOB_SWEEP_DC};     // pscv_set_tuning("sweep_dc", n): depth planes per workgroup sweep (0 = heuristic)
+Knob g_sweepc_pd = {0, KNOB_SWEEPC_PD};    // pscv_set_tuning("sweepc_pd", 1..3): prefetch distance (iterations) of the narrow-input sweep (0 = 1)
+Knob g_sweepc_slots = {0, KNOB_SWEEPC_SLOTS}; // pscv_set_tuning("sweepc_slots", n): resident-workgroup target of the narrow-input sweep (0 = 768)
+Knob g_sweep_th16 = {0, KNOB_SWEEP_TH16};   // pscv_set_tuning("sweep_th16", 1) selects the 16-row / 512-thread tile variant (measured
                         // 116 us vs 107 us for 8-row tiles at the headline size: one workgroup per CU hides less latency)
 
 struct SweepArgs {

@@ -36,8 +36,8 @@ template <> struct S2Mfma<f16_t> {
     }
 };
 
-thread_local int g_conv_s2_sweep = 1;   // pscv_set_tuning("conv_s2_sweep", 0): always the brick kernel; 2: the sweep at any size
-thread_local int g_s2s_slots = 0;       // pscv_set_tuning("s2s_slots", n): resident-workgroup target that sizes the depth chunks (0 = 768)
+Knob g_conv_s2_sweep = {1, KNOB_CONV_S2_SWEEP};   // pscv_set_tuning("conv_s2_sweep", 0): always the brick kernel; 2: the sweep at any size
+Knob g_s2s_slots = {0, KNOB_S2S_SLOTS};       // pscv_set_tuning("s2s_slots", n): resident-workgroup target that sizes the depth chunks (0 = 768)
 
 struct S2sArgs {
     const uint16_t* in;

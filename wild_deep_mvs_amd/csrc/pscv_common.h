@@ -12,6 +12,22 @@ namespace pscv {
 // ---- error channel ---------------------------------------------------------
 void set_error(const char* fmt, ...);
 
+// Tuning knob (pscv_set_tuning): ONE process-wide value, seen by every host thread that launches -- PyTorch runs autograd's backward
+// on its own thread and DataParallel runs replicas on worker threads, so a knob set from the main thread must reach them --
+// plus an optional override for the calling thread only (pscv_set_tuning_thread: concurrent A/B runs on different streams).
+// Reads like an int at the use sites.
+struct Knob {
+    int process;                    // written by pscv_set_tuning (relaxed atomic through the builtins below)
+    int id;                         // slot of the thread-local override table (pscv_host.cpp)
+    operator int() const;
+    void set(int v) { __atomic_store_n(&process, v, __ATOMIC_RELAXED); }
+};
+enum { KNOB_WARP_LPV, KNOB_WARP_PPD, KNOB_WARP_TILED, KNOB_WARP_Q2, KNOB_CONV_SMALL_TILES, KNOB_SWEEP_TH16, KNOB_SWEEP_DC,
+       KNOB_SWEEPC_SLOTS, KNOB_SWEEPC_PD, KNOB_C1_NB, KNOB_C1_SWEEP, KNOB_WARP_BWD_DIRECT, KNOB_CONV_S2_SWEEP, KNOB_S2S_SLOTS,
+       KNOB_WARP_TILE, KNOB_FUSE_C0, KNOB_SPARE1, KNOB_SPARE2, KNOB_COUNT };
+bool knob_thread_value(int id, int* v);             // this thread's override of slot id, if one is set
+void knob_thread_set(int id, int v, bool enable);
+
 #define PSCV_CHECK_ARG(cond, ...)          \
     do {                                   \
         if (!(cond)) {                     \

@@ -16,6 +16,23 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+static thread_local int g_knob_tl[KNOB_COUNT];
+static thread_local unsigned g_knob_tl_mask = 0;
+
+bool knob_thread_value(int id, int* v) {
+    if (!(g_knob_tl_mask >> id & 1u)) return false;
+    *v = g_knob_tl[id];
+    return true;
+}
+void knob_thread_set(int id, int v, bool enable) {
+    g_knob_tl[id] = v;
+    g_knob_tl_mask = enable ? (g_knob_tl_mask | 1u << id) : (g_knob_tl_mask & ~(1u << id));
+}
+Knob::operator int() const {
+    int v;
+    return knob_thread_value(id, &v) ? v : __atomic_load_n(&process, __ATOMIC_RELAXED);
+}
+
 }  // namespace pscv
 
 extern "C" const char* pscv_last_error(void) { return pscv::g_err; }

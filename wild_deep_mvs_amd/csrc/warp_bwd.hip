@@ -583,7 +583,7 @@ __global__ __launch_bounds__(256) void warp_bwd_tile_kernel(const WarpBwdArgs A)
     }
 }
 
-thread_local int g_warp_bwd_direct = 0;   // pscv_set_tuning("warp_bwd_direct", 1): the one-global-atomic-per-tap kernel (measurement / tests)
+Knob g_warp_bwd_direct = {0, KNOB_WARP_BWD_DIRECT};   // pscv_set_tuning("warp_bwd_direct", 1): the one-global-atomic-per-tap kernel (measurement / tests)
 
 template <typename TIn, typename TG, int C>
 static int bwd_tile_launch(WarpBwdArgs& A, int geom, int cost, hipStream_t st) {

@@ -240,23 +240,23 @@ __global__ __launch_bounds__(256, 4) void warp_cost_kernel(const WarpArgs a) {
 }
 
 // ---- host side ---------------------------------------------------------------------------------
-static thread_local int g_warp_lpv_override = 0;  // 0 = default heuristic; set through pscv_set_tuning("warp_lpv", n)
-static thread_local int g_warp_ppd_override = 0;
-static thread_local int g_warp_tiled = 1;     // 1 (default): use the LDS-staged kernel (warp_cost_tiled.hip) where it applies: fp32 patches,
+static Knob g_warp_lpv_override = {0, KNOB_WARP_LPV};  // 0 = default heuristic; set through pscv_set_tuning("warp_lpv", n)
+static Knob g_warp_ppd_override = {0, KNOB_WARP_PPD};
+static Knob g_warp_tiled = {1, KNOB_WARP_TILED};     // 1 (default): use the LDS-staged kernel (warp_cost_tiled.hip) where it applies: fp32 patches,
                                  // full-rate fp32 blend; 129 us vs 166 us for the quad kernel inside the headline step, same bits
-extern thread_local int g_conv_small_tiles;   // conv3d.hip
-extern thread_local int g_sweep_th16;         // conv3d_sweep.hip
-extern thread_local int g_sweep_dc;
-extern thread_local int g_sweepc_slots;
-extern thread_local int g_sweepc_pd;
+extern Knob g_conv_small_tiles;   // conv3d.hip
+extern Knob g_sweep_th16;         // conv3d_sweep.hip
+extern Knob g_sweep_dc;
+extern Knob g_sweepc_slots;
+extern Knob g_sweepc_pd;
 }
-extern thread_local int g_c1_nb;
-extern thread_local int g_c1_sweep;
+extern pscv::Knob g_c1_nb;
+extern pscv::Knob g_c1_sweep;
 namespace pscv {
-extern thread_local int g_warp_bwd_direct;    // warp_bwd.hip
-extern thread_local int g_conv_s2_sweep;      // conv3d_sweep_s2.hip
-extern thread_local int g_s2s_slots;
-static thread_local int g_warp_q2 = 1;        // 1: 32-channel 16-bit sweeps use the quad-mapped kernel (warp_cost_q2.hip)
+extern Knob g_warp_bwd_direct;    // warp_bwd.hip
+extern Knob g_conv_s2_sweep;      // conv3d_sweep_s2.hip
+extern Knob g_s2s_slots;
+static Knob g_warp_q2 = {1, KNOB_WARP_Q2};        // 1: 32-channel 16-bit sweeps use the quad-mapped kernel (warp_cost_q2.hip)
 int warp_cost_q2_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, int out_dtype, int ppd_override, hipStream_t st);
 int warp_cost_tiled_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, int out_dtype, int ppd_override, hipStream_t st);
 
@@ -340,25 +340,48 @@ static int launch_channels(WarpArgs& a, int C, int geom, int cost, hipStream_t s
 
 }  // namespace pscv
 
+namespace pscv {
+Knob g_warp_tile = {0, KNOB_WARP_TILE};       // warp_cost_tiled.hip variants (measurement)
+Knob g_fuse_c0 = {0, KNOB_FUSE_C0};           // reserved: fused warp -> conv0 experiment
+static Knob* find_knob(const char* key) {
+    static const struct { const char* name; Knob* k; } table[] = {
+        {"warp_lpv", &g_warp_lpv_override}, {"warp_ppd", &g_warp_ppd_override}, {"conv_small_tiles", &g_conv_small_tiles},
+        {"warp_tiled", &g_warp_tiled}, {"warp_q2", &g_warp_q2}, {"c1_nb", &g_c1_nb}, {"c1_sweep", &g_c1_sweep},
+        {"sweep_th16", &g_sweep_th16}, {"sweep_dc", &g_sweep_dc}, {"sweepc_slots", &g_sweepc_slots}, {"sweepc_pd", &g_sweepc_pd},
+        {"warp_bwd_direct", &g_warp_bwd_direct}, {"conv_s2_sweep", &g_conv_s2_sweep}, {"s2s_slots", &g_s2s_slots},
+        {"warp_tile", &g_warp_tile}, {"fuse_c0", &g_fuse_c0}};
+    for (const auto& e : table)
+        if (!strcmp(key, e.name)) return e.k;
+    return nullptr;
+}
+static int knob_value(const char* key, int value) { return (!strcmp(key, "warp_tiled") && value < 0) ? 1 : value; }   // -1: default
+}  // namespace pscv
+
 extern "C" int pscv_set_tuning(const char* key, int value) {
     using namespace pscv;
     PSCV_CHECK_ARG(key, "pscv_set_tuning: null key");
-    if (!strcmp(key, "warp_lpv")) { g_warp_lpv_override = value; return 0; }
-    if (!strcmp(key, "warp_ppd")) { g_warp_ppd_override = value; return 0; }
-    if (!strcmp(key, "conv_small_tiles")) { g_conv_small_tiles = value; return 0; }
-    if (!strcmp(key, "warp_tiled")) { g_warp_tiled = value < 0 ? 1 : value; return 0; }   // -1: back to the default
-    if (!strcmp(key, "warp_q2")) { g_warp_q2 = value; return 0; }
-    if (!strcmp(key, "c1_nb")) { g_c1_nb = value; return 0; }
-    if (!strcmp(key, "c1_sweep")) { g_c1_sweep = value; return 0; }
-    if (!strcmp(key, "sweep_th16")) { g_sweep_th16 = value; return 0; }
-    if (!strcmp(key, "sweep_dc")) { g_sweep_dc = value; return 0; }
-    if (!strcmp(key, "sweepc_slots")) { g_sweepc_slots = value; return 0; }
-    if (!strcmp(key, "sweepc_pd")) { g_sweepc_pd = value; return 0; }
-    if (!strcmp(key, "warp_bwd_direct")) { g_warp_bwd_direct = value; return 0; }
-    if (!strcmp(key, "conv_s2_sweep")) { g_conv_s2_sweep = value; return 0; }
-    if (!strcmp(key, "s2s_slots")) { g_s2s_slots = value; return 0; }
-    set_error("pscv_set_tuning: unknown key '%s'", key);
-    return -1;
+    Knob* k = find_knob(key);
+    if (!k) { set_error("pscv_set_tuning: unknown key '%s'", key); return -1; }
+    k->set(knob_value(key, value));
+    return 0;
+}
+
+extern "C" int pscv_set_tuning_thread(const char* key, int value, int enable) {
+    using namespace pscv;
+    PSCV_CHECK_ARG(key, "pscv_set_tuning_thread: null key");
+    Knob* k = find_knob(key);
+    if (!k) { set_error("pscv_set_tuning_thread: unknown key '%s'", key); return -1; }
+    knob_thread_set(k->id, knob_value(key, value), enable != 0);
+    return 0;
+}
+
+extern "C" int pscv_get_tuning(const char* key, int* value) {
+    using namespace pscv;
+    PSCV_CHECK_ARG(key && value, "pscv_get_tuning: null argument");
+    Knob* k = find_knob(key);
+    if (!k) { set_error("pscv_get_tuning: unknown key '%s'", key); return -1; }
+    *value = (int)*k;
+    return 0;
 }
 
 extern "C" int pscv_warp_cost(const void* ref, const void* const* srcs, int n_src, const float* cams,

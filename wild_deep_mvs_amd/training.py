@@ -525,8 +525,9 @@ def _cached_layer(net, tag, weight, dtype, make):
     """Packed 2-D layers are built on the host (pscv_pack_conv2d_weights): keep them per (weight version, dtype) on the module so
     that the views of one step -- same weights -- do not repack (and synchronise) once per view."""
     cache = net.__dict__.setdefault("_pscv_train_layers", {})
-    key = (ops.weights_epoch(), tag, weight.data_ptr(), weight._version, dtype)
+    key = (tag, ops.weights_epoch(), weight.data_ptr(), weight._version, dtype)
     if key not in cache:
+        # one live entry per tag: an optimiser step bumps weight._version, the previous step's packed layer goes here
         for k in [k for k in cache if k[0] == tag]:
             del cache[k]
         cache[key] = make()
