@@ -469,3 +469,36 @@ def test_fused_prob_softargmin_tail_equals_separate_launches(env, shape, dtype):
     # and against the definition
     p = torch.softmax(logits.double(), 1)
     check_close(f"fused tail depth vs softmax {shape}", fused["depth"].cpu(), (p * dv.double().view(2, D, 1, 1)).sum(1).float().cpu(), max_abs=2e-5 * 9.0)
+
+
+@pytest.mark.parametrize("cin,cout,kind,shape", [(32, 8, 0, (16, 16, 32)),      # conv0's depth sweep
+                                                  (8, 8, 0, (16, 16, 32)),       # narrow sweep
+                                                  (8, 16, 1, (16, 16, 32)),      # stride-2 (brick at this size; sweep forced below)
+                                                  (16, 16, 0, (6, 10, 21)),      # brick kernel
+                                                  (16, 8, 2, (4, 8, 16)),        # parity-pair deconv
+                                                  (8, 1, 0, (16, 16, 32))])      # one-channel head
+@pytest.mark.parametrize("relu", [True, False])
+def test_conv3d_epilogue_propagates_nan_like_torch_relu(env, cin, cout, kind, shape, relu):
+    """A NaN activation must stay NaN through `[relu](scale * conv + bias)` exactly where ATen's conv + F.relu give NaN
+    (round-2 advisor finding: max(NaN, -inf) = -inf / max(NaN, 0) = 0 hid divergence from isfinite checks)."""
+    L, ops = env
+    g = torch.Generator().manual_seed(3)
+    D, H, W = shape
+    transposed = kind == L.CONV_T2
+    x = bf16_round(torch.randn(1, cin, D, H, W, generator=g))
+    x[0, 1, D // 2, H // 2, W // 2] = float("nan")
+    wshape = (cin, cout, 3, 3, 3) if transposed else (cout, cin, 3, 3, 3)
+    w = bf16_round(torch.randn(wshape, generator=g) / np.sqrt(27 * cin))
+    layer = ops.Conv3dLayer.build(w, kind=kind, transposed=transposed, device="cuda", relu=relu, dtype=torch.float16)
+    L.set_tuning("conv_s2_sweep", 2)
+    try:
+        y = ops.conv3d(ops.to_channels_last(x.cuda(), torch.float16), layer, out_dtype=torch.float32)
+    finally:
+        L.set_tuning("conv_s2_sweep", 1)
+    ref = _ref_conv(x, w, kind, transposed, L)
+    if relu:
+        ref = F.relu(ref)
+    got = y.permute(0, 4, 1, 2, 3).cpu()
+    assert torch.isnan(ref).any()
+    assert torch.equal(torch.isnan(got), torch.isnan(ref)), (int(torch.isnan(got).sum()), int(torch.isnan(ref).sum()))
+    assert not torch.isinf(got).any()

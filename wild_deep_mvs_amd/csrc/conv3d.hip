@@ -119,7 +119,7 @@ __device__ __noinline__ void epi_ragged(float y0, float y1, float y2, float y3, 
     for (int k = 0; k < cnt; ++k) {
         float v = y[k];
         if (sp) v += Half16<H>::one(sp[k]);
-        v = fmaxf(v, lo_post);
+        v = relu_floor(v, lo_post);
         if (out_f32) reinterpret_cast<float*>(op)[k] = v;
         else reinterpret_cast<uint16_t*>(op)[k] = Half16<H>::bits(v);
     }
@@ -344,16 +344,16 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
             const float4 sc = *reinterpret_cast<const float4*>(epi_sc + m * 16 + g * 4);
             const float4 bi = *reinterpret_cast<const float4*>(epi_bi + m * 16 + g * 4);
             const float4 fl = *reinterpret_cast<const float4*>(epi_fl + m * 16 + g * 4);
-            float y[4] = {fmaxf(fmaf(acc[m][0], sc.x, bi.x), fl.x), fmaxf(fmaf(acc[m][1], sc.y, bi.y), fl.y),
-                          fmaxf(fmaf(acc[m][2], sc.z, bi.z), fl.z), fmaxf(fmaf(acc[m][3], sc.w, bi.w), fl.w)};
+            float y[4] = {relu_floor(fmaf(acc[m][0], sc.x, bi.x), fl.x), relu_floor(fmaf(acc[m][1], sc.y, bi.y), fl.y),
+                          relu_floor(fmaf(acc[m][2], sc.z, bi.z), fl.z), relu_floor(fmaf(acc[m][3], sc.w, bi.w), fl.w)};
             const unsigned lo = lane_out + (unsigned)(pw * a.out_cs + m * 16), ls = lane_skip + (unsigned)(pw * a.skip_cs + m * 16);
             if (lane_ok && cg + m * 16 < a.cout) {
                 if (cout4) {
                     uint2 sv = make_uint2(0u, 0u);
                     if (pre) sv = pre[m];
                     else if (a.skip) sv = *reinterpret_cast<const uint2*>(a.skip + srow + ls);
-                    y[0] = fmaxf(y[0] + Half16<H>::lo(sv.x), lo_post); y[1] = fmaxf(y[1] + Half16<H>::hi(sv.x), lo_post);
-                    y[2] = fmaxf(y[2] + Half16<H>::lo(sv.y), lo_post); y[3] = fmaxf(y[3] + Half16<H>::hi(sv.y), lo_post);
+                    y[0] = relu_floor(y[0] + Half16<H>::lo(sv.x), lo_post); y[1] = relu_floor(y[1] + Half16<H>::hi(sv.x), lo_post);
+                    y[2] = relu_floor(y[2] + Half16<H>::lo(sv.y), lo_post); y[3] = relu_floor(y[3] + Half16<H>::hi(sv.y), lo_post);
                     if (a.out_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + orow + lo) = make_float4(y[0], y[1], y[2], y[3]);
                     else *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.out) + orow + lo) =
                              make_uint2(Half16<H>::pack(y[0], y[1]), Half16<H>::pack(y[2], y[3]));

@@ -191,8 +191,8 @@ __global__ __launch_bounds__(256) void conv3d_c1_kernel(const C1Args a) {
             float y[2][4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                y[0][r] = fmaxf(fmaxf(fmaf(acc0[r], e_scale, e_bias), lo_pre), lo_post);
-                y[1][r] = fmaxf(fmaxf(fmaf(acc1[r], e_scale, e_bias), lo_pre), lo_post);
+                y[0][r] = relu_floor(relu_floor(fmaf(acc0[r], e_scale, e_bias), lo_pre), lo_post);
+                y[1][r] = relu_floor(relu_floor(fmaf(acc1[r], e_scale, e_bias), lo_pre), lo_post);
             }
             if (g < 2) {          // rows 0,1 (g = 0) and 4,5 (g = 1)
 #pragma unroll
@@ -227,9 +227,9 @@ __global__ __launch_bounds__(256) void conv3d_c1_kernel(const C1Args a) {
                 for (int r = 0; r < 4; ++r) {
                     const int m = 4 * g + r;
                     if (m >= C1_P || d0 + m >= a.D) continue;
-                    float y = fmaxf(fmaf(ct ? acc1[r] : acc0[r], e_scale, e_bias), lo_pre);
+                    float y = relu_floor(fmaf(ct ? acc1[r] : acc0[r], e_scale, e_bias), lo_pre);
                     if (a.skip) y += Half16<H>::one(*reinterpret_cast<const uint16_t*>(sb + r * skip_plane + soff));
-                    y = fmaxf(y, lo_post);
+                    y = relu_floor(y, lo_post);
                     if (a.out_f32) *reinterpret_cast<float*>(ob + r * out_plane + ooff) = y;
                     else *reinterpret_cast<uint16_t*>(ob + r * out_plane + ooff) = Half16<H>::bits(y);
                 }
@@ -393,9 +393,9 @@ __global__ __launch_bounds__(256, 3) void conv3d_c1_sweep_kernel(const C1Args a)
                 for (int r = 0; r < 4; ++r) {
                     const int m = 4 * g + r;
                     if (m >= C1_P || d0 + m >= a.D) continue;
-                    float y = fmaxf(fmaf(ct ? acc1[r] : acc0[r], e_scale, e_bias), lo_pre);
+                    float y = relu_floor(fmaf(ct ? acc1[r] : acc0[r], e_scale, e_bias), lo_pre);
                     if (a.skip) y += Half16<H>::one(*reinterpret_cast<const uint16_t*>(sb + r * skip_plane + soff));
-                    y = fmaxf(y, lo_post);
+                    y = relu_floor(y, lo_post);
                     if (a.out_f32) *reinterpret_cast<float*>(ob + r * out_plane + ooff) = y;
                     else *reinterpret_cast<uint16_t*>(ob + r * out_plane + ooff) = Half16<H>::bits(y);
                 }

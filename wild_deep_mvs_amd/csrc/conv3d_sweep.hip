@@ -216,7 +216,7 @@ __global__ __launch_bounds__(32 * SW_TH, 2) void conv3d_sweep8_kernel(const Swee
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     y[k] = fmaf(acc[r][k], sc[k], bi[k]);
-                    if (a.epi & PSCV_EPI_RELU_PRE) y[k] = fmaxf(y[k], fl[k]);
+                    if (a.epi & PSCV_EPI_RELU_PRE) y[k] = relu_floor(y[k], fl[k]);
                 }
                 if (a.skip) {
                     const uint2 sv = *reinterpret_cast<const uint2*>(a.skip + vox * a.skip_cs + a.skip_co + c0);
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(32 * SW_TH, 2) void conv3d_sweep8_kernel(const Swee
                 }
                 if (a.epi & PSCV_EPI_RELU_POST) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) y[k] = fmaxf(y[k], 0.0f);
+                    for (int k = 0; k < 4; ++k) y[k] = relu_floor(y[k], 0.0f);
                 }
                 if (a.out_f32) {
                     *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + vox * a.out_cs + a.out_co + c0) =
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(256, (CIN == 8 && PD <= 2) ? 4 : (CIN == 8 || (PD =
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
                                 y[k] = fmaf(acc[op][r][k], sc[k], bi[k]);
-                                if (a.epi & PSCV_EPI_RELU_PRE) y[k] = fmaxf(y[k], fl[k]);
+                                if (a.epi & PSCV_EPI_RELU_PRE) y[k] = relu_floor(y[k], fl[k]);
                             }
                             if (a.skip) {
                                 y[0] += Half16<H>::lo(sk[s][op][r].x); y[1] += Half16<H>::hi(sk[s][op][r].x);
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256, (CIN == 8 && PD <= 2) ? 4 : (CIN == 8 || (PD =
                             }
                             if (a.epi & PSCV_EPI_RELU_POST) {
 #pragma unroll
-                                for (int k = 0; k < 4; ++k) y[k] = fmaxf(y[k], 0.0f);
+                                for (int k = 0; k < 4; ++k) y[k] = relu_floor(y[k], 0.0f);
                             }
                             if (a.out_f32) {
                                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + vox * a.out_cs + a.out_co + c0) =

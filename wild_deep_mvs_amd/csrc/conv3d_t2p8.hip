@@ -167,9 +167,9 @@ __global__ __launch_bounds__(256) void conv3d_t2p8_kernel(const Tp8Args a) {
                     const uint2 sv = skv[i][pd * 2 + ph];
                     float y[4];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) y[k] = fmaxf(fmaf(acc[k], sc[k], bi[k]), fl[k]);
-                    y[0] = fmaxf(y[0] + Half16<H>::lo(sv.x), lo_post); y[1] = fmaxf(y[1] + Half16<H>::hi(sv.x), lo_post);
-                    y[2] = fmaxf(y[2] + Half16<H>::lo(sv.y), lo_post); y[3] = fmaxf(y[3] + Half16<H>::hi(sv.y), lo_post);
+                    for (int k = 0; k < 4; ++k) y[k] = relu_floor(fmaf(acc[k], sc[k], bi[k]), fl[k]);
+                    y[0] = relu_floor(y[0] + Half16<H>::lo(sv.x), lo_post); y[1] = relu_floor(y[1] + Half16<H>::hi(sv.x), lo_post);
+                    y[2] = relu_floor(y[2] + Half16<H>::lo(sv.y), lo_post); y[3] = relu_floor(y[3] + Half16<H>::hi(sv.y), lo_post);
                     if (lane_ok) {
                         if (a.out_f32)
                             *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + orow + lane_out) = make_float4(y[0], y[1], y[2], y[3]);

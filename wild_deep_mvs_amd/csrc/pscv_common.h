@@ -148,15 +148,25 @@ __device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
 // Saturating fp32 -> fp16 stores without the two v_med3 clamps per pair: with MODE.FP16_OVFL set (once per wave, at kernel entry)
 // the hardware conversion clamps an overflowing result to +-65504 itself.  Kernels that call fp16_ovfl_mode() may pack with
 // pack_f16x2_ovfl(); everything else keeps pack_f16x2().
-__device__ __forceinline__ void fp16_ovfl_mode() { __builtin_amdgcn_s_setreg((1 - 1) << 11 | 23 << 6 | 1, 1); }   // hwreg(HW_REG_MODE, 23, 1)
+// Exception: the mode clamps OVERFLOWING FINITE results only -- a true +-inf input stays +-inf (pack_f16x2's med3 clamp stores
+// +-65504 for it).  On the engine's own path no stored tensor can hold inf (every 16-bit store saturates), so the difference is
+// reachable only through caller-supplied feature maps that already contain inf; tests/test_gpu_warp_cost.py pins that behaviour.
+// The conversions carry no dependency on MODE, so nothing may be scheduled across the s_setreg: sched_barrier right behind it.
+__device__ __forceinline__ void fp16_ovfl_mode() {
+    __builtin_amdgcn_s_setreg((1 - 1) << 11 | 23 << 6 | 1, 1);   // hwreg(HW_REG_MODE, 23, 1)
+    __builtin_amdgcn_sched_barrier(0);
+}
 __device__ __forceinline__ uint32_t pack_f16x2_ovfl(float lo, float hi) {
     h2_t v;
     v[0] = (_Float16)lo;
     v[1] = (_Float16)hi;
     return __builtin_bit_cast(uint32_t, v);
 }
-// max(x, lo) as ONE instruction (fmaxf canonicalises a possibly-signalling operand with an extra v_max first)
-__device__ __forceinline__ float clamp_lo(float x, float lo) { return __builtin_amdgcn_fmed3f(x, lo, __builtin_inff()); }
+// ReLU floor max(x, lo) that PROPAGATES NaN like torch.relu / the reference's modules do (v_max / v_med3 / fmaxf return the
+// non-NaN operand, which turned a diverged activation into -inf or 0 and hid it from isfinite checks): v_cmp + v_cndmask.
+// lo = -inf is the "no ReLU" constant of the conv epilogues (x < -inf is never true).
+__device__ __forceinline__ float relu_floor(float x, float lo) { return x < lo ? lo : x; }
+__device__ __forceinline__ float clamp_lo(float x, float lo) { return relu_floor(x, lo); }
 
 // 16-bit storage type tags (both are raw uint16 in memory)
 struct bf16_t { uint16_t bits; };

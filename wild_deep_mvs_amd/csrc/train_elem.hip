@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const uint4* __restrict__ y
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             v[j] = fmaf(v[j], sc[j], bi[j]);
-            if (relu == 1) v[j] = fmaxf(v[j], 0.0f);
+            if (relu == 1) v[j] = relu_floor(v[j], 0.0f);
         }
         if (skip) {
             float s[8];
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const uint4* __restrict__ y
         }
         if (relu == 2) {   // ReLU after the residual add (Vis BasicBlock, models/VisMVSNet/nn_utils.py:123-171)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.0f);
+            for (int j = 0; j < 8; ++j) v[j] = relu_floor(v[j], 0.0f);
         }
         out[i] = pack8<H>(v);
     }
