@@ -19,17 +19,19 @@ cm = ops.proj_cams([proj[:, i] for i in range(1, V)], proj[:, 0])
 out = torch.empty(1, D, h, w, 32, dtype=torch.float16, device=dev)
 lib = L.lib()
 TEMP = float(os.environ.get("WL_TEMP", "1.0"))
-for ppd in [int(x) for x in sys.argv[1:]] or [24]:
+L.set_tuning("warp_tile", int(os.environ.get("WL_VARIANT", "0")))
+TH = int(os.environ.get("WL_TILE_H", "4"))
+for ppd in [int(x) for x in sys.argv[1:]] or [32]:
     L.set_tuning("warp_tiled", 1); L.set_tuning("warp_ppd", ppd)
     buf = (ctypes.c_ulonglong * 16)()
     for _ in range(3):
         ops.warp_cost(fcl[0], fcl[1:], cm, dv, cost=L.COST_VARIANCE, out=out, temp=TEMP)
     torch.cuda.synchronize()
-    nblk = (D + ppd - 1) // ppd * (h // 8) * (w // 8)
+    nblk = (D + ppd - 1) // ppd * (h // TH) * (w // 8)
     lib.pscv_debug_wl_prof(buf, nblk)
     names = ["lane consts issued", "box phase (wave 0) / wait", "barrier 1", "table read + fill", "barrier 2", "sweep"]
     print(f"ppd={ppd}: average cycles per block")
-    for wv, off in (("wave 0", 0), ("wave 7", 8)):
+    for wv, off in (("wave 0", 0), ("last wave", 8)):
         tot = sum(buf[off + i] for i in range(6)) / nblk
         print(f"  {wv}: total {tot:8.0f}  " + "  ".join(f"{names[i]} {buf[off + i] / nblk:7.0f}" for i in range(6)))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--ppd", type=int, nargs="*", default=[0])
     ap.add_argument("--views", type=int, default=5)
     ap.add_argument("--baseline-scale", type=float, default=1.0)
+    ap.add_argument("--variants", type=int, nargs="*", default=[0], help='values of the "warp_tile" knob to time on the LDS-staged kernel '
+                                                                         "(0 = default pipelined sweep, 1 = the round-2 loop)")
     args = ap.parse_args()
     dt = {"bf16": torch.bfloat16, "f16": torch.float16}[args.dtype]
     dev = "cuda"
@@ -55,15 +57,20 @@ def main():
         if args.only and args.only != name:
             continue
         for ppd in args.ppd:
-            out = torch.empty(1, D, h, w, 32, dtype=dt, device=dev)
-            L.set_tuning("warp_tiled", tiled); L.set_tuning("warp_ppd", ppd)
-            try:
-                us = timeit(lambda: ops.warp_cost(fcl[0], fcl[1:], cm, dv, cost=L.COST_VARIANCE, out=out), args.reps)
-            finally:
-                L.set_tuning("warp_tiled", -1); L.set_tuning("warp_ppd", 0)
-            outs[name] = out
-            print(f"warp_cost variance {args.dtype} {name:6s} ppd={ppd:2d}: {us:8.1f} us  {nbytes / us / 1e3:7.1f} GB/s (algorithmic)"
-                  f"  = {nbytes / us / 1e3 / 8000:.3f} of 8 TB/s")
+            for variant in (args.variants if tiled else [0]):
+                out = torch.empty(1, D, h, w, 32, dtype=dt, device=dev)
+                L.set_tuning("warp_tiled", tiled); L.set_tuning("warp_ppd", ppd); L.set_tuning("warp_tile", variant)
+                try:
+                    us = timeit(lambda: ops.warp_cost(fcl[0], fcl[1:], cm, dv, cost=L.COST_VARIANCE, out=out), args.reps)
+                finally:
+                    L.set_tuning("warp_tiled", -1); L.set_tuning("warp_ppd", 0); L.set_tuning("warp_tile", 0)
+                if tiled and variant != args.variants[0]:
+                    ne = (outs[name].view(torch.int16) != out.view(torch.int16)).sum().item()
+                    print(f"   variant {variant} vs {args.variants[0]}: {ne} stored values differ")
+                else:
+                    outs[name] = out
+                print(f"warp_cost variance {args.dtype} {name:6s} ppd={ppd:2d} variant={variant}: {us:8.1f} us  {nbytes / us / 1e3:7.1f} GB/s (algorithmic)"
+                      f"  = {nbytes / us / 1e3 / 8000:.3f} of 8 TB/s")
     if len(outs) == 2:
         a, b = outs["q2"].float(), outs["tiled"].float()
         ne = (outs["q2"].view(torch.int16) != outs["tiled"].view(torch.int16)).sum().item()

@@ -128,3 +128,65 @@ def test_bench_gpus2_under_torch_distributed_run():
 def test_bench_refuses_a_launcher_that_disagrees_with_gpus_flag():
     p = _run_bench(["bench.py", "--gpus", "2", "--backend", "gloo", "--rendezvous-only"], env_extra={"WORLD_SIZE": "1", "RANK": "0"})
     assert p.returncode != 0 and "WORLD_SIZE=1" in (p.stderr + p.stdout)
+
+
+# ---- slab exchange of the Vis source-view shard: reduce-scatter of 16-bit shares + neighbour halos ----------------------------
+def _slab_worker(rank, world, port, shape, axis, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        shares = [torch.randint(-8, 9, shape, generator=torch.Generator().manual_seed(100 + r)).to(torch.float16) for r in range(world)]
+        total = torch.stack(shares).sum(0)                      # small integers: exact in fp16 in any summation order
+        ext, lo, a, b = pdist.reduce_to_slab(shares[rank], axis, halo=pdist.FUSE_HALO)
+        E = shape[axis]
+        S = pdist.slab_size(E, world)
+        ok = True
+        if ext is None:
+            ok = a == b == rank * S and rank * S >= E
+            rows = torch.zeros((shape[0], 1, 0, shape[3]), dtype=torch.float32)
+        else:
+            hi = lo + ext.shape[axis]
+            ok = (a == rank * S and b == min(E, a + S) and lo == max(0, a - pdist.FUSE_HALO) and hi == min(E, b + pdist.FUSE_HALO)
+                  and torch.equal(ext, total.narrow(axis, lo, hi - lo)) and ext.is_contiguous())
+            rows = total.float().narrow(axis, a, b - a).sum(dim=(1 if axis == 2 else 2, 4)).unsqueeze(1) if axis == 2 else None
+        gathered = None
+        if axis == 2:
+            full = pdist.gather_rows(rows, E, S)
+            gathered = bool(torch.equal(full, total.float().sum(dim=(1, 4)).unsqueeze(1)))
+        q.put((rank, bool(ok), gathered, (lo, a, b)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("world,shape,axis", [(2, (1, 32, 6, 5, 8), 1), (3, (2, 4, 50, 3, 8), 2), (4, (1, 6, 50, 3, 8), 2),
+                                              (5, (1, 2, 32, 3, 8), 2)])     # 32 rows / 5 ranks: slabs of 8, the tail rank owns none
+def test_reduce_to_slab_sums_and_exchanges_halos(world, shape, axis):
+    """Every rank ends up with the SUM of all shares on its owned units + FUSE_HALO units per inner side, contiguous in the
+    original layout; uneven extents (50 rows over 3 / 4 ranks: the tail rank owns fewer rows, or none) included; gather_rows
+    reassembles per-row results on every rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_slab_worker, args=(r, world, port, shape, axis, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=150) for _ in range(world))
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res
+    if axis == 2:
+        assert all(r[2] for r in res), res
+    spans = [r[3] for r in res]
+    assert spans[0][1] == 0 and max(s[2] for s in spans) == shape[axis]
+
+
+def test_slab_axis_prefers_the_thicker_slab_and_refuses_thin_ones():
+    assert pdist.slab_axis(256, 144, 8) == (1, 32)          # configuration 5, stage 1: depth slabs of 32 planes
+    assert pdist.slab_axis(32, 288, 8) == (2, 36)           # stage 2: row slabs
+    assert pdist.slab_axis(16, 576, 8) == (2, 72)           # stage 3
+    assert pdist.slab_axis(16, 8, 2) == (1, 8)
+    assert pdist.slab_axis(8, 12, 2) is None                # tiny fixture: replicated path
+    assert pdist.slab_size(50, 4) == 14 and pdist.slab_size(50, 3) == 18

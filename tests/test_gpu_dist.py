@@ -291,6 +291,93 @@ def test_vis_depth_plane_shard_two_ranks_one_gpu():
         assert rel <= 1e-3
 
 
+def _vis_view_slab_worker(rank, world, port, q):
+    _init(rank, world, port)
+    try:
+        from wild_deep_mvs_amd import synthetic
+        from wild_deep_mvs_amd.dist import CollectiveTrace
+        from wild_deep_mvs_amd.models.VisMVSNet.frontend import Frontend
+        dev = torch.device("cuda", rank if os.environ.get("PSCV_TEST_BACKEND") == "nccl" else 0)
+        net = Frontend()
+        net.load_state_dict(synthetic.sharpened_state_dict("vis", synthetic.template_of(net), seed=0))
+        net = net.to(dev).eval()
+        kw = dict(depth_nums=[32, 16, 8], interval_scales=[4, 2, 1])
+        scene = {k: v.to(dev) for k, v in synthetic.make_scene(1, 5, 256, 320, seed=3).items()}
+        call = lambda: net(scene["imgs"], scene["K"], scene["R"], scene["t"], scene["depth_min"], scene["depth_max"], **kw)
+        outs = {}
+        with torch.no_grad():
+            net.set_view_group(None)
+            outs["unsharded"] = call()
+            net.set_view_group(dist.group.WORLD)
+            for label, slabs in (("slabs", True), ("replicated", False)):
+                for st in (net.model.stage1, net.model.stage2, net.model.stage3):
+                    st.view_slabs = slabs
+                with CollectiveTrace() as tr:
+                    outs[label] = call()
+                outs[label + "_coll"] = tr.summary()
+        ref = outs["unsharded"]
+        rec = {}
+        for label in ("slabs", "replicated"):
+            o = outs[label]
+            rec[label] = dict(
+                depth=[float((a - b).abs().mean() / b.abs().mean()) for a, b in zip(o["depth_est_list"], ref["depth_est_list"])],
+                prob=float((o["photometric_confidence"] - ref["photometric_confidence"]).abs().mean()),
+                # (depth_pair_list is finest stage first; only the coarsest stage's pair branch is independent of a fused depth)
+                pairs=[max(float((a[0] - b[0]).abs().max() / b[0].abs().max()) for a, b in zip(sa, sb))
+                       for sa, sb in zip(o["depth_pair_list"], ref["depth_pair_list"])],
+                coll=[(c["collective"], c["bytes_per_rank"], c["calls"]) for c in outs[label + "_coll"]])
+        q.put((rank, rec, outs["slabs"]["depth"].cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_vis_view_shard_slab_regfuse_two_ranks_one_gpu():
+    """Source-view shard with the reduce-scatter form of the fusion (reference model_cas.py:354-357,385-405 across
+    ranks): 5 views 256x320, stages (d,h,w) = (32,32,40), (16,64,80), (8,128,160) over two ranks -> stage 1 cuts DEPTH slabs
+    (16 owned planes + 8 halo, heads merged from log-sum-exp partials), stages 2-3 cut ROW slabs (32 / 64 owned rows + 8 halo,
+    rows all-gathered).  Against the unsharded run on the same rank: the fused volume is a sum of two 16-bit shares instead of
+    one rounded fp32 sum (one extra 16-bit rounding), so depth agrees in rel-L1 (2e-4 per stage like the depth-plane shard), pair
+    results of the first stage to fp32 order, ranks agree with each other exactly; the 16-bit all-reduce + replicated RegFuse variant is held to
+    the same bars; every volume-sized collective carries 16-bit payloads."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_vis_view_slab_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, rec, _ in res:
+        for label, r in rec.items():
+            print(f"[parity] view shard ({label}) rank {rank}: depth rel-L1 per stage (fine->coarse) " + " ".join(f"{e:.2e}" for e in r["depth"]) +
+                  f", window prob mean abs {r['prob']:.2e}, pair depth max rel per stage " + " ".join(f"{e:.1e}" for e in r["pairs"]) +
+                  f"; collectives {r['coll']}", flush=True)
+            # stage 1's pair branch sees the same inputs as the unsharded run; the later stages start from a fused depth that
+            # differs by ~1e-4, so their hypothesis planes (and pair depths) move with it
+            assert max(r["depth"]) <= 3e-4 and r["prob"] <= 2e-3 and r["pairs"][-1] <= 1e-5 and max(r["pairs"]) <= 5e-3
+        names = {c[0] for c in rec["slabs"]["coll"]}
+        assert "reduce_scatter_tensor" in names
+        vol16 = {1: 32 * 32 * 40 * 16, 2: 16 * 64 * 80 * 16, 3: 8 * 128 * 160 * 16}            # bytes of a stage's 16-bit fused volume
+        rs = sorted(c[1] for c in rec["slabs"]["coll"] if c[0] == "reduce_scatter_tensor")
+        assert rs == sorted(vol16.values()), rs                                               # the full 16-bit volume goes in, nothing wider
+        ar = [c[1] for c in rec["replicated"]["coll"] if c[0] == "all_reduce"]
+        assert max(ar) == max(vol16.values())
+    assert np.array_equal(res[0][2], res[1][2]), "ranks must agree on the fused result"
+
+
+@pytest.mark.skipif(not torch.cuda.is_available() or torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: 2+ MI355X")
+@pytest.mark.timeout(300)
+def test_vis_view_shard_slab_regfuse_two_ranks_nccl(monkeypatch):
+    monkeypatch.setenv("PSCV_TEST_BACKEND", "nccl")
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    test_vis_view_shard_slab_regfuse_two_ranks_one_gpu()
+
+
 # ---- the same three shardings over RCCL: one GPU per rank, backend "nccl" (skipped on one-GPU boxes) --------------------------
 needs_two_gpus = pytest.mark.skipif(not torch.cuda.is_available() or torch.cuda.device_count() < 2,
                                     reason="RCCL needs one GPU per rank: 2+ MI355X")
@@ -355,7 +442,9 @@ def test_bench_sharded_legs_two_ranks_one_gpu():
         assert "error" not in r, r
         print(f"[bench sharded] {mode}: 1 GPU {r['ms_per_forward_1gpu']:.2f} ms, 2 ranks {r['ms_per_forward_sharded']:.2f} ms, "
               f"depth rel-L1 vs unsharded {r['depth_rel_l1_vs_unsharded']:.2e}, collectives {r['collectives']}", flush=True)
-        assert r["depth_rel_l1_vs_unsharded"] <= 3e-4 and r["n_gpus"] == 2 and r["scaling"] == "strong"
+        assert r["depth_rel_l1_vs_unsharded"] <= (5e-4 if mode == "view" else 3e-4) and r["n_gpus"] == 2 and r["scaling"] == "strong"
         assert len(r["collectives"]) >= 1 and all(c["calls"] >= 1 and c["bytes_per_rank"] > 0 for c in r["collectives"])
     names = {c["collective"] for c in res[0]["view"]["collectives"]}
-    assert "all_reduce" in names                  # the visibility-weighted partial sums of the source-view shard
+    assert "reduce_scatter_tensor" in names       # the 16-bit shares of the fused volume of the source-view shard
+    rs = max(c["bytes_per_rank"] for c in res[0]["view"]["collectives"] if c["collective"] == "reduce_scatter_tensor")
+    assert rs == 256 * 144 * 200 * 8 * 2          # stage 1 of configuration 5: the 16-bit volume (118 MB), nothing wider

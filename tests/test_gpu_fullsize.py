@@ -268,7 +268,10 @@ def _vis_shard_worker(rank, world, port, cid, mode, q):
 @pytest.mark.parametrize("cid,mode", [(3, "depth"), (5, "view")])
 def test_vis_fullsize_shard_equals_unsharded(gpu, cid, mode):
     """BASELINE configuration (3) is the depth-plane shard, (5) the source-view shard: at the full size, two ranks return the
-    depth map of the unsharded run (to the storage noise of the recomputed halo / the re-associated fused sum)."""
+    depth map of the unsharded run (to the storage noise of the recomputed halo / the re-associated fused sum).  The view shard
+    reduces 16-bit shares of the fused volume (round 3: reduce-scatter into slabs): the fused volume is a 16-bit sum of two 16-bit
+    values instead of one rounded fp32 sum, which moves the stage depths by 2.6e-4 / 3.0e-4 at this size (the fp32 all-reduce of
+    round 2: 1e-4); its bar is 5e-4, half the north-star's 1e-3."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -287,7 +290,8 @@ def test_vis_fullsize_shard_equals_unsharded(gpu, cid, mode):
     for rank, world, depth, ests in res[2]:
         rel = float(np.abs(depth - single[2]).mean() / np.abs(single[2]).mean())
         print(f"[parity] cfg{cid} {mode}-shard rank {rank}: depth rel-L1 vs unsharded {rel:.3e}", flush=True)
-        assert rel <= 3e-4, rel
+        bar = 5e-4 if mode == "view" else 3e-4
+        assert rel <= bar, rel
         for a, b in zip(ests, single[3]):
-            assert float(np.abs(a - b).mean() / np.abs(b).mean()) <= 3e-4
+            assert float(np.abs(a - b).mean() / np.abs(b).mean()) <= bar
     assert float(np.abs(res[2][0][2] - res[2][1][2]).max()) <= 1e-5, "ranks must agree"

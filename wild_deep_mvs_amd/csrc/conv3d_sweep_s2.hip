@@ -82,7 +82,6 @@ __global__ __launch_bounds__(256) void conv3d_sweep_s2_kernel(const S2sArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, g = lane >> 4;
     PSCV_PROF_BEGIN
-    fp16_ovfl_mode();
 
     // ---- A fragments of the whole layer ----
     uint4 wf[S2S_STEPS][NT];
@@ -216,6 +215,7 @@ __global__ __launch_bounds__(256) void conv3d_sweep_s2_kernel(const S2sArgs a) {
 
         // epilogue: the base of output plane o is scalar arithmetic; a lane adds its precomputed row / column / channel offset
         {
+            fp16_ovfl_mode(true);     // saturating 16-bit stores; off again before the next plane's MFMAs (pscv_common.h)
             const long obase = ((long)b * a.Do + o) * oplane + a.out_co, sbase = ((long)b * a.Do + o) * splane + a.skip_co;
 #pragma unroll
             for (int r = 0; r < S2S_R; ++r)
@@ -243,6 +243,7 @@ __global__ __launch_bounds__(256) void conv3d_sweep_s2_kernel(const S2sArgs a) {
                                 make_uint2(Half16<H>::pack_ovfl(y[0], y[1]), Half16<H>::pack_ovfl(y[2], y[3]));
                     }
                 }
+            fp16_ovfl_mode(false);
         }
         PSCV_STAMP(3)
         ring += 2;

@@ -152,8 +152,13 @@ __device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
 // +-65504 for it).  On the engine's own path no stored tensor can hold inf (every 16-bit store saturates), so the difference is
 // reachable only through caller-supplied feature maps that already contain inf; tests/test_gpu_warp_cost.py pins that behaviour.
 // The conversions carry no dependency on MODE, so nothing may be scheduled across the s_setreg: sched_barrier right behind it.
-__device__ __forceinline__ void fp16_ovfl_mode() {
-    __builtin_amdgcn_s_setreg((1 - 1) << 11 | 23 << 6 | 1, 1);   // hwreg(HW_REG_MODE, 23, 1)
+// Measured on gfx950 (scripts/dev/nan_probe.py): with the bit set, v_mfma_f32_16x16x32_f16 no longer propagates a NaN operand
+// (the stride-2 depth sweep, the only MFMA kernel that kept the bit set for its whole lifetime, returned finite values for a NaN
+// input).  MFMA kernels therefore raise the bit only around their store conversions: fp16_ovfl_mode(true) ... (false).
+__device__ __forceinline__ void fp16_ovfl_mode(bool on = true) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (on) __builtin_amdgcn_s_setreg((1 - 1) << 11 | 23 << 6 | 1, 1);   // hwreg(HW_REG_MODE, 23, 1)
+    else __builtin_amdgcn_s_setreg((1 - 1) << 11 | 23 << 6 | 1, 0);
     __builtin_amdgcn_sched_barrier(0);
 }
 __device__ __forceinline__ uint32_t pack_f16x2_ovfl(float lo, float hi) {

@@ -17,6 +17,7 @@ struct WarpArgs {
     int ppd;             // depth planes per block
     int npb_batch;       // pixel blocks per batch item: ceil(h*w / PPB)
     int n_dchunks;       // ceil(D / ppd)
+    int variant;         // measurement switch of the LDS-staged kernel (pscv_set_tuning("warp_tile")): 1 = the round-2 sweep loop
     float temp;
     float sx, sy;        // index scale: PROJ 1, HOMOG (W-1)/W
     float xlo, xhi, ylo, yhi;  // clamp of the pixel index implied by the reference's grid clamp

@@ -408,6 +408,7 @@ extern "C" int pscv_warp_cost(const void* ref, const void* const* srcs, int n_sr
     a.n_src = n_src; a.B = B; a.h = h; a.w = w; a.hs = hs; a.ws = ws; a.D = D;
     a.depth_per_pixel = depth_per_pixel;
     a.temp = temp;
+    a.variant = 0;
     const long vol = (long)B * D * h * w;
     a.out_view_stride = cost == PSCV_COST_GROUPCORR ? vol * (C / 4) : vol * C;   // (PARTIAL: offset of the sum-of-squares half)
     if (geom == PSCV_GEOM_PROJ) {

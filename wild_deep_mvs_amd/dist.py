@@ -56,6 +56,110 @@ def merge_partials(partials: torch.Tensor, group: Optional[dist.ProcessGroup] = 
     return merge_partials_local(bufs)
 
 
+# ---- slab exchange of the Vis-MVSNet source-view shard (reduce-scatter -> slab-sharded RegFuse) ----------
+FUSE_HALO = 8      # reach of the fuse U-Net (+-7) plus its 3x3x3 head (+-1) along every axis, in voxels (scripts/dev/depth_shard_probe.py)
+
+
+def slab_size(extent: int, world: int) -> int:
+    """Units per rank along a sharded axis: even (the U-Net's stride-2 phase) and equal on every rank (reduce_scatter_tensor needs
+    equal chunks; the tail rank(s) own fewer VALID units when world * size > extent)."""
+    return 2 * ((extent + 2 * world - 1) // (2 * world))
+
+
+def slab_axis(d: int, h: int, world: int, halo: int = FUSE_HALO):
+    """Which axis of a [n,d,h,w,c] volume to cut into per-rank slabs: depth (1) or rows (2), whichever leaves the thicker slab
+    (least halo recompute); None when neither slab is at least ``halo`` thick (then a halo would span several ranks and the
+    replicated path is used).  Extents must be even like the U-Net requires."""
+    best = None
+    for axis, extent in ((1, d), (2, h)):
+        S = slab_size(extent, world)
+        if extent % 2 == 0 and S >= halo and (best is None or S > best[1]):
+            best = (axis, S)
+    return best
+
+
+def reduce_to_slab(share: torch.Tensor, axis: int, group=None, halo: int = FUSE_HALO):
+    """Every rank holds an additive 16-bit ``share`` [n,d,h,w,c] of one volume (sum over ranks = the volume).  Returns
+    ``(ext, lo, a, b)``: rank r owns units [a, b) of ``axis`` and gets the SUMMED volume on [lo, lo + ext.shape[axis]) =
+    [a - halo, b + halo) clipped to the volume, contiguous in the original layout (b == a on a tail rank without valid units:
+    ext is None).
+
+    Two steps, both in the storage format (the 16-bit payload SURVEY 8e budgets):
+      1. ``reduce_scatter_tensor`` of the per-rank slabs (payload (world-1)/world of the volume per rank);
+      2. the first / last ``halo`` units of the reduced slab go to the two neighbours (point-to-point, 2 * halo / extent of the
+         volume) -- recomputing the U-Net on that overlap replaces a per-layer halo exchange."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    E = share.shape[axis]
+    S = slab_size(E, world)
+    if S < halo:
+        raise ValueError(f"reduce_to_slab: slabs of {S} units are thinner than the halo ({halo}); use the replicated path")
+    xs = share.movedim(axis, 0)                                    # [E, ...] (a view; contiguous already when n == 1, axis == 1)
+    if world * S == E:
+        buf = xs.contiguous()
+    else:
+        buf = torch.zeros((world * S,) + tuple(xs.shape[1:]), dtype=share.dtype, device=share.device)
+        buf[:E] = xs
+    own = torch.empty((S,) + tuple(xs.shape[1:]), dtype=share.dtype, device=share.device)
+    dist.reduce_scatter_tensor(own, buf, group=group)
+    valid = [max(0, min(S, E - r * S)) for r in range(world)]
+    a, b = rank * S, rank * S + valid[rank]
+    if valid[rank] == 0:
+        return None, a, a, a
+    own = own[:valid[rank]]
+    # halo exchange with the neighbours that own valid units (only trailing ranks can be empty)
+    n_lo = min(halo, valid[rank - 1]) if rank > 0 else 0
+    n_hi = min(halo, valid[rank + 1]) if rank + 1 < world else 0
+    lo_buf = torch.empty((n_lo,) + tuple(own.shape[1:]), dtype=own.dtype, device=own.device) if n_lo else None
+    hi_buf = torch.empty((n_hi,) + tuple(own.shape[1:]), dtype=own.dtype, device=own.device) if n_hi else None
+    peer = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
+    sends, recvs = [], []
+    if rank > 0:                                                   # (valid[rank] > 0 implies valid[rank - 1] == S)
+        sends.append((own[:min(halo, valid[rank])].contiguous(), peer(rank - 1)))
+        recvs.append((lo_buf, peer(rank - 1)))
+    if n_hi:
+        sends.append((own[valid[rank] - min(halo, valid[rank]):].contiguous(), peer(rank + 1)))
+        recvs.append((hi_buf, peer(rank + 1)))
+    exchange(sends, recvs, group)
+    parts = [t for t in (lo_buf, own, hi_buf) if t is not None]
+    ext = (torch.cat(parts, dim=0) if len(parts) > 1 else own).movedim(0, axis).contiguous()
+    return ext, a - n_lo, a, b
+
+
+def exchange(sends, recvs, group=None) -> None:
+    """Point-to-point exchange: ``sends`` = [(tensor, global peer rank)], ``recvs`` = [(buffer, global peer rank)], all in one
+    ``batch_isend_irecv`` (RCCL groups them into one launch: every pair of GPUs has its own xGMI link, so neighbours exchange
+    at link rate).  RCCL takes device pointers and runs on the current stream.  Any other backend (gloo in the one-GPU tests)
+    gets HOST copies: ProcessGroupGloo's send / recv hand the raw pointer to a CPU transport that is not ordered with the HIP
+    stream -- with device tensors it reads slabs the producing kernel has not finished (seen as 1e-3..1e-2 depth errors at
+    configuration 5) -- so the payload goes through ``.cpu()`` (which synchronises) and back."""
+    if not sends and not recvs:
+        return
+    if dist.get_backend(group) == "nccl":
+        ops = [dist.P2POp(dist.isend, t, p, group) for t, p in sends] + [dist.P2POp(dist.irecv, t, p, group) for t, p in recvs]
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        return
+    host_s = [(t.cpu(), p) for t, p in sends]
+    host_r = [(torch.empty(t.shape, dtype=t.dtype), p) for t, p in recvs]
+    ops = [dist.P2POp(dist.isend, t, p, group) for t, p in host_s] + [dist.P2POp(dist.irecv, t, p, group) for t, p in host_r]
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+    for (dst, _), (src, _) in zip(recvs, host_r):
+        dst.copy_(src)
+
+
+def gather_rows(maps: torch.Tensor, rows: int, S: int, group=None) -> torch.Tensor:
+    """Row-slab results [n,k,valid,w] of every rank (valid = 0 on a tail rank without rows) -> the full maps [n,k,rows,w] on
+    every rank: one all-gather of S-row blocks (tail blocks zero-padded)."""
+    world = dist.get_world_size(group)
+    n, k, v, w = maps.shape
+    blk = torch.zeros((n, k, S, w), dtype=maps.dtype, device=maps.device)
+    blk[:, :, :v] = maps
+    bufs = [torch.empty_like(blk) for _ in range(world)]
+    dist.all_gather(bufs, blk, group=group)
+    return torch.cat(bufs, dim=2)[:, :, :rows].contiguous()
+
+
 class CollectiveTrace:
     """Measurement aid (bench.py ``sharded`` legs): while active, every ``torch.distributed`` collective the sharded models issue
     (``all_reduce``, ``all_gather``, ``broadcast``) is bracketed by CUDA events on the current stream and recorded as

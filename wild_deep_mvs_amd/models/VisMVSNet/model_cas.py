@@ -223,9 +223,13 @@ class SingleStage(nn.Module):
         self.storage_dtype = torch.float16
         self.train_storage_dtype = torch.bfloat16   # train(): bf16 activations / gradients by default (range), fp32 accumulation
         # source-view shard: with a torch.distributed group set here, rank r warps and
-        # regularises source views r, r+G, ... only; the visibility-weighted sums are all-reduced (RCCL) and every rank
-        # then runs RegFuse on the same fused volume.  The reference has no counterpart (it loops over all views).
+        # regularises source views r, r+G, ... only; the visibility-weighted sums are reduce-scattered (RCCL, 16-bit shares)
+        # into per-rank depth / row slabs and RegFuse runs slab-sharded (``_fuse_view_shard``).  The reference has no
+        # counterpart (it loops over all views).
         self.view_group = None
+        # source-view shard: True (default) = the fused volume is reduce-scattered into per-rank slabs and RegFuse runs on the
+        # slab (+ recomputed halo); False = 16-bit all-reduce + replicated RegFuse at every stage (measurement / tests)
+        self.view_slabs = True
         # depth-plane shard: with a group set here, rank r sweeps, regularises and fuses only
         # the planes it owns plus a 16-plane halo per side (the pair U-Net + head and the fuse U-Net + head each reach 8
         # planes), and the softmax over D is merged from per-rank partials.  The reference has no counterpart.
@@ -276,6 +280,77 @@ class SingleStage(nn.Module):
         est_depth = idx.unsqueeze(1) * depth_interval + depth_start                      # model_cas.py:404-405
         return est_depth, conf.unsqueeze(1), pair_results
 
+    @staticmethod
+    def _merged_head(score_ext, a, b, ea, grp, window=None):
+        """Softmax statistics over ALL depth planes from a rank's scores on [ea, ea + score_ext.shape[1]): log-sum-exp partials
+        (max, sum e, sum e*logit, sum e*index) of the OWNED planes [a, b) (none: a neutral partial), one small all-gather, local
+        merge -> (expected index, entropy, +-window probability or None); the window probability is one more all-reduce of a
+        [n,h,w] map."""
+        import torch.distributed as dist
+        world = dist.get_world_size(grp)
+        n, _, h, w = score_ext.shape
+        if b > a:
+            own = score_ext[:, a - ea:b - ea].contiguous()
+            part = ops.softargmin(own, own, want_partials=True, index_offset=a)["partials"]     # "depth" := the logits
+        else:
+            part = torch.zeros((n, 4, h, w), dtype=torch.float32, device=score_ext.device)
+            part[:, 0] = -3.0e38
+        bufs = [torch.empty_like(part) for _ in range(world)]
+        dist.all_gather(bufs, part, group=grp)
+        st = torch.stack(bufs)                                                          # [world,n,4,h,w]
+        m = st[:, :, 0].max(dim=0).values
+        f = torch.exp(st[:, :, 0] - m.unsqueeze(0))
+        Z, sl, si = (st[:, :, 1] * f).sum(0), (st[:, :, 2] * f).sum(0), (st[:, :, 3] * f).sum(0)
+        idx = si / Z
+        entropy = m + torch.log(Z) - sl / Z               # -sum p log p = log-sum-exp - E[logit]
+        conf = None
+        if window is not None:
+            if b > a:
+                conf = ops.softargmin_window(own, torch.stack([m, Z, idx], dim=1).contiguous(), window=window, index_offset=a)
+            else:
+                conf = torch.zeros((n, h, w), dtype=torch.float32, device=score_ext.device)
+            dist.all_reduce(conf, group=grp)
+        return idx, entropy, conf
+
+    def _fuse_view_shard(self, interms, uncerts, grp):
+        """Source-view shard, fusion + fuse net (reference model_cas.py:354-357,385-405 across ranks).  Rank r holds the pair
+        volumes of ITS source views.  (1) all-reduce of the weight sums [n,h,w] (tiny); (2) each rank normalises its partial
+        sum by the TOTAL weight and rounds it to the storage format: an additive 16-bit share of the fused volume; (3)
+        ``dist.reduce_to_slab``: reduce-scatter of the shares into per-rank slabs along depth or rows (whichever slab is
+        thicker) + 8-unit halos from the two neighbours; (4) RegFuse + head on the slab (the halo is recomputed: values more
+        than 8 units inside an artificial border equal the unsharded ones); (5) heads: depth slabs merge log-sum-exp partials,
+        row slabs regress locally and all-gather their rows.  Stages whose slabs would be thinner than the halo reduce the
+        16-bit shares with one all-reduce and run RegFuse replicated.  Returns (expected index [n,h,w], +-2 probability [n,h,w],
+        fused volume or None)."""
+        import torch.distributed as dist
+        from ... import dist as pdist
+        world = dist.get_world_size(grp)
+        part, wsum = ops.fuse_pairs(interms, uncerts, normalise=False, want_wsum=True)
+        dist.all_reduce(wsum, group=grp)                                               # sum_v w_v over ALL views
+        share = ops.fuse_finish(part, wsum, interms[0].dtype)                          # (sum_{v in rank} w_v interm_v) / sum_v w_v
+        n, d, h, w, _ = share.shape
+        plan = pdist.slab_axis(d, h, world) if self.view_slabs else None
+        if plan is None:
+            dist.all_reduce(share, group=grp)                                          # 16-bit payload, replicated fuse net
+            score = self.reg_fuse(share)
+            o = ops.softargmin(score, None, want_index=True, want_conf=True, conf_mode=1, window=2.0)
+            return o["index"], o["conf"], share, score
+        axis, S = plan
+        ext, lo, a, b = pdist.reduce_to_slab(share, axis, grp)
+        score = self.reg_fuse(ext) if ext is not None else None                        # fp32 scores on the extended slab
+        if axis == 1:
+            if score is None:
+                score = torch.zeros((n, 0, h, w), dtype=torch.float32, device=share.device)
+            idx, _, conf = self._merged_head(score, a, b, lo, grp, window=2.0)
+            return idx, conf, None, None
+        if score is not None:
+            o = ops.softargmin(score[:, :, a - lo:b - lo].contiguous(), None, want_index=True, want_conf=True, conf_mode=1, window=2.0)
+            rows = torch.stack([o["index"], o["conf"]], dim=1)                         # [n,2,valid,w]
+        else:
+            rows = torch.zeros((n, 2, 0, w), dtype=torch.float32, device=share.device)
+        full = pdist.gather_rows(rows, h, S, grp)
+        return full[:, 0], full[:, 1], None, None
+
     DEPTH_HALO = 16   # planes of redundant compute per side: 8 (pair U-Net + head) + 8 (fuse U-Net + head)
 
     def forward_depth_shard(self, ref_feat, ref_cam, srcs_feat, srcs_cam, depth_num, depth_start, depth_interval, s_scale):
@@ -293,22 +368,7 @@ class SingleStage(nn.Module):
         costs = self.build_cost_volume(ref_feat, ref_cam, srcs_feat, srcs_cam, eb - ea, depth_start + depth_interval * ea,
                                        depth_interval, s_scale)
 
-        def merged(score_ext, window=None):
-            own = score_ext[:, a - ea:b - ea].contiguous()
-            part = ops.softargmin(own, own, want_partials=True, index_offset=a)["partials"]     # "depth" := the logits
-            bufs = [torch.empty_like(part) for _ in range(world)]
-            dist.all_gather(bufs, part, group=grp)
-            st = torch.stack(bufs)                                                          # [world,n,4,h,w]
-            m = st[:, :, 0].max(dim=0).values
-            f = torch.exp(st[:, :, 0] - m.unsqueeze(0))
-            Z, sl, si = (st[:, :, 1] * f).sum(0), (st[:, :, 2] * f).sum(0), (st[:, :, 3] * f).sum(0)
-            idx = si / Z
-            entropy = m + torch.log(Z) - sl / Z               # -sum p log p = log-sum-exp - E[logit]
-            conf = None
-            if window is not None:
-                conf = ops.softargmin_window(own, torch.stack([m, Z, idx], dim=1).contiguous(), window=window, index_offset=a)
-                dist.all_reduce(conf, group=grp)
-            return idx, entropy, conf
+        merged = lambda score_ext, window=None: self._merged_head(score_ext, a, b, ea, grp, window)
 
         interms, uncerts, pair_results = [], [], []
         for i in range(len(srcs_feat)):
@@ -370,12 +430,12 @@ class SingleStage(nn.Module):
                 taps.update(uncert0=heads[0])
         if world == 1:
             fused = ops.fuse_pairs(interms, uncerts)                                   # model_cas.py:354-357,385-386
+            score = self.reg_fuse(fused)
+            o = ops.softargmin(score, None, want_index=True, want_conf=True, conf_mode=1, window=2.0)
+            index, conf = o["index"], o["conf"]
         else:
             import torch.distributed as dist
-            part, wsum = ops.fuse_pairs(interms, uncerts, normalise=False, want_wsum=True)
-            dist.all_reduce(part, group=self.view_group)                               # sum_v w_v interm_v  over all ranks
-            dist.all_reduce(wsum, group=self.view_group)                               # sum_v w_v
-            fused = ops.fuse_finish(part, wsum, interms[0].dtype)
+            index, conf, fused, score = self._fuse_view_shard(interms, uncerts, self.view_group)
             # every rank reports the pair results of ALL views, in view order
             flat = torch.stack([torch.cat([ed, hd[0]], dim=1) for ed, hd in pair_results])   # [mine,n,2,h,w]
             slots = (n_views + world - 1) // world
@@ -387,12 +447,10 @@ class SingleStage(nn.Module):
             for i in range(n_views):
                 rec = gathered[i % world][i // world]
                 pair_results.append([rec[:, 0:1], [rec[:, 1:2]]])
-        score = self.reg_fuse(fused)
-        o = ops.softargmin(score, None, want_index=True, want_conf=True, conf_mode=1, window=2.0)
-        est_depth = o["index"].unsqueeze(1) * depth_interval + depth_start             # model_cas.py:404-405
+        est_depth = index.unsqueeze(1) * depth_interval + depth_start                  # model_cas.py:404-405
         if taps is not None:
             taps.update(fused=fused, score=score)
-        return est_depth, o["conf"].unsqueeze(1), pair_results
+        return est_depth, conf.unsqueeze(1), pair_results
 
 
 class Model(nn.Module):
