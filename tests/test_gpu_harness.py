@@ -142,3 +142,78 @@ def test_load_network_flow_dataparallel_module_prefix_strict_false(env, architec
     assert torch.isfinite(out["depth"]).all() and torch.equal(out["depth"], bare["depth"])
     down = {"mvsnet": 4, "mvsnet-s": 4, "vis_mvsnet": 2, "cvp_mvsnet": 1}[architecture]           # pipeline_utils.py:140-154
     assert tuple(out["depth"].shape) == (1, 64 // down, 96 // down)
+
+
+@pytest.mark.parametrize("architecture", ["mvsnet", "vis_mvsnet", "cvp_mvsnet"])
+def test_unchanged_caller_gets_graph_replay(env, architecture):
+    """depthmap_eval.py:106 / run_depthmaps.py:57 call ``model(...)`` on a fresh sample per iteration and know nothing about
+    hipGraphs: from the second call of an input signature on, the mirrors' eval-mode forward replays a captured graph.  Fresh
+    inputs every call must give the eager result bit for bit (the graph reads its inputs from static buffers that are refilled),
+    through nn.DataParallel like the reference's loader wraps it; changing an option (num_depth / depth_nums) or the weights
+    re-captures; ``graph_replay = False`` opts out; a deepcopy of a model that has replayed still works."""
+    import copy
+    import time
+    import torch.nn as nn
+    from wild_deep_mvs_amd import graph as G, synthetic
+    if architecture == "mvsnet":
+        from wild_deep_mvs_amd.models.MVSNet.model import MVSNet
+        net, kind, kw = MVSNet("variance"), "mvsnet", {}
+        net.num_depth = 32
+    elif architecture == "vis_mvsnet":
+        from wild_deep_mvs_amd.models.VisMVSNet.frontend import Frontend
+        net, kind, kw = Frontend(), "vis", dict(depth_nums=[16, 8, 4], interval_scales=[4, 2, 1])
+    else:
+        from wild_deep_mvs_amd.models.CVP_MVSNet.frontend import Frontend
+        net, kind, kw = Frontend(), "cvp", {}
+    net.load_state_dict(synthetic.sharpened_state_dict(kind, synthetic.template_of(net), seed=0))
+    net = net.cuda().eval()
+    wrapped = nn.DataParallel(net, device_ids=[0])
+    scenes = [{k: v.cuda() for k, v in synthetic.make_scene(1, 3, 128, 160, seed=s).items()} for s in range(4)]
+    call = lambda m, sc: m(sc["imgs"], sc["K"], sc["R"], sc["t"], sc["depth_min"], sc["depth_max"], **kw)
+    with torch.no_grad():
+        net.graph_replay = False
+        eager = [call(wrapped, sc) for sc in scenes]
+        net.graph_replay = True
+        got = [call(wrapped, sc) for sc in scenes]                 # call 1 eager, call 2 captures, calls 3-4 replay
+        state = G._REPLAY[net]
+        assert len(state["graphs"]) == 1 and not state["failed"]
+        for e, g in zip(eager, got):
+            assert torch.equal(e["depth"], g["depth"]) and torch.equal(e["photometric_confidence"], g["photometric_confidence"])
+            for a, b in zip(e["depth_est_list"], g["depth_est_list"]):
+                assert torch.equal(a, b)
+        # replay is not slower than eager launches (it removes the host launch gaps: ~300 launches for Vis-MVSNet)
+        def timeit(flag):
+            net.graph_replay = flag
+            call(wrapped, scenes[0]); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(10):
+                call(wrapped, scenes[i % 4])
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / 10
+        t_eager, t_replay = timeit(False), timeit(True)
+        print(f"[replay] {architecture}: eager {t_eager * 1e3:.2f} ms, in-forward replay {t_replay * 1e3:.2f} ms per call", flush=True)
+        assert t_replay <= 1.1 * t_eager
+        # an option change is a new signature: first call eager, second captures
+        if architecture == "mvsnet":
+            net.num_depth = 16
+        elif architecture == "vis_mvsnet":
+            kw["depth_nums"] = [8, 8, 4]
+        else:
+            net.model.nscale = 3
+        net.graph_replay = False
+        ref2 = call(wrapped, scenes[1])
+        net.graph_replay = True
+        outs2 = [call(wrapped, scenes[1]) for _ in range(3)]
+        assert all(torch.equal(o["depth"], ref2["depth"]) for o in outs2)
+        assert len(state["graphs"]) == 2
+        # new weights (in place, as load_state_dict / an optimizer step do): the old graph must not be replayed
+        sd = synthetic.sharpened_state_dict(kind, synthetic.template_of(net), seed=1)
+        wrapped.module.load_state_dict(sd)
+        net.graph_replay = False
+        ref3 = call(wrapped, scenes[2])
+        net.graph_replay = True
+        outs3 = [call(wrapped, scenes[2]) for _ in range(3)]
+        assert all(torch.equal(o["depth"], ref3["depth"]) for o in outs3)
+        assert not torch.equal(ref3["depth"], ref2["depth"])
+        clone = copy.deepcopy(net)
+        assert torch.equal(call(clone, scenes[2])["depth"], ref3["depth"])

@@ -177,8 +177,13 @@ def lib():
     return _lib
 
 
+TUNING_GEN = 0      # bumped by every knob change: captured hipGraphs (graph.replayable) froze the kernel selection of their capture
+
+
 def set_tuning(key: str, value: int) -> None:
     """Process-wide: also seen by launches from other host threads (autograd's backward thread, DataParallel replicas)."""
+    global TUNING_GEN
+    TUNING_GEN += 1
     check(lib().pscv_set_tuning(key.encode(), int(value)), "pscv_set_tuning")
 
 
@@ -191,6 +196,8 @@ def get_tuning(key: str) -> int:
 
 def set_tuning_thread(key: str, value: int, enable: bool = True) -> None:
     """Override (or, enable=False, stop overriding) a knob for the calling host thread only."""
+    global TUNING_GEN
+    TUNING_GEN += 1
     check(lib().pscv_set_tuning_thread(key.encode(), int(value), 1 if enable else 0), "pscv_set_tuning_thread")
 
 

@@ -2,10 +2,11 @@
 import torch
 from torch import nn
 
+from ...graph import ReplayHooks, replayable
 from .models.net import network
 
 
-class Frontend(nn.Module):
+class Frontend(ReplayHooks, nn.Module):
     def __init__(self):
         super().__init__()
         self.model = network()
@@ -34,6 +35,7 @@ class Frontend(nn.Module):
     def feature_engine(self, name):
         self.model.feature_engine = name
 
+    @replayable
     def forward(self, imgs, K, R, t, depth_min, depth_max, reference_frame=0, **kwargs):
         src_idx = [i for i in range(K.shape[1]) if i != reference_frame]
         if isinstance(imgs, torch.Tensor):

@@ -17,6 +17,7 @@ import torch.nn as nn
 from ... import _lib as L
 from ... import ops
 from ... import training as T
+from ...graph import ReplayHooks, replayable
 from .module import ConvBnReLU, ConvBnReLU3D, deconv_engine_layer, homo_warping, depth_regression  # noqa: F401
 
 
@@ -177,7 +178,7 @@ class CostRegNet(nn.Module):
         return logits, {"depth": fused["depth"], "conf": fused["conf"]}
 
 
-class MVSNet(nn.Module):
+class MVSNet(ReplayHooks, nn.Module):
     def __init__(self, aggregation="variance"):
         super().__init__()
         if aggregation not in ("variance", "softmin"):
@@ -301,6 +302,7 @@ class MVSNet(nn.Module):
         blocks = self.cost_regularization.train_blocks()
         return T.RegressFn.apply(blocks, depth_values, dt, cost, *T.RegressFn.block_params(blocks))
 
+    @replayable
     def forward(self, imgs, K, R, t, depth_min, depth_max, reference_frame=0, **kwargs):
         if isinstance(imgs, torch.Tensor):
             imgs = torch.unbind(imgs, 1)

@@ -3,10 +3,11 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+from ...graph import ReplayHooks, replayable
 from .model_cas import Model
 
 
-class Frontend(nn.Module):
+class Frontend(ReplayHooks, nn.Module):
     def __init__(self):
         super().__init__()
         self.model = Model()
@@ -51,6 +52,7 @@ class Frontend(nn.Module):
         cam[:, 1, 3, 0], cam[:, 1, 3, 1] = start_depth, depth_interval
         return cam
 
+    @replayable
     def forward(self, imgs, K, R, t, depth_min, depth_max, reference_frame=0, **kwargs):
         depth_interval = (depth_max - depth_min) / 128                                   # frontend.py:27
         interval_scales = kwargs.get("interval_scales", self.interval_scales)
