@@ -63,17 +63,55 @@ DTYPES = {"f16": torch.float16, "bf16": torch.bfloat16}
 
 
 def pmc_traffic(name: str):
-    """HBM bytes per launch of `name` from the committed rocprofv3 PMC capture (profiles/r02_traffic.json, made by
-    scripts/profile.sh + scripts/prof_summary.py on the same command; regenerate it whenever the dominant kernel changes), or None."""
-    path = os.path.join(REPO, "profiles", "r02_traffic.json")
+    """HBM bytes per launch of `name` from the newest committed rocprofv3 PMC capture (profiles/rNN_traffic.json, made by
+    scripts/profile.sh + scripts/prof_summary.py on the same command: FETCH_SIZE doubled per the gfx950 note, WRITE_SIZE as is;
+    both 16-bit formats launch the same grid and move the same bytes), with the file it came from -- or (None, None).  The
+    capture is a separate rocprofv3 run (counters cannot be read from inside the timed process): regenerate it whenever the
+    dominant kernel changes; the file name in the line says which capture the number is from."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_traffic.json")), reverse=True):
+        try:
+            table = json.load(open(path))
+        except Exception:
+            continue
+        for key, rec in table.items():
+            if name.startswith(key) and rec.get("hbm_bytes"):
+                return rec["hbm_bytes"], os.path.basename(path)
+    return None, None
+
+
+def live_traffic(dtype_name: str, timeout_s: int = 150):
+    """HBM bytes per launch of the headline step's full-resolution kernels, measured NOW: two short rocprofv3 counter passes
+    (FETCH_SIZE and WRITE_SIZE each in its own run, kernel trace only -- MI355X_MICROARCH.md's HBM recipe) over this same script
+    with `--steps 3 --eager`, read back from the rocpd databases by scripts/prof_summary.py.  Returns ({kernel: bytes}, note) or
+    (None, reason).  Runs after the timed regions, in child processes; the committed capture stays the fallback."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    root = tempfile.mkdtemp(prefix="pscv_traffic_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs",
+           "--eager", "--no-live-traffic", "--dtype", dtype_name]
     try:
-        table = json.load(open(path))
-    except Exception:
-        return None
-    for key, rec in table.items():
-        if name.startswith(key):
-            return rec.get("hbm_bytes")
-    return None
+        for sub, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+            r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "-d", os.path.join(root, sub), "-o", "bench", "--"] + cmd,
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} rc={r.returncode}: {r.stderr[-200:]}"
+        sys.path.insert(0, os.path.join(REPO, "scripts"))
+        import prof_summary
+        prof_summary.traffic_json(root)
+        table = json.load(open(os.path.join(root, "traffic.json")))
+        return {k: v["hbm_bytes"] for k, v in table.items()}, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run (FETCH_SIZE x 2: gfx950)"
+    except Exception as e:   # pragma: no cover
+        return None, f"{type(e).__name__}: {e}"[:200]
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
 
 
 def build_inputs(device, rank: int, dtype):
@@ -228,13 +266,15 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-other-configs", action="store_true", help="skip the forward() timings of BASELINE configurations 3-5")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the full-forward() timings / rooflines of BASELINE configurations 1-5")
     ap.add_argument("--no-sharded", action="store_true", help="N > 1: skip the depth-plane / source-view sharded legs (configurations 3 and 5)")
     ap.add_argument("--dtype", choices=sorted(DTYPES), default="f16",
                     help="16-bit HBM storage format (arithmetic is fp32); f16 is the engine default, see DESIGN.md section 5")
     ap.add_argument("--dump-events", default=None, help="write every per-launch event duration to this file")
     ap.add_argument("--eager", action="store_true", help="time eager launches instead of hipGraph replays")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="pscv_set_tuning knob (measurement runs)")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not run the two rocprofv3 counter passes that measure roofline.traffic "
+                                                                    "(then the newest committed profiles/rNN_traffic.json is quoted)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of an N > 1 run (nccl = RCCL over xGMI; gloo only "
                                                       "for the CPU rendezvous test)")
     ap.add_argument("--rendezvous-only", action="store_true",
@@ -397,9 +437,17 @@ def run(args):
         name, (n, ms) = max(kern.items(), key=lambda kv: kv[1][1])
         avg_s = ms / n * 1e-3
         ab = algorithmic_bytes(name)
+        traffic, traffic_source = pmc_traffic(name)
+        if world == 1 and not args.no_live_traffic:
+            live, note = live_traffic(args.dtype)
+            hit = [v for k, v in (live or {}).items() if name.startswith(k)]
+            if hit:
+                traffic, traffic_source = hit[0], note
+            else:
+                traffic_source = f"{traffic_source} (live capture unavailable: {note})"
         roof = {"kernel": name, "bound": "hbm", "achieved": ab / avg_s / 1e9 if ab else None, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": (ab / avg_s / 1e9 / HBM_PEAK_GBS) if ab else None,
-                "traffic": pmc_traffic(name) if args.dtype == "f16" else None,
+                "traffic": traffic, "traffic_source": traffic_source,
                 "avg_us": avg_s * 1e6, "algorithmic_bytes": ab, "share_of_gpu_time": ms / total_ms}
         # the matrix-core side of the path (north_star: "MFMA utilisation on the 3D conv against gfx950 peak"): the layer with
         # 68 % of the regulariser's FLOPs, conv0 32 -> 8 at full resolution (2 * 27 * 32 * 8 FLOP per voxel).  Per layer it is
@@ -441,15 +489,16 @@ def run(args):
             line["alt"]["depth_rel_l1_vs_oracle"] = rel[alt_name]
         else:
             line["cpu_baseline"] = None
-        # BASELINE configurations 3, 4, 5 in their single-GPU forms (parity cases of tests/test_gpu_fullsize.py, not bench lines):
-        # driver-timed ms of the full forward(), after the headline region
+        # all five BASELINE configurations in their single-GPU forms (parity cases of tests/test_gpu_fullsize.py, not bench lines):
+        # driver-timed ms of the full forward() called like the reference's scripts call it (in-forward hipGraph replay and eager),
+        # with the three heaviest kernels of each against their rooflines; after the headline region
         line["sharded"] = sharded
         line["other_configs"] = None
         if world == 1 and not args.no_other_configs:
             try:
                 sys.path.insert(0, os.path.join(REPO, "scripts"))
                 import run_configs
-                line["other_configs"] = [run_configs.time_config(c) for c in (3, 4, 5)]
+                line["other_configs"] = [run_configs.time_config(c) for c in (1, 2, 3, 4, 5)]
             except Exception as e:   # pragma: no cover  (never lose the headline line to a side measurement)
                 line["other_configs"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         print(json.dumps(line), flush=True)

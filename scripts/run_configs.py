@@ -41,11 +41,37 @@ CONFIGS = {
 }
 
 
+HBM_PEAK_GBS, MFMA_PEAK_TFLOPS = 8000.0, 2500.0     # /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def kernel_rooflines(detail: dict, top: int = 3) -> list:
+    """The ``top`` kernels by GPU time of one eager forward (ops.EventTimer.detail()): algorithmic bytes / flops per launch,
+    average duration, and the fraction of the HBM and dense-MFMA peaks they reach; ``bound`` = the roofline that is nearer
+    (arithmetic intensity against the 312 FLOP/B ridge)."""
+    total = sum(v["ms"] for v in detail.values()) or 1.0
+    rows = []
+    for name, v in sorted(detail.items(), key=lambda kv: -kv[1]["ms"])[:top]:
+        t = v["ms"] * 1e-3
+        gbs = v["bytes"] / t / 1e9 if v["bytes"] else None
+        tfs = v["flops"] / t / 1e12 if v["flops"] else None
+        mfma = name.startswith("conv")
+        ai = v["flops"] / v["bytes"] if v["bytes"] else None
+        bound = "mfma" if (mfma and ai is not None and ai > MFMA_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS) else "hbm"
+        rows.append({"kernel": name, "launches": v["launches"], "avg_us": v["ms"] / v["launches"] * 1e3, "share_of_gpu_time": v["ms"] / total,
+                     "bound": bound, "achieved_GBs": gbs, "hbm_frac": None if gbs is None else gbs / HBM_PEAK_GBS,
+                     "achieved_TFLOPs": tfs if mfma else None, "mfma_frac": (tfs / MFMA_PEAK_TFLOPS) if (mfma and tfs) else None,
+                     "frac": (tfs / MFMA_PEAK_TFLOPS) if bound == "mfma" else (None if gbs is None else gbs / HBM_PEAK_GBS)})
+    return rows
+
+
 def time_config(cid: int, reps: int = 3) -> dict:
-    """One BASELINE configuration through the engine's full forward() (2-D features included): ms per forward (eager launches,
-    wall clock between synchronisations, after two warm-up calls), cost-volume voxels and output sanity.  Used by bench.py's
+    """One BASELINE configuration through the engine's full forward() (2-D features included), driven the way the reference's
+    callers drive it -- ``net(...)`` on the same signature again and again (depthmap_eval.py:106): ms per forward with the
+    in-forward hipGraph replay (the default) and with eager launches (``graph_replay = False``), wall clock between
+    synchronisations after warm-up; then one eager pass under HIP events for the per-kernel rooflines.  Used by bench.py's
     "other_configs" and by this script."""
     import gc
+    from wild_deep_mvs_amd import ops
     cfg = CONFIGS[cid]
     net = build(cfg["arch"])
     cfg["setup"](net)
@@ -53,46 +79,40 @@ def time_config(cid: int, reps: int = 3) -> dict:
     if "bscale" in cfg:
         scene["t"] = scene["t"] * cfg["bscale"]
     dev = {k: v.cuda() for k, v in scene.items()}
-    with torch.no_grad():
-        call = lambda: net(dev["imgs"], dev["K"], dev["R"], dev["t"], dev["depth_min"], dev["depth_max"], **cfg["kw"])
-        out = call()
-        out = call()
+    call = lambda: net(dev["imgs"], dev["K"], dev["R"], dev["t"], dev["depth_min"], dev["depth_max"], **cfg["kw"])
+
+    def timed():
+        out = call(); out = call(); out = call()        # (eager, capture, replay -- or three eager calls)
         torch.cuda.synchronize()
         gc.collect(); gc.disable()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            out = call()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / reps
-        gc.enable()
-        # the same forward replayed from a hipGraph (graph.GraphedModel: one capture per input signature, inputs copied into
-        # static buffers): what a serving loop runs; the eager number above is bound by the host's launch rate on the small sizes
-        dt_graph = None
         try:
-            from wild_deep_mvs_amd.graph import GraphedModel
-            gnet = GraphedModel(net)
-            gcall = lambda: gnet(dev["imgs"], dev["K"], dev["R"], dev["t"], dev["depth_min"], dev["depth_max"], **cfg["kw"])
-            gout = gcall(); gout = gcall()
-            torch.cuda.synchronize()
-            gc.collect(); gc.disable()
             t0 = time.perf_counter()
             for _ in range(reps):
-                gout = gcall()
+                out = call()
             torch.cuda.synchronize()
-            dt_graph = (time.perf_counter() - t0) / reps
+            return (time.perf_counter() - t0) / reps, out
+        finally:
             gc.enable()
-            same = float((gout["depth"] - out["depth"]).abs().max())
-            del gnet, gout
-        except Exception as e:   # noqa: BLE001  (reported, not hidden: the eager number stands on its own)
-            gc.enable()
-            dt_graph, same = None, f"{type(e).__name__}: {e}"[:200]
+    with torch.no_grad():
+        net.graph_replay = False
+        dt_eager, out = timed()
+        with ops.EventTimer() as tm:
+            call()
+        detail = tm.detail()
+        net.graph_replay = True
+        dt, gout = timed()
+        same = float((gout["depth"] - out["depth"]).abs().max())
     d = out["depth"]
+    gpu_ms = sum(v["ms"] for v in detail.values())
     res = {"config": cid, "model": cfg["arch"], "views": cfg["V"], "image": [cfg["H"], cfg["W"]], "kwargs": {k: v for k, v in cfg["kw"].items()},
            "ms_per_forward": dt * 1e3, "voxels": cfg["vox"](), "voxels_per_s": cfg["vox"]() / dt,
            "finite": bool(torch.isfinite(d).all()) and bool(torch.isfinite(out["photometric_confidence"]).all()),
-           "timed": "full forward() incl. 2-D feature nets, eager launches, fp16 storage",
-           "ms_per_forward_graph": None if dt_graph is None else dt_graph * 1e3, "graph_max_abs_diff_vs_eager": same}
-    del net, out, dev
+           "timed": "full forward() incl. 2-D feature nets called like depthmap_eval.py:106 (the forward replays its own hipGraph from "
+                    "the second call of a signature on), fp16 storage",
+           "ms_per_forward_eager": dt_eager * 1e3, "replay_max_abs_diff_vs_eager": same,
+           "engine_kernel_ms_eager_pass": gpu_ms, "engine_launches": sum(v["launches"] for v in detail.values()),
+           "roofline": kernel_rooflines(detail)}
+    del net, out, gout, dev
     torch.cuda.empty_cache()
     return res
 

@@ -68,6 +68,7 @@ class EventTimer:
 
     def __init__(self):
         self.records = []
+        self.costs = []
 
     def __enter__(self):
         global _timer
@@ -79,13 +80,15 @@ class EventTimer:
         _timer = self._prev
         return False
 
-    def launch(self, name, fn):
+    def launch(self, name, fn, cost=None):
         st = torch.cuda.current_stream()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(st)
         rc = fn()
         e1.record(st)
         self.records.append((name, e0, e1))
+        if cost is not None:
+            self.costs.append((name,) + tuple(cost()))
         return rc
 
     def summary(self):
@@ -96,12 +99,24 @@ class EventTimer:
             out[name] = (n + 1, ms + e0.elapsed_time(e1))
         return out
 
+    def detail(self):
+        """{name: dict(launches, ms, bytes, flops)}: ``bytes`` / ``flops`` are the ALGORITHMIC HBM bytes (operands read once,
+        results written once) and floating-point operations the launches of that name asked for (conv3d / conv2d / warp_cost
+        report them; 0 for the others)."""
+        out = {k: dict(launches=n, ms=ms, bytes=0.0, flops=0.0) for k, (n, ms) in self.summary().items()}
+        for name, b, f in self.costs:
+            out[name]["bytes"] += b
+            out[name]["flops"] += f
+        return out
+
 
 _timer: Optional[EventTimer] = None
 
 
-def _launch(name, fn):
-    return _timer.launch(name, fn) if _timer is not None else fn()
+def _launch(name, fn, cost=None):
+    """Run a C-ABI launch; under an EventTimer it is bracketed by HIP events and ``cost()`` -> (algorithmic bytes, flops) is
+    recorded with it (evaluated only then)."""
+    return _timer.launch(name, fn, cost) if _timer is not None else fn()
 
 
 # --------------------------------------------------------------------------------------------
@@ -296,7 +311,9 @@ def conv2d(x: torch.Tensor, layer: Conv2dLayer, *, out_dtype: Optional[torch.dty
     rc = _launch(f"conv2d[{layer.c_in}->{layer.c_out},k{layer.ks}s{layer.stride}]", lambda: L.lib().pscv_conv2d_ex(
         _p(x), _dt(x), _p(layer.packed), _p(layer.scale), _p(layer.bias), _p(skip), 0 if skip is None else skip.shape[3], skip_coff,
         _p(out), out.shape[3], out_coff, _dt(out), B, H, W, layer.c_in, layer.c_out, layer.ks, layer.stride, int(parity),
-        float(layer.neg_slope), _stream()))
+        float(layer.neg_slope), _stream()),
+        cost=lambda: _conv_cost(B * H * W, B * Ho * Wo, layer.c_in, layer.c_out, layer.ks * layer.ks, False, out.element_size(),
+                                skip is not None))
     L.check(rc, "pscv_conv2d")
     return out
 
@@ -416,7 +433,10 @@ def warp_cost(ref: Optional[torch.Tensor], srcs: Sequence[torch.Tensor], cams: t
     ptrs = (C.c_void_p * n)(*[s.data_ptr() for s in srcs])
     rc = _launch(f"warp_cost[{cost}]", lambda: L.lib().pscv_warp_cost(
         _p(ref), ptrs, n, _p(cams), _p(depth), bstride, int(per_pixel), geom, cost, float(temp), _p(out), B, Cc, h, w,
-        hs, ws, D, _dt(srcs[0]), _dt(out), _stream()))
+        hs, ws, D, _dt(srcs[0]), _dt(out), _stream()),
+        # feature maps once + the volume once; per (voxel, view, channel) 4 blend FMAs + the cost statistic (2 FMAs)
+        cost=lambda: (float((n + (ref is not None)) * B * hs * ws * Cc * srcs[0].element_size() + out.numel() * out.element_size()),
+                      2.0 * 6 * n * B * D * h * w * Cc))
     L.check(rc, "pscv_warp_cost")
     return out
 
@@ -574,6 +594,14 @@ def conv_out_shape(kind: int, D: int, H: int, W: int):
     return 2 * D, 2 * H, 2 * W   # CONV_T2, CONV_T2P8
 
 
+def _conv_cost(vox_in: int, vox_out: int, c_in: int, c_out: int, taps: int, transposed_s2: bool, out_bytes: int, with_skip: bool):
+    """(algorithmic HBM bytes, flops) of one convolution launch: input and output once (+ the skip tensor), 2 x taps x c_in x c_out
+    per output voxel (a stride-2 transposed layer touches every input voxel with every tap instead)."""
+    b = vox_in * c_in * 2 + vox_out * c_out * out_bytes + (vox_out * c_out * 2 if with_skip else 0)
+    f = 2.0 * taps * c_in * c_out * (vox_in if transposed_s2 else vox_out)
+    return float(b), f
+
+
 def conv3d(x: torch.Tensor, layer: Conv3dLayer, *, skip: Optional[torch.Tensor] = None, in_coff: int = 0,
            skip_coff: int = 0, out: Optional[torch.Tensor] = None, out_coff: int = 0,
            out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
@@ -595,7 +623,9 @@ def conv3d(x: torch.Tensor, layer: Conv3dLayer, *, skip: Optional[torch.Tensor] 
     rc = _launch(f"conv3d[{layer.c_in}->{layer.c_out},k{layer.kind}]", lambda: L.lib().pscv_conv3d(
         _p(x), _dt(x), cs, in_coff, _p(layer.packed), _p(layer.scale), _p(layer.bias), _p(layer.floor), _p(skip),
         0 if skip is None else skip.shape[4], skip_coff, _p(out), out.shape[4], out_coff, _dt(out), B, D, H, W,
-        layer.c_in, layer.c_out, layer.kind, layer.epi, _stream()))
+        layer.c_in, layer.c_out, layer.kind, layer.epi, _stream()),
+        cost=lambda: _conv_cost(B * D * H * W, B * Do * Ho * Wo, layer.c_in, layer.c_out, 27, layer.kind in (L.CONV_T2, getattr(L, "CONV_T2P8", -1)),
+                                out.element_size(), skip is not None))
     L.check(rc, "pscv_conv3d")
     return out
 
