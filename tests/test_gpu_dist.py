@@ -378,6 +378,71 @@ def test_vis_view_shard_slab_regfuse_two_ranks_nccl(monkeypatch):
     test_vis_view_shard_slab_regfuse_two_ranks_one_gpu()
 
 
+def _mvsnet_depth_shard_worker(rank, world, port, cases, q):
+    _init(rank, world, port)
+    try:
+        from wild_deep_mvs_amd import synthetic
+        from wild_deep_mvs_amd.dist import CollectiveTrace
+        from wild_deep_mvs_amd.models.MVSNet.model import MVSNet
+        dev = torch.device("cuda", rank if os.environ.get("PSCV_TEST_BACKEND") == "nccl" else 0)
+        out = []
+        for (agg, B, V, H, W, D) in cases:
+            net = MVSNet(agg)
+            net.load_state_dict(synthetic.sharpened_state_dict("mvsnet", synthetic.template_of(net), seed=0))
+            net = net.to(dev).eval()
+            net.num_depth = D
+            scene = {k: v.to(dev) for k, v in synthetic.make_scene(B, V, H, W, seed=7).items()}
+            call = lambda: net(scene["imgs"], scene["K"], scene["R"], scene["t"], scene["depth_min"], scene["depth_max"])
+            with torch.no_grad():
+                net.set_depth_group(None)
+                ref = call()
+                net.set_depth_group(dist.group.WORLD)
+                got = call()
+            d_abs = float((got["depth"] - ref["depth"]).abs().max() / ref["depth"].abs().max())
+            c_abs = float((got["photometric_confidence"] - ref["photometric_confidence"]).abs().max())
+            out.append((agg, D, d_abs, c_abs, got["depth"].cpu().numpy()))
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_mvsnet_depth_plane_shard_with_halo_exchange_two_ranks_one_gpu():
+    """Depth-plane shard of the WHOLE MVSNet hot path, regulariser included (SURVEY 8e's recommended shard; reference
+    models/MVSNet/model.py:43-84,109-139,207-215 across ranks): each rank warps planes [a - 2, b + 2) itself, the 11 U-Net layers
+    exchange one boundary plane per neighbour, the softmax and the 4-plane photometric confidence are merged from per-rank
+    partials.  Same kernels, same operands -> depth equals the unsharded run to fp32 merge order (1e-6 of the range), the
+    confidence to 1e-5; cases: D = 48 (24 planes per rank, three stride-2 levels down to 3 planes), batch of two, soft-min, and
+    the headline size 512x640 D = 192."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    cases = [("variance", 2, 3, 128, 160, 48), ("softmin", 1, 3, 128, 160, 16), ("variance", 1, 5, 512, 640, 192)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mvsnet_depth_shard_worker, args=(r, 2, port, cases, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        for agg, D, d_err, c_err, _ in res[rank]:
+            print(f"[parity] MVSNet depth-plane shard rank {rank} {agg} D={D}: depth max rel {d_err:.2e}, confidence max abs {c_err:.2e}", flush=True)
+            assert d_err <= 2e-6 and c_err <= 2e-5
+    for (_, _, _, _, d0), (_, _, _, _, d1) in zip(res[0], res[1]):
+        assert np.array_equal(d0, d1), "ranks must agree"
+
+
+@pytest.mark.skipif(not torch.cuda.is_available() or torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: 2+ MI355X")
+@pytest.mark.timeout(300)
+def test_mvsnet_depth_plane_shard_with_halo_exchange_two_ranks_nccl(monkeypatch):
+    monkeypatch.setenv("PSCV_TEST_BACKEND", "nccl")
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    test_mvsnet_depth_plane_shard_with_halo_exchange_two_ranks_one_gpu()
+
+
 # ---- the same three shardings over RCCL: one GPU per rank, backend "nccl" (skipped on one-GPU boxes) --------------------------
 needs_two_gpus = pytest.mark.skipif(not torch.cuda.is_available() or torch.cuda.device_count() < 2,
                                     reason="RCCL needs one GPU per rank: 2+ MI355X")

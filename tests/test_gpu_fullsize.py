@@ -96,14 +96,25 @@ def _nchw32(x, channels_last):
     return (x.permute(0, 3, 1, 2) if channels_last else x).contiguous().cpu()
 
 
-@pytest.mark.parametrize("cid", [3, 5])
-def test_vis_fullsize_stages_match_oracle_on_windows(gpu, cid):
+# bf16 storage (the format BASELINE configuration 2 names) at the full sizes: the same windows, against the fp32 oracle.  Its
+# 8-bit significand through ~20 stored tensors per stage does not meet the 1e-3 north-star bar on these nets (DESIGN.md section 5:
+# no mixed scheme is possible without per-layer mixed-operand kernels); the bars below are 1.5 x the values measured in round 3
+# and exist to catch regressions, fp16 keeps the north-star bar.  Measured (round 3): Vis configuration 3 stage depths 2.0e-3 / 4e-4 /
+# 1.4e-4 (coarse -> fine), CVP configuration 4 levels 6e-4 ... 3e-5: the coarse stages carry the error, the FINAL maps are inside 1e-3
+# (asserted below), like MVSNet's 7.4e-4 at configuration 2.
+WINDOW_BARS = {torch.float16: dict(depth=1e-3, pair=2e-3, prob=3e-2, cvp_cost=3e-3, cvp_logits=2e-2, cvp_depth=1e-3),
+               torch.bfloat16: dict(depth=6e-3, pair=1.2e-2, prob=2e-1, cvp_cost=2.5e-2, cvp_logits=1.5e-1, cvp_depth=6e-3)}
+
+
+@pytest.mark.parametrize("cid,dtype", [(3, torch.float16), (5, torch.float16), (3, torch.bfloat16)])
+def test_vis_fullsize_stages_match_oracle_on_windows(gpu, cid, dtype):
     """Every cascade stage of the full-size run against ``oracle.vismvsnet.single_stage`` on two windows of the stage's
     reference pixels (image corner and an interior window): fused depth, window probability and every pair depth."""
     L, ops, synthetic = gpu
     from oracle import vismvsnet as OV
     cfg = VIS_CONFIGS[cid]
-    net, sd = _vis_net(synthetic)
+    bars = WINDOW_BARS[dtype]
+    net, sd = _vis_net(synthetic, dtype=dtype)
     scene = {k: v.cuda() for k, v in synthetic.make_scene(1, cfg["V"], cfg["H"], cfg["W"], seed=cid).items()}
     captured = []
     stages = (net.model.stage1, net.model.stage2, net.model.stage3)
@@ -142,17 +153,19 @@ def test_vis_fullsize_stages_match_oracle_on_windows(gpu, cid):
             yb, xb = win - VIS_MARGIN, win - VIS_MARGIN
             sel = (slice(None), slice(None), slice(ya, yb), slice(xa, xb))
             e_est = est.float().cpu()[:, :, y0:y0 + win, x0:x0 + win]
-            s = check_close(f"cfg{cid} stage{k + 1} depth window ({y0},{x0})", e_est[sel], o_est[sel])
-            assert s["rel_l1"] <= 1e-3, s
-            check_close(f"cfg{cid} stage{k + 1} prob window ({y0},{x0})", prob.float().cpu()[:, :, y0:y0 + win, x0:x0 + win][sel],
-                        o_prob[sel], rel_l1=3e-2)
+            s = check_close(f"cfg{cid} {dtype} stage{k + 1} depth window ({y0},{x0})", e_est[sel], o_est[sel])
+            assert s["rel_l1"] <= bars["depth"], s
+            if k == 2:          # the FINAL depth map meets the north-star bar in both storage formats at the full sizes
+                assert s["rel_l1"] <= 1e-3, s
+            check_close(f"cfg{cid} {dtype} stage{k + 1} prob window ({y0},{x0})", prob.float().cpu()[:, :, y0:y0 + win, x0:x0 + win][sel],
+                        o_prob[sel], rel_l1=bars["prob"])
             m = VIS_MARGIN // 2
             ya, xa = (0 if y0 == 0 else m), (0 if x0 == 0 else m)
             selp = (slice(None), slice(None), slice(ya, win - m), slice(xa, win - m))
             for vi, ((ed, _), (o_ed, _)) in enumerate(zip(pairs, o_pairs)):
-                sp = check_close(f"cfg{cid} stage{k + 1} pair {vi} depth window ({y0},{x0})",
+                sp = check_close(f"cfg{cid} {dtype} stage{k + 1} pair {vi} depth window ({y0},{x0})",
                                  ed.float().cpu()[:, :, y0:y0 + win, x0:x0 + win][selp], o_ed[selp])
-                assert sp["rel_l1"] <= 2e-3, sp
+                assert sp["rel_l1"] <= bars["pair"], sp
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -161,7 +174,8 @@ def test_vis_fullsize_stages_match_oracle_on_windows(gpu, cid):
 CVP_MARGIN = 20      # receptive radius of the CVP CostRegNet is 17 voxels
 
 
-def test_cvp_fullsize_levels_match_oracle_on_windows(gpu):
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_cvp_fullsize_levels_match_oracle_on_windows(gpu, dtype):
     """Every pyramid level of the full-size run (96 coarse planes, then 8 per-pixel hypotheses per level up to 1024x1280, where
     the 64-channel convs run on 10.5 M voxels): ``calDepthHypo`` on the whole map, warp + variance + U-Net + regression on windows."""
     L, ops, synthetic = gpu
@@ -172,7 +186,8 @@ def test_cvp_fullsize_levels_match_oracle_on_windows(gpu):
     net = Frontend()
     sd = synthetic.sharpened_state_dict("cvp", synthetic.template_of(net), seed=0)
     net.load_state_dict(sd, strict=True)
-    net.storage_dtype = torch.float16
+    net.storage_dtype = dtype
+    bars = WINDOW_BARS[dtype]
     net = net.cuda().eval()
     scene = synthetic.make_scene(1, V, H, W, seed=4)
     scene["t"] = scene["t"] * 8
@@ -182,7 +197,7 @@ def test_cvp_fullsize_levels_match_oracle_on_windows(gpu):
         out = net(dev["imgs"], dev["K"], dev["R"], dev["t"], dev["depth_min"], dev["depth_max"], nscale=nscale, taps=taps)
         assert tuple(out["depth"].shape) == (1, H, W) and torch.isfinite(out["depth"]).all()
         # the engine's own pyramid (fp16, channels-last) as the oracle's input features
-        pyr = net.model.featurePyramid.forward_engine(torch.cat([dev["imgs"][:, i] for i in range(V)], 0), nscale, torch.float16)
+        pyr = net.model.featurePyramid.forward_engine(torch.cat([dev["imgs"][:, i] for i in range(V)], 0), nscale, dtype)
     feats = [[p[i:i + 1].float().permute(0, 3, 1, 2).contiguous().cpu() for p in pyr] for i in range(V)]     # [view][level] NCHW
     B = 1
     row = torch.tensor([0.0, 0.0, 0.0, 1.0])
@@ -218,15 +233,17 @@ def test_cvp_fullsize_levels_match_oracle_on_windows(gpu):
                 prob = torch.softmax(logits, 1)
                 o_depth = torch.sum(prob * (hw_.view(B, -1, 1, 1) if hw_.dim() == 2 else hw_), 1)
             e_cost = lt["cost"].float().cpu()[:, :, y0:y0 + win, x0:x0 + win].permute(0, 4, 1, 2, 3)
-            check_close(f"cfg4 level {level} cost window ({y0},{x0})", e_cost, cost, rel_l2=3e-3)
+            check_close(f"cfg4 {dtype} level {level} cost window ({y0},{x0})", e_cost, cost, rel_l2=bars["cvp_cost"])
             ya, xa = (0 if y0 == 0 else CVP_MARGIN), (0 if x0 == 0 else CVP_MARGIN)
             yb = win if y0 + win >= h else win - CVP_MARGIN
             xb = win if x0 + win >= w else win - CVP_MARGIN
             e_logits = lt["logits"].float().cpu()[:, :, y0:y0 + win, x0:x0 + win]
-            check_close(f"cfg4 level {level} logits window ({y0},{x0})", e_logits[:, :, ya:yb, xa:xb], logits[:, :, ya:yb, xa:xb], rel_l2=2e-2)
+            check_close(f"cfg4 {dtype} level {level} logits window ({y0},{x0})", e_logits[:, :, ya:yb, xa:xb], logits[:, :, ya:yb, xa:xb], rel_l2=bars["cvp_logits"])
             e_depth = out["depth_est_list"][level].float().cpu()[:, y0:y0 + win, x0:x0 + win]
-            s = check_close(f"cfg4 level {level} depth window ({y0},{x0})", e_depth[:, ya:yb, xa:xb], o_depth[:, ya:yb, xa:xb])
-            assert s["rel_l1"] <= 1e-3, s
+            s = check_close(f"cfg4 {dtype} level {level} depth window ({y0},{x0})", e_depth[:, ya:yb, xa:xb], o_depth[:, ya:yb, xa:xb])
+            assert s["rel_l1"] <= bars["cvp_depth"], s
+            if level == 0:      # the FINAL depth map meets the north-star bar in both storage formats
+                assert s["rel_l1"] <= 1e-3, s
         depth_prev = out["depth_est_list"][level].float().cpu()
 
 

@@ -56,6 +56,60 @@ def merge_partials(partials: torch.Tensor, group: Optional[dist.ProcessGroup] = 
     return merge_partials_local(bufs)
 
 
+def merge_partials_stats(partials: torch.Tensor, group: Optional[dist.ProcessGroup] = None):
+    """Like ``merge_partials`` but also returns the merged softmax statistics: (depth, index, max, sum exp), each [B,h,w]."""
+    world = dist.get_world_size(group)
+    bufs = [torch.empty_like(partials) for _ in range(world)]
+    dist.all_gather(bufs, partials.contiguous(), group=group)
+    stack = torch.stack(bufs)
+    m = stack[:, :, 0].max(dim=0).values
+    scale = torch.exp(stack[:, :, 0] - m.unsqueeze(0))
+    se = (stack[:, :, 1] * scale).sum(0)
+    return (stack[:, :, 2] * scale).sum(0) / se, (stack[:, :, 3] * scale).sum(0) / se, m, se
+
+
+def photometric_confidence_shard(own_logits: torch.Tensor, m: torch.Tensor, Z: torch.Tensor, index: torch.Tensor, a: int,
+                                 group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """MVSNet / CVP photometric confidence (reference models/MVSNet/model.py:211-215) with the depth planes sharded: this rank's
+    logits [B,n,h,w] are planes [a, a+n); under the merged statistics (max m, sum of exp Z, expected index) every rank adds the
+    probabilities of the planes i-1 .. i+2 it owns, i = trunc(E[index]); one all-reduce of a [B,h,w] map finishes the sum."""
+    n = own_logits.shape[1]
+    i0 = index.to(torch.int64)                                        # trunc: the expected index is >= 0
+    conf = torch.zeros_like(m)
+    for k in (-1, 0, 1, 2):
+        g = i0 + k - a
+        ok = (g >= 0) & (g < n)
+        val = torch.gather(own_logits, 1, g.clamp(0, n - 1).unsqueeze(1)).squeeze(1)
+        conf = conf + torch.where(ok, torch.exp(val - m) / Z, torch.zeros_like(m))
+    dist.all_reduce(conf, group=group)
+    return conf
+
+
+def halo_sync(y_ext: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> None:
+    """Depth-plane shard of a 3-tap-per-layer U-Net: ``y_ext`` [1, n + 4, ...] holds a layer's output on this rank's n owned
+    planes at [2, n + 2) with two halo slots per side.  The slot next to the owned planes is filled with the neighbour's boundary
+    plane (one point-to-point message per neighbour: C x h x w elements, 328 KB for MVSNet's first layer at 128 x 160); at the
+    ends of the volume the halo slots are zeroed = the convolution's own padding.  The outer slots only ever feed outputs that
+    are discarded."""
+    if y_ext.shape[0] != 1:
+        raise ValueError("halo_sync: one batch item at a time (plane slices must be contiguous)")
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = y_ext.shape[1] - 4
+    peer = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
+    sends, recvs = [], []
+    if rank > 0:
+        sends.append((y_ext[:, 2], peer(rank - 1)))
+        recvs.append((y_ext[:, 1], peer(rank - 1)))
+    else:
+        y_ext[:, :2].zero_()
+    if rank + 1 < world:
+        sends.append((y_ext[:, n + 1], peer(rank + 1)))
+        recvs.append((y_ext[:, n + 2], peer(rank + 1)))
+    else:
+        y_ext[:, n + 2:].zero_()
+    exchange(sends, recvs, group)
+
+
 # ---- slab exchange of the Vis-MVSNet source-view shard (SURVEY.md section 8e: reduce-scatter -> slab-sharded RegFuse) ----------
 FUSE_HALO = 8      # reach of the fuse U-Net (+-7) plus its 3x3x3 head (+-1) along every axis, in voxels (scripts/dev/depth_shard_probe.py)
 

@@ -178,6 +178,58 @@ class CostRegNet(nn.Module):
         return logits, {"depth": fused["depth"], "conf": fused["conf"]}
 
 
+def _regnet_forward_depth_shard(self, x_ext: torch.Tensor, group) -> torch.Tensor:
+    """``CostRegNet`` on one rank's depth planes (the recommended shard for MVSNet / CVP; reference
+    models/MVSNet/model.py:43-84 has no counterpart).  ``x_ext`` [1, n + 4, h, w, 32]: the n owned planes (a multiple of 8) at
+    [2, n + 2), valid cost planes in the inner halo slots (the warp kernel computes them itself: no exchange for the first
+    layer), zeros beyond the ends of the volume.  Every layer runs the single-GPU kernel on the extended tensor -- the U-Net's
+    receptive field along depth is +-30 planes, so the halo cannot be recomputed like Vis-MVSNet's: ONE boundary plane per
+    layer and neighbour is exchanged instead (``dist.halo_sync``, 10 exchanges per forward) -- and keeps the owned planes at
+    [2, n_level + 2) of its output:
+      stride 1: out_ext = conv(in_ext);  stride 2: output plane t of the rank reads local input planes 2t+1 .. 2t+3, i.e. it is
+      output t + 1 of conv(in_ext) -> written at out_ext[1:];  transposed stride 2: run on in_ext[1 : m + 3] (halo, owned, halo),
+      whose 2 (m + 2) output planes are exactly out_ext.
+    Returns fp32 logits [1, n + 4, h, w] (owned planes at [2, n + 2))."""
+    from ... import dist as pdist
+    if self.training:
+        raise RuntimeError("pscv CostRegNet: the depth-plane shard is an inference path")
+    B, ne, h, w, _ = x_ext.shape
+    n = ne - 4
+    if B != 1 or n % 8 or h % 8 or w % 8:
+        raise ValueError(f"depth-plane shard: one batch item, owned planes / h / w multiples of 8 (got B={B}, n={n}, {h}x{w})")
+    ly = self.engine_layers(x_ext.dtype)
+    dt, dev = x_ext.dtype, x_ext.device
+    sync = lambda y: pdist.halo_sync(y, group)
+
+    def down(x, layer, n_out, c_out, hh, ww):          # stride 2: owned output planes land at [2, n_out + 2)
+        y = torch.empty((1, n_out + 4, hh, ww, c_out), dtype=dt, device=dev)
+        ops.conv3d(x, layer, out=y[:, 1:n_out + 3])
+        sync(y)
+        return y
+
+    def same(x, layer):
+        y = ops.conv3d(x, layer)
+        sync(y)
+        return y
+
+    def up(x, layer, skip):                            # transposed stride 2 on (halo, owned, halo)
+        m = x.shape[1] - 4
+        y = ops.conv3d(x[:, 1:m + 3], layer, skip=skip)
+        sync(y)
+        return y
+    c0 = same(x_ext, ly["conv0"])
+    c2 = same(down(c0, ly["conv1"], n // 2, 16, h // 2, w // 2), ly["conv2"])
+    c4 = same(down(c2, ly["conv3"], n // 4, 32, h // 4, w // 4), ly["conv4"])
+    c6 = same(down(c4, ly["conv5"], n // 8, 64, h // 8, w // 8), ly["conv6"])
+    u7 = up(c6, ly["conv7"], c4)
+    u9 = up(u7, ly["conv9"], c2)
+    u11 = up(u9, ly["conv11"], c0)
+    return ops.conv3d(u11, ly["prob"], out_dtype=torch.float32).view(1, ne, h, w)
+
+
+CostRegNet.forward_depth_shard = _regnet_forward_depth_shard
+
+
 class MVSNet(ReplayHooks, nn.Module):
     def __init__(self, aggregation="variance"):
         super().__init__()
@@ -209,6 +261,11 @@ class MVSNet(ReplayHooks, nn.Module):
         # counterpart.  (At the headline size the all-reduce of 2 x 503 MB costs more than warping all views locally --
         # DESIGN.md section 7 -- it pays off only when the per-view work dominates: many views, large maps.)
         self.view_group = None
+        # depth-plane shard (``set_depth_group``): rank r sweeps, regularises and regresses planes
+        # [a, b) of every reference view: the warp needs nothing from the other ranks, each of the 11 U-Net layers exchanges one
+        # boundary plane with each neighbour, the softmax over D is merged from log-sum-exp partials.  Strong scaling of ONE
+        # reference view; pays off when a rank's share of the regulariser outweighs ~10 point-to-point latencies
+        self.depth_group = None
 
     # -- upstream ---------------------------------------------------------------------------
     def extract_features(self, imgs: Sequence[torch.Tensor]) -> List[torch.Tensor]:
@@ -233,6 +290,48 @@ class MVSNet(ReplayHooks, nn.Module):
     def set_view_group(self, group):
         """Shard the source views of the variance cost volume over a torch.distributed group (None = no sharding)."""
         self.view_group = group
+
+    def set_depth_group(self, group):
+        """Shard the depth planes of the whole hot path over a torch.distributed group (None = no sharding)."""
+        self.depth_group = group
+
+    def _hot_path_depth_shard(self, features_cl, proj, depth_values, reference_frame):
+        import torch.distributed as dist
+        from ... import dist as pdist
+        grp = self.depth_group
+        world, rank = dist.get_world_size(grp), dist.get_rank(grp)
+        V = len(features_cl)
+        src_idx = [i for i in range(V) if i != reference_frame]
+        B, h, w, C = features_cl[reference_frame].shape
+        D = depth_values.shape[1]
+        if D % 8 or h % 8 or w % 8:
+            raise ValueError(f"MVSNet CostRegNet needs D,h,w multiples of 8 (got {D},{h},{w}), as in the reference")
+        a, b = pdist.plane_shard(D, world, rank, multiple=8)
+        n = b - a
+        if n == 0:
+            raise ValueError(f"depth-plane shard: {world} ranks for {D} planes leaves rank {rank} without an 8-plane block")
+        cams = ops.proj_cams_device(proj.to(torch.float32).contiguous(), reference_frame)
+        dv = depth_values.to(torch.float32)
+        lo, hi = max(0, a - 2), min(D, b + 2)              # the planes of the extended range [a - 2, b + 2) that exist
+        code = L.COST_VARIANCE if self.aggregation == "variance" else L.COST_SOFTMIN
+        if code == L.COST_SOFTMIN:
+            key = (ops.weights_epoch(), self.temp.data_ptr(), self.temp._version)
+            if getattr(self, "_temp_key", None) != key:
+                self._temp_val, self._temp_key = float(self.temp.detach().float().item()), key
+        depths, confs = [], []
+        for bi in range(B):                                # (plane slices of one batch item are contiguous views)
+            fb = [f[bi:bi + 1] for f in features_cl]
+            cost_ext = torch.empty((1, n + 4, h, w, C), dtype=fb[0].dtype, device=fb[0].device)
+            cost_ext[:, :lo - (a - 2)].zero_()
+            cost_ext[:, hi - (a - 2):].zero_()
+            ops.warp_cost(fb[reference_frame], [fb[i] for i in src_idx], cams[:, bi:bi + 1].contiguous(), dv[bi:bi + 1, lo:hi].contiguous(),
+                          geom=L.GEOM_PROJ, cost=code, temp=getattr(self, "_temp_val", 0.0), out=cost_ext[:, lo - (a - 2):hi - (a - 2)])
+            logits = self.cost_regularization.forward_depth_shard(cost_ext, grp)[:, 2:n + 2].contiguous()
+            part = ops.softargmin(logits, dv[bi:bi + 1, a:b].contiguous(), want_partials=True, index_offset=a)["partials"]
+            depth, index, m, Z = pdist.merge_partials_stats(part, grp)
+            depths.append(depth)
+            confs.append(pdist.photometric_confidence_shard(logits, m, Z, index, a, grp))
+        return torch.cat(depths, 0), torch.cat(confs, 0)
 
     def _sharded_variance(self, ref_feature, src_features, cams, depth_values):
         import torch.distributed as dist
@@ -272,6 +371,10 @@ class MVSNet(ReplayHooks, nn.Module):
                  reference_frame: int = 0, taps: Optional[dict] = None):
         """features_cl: V channels-last maps [B,h,w,32]; proj [B,V,4,4]; depth_values [B,D] fp32 (reference view).
         Returns (depth [B,h,w], photometric_confidence [B,h,w]) -- reference model.py:197-215."""
+        if self.depth_group is not None:
+            if self.view_group is not None or taps is not None:
+                raise NotImplementedError("pscv MVSNet: the depth-plane shard excludes the source-view shard and taps")
+            return self._hot_path_depth_shard(features_cl, proj, depth_values, reference_frame)
         V = len(features_cl)
         src_idx = [i for i in range(V) if i != reference_frame]
         cams = ops.proj_cams_device(proj.to(torch.float32).contiguous(), reference_frame)
