@@ -351,6 +351,7 @@ class SingleStage(nn.Module):
         full = pdist.gather_rows(rows, h, S, grp)
         return full[:, 0], full[:, 1], None, None
 
+    PAIR_BATCH_BYTES = 48 << 20   # pair volumes (8 channels, 16-bit) batched into one U-Net pass: at most this many bytes per group
     DEPTH_HALO = 16   # planes of redundant compute per side: 8 (pair U-Net + head) + 8 (fuse U-Net + head)
 
     def forward_depth_shard(self, ref_feat, ref_cam, srcs_feat, srcs_cam, depth_num, depth_start, depth_interval, s_scale):
@@ -409,15 +410,27 @@ class SingleStage(nn.Module):
             raise ValueError("view shard: more ranks than source views")
         costs = self.build_cost_volume(ref_feat, ref_cam, srcs_feat, srcs_cam, depth_num, depth_start, depth_interval, s_scale)
         interms, uncerts, pair_results, est_depths, entropies = [], [], [], [], []
-        for i in range(len(srcs_feat)):
-            interm = self.reg(costs[i])
-            score = self.reg_pair(interm)                                              # fp32 [n,d,h,w]
-            o = ops.softargmin(score, None, want_index=True, want_entropy=True)
-            est_depths.append(o["index"].unsqueeze(1) * depth_interval + depth_start)  # model_cas.py:348
-            entropies.append(o["entropy"].unsqueeze(1))
-            interms.append(interm)
-            if taps is not None and i == 0:
-                taps.update(cost0=costs[0], interm0=interm, score0=score, entropy0=o["entropy"])
+        # the pair branch of ALL source views as ONE batch per layer (the views share `reg` / `reg_pair`, and the fused warp
+        # launch already wrote their volumes back to back: [n_src, n, d, h, w, 8] -> [n_src * n, d, h, w, 8]): 7 + 1 + 1 launches
+        # per stage instead of 9 per source view -- at 512x640 a per-view launch is 10-20 us of a few hundred workgroups
+        # (configuration 3: 162 -> 66 launches per forward); same kernels, same values
+        # ... as long as a group's 8-channel volume stays well inside the 256 MiB Infinity Cache: between the layers of ONE view's
+        # U-Net the activations are served from it, a batch of eight 118 MB volumes (configuration 5) is not -- measured there:
+        # deconv 1.53 -> 1.98 ms when batched, the stage as a whole no faster -- so large volumes keep one launch per view
+        n_s, n_b = costs.shape[0], costs.shape[1]
+        group = max(1, min(n_s, self.PAIR_BATCH_BYTES // max(1, costs[0].numel() * costs.element_size())))
+        for g0 in range(0, n_s, group):
+            g1 = min(n_s, g0 + group)
+            interm_all = self.reg(costs[g0:g1].view(((g1 - g0) * n_b,) + tuple(costs.shape[2:])))
+            score_all = self.reg_pair(interm_all)                                      # fp32 [views * n, d, h, w]
+            o_all = ops.softargmin(score_all, None, want_index=True, want_entropy=True)
+            for i in range(g0, g1):
+                sl = slice((i - g0) * n_b, (i - g0 + 1) * n_b)
+                est_depths.append(o_all["index"][sl].unsqueeze(1) * depth_interval + depth_start)  # model_cas.py:348
+                entropies.append(o_all["entropy"][sl].unsqueeze(1))
+                interms.append(interm_all[sl])
+                if taps is not None and i == 0:
+                    taps.update(cost0=costs[0], interm0=interm_all[sl], score0=score_all[sl], entropy0=o_all["entropy"][sl])
         # the 2-D UncertNet (eval-mode BatchNorm: per-sample) runs ONCE on the entropy maps of all pairs stacked along the batch
         # axis -- 3 convolutions per stage instead of 3 per source view (72 -> 9 launches of ~23 us at 9 views); same values
         n_b = entropies[0].shape[0]
