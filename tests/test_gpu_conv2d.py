@@ -50,11 +50,13 @@ def test_conv2d_matches_aten(env, ci, co, ks, stride, B, H, W, dtype):
     check_close("16-bit store", got16.float().cpu(), got.cpu(), max_abs=ulp * float(got.abs().max()) + 1e-6, rel_l2=ulp)
 
 
-@pytest.mark.parametrize("ci,co", [(3, 64), (64, 64), (64, 32), (32, 16), (16, 16)])
-def test_conv2d_leaky_relu_layers_of_the_cvp_pyramid(env, ci, co):
-    """conv 3x3 + bias + LeakyReLU(0.1) (models/CVP_MVSNet/models/modules.py:24-28), incl. the 64-channel layers whose
-    72 weight fragments stream through the prefetch ring."""
+@pytest.mark.parametrize("ci,co,wlds", [(3, 64, 1), (64, 64, 0), (64, 64, 2), (64, 32, 0), (64, 32, 2), (32, 16, 1), (16, 16, 1)])
+def test_conv2d_leaky_relu_layers_of_the_cvp_pyramid(env, ci, co, wlds):
+    """conv 3x3 + bias + LeakyReLU(0.1) (models/CVP_MVSNet/models/modules.py:24-28), incl. the 64-channel layers on both of
+    their kernels: weight fragments streamed per wave through the prefetch ring (conv2d_wlds = 0) and the persistent kernel
+    with the layer's weights resident in LDS (2 = at any size; ragged 45 x 70 maps: partial tiles, 2 x 12 tiles over the CUs)."""
     L, ops = env
+    L.set_tuning("conv2d_wlds", wlds)
     g = torch.Generator().manual_seed(ci + co)
     B, H, W = 2, 45, 70
     x = torch.randn(B, ci, H, W, generator=g)
@@ -65,8 +67,13 @@ def test_conv2d_leaky_relu_layers_of_the_cvp_pyramid(env, ci, co):
     layer = ops.Conv2dLayer.build(w, stride=1, device="cuda", conv_bias=bias, leaky=0.1, dtype=dtype)
     xcl = torch.zeros(B, H, W, layer.c_in, dtype=dtype)
     xcl[..., :ci] = x.permute(0, 2, 3, 1).to(dtype)
-    got = ops.conv2d(xcl.cuda(), layer, out_dtype=torch.float32)
+    try:
+        got = ops.conv2d(xcl.cuda(), layer, out_dtype=torch.float32)
+        got16 = ops.conv2d(xcl.cuda(), layer)
+    finally:
+        L.set_tuning("conv2d_wlds", 1)
     check_close(f"leaky conv2d {ci}->{co}", got.permute(0, 3, 1, 2).cpu(), ref, max_abs=3e-5 * float(ref.abs().max()) + 1e-6, rel_l2=1e-5)
+    assert torch.equal(got16, got.to(dtype))
     assert float((ref < 0).float().mean()) > 0.2     # the negative branch is exercised
 
 

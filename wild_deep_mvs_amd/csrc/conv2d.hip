@@ -220,6 +220,237 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const Conv2dArgs a) {
     }
 }
 
+// ---- 64-channel 3x3 stride-1 layers (CVP-MVSNet's FeaturePyramid 64 -> 64 / 64 -> 32, Vis FeatExt 64 -> 64) -------------------
+// conv2d_kernel fetches its A fragments (the weights) from global memory per WAVE: at 64 input channels that is 18 k-steps x
+// NT tiles x 1 KB = 74 KB per wave and 295 KB per 256-pixel workgroup against a 49 KB input brick -- six times more bytes
+// through the CU's vector-memory path for the weights than for the image (TA busy 68 %, 25 % of the MFMA peak; round-2 notes).
+// Here the layer's packed weights live in LDS, loaded ONCE per workgroup, and the workgroups are persistent: one per CU
+// (74 KB weights + 49 KB brick), 512 threads, each wave one 32-pixel row of the 8 x 32 tile (2 M-tiles x NT N-tiles: 2 operand +
+// NT weight `ds_read_b128` per 2 NT MFMAs), looping over tiles with the NEXT tile's brick in flight (global -> registers)
+// while the current one is contracted, so HBM latency hides under the MFMAs instead of under other workgroups.
+constexpr int C2W_TH = 8, C2W_BH = 10, C2W_BW = 34, C2W_VS = 128, C2W_STEPS = 18, C2W_THREADS = 512;
+// Brick pixels are 128 bytes apart and the eight 16-byte chunks of pixel p (= row * 34 + column) sit at chunk ^ (p & 7): a
+// `ds_read_b128` lane group is 8 lanes with chunk A on pixels p0 + {0-3, 12-15} and 8 lanes with chunk A ^ 1 on p0 + {4-11}; under the
+// XOR the sixteen 16-byte bank granules they touch are all different (the 144-byte padded pitch of conv2d_kernel collides for 7 of
+// the 8 pairs of such a mixed group).
+__device__ __forceinline__ int c2w_lds(int p, int chunk) { return p * C2W_VS + ((chunk ^ (p & 7)) << 4); }
+constexpr int C2W_BRICK = C2W_BH * C2W_BW * C2W_VS;                       // 48 960 B
+constexpr int C2W_CHUNKS = C2W_BH * C2W_BW * 8;                           // 16-byte chunks of a brick (2720)
+constexpr int C2W_NLD = (C2W_CHUNKS + C2W_THREADS - 1) / C2W_THREADS;     // 6 per thread
+
+PSCV_PROF_BUFFER(c2w)
+template <typename H, int NT>
+__global__ __launch_bounds__(C2W_THREADS, 2) void conv2d_wlds_kernel(const Conv2dArgs a, int n_tiles) {
+    constexpr int W_BYTES = C2W_STEPS * NT * 1024;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int OPITCH = NT * 32 + 16;             // bytes per pixel of the output staging rows (+16: conflict-free 8-byte writes)
+    unsigned char* const sw = smem;                  // [step][tile][lane] x 16 B
+    unsigned char* const sb = smem + W_BYTES;        // brick
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned char* const so = smem + W_BYTES + C2W_BRICK + wave * (32 * OPITCH);   // this wave's output row: 32 pixels
+    const int n = lane & 15, g = lane >> 4;
+
+    // weights -> LDS (once)
+    for (int q = tid; q < C2W_STEPS * NT * 64; q += C2W_THREADS) {
+        const int st = q / (NT * 64), rem = q - st * (NT * 64);
+        const int m = rem >> 6, ln = rem & 63;
+        *reinterpret_cast<uint4*>(sw + q * 16) = a.wpk[(st * a.nt_total + m) * 64 + ln];
+    }
+    // this thread's chunks of a brick (tile-invariant part)
+    int cr[C2W_NLD], cbw[C2W_NLD], loff[C2W_NLD];
+    unsigned ccoff[C2W_NLD];
+    bool cin[C2W_NLD];
+#pragma unroll
+    for (int k = 0; k < C2W_NLD; ++k) {
+        const int q = tid + C2W_THREADS * k;
+        cin[k] = q < C2W_CHUNKS;
+        const int r = q / (C2W_BW * 8), rem = q - r * (C2W_BW * 8);
+        cr[k] = r; cbw[k] = rem >> 3;
+        ccoff[k] = (unsigned)(rem & 7) * 16u;
+        loff[k] = c2w_lds(r * C2W_BW + cbw[k], rem & 7);
+    }
+    float sc[NT][4], bi[NT][4];
+#pragma unroll
+    for (int m = 0; m < NT; ++m)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = m * 16 + g * 4 + k;
+            sc[m][k] = (a.scale && c < a.cout) ? a.scale[c] : 1.0f;
+            bi[m][k] = (a.bias && c < a.cout) ? a.bias[c] : 0.0f;
+        }
+    const unsigned row_bytes = (unsigned)a.Wi * 128u;
+    const int tiles_per_img = a.nth * a.ntw;
+    unsigned roff[C2W_NLD];                             // chunk offset from the brick's first pixel (interior tiles)
+#pragma unroll
+    for (int k = 0; k < C2W_NLD; ++k) roff[k] = cin[k] ? (unsigned)cr[k] * row_bytes + (unsigned)cbw[k] * 128u + ccoff[k] : 0u;
+    auto fetch = [&](int t, uint4 (&val)[C2W_NLD]) {
+        const int b = t / tiles_per_img, rt = t - b * tiles_per_img;
+        const int th_i = rt / a.ntw, tw_i = rt - th_i * a.ntw;
+        const int iy0 = th_i * C2W_TH - 1, ix0 = tw_i * C2_TW - 1;
+        const char* inb = reinterpret_cast<const char*>(a.in) + (unsigned long)b * a.Hi * row_bytes;
+        if (iy0 >= 0 && ix0 >= 0 && iy0 + C2W_BH <= a.Hi && ix0 + C2W_BW <= a.Wi) {
+            // interior tile (workgroup-uniform): one scalar base + a precomputed 32-bit lane offset per chunk, no bounds tests --
+            // the general form below cost ~1100 cycles per tile in 64-bit address arithmetic and predicates
+            const char* base = inb + (unsigned long)iy0 * row_bytes + (unsigned)ix0 * 128u;
+#pragma unroll
+            for (int k = 0; k < C2W_NLD; ++k) val[k] = *reinterpret_cast<const uint4*>(base + roff[k]);
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < C2W_NLD; ++k) {
+            const int gy = iy0 + cr[k], gx = ix0 + cbw[k];
+            const bool ok = cin[k] && (unsigned)gy < (unsigned)a.Hi && (unsigned)gx < (unsigned)a.Wi;
+            val[k] = make_uint4(0u, 0u, 0u, 0u);
+            if (ok) val[k] = *reinterpret_cast<const uint4*>(inb + (unsigned long)gy * row_bytes + (unsigned)gx * 128u + ccoff[k]);
+        }
+    };
+    const int p_anchor = wave * C2W_BW + n;                      // this wave's row, column tile 0; tile 1 = + 16 pixels
+    uint4 val[C2W_NLD];
+    int t = blockIdx.x;
+    if (t < n_tiles) fetch(t, val);
+    PSCV_PROF_BEGIN   // (profile builds, summed over the tiles: brick landed + written | barrier | next fetch issued | k-loop | epilogue | barrier)
+    for (; t < n_tiles; t += gridDim.x) {
+#pragma unroll
+        for (int k = 0; k < C2W_NLD; ++k)
+            if (cin[k]) *reinterpret_cast<uint4*>(sb + loff[k]) = val[k];
+        PSCV_STAMP_WAIT(0)
+        __syncthreads();
+        PSCV_STAMP(1)
+        const int tn = t + gridDim.x;
+        if (tn < n_tiles) fetch(tn, val);                        // in flight during the contraction below
+        PSCV_STAMP(2)
+
+        c2_f32x4 acc[2][NT];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int m = 0; m < NT; ++m) acc[i][m] = c2_f32x4{0.f, 0.f, 0.f, 0.f};
+        // k-loop, software-pipelined by hand: the operands of step s + 1 are requested BEFORE the MFMAs of step s (two register
+        // sets).  Left to the compiler each group of four MFMAs waited for `ds_read`s issued right in front of it, and with two
+        // waves per SIMD the LDS latency was exposed at every step (29 % of the MFMA peak).
+        uint4 wf[2][NT], xf[2][2];
+        auto request = [&](int s_, uint4 (&w_)[NT], uint4 (&x_)[2]) {
+            const int tap = s_ >> 1, kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+            for (int m = 0; m < NT; ++m) w_[m] = *reinterpret_cast<const uint4*>(sw + ((s_ * NT + m) * 64 + lane) * 16);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) x_[i] = *reinterpret_cast<const uint4*>(sb + c2w_lds(p_anchor + i * 16 + kh * C2W_BW + kw, (s_ & 1) * 4 + g));
+        };
+        request(0, wf[0], xf[0]);
+#pragma unroll
+        for (int s = 0; s < C2W_STEPS; ++s) {
+            if (s + 1 < C2W_STEPS) request(s + 1, wf[(s + 1) & 1], xf[(s + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int m = 0; m < NT; ++m) acc[i][m] = C2Mfma<H>::run(wf[s & 1][m], xf[s & 1][i], acc[i][m]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        PSCV_STAMP(3)
+        // ---- epilogue: lane (n, g) owns channels 16 m + 4 g .. + 3 of pixel n of each of its two column tiles ----
+        {
+            const int b = t / tiles_per_img, rt = t - b * tiles_per_img;
+            const int th_i = rt / a.ntw, tw_i = rt - th_i * a.ntw;
+            const int oy = th_i * C2W_TH + wave;
+            if (!a.skip && !a.out_f32 && !((a.out_cs | a.out_co) & 7) && a.cout == NT * 16) {
+                // 16-bit output without a residual (every CVP pyramid layer): the wave's row is 32 pixels x NT x 32 contiguous
+                // bytes in memory.  An 8-byte store per lane and (column tile, channel tile) is store-ISSUE bound (~7 B/clk/CU: the
+                // 32 KB of a tile cost as many cycles as its MFMAs); the packed values go through a per-wave LDS row instead and
+                // leave as 16-byte stores, a lane covering 8 consecutive channels of a pixel (same bits)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int m = 0; m < NT; ++m) {
+                        float y[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float v = fmaf(acc[i][m][k], sc[m][k], bi[m][k]);
+                            y[k] = fmaxf(v, v * a.neg_slope);
+                        }
+                        *reinterpret_cast<uint2*>(so + (i * 16 + n) * OPITCH + (m * 16 + g * 4) * 2) =
+                            make_uint2(Half16<H>::pack(y[0], y[1]), Half16<H>::pack(y[2], y[3]));
+                    }
+                __builtin_amdgcn_wave_barrier();          // (LDS executes a wave's operations in order: the reads below see the row)
+                if (oy < a.Ho) {
+                    const unsigned long rowpix = ((unsigned long)b * a.Hof + (oy * a.oys + a.oyo)) * a.Wof;
+#pragma unroll
+                    for (int k = 0; k < NT; ++k) {
+                        const int q = lane + 64 * k, p = q / (NT * 2), c = q - p * (NT * 2);
+                        const uint4 v = *reinterpret_cast<const uint4*>(so + p * OPITCH + c * 16);
+                        const int ox = tw_i * C2_TW + p;
+                        if (ox < a.Wo)
+                            *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(a.out) + (rowpix + (ox * a.oxs + a.oxo)) * a.out_cs + a.out_co + c * 8) = v;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                // (issuing these stores one tile late, between the k-steps of the next tile, was measured: the k-loop grows by what
+                // the epilogue loses -- the CU moves 43.5 KB in + 32 KB out per tile through a ~10 B/clk memory path either way)
+            } else
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ox = tw_i * C2_TW + i * 16 + n;
+                if (oy >= a.Ho || ox >= a.Wo) continue;
+                const unsigned long pix = ((unsigned long)b * a.Hof + (oy * a.oys + a.oyo)) * a.Wof + (ox * a.oxs + a.oxo);
+#pragma unroll
+                for (int m = 0; m < NT; ++m) {
+                    const int c0 = m * 16 + g * 4;
+                    if (c0 >= a.cout) continue;
+                    float v[4], y[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = fmaf(acc[i][m][k], sc[m][k], bi[m][k]);
+                    if (a.skip) {
+                        const uint2 sv = *reinterpret_cast<const uint2*>(a.skip + pix * a.skip_cs + a.skip_co + c0);
+                        v[0] += Half16<H>::lo(sv.x); v[1] += Half16<H>::hi(sv.x); v[2] += Half16<H>::lo(sv.y); v[3] += Half16<H>::hi(sv.y);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) y[k] = fmaxf(v[k], v[k] * a.neg_slope);
+                    if (a.out_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + pix * a.out_cs + a.out_co + c0) = make_float4(y[0], y[1], y[2], y[3]);
+                    else *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.out) + pix * a.out_cs + a.out_co + c0) =
+                             make_uint2(Half16<H>::pack(y[0], y[1]), Half16<H>::pack(y[2], y[3]));
+                }
+            }
+        }
+        PSCV_STAMP(4)
+        __syncthreads();                                         // the brick is free for the next tile
+        PSCV_STAMP(5)
+    }
+    PSCV_PROF_END(c2w, blockIdx.x)
+}
+
+}  // namespace pscv
+PSCV_PROF_EXPORT(c2w)
+namespace pscv {
+Knob g_conv2d_wlds = {1, KNOB_SPARE1};    // pscv_set_tuning("conv2d_wlds", 0): 64-channel k3 s1 layers back on conv2d_kernel; 2: at any size
+
+template <typename H, int NT>
+static int c2w_launch(Conv2dArgs& a, hipStream_t st) {
+    constexpr int LDS = C2W_STEPS * NT * 1024 + C2W_BRICK + 8 * 32 * (NT * 32 + 16);
+    static_assert(LDS <= 160 * 1024, "weights + brick + output rows must fit the LDS");
+    a.nth = c2_ceil_div(a.Ho, C2W_TH); a.ntw = c2_ceil_div(a.Wo, C2_TW);
+    const long tiles = (long)a.B * a.nth * a.ntw;
+    if (tiles <= 0 || tiles > 0x7fffffffL) { set_error("pscv_conv2d: bad grid %ld", tiles); return -1; }
+    auto kern = conv2d_wlds_kernel<H, NT>;
+    static bool done = false;   // per instantiation
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) { set_error("pscv_conv2d: hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e)); return -2; }
+        done = true;
+    }
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { set_error("pscv_conv2d: device query failed"); return -2; }
+        n_cu = prop.multiProcessorCount;
+    }
+    const int per_cu = LDS <= 80 * 1024 ? 2 : 1;
+    const long grid = tiles < (long)n_cu * per_cu ? tiles : (long)n_cu * per_cu;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C2W_THREADS), LDS, st, a, (int)tiles);
+    return 0;
+}
+
 template <typename H, int CIN, int NT, int KS, int STRIDE>
 static int c2_launch(Conv2dArgs& a, int n_split, hipStream_t st) {
     constexpr int TH = STRIDE == 1 ? 8 : 4;
@@ -250,6 +481,9 @@ static int c2_dispatch(Conv2dArgs& a, int c_in, int c_out, int ks, int stride, h
     a.nt_total = nt;
     // (c_in, output tiles per workgroup, kernel size, stride); layers wider than 4 tiles (64 channels) split their output
     // tiles over blockIdx.y in groups of 4
+    if (c_in == 64 && ks == 3 && stride == 1 && (nt == 4 || nt == 2) && g_conv2d_wlds &&
+        (g_conv2d_wlds == 2 || (long)a.B * c2_ceil_div(a.Ho, C2W_TH) * c2_ceil_div(a.Wo, C2_TW) >= 512))
+        return nt == 4 ? c2w_launch<H, 4>(a, st) : c2w_launch<H, 2>(a, st);
     const int ntw = nt > 4 ? 4 : nt;
     const int split = (nt + ntw - 1) / ntw;
     if (nt > 4 && nt % 4) { set_error("pscv_conv2d: c_out=%d above 64 must be a multiple of 64", c_out); return -1; }
