@@ -175,14 +175,32 @@ def cpu_baseline(sd, feats, proj, dv, gpu_depths: dict):
 
 
 SHARDED = {
+    # BASELINE configuration 2 (the headline workload, full forward): MVSNet 5-view 512x640 D=192 with the depth planes of the WHOLE
+    # hot path sharded (MVSNet.set_depth_group: per-layer one-plane halo exchange, LSE-merged regression) -- and the size SURVEY 8e
+    # names for where that shard can pay: 1152x1600 images (288x400 maps), D = 256, 29 M cost-volume voxels
+    "mvsnet_depth": dict(config=2, model="mvsnet", V=5, H=512, W=640, num_depth=192, kw={}, vox=192 * 128 * 160, setter="set_depth_group"),
+    "mvsnet_depth_large": dict(config="2-large", model="mvsnet", V=5, H=1152, W=1600, num_depth=256, kw={}, vox=256 * 288 * 400,
+                               setter="set_depth_group"),
     # BASELINE configuration 3: Vis-MVSNet 5-view 512x640, depth planes [192,32,16] sharded over the ranks (LSE-merged heads)
-    "depth": dict(config=3, V=5, H=512, W=640, kw=dict(depth_nums=[192, 32, 16], interval_scales=[128 / 192, 1, 0.5]),
-                  vox=192 * 64 * 80 + 32 * 128 * 160 + 16 * 256 * 320),
-    # BASELINE configuration 5: Vis-MVSNet 9-view 1152x1600 [256,32,16], the 8 source views sharded over the ranks (all-reduce of
-    # the visibility-weighted partial sums, the "RCCL variance reduce" of that model)
-    "view": dict(config=5, V=9, H=1152, W=1600, kw=dict(depth_nums=[256, 32, 16], interval_scales=[0.5, 1, 0.5]),
-                 vox=256 * 144 * 200 + 32 * 288 * 400 + 16 * 576 * 800),
+    "depth": dict(config=3, model="vis", V=5, H=512, W=640, kw=dict(depth_nums=[192, 32, 16], interval_scales=[128 / 192, 1, 0.5]),
+                  vox=192 * 64 * 80 + 32 * 128 * 160 + 16 * 256 * 320, setter="set_depth_group"),
+    # BASELINE configuration 5: Vis-MVSNet 9-view 1152x1600 [256,32,16], the 8 source views sharded over the ranks (16-bit shares of
+    # the visibility-weighted sums reduce-scattered into depth / row slabs, slab-sharded RegFuse: the "RCCL variance reduce" of that model)
+    "view": dict(config=5, model="vis", V=9, H=1152, W=1600, kw=dict(depth_nums=[256, 32, 16], interval_scales=[0.5, 1, 0.5]),
+                 vox=256 * 144 * 200 + 32 * 288 * 400 + 16 * 576 * 800, setter="set_view_group"),
 }
+
+
+def _sharded_net(cfg, device):
+    if cfg["model"] == "mvsnet":
+        net = MVSNet("variance")
+        net.load_state_dict(synthetic.sharpened_state_dict("mvsnet", synthetic.template_of(net), seed=0))
+        net.num_depth = cfg["num_depth"]
+    else:
+        from wild_deep_mvs_amd.models.VisMVSNet.frontend import Frontend
+        net = Frontend()
+        net.load_state_dict(synthetic.sharpened_state_dict("vis", synthetic.template_of(net), seed=0))
+    return net.to(device).eval()
 
 
 def _all_ok(dist, device, ok: bool) -> bool:
@@ -193,7 +211,7 @@ def _all_ok(dist, device, ok: bool) -> bool:
     return bool(flag.item())
 
 
-def sharded_legs(dist, device, world, rank, reps=5):
+def sharded_legs(dist, device, world, rank, reps=5, only=None):
     """N > 1 only, after the headline region: ONE reference view computed cooperatively by all ranks (strong scaling) through the
     two shardings of the path that need a collective -- ``Frontend.set_depth_group`` and ``Frontend.set_view_group`` -- over
     RCCL.  Every rank runs the forward; times are the max over ranks; a second, traced pass attributes time and bytes to each
@@ -202,16 +220,15 @@ def sharded_legs(dist, device, world, rank, reps=5):
     Failure handling: the set-up of a leg (model, scene: where an out-of-memory would strike) is agreed on across the ranks before
     the first collective of the leg; a failure INSIDE a collective is bounded by the process group's timeout (``rendezvous``)."""
     from wild_deep_mvs_amd.dist import CollectiveTrace
-    from wild_deep_mvs_amd.models.VisMVSNet.frontend import Frontend
     out = {}
     for mode, cfg in SHARDED.items():
+        if only is not None and mode not in only:
+            continue
         net = scene = None
         err = None
         try:
-            net = Frontend()
-            net.load_state_dict(synthetic.sharpened_state_dict("vis", synthetic.template_of(net), seed=0))
-            net = net.to(device).eval()
-            scene = {k: v.to(device) for k, v in synthetic.make_scene(1, cfg["V"], cfg["H"], cfg["W"], seed=cfg["config"]).items()}
+            net = _sharded_net(cfg, device)
+            scene = {k: v.to(device) for k, v in synthetic.make_scene(1, cfg["V"], cfg["H"], cfg["W"], seed=5 if cfg["model"] == "mvsnet" else cfg["config"]).items()}
         except Exception as e:   # pragma: no cover
             err = f"setup: {type(e).__name__}: {e}"[:300]
         if not _all_ok(dist, device, err is None):
@@ -223,7 +240,7 @@ def sharded_legs(dist, device, world, rank, reps=5):
         try:
             times = {}
             for label, group in (("unsharded_replicated", None), ("sharded", dist.group.WORLD)):
-                (net.set_depth_group if mode == "depth" else net.set_view_group)(group)
+                getattr(net, cfg["setter"])(group)
                 with torch.no_grad():
                     call(); call()
                     dist.barrier(); torch.cuda.synchronize()
@@ -245,7 +262,7 @@ def sharded_legs(dist, device, world, rank, reps=5):
                 call()
             rel = float((depth - ref_depth).abs().mean() / ref_depth.abs().mean())
             coll = tr.summary()
-            out[mode] = {"config": cfg["config"], "model": "vis", "views": cfg["V"], "image": [cfg["H"], cfg["W"]], "kwargs": cfg["kw"],
+            out[mode] = {"config": cfg["config"], "model": cfg["model"], "views": cfg["V"], "image": [cfg["H"], cfg["W"]], "kwargs": cfg["kw"],
                          "scaling": "strong", "ms_per_forward_1gpu": times["unsharded_replicated"] * 1e3,
                          "ms_per_forward_sharded": times["sharded"] * 1e3, "n_gpus": world,
                          "voxels_per_s": cfg["vox"] / times["sharded"], "speedup_vs_1gpu": times["unsharded_replicated"] / times["sharded"],

@@ -86,11 +86,13 @@ def time_config(cid: int, reps: int = 3) -> dict:
         torch.cuda.synchronize()
         gc.collect(); gc.disable()
         try:
-            t0 = time.perf_counter()
-            for _ in range(reps):
+            ts = []
+            for _ in range(max(reps, 5)):                # median of individually timed calls: one allocator / driver hiccup
+                t0 = time.perf_counter()                 # (a 50 ms outlier was seen once) must not become the number
                 out = call()
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t0) / reps, out
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            return sorted(ts)[len(ts) // 2], out
         finally:
             gc.enable()
     with torch.no_grad():

@@ -480,7 +480,7 @@ def _bench_sharded_worker(rank, world, port, q):
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         import bench
         dev = torch.device("cuda", rank if os.environ.get("PSCV_TEST_BACKEND") == "nccl" else 0)
-        res = bench.sharded_legs(dist, dev, world, rank, reps=1)
+        res = bench.sharded_legs(dist, dev, world, rank, reps=1, only=("mvsnet_depth", "depth", "view"))
         q.put((rank, res))
     finally:
         dist.destroy_process_group()
@@ -488,8 +488,9 @@ def _bench_sharded_worker(rank, world, port, q):
 
 @pytest.mark.timeout(600)
 def test_bench_sharded_legs_two_ranks_one_gpu():
-    """``bench.py --gpus N``'s ``sharded`` object: configuration 3 through the depth-plane shard and configuration 5 through the
-    source-view shard, each against the unsharded run on the same rank, with the per-collective trace."""
+    """``bench.py --gpus N``'s ``sharded`` object: configuration 2 through MVSNet's depth-plane shard (per-layer halo exchange),
+    configuration 3 through the Vis depth-plane shard and configuration 5 through the source-view shard, each against the
+    unsharded run on the same rank, with the per-collective trace (the 1152x1600 MVSNet leg runs on multi-GPU nodes only)."""
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
     ctx = mp.get_context("spawn")
@@ -502,7 +503,7 @@ def test_bench_sharded_legs_two_ranks_one_gpu():
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    assert res[1] is None and set(res[0]) == {"depth", "view"}
+    assert res[1] is None and set(res[0]) == {"mvsnet_depth", "depth", "view"}
     for mode, r in res[0].items():
         assert "error" not in r, r
         print(f"[bench sharded] {mode}: 1 GPU {r['ms_per_forward_1gpu']:.2f} ms, 2 ranks {r['ms_per_forward_sharded']:.2f} ms, "

@@ -220,7 +220,7 @@ class CollectiveTrace:
     ``(name, payload bytes of this rank, milliseconds)``.  ``summary()`` groups the records by (name, bytes).  The events add a
     few microseconds per call; the traced pass is therefore separate from the timed one."""
 
-    NAMES = ("all_reduce", "all_gather", "broadcast", "reduce_scatter_tensor", "all_gather_into_tensor")
+    NAMES = ("all_reduce", "all_gather", "broadcast", "reduce_scatter_tensor", "all_gather_into_tensor", "batch_isend_irecv")
 
     def __init__(self):
         self.records = []
@@ -228,8 +228,12 @@ class CollectiveTrace:
 
     def _wrap(self, name, fn):
         def traced(*args, **kwargs):
-            tensors = [a for a in args if torch.is_tensor(a)] + [x for a in args if isinstance(a, (list, tuple)) for x in a if torch.is_tensor(x)]
-            payload = max((x.numel() * x.element_size() for x in tensors), default=0)
+            if name == "batch_isend_irecv":         # a list of P2POp: the payload is what this rank SENDS
+                tensors = [op.tensor for op in args[0]]
+                payload = sum(op.tensor.numel() * op.tensor.element_size() for op in args[0] if op.op is dist.isend)
+            else:
+                tensors = [a for a in args if torch.is_tensor(a)] + [x for a in args if isinstance(a, (list, tuple)) for x in a if torch.is_tensor(x)]
+                payload = max((x.numel() * x.element_size() for x in tensors), default=0)
             if not tensors or not tensors[0].is_cuda:
                 return fn(*args, **kwargs)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
