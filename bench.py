@@ -4,7 +4,9 @@
 A step = one pass of the hot path (fused warp + variance cost volume -> 3-D U-Net regularisation ->
 softmax / depth regression / confidence) over one batch of synthetic input that is already resident in
 HBM: BASELINE.json configs[1] = MVSNet, 1 ref + 4 src views, 512x640 images (128x160x32 feature maps),
-D = 192 planes, bf16 storage / fp32 accumulation.  3 932 160 cost-volume voxels per reference view.
+D = 192 planes, bf16 storage / fp32 accumulation.  3 932 160 cost-volume voxels per reference view; a batch is
+--batch reference views (default 3, each with its own source views; the engine runs the items of a batch on
+separate HIP streams; --batch 1 = one view at a time as in rounds 1-2, also reported in every line).
 
 Multi-GPU (--gpus N, one process per GPU): reference views are independent objects, so each rank sweeps its own
 view (global batch = N) with no data-path collective -> weak scaling.  Ranks come either from a launcher
@@ -114,20 +116,20 @@ def live_traffic(dtype_name: str, timeout_s: int = 150):
         shutil.rmtree(root, ignore_errors=True)
 
 
-def build_inputs(device, rank: int, dtype):
+def build_inputs(device, rank: int, dtype, batch: int = 1):
     net = MVSNet("variance")
     sd = synthetic.sharpened_state_dict("mvsnet", synthetic.template_of(net), seed=0)
     net.load_state_dict(sd)
     net = net.to(device).eval()
     net.num_depth = D
     net.storage_dtype = dtype
-    cams = synthetic.make_cameras(1, V, IMG_H, IMG_W)
+    cams = synthetic.make_cameras(batch, V, IMG_H, IMG_W)
     Ks = cams["K"].clone()
     Ks[:, :, :2] /= 4
     proj = build_proj_matrices(Ks, cams["R"], cams["t"])
     steps = torch.arange(D, dtype=torch.float32).view(1, -1)
     dv = cams["depth_min"][:, :1] + (cams["depth_max"][:, :1] - cams["depth_min"][:, :1]) / (D - 1) * steps
-    feats = synthetic.make_features(1, V, C, h, w, seed=1 + rank)           # [V,1,C,h,w] fp32
+    feats = synthetic.make_features(batch, V, C, h, w, seed=1 + rank)           # [V,batch,C,h,w] fp32: every reference view its own maps
     feats_cl = [ops.to_channels_last(feats[i].to(device), dtype) for i in range(V)]
     return net, sd, feats, feats_cl, proj.to(device), dv.to(device).contiguous(), proj, dv
 
@@ -151,26 +153,35 @@ def physical_cores() -> int:
 
 def cpu_baseline(sd, feats, proj, dv, gpu_depths: dict):
     """The oracle's hot path in the reference's eval-mode order (view by view, in-place sums: oracle.mvsnet.hot_path(streaming=True),
-    same stages, fp32 ATen) on the same workload: one warm-up pass, then the median of three, on the physical host cores.
-    The depth map of the pass also yields the second half of BASELINE.json's metric at the full headline size: relative L1 of the
-    engine's depth maps (one per storage format) against it."""
+    same stages, fp32 ATen) on ONE reference view of the step's batch (a bounded sample of the same workload): one warm-up pass, then
+    the median of three, on the physical host cores.  One more pass per remaining batch item (untimed) so that the second half of
+    BASELINE.json's metric -- relative L1 of the engine's depth maps (one per storage format) against the oracle at the full
+    headline size -- covers every view of the step."""
     from oracle import mvsnet as O          # cpu_baseline leg only
     cores = physical_cores()
     torch.set_num_threads(cores)
+    B = feats.shape[1]
     dvv = dv.unsqueeze(1).expand(-1, V, -1)
-    fl = [feats[i] for i in range(V)]
-    times = []
+    item = lambda b: ([feats[i][b:b + 1] for i in range(V)], proj[b:b + 1], dvv[b:b + 1])
+    times, o_depths = [], []
     with torch.no_grad():
-        o_depth, _ = O.hot_path(fl, proj, dvv, sd, streaming=True)     # warm-up: thread pool, allocator
+        fl, pj, dd = item(0)
+        o_depth, _ = O.hot_path(fl, pj, dd, sd, streaming=True)     # warm-up: thread pool, allocator
         for _ in range(3):
             t0 = time.perf_counter()
-            o_depth, _ = O.hot_path(fl, proj, dvv, sd, streaming=True)
+            o_depth, _ = O.hot_path(fl, pj, dd, sd, streaming=True)
             times.append(time.perf_counter() - t0)
+        o_depths.append(o_depth)
+        for b in range(1, B):
+            fl, pj, dd = item(b)
+            o_depths.append(O.hot_path(fl, pj, dd, sd, streaming=True)[0])
+    o_all = torch.cat(o_depths, 0)
     dt = sorted(times)[1]
-    rel = {k: float((d.float().cpu() - o_depth).abs().mean() / o_depth.abs().mean()) for k, d in gpu_depths.items()}
+    rel = {k: float((d.float().cpu() - o_all).abs().mean() / o_all.abs().mean()) for k, d in gpu_depths.items()}
     return {"value": VOX / dt, "unit": "voxels/s", "cores": cores, "kind": "port",
-            "sample": f"the same workload (5-view 128x160x32 features, D=192, fp32), eval-mode order of the reference; warm-up + median of "
-                      f"3 passes ({dt:.2f} s; all: {', '.join(f'{t:.2f}' for t in times)})",
+            "sample": f"one reference view of the step's batch (5-view 128x160x32 features, D=192, fp32), eval-mode order of the reference; "
+                      f"warm-up + median of 3 passes ({dt:.2f} s; all: {', '.join(f'{t:.2f}' for t in times)}); the depth comparison covers all "
+                      f"{B} views of the step",
             "ref_container_s": REF_CONTAINER["seconds"], "ref_container": REF_CONTAINER}, rel
 
 
@@ -282,6 +293,8 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=3, help="reference views per step and GPU (each with its own 4 source views): the engine runs "
+                                                          "the items of a batch on separate HIP streams (1 = one view at a time, as in rounds 1-2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the full-forward() timings / rooflines of BASELINE configurations 1-5")
     ap.add_argument("--no-sharded", action="store_true", help="N > 1: skip the depth-plane / source-view sharded legs (configurations 3 and 5)")
@@ -375,7 +388,8 @@ def run(args):
         from wild_deep_mvs_amd import _lib
         k, v = kv.split("=")
         _lib.set_tuning(k, int(v))
-    net, sd, feats, feats_cl, proj_d, dv_d, proj, dv = build_inputs(device, rank, DTYPES[args.dtype])
+    net, sd, feats, feats_cl, proj_d, dv_d, proj, dv = build_inputs(device, rank, DTYPES[args.dtype], args.batch)
+    NB = args.batch
 
     def timed_region(dtype_name, feats_cl_, steps):
         """W warm-up steps, then exactly `steps` steps between barrier + synchronize on both sides; then the same steps once
@@ -405,12 +419,17 @@ def run(args):
                     graph = None
                     torch.cuda.synchronize()
             run = graph.replay if graph is not None else step
+            # no cyclic-GC pause inside a timed region (a gen-2 collection with torch loaded costs ~40 ms) -- and none right in
+            # front of it either: tens of ms of host work leave the GPU idle, its clocks fall, and the first timed steps ran at the
+            # ramp (20 timed steps right behind the collection: 0.79 ms per 2-view step, steady state 0.69).  So: collect first,
+            # then the remaining warm-up on the path that is timed, then barrier + synchronize, then the clock starts
+            gc.collect()
+            gc.disable()
+            for _ in range(max(args.warmup, 1) * 8):
+                run()
             if dist is not None:
                 dist.barrier()
             torch.cuda.synchronize()
-            # no cyclic-GC pause inside a timed region (a gen-2 collection with torch loaded costs ~40 ms)
-            gc.collect()
-            gc.disable()
             t0 = time.perf_counter()
             for _ in range(steps):
                 run()
@@ -419,20 +438,39 @@ def run(args):
                 dist.barrier()
             torch.cuda.synchronize()
             elapsed = time.perf_counter() - t0
+            # per-kernel durations: the same launches (every batch item is launched on its own: B = 1 grids), but one item after
+            # the other on ONE stream, so that a kernel's HIP events time it alone rather than beside another item's kernels
+            item = lambda b: net.hot_path([f[b:b + 1] for f in feats_cl_], proj_d[b:b + 1], dv_d[b:b + 1])
             with ops.EventTimer() as tm:
                 t1 = time.perf_counter()
                 for _ in range(steps):
-                    depth, conf = step()
+                    for b in range(NB):
+                        item(b)
                 torch.cuda.synchronize()
                 elapsed_eager = time.perf_counter() - t1
+            # one view at a time (rounds 1-2's step): a replayed graph of item 0 alone
+            one_view = None
+            if NB > 1 and graph is not None:
+                try:
+                    g1 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+                        item(0)
+                    g1.replay(); torch.cuda.synchronize()
+                    t2 = time.perf_counter()
+                    for _ in range(steps):
+                        g1.replay()
+                    torch.cuda.synchronize()
+                    one_view = (time.perf_counter() - t2) / steps
+                except Exception:   # pragma: no cover
+                    one_view = None
             gc.enable()
         assert torch.isfinite(depth).all()
         t_max = torch.tensor([elapsed], device=device, dtype=torch.float64)
         if dist is not None:
             dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-        return float(t_max.item()), tm, depth.clone(), graph is not None, elapsed_eager
+        return float(t_max.item()), tm, depth.clone(), graph is not None, elapsed_eager, one_view
 
-    elapsed, tm, depth, graphed, elapsed_eager = timed_region(args.dtype, feats_cl, args.steps)
+    elapsed, tm, depth, graphed, elapsed_eager, one_view = timed_region(args.dtype, feats_cl, args.steps)
     kern = {k: v for k, v in tm.summary().items() if k != "proj_cams"}
     if args.dump_events and rank == 0:
         with open(args.dump_events, "w") as f:
@@ -441,7 +479,7 @@ def run(args):
     # the other 16-bit storage format on the same workload (BASELINE.json names bf16; same bytes, same MFMA rate)
     alt_name = "bf16" if args.dtype == "f16" else "f16"
     feats_alt = [ops.to_channels_last(feats[i].to(device), DTYPES[alt_name]) for i in range(V)]
-    alt_elapsed, alt_tm, alt_depth, _, _ = timed_region(alt_name, feats_alt, args.steps)
+    alt_elapsed, alt_tm, alt_depth, _, _, alt_one_view = timed_region(alt_name, feats_alt, args.steps)
     net.storage_dtype = DTYPES[args.dtype]
     graph = graphed
 
@@ -479,7 +517,7 @@ def run(args):
                          "frac": fl / t0s / 1e12 / MFMA_PEAK_TFLOPS, "avg_us": t0s * 1e6, "flops": fl,
                          "hbm_frac": algorithmic_bytes(c0[0]) / t0s / 1e9 / HBM_PEAK_GBS}
         line = {
-            "metric": "cost-volume voxels/sec (BxDxHxW), MVSNet hot path", "value": world * VOX * args.steps / elapsed,
+            "metric": "cost-volume voxels/sec (BxDxHxW), MVSNet hot path", "value": world * NB * VOX * args.steps / elapsed,
             "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
@@ -487,17 +525,24 @@ def run(args):
                           "rate; its driver-timed line and full-size depth error are under \"alt\" (and vice versa with --dtype bf16). "
                           "fp16 is the headline because bf16 storage sits at the 1e-3 parity bar (DESIGN.md section 3)",
             "config": {"workload": "MVSNet variance, 1 ref + 4 src views, 512x640 images (128x160x32 features), D=192, "
-                                   "features resident in HBM -> depth + confidence", "global_batch": world,
-                       "voxels_per_step_per_gpu": VOX, "parallelism": f"reference-view shard x{world}, no collective"},
+                                   f"features resident in HBM -> depth + confidence; a step = a batch of {NB} reference view(s) per GPU, "
+                                   "each with its own 4 source views", "global_batch": world * NB, "batch_per_gpu": NB,
+                       "voxels_per_step_per_gpu": NB * VOX, "parallelism": f"reference-view shard x{world}, no collective"},
             "timing": ("hipGraph replay of the step" if graph else "eager launches") +
-                      f"; per-kernel HIP events from an eager pass of the same {args.steps} steps "
-                      f"({elapsed_eager / args.steps * 1e3:.3f} ms/step eager)",
+                      (f"; the {NB} views of a step run on {NB} HIP streams (parallel branches of the graph): one view's vector-ALU-bound warp "
+                       "beside another's MFMA / memory-bound U-Net, same kernels and bit-equal outputs (MVSNet._hot_path_streams), so a step "
+                       "is SHORTER than the sum of its kernels' stand-alone durations below" if NB > 1 else "") +
+                      f"; kernels_us / roofline: HIP events of an eager pass of the same {args.steps} steps, one view after the other on one "
+                      f"stream (each launch timed alone; {elapsed_eager / args.steps * 1e3:.3f} ms/step that way)",
+            "one_view_at_a_time": None if one_view is None else {"ms_per_view": one_view * 1e3, "value": world * VOX / one_view, "unit": "voxels/s",
+                                                                 "what": "the step of rounds 1-2: one reference view per replay on one stream"},
             "roofline": roof,
             "roofline_mfma": roof_mfma,
             "kernels_us": {k: round(ms / n * 1e3, 2) for k, (n, ms) in sorted(kern.items(), key=lambda kv: -kv[1][1])},
         }
         alt_kern = {k: v for k, v in alt_tm.summary().items() if k != "proj_cams"}
-        line["alt"] = {"dtype": alt_name, "value": world * VOX * args.steps / alt_elapsed, "unit": "voxels/s",
+        line["alt"] = {"dtype": alt_name, "value": world * NB * VOX * args.steps / alt_elapsed, "unit": "voxels/s",
+                       "one_view_at_a_time_ms": None if alt_one_view is None else alt_one_view * 1e3,
                        "ms_per_step": alt_elapsed / args.steps * 1e3,
                        "kernels_us": {k: round(ms / n * 1e3, 2) for k, (n, ms) in sorted(alt_kern.items(), key=lambda kv: -kv[1][1])}}
         if world == 1 and not args.no_cpu_baseline:

@@ -207,3 +207,39 @@ def test_fused_tail_option_equals_default_path(env):
         L.set_tuning("c1_sweep", 1)
     check_close("fused tail depth", got["depth"].cpu(), want["depth"].cpu(), max_abs=2e-5)
     check_close("fused tail confidence", got["photometric_confidence"].cpu(), want["photometric_confidence"].cpu(), max_abs=5e-5)
+
+
+@pytest.mark.parametrize("B", [2, 3])
+def test_batch_items_on_separate_streams_equal_the_one_item_runs(env, B):
+    """``MVSNet._hot_path_streams``: the reference views of a batch run on their own HIP streams (one item's VALU-bound warp
+    beside another's MFMA / memory-bound U-Net).  Different scenes per item (a race between the branches must show), eager and
+    replayed from a captured graph (parallel branches) twenty times: depth and confidence equal the one-item runs bit for bit,
+    and the stream-less batched launches (``batch_streams = False``) to fp32 order."""
+    L, ops, synthetic, MVSNet, O = env
+    net = MVSNet("variance")
+    net.load_state_dict(synthetic.sharpened_state_dict("mvsnet", synthetic.template_of(net), seed=0))
+    net = net.cuda().eval()
+    net.num_depth, net.graph_replay = 32, False
+    scenes = [synthetic.make_scene(1, 4, 128, 160, seed=20 + b) for b in range(B)]
+    batch = {k: torch.cat([sc[k] for sc in scenes], 0).cuda() for k in scenes[0]}
+    keys = ("imgs", "K", "R", "t", "depth_min", "depth_max")
+    with torch.no_grad():
+        singles = [net(*[sc[k].cuda() for k in keys]) for sc in scenes]
+        got = net(*[batch[k] for k in keys])
+        for b in range(B):
+            assert torch.equal(got["depth"][b], singles[b]["depth"][0]) and torch.equal(got["photometric_confidence"][b], singles[b]["photometric_confidence"][0])
+        net.batch_streams = False
+        plain = net(*[batch[k] for k in keys])
+        net.batch_streams = True
+        assert float((plain["depth"] - got["depth"]).abs().max()) <= 1e-5 * float(got["depth"].abs().max())
+        static = {k: batch[k].clone() for k in keys}
+        for _ in range(2):
+            net(*[static[k] for k in keys])
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = net(*[static[k] for k in keys])
+        for rep in range(20):
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out["depth"], got["depth"]) and torch.equal(out["photometric_confidence"], got["photometric_confidence"]), rep

@@ -499,3 +499,35 @@ def test_tuning_knobs_are_process_wide_with_a_per_thread_override():
         L.set_tuning("no_such_knob", 1)
     with pytest.raises(L.PscvError):
         L.set_tuning_thread("no_such_knob", 1)
+
+
+def test_replay_keys_follow_options_weights_and_groups():
+    """Host logic of graph.replayable (the in-forward hipGraph replay): the option key sees every plain attribute of the model tree,
+    a torch.distributed group attached to any sub-module disables replay, the weights key follows in-place updates and storage
+    moves (`_apply`), and on CPU the decorated forward is simply the eager one."""
+    from wild_deep_mvs_amd import graph as G
+    from wild_deep_mvs_amd.models.MVSNet.model import MVSNet
+    from wild_deep_mvs_amd.models.VisMVSNet.frontend import Frontend
+    net = MVSNet("variance")
+    st = {}
+    k0 = G._options_key(net, st)
+    assert ("", "num_depth", 192) in k0 and ("", "storage_dtype", torch.float16) in k0
+    net.num_depth = 96
+    assert G._options_key(net, st) != k0 and ("", "num_depth", 96) in G._options_key(net, st)
+    net.depth_group = object()
+    assert G._options_key(net, st) is None
+    net.depth_group = None
+    w0 = G._fast_weights_key(net, st)
+    with torch.no_grad():
+        net.cost_regularization.prob.bias.add_(1.0)
+    w1 = G._fast_weights_key(net, st)
+    assert w1 != w0
+    net.double()                                    # storage replaced through _apply: the generation moves, the tensor list is rebuilt
+    w2 = G._fast_weights_key(net, st)
+    assert w2[1] == w1[1] + 1 and w2 != w1
+    vis = Frontend()
+    kv = G._options_key(vis, {})
+    assert ("", "depth_nums", repr([32, 16, 8])) in kv
+    vis.model.stage2.view_group = object()
+    assert G._options_key(vis, {}) is None
+    assert hasattr(MVSNet.forward, "eager")         # the decorator keeps the plain forward reachable
