@@ -98,7 +98,7 @@ def live_traffic(dtype_name: str, timeout_s: int = 150):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs",
-           "--eager", "--no-live-traffic", "--dtype", dtype_name]
+           "--eager", "--no-live-traffic", "--batch", "1", "--dtype", dtype_name]
     try:
         for sub, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
             r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "-d", os.path.join(root, sub), "-o", "bench", "--"] + cmd,
@@ -404,7 +404,10 @@ def run(args):
                 depth, conf = step()
             torch.cuda.synchronize()
             graph = None
-            if not args.eager:
+            # a batch of several views runs its items on separate streams with EAGER launches: forked into a hipGraph the same
+            # step replays wrongly on ROCm 7.2 once inputs change (MVSNet._hot_path_streams), and the host keeps ahead of the
+            # GPU anyway (~40 launches per ~1 ms step)
+            if not args.eager and NB == 1:
                 # the 13-launch step is launch-gap bound between its small kernels: capture it once, replay it
                 try:
                     graph = torch.cuda.CUDAGraph()
@@ -450,7 +453,7 @@ def run(args):
                 elapsed_eager = time.perf_counter() - t1
             # one view at a time (rounds 1-2's step): a replayed graph of item 0 alone
             one_view = None
-            if NB > 1 and graph is not None:
+            if NB > 1 and not args.eager:
                 try:
                     g1 = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g1, capture_error_mode="thread_local"):
@@ -529,9 +532,10 @@ def run(args):
                                    "each with its own 4 source views", "global_batch": world * NB, "batch_per_gpu": NB,
                        "voxels_per_step_per_gpu": NB * VOX, "parallelism": f"reference-view shard x{world}, no collective"},
             "timing": ("hipGraph replay of the step" if graph else "eager launches") +
-                      (f"; the {NB} views of a step run on {NB} HIP streams (parallel branches of the graph): one view's vector-ALU-bound warp "
-                       "beside another's MFMA / memory-bound U-Net, same kernels and bit-equal outputs (MVSNet._hot_path_streams), so a step "
-                       "is SHORTER than the sum of its kernels' stand-alone durations below" if NB > 1 else "") +
+                      (f"; the {NB} views of a step run on {NB} HIP streams: one view's vector-ALU-bound warp beside another's MFMA / "
+                       "memory-bound U-Net, same kernels and bit-equal outputs (MVSNet._hot_path_streams; eager because ROCm 7.2 replays "
+                       "multi-branch graphs of this path wrongly on changing inputs), so a step is SHORTER than the sum of its kernels' "
+                       "stand-alone durations below" if NB > 1 else "") +
                       f"; kernels_us / roofline: HIP events of an eager pass of the same {args.steps} steps, one view after the other on one "
                       f"stream (each launch timed alone; {elapsed_eager / args.steps * 1e3:.3f} ms/step that way)",
             "one_view_at_a_time": None if one_view is None else {"ms_per_view": one_view * 1e3, "value": world * VOX / one_view, "unit": "voxels/s",

@@ -95,8 +95,8 @@ int pscv_abi_version(void);
  *   "conv_s2_sweep"  1 (default): stride-2 layers with 8 input channels and <= 32 output channels on volumes of >= 64 Ki output
  *               voxels run the stride-2 depth-sweep kernel; 0: always the brick kernel; 2: the sweep at any size (same packed weights, same result up to
  *               fp32 summation order).  "s2s_slots": resident-workgroup target that sizes its depth chunks (0 = 768)
- *   "warp_tile"  0 (default): the LDS-staged warp kernel sweeps with the software-pipelined loop over compacted view slots
- *               (round 3) wherever every contributing view is staged; 1: the round-2 loop everywhere (same bits)
+ *   "warp_tile"  builds with -DWL_PIPELINED only (the software-pipelined sweep of the LDS-staged warp kernel, round 3): 0 = that
+ *               sweep wherever every contributing view is staged, 1 = the plain loop (same bits); no effect in the default build
  *   "conv2d_wlds"  1 (default): 64-channel k3 s1 2-D layers with 32 | 64 output channels and >= 512 tiles run the persistent
  *               kernel that keeps the layer's packed weights in LDS; 0: always conv2d_kernel; 2: at any size (same bits)
  *   "conv_small_tiles"  1 (default): small volumes use 1x4x16 tiles with the output channels split over

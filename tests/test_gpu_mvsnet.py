@@ -212,26 +212,35 @@ def test_fused_tail_option_equals_default_path(env):
 @pytest.mark.parametrize("B", [2, 3])
 def test_batch_items_on_separate_streams_equal_the_one_item_runs(env, B):
     """``MVSNet._hot_path_streams``: the reference views of a batch run on their own HIP streams (one item's VALU-bound warp
-    beside another's MFMA / memory-bound U-Net).  Different scenes per item (a race between the branches must show), eager and
-    replayed from a captured graph (parallel branches) twenty times: depth and confidence equal the one-item runs bit for bit,
-    and the stream-less batched launches (``batch_streams = False``) to fp32 order."""
+    beside another's MFMA / memory-bound U-Net), eager launches only.  The inputs CHANGE from call to call (a stale read or a
+    race between the streams must show): depth and confidence equal the one-item runs bit for bit on every one of eight
+    calls, and the stream-less batched launches (``batch_streams = False``) to fp32 order.  Under a hipGraph capture the
+    forward must NOT fork (multi-branch graphs of this path replay wrongly on ROCm 7.2 when inputs change): a captured forward
+    replayed on changing inputs equals the eager result bit for bit."""
     L, ops, synthetic, MVSNet, O = env
     net = MVSNet("variance")
     net.load_state_dict(synthetic.sharpened_state_dict("mvsnet", synthetic.template_of(net), seed=0))
     net = net.cuda().eval()
     net.num_depth, net.graph_replay = 32, False
-    scenes = [synthetic.make_scene(1, 4, 128, 160, seed=20 + b) for b in range(B)]
-    batch = {k: torch.cat([sc[k] for sc in scenes], 0).cuda() for k in scenes[0]}
     keys = ("imgs", "K", "R", "t", "depth_min", "depth_max")
+
+    def batch_of(seed0):
+        scenes = [synthetic.make_scene(1, 4, 128, 160, seed=seed0 + b) for b in range(B)]
+        return scenes, {k: torch.cat([sc[k] for sc in scenes], 0).cuda() for k in keys}
     with torch.no_grad():
-        singles = [net(*[sc[k].cuda() for k in keys]) for sc in scenes]
-        got = net(*[batch[k] for k in keys])
-        for b in range(B):
-            assert torch.equal(got["depth"][b], singles[b]["depth"][0]) and torch.equal(got["photometric_confidence"][b], singles[b]["photometric_confidence"][0])
-        net.batch_streams = False
-        plain = net(*[batch[k] for k in keys])
-        net.batch_streams = True
-        assert float((plain["depth"] - got["depth"]).abs().max()) <= 1e-5 * float(got["depth"].abs().max())
+        for it in range(8):
+            scenes, batch = batch_of(20 + 7 * it)
+            got = net(*[batch[k] for k in keys])
+            net.batch_streams = False
+            singles = [net(*[sc[k].cuda() for k in keys]) for sc in scenes]
+            plain = net(*[batch[k] for k in keys])
+            net.batch_streams = True
+            for b in range(B):
+                assert torch.equal(got["depth"][b], singles[b]["depth"][0]), (it, b)
+                assert torch.equal(got["photometric_confidence"][b], singles[b]["photometric_confidence"][0]), (it, b)
+            assert float((plain["depth"] - got["depth"]).abs().max()) <= 1e-5 * float(got["depth"].abs().max())
+        # captured: no fork inside the graph; replays on changing inputs are right
+        scenes, batch = batch_of(100)
         static = {k: batch[k].clone() for k in keys}
         for _ in range(2):
             net(*[static[k] for k in keys])
@@ -239,7 +248,13 @@ def test_batch_items_on_separate_streams_equal_the_one_item_runs(env, B):
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             out = net(*[static[k] for k in keys])
-        for rep in range(20):
+        for rep in range(6):
+            scenes, batch = batch_of(200 + 5 * rep)
+            for k in keys:
+                static[k].copy_(batch[k])
             g.replay()
             torch.cuda.synchronize()
-            assert torch.equal(out["depth"], got["depth"]) and torch.equal(out["photometric_confidence"], got["photometric_confidence"]), rep
+            net.batch_streams = False
+            want = net(*[batch[k] for k in keys])
+            net.batch_streams = True
+            assert torch.equal(out["depth"], want["depth"]) and torch.equal(out["photometric_confidence"], want["photometric_confidence"]), rep

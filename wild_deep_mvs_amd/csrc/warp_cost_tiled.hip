@@ -388,7 +388,18 @@ __device__ __forceinline__ void wl_sweep_pipe(const WarpArgs& a, const WlSweep& 
 }
 
 template <typename TIn, typename TOut, int GEOM, int COST>
-__global__ __launch_bounds__(WL_THREADS, 3) void warp_cost_lds_kernel(const WarpArgs a) {
+// WL_PIPELINED (A/B builds: bash scripts/dev/ab_build.sh pipe warp_cost_tiled.hip -DWL_PIPELINED) compiles the round-3
+// software-pipelined sweep in.  It needs 164 VGPRs = three workgroups per CU; in the SAME binary it beats the plain loop by 2 %
+// (115.6 vs 118.5 us in the step), but the plain loop ALONE compiles to 101 VGPRs = four workgroups per CU and runs 109.8 us
+// against 115.3 us (two alternating pairs of runs on one box): four simple waves per SIMD hide the LDS latency better than three
+// pipelined ones, and the sweep is VALU-bound either way.  The default build is therefore the plain loop; the pipelined code
+// stays as the record of the experiment (bit-equal: `scripts/wbench.py --variants 0 1` on that build, 0 of 125 829 120 values differ).
+#ifdef WL_PIPELINED
+#define WL_MIN_WAVES 3
+#else
+#define WL_MIN_WAVES 4
+#endif
+__global__ __launch_bounds__(WL_THREADS, WL_MIN_WAVES) void warp_cost_lds_kernel(const WarpArgs a) {
     constexpr int C = 32, PIXB = 64;
     constexpr int OB = (int)sizeof(TOut);
     constexpr bool VAR = COST == PSCV_COST_VARIANCE || COST == PSCV_COST_VARIANCE_CVP;
@@ -549,7 +560,11 @@ __global__ __launch_bounds__(WL_THREADS, 3) void warp_cost_lds_kernel(const Warp
         if (j >= n_act) vl[j] = vl[n_act > 0 ? n_act - 1 : 0];
     // a soft-min sweep needs the zero-padded views too (their weight e is not zero); blocks with a direct-tap view keep the
     // general loop.  a.variant == 1 forces the round-2 loop everywhere (measurement)
+#ifdef WL_PIPELINED
     const bool pipe = a.variant != 1 && !any_direct && n_act >= 1 && (VAR || !any_zero);
+#else
+    const bool pipe = false;
+#endif
     const int sel = pipe ? (l == 0 ? vl[0] : l == 1 ? vl[1] : l == 2 ? vl[2] : vl[3]) : l;
     if (pipe) {   // this lane's ray terms were loaded for view l: fetch those of view sel from quad lane sel
         const int src_lane = ((lane & ~3) | sel) << 2;
@@ -619,6 +634,7 @@ __global__ __launch_bounds__(WL_THREADS, 3) void warp_cost_lds_kernel(const Warp
     WL_STAMP(4)
 
     // ---- 5a. pipelined sweep: every contributing view is staged (the common case) ----
+#ifdef WL_PIPELINED
     if (pipe) {
         WlSweep S;
         S.lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lsm;
@@ -644,6 +660,7 @@ __global__ __launch_bounds__(WL_THREADS, 3) void warp_cost_lds_kernel(const Warp
             default: wl_sweep_pipe<TOut, COST, 4, true>(a, S, Ln, rf2, dlane, dstart); break;
         }
     }
+#endif
 
     // ---- 5b. general sweep (round 2): one voxel per quad and step, all source views, per-view mode branches ----
     int d1_eff = pipe ? d0 : d1;

@@ -378,7 +378,8 @@ class MVSNet(ReplayHooks, nn.Module):
                 raise NotImplementedError("pscv MVSNet: the depth-plane shard excludes the source-view shard and taps")
             return self._hot_path_depth_shard(features_cl, proj, depth_values, reference_frame)
         B = features_cl[0].shape[0]
-        if 2 <= B <= self.MAX_BATCH_STREAMS and self.batch_streams and taps is None and self.view_group is None and features_cl[0].is_cuda:
+        if (2 <= B <= self.MAX_BATCH_STREAMS and self.batch_streams and taps is None and self.view_group is None and features_cl[0].is_cuda
+                and not torch.cuda.is_current_stream_capturing()):
             return self._hot_path_streams(features_cl, proj, depth_values, reference_frame)
         V = len(features_cl)
         src_idx = [i for i in range(V) if i != reference_frame]
@@ -395,12 +396,16 @@ class MVSNet(ReplayHooks, nn.Module):
     def _hot_path_streams(self, features_cl, proj, depth_values, reference_frame):
         """The reference views of a batch are independent objects whose hot paths have COMPLEMENTARY bottlenecks: the warp is
         bound by vector-ALU issue, conv0 and the full-resolution layers by the matrix cores and the CUs' memory path.  Batch
-        item b therefore runs on its own HIP stream (fork from / join into the caller's stream; under a hipGraph capture the
-        items become parallel branches of the graph), so that one item's warp shares the chip with another item's U-Net:
-        measured at the headline size, two views 684 us against 764 us one after the other (+12 % voxels/s; three views +15 %),
-        outputs bit-equal to the one-item runs (`scripts/dev/overlap_n.py`, tests/test_gpu_mvsnet.py).  One item per stream
-        and at most MAX_BATCH_STREAMS items (captured graphs with several views CHAINED on one branch beside another branch
-        replayed wrongly on ROCm 7.2: larger batches take the batched launches); `net.batch_streams = False` turns it off."""
+        item b therefore runs on its own HIP stream (fork from / join into the caller's stream), so that one item's warp shares
+        the chip with another item's U-Net: measured at the headline size with eager launches, two views 0.673-0.693 ms against
+        0.725-0.740 ms for the batched launches on one stream, three views ~0.33 ms per view (`scripts/dev/graph_branch_toy.py`,
+        `bench.py`), outputs bit-equal to the one-item runs (tests/test_gpu_mvsnet.py).  EAGER ONLY: under a hipGraph capture the
+        items would become parallel branches of the graph, and ROCm 7.2 replays such graphs of this path WRONGLY as soon as the
+        inputs change between replays (`scripts/dev/graph_branch_probe.py`, `graph_branch_bisect.py`: a branch's cost volume is
+        exact while the branch ends there and off by 0.4 once a conv node follows it; a toy graph of element-wise kernels
+        replays fine) -- with static inputs the error is invisible, which is how a bench would never notice.  So a capturing
+        stream takes the plain batched launches (`hot_path` checks), and the host's launch rate (39 launches per 3-view step)
+        is far from binding at this size.  At most MAX_BATCH_STREAMS items; `net.batch_streams = False` turns it off."""
         B = features_cl[0].shape[0]
         dev = features_cl[0].device
         pool = self.__dict__.setdefault("_side_streams", {})
