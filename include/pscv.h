@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PSCV_ABI_VERSION 4
+#define PSCV_ABI_VERSION 5
 
 /* storage dtypes */
 #define PSCV_F32 0
@@ -193,6 +193,19 @@ int pscv_conv3d(const void* in, int dtype, int in_cstride, int in_coff, const ui
                 const float* bias, const float* floor, const void* skip, int skip_cstride, int skip_coff, void* out,
                 int out_cstride, int out_coff, int out_dtype, int B, int Di, int Hi, int Wi, int c_in, int c_out,
                 int kind, int epi_flags, void* stream);
+
+/*
+ * The same stride-1 3x3x3 convolution for a 16-channel input that is the CONCATENATION of two 8-channel slices living in different
+ * tensors: channels 0..7 = in_a[..., a_coff : a_coff + 8], channels 8..15 = in_b[..., b_coff : b_coff + 8] -- the
+ * `torch.cat([deconv_out, enc], dim=1)` in front of the Vis U-Net's decoder conv (models/VisMVSNet/nn_utils.py:269-272) is never
+ * written: its two producers store dense 8-channel volumes (a strided half-voxel store into a 16-channel buffer costs the 8 -> 8
+ * sweep 119 us instead of 65 us at 256 x 144 x 200) and this launch gathers them while staging.  `packed` is the PSCV_CONV_S1P8
+ * packing of the [c_out, 16, 3, 3, 3] weight; c_out 8 or 16; everything else as pscv_conv3d.
+ */
+int pscv_conv3d_cat2(const void* in_a, int a_cstride, int a_coff, const void* in_b, int b_cstride, int b_coff, int dtype,
+                     const uint16_t* packed, const float* scale, const float* bias, const float* floor, const void* skip,
+                     int skip_cstride, int skip_coff, void* out, int out_cstride, int out_coff, int out_dtype, int B, int D, int H,
+                     int W, int c_out, int epi_flags, void* stream);
 
 /*
  * Visibility-weighted fusion of per-pair volumes (Vis-MVSNet, mode 'soft'), one pass:

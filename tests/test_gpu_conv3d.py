@@ -510,3 +510,49 @@ def test_conv3d_epilogue_propagates_nan_like_torch_relu(env, cin, cout, kind, sh
     scale = 2 if kind == L.CONV_T2 else 1
     assert int((dpl.float() / scale - (D // 2) / (2 if kind == L.CONV_S2 else 1)).abs().max()) <= 3
     assert not torch.isinf(got).any()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("cout", [8, 16])
+@pytest.mark.parametrize("shape", [(16, 16, 32), (13, 11, 21), (2, 3, 5), (40, 9, 37)])
+def test_two_tensor_input_equals_the_concatenated_input(env, shape, cout, dtype):
+    """pscv_conv3d_cat2: the 16 input channels gathered from two tensors (dense, and 8-channel slices of wider ones) give the
+    bits the same kernel gives on torch.cat([a, b], channel) -- the Vis U-Net's decoder conv (nn_utils.py:269-272) without
+    the concatenated buffer."""
+    L, ops = env
+    D, H, W = shape
+    g = torch.Generator().manual_seed(D * 100 + W + cout)
+    B = 2
+    a = bf16_round(torch.randn(B, D, H, W, 8, generator=g)).cuda().to(dtype)
+    b = bf16_round(torch.randn(B, D, H, W, 8, generator=g)).cuda().to(dtype)
+    sk = bf16_round(torch.randn(B, D, H, W, cout, generator=g)).cuda().to(dtype)
+    w = bf16_round(torch.randn(cout, 16, 3, 3, 3, generator=g) / np.sqrt(27 * 16))
+    bn = tuple(torch.rand(cout, generator=g) + 0.5 for _ in range(2)) + (torch.randn(cout, generator=g) * 0.1, torch.rand(cout, generator=g) + 0.5)
+    layer = ops.Conv3dLayer.build(w, kind=L.CONV_S1P8, device="cuda", dtype=dtype, bn=bn, relu=True)
+    cat = torch.cat([a, b], dim=4).contiguous()
+    want = ops.conv3d(cat, layer, skip=sk)
+    got = ops.conv3d(a, layer, x2=b, skip=sk)
+    assert torch.equal(got, want)
+    # slices of wider tensors on both sides, output into a channel slice, fp32 output
+    wa = torch.full((B, D, H, W, 24), float("nan"), dtype=dtype, device="cuda")
+    wb = torch.full((B, D, H, W, 16), float("nan"), dtype=dtype, device="cuda")
+    wa[..., 16:24] = a
+    wb[..., 0:8] = b
+    out = torch.full((B, D, H, W, 2 * cout), -7.0, dtype=torch.float32, device="cuda")
+    ops.conv3d(wa, layer, in_coff=16, x2=wb, x2_coff=0, out=out, out_coff=cout)
+    want32 = ops.conv3d(cat, layer, out_dtype=torch.float32)
+    assert torch.equal(out[..., cout:], want32) and bool((out[..., :cout] == -7.0).all())
+    # and against ATen
+    ref = F.relu(F.batch_norm(F.conv3d(cat.float().permute(0, 4, 1, 2, 3).cpu(), w, padding=1), bn[2], bn[3], bn[0], bn[1], eps=1e-5))
+    check_close(f"cat2 16->{cout} {dtype}", want32.permute(0, 4, 1, 2, 3).cpu(), ref, max_abs=3e-3, rel_l2=2e-4)
+
+
+def test_two_tensor_input_rejects_other_layers(env):
+    L, ops = env
+    x = torch.zeros(1, 4, 4, 8, 8, dtype=torch.float16, device="cuda")
+    lay = ops.Conv3dLayer.build(torch.zeros(16, 16, 3, 3, 3), kind=L.CONV_S2, device="cuda", dtype=torch.float16)
+    with pytest.raises(ValueError):
+        ops.conv3d(x, lay, x2=x)
+    lay = ops.Conv3dLayer.build(torch.zeros(8, 16, 3, 3, 3), kind=L.CONV_S1P8, device="cuda", dtype=torch.float16)
+    with pytest.raises(ValueError):
+        ops.conv3d(x, lay, x2=x[:, :2])

@@ -605,7 +605,7 @@ int pscv_conv3d_sweep8_launch(const void* in, int dtype, int in_cstride, int in_
 int pscv_conv3d_sweepc_launch(const void* in, int dtype, int c_in, int c_out, int in_cstride, int in_coff, const uint16_t* packed,
                               const float* scale, const float* bias, const float* floor, const void* skip, int skip_cstride,
                               int skip_coff, void* out, int out_cstride, int out_coff, int out_dtype, int B, int D, int Hh, int W,
-                              int epi_flags, hipStream_t st);
+                              int epi_flags, hipStream_t st, const void* in2 = nullptr, int in2_cstride = 0, int in2_coff = 0);
 
 int pscv_conv3d_sweep_s2_launch(const void* in, int dtype, int in_cstride, int in_coff, const uint16_t* packed, const float* scale,
                                 const float* bias, const float* floor, const void* skip, int skip_cstride, int skip_coff, void* out,
@@ -621,6 +621,28 @@ int pscv_conv3d_t2p8_launch(const void* in, int dtype, int in_cstride, int in_co
                             const float* scale, const float* bias, const float* floor, const void* skip, int skip_cstride,
                             int skip_coff, void* out, int out_cstride, int out_coff, int out_dtype, int B, int Di, int Hi,
                             int Wi, int epi_flags, hipStream_t st);
+
+extern "C" int pscv_conv3d_cat2(const void* in_a, int a_cstride, int a_coff, const void* in_b, int b_cstride, int b_coff, int dtype,
+                                const uint16_t* packed, const float* scale, const float* bias, const float* floor, const void* skip,
+                                int skip_cstride, int skip_coff, void* out, int out_cstride, int out_coff, int out_dtype, int B, int D,
+                                int H, int W, int c_out, int epi_flags, void* stream) {
+    using namespace pscv;
+    PSCV_CHECK_ARG(in_a && in_b && packed && out, "pscv_conv3d_cat2: null pointer argument");
+    PSCV_CHECK_ARG(B > 0 && D > 0 && H > 0 && W > 0, "pscv_conv3d_cat2: bad sizes");
+    PSCV_CHECK_ARG(c_out == 8 || c_out == 16, "pscv_conv3d_cat2: c_out=%d must be 8 or 16", c_out);
+    PSCV_CHECK_ARG(a_cstride % 8 == 0 && a_coff % 8 == 0 && a_coff + 8 <= a_cstride && b_cstride % 8 == 0 && b_coff % 8 == 0 && b_coff + 8 <= b_cstride,
+                   "pscv_conv3d_cat2: both inputs contribute an 8-aligned slice of 8 channels");
+    PSCV_CHECK_ARG(out_coff + c_out <= out_cstride && out_cstride % 4 == 0 && out_coff % 4 == 0, "pscv_conv3d_cat2: bad output channel slice");
+    PSCV_CHECK_ARG(!skip || (skip_cstride % 4 == 0 && skip_coff % 4 == 0), "pscv_conv3d_cat2: skip slice must be 4-aligned");
+    PSCV_CHECK_ARG(dtype == PSCV_BF16 || dtype == PSCV_F16, "pscv_conv3d_cat2: storage dtype %d must be bf16 or fp16", dtype);
+    PSCV_CHECK_ARG(out_dtype == dtype || out_dtype == PSCV_F32, "pscv_conv3d_cat2: out dtype %d must be the storage dtype or fp32", out_dtype);
+    const int rc = pscv_conv3d_sweepc_launch(in_a, dtype, 16, c_out, a_cstride, a_coff, packed, scale, bias, floor, skip, skip_cstride, skip_coff,
+                                             out, out_cstride, out_coff, out_dtype, B, D, H, W, epi_flags, reinterpret_cast<hipStream_t>(stream),
+                                             in_b, b_cstride, b_coff);
+    if (rc) return rc;
+    PSCV_CHECK_LAUNCH("pscv_conv3d_cat2");
+    return 0;
+}
 
 extern "C" int pscv_conv3d(const void* in, int dtype, int in_cstride, int in_coff, const uint16_t* packed, const float* scale,
                            const float* bias, const float* floor, const void* skip, int skip_cstride, int skip_coff,

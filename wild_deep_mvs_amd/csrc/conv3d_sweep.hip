@@ -54,6 +54,8 @@ struct SweepArgs {
     int out_f32;
     int B, D, Hh, W;
     int epi;
+    const uint16_t* in2;     // narrow sweep, C_in = 16: channels 8..15 come from this tensor (the same tensor at in_co + 8 for a plain
+    int in2_cs, in2_co;      // 16-channel input; another tensor for pscv_conv3d_cat2: torch.cat([a, b], channel) never materialised)
     int nth, ntw, ndc, dc;   // tiles along h, w; depth chunks and planes per chunk (even)
     unsigned mg_th, mg_tw, mg_dc;
 };
@@ -318,31 +320,43 @@ __global__ __launch_bounds__(256, (CIN == 8 && PD <= 2) ? 4 : (CIN == 8 || (PD =
     const int pl0 = CIN == 8 ? g : (g >> 1);      // this lane's plane (relative to d-1) in MFMA set 0; set 1 (C_in = 16) adds 2
 
     // (raw buffer loads as in the 32 -> 8 sweep: out-of-image chunks and out-of-volume planes come back as zeros from the hardware)
+    // a thread owns ONE voxel of the 10 x 18 plane and load i fetches that voxel's 16-byte chunk i: chunk 0 (channels 0..7) from
+    // `in`, chunk 1 (C_in = 16: channels 8..15) from `in2` -- each load instruction has its own per-plane descriptor, so the two
+    // halves of a 16-channel input may live in different tensors (the decoder's cat([deconv, enc]) is never written)
+    static_assert(NLD == CCH, "one load per 16-byte chunk of a voxel");
     unsigned goff[NLD];
     int loff[NLD];
     bool lval[NLD];
-    const long plane_stride = (long)a.Hh * a.W * a.in_cs;
-    const unsigned plane_bytes = (unsigned)(plane_stride * 2 - a.in_co * 2);
-    const uint16_t* inb = a.in + (long)b * a.D * plane_stride + a.in_co;
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-        const int id = tid + 256 * i;
-        const int v = id / CCH, c = id - v * CCH;
+    long plane_stride[NLD];
+    unsigned plane_bytes[NLD];
+    const uint16_t* inb[NLD];
+    {
+        const int v = tid;
         const int bh = v / SW_BW, bw = v - bh * SW_BW;
         const int gh = h0 - 1 + bh, gw = w0 - 1 + bw;
-        lval[i] = id < CHUNKS;
-        const bool gval = lval[i] && (unsigned)gh < (unsigned)a.Hh && (unsigned)gw < (unsigned)a.W;
-        goff[i] = gval ? ((unsigned)(gh * a.W + gw) * (unsigned)a.in_cs + (unsigned)(c * 8)) * 2u : 0x7ffffff0u;
-        loff[i] = v * VB + c * 16;
+        const bool in_tile = v < G::BH * SW_BW;
+        const bool gval = in_tile && (unsigned)gh < (unsigned)a.Hh && (unsigned)gw < (unsigned)a.W;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int cs = i == 0 ? a.in_cs : a.in2_cs, co = i == 0 ? a.in_co : a.in2_co;
+            const uint16_t* base = i == 0 ? a.in : a.in2;
+            lval[i] = in_tile;
+            plane_stride[i] = (long)a.Hh * a.W * cs;
+            plane_bytes[i] = (unsigned)(plane_stride[i] * 2 - co * 2);
+            inb[i] = base + (long)b * a.D * plane_stride[i] + co;
+            goff[i] = gval ? (unsigned)(gh * a.W + gw) * (unsigned)cs * 2u : 0x7ffffff0u;
+            loff[i] = v * VB + i * 16;
+        }
     }
     const int plane_hi = min(a.D - 1, dend);
     auto fetch = [&](int plane, uint4 (&reg)[NLD]) {
         const bool pv = plane >= 0 && plane <= plane_hi;                                         // wave-uniform
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<uint16_t*>(inb + (long)(pv ? plane : 0) * plane_stride), (short)0, pv ? (int)plane_bytes : 0, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < NLD; ++i)
+        for (int i = 0; i < NLD; ++i) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<uint16_t*>(inb[i] + (long)(pv ? plane : 0) * plane_stride[i]), (short)0, pv ? (int)plane_bytes[i] : 0, 0x00020000);
             reg[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)goff[i], 0, 0));
+        }
     };
     auto stash = [&](int ring, const uint4 (&reg)[NLD]) {
         unsigned char* sp = smem + ring * PB;
@@ -515,11 +529,15 @@ static int sweepc_launch_pd(pscv::SweepArgs& a, long nblk, hipStream_t st) {
 int pscv_conv3d_sweepc_launch(const void* in, int dtype, int c_in, int c_out, int in_cstride, int in_coff, const uint16_t* packed,
                               const float* scale, const float* bias, const float* floor, const void* skip, int skip_cstride,
                               int skip_coff, void* out, int out_cstride, int out_coff, int out_dtype, int B, int D, int Hh, int W,
-                              int epi_flags, hipStream_t st) {
+                              int epi_flags, hipStream_t st, const void* in2, int in2_cstride, int in2_coff) {
     using namespace pscv;
     PSCV_CHECK_ARG((long)Hh * W * in_cstride * 2 < 0x7fffffffL, "pscv_conv3d(sweep): an input plane of %d x %d x %d channels exceeds 2 GiB", Hh, W, in_cstride);
+    PSCV_CHECK_ARG(!in2 || (c_in == 16 && (long)Hh * W * in2_cstride * 2 < 0x7fffffffL), "pscv_conv3d(sweep): a second input tensor needs c_in = 16 and planes below 2 GiB");
     SweepArgs a;
     a.in = reinterpret_cast<const uint16_t*>(in);
+    a.in2 = in2 ? reinterpret_cast<const uint16_t*>(in2) : a.in;
+    a.in2_cs = in2 ? in2_cstride : in_cstride;
+    a.in2_co = in2 ? in2_coff : in_coff + 8;
     a.wpk = packed; a.scale = scale; a.bias = bias; a.floor = floor;
     a.skip = reinterpret_cast<const uint16_t*>(skip);
     a.out = out;

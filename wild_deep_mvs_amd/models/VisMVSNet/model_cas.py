@@ -147,13 +147,16 @@ class _RegUNet(nn.Module):
         if d % 2 or h % 2 or w % 2:
             raise ValueError(f"Vis U-Net needs even d,h,w (got {d},{h},{w}), as in the reference")
         ly = self._layers(x.dtype)
-        cat = torch.empty((n, d, h, w, 16), dtype=x.dtype, device=x.device)       # [deconv | enc0] (nn_utils.py:269-271)
         t = ops.conv3d(x, ly["e0c1"])
-        ops.conv3d(t, ly["e0c2"], skip=x, out=cat, out_coff=8)                    # enc0 -> cat[..., 8:16]
-        t1ds = ops.conv3d(cat, ly["e1c1ds"], in_coff=8)                           # [relu(bn1(conv1)) | bn_ds(shortcut)]
+        e0 = ops.conv3d(t, ly["e0c2"], skip=x)
+        t1ds = ops.conv3d(e0, ly["e1c1ds"])                                       # [relu(bn1(conv1)) | bn_ds(shortcut)]
         e1 = ops.conv3d(t1ds, ly["e1c2"], skip=t1ds, skip_coff=16)
-        ops.conv3d(e1, ly["dec"], out=cat, out_coff=0)                            # deconv -> cat[..., 0:8]
-        return ops.conv3d(cat, ly["post"])
+        up = ops.conv3d(e1, ly["dec"])
+        if ly["post"].kind == L.CONV_S1P8:
+            # cat([deconv, enc0]) (nn_utils.py:269-271) is gathered by the decoder conv's staging: both producers store dense
+            # 8-channel volumes (half-voxel stores into a 16-channel buffer cost them 20-50 us each at 256 x 144 x 200)
+            return ops.conv3d(up, ly["post"], x2=e0)
+        return ops.conv3d(torch.cat([up, e0], dim=4), ly["post"])
 
 
 class Reg(_RegUNet):            # reference model_cas.py:38-48

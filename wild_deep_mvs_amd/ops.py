@@ -604,10 +604,11 @@ def _conv_cost(vox_in: int, vox_out: int, c_in: int, c_out: int, taps: int, tran
 
 def conv3d(x: torch.Tensor, layer: Conv3dLayer, *, skip: Optional[torch.Tensor] = None, in_coff: int = 0,
            skip_coff: int = 0, out: Optional[torch.Tensor] = None, out_coff: int = 0,
-           out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+           out_dtype: Optional[torch.dtype] = None, x2: Optional[torch.Tensor] = None, x2_coff: int = 0) -> torch.Tensor:
     """x [B,D,H,W,Cs] in the layer's 16-bit format (reads channels [in_coff, in_coff+c_in)) ->
     [B,Do,Ho,Wo,c_out] in the same format or fp32 (or writes the channel slice [out_coff, out_coff+c_out)
-    of ``out``)."""
+    of ``out``).  With ``x2`` (16-channel depth-sweep layers) the input is the channel concatenation of
+    x[..., in_coff:in_coff+8] and x2[..., x2_coff:x2_coff+8], gathered while staging (pscv_conv3d_cat2)."""
     _dev(x, skip, out, layer.packed)
     if x.dtype != layer.dtype or x.dim() != 5:
         raise TypeError(f"pscv.conv3d: input must be a {layer.dtype} [B,D,H,W,C] volume, got {x.dtype} {tuple(x.shape)}")
@@ -620,6 +621,19 @@ def conv3d(x: torch.Tensor, layer: Conv3dLayer, *, skip: Optional[torch.Tensor] 
         raise ValueError(f"pscv.conv3d: out has shape {tuple(out.shape)}, expected [B,{Do},{Ho},{Wo},*]")
     if skip is not None and (skip.dtype != layer.dtype or tuple(skip.shape[:4]) != (B, Do, Ho, Wo)):
         raise ValueError("pscv.conv3d: skip must have the layer's dtype and the output's spatial shape")
+    if x2 is not None:
+        # the 16 input channels are cat([x[..., in_coff:in_coff+8], x2[..., x2_coff:x2_coff+8]]) -- never materialised
+        _dev(x2)
+        if layer.kind != L.CONV_S1P8 or layer.c_in != 16 or x2.dtype != layer.dtype or tuple(x2.shape[:4]) != (B, D, H, W):
+            raise ValueError("pscv.conv3d: a second input needs a depth-sweep (S1P8) layer with c_in = 16 and a volume of x's "
+                             f"spatial shape in the layer's dtype (layer kind {layer.kind}, c_in {layer.c_in}, x2 {tuple(x2.shape)})")
+        rc = _launch(f"conv3d[8+8->{layer.c_out},k{layer.kind}]", lambda: L.lib().pscv_conv3d_cat2(
+            _p(x), cs, in_coff, _p(x2), x2.shape[4], x2_coff, _dt(x), _p(layer.packed), _p(layer.scale), _p(layer.bias),
+            _p(layer.floor), _p(skip), 0 if skip is None else skip.shape[4], skip_coff, _p(out), out.shape[4], out_coff, _dt(out),
+            B, D, H, W, layer.c_out, layer.epi, _stream()),
+            cost=lambda: _conv_cost(B * D * H * W, B * Do * Ho * Wo, 16, layer.c_out, 27, False, out.element_size(), skip is not None))
+        L.check(rc, "pscv_conv3d_cat2")
+        return out
     rc = _launch(f"conv3d[{layer.c_in}->{layer.c_out},k{layer.kind}]", lambda: L.lib().pscv_conv3d(
         _p(x), _dt(x), cs, in_coff, _p(layer.packed), _p(layer.scale), _p(layer.bias), _p(layer.floor), _p(skip),
         0 if skip is None else skip.shape[4], skip_coff, _p(out), out.shape[4], out_coff, _dt(out), B, D, H, W,
