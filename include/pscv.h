@@ -208,6 +208,18 @@ int pscv_conv3d_cat2(const void* in_a, int a_cstride, int a_coff, const void* in
                      int W, int c_out, int epi_flags, void* stream);
 
 /*
+ * Vis-MVSNet's UncertNet (models/VisMVSNet/model_cas.py:77-98) in eval mode, one launch for the entropy maps of all pairs:
+ *   t1 = relu(s1 * conv3x3(x; w1) + b1)   1 -> 8      (BatchNorm folded: s = gamma / sqrt(var + eps), b = beta - mean * s)
+ *   t2 = relu(s2 * conv3x3(t1; w2) + b2) + x          (x broadcast over the 8 channels, model_cas.py:95)
+ *   out = conv3x3(t2; head)               8 -> 1      (head_convs[0]; the reference's live model has one head)
+ * every convolution zero-pads its own input (padding 1), fp32 throughout like the reference.
+ *   entropy [N, H, W] fp32 -> out [N, H, W] fp32 (the log-uncertainty that weights a pair in pscv_fuse_pairs).
+ *   params  752 floats: w1 as [tap][c_out] (72) | s1 (8) | b1 (8) | w2 as [c_in][tap][c_out] (576) | s2 (8) | b2 (8) |
+ *           head as [c_in][tap] (72); tap = 3 * ky + kx.
+ */
+int pscv_uncert_net(const float* entropy, const float* params, float* out, int N, int H, int W, void* stream);
+
+/*
  * Visibility-weighted fusion of per-pair volumes (Vis-MVSNet, mode 'soft'), one pass:
  *     out = sum_v exp(-uncert_v) * interm_v / sum_v exp(-uncert_v)
  * Replaces the accumulate / divide sequence of models/VisMVSNet/model_cas.py:354-357,385-386.

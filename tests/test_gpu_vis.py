@@ -216,3 +216,48 @@ def test_function_level_homography_warping_with_per_pixel_matrices(env):
     check_close("vis homography_warping per-pixel H", got.cpu(), want, max_abs=3e-4)
     with pytest.raises(ValueError):
         homography_warping(src.cuda(), Hs.cuda(), (h + 1, w))
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 32), (3, 37, 45), (1, 5, 3), (2, 72, 100), (1, 1, 1)])
+def test_fused_uncert_net_vs_oracle_and_torch_layers(env, shape):
+    """pscv_uncert_net (three convolutions + folded BatchNorms + the broadcast residual in one launch, model_cas.py:77-98)
+    against the oracle's layer-by-layer restatement and against the module's own torch layers; ragged sizes cross tile
+    borders, where every convolution pads ITS input with zeros."""
+    L, ops, synthetic, Frontend, OV = env
+    from wild_deep_mvs_amd.models.VisMVSNet.model_cas import UncertNet
+    N, H, W = shape
+    g = torch.Generator().manual_seed(N * 1000 + H * 10 + W)
+    net = UncertNet(1)
+    with torch.no_grad():
+        for m in (net.conv1[1], net.conv2[1]):
+            m.weight.copy_(torch.rand(8, generator=g) + 0.5)
+            m.bias.copy_(torch.randn(8, generator=g) * 0.2)
+            m.running_mean.copy_(torch.randn(8, generator=g) * 0.3)
+            m.running_var.copy_(torch.rand(8, generator=g) + 0.5)
+        for c in (net.conv1[0], net.conv2[0], net.head_convs[0]):
+            c.weight.copy_(torch.randn(c.weight.shape, generator=g) * (2.0 / (9 * c.weight.shape[1])) ** 0.5)
+    net.eval()
+    x = torch.rand(N, 1, H, W, generator=g) * 4.0                    # entropies of a softmax over up to 256 planes: [0, 5.5]
+    sd = {"u." + k: v.double() for k, v in net.state_dict().items()}
+    want = OV.uncert_net(x.double(), sd, "u")
+    with torch.no_grad():
+        got = net.cuda()(x.cuda())[0]
+        layers = net.head_convs[0](net.conv2(net.conv1(x.cuda())) + x.cuda())
+    assert got.shape == (N, 1, H, W)
+    check_close(f"fused UncertNet vs oracle {shape}", got.cpu(), want.float(), max_abs=2e-5, rel_l2=2e-6)
+    check_close(f"fused UncertNet vs torch layers {shape}", got.cpu(), layers.cpu(), max_abs=2e-5, rel_l2=2e-6)
+
+
+def test_uncert_net_tracks_parameter_updates_and_train_mode(env):
+    L, ops, synthetic, Frontend, OV = env
+    from wild_deep_mvs_amd.models.VisMVSNet.model_cas import UncertNet
+    net = UncertNet(1).cuda().eval()
+    x = torch.rand(1, 1, 20, 24, device="cuda")
+    with torch.no_grad():
+        a = net(x)[0].clone()
+        net.head_convs[0].weight.mul_(2.0)                           # an in-place update bumps the version: block rebuilt
+        b = net(x)[0]
+    check_close("head weight doubled", b.cpu(), 2.0 * a.cpu(), max_abs=1e-5, rel_l2=1e-6)
+    net.train()
+    y = net(x)[0]                                                    # batch-statistics BatchNorm under autograd: torch layers
+    assert y.requires_grad

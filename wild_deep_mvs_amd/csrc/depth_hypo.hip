@@ -3,7 +3,7 @@
 // Reference: calDepthHypo, models/CVP_MVSNet/models/modules.py:131-226 -- per batch item (a Python loop, fp64), the depth
 // step that moves a pixel's projection into the FIRST source view by one pixel along its epipolar line, the MEDIAN of
 // |step| over the valid pixels, then 8 hypothesis planes depth + k * median, k = -4..3.
-// Three launches: (1) per-pixel |step| in fp64 -> 64-bit keys (bit patterns of non-negative doubles order like the
+// Three stages: (1) per-pixel |step| in fp64 -> 64-bit keys (bit patterns of non-negative doubles order like the
 // values; invalid pixels get the all-ones key), (2) the lower median by an 8-pass MSB-first radix select (one launch per
 // pass over many workgroups, integer histograms: exact and order-independent; a first single-workgroup version took 4.2 ms
 // at 1024x1280 -- every key shares its leading digits, so the LDS atomics serialised on one bin), (3) the planes.
@@ -84,24 +84,40 @@ __device__ __forceinline__ SelState* sel_state(unsigned long long* ws, int b) {
     return reinterpret_cast<SelState*>(ws + (long)b * SEL_WS_U64 + 8 * 256 / 2);
 }
 
-// state after pass `done` (0-based) from the state before it and that pass's histogram; thread 0 of the block, result in LDS
-__device__ void sel_advance(const unsigned* __restrict__ hist, SelState prev, int done, SelState* out) {
+// state after pass `done` (0-based) from the state before it and that pass's histogram, by all 256 threads of the block (bin
+// tid each): wave prefix sums + a 4-entry cross-wave table, then the ONE thread whose bin holds the rank publishes the state in
+// LDS (bins [excl, incl) are disjoint, and bin 255 takes whatever is left -- the serial form's fall-through).  A first version
+// walked the 256 bins from one thread: ~10 us of dependent loads per pass, 8 passes per call.
+__device__ __forceinline__ void sel_advance(const unsigned* __restrict__ hist, SelState prev, int done, SelState* out, unsigned* wave_tot) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int shift = 56 - 8 * done;
+    const unsigned h = hist[tid];
+    unsigned incl = h;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wave_tot[wv] = incl;
+    __syncthreads();
+    unsigned base = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned t = wave_tot[i];
+        if (i < wv) base += t;
+        total += t;
+    }
+    incl += base;
+    const unsigned excl = incl - h;
     unsigned long long rank = prev.rank;
-    if (done == 0) {
-        unsigned total = 0;
-        for (int j = 0; j < 256; ++j) total += hist[j];
-        rank = total ? (unsigned long long)((total - 1) / 2) : ~0ull;
+    if (done == 0) rank = total ? (unsigned long long)((total - 1) / 2) : ~0ull;
+    if (rank == ~0ull) {
+        if (tid == 0) { out->prefix = 0; out->rank = ~0ull; }
+    } else if ((unsigned long long)excl <= rank && (rank < (unsigned long long)incl || tid == 255)) {
+        out->prefix = prev.prefix | ((unsigned long long)tid << shift);
+        out->rank = rank - excl;
     }
-    if (rank == ~0ull) { out->prefix = 0; out->rank = ~0ull; return; }
-    unsigned long long acc = 0;
-    int j = 0;
-    for (; j < 255; ++j) {
-        if (acc + hist[j] > rank) break;
-        acc += hist[j];
-    }
-    out->prefix = prev.prefix | ((unsigned long long)j << shift);
-    out->rank = rank - acc;
+    __syncthreads();
 }
 
 __global__ __launch_bounds__(256) void hypo_select_pass_kernel(const unsigned long long* __restrict__ keys, unsigned long long* __restrict__ ws,
@@ -109,18 +125,19 @@ __global__ __launch_bounds__(256) void hypo_select_pass_kernel(const unsigned lo
     __shared__ unsigned hist[256];
     __shared__ SelState st;
     const int b = blockIdx.y, tid = threadIdx.x;
+    __shared__ unsigned wave_tot[4];
     hist[tid] = 0;
-    if (tid == 0) {
+    {
         SelState prev{0, 0};
         if (pass >= 2) prev = sel_state(ws, b)[pass - 2];
         if (pass >= 1) {
-            sel_advance(sel_hist(ws, b, pass - 1), prev, pass - 1, &st);
-            if (blockIdx.x == 0) sel_state(ws, b)[pass - 1] = st;
+            sel_advance(sel_hist(ws, b, pass - 1), prev, pass - 1, &st, wave_tot);
+            if (blockIdx.x == 0 && tid == 0) sel_state(ws, b)[pass - 1] = st;
         } else {
-            st = prev;
+            if (tid == 0) st = prev;
+            __syncthreads();
         }
     }
-    __syncthreads();
     if (st.rank == ~0ull) return;
     const int shift = 56 - 8 * pass;
     const unsigned long long prefix = st.prefix;
@@ -143,20 +160,19 @@ __global__ __launch_bounds__(256) void hypo_select_pass_kernel(const unsigned lo
     if (hist[tid]) atomicAdd(sel_hist(ws, b, pass) + tid, hist[tid]);
 }
 
-__global__ void hypo_median_finish_kernel(unsigned long long* __restrict__ ws, const float* __restrict__ fallback, double* __restrict__ steps) {
-    const int b = blockIdx.x;
-    if (threadIdx.x != 0) return;
-    SelState st;
-    sel_advance(sel_hist(ws, b, 7), sel_state(ws, b)[6], 7, &st);
-    steps[b] = st.rank == ~0ull ? (double)fallback[b] : __longlong_as_double((long long)st.prefix);
-}
-
-__global__ __launch_bounds__(256) void hypo_planes_kernel(const float* __restrict__ depth, const double* __restrict__ steps,
+// the last advance (redundantly per block, like the passes) + the 8 planes depth + k * median
+__global__ __launch_bounds__(256) void hypo_planes_kernel(const float* __restrict__ depth, unsigned long long* __restrict__ ws,
+                                                          const float* __restrict__ fallback, double* __restrict__ steps,
                                                           float* __restrict__ hypos, int hw) {
+    __shared__ SelState st;
+    __shared__ unsigned wave_tot[4];
     const int b = blockIdx.y;
+    sel_advance(sel_hist(ws, b, 7), sel_state(ws, b)[6], 7, &st, wave_tot);
+    const double s = st.rank == ~0ull ? (double)fallback[b] : __longlong_as_double((long long)st.prefix);
+    if (blockIdx.x == 0 && threadIdx.x == 0) steps[b] = s;
     const int pix = blockIdx.x * 256 + threadIdx.x;
     if (pix >= hw) return;
-    const double d = (double)depth[(long)b * hw + pix], s = steps[b];
+    const double d = (double)depth[(long)b * hw + pix];
 #pragma unroll
     for (int k = 0; k < 8; ++k) hypos[((long)b * 8 + k) * hw + pix] = (float)(d + (double)(k - 4) * s);
 }
@@ -179,9 +195,7 @@ extern "C" int pscv_cvp_depth_hypos(const float* depth, const double* cams, cons
     for (int pass = 0; pass < 8; ++pass)
         hipLaunchKernelGGL(hypo_select_pass_kernel, dim3(nsel, B), dim3(256), 0, st, keys, ws, hw, pass);
     PSCV_CHECK_LAUNCH("pscv_cvp_depth_hypos(select)");
-    hipLaunchKernelGGL(hypo_median_finish_kernel, dim3(B), dim3(64), 0, st, ws, fallback, steps);
-    PSCV_CHECK_LAUNCH("pscv_cvp_depth_hypos(median)");
-    hipLaunchKernelGGL(hypo_planes_kernel, dim3((hw + 255) / 256, B), dim3(256), 0, st, depth, steps, hypos, hw);
+    hipLaunchKernelGGL(hypo_planes_kernel, dim3((hw + 255) / 256, B), dim3(256), 0, st, depth, ws, fallback, steps, hypos, hw);
     PSCV_CHECK_LAUNCH("pscv_cvp_depth_hypos(planes)");
     return 0;
 }

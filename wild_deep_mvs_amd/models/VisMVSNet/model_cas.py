@@ -202,7 +202,8 @@ class RegFuse(_RegUNet):        # reference model_cas.py:62-74
 
 
 class UncertNet(nn.Module):
-    """2-D entropy -> log-uncertainty net (reference model_cas.py:77-98); small 2-D convs, PyTorch-ROCm."""
+    """2-D entropy -> log-uncertainty net (reference model_cas.py:77-98).  Eval mode on the GPU: one
+    fused HIP launch (``pscv_uncert_net``); train mode / autograd: the torch layers (batch-statistics BatchNorm)."""
 
     def __init__(self, num_heads=1):
         super().__init__()
@@ -210,7 +211,21 @@ class UncertNet(nn.Module):
         self.conv2 = nn.Sequential(nn.Conv2d(8, 8, 3, 1, 1, bias=False), nn.BatchNorm2d(8), nn.ReLU())
         self.head_convs = nn.ModuleList([nn.Conv2d(8, 1, 3, 1, 1, bias=False) for _ in range(num_heads)])
 
+    def engine_params(self) -> torch.Tensor:
+        """The folded parameter block of ``ops.uncert_net``, rebuilt when a parameter / buffer changes."""
+        ts = list(self.parameters()) + list(self.buffers())
+        key = (ops.weights_epoch(),) + tuple((t.data_ptr(), t._version) for t in ts)
+        if getattr(self, "_prm", None) is None or self._prm_key != key:
+            c1, n1, c2, n2 = self.conv1[0], self.conv1[1], self.conv2[0], self.conv2[1]
+            self._prm = ops.pack_uncert_params(c1.weight, _bn_tuple(n1), c2.weight, _bn_tuple(n2), self.head_convs[0].weight, n1.eps, n2.eps)
+            self._prm_key = key
+        return self._prm
+
     def forward(self, x):
+        if not self.training and x.is_cuda and x.dtype == torch.float32 and len(self.head_convs) == 1:
+            # eval hot path: the three convolutions, two BatchNorms and the residual add in ONE launch (csrc/uncert_net.hip)
+            n, _, h, w = x.shape
+            return [ops.uncert_net(x.reshape(n, h, w).contiguous(), self.engine_params()).view(n, 1, h, w)]
         out = self.conv2(self.conv1(x))
         out = out + x
         return [conv(out) for conv in self.head_convs]

@@ -645,6 +645,39 @@ def conv3d(x: torch.Tensor, layer: Conv3dLayer, *, skip: Optional[torch.Tensor] 
 
 
 # --------------------------------------------------------------------------------------------
+# Vis-MVSNet UncertNet (eval mode), one launch
+# --------------------------------------------------------------------------------------------
+def pack_uncert_params(w1, bn1, w2, bn2, head, eps1: float = 1e-5, eps2: float = 1e-5) -> torch.Tensor:
+    """The 752-float parameter block of ``pscv_uncert_net`` (include/pscv.h) from the module's tensors: conv weights
+    [8,1,3,3], [8,8,3,3], [1,8,3,3]; ``bn*`` = (gamma, beta, running_mean, running_var), folded in fp32."""
+    f = lambda t: t.detach().to(torch.float32)
+
+    def fold(bn, eps):
+        g, b, m, v = [f(t) for t in bn]
+        s = g / torch.sqrt(v + eps)
+        return s, b - m * s
+    s1, b1 = fold(bn1, eps1)
+    s2, b2 = fold(bn2, eps2)
+    return torch.cat([f(w1).reshape(8, 9).t().reshape(-1), s1, b1,                     # [tap][co]
+                      f(w2).reshape(8, 8, 9).permute(1, 2, 0).reshape(-1), s2, b2,       # [ci][tap][co]
+                      f(head).reshape(8, 9).reshape(-1)]).contiguous()                   # [ci][tap]
+
+
+def uncert_net(entropy: torch.Tensor, params: torch.Tensor) -> torch.Tensor:
+    """entropy [N,H,W] fp32 -> log-uncertainty [N,H,W] fp32 (reference model_cas.py:77-98, eval mode)."""
+    _dev(entropy, params)
+    if entropy.dtype != torch.float32 or entropy.dim() != 3 or not entropy.is_contiguous():
+        raise ValueError("pscv.uncert_net: entropy must be a contiguous fp32 [N,H,W] map")
+    if params.dtype != torch.float32 or params.numel() != 752 or not params.is_contiguous():
+        raise ValueError("pscv.uncert_net: params must be the 752-float block of pack_uncert_params")
+    N, H, W = entropy.shape
+    out = torch.empty_like(entropy)
+    rc = _launch("uncert_net", lambda: L.lib().pscv_uncert_net(_p(entropy), _p(params), _p(out), N, H, W, _stream()))
+    L.check(rc, "pscv_uncert_net")
+    return out
+
+
+# --------------------------------------------------------------------------------------------
 # softargmin
 # --------------------------------------------------------------------------------------------
 def softargmin(logits: torch.Tensor, depth: Optional[torch.Tensor] = None, *, want_index: bool = False,
