@@ -52,20 +52,32 @@ class Frontend(ReplayHooks, nn.Module):
         cam[:, 1, 3, 0], cam[:, 1, 3, 1] = start_depth, depth_interval
         return cam
 
+    def fill_cam_arrays(self, K, R, t, start_depth, depth_interval):
+        """``fill_cam_array`` of every view in six launches: [V,b,2,4,4], view-major so that ``[1:].unbind(0)`` hands the stages
+        their source cameras as back-to-back views of one buffer (``ops.homog_cams_device`` then reads them without a stack)."""
+        b, v = K.shape[:2]
+        cam = torch.zeros((v, b, 2, 4, 4), device=K.device)
+        cam[:, :, 0, :3, :3], cam[:, :, 0, :3, 3:4], cam[:, :, 1, :3, :3] = R.transpose(0, 1), t.transpose(0, 1), K.transpose(0, 1)
+        cam[:, :, 1, 3, 0], cam[:, :, 1, 3, 1] = start_depth.transpose(0, 1), depth_interval.transpose(0, 1)
+        return cam
+
     @replayable
     def forward(self, imgs, K, R, t, depth_min, depth_max, reference_frame=0, **kwargs):
         depth_interval = (depth_max - depth_min) / 128                                   # frontend.py:27
         interval_scales = kwargs.get("interval_scales", self.interval_scales)
         depth_nums = kwargs.get("depth_nums", self.depth_nums)
         taps = kwargs.get("taps")
+        imgs_all = None
         if not isinstance(imgs, (list, tuple)):
+            imgs_all = imgs                                                              # [n,V,3,H,W]
             imgs = torch.unbind(imgs, dim=1)
         v = len(imgs)
         src_idx = [i for i in range(v) if i != reference_frame]
         n = imgs[reference_frame].shape[0]
-        ref_cam = self.fill_cam_array(K[:, reference_frame], R[:, reference_frame], t[:, reference_frame],
-                                      depth_min[:, reference_frame], depth_interval[:, reference_frame])
-        srcs_cam = [self.fill_cam_array(K[:, i], R[:, i], t[:, i], depth_min[:, i], depth_interval[:, i]) for i in src_idx]
+        order = [reference_frame] + src_idx
+        pick = (lambda a: torch.stack([a[:, i] for i in order], 1)) if reference_frame != 0 else (lambda a: a)   # (device-side only)
+        cams = self.fill_cam_arrays(pick(K), pick(R), pick(t), pick(depth_min), pick(depth_interval))    # reference view first
+        ref_cam, srcs_cam = cams[0], list(cams[1:].unbind(0))
         with torch.set_grad_enabled(self.training):
             grp = self.model.stage1.view_group
             if self.training:
@@ -83,7 +95,11 @@ class Frontend(ReplayHooks, nn.Module):
                 pass
             elif grp is None and len({tuple(i.shape) for i in imgs}) == 1:
                 # all views through the 2-D extractor as one batch (same result as the per-view loop in eval mode)
-                packs = [torch.chunk(f, v, 0) for f in fe(torch.cat([imgs[reference_frame]] + [imgs[i] for i in src_idx], 0))]
+                if imgs_all is not None and reference_frame == 0:
+                    batch = imgs_all.transpose(0, 1).reshape((v * n,) + tuple(imgs_all.shape[2:]))   # view-major; a view when n == 1
+                else:
+                    batch = torch.cat([imgs[i] for i in order], 0)
+                packs = [torch.chunk(f, v, 0) for f in fe(batch)]
                 ref_feats = tuple(p[0] for p in packs)
                 src_feats = [tuple(p[j + 1] for p in packs) for j in range(len(src_idx))]
             elif grp is None:

@@ -427,7 +427,7 @@ class SingleStage(nn.Module):
         if not mine:
             raise ValueError("view shard: more ranks than source views")
         costs = self.build_cost_volume(ref_feat, ref_cam, srcs_feat, srcs_cam, depth_num, depth_start, depth_interval, s_scale)
-        interms, uncerts, pair_results, est_depths, entropies = [], [], [], [], []
+        interms, uncerts, pair_results = [], [], []
         # the pair branch of ALL source views as ONE batch per layer (the views share `reg` / `reg_pair`, and the fused warp
         # launch already wrote their volumes back to back: [n_src, n, d, h, w, 8] -> [n_src * n, d, h, w, 8]): 7 + 1 + 1 launches
         # per stage instead of 9 per source view -- at 512x640 a per-view launch is 10-20 us of a few hundred workgroups
@@ -436,26 +436,30 @@ class SingleStage(nn.Module):
         # U-Net the activations are served from it, a batch of eight 118 MB volumes (configuration 5) is not -- measured there:
         # deconv 1.53 -> 1.98 ms when batched, the stage as a whole no faster -- so large volumes keep one launch per view
         n_s, n_b = costs.shape[0], costs.shape[1]
+        h, w = costs.shape[3], costs.shape[4]
         group = max(1, min(n_s, self.PAIR_BATCH_BYTES // max(1, costs[0].numel() * costs.element_size())))
+        # expected index and entropy of ALL pairs land in two buffers (each group's softargmin writes its batch slice), so the
+        # per-pair `index * interval + start` (model_cas.py:348) is two launches per stage and the UncertNet reads its batch in place
+        index_all = torch.empty((n_s * n_b, h, w), dtype=torch.float32, device=costs.device)
+        entropy_all = torch.empty((n_s * n_b, h, w), dtype=torch.float32, device=costs.device)
         for g0 in range(0, n_s, group):
             g1 = min(n_s, g0 + group)
             interm_all = self.reg(costs[g0:g1].view(((g1 - g0) * n_b,) + tuple(costs.shape[2:])))
             score_all = self.reg_pair(interm_all)                                      # fp32 [views * n, d, h, w]
-            o_all = ops.softargmin(score_all, None, want_index=True, want_entropy=True)
+            ops.softargmin(score_all, None, want_index=True, want_entropy=True,
+                           into={"index": index_all[g0 * n_b:g1 * n_b], "entropy": entropy_all[g0 * n_b:g1 * n_b]})
             for i in range(g0, g1):
                 sl = slice((i - g0) * n_b, (i - g0 + 1) * n_b)
-                est_depths.append(o_all["index"][sl].unsqueeze(1) * depth_interval + depth_start)  # model_cas.py:348
-                entropies.append(o_all["entropy"][sl].unsqueeze(1))
                 interms.append(interm_all[sl])
                 if taps is not None and i == 0:
-                    taps.update(cost0=costs[0], interm0=interm_all[sl], score0=score_all[sl], entropy0=o_all["entropy"][sl])
+                    taps.update(cost0=costs[0], interm0=interm_all[sl], score0=score_all[sl], entropy0=entropy_all[:n_b])
+        est_all = index_all.view(n_s, n_b, 1, h, w) * depth_interval + depth_start       # [n_b,1,1,1] / [n_b,1,h,w] broadcast
         # the 2-D UncertNet (eval-mode BatchNorm: per-sample) runs ONCE on the entropy maps of all pairs stacked along the batch
-        # axis -- 3 convolutions per stage instead of 3 per source view (72 -> 9 launches of ~23 us at 9 views); same values
-        n_b = entropies[0].shape[0]
-        heads_all = self.uncert_net(torch.cat(entropies, 0))
+        # axis: one fused launch per stage (csrc/uncert_net.hip); same values
+        heads_all = self.uncert_net(entropy_all.unsqueeze(1))
         for i in range(len(srcs_feat)):
             heads = [hd[i * n_b:(i + 1) * n_b] for hd in heads_all]
-            pair_results.append([est_depths[i], heads])
+            pair_results.append([est_all[i], heads])
             uncerts.append(heads[0].squeeze(1).to(torch.float32).contiguous())
             if taps is not None and i == 0:
                 taps.update(uncert0=heads[0])

@@ -178,10 +178,27 @@ def proj_cams_device(proj: torch.Tensor, reference_frame: int = 0) -> torch.Tens
     return cams
 
 
+def _consecutive_views(ts: Sequence[torch.Tensor]) -> Optional[torch.Tensor]:
+    """[n, *shape] view over ``ts`` when they are equally shaped contiguous tensors lying back to back in one storage (e.g.
+    ``base[1:].unbind(0)``): no copy.  None otherwise."""
+    ts = list(ts)
+    t0 = ts[0]
+    if not all(t.is_contiguous() and t.shape == t0.shape and t.dtype == t0.dtype and t.device == t0.device
+               and t.untyped_storage().data_ptr() == t0.untyped_storage().data_ptr() for t in ts):
+        return None
+    step = t0.numel()
+    if step == 0 or any(t.storage_offset() != t0.storage_offset() + i * step for i, t in enumerate(ts)):
+        return None
+    return torch.as_strided(t0, (len(ts),) + tuple(t0.shape), (step,) + tuple(t0.stride()))
+
+
 def homog_cams_device(ref_cam: torch.Tensor, src_cams: Sequence[torch.Tensor], scale: float) -> torch.Tensor:
     """HOMOG-geometry camera blocks [n_src,B,18] (A[9], Bm[9]) from Vis-style cam arrays [B,2,4,4] in one HIP
     launch (pscv_homog_cams); ``scale`` = 1 / s_scale is applied to the intrinsics like scale_camera."""
-    src = torch.stack(list(src_cams)).to(torch.float32).contiguous()
+    src = _consecutive_views(src_cams)
+    if src is None:
+        src = torch.stack(list(src_cams))
+    src = src.to(torch.float32).contiguous()
     ref = ref_cam.to(torch.float32).contiguous()
     _dev(ref, src)
     n, B = src.shape[:2]
@@ -682,9 +699,10 @@ def uncert_net(entropy: torch.Tensor, params: torch.Tensor) -> torch.Tensor:
 # --------------------------------------------------------------------------------------------
 def softargmin(logits: torch.Tensor, depth: Optional[torch.Tensor] = None, *, want_index: bool = False,
                want_conf: bool = False, conf_mode: int = 0, window: float = 2.0, want_entropy: bool = False,
-               want_prob: bool = False, want_partials: bool = False, index_offset: int = 0) -> dict:
+               want_prob: bool = False, want_partials: bool = False, index_offset: int = 0, into: Optional[dict] = None) -> dict:
     """logits [B,D,h,w] (fp32 or bf16); depth [B,D] or [B,D,h,w] fp32.  Returns a dict with the requested
-    maps, each [B,h,w] fp32 (``prob`` [B,D,h,w], ``partials`` [B,4,h,w])."""
+    maps, each [B,h,w] fp32 (``prob`` [B,D,h,w], ``partials`` [B,4,h,w]).  ``into`` = {name: tensor}: write those maps into
+    the caller's contiguous fp32 tensors (e.g. batch slices of one buffer for all source views) instead of new ones."""
     _dev(logits, depth)
     if logits.dim() != 4:
         raise ValueError("pscv.softargmin: logits must be [B,D,h,w]")
@@ -702,6 +720,10 @@ def softargmin(logits: torch.Tensor, depth: Optional[torch.Tensor] = None, *, wa
         "prob": mk(B, D, h, w) if want_prob else None,
         "partials": mk(B, 4, h, w) if want_partials else None,
     }
+    for k, tgt in (into or {}).items():
+        if o.get(k) is None or tgt.dtype != torch.float32 or tgt.shape != o[k].shape or not tgt.is_contiguous() or tgt.device != logits.device:
+            raise ValueError(f"pscv.softargmin: into[{k!r}] must be a requested map's contiguous fp32 tensor of shape {tuple(o[k].shape) if o.get(k) is not None else None}")
+        o[k] = tgt
     rc = _launch("softargmin", lambda: L.lib().pscv_softargmin(
         _p(logits), _dt(logits), _p(depth), 0 if depth is None else depth.stride(0), int(per_pixel), _p(o["depth"]),
         _p(o["index"]), _p(o["conf"]), _p(o["entropy"]), _p(o["prob"]), _p(o["partials"]), conf_mode, float(window),
