@@ -50,7 +50,8 @@ def test_conv2d_matches_aten(env, ci, co, ks, stride, B, H, W, dtype):
     check_close("16-bit store", got16.float().cpu(), got.cpu(), max_abs=ulp * float(got.abs().max()) + 1e-6, rel_l2=ulp)
 
 
-@pytest.mark.parametrize("ci,co,wlds", [(3, 64, 1), (64, 64, 0), (64, 64, 2), (64, 32, 0), (64, 32, 2), (32, 16, 1), (16, 16, 1)])
+@pytest.mark.parametrize("ci,co,wlds", [(3, 64, 1), (64, 64, 0), (64, 64, 2), (64, 32, 0), (64, 32, 2), (32, 16, 0), (32, 16, 2), (32, 32, 0),
+                                        (32, 32, 2), (16, 16, 1)])
 def test_conv2d_leaky_relu_layers_of_the_cvp_pyramid(env, ci, co, wlds):
     """conv 3x3 + bias + LeakyReLU(0.1) (models/CVP_MVSNet/models/modules.py:24-28), incl. the 64-channel layers on both of
     their kernels: weight fragments streamed per wave through the prefetch ring (conv2d_wlds = 0) and the persistent kernel
@@ -95,3 +96,38 @@ def test_conv2d_plain_conv_with_bias_at_feature_size(env):
     check_close("linearity", fz.cpu(), want.cpu(), max_abs=2e-3 * float(want.abs().max()), rel_l2=1e-3)
     ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.to(torch.float16).float().cuda(), bias.cuda(), padding=1).permute(0, 2, 3, 1)
     check_close("vs ATen on the GPU", fx.cpu(), ref.cpu(), max_abs=1e-4 * float(ref.abs().max()), rel_l2=2e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("ci,co", [(32, 32), (64, 64), (32, 16)])
+def test_weights_in_lds_kernel_with_residual_equals_streaming_kernel(env, ci, co, dtype):
+    """The persistent weights-in-LDS kernel (conv2d_wlds = 2) on a residual block's second conv (BN + skip + ReLU, the Vis
+    extractor's blocks, nn_utils.py:60-100) against the streaming kernel (0): same bits; skip and output as channel slices of
+    wider tensors; a ragged size with partial tiles on both axes."""
+    L, ops = env
+    g = torch.Generator().manual_seed(ci * 7 + co)
+    B, H, W = 2, 45, 70
+    x = torch.randn(B, H, W, ci, generator=g).to(dtype).cuda()
+    w = torch.randn(co, ci, 3, 3, generator=g) / (ci * 9) ** 0.5
+    bn = (torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g) * 0.1, torch.randn(co, generator=g) * 0.1, torch.rand(co, generator=g) + 0.5)
+    layer = ops.Conv2dLayer.build(w, stride=1, device="cuda", bn=bn, relu=True, dtype=dtype)
+    skip_wide = torch.randn(B, H, W, co + 8, generator=g).to(dtype).cuda()
+    res = {}
+    for wl in (0, 2):
+        L.set_tuning("conv2d_wlds", wl)
+        try:
+            out = torch.full((B, H, W, co + 16), -3.0, dtype=dtype, device="cuda")
+            ops.conv2d(x, layer, skip=skip_wide, skip_coff=8, out=out, out_coff=8)
+            res[wl] = (out, ops.conv2d(x, layer, skip=skip_wide[..., 8:].contiguous()), ops.conv2d(x, layer))
+        finally:
+            L.set_tuning("conv2d_wlds", 1)
+    for a, b in zip(res[0], res[2]):
+        assert torch.equal(a, b)
+    out = res[2][0]
+    assert bool((out[..., :8] == -3.0).all()) and bool((out[..., 8 + co:] == -3.0).all())
+    assert torch.equal(out[..., 8:8 + co], res[2][1])
+    scale = bn[0] / torch.sqrt(bn[3] + 1e-5)
+    ref = F.relu(F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.to(dtype).float(), padding=1) * scale.view(1, -1, 1, 1)
+                 + (bn[1] - bn[2] * scale).view(1, -1, 1, 1) + skip_wide[..., 8:].float().cpu().permute(0, 3, 1, 2))
+    ulp = 2 ** -8 if dtype == torch.bfloat16 else 2 ** -11
+    check_close(f"residual conv2d {ci}->{co} {dtype}", res[2][1].float().cpu().permute(0, 3, 1, 2), ref, max_abs=2 * ulp * float(ref.abs().max()) + 1e-5, rel_l2=2 * ulp)

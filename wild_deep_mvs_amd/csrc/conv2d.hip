@@ -228,19 +228,35 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const Conv2dArgs a) {
 // (74 KB weights + 49 KB brick), 512 threads, each wave one 32-pixel row of the 8 x 32 tile (2 M-tiles x NT N-tiles: 2 operand +
 // NT weight `ds_read_b128` per 2 NT MFMAs), looping over tiles with the NEXT tile's brick in flight (global -> registers)
 // while the current one is contracted, so HBM latency hides under the MFMAs instead of under other workgroups.
-constexpr int C2W_TH = 8, C2W_BH = 10, C2W_BW = 34, C2W_VS = 128, C2W_STEPS = 18, C2W_THREADS = 512;
-// Brick pixels are 128 bytes apart and the eight 16-byte chunks of pixel p (= row * 34 + column) sit at chunk ^ (p & 7): a
+constexpr int C2W_TH = 8, C2W_BH = 10, C2W_BW = 34, C2W_THREADS = 512;
+// 64 channels: brick pixels are 128 bytes apart and the eight 16-byte chunks of pixel p (= row * 34 + column) sit at chunk ^ (p & 7): a
 // `ds_read_b128` lane group is 8 lanes with chunk A on pixels p0 + {0-3, 12-15} and 8 lanes with chunk A ^ 1 on p0 + {4-11}; under the
 // XOR the sixteen 16-byte bank granules they touch are all different (the 144-byte padded pitch of conv2d_kernel collides for 7 of
 // the 8 pairs of such a mixed group).
-__device__ __forceinline__ int c2w_lds(int p, int chunk) { return p * C2W_VS + ((chunk ^ (p & 7)) << 4); }
-constexpr int C2W_BRICK = C2W_BH * C2W_BW * C2W_VS;                       // 48 960 B
-constexpr int C2W_CHUNKS = C2W_BH * C2W_BW * 8;                           // 16-byte chunks of a brick (2720)
-constexpr int C2W_NLD = (C2W_CHUNKS + C2W_THREADS - 1) / C2W_THREADS;     // 6 per thread
+// 32 channels (CVP's 32 -> 32 / 32 -> 16 pyramid layers, the Vis extractor's full-resolution blocks): 64 bytes per pixel, so the
+// granule of (p, chunk) is 4 (p mod 4) + chunk': the four pixels p, p + 4, p + 8, p + 12 of a lane group's 16-pixel window share
+// 4 (p mod 4) and carry chunks (A, A ^ 1, A ^ 1, A); chunk' = chunk ^ (2 if (p >> 2) is odd) makes them (A, A ^ 3, A ^ 1, A ^ 2) or
+// (A ^ 2, A ^ 1, A ^ 3, A): all different, for either kind of group.
+template <int CIN> struct C2WGeom {
+    static_assert(CIN == 32 || CIN == 64, "weights-in-LDS conv2d: 32 or 64 input channels");
+    static constexpr int VS = CIN * 2;                          // bytes per brick pixel
+    static constexpr int CPP = CIN / 8;                         // 16-byte chunks per pixel
+    static constexpr int KSTEPS = CIN / 32;                     // 32-channel k-steps per tap
+    static constexpr int STEPS = 9 * KSTEPS;
+    static constexpr int BRICK = C2W_BH * C2W_BW * VS;          // 48 960 B / 21 760 B
+    static constexpr int CHUNKS = C2W_BH * C2W_BW * CPP;        // 2720 / 1360
+    static constexpr int NLD = (CHUNKS + C2W_THREADS - 1) / C2W_THREADS;   // 6 / 3 per thread
+    static __device__ __forceinline__ int lds(int p, int chunk) {
+        if constexpr (CIN == 64) return p * VS + ((chunk ^ (p & 7)) << 4);
+        else return p * VS + ((chunk ^ ((p >> 1) & 2)) << 4);
+    }
+};
 
 PSCV_PROF_BUFFER(c2w)
-template <typename H, int NT>
+template <typename H, int NT, int CIN>
 __global__ __launch_bounds__(C2W_THREADS, 2) void conv2d_wlds_kernel(const Conv2dArgs a, int n_tiles) {
+    using G = C2WGeom<CIN>;
+    constexpr int C2W_STEPS = G::STEPS, C2W_BRICK = G::BRICK, C2W_CHUNKS = G::CHUNKS, C2W_NLD = G::NLD, CPP = G::CPP;
     constexpr int W_BYTES = C2W_STEPS * NT * 1024;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int OPITCH = NT * 32 + 16;             // bytes per pixel of the output staging rows (+16: conflict-free 8-byte writes)
@@ -265,10 +281,10 @@ __global__ __launch_bounds__(C2W_THREADS, 2) void conv2d_wlds_kernel(const Conv2
     for (int k = 0; k < C2W_NLD; ++k) {
         const int q = tid + C2W_THREADS * k;
         cin[k] = q < C2W_CHUNKS;
-        const int r = q / (C2W_BW * 8), rem = q - r * (C2W_BW * 8);
-        cr[k] = r; cbw[k] = rem >> 3;
-        ccoff[k] = (unsigned)(rem & 7) * 16u;
-        loff[k] = c2w_lds(r * C2W_BW + cbw[k], rem & 7);
+        const int r = q / (C2W_BW * CPP), rem = q - r * (C2W_BW * CPP);
+        cr[k] = r; cbw[k] = rem / CPP;
+        ccoff[k] = (unsigned)(rem % CPP) * 16u;
+        loff[k] = G::lds(r * C2W_BW + cbw[k], rem % CPP);
     }
     float sc[NT][4], bi[NT][4];
 #pragma unroll
@@ -279,11 +295,11 @@ __global__ __launch_bounds__(C2W_THREADS, 2) void conv2d_wlds_kernel(const Conv2
             sc[m][k] = (a.scale && c < a.cout) ? a.scale[c] : 1.0f;
             bi[m][k] = (a.bias && c < a.cout) ? a.bias[c] : 0.0f;
         }
-    const unsigned row_bytes = (unsigned)a.Wi * 128u;
+    const unsigned row_bytes = (unsigned)a.Wi * (unsigned)G::VS;
     const int tiles_per_img = a.nth * a.ntw;
     unsigned roff[C2W_NLD];                             // chunk offset from the brick's first pixel (interior tiles)
 #pragma unroll
-    for (int k = 0; k < C2W_NLD; ++k) roff[k] = cin[k] ? (unsigned)cr[k] * row_bytes + (unsigned)cbw[k] * 128u + ccoff[k] : 0u;
+    for (int k = 0; k < C2W_NLD; ++k) roff[k] = cin[k] ? (unsigned)cr[k] * row_bytes + (unsigned)cbw[k] * (unsigned)G::VS + ccoff[k] : 0u;
     auto fetch = [&](int t, uint4 (&val)[C2W_NLD]) {
         const int b = t / tiles_per_img, rt = t - b * tiles_per_img;
         const int th_i = rt / a.ntw, tw_i = rt - th_i * a.ntw;
@@ -292,7 +308,7 @@ __global__ __launch_bounds__(C2W_THREADS, 2) void conv2d_wlds_kernel(const Conv2
         if (iy0 >= 0 && ix0 >= 0 && iy0 + C2W_BH <= a.Hi && ix0 + C2W_BW <= a.Wi) {
             // interior tile (workgroup-uniform): one scalar base + a precomputed 32-bit lane offset per chunk, no bounds tests --
             // the general form below cost ~1100 cycles per tile in 64-bit address arithmetic and predicates
-            const char* base = inb + (unsigned long)iy0 * row_bytes + (unsigned)ix0 * 128u;
+            const char* base = inb + (unsigned long)iy0 * row_bytes + (unsigned)ix0 * (unsigned)G::VS;
 #pragma unroll
             for (int k = 0; k < C2W_NLD; ++k) val[k] = *reinterpret_cast<const uint4*>(base + roff[k]);
             return;
@@ -302,7 +318,7 @@ __global__ __launch_bounds__(C2W_THREADS, 2) void conv2d_wlds_kernel(const Conv2
             const int gy = iy0 + cr[k], gx = ix0 + cbw[k];
             const bool ok = cin[k] && (unsigned)gy < (unsigned)a.Hi && (unsigned)gx < (unsigned)a.Wi;
             val[k] = make_uint4(0u, 0u, 0u, 0u);
-            if (ok) val[k] = *reinterpret_cast<const uint4*>(inb + (unsigned long)gy * row_bytes + (unsigned)gx * 128u + ccoff[k]);
+            if (ok) val[k] = *reinterpret_cast<const uint4*>(inb + (unsigned long)gy * row_bytes + (unsigned)gx * (unsigned)G::VS + ccoff[k]);
         }
     };
     const int p_anchor = wave * C2W_BW + n;                      // this wave's row, column tile 0; tile 1 = + 16 pixels
@@ -331,11 +347,11 @@ __global__ __launch_bounds__(C2W_THREADS, 2) void conv2d_wlds_kernel(const Conv2
         // waves per SIMD the LDS latency was exposed at every step (29 % of the MFMA peak).
         uint4 wf[2][NT], xf[2][2];
         auto request = [&](int s_, uint4 (&w_)[NT], uint4 (&x_)[2]) {
-            const int tap = s_ >> 1, kh = tap / 3, kw = tap - kh * 3;
+            const int tap = s_ / G::KSTEPS, kh = tap / 3, kw = tap - kh * 3;
 #pragma unroll
             for (int m = 0; m < NT; ++m) w_[m] = *reinterpret_cast<const uint4*>(sw + ((s_ * NT + m) * 64 + lane) * 16);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) x_[i] = *reinterpret_cast<const uint4*>(sb + c2w_lds(p_anchor + i * 16 + kh * C2W_BW + kw, (s_ & 1) * 4 + g));
+            for (int i = 0; i < 2; ++i) x_[i] = *reinterpret_cast<const uint4*>(sb + G::lds(p_anchor + i * 16 + kh * C2W_BW + kw, (s_ % G::KSTEPS) * 4 + g));
         };
         request(0, wf[0], xf[0]);
 #pragma unroll
@@ -354,27 +370,44 @@ __global__ __launch_bounds__(C2W_THREADS, 2) void conv2d_wlds_kernel(const Conv2
             const int b = t / tiles_per_img, rt = t - b * tiles_per_img;
             const int th_i = rt / a.ntw, tw_i = rt - th_i * a.ntw;
             const int oy = th_i * C2W_TH + wave;
-            if (!a.skip && !a.out_f32 && !((a.out_cs | a.out_co) & 7) && a.cout == NT * 16) {
+            if (!a.out_f32 && !((a.out_cs | a.out_co) & 7) && a.cout == NT * 16 && (!a.skip || !((a.skip_cs | a.skip_co) & 7))) {
                 // 16-bit output without a residual (every CVP pyramid layer): the wave's row is 32 pixels x NT x 32 contiguous
                 // bytes in memory.  An 8-byte store per lane and (column tile, channel tile) is store-ISSUE bound (~7 B/clk/CU: the
                 // 32 KB of a tile cost as many cycles as its MFMAs); the packed values go through a per-wave LDS row instead and
                 // leave as 16-byte stores, a lane covering 8 consecutive channels of a pixel (same bits)
+                const unsigned long rowpix = ((unsigned long)b * a.Hof + (oy * a.oys + a.oyo)) * a.Wof;
+                if (a.skip) {
+                    // the residual input (the Vis extractor's blocks) takes the same road in: 16-byte loads of the row into the
+                    // staging row, from which each lane picks the 8 bytes of its own channels (fp32 add before the activation,
+                    // like conv2d_kernel: same bits)
+#pragma unroll
+                    for (int k = 0; k < NT; ++k) {
+                        const int q = lane + 64 * k, p = q / (NT * 2), c = q - p * (NT * 2);
+                        const int ox = tw_i * C2_TW + p;
+                        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                        if (oy < a.Ho && ox < a.Wo) v = *reinterpret_cast<const uint4*>(a.skip + (rowpix + (ox * a.oxs + a.oxo)) * a.skip_cs + a.skip_co + c * 8);
+                        *reinterpret_cast<uint4*>(so + p * OPITCH + c * 16) = v;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int m = 0; m < NT; ++m) {
-                        float y[4];
+                        float v[4], y[4];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const float v = fmaf(acc[i][m][k], sc[m][k], bi[m][k]);
-                            y[k] = fmaxf(v, v * a.neg_slope);
+                        for (int k = 0; k < 4; ++k) v[k] = fmaf(acc[i][m][k], sc[m][k], bi[m][k]);
+                        unsigned char* const slot = so + (i * 16 + n) * OPITCH + (m * 16 + g * 4) * 2;
+                        if (a.skip) {
+                            const uint2 sv = *reinterpret_cast<const uint2*>(slot);
+                            v[0] += Half16<H>::lo(sv.x); v[1] += Half16<H>::hi(sv.x); v[2] += Half16<H>::lo(sv.y); v[3] += Half16<H>::hi(sv.y);
                         }
-                        *reinterpret_cast<uint2*>(so + (i * 16 + n) * OPITCH + (m * 16 + g * 4) * 2) =
-                            make_uint2(Half16<H>::pack(y[0], y[1]), Half16<H>::pack(y[2], y[3]));
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) y[k] = fmaxf(v[k], v[k] * a.neg_slope);
+                        *reinterpret_cast<uint2*>(slot) = make_uint2(Half16<H>::pack(y[0], y[1]), Half16<H>::pack(y[2], y[3]));
                     }
                 __builtin_amdgcn_wave_barrier();          // (LDS executes a wave's operations in order: the reads below see the row)
                 if (oy < a.Ho) {
-                    const unsigned long rowpix = ((unsigned long)b * a.Hof + (oy * a.oys + a.oyo)) * a.Wof;
 #pragma unroll
                     for (int k = 0; k < NT; ++k) {
                         const int q = lane + 64 * k, p = q / (NT * 2), c = q - p * (NT * 2);
@@ -424,14 +457,14 @@ PSCV_PROF_EXPORT(c2w)
 namespace pscv {
 Knob g_conv2d_wlds = {1, KNOB_SPARE1};    // pscv_set_tuning("conv2d_wlds", 0): 64-channel k3 s1 layers back on conv2d_kernel; 2: at any size
 
-template <typename H, int NT>
+template <typename H, int NT, int CIN>
 static int c2w_launch(Conv2dArgs& a, hipStream_t st) {
-    constexpr int LDS = C2W_STEPS * NT * 1024 + C2W_BRICK + 8 * 32 * (NT * 32 + 16);
+    constexpr int LDS = C2WGeom<CIN>::STEPS * NT * 1024 + C2WGeom<CIN>::BRICK + 8 * 32 * (NT * 32 + 16);
     static_assert(LDS <= 160 * 1024, "weights + brick + output rows must fit the LDS");
     a.nth = c2_ceil_div(a.Ho, C2W_TH); a.ntw = c2_ceil_div(a.Wo, C2_TW);
     const long tiles = (long)a.B * a.nth * a.ntw;
     if (tiles <= 0 || tiles > 0x7fffffffL) { set_error("pscv_conv2d: bad grid %ld", tiles); return -1; }
-    auto kern = conv2d_wlds_kernel<H, NT>;
+    auto kern = conv2d_wlds_kernel<H, NT, CIN>;
     static bool done = false;   // per instantiation
     if (!done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -481,9 +514,13 @@ static int c2_dispatch(Conv2dArgs& a, int c_in, int c_out, int ks, int stride, h
     a.nt_total = nt;
     // (c_in, output tiles per workgroup, kernel size, stride); layers wider than 4 tiles (64 channels) split their output
     // tiles over blockIdx.y in groups of 4
-    if (c_in == 64 && ks == 3 && stride == 1 && (nt == 4 || nt == 2) && g_conv2d_wlds &&
-        (g_conv2d_wlds == 2 || (long)a.B * c2_ceil_div(a.Ho, C2W_TH) * c2_ceil_div(a.Wo, C2_TW) >= 512))
-        return nt == 4 ? c2w_launch<H, 4>(a, st) : c2w_launch<H, 2>(a, st);
+    if (ks == 3 && stride == 1 && g_conv2d_wlds &&
+        (g_conv2d_wlds == 2 || (long)a.B * c2_ceil_div(a.Ho, C2W_TH) * c2_ceil_div(a.Wo, C2_TW) >= 512)) {
+        if (c_in == 64 && nt == 4) return c2w_launch<H, 4, 64>(a, st);
+        if (c_in == 64 && nt == 2) return c2w_launch<H, 2, 64>(a, st);
+        if (c_in == 32 && nt == 2) return c2w_launch<H, 2, 32>(a, st);
+        if (c_in == 32 && nt == 1) return c2w_launch<H, 1, 32>(a, st);
+    }
     const int ntw = nt > 4 ? 4 : nt;
     const int split = (nt + ntw - 1) / ntw;
     if (nt > 4 && nt % 4) { set_error("pscv_conv2d: c_out=%d above 64 must be a multiple of 64", c_out); return -1; }
