@@ -453,6 +453,21 @@ int pscv_prob_softargmin(const void* in, int dtype, int in_cstride, int in_coff,
                          int H, int W, void* stream);
 
 /*
+ * Fused head of a Vis-MVSNet PAIR branch: RegPair.final_conv (8 -> 1, kind S1C1 packing, depth-sweep variant) + soft_argmin's expected
+ * plane index + the entropy of the softmax over depth, in one pass over the pair volume.  Replaces RegPair.forward + soft_argmin +
+ * entropy (models/VisMVSNet/model_cas.py:55-59,342-348; nn_utils.py:453-470): the pair branch only needs these two maps, so the fp32
+ * score volume need not exist (`logits` may be null: 24 -> 16 B of traffic per voxel and one launch instead of two).
+ *   entropy = log Z - sum_d e_d (l_d - max) / Z  with e_d = exp(l_d - max), Z = sum e_d: the reference's -sum p log(clamp(p, 1e-9, 1))
+ *   without the clamp (planes with p < 1e-9 differ by < 3e-6 in total).
+ * Returns -3 when the layer / size does not qualify (then call pscv_conv3d and pscv_softargmin).  Arguments as pscv_prob_softargmin;
+ *   workspace pscv_prob_softargmin_workspace(B,D,H,W) floats (used when the depth axis is split into chunks);
+ *   out_index / out_entropy device fp32 [B,H,W].
+ */
+int pscv_head_index_entropy(const void* in, int dtype, int in_cstride, int in_coff, const uint16_t* packed, const float* scale,
+                            const float* bias, const float* floor, int c_in, int epi_flags, float* logits, float* workspace,
+                            long workspace_floats, float* out_index, float* out_entropy, int B, int D, int H, int W, void* stream);
+
+/*
  * Function-level homography warp: one 3x3 matrix per batch item or per reference pixel.  Replaces homography_warping +
  * interpolate of models/VisMVSNet/homography.py:84-120 for direct callers (inside the model the homographies are built in the
  * fused sweep and never materialised).  Pixel centres at +0.5, z <= 0 -> zero sample, divisor clamped at 1e-9,

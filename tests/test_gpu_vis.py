@@ -261,3 +261,49 @@ def test_uncert_net_tracks_parameter_updates_and_train_mode(env):
     net.train()
     y = net(x)[0]                                                    # batch-statistics BatchNorm under autograd: torch layers
     assert y.requires_grad
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape,force", [((2, 16, 36, 40), True), ((1, 32, 9, 70), True), ((3, 192, 16, 32), True), ((1, 256, 20, 33), True),
+                                         ((2, 14, 8, 16), True), ((1, 16, 256, 320), False), ((2, 16, 36, 40), False)])
+def test_fused_pair_head_equals_head_plus_softargmin(env, shape, force, dtype):
+    """pscv_head_index_entropy (RegPair.final_conv + soft_argmin + entropy in one pass, model_cas.py:55-59,342-348) against
+    the two separate launches: scores bit-equal, expected index / entropy within fp32 rounding (the fused entropy is the
+    log-sum-exp form without the reference's clamp of p at 1e-9: < 3e-6).  One depth chunk (16 / 32 planes: written by the
+    sweep itself) and several (merge launch)."""
+    L, ops, synthetic, Frontend, OV = env
+    from wild_deep_mvs_amd.models.VisMVSNet.model_cas import RegPair
+    B, D, H, W = shape
+    g = torch.Generator().manual_seed(D * 100 + W)
+    x = (torch.randn(B, D, H, W, 8, generator=g) * 2.0).to(dtype).cuda()
+    head = RegPair().cuda().eval()
+    with torch.no_grad():
+        head.final_conv.weight.copy_(torch.randn(1, 8, 3, 3, 3, generator=g) * 0.3)     # logits spread over +-15: peaked and flat pixels
+    idx = torch.empty(B, H, W, device="cuda")
+    ent = torch.empty(B, H, W, device="cuda")
+    # small volumes take the brick head + pscv_softargmin (None); c1_sweep = 2 puts any size on the depth sweep
+    tiles, nblocks = B * ((H + 3) // 4) * ((W + 31) // 32), (D + 5) // 6
+    ndc = min(1 if tiles >= 768 else 768 // tiles, nblocks)
+    qualifies = force or (nblocks + ndc - 1) // ndc >= 3
+    L.set_tuning("c1_sweep", 2 if force else 1)
+    try:
+        score = head(x)                                                                  # (the same head kernel: same bits)
+        want = ops.softargmin(score, None, want_index=True, want_entropy=True)
+        got = head.head_index_entropy(x, idx, ent, want_scores=True)
+        idx2, ent2 = torch.empty_like(idx), torch.empty_like(ent)
+        got2 = head.head_index_entropy(x, idx2, ent2)                                    # no score volume: same maps
+    finally:
+        L.set_tuning("c1_sweep", 1)
+    if not qualifies:
+        assert got is None and got2 is None
+        return
+    assert got is not None and torch.equal(got, score)
+    assert got2 is True and torch.equal(idx2, idx) and torch.equal(ent2, ent)
+    check_close(f"fused head index {shape} {dtype}", idx.cpu(), want["index"].cpu(), max_abs=2e-4, rel_l2=2e-6)
+    check_close(f"fused head entropy {shape} {dtype}", ent.cpu(), want["entropy"].cpu(), max_abs=2e-5, rel_l2=5e-6)
+    # against the reference formula in fp64 on the same scores
+    p = torch.softmax(score.double().cpu(), dim=1)
+    want_ent = -(p * torch.log(p.clamp(1e-9, 1.0))).sum(1)
+    want_idx = (p * torch.arange(D, dtype=torch.float64).view(1, D, 1, 1)).sum(1)
+    check_close(f"fused head entropy vs fp64 {shape}", ent.cpu(), want_ent.float(), max_abs=2e-5, rel_l2=5e-6)
+    check_close(f"fused head index vs fp64 {shape}", idx.cpu(), want_idx.float(), max_abs=2e-4, rel_l2=2e-6)

@@ -57,6 +57,10 @@ struct C1Args {
     const float* depth;      // [B][D] planes, row stride depth_bstride
     long depth_bstride;
     float* part;             // [B][ndc][4][Hh][W]
+    // FUSE = 2 (Vis pair head, pscv_head_index_entropy): the statistics are (max, sum e, sum e * (logit - max), sum e * index); with one
+    // depth chunk the kernel writes the expected index and the entropy itself, otherwise the partials above + the merge launch
+    float* o_index;          // [B][Hh][W]
+    float* o_entropy;
 };
 
 constexpr int C1_P = 6;                        // output planes per block (MFMA rows 0..5)
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(256) void conv3d_c1_kernel(const C1Args a) {
 // A lane group reads two planes per block (4 (g >> 1) + (g & 1) and + 2): two ring addresses per block, taps as immediates.
 constexpr int C1S_NSLOT = 16;
 
-template <typename H, bool FUSE>      // FUSE: also keep the softmax statistics of the fused tail (its registers cost the plain head a wave per SIMD)
+template <typename H, int FUSE>      // FUSE 1 / 2: also keep the softmax statistics of a fused tail (its registers cost the plain head a wave per SIMD)
 __global__ __launch_bounds__(256, 3) void conv3d_c1_sweep_kernel(const C1Args a) {
     constexpr int VB = 16, NSTEPS = 18, PV = C1_BH * C1_BW, PSB = C1_PS * VB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [16 slots][C1_PS][16 B]
@@ -309,7 +313,7 @@ __global__ __launch_bounds__(256, 3) void conv3d_c1_sweep_kernel(const C1Args a)
     // fused tail: the chunk's depth planes in LDS (a global load per block sat in the block's dependency chain: 59 us fused
     // against 40 us for the two separate launches)
     __shared__ float sdep[256];
-    if (FUSE && tid < 256) sdep[tid] = a.depth[(long)b * a.depth_bstride + min(dbeg + tid, a.D - 1)];
+    if (FUSE == 1 && tid < 256) sdep[tid] = a.depth[(long)b * a.depth_bstride + min(dbeg + tid, a.D - 1)];
     __syncthreads();
     PSCV_STAMP(0)
 
@@ -320,10 +324,11 @@ __global__ __launch_bounds__(256, 3) void conv3d_c1_sweep_kernel(const C1Args a)
     const unsigned long out_plane = (unsigned long)a.Hh * a.W * a.out_cs * OB;
     const unsigned long skip_plane = (unsigned long)a.Hh * a.W * a.skip_cs * 2;
     const unsigned pix0 = (unsigned)(oh * a.W + w0 + n);
-    const bool row_ok = g < 2 && oh < a.Hh;
+    const bool store = FUSE != 2 || a.out != nullptr;        // (the Vis pair head may keep its logits to itself)
+    const bool row_ok = g < 2 && oh < a.Hh && store;
     const unsigned ostep = (unsigned)a.out_cs * (unsigned)OB;
     const unsigned ooff_g = (pix0 * (unsigned)a.out_cs + (unsigned)a.out_co) * (unsigned)OB + (unsigned)(4 * g) * (unsigned)out_plane;
-    const bool tile_full = w0 + C1_TW <= a.W && !a.skip && oh < a.Hh;
+    const bool tile_full = w0 + C1_TW <= a.W && !a.skip && oh < a.Hh && store;
     // running softmax statistics of this lane's own logits (planes d0 + 4 g + r of pixels (oh, w0 + ct * 16 + n)), merged across the two
     // lane groups once per chunk
     float sM[2] = {-__builtin_inff(), -__builtin_inff()}, sZ[2] = {0.f, 0.f}, sD[2] = {0.f, 0.f}, sI[2] = {0.f, 0.f};
@@ -405,7 +410,7 @@ __global__ __launch_bounds__(256, 3) void conv3d_c1_sweep_kernel(const C1Args a)
             // fused tail: fold the block's logits (fp32, before any store rounding) into the lane's softmax statistics
             float dpl[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dpl[r] = sdep[min(k * C1_P + 4 * g + r, 255)];
+            for (int r = 0; r < 4; ++r) dpl[r] = FUSE == 1 ? sdep[min(k * C1_P + 4 * g + r, 255)] : 0.0f;
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
                 float yv[4];
@@ -421,13 +426,16 @@ __global__ __launch_bounds__(256, 3) void conv3d_c1_sweep_kernel(const C1Args a)
                 if (lmax > -__builtin_inff()) {
                     const float mn = fmaxf(sM[ct], lmax);
                     const float sc = sM[ct] > -__builtin_inff() ? __expf(sM[ct] - mn) : 0.0f;
-                    float z = sZ[ct] * sc, sd = sD[ct] * sc, si = sI[ct] * sc;
+                    float z = sZ[ct] * sc, si = sI[ct] * sc;
+                    // FUSE 1: sum e * depth plane.  FUSE 2: sum e * (logit - max), re-based when the max moves (entropy = log Z - that / Z:
+                    // both terms of the entropy's size, where max + log Z - E[logit] would cancel two large numbers)
+                    float sd = FUSE == 1 ? sD[ct] * sc : (sM[ct] > -__builtin_inff() ? sc * fmaf(sM[ct] - mn, sZ[ct], sD[ct]) : 0.0f);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         if (ok[r]) {
                             const float e = __expf(yv[r] - mn);
                             z += e;
-                            sd = fmaf(e, dpl[r], sd);
+                            sd = fmaf(e, FUSE == 1 ? dpl[r] : yv[r] - mn, sd);
                             si = fmaf(e, (float)(d0 + 4 * g + r), si);
                         }
                     }
@@ -459,11 +467,22 @@ __global__ __launch_bounds__(256, 3) void conv3d_c1_sweep_kernel(const C1Args a)
             const int ow = w0 + ct * 16 + n;
             if (g == 0 && oh < a.Hh && ow < a.W) {
                 const long hw = (long)a.Hh * a.W;
-                float* pp = a.part + (((long)b * a.ndc + dci) * 4) * hw + (long)oh * a.W + ow;
-                pp[0] = mn;
-                pp[hw] = sZ[ct] * f0 + z1 * f1;
-                pp[2 * hw] = sD[ct] * f0 + d1 * f1;
-                pp[3 * hw] = sI[ct] * f0 + i1 * f1;
+                const float Z = sZ[ct] * f0 + z1 * f1, SI = sI[ct] * f0 + i1 * f1;
+                float SD;
+                if (FUSE == 1) SD = sD[ct] * f0 + d1 * f1;
+                else SD = (f0 > 0.0f ? f0 * fmaf(sM[ct] - mn, sZ[ct], sD[ct]) : 0.0f) + (f1 > 0.0f ? f1 * fmaf(m1 - mn, z1, d1) : 0.0f);
+                if (FUSE == 2 && a.ndc == 1) {
+                    const long o = (long)b * hw + (long)oh * a.W + ow;
+                    const float inv = 1.0f / Z;
+                    a.o_index[o] = SI * inv;
+                    a.o_entropy[o] = __logf(Z) - SD * inv;
+                } else {
+                    float* pp = a.part + (((long)b * a.ndc + dci) * 4) * hw + (long)oh * a.W + ow;
+                    pp[0] = mn;
+                    pp[hw] = Z;
+                    pp[2 * hw] = SD;
+                    pp[3 * hw] = SI;
+                }
             }
         }
     }
@@ -503,6 +522,30 @@ __global__ __launch_bounds__(256) void softargmin_merge_kernel(const float* __re
 }
 
 
+// Merge of the per-chunk partials (max, Z, sum e (logit - max), sum e index) of the Vis pair head: expected index and entropy.
+__global__ __launch_bounds__(256) void index_entropy_merge_kernel(const float* __restrict__ part, int ndc, int B, long hw,
+                                                                  float* __restrict__ o_index, float* __restrict__ o_entropy) {
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= (long)B * hw) return;
+    const int b = (int)(p / hw);
+    const long pf = p - (long)b * hw;
+    const float* pp = part + ((long)b * ndc * 4) * hw + pf;
+    float M = -__builtin_inff();
+    for (int c = 0; c < ndc; ++c) M = fmaxf(M, pp[(long)c * 4 * hw]);
+    float Z = 0.f, S = 0.f, SI = 0.f;
+    for (int c = 0; c < ndc; ++c) {
+        const float* q = pp + (long)c * 4 * hw;
+        if (q[0] == -__builtin_inff()) continue;
+        const float f = expf(q[0] - M);
+        Z = fmaf(q[hw], f, Z);
+        S += f * fmaf(q[0] - M, q[hw], q[2 * hw]);
+        SI = fmaf(q[3 * hw], f, SI);
+    }
+    const float inv = 1.0f / Z;
+    o_index[p] = SI * inv;
+    o_entropy[p] = logf(Z) - S * inv;
+}
+
 template <typename H, int CIN>
 static int c1_launch(const C1Args& a, long nblk, hipStream_t st) {
     auto kern = conv3d_c1_kernel<H, CIN>;
@@ -527,10 +570,12 @@ static int c1_dispatch(const void* in, int dtype, int in_cstride, int in_coff, c
                        const float* scale, const float* bias, const float* floor, const void* skip, int skip_cstride, int skip_coff, void* out,
                        int out_cstride, int out_coff, int out_dtype, int B, int D, int Hh, int W, int c_in,
                        int epi_flags, hipStream_t st, const float* depth, long depth_bstride, float* part, long part_floats,
-                       float* o_depth, float* o_conf) {
+                       float* o_depth, float* o_conf, float* o_index = nullptr, float* o_entropy = nullptr) {
     using namespace pscv;
     C1Args a;
     a.depth = depth; a.depth_bstride = depth_bstride; a.part = nullptr;
+    a.o_index = o_index; a.o_entropy = o_entropy;
+    const bool ie = o_index != nullptr;       // the Vis pair head: index + entropy (FUSE = 2)
     a.in = reinterpret_cast<const uint16_t*>(in);
     a.wpk = reinterpret_cast<const uint4*>(packed);
     a.skip = reinterpret_cast<const uint16_t*>(skip);
@@ -561,18 +606,28 @@ static int c1_dispatch(const void* in, int dtype, int in_cstride, int in_coff, c
     a.mg_th = fast_div_magic(a.nth); a.mg_tw = fast_div_magic(a.ntw); a.mg_dc = fast_div_magic(a.ndc);
     if (nblk <= 0 || nblk > 0x7fffffffL) { set_error("pscv_conv3d(c1): bad grid %ld", nblk); return -1; }
     if (part) {
-        if (!sweep || skip || out_dtype != PSCV_F32 || out_cstride != 1 || a.nb * C1_P > 256) return 1;
+        if (!sweep || skip || out_dtype != PSCV_F32 || out_cstride != 1 || (!ie && a.nb * C1_P > 256)) return 1;
         if ((long)B * a.ndc * 4 * Hh * W > part_floats) { set_error("pscv_prob_softargmin: workspace of %ld floats is too small", part_floats); return -1; }
         a.part = part;
     }
     if (sweep) {
         const size_t lds = (size_t)C1S_NSLOT * C1_PS * 16;
+        if (part && ie) {
+            if (dtype == PSCV_BF16) hipLaunchKernelGGL((conv3d_c1_sweep_kernel<bf16_t, 2>), dim3((unsigned)nblk), dim3(256), lds, st, a);
+            else hipLaunchKernelGGL((conv3d_c1_sweep_kernel<f16_t, 2>), dim3((unsigned)nblk), dim3(256), lds, st, a);
+            if (a.ndc > 1) {
+                const long npix = (long)B * Hh * W;
+                hipLaunchKernelGGL(index_entropy_merge_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, part, a.ndc, B, (long)Hh * W,
+                                   o_index, o_entropy);
+            }
+            return 0;
+        }
         if (part) {
-            if (dtype == PSCV_BF16) hipLaunchKernelGGL((conv3d_c1_sweep_kernel<bf16_t, true>), dim3((unsigned)nblk), dim3(256), lds, st, a);
-            else hipLaunchKernelGGL((conv3d_c1_sweep_kernel<f16_t, true>), dim3((unsigned)nblk), dim3(256), lds, st, a);
+            if (dtype == PSCV_BF16) hipLaunchKernelGGL((conv3d_c1_sweep_kernel<bf16_t, 1>), dim3((unsigned)nblk), dim3(256), lds, st, a);
+            else hipLaunchKernelGGL((conv3d_c1_sweep_kernel<f16_t, 1>), dim3((unsigned)nblk), dim3(256), lds, st, a);
         } else {
-            if (dtype == PSCV_BF16) hipLaunchKernelGGL((conv3d_c1_sweep_kernel<bf16_t, false>), dim3((unsigned)nblk), dim3(256), lds, st, a);
-            else hipLaunchKernelGGL((conv3d_c1_sweep_kernel<f16_t, false>), dim3((unsigned)nblk), dim3(256), lds, st, a);
+            if (dtype == PSCV_BF16) hipLaunchKernelGGL((conv3d_c1_sweep_kernel<bf16_t, 0>), dim3((unsigned)nblk), dim3(256), lds, st, a);
+            else hipLaunchKernelGGL((conv3d_c1_sweep_kernel<f16_t, 0>), dim3((unsigned)nblk), dim3(256), lds, st, a);
         }
         if (part) {
             const long npix = (long)B * Hh * W;
@@ -616,5 +671,22 @@ extern "C" int pscv_prob_softargmin(const void* in, int dtype, int in_cstride, i
     if (rc < 0) return rc;
     if (rc == 1) { set_error("pscv_prob_softargmin: this layer does not run the depth-sweep head (needs c_in = 8 and a depth axis of >= 3 six-plane blocks per chunk); use pscv_conv3d + pscv_softargmin"); return -3; }
     PSCV_CHECK_LAUNCH("pscv_prob_softargmin");
+    return 0;
+}
+
+extern "C" int pscv_head_index_entropy(const void* in, int dtype, int in_cstride, int in_coff, const uint16_t* packed, const float* scale,
+                                       const float* bias, const float* floor, int c_in, int epi_flags, float* logits, float* workspace,
+                                       long workspace_floats, float* out_index, float* out_entropy, int B, int D, int H, int W, void* stream) {
+    using namespace pscv;
+    PSCV_CHECK_ARG(in && packed && workspace && out_index && out_entropy, "pscv_head_index_entropy: null pointer argument");
+    PSCV_CHECK_ARG(B > 0 && D > 0 && H > 0 && W > 0, "pscv_head_index_entropy: bad sizes");
+    PSCV_CHECK_ARG(dtype == PSCV_BF16 || dtype == PSCV_F16, "pscv_head_index_entropy: storage dtype %d must be bf16 or fp16", dtype);
+    PSCV_CHECK_ARG(in_cstride % 8 == 0 && in_coff % 8 == 0 && in_coff + c_in <= in_cstride, "pscv_head_index_entropy: input channel slice must be 8-aligned");
+    const int rc = c1_dispatch(in, dtype, in_cstride, in_coff, packed, scale, bias, floor, nullptr, 0, 0, logits, 1, 0, PSCV_F32, B, D, H, W, c_in,
+                               epi_flags, reinterpret_cast<hipStream_t>(stream), nullptr, 0, workspace, workspace_floats, nullptr, nullptr,
+                               out_index, out_entropy);
+    if (rc < 0) return rc;
+    if (rc == 1) { set_error("pscv_head_index_entropy: this layer does not run the depth-sweep head (needs c_in = 8 and a depth axis of >= 3 six-plane blocks per chunk); use pscv_conv3d + pscv_softargmin"); return -3; }
+    PSCV_CHECK_LAUNCH("pscv_head_index_entropy");
     return 0;
 }

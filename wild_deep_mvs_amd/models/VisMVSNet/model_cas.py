@@ -174,18 +174,26 @@ class _Head(nn.Module):
         self.final_conv = nn.Conv3d(8, 1, 3, 1, 1, bias=False)
         self._hl, self._hk = None, None
 
+    def head_layer(self, dtype):
+        w = self.final_conv.weight
+        key = (ops.weights_epoch(), dtype, w.data_ptr(), w._version)
+        if self._hl is None or key != self._hk:
+            self._hl, self._hk = ops.Conv3dLayer.build(w, kind=L.CONV_S1, device=w.device, dtype=dtype), key
+        return self._hl
+
     def head(self, x: torch.Tensor) -> torch.Tensor:
         """[n,d,h,w,8] -> fp32 scores [n,d,h,w]."""
-        w = self.final_conv.weight
-        key = (ops.weights_epoch(), x.dtype, w.data_ptr(), w._version)
-        if self._hl is None or key != self._hk:
-            self._hl, self._hk = ops.Conv3dLayer.build(w, kind=L.CONV_S1, device=w.device, dtype=x.dtype), key
-        return ops.conv3d(x, self._hl, out_dtype=torch.float32).squeeze(-1)
+        return ops.conv3d(x, self.head_layer(x.dtype), out_dtype=torch.float32).squeeze(-1)
 
 
 class RegPair(_Head):           # reference model_cas.py:51-59
     def forward(self, x):
         return self.head(x)
+
+    def head_index_entropy(self, x, index, entropy, want_scores=False):
+        """The head fused with soft_argmin + entropy (``ops.head_index_entropy``); None when this size takes the two-launch path."""
+        self.head_layer(x.dtype)
+        return ops.head_index_entropy(x, self._hl, index, entropy, want_scores=want_scores)
 
 
 class RegFuse(_RegUNet):        # reference model_cas.py:62-74
@@ -196,6 +204,7 @@ class RegFuse(_RegUNet):        # reference model_cas.py:62-74
         self._hl, self._hk = None, None
 
     head = _Head.head
+    head_layer = _Head.head_layer
 
     def forward(self, x):
         return self.head(self.run_unet(x))
@@ -252,6 +261,9 @@ class SingleStage(nn.Module):
         # the planes it owns plus a 16-plane halo per side (the pair U-Net + head and the fuse U-Net + head each reach 8
         # planes), and the softmax over D is merged from per-rank partials.  The reference has no counterpart.
         self.depth_group = None
+        # pair branch: RegPair's head, soft_argmin and the entropy as one launch (pscv_head_index_entropy); False = the head
+        # and pscv_softargmin as two launches with the fp32 score volume in between (the entropy then keeps the reference's clamp)
+        self.fused_pair_head = True
 
     def build_cost_volume(self, ref, ref_cam, srcs, srcs_cam, depth_num, depth_start, depth_interval, s_scale):
         """Pair-wise group-correlation volumes of ALL source views in one fused launch: [n_src,n,d,h,w,8]
@@ -445,9 +457,12 @@ class SingleStage(nn.Module):
         for g0 in range(0, n_s, group):
             g1 = min(n_s, g0 + group)
             interm_all = self.reg(costs[g0:g1].view(((g1 - g0) * n_b,) + tuple(costs.shape[2:])))
-            score_all = self.reg_pair(interm_all)                                      # fp32 [views * n, d, h, w]
-            ops.softargmin(score_all, None, want_index=True, want_entropy=True,
-                           into={"index": index_all[g0 * n_b:g1 * n_b], "entropy": entropy_all[g0 * n_b:g1 * n_b]})
+            idx_g, ent_g = index_all[g0 * n_b:g1 * n_b], entropy_all[g0 * n_b:g1 * n_b]
+            # head + expected index + entropy in ONE pass over the pair volume; the fp32 scores exist only for `taps`
+            score_all = self.reg_pair.head_index_entropy(interm_all, idx_g, ent_g, want_scores=taps is not None) if self.fused_pair_head else None
+            if score_all is None:
+                score_all = self.reg_pair(interm_all)                                  # fp32 [views * n, d, h, w]
+                ops.softargmin(score_all, None, want_index=True, want_entropy=True, into={"index": idx_g, "entropy": ent_g})
             for i in range(g0, g1):
                 sl = slice((i - g0) * n_b, (i - g0 + 1) * n_b)
                 interms.append(interm_all[sl])

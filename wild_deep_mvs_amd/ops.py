@@ -766,6 +766,34 @@ def prob_softargmin(x: torch.Tensor, layer: "Conv3dLayer", depth: torch.Tensor, 
     return out
 
 
+def head_index_entropy(x: torch.Tensor, layer: "Conv3dLayer", index: torch.Tensor, entropy: torch.Tensor, *, want_scores: bool = False):
+    """Fused head of a Vis pair branch (pscv_head_index_entropy): x [B,D,h,w,8] 16-bit -> the 1-channel head ``layer`` (kind S1C1)
+    -> expected plane index and entropy written into the caller's fp32 [B,h,w] tensors; the fp32 scores only with
+    ``want_scores``.  Returns None when the layer / size does not run the depth-sweep head (call ``conv3d`` + ``softargmin``
+    then), else the scores or True."""
+    _dev(x, layer.packed, index, entropy)
+    if layer.kind != L.CONV_S1C1 or layer.c_in != 8 or x.dtype != layer.dtype or x.dim() != 5:
+        return None
+    B, D, H, W, cs = x.shape
+    for t_ in (index, entropy):
+        if t_.dtype != torch.float32 or tuple(t_.shape) != (B, H, W) or not t_.is_contiguous():
+            raise ValueError("pscv.head_index_entropy: index / entropy must be contiguous fp32 [B,h,w] tensors")
+    n = int(L.lib().pscv_prob_softargmin_workspace(B, D, H, W))
+    ws = _tail_ws.get(x.device)
+    if ws is None or ws.numel() < n:
+        ws = torch.empty(n, dtype=torch.float32, device=x.device)
+        _tail_ws[x.device] = ws
+    scores = torch.empty((B, D, H, W), dtype=torch.float32, device=x.device) if want_scores else None
+    rc = _launch("head_index_entropy", lambda: L.lib().pscv_head_index_entropy(
+        _p(x), _dt(x), cs, 0, _p(layer.packed), _p(layer.scale), _p(layer.bias), _p(layer.floor), layer.c_in, layer.epi,
+        _p(scores), _p(ws), ws.numel(), _p(index), _p(entropy), B, D, H, W, _stream()),
+        cost=lambda: (B * D * H * W * (16 + (4 if want_scores else 0)), 2.0 * B * D * H * W * 27 * 8))
+    if rc == -3:
+        return None
+    L.check(rc, "pscv_head_index_entropy")
+    return scores if want_scores else True
+
+
 def softargmin_window(logits: torch.Tensor, stats: torch.Tensor, *, window: float, index_offset: int) -> torch.Tensor:
     """One depth shard's part of the +-window probability under globally merged softmax statistics: logits fp32 [B,D,h,w] (this
     shard's planes), stats fp32 [B,3,h,w] = (max, sum exp, expected index) -> fp32 [B,h,w] (pscv_softargmin_window)."""
