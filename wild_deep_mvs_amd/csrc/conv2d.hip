@@ -193,6 +193,67 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const Conv2dArgs a) {
         }
     }
 
+    // ---- epilogue, 16-bit output with full channel tiles: the packed values of an M-tile (16 pixels x NT x 32 contiguous bytes
+    // each) go through a per-wave LDS row (the brick is dead by now) and leave as 16-byte stores, a lane covering 8 consecutive
+    // channels of a pixel; a residual input comes in the same way.  8-byte stores per lane and channel tile are store-ISSUE bound
+    // (~7 B/clk/CU): the layers that write more than they read (3 -> 64, the stride-2 and 1x1 layers, the deconv parity
+    // sub-convs) spent most of their time there.  Same arithmetic, same bits. ----
+    // (measured per layer: 3 -> 64 118.6 -> 90.1 us at 1200 x 1600, 16 -> 32 k3 132 -> 108, 16 -> 32 k1 94 -> 72, the 64 -> 32 parity
+    // sub-convs 54 -> 43; the layers with long reductions -- 128 -> 128 k3: 36 k-steps -- are MFMA / weight-fetch bound and lose
+    // ~8 % to the extra barrier, so they keep the direct stores)
+    constexpr bool WIDE = NSTEPS <= 16;
+    if (WIDE && !a.out_f32 && !((a.out_cs | a.out_co) & 7) && (nt0 + NT) * 16 <= a.cout && (!a.skip || !((a.skip_cs | a.skip_co) & 7))) {
+        constexpr int OPITCH = NT * 32 + 16;                 // (+16: conflict-free 8-byte writes)
+        constexpr int NPC = 32 * NT, NPK = (NPC + 63) / 64;  // 16-byte pieces of an M-tile / per lane
+        static_assert(!WIDE || 4 * 16 * OPITCH <= BH * BWL * VS + 64, "output staging rows must fit the brick's LDS");
+        __syncthreads();                                     // every wave is done with the brick
+        unsigned char* const so = smem + wave * (16 * OPITCH);
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            const int mt = wave * MB + i;
+            const int oy = oy0 + (mt >> 1), oxb = ox0 + (mt & 1) * 16;
+            const unsigned long rowpix = ((unsigned long)b * a.Hof + (oy * a.oys + a.oyo)) * a.Wof;
+            if (a.skip) {
+#pragma unroll
+                for (int k = 0; k < NPK; ++k) {
+                    const int q = lane + 64 * k, p = q / (NT * 2), c = q - p * (NT * 2);
+                    const int ox = oxb + p;
+                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                    if (q < NPC && oy < a.Ho && ox < a.Wo)
+                        v = *reinterpret_cast<const uint4*>(a.skip + (rowpix + (ox * a.oxs + a.oxo)) * a.skip_cs + a.skip_co + nt0 * 16 + c * 8);
+                    if (q < NPC) *reinterpret_cast<uint4*>(so + p * OPITCH + c * 16) = v;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+#pragma unroll
+            for (int m = 0; m < NT; ++m) {
+                float v[4], y[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = fmaf(acc[i][m][k], sc[m][k], bi[m][k]);
+                unsigned char* const slot = so + n * OPITCH + (m * 16 + g * 4) * 2;
+                if (a.skip) {
+                    const uint2 sv = *reinterpret_cast<const uint2*>(slot);
+                    v[0] += Half16<H>::lo(sv.x); v[1] += Half16<H>::hi(sv.x); v[2] += Half16<H>::lo(sv.y); v[3] += Half16<H>::hi(sv.y);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) y[k] = fmaxf(v[k], v[k] * a.neg_slope);
+                *reinterpret_cast<uint2*>(slot) = make_uint2(Half16<H>::pack(y[0], y[1]), Half16<H>::pack(y[2], y[3]));
+            }
+            __builtin_amdgcn_wave_barrier();                 // (LDS executes a wave's operations in order)
+            if (oy < a.Ho) {
+#pragma unroll
+                for (int k = 0; k < NPK; ++k) {
+                    const int q = lane + 64 * k, p = q / (NT * 2), c = q - p * (NT * 2);
+                    const int ox = oxb + p;
+                    if (q < NPC && ox < a.Wo)
+                        *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(a.out) + (rowpix + (ox * a.oxs + a.oxo)) * a.out_cs + a.out_co + nt0 * 16 + c * 8) =
+                            *reinterpret_cast<const uint4*>(so + p * OPITCH + c * 16);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
     // ---- epilogue: lane (n, g) owns channels 16 m + 4 g .. + 3 of pixel n ----
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
