@@ -208,6 +208,18 @@ int pscv_conv3d_cat2(const void* in_a, int a_cstride, int a_coff, const void* in
                      int W, int c_out, int epi_flags, void* stream);
 
 /*
+ * Input side of the 2-D extractors: fp32 NCHW images -> [B,H,W,8] 16-bit channels-last pixels (channels C..7 zero: the first
+ * layer's padded input), and one level of CVP's image pyramid (FeaturePyramid.forward, models/CVP_MVSNet/models/net.py:34-47:
+ * F.interpolate(img, scale_factor=0.5, mode='bilinear') -- with align_corners = False the 2 x 2 mean, computed in ATen's operation
+ * order: same bits).  One pass over the image writes any of
+ *   out_cl8  [B,H,W,8] 16-bit        the image itself in the extractor layout            (may be null)
+ *   half_img [B,C,H/2,W/2] fp32      the half-resolution image (input of the next level)  (may be null)
+ *   half_cl8 [B,H/2,W/2,8] 16-bit    the half-resolution image in the extractor layout    (may be null)
+ * img device fp32 [B,C,H,W] contiguous, C <= 8; the half-resolution outputs need an even W.
+ */
+int pscv_image_prep(const float* img, int B, int C, int H, int W, int dtype, void* out_cl8, float* half_img, void* half_cl8, void* stream);
+
+/*
  * Vis-MVSNet's UncertNet (models/VisMVSNet/model_cas.py:77-98) in eval mode, one launch for the entropy maps of all pairs:
  *   t1 = relu(s1 * conv3x3(x; w1) + b1)   1 -> 8      (BatchNorm folded: s = gamma / sqrt(var + eps), b = beta - mean * s)
  *   t2 = relu(s2 * conv3x3(t1; w2) + b2) + x          (x broadcast over the 8 channels, model_cas.py:95)

@@ -131,3 +131,32 @@ def test_weights_in_lds_kernel_with_residual_equals_streaming_kernel(env, ci, co
                  + (bn[1] - bn[2] * scale).view(1, -1, 1, 1) + skip_wide[..., 8:].float().cpu().permute(0, 3, 1, 2))
     ulp = 2 ** -8 if dtype == torch.bfloat16 else 2 ** -11
     check_close(f"residual conv2d {ci}->{co} {dtype}", res[2][1].float().cpu().permute(0, 3, 1, 2), ref, max_abs=2 * ulp * float(ref.abs().max()) + 1e-5, rel_l2=2 * ulp)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 3, 64, 80), (1, 3, 37, 50), (3, 3, 2, 2), (1, 3, 75, 100)])
+def test_image_prep_equals_interpolate_and_conversion(env, shape, dtype):
+    """pscv_image_prep: the extractor input layout (3 channels + 5 zero channels, 16-bit) and the half-scale bilinear level of
+    CVP's image pyramid (net.py:44) have the bits of F.interpolate + the torch conversion; ops.image_pyramid_cl8 chains the
+    levels (odd widths take F.interpolate for that step)."""
+    L, ops = env
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(H * W)
+    x = (torch.randn(shape, generator=g) * 1.5).cuda()
+    want0 = torch.zeros(B, H, W, 8, dtype=dtype, device="cuda")
+    want0[..., :C] = x.permute(0, 2, 3, 1)
+    assert torch.equal(ops.image_to_channels_last8(x, dtype), want0)
+    levels = ops.image_pyramid_cl8(x, 4 if min(H, W) >= 16 else 2, dtype)
+    img = x
+    for l, got in enumerate(levels):
+        if l:
+            img = F.interpolate(img, scale_factor=0.5, mode="bilinear", align_corners=None)
+        want = torch.zeros(img.shape[0], img.shape[2], img.shape[3], 8, dtype=dtype, device="cuda")
+        want[..., :C] = img.permute(0, 2, 3, 1)
+        assert got.shape == want.shape and torch.equal(got, want), f"level {l}"
+    # slices of one batch tensor are batched without a copy
+    imgs = torch.randn(1, 4, 3, 8, 10, device="cuda")
+    v = ops.batch_views([imgs[:, i] for i in range(4)])
+    assert v.data_ptr() == imgs.data_ptr() and torch.equal(v, torch.cat([imgs[:, i] for i in range(4)], 0))
+    two = torch.randn(2, 4, 3, 8, 10, device="cuda")
+    assert torch.equal(ops.batch_views([two[:, i] for i in range(4)]), torch.cat([two[:, i] for i in range(4)], 0))

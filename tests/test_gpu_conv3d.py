@@ -556,3 +556,31 @@ def test_two_tensor_input_rejects_other_layers(env):
     lay = ops.Conv3dLayer.build(torch.zeros(8, 16, 3, 3, 3), kind=L.CONV_S1P8, device="cuda", dtype=torch.float16)
     with pytest.raises(ValueError):
         ops.conv3d(x, lay, x2=x[:, :2])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cout,shape", [(64, (6, 10, 21)), (32, (9, 17, 40)), (64, (4, 8, 16))])
+def test_tall_64_channel_tiles_equal_the_4x4_tiles(env, cout, shape, dtype):
+    """64-channel stride-1 layers on 4x8x16 tiles (conv_tall64 = 2: at any size; CVP's 64 -> 64 / 64 -> 32 at full size get them
+    by default) against the 4x4x16 tiles (0): same reduction order per output, same bits; with BN + ReLU + skip, ragged sizes."""
+    L, ops = env
+    D, H, W = shape
+    g = torch.Generator().manual_seed(cout + D)
+    x = bf16_round(torch.randn(2, D, H, W, 64, generator=g)).cuda().to(dtype)
+    sk = bf16_round(torch.randn(2, D, H, W, cout, generator=g)).cuda().to(dtype)
+    w = bf16_round(torch.randn(cout, 64, 3, 3, 3, generator=g) / np.sqrt(27 * 64))
+    bn = (torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1, torch.randn(cout, generator=g) * 0.1, torch.rand(cout, generator=g) + 0.5)
+    layer = ops.Conv3dLayer.build(w, kind=L.CONV_S1, device="cuda", dtype=dtype, bn=bn, relu=True)
+    res = {}
+    L.set_tuning("conv_small_tiles", 0)
+    try:
+        for tall in (0, 2):
+            L.set_tuning("conv_tall64", tall)
+            res[tall] = (ops.conv3d(x, layer, skip=sk), ops.conv3d(x, layer, out_dtype=torch.float32))
+    finally:
+        L.set_tuning("conv_tall64", 1)
+        L.set_tuning("conv_small_tiles", 1)
+    assert torch.equal(res[0][0], res[2][0]) and torch.equal(res[0][1], res[2][1])
+    scale = bn[0] / torch.sqrt(bn[3] + 1e-5)
+    ref = F.relu(F.conv3d(x.float().cpu().permute(0, 4, 1, 2, 3), w, padding=1) * scale.view(1, -1, 1, 1, 1) + (bn[1] - bn[2] * scale).view(1, -1, 1, 1, 1))
+    check_close(f"tall tiles 64->{cout} {dtype}", res[2][1].permute(0, 4, 1, 2, 3).cpu(), ref, max_abs=3e-3, rel_l2=2e-4)

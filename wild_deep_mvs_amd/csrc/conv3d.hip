@@ -40,6 +40,7 @@ template <> struct Mfma<f16_t> {
 
 PSCV_PROF_BUFFER(conv)
 Knob g_conv_small_tiles = {1, KNOB_CONV_SMALL_TILES};   // pscv_set_tuning("conv_small_tiles", 0) forces the large-tile variant
+Knob g_conv_tall64 = {1, KNOB_SPARE2};                  // pscv_set_tuning("conv_tall64", 0): 64-channel stride-1 layers back on 4x4x16 tiles; 2: 4x8x16 at any size
 
 struct ConvArgs {
     const uint16_t* in;
@@ -572,7 +573,16 @@ static int launch_kind(ConvArgs& a, int kind, hipStream_t st) {
     //  re-read the 5x5x33 input brick once per output tile)
     const bool small = big < 1024 && g_conv_small_tiles && kind != PSCV_CONV_S2;
     switch (kind) {
-        case PSCV_CONV_S1: return small ? launch_conv<H, CIN, 1, PSCV_CONV_S1, 1, 4>(a, NT, st) : launch_conv<H, CIN, NT, PSCV_CONV_S1, 4, 4>(a, 1, st);
+        case PSCV_CONV_S1:
+            if (small) return launch_conv<H, CIN, 1, PSCV_CONV_S1, 1, 4>(a, NT, st);
+            if constexpr (CIN == 64) {
+                // 64 input channels (CVP's 64 -> 64 / 64 -> 32 layers): a wave fetches NT KB of A fragments per k-step for MB x NT
+                // MFMAs, and at MB = 4 (4x4x16 tiles) that is 64 B/clk per CU -- the whole vector-memory path, 25 % of the MFMA
+                // peak measured.  4x8x16 tiles (MB = 8, 155 KB brick: one workgroup per CU) halve the fetch per MFMA.
+                if (g_conv_tall64 == 2 || (g_conv_tall64 && (long)a.B * ceil_div(rd, 4) * ceil_div(rh, 8) * ceil_div(rw, 16) >= 256))
+                    return launch_conv<H, CIN, NT, PSCV_CONV_S1, 4, 8>(a, 1, st);
+            }
+            return launch_conv<H, CIN, NT, PSCV_CONV_S1, 4, 4>(a, 1, st);
         case PSCV_CONV_S2: return launch_conv<H, CIN, NT, PSCV_CONV_S2, 2, 2>(a, 1, st);
         case PSCV_CONV_T2: return small ? launch_conv<H, CIN, 1, PSCV_CONV_T2, 1, 4>(a, NT, st) : launch_conv<H, CIN, NT, PSCV_CONV_T2, 2, 4>(a, 1, st);
     }

@@ -48,19 +48,16 @@ class FeaturePyramid(nn.Module):
 
     def forward_engine(self, img, scales: int, dtype: torch.dtype):
         """[B,3,H,W] on the GPU -> list of channels-last feature maps [B,H_l,W_l,16] in ``dtype``, finest first
-        (the image pyramid itself stays ``F.interpolate``: plumbing)."""
+        (image pyramid and input layout: ``ops.image_pyramid_cl8``)."""
         layers = self.engine_layers(dtype)
 
-        def tower(x):
-            y = ops.image_to_channels_last8(x, dtype)
+        def tower(y):
             for layer in layers:
                 y = ops.conv2d(y, layer)
             return y
-        levels = [tower(img)]
-        for _ in range(scales - 1):
-            img = F.interpolate(img, scale_factor=0.5, mode='bilinear', align_corners=None)
-            levels.append(tower(img))
-        return levels
+        # image pyramid (F.interpolate(img, scale_factor=0.5, mode='bilinear') between the levels, net.py:44) + the towers' 8-channel
+        # 16-bit input layout: one launch per level (ops.image_pyramid_cl8, same bits as F.interpolate + the conversion)
+        return [tower(y) for y in ops.image_pyramid_cl8(img, scales, dtype)]
 
 
 class CostRegNet(nn.Module):
@@ -190,7 +187,7 @@ class network(nn.Module):
             pyramid = (lambda x: self.featurePyramid.forward_engine(x, nscale, dt)) if engine else (lambda x: self.featurePyramid(x, nscale))
             if all(s.shape == ref_img.shape for s in src_imgs):
                 # all views through the pyramid tower as one batch (same result as the per-view loop)
-                levels = [torch.chunk(f, nsrc + 1, 0) for f in pyramid(torch.cat([ref_img] + list(src_imgs), 0))]
+                levels = [torch.chunk(f, nsrc + 1, 0) for f in pyramid(ops.batch_views([ref_img] + list(src_imgs)))]
                 ref_pyr = [lv[0] for lv in levels]
                 src_pyrs = [[lv[i + 1] for lv in levels] for i in range(nsrc)]
             else:

@@ -284,7 +284,7 @@ class MVSNet(ReplayHooks, nn.Module):
         imgs = list(imgs)
         if self.feature_engine == "pscv":
             if len({tuple(i.shape) for i in imgs}) == 1:
-                f = self.feature.forward_engine(torch.cat(imgs, 0), self.storage_dtype)
+                f = self.feature.forward_engine(ops.batch_views(imgs), self.storage_dtype)
                 return list(torch.chunk(f, len(imgs), 0))
             return [self.feature.forward_engine(img, self.storage_dtype) for img in imgs]
         return [ops.to_channels_last(f, self.storage_dtype) for f in self.extract_features(imgs)]

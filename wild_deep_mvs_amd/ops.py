@@ -11,7 +11,7 @@ from __future__ import annotations
 import ctypes as C
 import weakref
 from dataclasses import dataclass
-from typing import Optional, Sequence
+from typing import List, Optional, Sequence
 
 import numpy as np
 import torch
@@ -176,6 +176,15 @@ def proj_cams_device(proj: torch.Tensor, reference_frame: int = 0) -> torch.Tens
     rc = _launch("proj_cams", lambda: L.lib().pscv_proj_cams(_p(proj), B, V, int(reference_frame), _p(cams), _stream()))
     L.check(rc, "pscv_proj_cams")
     return cams
+
+
+def batch_views(ts: Sequence[torch.Tensor]) -> torch.Tensor:
+    """``torch.cat(ts, 0)`` -- as a VIEW when the tensors are back-to-back slices of one buffer (the views of an image batch
+    [1,V,3,H,W] picked with ``imgs[:, i]``): the extractors batch all views without a copy."""
+    v = _consecutive_views(ts)
+    if v is None:
+        return torch.cat(list(ts), 0)
+    return v.reshape((len(ts) * ts[0].shape[0],) + tuple(ts[0].shape[1:]))
 
 
 def _consecutive_views(ts: Sequence[torch.Tensor]) -> Optional[torch.Tensor]:
@@ -356,11 +365,44 @@ def deconv2d_parity_weights(weight: torch.Tensor):
 
 
 def image_to_channels_last8(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
-    """[B,3,H,W] image -> [B,H,W,8] in the storage dtype, channels 3-7 zero (the first layer's padded input)."""
+    """[B,3,H,W] image -> [B,H,W,8] in the storage dtype, channels 3-7 zero (the first layer's padded input): one HIP launch
+    (pscv_image_prep) for fp32 images on the GPU, torch ops otherwise."""
     B, c, H, W = x.shape
+    if x.is_cuda and x.dtype == torch.float32 and c <= 8 and B <= 65535:
+        x = x.contiguous()
+        out = torch.empty((B, H, W, 8), dtype=dtype, device=x.device)
+        rc = _launch("image_prep", lambda: L.lib().pscv_image_prep(_p(x), B, c, H, W, _dt(out), _p(out), None, None, _stream()))
+        L.check(rc, "pscv_image_prep")
+        return out
     out = torch.zeros((B, H, W, 8), dtype=dtype, device=x.device)
     out[..., :c] = x.permute(0, 2, 3, 1)
     return out
+
+
+def image_pyramid_cl8(x: torch.Tensor, scales: int, dtype: torch.dtype) -> List[torch.Tensor]:
+    """CVP's image pyramid in the extractor layout, finest first: level l+1 = F.interpolate(level l, scale_factor=0.5,
+    mode='bilinear') (net.py:34-47), every level as [B,H_l,W_l,8] 16-bit pixels.  One launch per level reads the fp32 image once
+    and writes its half-resolution fp32 image and that one's 8-channel form (pscv_image_prep); odd widths fall back to
+    F.interpolate for that step."""
+    B, c, H, W = x.shape
+    if not (x.is_cuda and x.dtype == torch.float32 and c <= 8 and B <= 65535):
+        raise TypeError("pscv.image_pyramid_cl8: fp32 [B,C<=8,H,W] images on the GPU expected")
+    x = x.contiguous()
+    levels = [image_to_channels_last8(x, dtype)]
+    for l in range(1, scales):
+        B, c, H, W = x.shape
+        if W % 2 or H < 2:
+            x = torch.nn.functional.interpolate(x, scale_factor=0.5, mode="bilinear", align_corners=None)
+            levels.append(image_to_channels_last8(x, dtype))
+            continue
+        last = l == scales - 1
+        half = None if last else torch.empty((B, c, H // 2, W // 2), dtype=torch.float32, device=x.device)
+        cl = torch.empty((B, H // 2, W // 2, 8), dtype=dtype, device=x.device)
+        rc = _launch("image_prep", lambda: L.lib().pscv_image_prep(_p(x), B, c, H, W, _dt(cl), None, _p(half), _p(cl), _stream()))
+        L.check(rc, "pscv_image_prep")
+        levels.append(cl)
+        x = half
+    return levels
 
 
 # --------------------------------------------------------------------------------------------
