@@ -232,6 +232,21 @@ int pscv_image_prep(const float* img, int B, int C, int H, int W, int dtype, voi
 int pscv_uncert_net(const float* entropy, const float* params, float* out, int N, int H, int W, void* stream);
 
 /*
+ * A residual block of two 8 -> 8 stride-1 3x3x3 convolutions in ONE depth sweep (Vis-MVSNet's 3-D U-Net: BasicBlock, models/
+ * VisMVSNet/nn_utils.py:27-37 -- conv1 + bn1 + relu, conv2 + bn2, + identity, relu):
+ *   t   = epi1(scale1 * conv(in; packed1) + bias1)                       kept in LDS as 16-bit planes, never written
+ *   out = epi2(scale2 * conv(t; packed2) + bias2 [+ in if residual])
+ * Same values as pscv_conv3d(layer 1) followed by pscv_conv3d(layer 2, skip = in): t is rounded to the storage format exactly
+ * as the stored volume was, zero outside the volume (layer 2's padding).  packed1 / packed2: PSCV_CONV_S1P8 packing of
+ * [8, 8, 3, 3, 3] weights; scale / bias / floor [8] or null; epi flags as pscv_conv3d; out 16-bit (the storage dtype), must not
+ * alias in.
+ */
+int pscv_conv3d_block8(const void* in, int dtype, int in_cstride, int in_coff, const uint16_t* packed1, const float* scale1,
+                       const float* bias1, const float* floor1, int epi1, const uint16_t* packed2, const float* scale2,
+                       const float* bias2, const float* floor2, int epi2, int residual, void* out, int out_cstride, int out_coff,
+                       int B, int D, int H, int W, void* stream);
+
+/*
  * Visibility-weighted fusion of per-pair volumes (Vis-MVSNet, mode 'soft'), one pass:
  *     out = sum_v exp(-uncert_v) * interm_v / sum_v exp(-uncert_v)
  * Replaces the accumulate / divide sequence of models/VisMVSNet/model_cas.py:354-357,385-386.

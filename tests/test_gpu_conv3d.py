@@ -584,3 +584,39 @@ def test_tall_64_channel_tiles_equal_the_4x4_tiles(env, cout, shape, dtype):
     scale = bn[0] / torch.sqrt(bn[3] + 1e-5)
     ref = F.relu(F.conv3d(x.float().cpu().permute(0, 4, 1, 2, 3), w, padding=1) * scale.view(1, -1, 1, 1, 1) + (bn[1] - bn[2] * scale).view(1, -1, 1, 1, 1))
     check_close(f"tall tiles 64->{cout} {dtype}", res[2][1].permute(0, 4, 1, 2, 3).cpu(), ref, max_abs=3e-3, rel_l2=2e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape,slots", [((16, 16, 28), 0), ((13, 11, 21), 0), ((2, 3, 5), 0), ((40, 9, 37), 0), ((37, 20, 33), 4096),
+                                         ((9, 64, 70), 0), ((1, 8, 14), 0)])
+def test_fused_residual_block_equals_the_two_launches(env, shape, slots, dtype):
+    """pscv_conv3d_block8 (BasicBlock of the Vis 3-D U-Net, nn_utils.py:27-37, in one depth sweep with the intermediate volume
+    in LDS) against conv3d(layer 1) + conv3d(layer 2, skip = x): same bits.  Ragged sizes (tiles of 8 x 14 cut on both axes, odd
+    depth), many depth chunks (block8_slots: halo planes recomputed at every seam), channel slices in and out."""
+    L, ops = env
+    D, H, W = shape
+    g = torch.Generator().manual_seed(D * 100 + W)
+    B = 2
+    xw = torch.full((B, D, H, W, 16), float("nan"), dtype=dtype, device="cuda")
+    x = bf16_round(torch.randn(B, D, H, W, 8, generator=g)).cuda().to(dtype)
+    xw[..., 8:] = x
+    mk = lambda relu, relu_post: ops.Conv3dLayer.build(
+        bf16_round(torch.randn(8, 8, 3, 3, 3, generator=g) / np.sqrt(27 * 8)), kind=L.CONV_S1P8, device="cuda", dtype=dtype,
+        bn=(torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g) * 0.1, torch.randn(8, generator=g) * 0.1, torch.rand(8, generator=g) + 0.5),
+        relu=relu, relu_post=relu_post)
+    l1, l2 = mk(True, False), mk(False, True)
+    want = ops.conv3d(ops.conv3d(x, l1), l2, skip=x)
+    L.set_tuning("block8_slots", slots)
+    try:
+        got = ops.conv3d_block8(x, l1, l2, residual=True)
+        out = torch.full((B, D, H, W, 12), -5.0, dtype=dtype, device="cuda")
+        ops.conv3d_block8(xw, l1, l2, residual=True, in_coff=8, out=out, out_coff=4)
+        plain = ops.conv3d_block8(x, l1, l2, residual=False)
+    finally:
+        L.set_tuning("block8_slots", 0)
+    assert got is not None and torch.equal(got, want)
+    assert torch.equal(out[..., 4:], want) and bool((out[..., :4] == -5.0).all())
+    assert torch.equal(plain, ops.conv3d(ops.conv3d(x, l1), l2))
+    # layers outside the depth-sweep family are declined
+    l16 = ops.Conv3dLayer.build(torch.zeros(16, 8, 3, 3, 3), kind=L.CONV_S2, device="cuda", dtype=dtype)
+    assert ops.conv3d_block8(x, l1, l16) is None

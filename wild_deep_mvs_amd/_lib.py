@@ -33,7 +33,7 @@ EXPORTS = ("pscv_last_error", "pscv_abi_version", "pscv_set_tuning", "pscv_proj_
            "pscv_bn_act", "pscv_bn_bwd_reduce", "pscv_bn_bwd_apply", "pscv_softargmin_bwd", "pscv_conv3d_wgrad_workspace",
            "pscv_conv3d_wgrad", "pscv_warp_cost_bwd", "pscv_cvp_depth_hypos", "pscv_relu_bwd", "pscv_fuse_pairs_bwd", "pscv_pack_conv3d_weights_device", "pscv_conv2d_ex", "pscv_variance_finish", "pscv_softargmin_window",
            "pscv_photo_warp", "pscv_photo_warp_bwd", "pscv_ssim", "pscv_ssim_bwd", "pscv_bn_finalize", "pscv_bn_bwd_coeffs", "pscv_cvp_cams", "pscv_homography_warp", "pscv_prob_softargmin", "pscv_prob_softargmin_workspace",
-           "pscv_set_tuning_thread", "pscv_get_tuning", "pscv_conv3d_cat2", "pscv_uncert_net", "pscv_head_index_entropy", "pscv_image_prep")
+           "pscv_set_tuning_thread", "pscv_get_tuning", "pscv_conv3d_cat2", "pscv_uncert_net", "pscv_head_index_entropy", "pscv_image_prep", "pscv_conv3d_block8")
 
 
 class PscvMissingError(RuntimeError):
@@ -120,6 +120,8 @@ def _declare(lib):
     lib.pscv_head_index_entropy.argtypes = [vp, i, i, i, vp, vp, vp, vp, i, i, vp, vp, C.c_long, vp, vp, i, i, i, i, vp]
     lib.pscv_image_prep.restype = i
     lib.pscv_image_prep.argtypes = [vp, i, i, i, i, i, vp, vp, vp, vp]
+    lib.pscv_conv3d_block8.restype = i
+    lib.pscv_conv3d_block8.argtypes = [vp, i, i, i, vp, vp, vp, vp, i, vp, vp, vp, vp, i, i, vp, i, i, i, i, i, i, vp]
     lib.pscv_softargmin.restype = i
     lib.pscv_softargmin.argtypes = [vp, i, vp, l, i, vp, vp, vp, vp, vp, vp, i, f, i, i, i, i, i, vp]
     lib.pscv_train_workspace_floats.restype = l

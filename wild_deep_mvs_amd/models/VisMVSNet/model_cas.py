@@ -138,6 +138,11 @@ class _RegUNet(nn.Module):
             self._key = key
         return self._lay
 
+    # True: enc0's two convolutions as ONE depth sweep with the intermediate volume in LDS (pscv_conv3d_block8, same bits).  Built
+    # and measured in round 3: 147-157 us against 126 us for the two launches at 16 x 576 x 800 (its fetch / MFMA / epilogue phases
+    # run back to back inside a workgroup and the halo recompute costs 29 % more MFMAs), so the two launches stay the default.
+    FUSED_BLOCK = False
+
     def run_unet(self, x: torch.Tensor) -> torch.Tensor:
         """x [n,d,h,w,8] 16-bit channels-last -> [n,d,h,w,8]."""
         if self.training:
@@ -147,8 +152,12 @@ class _RegUNet(nn.Module):
         if d % 2 or h % 2 or w % 2:
             raise ValueError(f"Vis U-Net needs even d,h,w (got {d},{h},{w}), as in the reference")
         ly = self._layers(x.dtype)
-        t = ops.conv3d(x, ly["e0c1"])
-        e0 = ops.conv3d(t, ly["e0c2"], skip=x)
+        # the full-resolution BasicBlock (conv1 + bn + relu, conv2 + bn, + x, relu) as ONE depth sweep: its intermediate volume
+        # stays in LDS (same values); layers that are not on the depth-sweep kernels run as two launches
+        e0 = ops.conv3d_block8(x, ly["e0c1"], ly["e0c2"], residual=True) if self.FUSED_BLOCK else None
+        if e0 is None:
+            t = ops.conv3d(x, ly["e0c1"])
+            e0 = ops.conv3d(t, ly["e0c2"], skip=x)
         t1ds = ops.conv3d(e0, ly["e1c1ds"])                                       # [relu(bn1(conv1)) | bn_ds(shortcut)]
         e1 = ops.conv3d(t1ds, ly["e1c2"], skip=t1ds, skip_coff=16)
         up = ops.conv3d(e1, ly["dec"])

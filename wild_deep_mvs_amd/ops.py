@@ -703,6 +703,30 @@ def conv3d(x: torch.Tensor, layer: Conv3dLayer, *, skip: Optional[torch.Tensor] 
     return out
 
 
+def conv3d_block8(x: torch.Tensor, layer1: Conv3dLayer, layer2: Conv3dLayer, *, residual: bool = True, in_coff: int = 0,
+                  out: Optional[torch.Tensor] = None, out_coff: int = 0) -> Optional[torch.Tensor]:
+    """Two stacked 8 -> 8 depth-sweep layers (+ the block input as residual) in one launch (pscv_conv3d_block8): the values of
+    ``conv3d(conv3d(x, layer1), layer2, skip=x)`` without the intermediate volume.  Returns None when the layers are not both
+    8 -> 8 depth-sweep (S1P8) layers in x's dtype (run the two launches then)."""
+    _dev(x, out, layer1.packed, layer2.packed)
+    if not (layer1.kind == layer2.kind == L.CONV_S1P8 and layer1.c_in == layer1.c_out == layer2.c_in == layer2.c_out == 8
+            and layer1.dtype == layer2.dtype == x.dtype and x.dim() == 5):
+        return None
+    B, D, H, W, cs = x.shape
+    if out is None:
+        out = torch.empty((B, D, H, W, 8), dtype=x.dtype, device=x.device)
+    if tuple(out.shape[:4]) != (B, D, H, W) or out.dtype != x.dtype:
+        raise ValueError(f"pscv.conv3d_block8: out has shape {tuple(out.shape)} / {out.dtype}, expected [B,{D},{H},{W},*] {x.dtype}")
+    vox = B * D * H * W
+    rc = _launch("conv3d_block8", lambda: L.lib().pscv_conv3d_block8(
+        _p(x), _dt(x), cs, in_coff, _p(layer1.packed), _p(layer1.scale), _p(layer1.bias), _p(layer1.floor), layer1.epi,
+        _p(layer2.packed), _p(layer2.scale), _p(layer2.bias), _p(layer2.floor), layer2.epi, int(residual),
+        _p(out), out.shape[4], out_coff, B, D, H, W, _stream()),
+        cost=lambda: (float(vox * 32), 2.0 * 2 * 27 * 8 * 8 * vox))
+    L.check(rc, "pscv_conv3d_block8")
+    return out
+
+
 # --------------------------------------------------------------------------------------------
 # Vis-MVSNet UncertNet (eval mode), one launch
 # --------------------------------------------------------------------------------------------
