@@ -70,7 +70,7 @@ def test_vis_source_view_shard_two_ranks_one_gpu():
     res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
-        assert p.exitcode == 0
+        assert p.exitcode == 0, f"a rank process exited with code {p.exitcode}"
     g = load_golden("vis_tiny.npz")
     ref = g["depth"]
     for rank, depth, pairs in res:
@@ -149,7 +149,7 @@ def test_mvsnet_training_under_ddp_two_ranks_one_gpu():
     res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
-        assert p.exitcode == 0
+        assert p.exitcode == 0, f"a rank process exited with code {p.exitcode}"
     q2 = ctx.Queue()
     p = ctx.Process(target=_single_worker, args=(q2,))
     p.start()
@@ -205,7 +205,7 @@ def test_mvsnet_source_view_shard_variance_reduce_two_ranks_one_gpu():
     res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
-        assert p.exitcode == 0
+        assert p.exitcode == 0, f"a rank process exited with code {p.exitcode}"
     g = load_golden("mvsnet_behind.npz")
     ref_cost = np.transpose(g["cost_volume"], (0, 2, 3, 4, 1))
     for rank, depth, cost in res:
@@ -279,7 +279,7 @@ def test_vis_depth_plane_shard_two_ranks_one_gpu():
     res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
-        assert p.exitcode == 0
+        assert p.exitcode == 0, f"a rank process exited with code {p.exitcode}"
     for rank, per_stage, rel in res:
         for si, errs in enumerate(per_stage):
             print(f"[parity] depth-plane shard rank {rank} stage {si + 1}: depth rel-L1 {errs[0]:.2e}, window prob mean abs {errs[1]:.2e} "
@@ -351,7 +351,7 @@ def test_vis_view_shard_slab_regfuse_two_ranks_one_gpu():
     res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
-        assert p.exitcode == 0
+        assert p.exitcode == 0, f"a rank process exited with code {p.exitcode}"
     for rank, rec, _ in res:
         for label, r in rec.items():
             print(f"[parity] view shard ({label}) rank {rank}: depth rel-L1 per stage (fine->coarse) " + " ".join(f"{e:.2e}" for e in r["depth"]) +
@@ -426,7 +426,7 @@ def test_mvsnet_depth_plane_shard_with_halo_exchange_two_ranks_one_gpu():
     res = dict(q.get(timeout=240) for _ in range(2))
     for p in procs:
         p.join(timeout=60)
-        assert p.exitcode == 0
+        assert p.exitcode == 0, f"a rank process exited with code {p.exitcode}"
     for rank in (0, 1):
         for agg, D, d_err, c_err, _ in res[rank]:
             print(f"[parity] MVSNet depth-plane shard rank {rank} {agg} D={D}: depth max rel {d_err:.2e}, confidence max abs {c_err:.2e}", flush=True)
