@@ -73,3 +73,35 @@ def test_shift_invariance_and_partials_at_full_size(env):
     index = (lo[:, 3] * a + hi[:, 3] * b) / se
     assert float((depth - full["depth"]).abs().max()) <= 1e-4
     assert float((index - full["index"]).abs().max()) <= 2e-3
+
+
+@pytest.mark.parametrize("D", [1, 5, 8, 9, 16, 24, 32])
+@pytest.mark.parametrize("per_pixel", [False, True])
+def test_short_depth_axes_thread_per_pixel_kernel(env, D, per_pixel):
+    """D <= 32 takes the one-thread-per-pixel kernel (CVP's 8 hypotheses, Vis stages 2-3): every output mode against the fp64
+    formulas (model.py:207-215, nn_utils.py:453-470) and against the slice kernel (softargmin_small = 0); ragged pixel count."""
+    L, ops, O = env
+    gen = torch.Generator().manual_seed(D)
+    B, h, w = 2, 19, 27
+    logits = (torch.randn(B, D, h, w, generator=gen) * 4).cuda()
+    depth = (torch.rand(B, D, h, w, generator=gen) + torch.arange(D).view(1, D, 1, 1)) if per_pixel else (torch.rand(B, D, generator=gen) * 3 + 1)
+    depth = depth.cuda()
+    p = torch.softmax(logits.double().cpu(), 1)
+    idx = torch.arange(D, dtype=torch.float64).view(1, D, 1, 1)
+    dd = depth.double().cpu() if per_pixel else depth.double().cpu().view(B, D, 1, 1)
+    e_idx = (p * idx).sum(1)
+    for mode in (0, 1):
+        res = {}
+        for small in (1, 0):
+            L.set_tuning("softargmin_small", small)
+            try:
+                res[small] = ops.softargmin(logits, depth, want_index=True, want_conf=True, conf_mode=mode, window=2.0, want_entropy=True,
+                                            index_offset=3)
+            finally:
+                L.set_tuning("softargmin_small", 1)
+        o = res[1]
+        check_close(f"depth D={D}", o["depth"].cpu(), (p * dd).sum(1).float(), max_abs=3e-5 * float(dd.max()))
+        check_close(f"index D={D}", o["index"].cpu(), (e_idx + 3).float(), max_abs=2e-5 * max(D, 4))
+        check_close(f"entropy D={D}", o["entropy"].cpu(), (-p * p.clamp(1e-9, 1.0).log()).sum(1).float(), max_abs=2e-5)
+        for k in ("depth", "index", "entropy", "conf"):
+            check_close(f"{k} small vs slice kernel D={D} mode {mode}", o[k].cpu(), res[0][k].cpu(), max_abs=3e-5 * max(1.0, float(res[0][k].abs().max())))

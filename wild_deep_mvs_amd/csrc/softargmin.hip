@@ -144,6 +144,67 @@ __global__ __launch_bounds__(256) void softargmin_kernel(const SoftArgs a) {
     }
 }
 
+// Short depth axes (D <= 32: CVP's 8 refinement hypotheses, the 16 / 32-plane stages of Vis-MVSNet): ONE thread per pixel with the
+// whole logit column in registers.  The kernel above gives a pixel 8 threads (one per depth slice) and merges them through LDS:
+// at D = 8 that is one plane per thread, 256 threads for 32 pixels and two barriers -- 0.9 TB/s at 1024 x 1280 x 8.  Here
+// consecutive lanes read consecutive pixels of every plane (coalesced), all D loads are in flight together, and the statistics
+// are plain sequential sums over d (fp32; the order differs from the slice merge above in the last bits only).
+template <typename T, int DMAX>
+__global__ __launch_bounds__(256) void softargmin_small_kernel(const SoftArgs a) {
+    const long hw = (long)a.h * a.w;
+    const long pix = (long)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= (long)a.B * hw) return;
+    const int b = (int)(pix / hw);
+    const long pf = pix - (long)b * hw;
+    const T* lp = reinterpret_cast<const T*>(a.logits) + (long)b * a.D * hw + pf;
+    const float* dp = a.depth ? a.depth + (long)b * a.depth_bstride + (a.depth_per_pixel ? pf : 0) : nullptr;
+    const long dstep = a.depth_per_pixel ? hw : 1;
+    float v[DMAX], dv[DMAX];
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) v[d] = d < a.D ? ldlogit<T>(lp + (long)d * hw) : -INFINITY;
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) dv[d] = (dp && d < a.D) ? dp[d * dstep] : 0.0f;
+    float M = -INFINITY;
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) M = fmaxf(M, v[d]);
+    float SE = 0.f, SD = 0.f, SI = 0.f;
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) {
+        v[d] = d < a.D ? expf(v[d] - M) : 0.0f;              // from here on: e_d
+        SE += v[d];
+        SD = fmaf(v[d], dv[d], SD);
+        SI = fmaf(v[d], (float)(d + a.index_offset), SI);
+    }
+    const float inv = 1.0f / SE;
+    const float eidx = SI * inv;
+    if (a.o_depth) a.o_depth[pix] = SD * inv;
+    if (a.o_index) a.o_index[pix] = eidx;
+    if (a.o_conf) {
+        const float lidx = eidx - (float)a.index_offset;
+        float c = 0.f;
+        if (a.conf_mode == 0) {
+            const int i = (int)lidx;                          // planes i-1 .. i+2 (zero padded)          model.py:211-215
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d)
+                if (d >= i - 1 && d <= i + 2) c += v[d] * inv;
+        } else {
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d)                    // |d - E[index]| <= window                  nn_utils.py:464-465
+                if (fabsf((float)d - lidx) <= a.window) c += v[d] * inv;
+        }
+        a.o_conf[pix] = c;
+    }
+    if (a.o_entropy) {
+        float ent = 0.f;
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) {
+            const float p = v[d] * inv;
+            if (d < a.D) ent -= p * logf(fminf(fmaxf(p, 1e-9f), 1.0f));   // nn_utils.py:469-470
+        }
+        a.o_entropy[pix] = ent;
+    }
+}
+
 // Window probability of ONE depth shard under the globally merged softmax statistics (depth-plane shard across GPUs):
 //     out[pix] = sum over this shard's planes d with |d + index_offset - E[index]| <= window of exp(l_d - M) / Z
 // stats [B,3,h,w] = (global max M, global sum Z, global expected index); the shards' outputs are summed by an all-reduce.
@@ -177,6 +238,8 @@ extern "C" int pscv_softargmin_window(const float* logits, const float* stats, f
     return 0;
 }
 
+pscv::Knob g_softargmin_small = {1, pscv::KNOB_SPARE4};   // pscv_set_tuning("softargmin_small", 0): short depth axes back on the slice kernel
+
 extern "C" int pscv_softargmin(const void* logits, int logit_dtype, const float* depth, long depth_bstride,
                                int depth_per_pixel, float* out_depth, float* out_index, float* out_conf,
                                float* out_entropy, float* out_prob, float* out_partials, int conf_mode, float window,
@@ -195,6 +258,14 @@ extern "C" int pscv_softargmin(const void* logits, int logit_dtype, const float*
     const long npix = (long)B * h * w;
     const unsigned nblk = (unsigned)((npix + pscv::SA_PX - 1) / pscv::SA_PX);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (D <= 32 && !out_prob && !out_partials && logit_dtype == PSCV_F32 && g_softargmin_small) {
+        const unsigned nb = (unsigned)((npix + 255) / 256);
+        if (D <= 8) hipLaunchKernelGGL((softargmin_small_kernel<float, 8>), dim3(nb), dim3(256), 0, st, a);
+        else if (D <= 16) hipLaunchKernelGGL((softargmin_small_kernel<float, 16>), dim3(nb), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((softargmin_small_kernel<float, 32>), dim3(nb), dim3(256), 0, st, a);
+        PSCV_CHECK_LAUNCH("pscv_softargmin(small)");
+        return 0;
+    }
     if (logit_dtype == PSCV_F32) hipLaunchKernelGGL(softargmin_kernel<float>, dim3(nblk), dim3(256), 0, st, a);
     else if (logit_dtype == PSCV_BF16) hipLaunchKernelGGL(softargmin_kernel<bf16_t>, dim3(nblk), dim3(256), 0, st, a);
     else if (logit_dtype == PSCV_F16) hipLaunchKernelGGL(softargmin_kernel<f16_t>, dim3(nblk), dim3(256), 0, st, a);

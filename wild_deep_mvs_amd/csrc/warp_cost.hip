@@ -347,6 +347,7 @@ extern Knob g_conv2d_wlds;                    // conv2d.hip
 extern Knob g_conv_tall64;                    // conv3d.hip
 }
 extern pscv::Knob g_block8_slots;             // conv3d_block8.hip
+extern pscv::Knob g_softargmin_small;         // softargmin.hip
 namespace pscv {
 static Knob* find_knob(const char* key) {
     static const struct { const char* name; Knob* k; } table[] = {
@@ -354,7 +355,7 @@ static Knob* find_knob(const char* key) {
         {"warp_tiled", &g_warp_tiled}, {"warp_q2", &g_warp_q2}, {"c1_nb", &g_c1_nb}, {"c1_sweep", &g_c1_sweep},
         {"sweep_th16", &g_sweep_th16}, {"sweep_dc", &g_sweep_dc}, {"sweepc_slots", &g_sweepc_slots}, {"sweepc_pd", &g_sweepc_pd},
         {"warp_bwd_direct", &g_warp_bwd_direct}, {"conv_s2_sweep", &g_conv_s2_sweep}, {"s2s_slots", &g_s2s_slots},
-        {"warp_tile", &g_warp_tile}, {"fuse_c0", &g_fuse_c0}, {"conv2d_wlds", &g_conv2d_wlds}, {"conv_tall64", &g_conv_tall64}, {"block8_slots", &::g_block8_slots}};
+        {"warp_tile", &g_warp_tile}, {"fuse_c0", &g_fuse_c0}, {"conv2d_wlds", &g_conv2d_wlds}, {"conv_tall64", &g_conv_tall64}, {"block8_slots", &::g_block8_slots}, {"softargmin_small", &::g_softargmin_small}};
     for (const auto& e : table)
         if (!strcmp(key, e.name)) return e.k;
     return nullptr;
