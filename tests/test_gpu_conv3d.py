@@ -181,6 +181,63 @@ def test_sweep_kernel_matches_brick_kernel_and_aten(env, shape, th16, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape,dc,pd,with_skip,out_f32,transposed", [((16, 16, 32), 0, 1, True, True, False), ((13, 11, 21), 5, 1, False, False, False),
+                                                                     ((2, 8, 16), 0, 1, True, False, False), ((37, 9, 40), 7, 2, True, True, True),
+                                                                     ((9, 37, 24), 4, 2, False, True, False), ((1, 3, 5), 0, 1, False, True, False)])
+def test_kd_in_rows_sweep_matches_plane_pair_sweep_and_aten(env, shape, dc, pd, with_skip, out_f32, transposed, dtype):
+    """The kd-in-rows variant of the 32 -> 8 depth sweep (pscv_set_tuning("sweep_kdm", 1): 32 x 32 x 16 MFMAs whose rows hold the
+    three depth taps, one input plane per iteration, 3-slot ring) against the default plane-pair kernel and ATen: sizes that are
+    not multiples of the tile, odd depth chunks (one plane of a chunk can be the volume's last), both prefetch distances, with and
+    without the residual, fp32 and 16-bit outputs, a stride-1 deconv (flipped taps).  Same products, another summation order:
+    fp32 outputs agree to 1e-4, not bit for bit."""
+    L, ops = env
+    g = torch.Generator().manual_seed(sum(shape) + dc)
+    D, H, W = shape
+    x = bf16_round(torch.randn(2, 32, D, H, W, generator=g))
+    wshape = (32, 8, 3, 3, 3) if transposed else (8, 32, 3, 3, 3)
+    w = bf16_round(torch.randn(wshape, generator=g) / np.sqrt(27 * 32))
+    gamma, beta = torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g) * 0.3
+    mean, var = torch.randn(8, generator=g) * 0.2, torch.rand(8, generator=g) + 0.5
+    skip = bf16_round(torch.randn(2, 8, D, H, W, generator=g)) if with_skip else None
+    ref = F.relu(F.batch_norm(_ref_conv(x, w, L.CONV_S1, transposed, L), mean, var, gamma, beta, training=False, eps=1e-5))
+    if with_skip:
+        ref = ref + skip
+    xcl = ops.to_channels_last(x.cuda(), dtype)
+    scl = ops.to_channels_last(skip.cuda(), dtype) if with_skip else None
+    layer = ops.Conv3dLayer.build(w, kind=L.CONV_S1, transposed=transposed, device="cuda", bn=(gamma, beta, mean, var), relu=True, dtype=dtype)
+    assert layer.kind == L.CONV_S1P8
+    outs = {}
+    for kdm in (0, 1, 2):
+        L.set_tuning("sweep_kdm", kdm); L.set_tuning("sweep_dc", dc if kdm else 0); L.set_tuning("sweep_kdm_pd", pd)
+        try:
+            out = torch.full((2, D, H, W, 8), float("nan"), dtype=torch.float32 if out_f32 else dtype, device="cuda")
+            ops.conv3d(xcl, layer, skip=scl, out=out)
+            outs[kdm] = out.float().permute(0, 4, 1, 2, 3).cpu()
+        finally:
+            L.set_tuning("sweep_kdm", 0); L.set_tuning("sweep_dc", 0); L.set_tuning("sweep_kdm_pd", 0)
+    ulp = 2 ** -8 if dtype == torch.bfloat16 else 2 ** -11
+    for kdm in (1, 2):
+        check_close(f"kd-in-rows({kdm}) vs ATen {shape} {dtype}", outs[kdm], ref, max_abs=3e-3 if out_f32 else None, rel_l2=2e-4 if out_f32 else 2 * ulp)
+        if out_f32:
+            check_close(f"kd-in-rows({kdm}) vs plane-pair {shape} {dtype}", outs[kdm], outs[0], max_abs=1e-4)
+        else:   # 16-bit stores: the two summation orders may round a value to neighbouring representable numbers
+            assert float((outs[kdm] - outs[0]).abs().max()) <= 2 * ulp * float(outs[0].abs().max()) + 1e-6
+    # NaN in, NaN out (relu_floor keeps it) -- and only where the receptive field holds it
+    xn = xcl.clone()
+    xn[0, D // 2, H // 2, W // 2, 3] = float("nan")
+    L.set_tuning("sweep_kdm", 1)
+    try:
+        yn = ops.conv3d(xn, layer, skip=scl, out_dtype=torch.float32)
+    finally:
+        L.set_tuning("sweep_kdm", 0)
+    nan = torch.isnan(yn[0]).any(-1)
+    d0, h0, w0 = D // 2, H // 2, W // 2
+    exp = torch.zeros_like(nan)
+    exp[max(d0 - 1, 0):d0 + 2, max(h0 - 1, 0):h0 + 2, max(w0 - 1, 0):w0 + 2] = True
+    assert bool((nan == exp).all()) and not bool(torch.isnan(yn[1]).any())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("cin,shape,transposed,dc", [(8, (16, 16, 32), False, 0), (8, (13, 11, 21), False, 4), (8, (37, 9, 40), True, 0),
                                                      (16, (16, 16, 32), False, 0), (16, (9, 37, 24), False, 6), (16, (2, 8, 16), True, 0),
                                                      (8, (2, 3, 5), False, 0)])

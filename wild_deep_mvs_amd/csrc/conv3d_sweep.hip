@@ -255,6 +255,245 @@ __global__ __launch_bounds__(32 * SW_TH, 2) void conv3d_sweep8_kernel(const Swee
     PSCV_PROF_END(sweep, blockIdx.x)
 }
 
+// ---- kd-in-rows variant of the 32 -> 8 sweep (round 3, `pscv_set_tuning("sweep_kdm", 1)`) ---------------------------------
+// The plane-pair kernel above reads every (plane, tap) B fragment for ONE 16-row MFMA: 72 ds_read_b128 + 72 MFMAs per wave and
+// plane pair, 144 VGPRs of weights, 70 KiB of ring -> two workgroups per CU whose MFMA phases (2.2 K of ~5 K cycles per
+// iteration, phase stamps in profiles/README.md) cover each other only by chance.  Here the three depth taps of the kernel
+// sit in the ROWS of a 32 x 32 x 16 MFMA instead: rows 8 kd + c_out (kd = 0..2; rows 24..31 carry zero weights), columns =
+// the wave's 2 x 16 pixels, reduction = 16 of the 32 channels.  An input plane p is then read ONCE -- 9 (kh, kw) taps x 2
+// channel halves = 18 B fragments / 18 MFMAs (the same 75 % of useful MFMA rows as the pair packing) -- and feeds output planes
+// p+1 (kd 0), p (kd 1), p-1 (kd 2) at the same time: the three 8-row blocks of the accumulator slide down one block per
+// plane (12 register moves), and the block that leaves is a finished output plane.  Half the LDS reads and half the weight
+// registers (72) of the pair kernel, a 3-slot ring (plane p being read, p+1 landed, p+2 in flight in registers; 36 KiB):
+// three to four workgroups per CU.  Lane -> pixel map: the hardware serves a ds_read_b128 in the lane groups {0-3, 12-15, 20-27} /
+// {4-11, 16-19, 28-31} (+32); each group gets 16 x-ADJACENT pixels of one row, and with chunk ^= (voxel >> 2) & 3 sixteen
+// consecutive 64-byte voxels fall on the sixteen 16-byte slots of the 256-byte bank row for every tap offset.
+// Weights: the PSCV_CONV_S1P8 packing, gathered (rows 0-7 of p_rel = kd hold kernel slice kd).
+typedef __attribute__((ext_vector_type(16))) float sw_f32x16;
+template <typename H> struct SwMfma32;
+template <> struct SwMfma32<bf16_t> {
+    __device__ static __forceinline__ sw_f32x16 run(const uint4& a, const uint4& b, const sw_f32x16& c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sw_bf16x8, a), __builtin_bit_cast(sw_bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct SwMfma32<f16_t> {
+    __device__ static __forceinline__ sw_f32x16 run(const uint4& a, const uint4& b, const sw_f32x16& c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(sw_f16x8, a), __builtin_bit_cast(sw_f16x8, b), c, 0, 0, 0);
+    }
+};
+
+extern Knob g_fuse_c0;
+Knob g_sweep_kdm_pd = {0, KNOB_SWEEP_KDM_PD};    // prefetch distance (planes in flight per workgroup) of the kd-in-rows kernel: 1 (default) or 2
+Knob g_sweep_kdm = {0, KNOB_SWEEP_KDM};      // pscv_set_tuning("sweep_kdm", 1): kd-in-rows kernel for the 32 -> 8 layer; 2: with four workgroups per CU as the chunking target
+constexpr int KM_NSLOT = 3;
+constexpr int KM_PV = 192;                    // 10 x 18 = 180 voxels per plane, padded to a multiple of 16 (swizzle is slot-invariant)
+constexpr int KM_PB = KM_PV * SW_VB;
+constexpr int KM_LDS = KM_NSLOT * KM_PB + 96;   // + scale / bias / floor of the 8 output channels
+constexpr int KM_CHUNKS = 10 * SW_BW * 4;
+constexpr int KM_NLD = (KM_CHUNKS + 255) / 256;
+
+// -DPSCV_ABLATE builds read ablation flags from pscv_set_tuning("fuse_c0", bits) (measurement only; results are wrong with any bit set)
+#ifdef PSCV_ABLATE
+#define KM_ABL(bit) (a.in2_cs & (bit))
+#else
+#define KM_ABL(bit) false
+#endif
+__device__ __forceinline__ int km_lds_off(int v, int chunk) { return v * SW_VB + ((chunk ^ ((v >> 2) & 3)) << 4); }
+
+template <typename H, bool SKIP, int PD>
+__global__ __launch_bounds__(256, 3) void conv3d_sweep8_kdm_kernel(const SweepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NLD = KM_NLD;
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, slot_ = bid >> 3, q = nwg >> 3, r_ = nwg & 7;
+    int wg = (xcd < r_ ? xcd * (q + 1) : r_ * (q + 1) + (xcd - r_) * q) + slot_;
+    const int dci = fast_divmod(wg, a.ndc, a.mg_dc);
+    const int twi = fast_divmod(wg, a.ntw, a.mg_tw);
+    const int thi = fast_divmod(wg, a.nth, a.mg_th);
+    const int b = wg;
+    const int h0 = thi * 8, w0 = twi * 16;
+    const int dbeg = dci * a.dc, dend = min(a.D, dbeg + a.dc);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, nn = lane & 31;
+    // this lane's pixel: quads {0, 3, 5, 6} of a 32-lane half form one ds_read_b128 lane group -> row 0, quads {1, 2, 4, 7} -> row 1;
+    // x = 4 x (rank of the quad in its group) + lane in quad, and the rank is quad >> 1 in both groups
+    const int quad = nn >> 2;
+    const int rr = ((0x69 >> quad) & 1) ? 0 : 1;
+    const int px = (quad >> 1) * 4 + (nn & 3);
+    const int row0 = wave * 2;
+
+    // ---- A fragments: row nn = 8 kd + c_out, k = 8 half + j -> channel 16 h + 8 half + j = lane group g = 2 h + half of the packing ----
+    uint4 wf[9][2];
+    {
+        const uint4* wp = reinterpret_cast<const uint4*>(a.wpk);
+        const int kdb = nn >> 3, co = nn & 7;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                wf[t][h] = kdb < 3 ? wp[(kdb * 9 + t) * 64 + (2 * h + half) * 16 + co] : make_uint4(0u, 0u, 0u, 0u);
+    }
+
+    // ---- B fragment offsets inside a plane slot (channel half 0; half 1 = the same address ^ 32) ----
+    int boff[3][3];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) boff[kh][kw] = km_lds_off((row0 + rr + kh) * SW_BW + px + kw, half);
+
+    // ---- staging: raw buffer loads, zero padding from the descriptor bounds (as in the pair kernel) ----
+    unsigned goff[NLD];
+    // chunk id = tid + 256 i -> voxel (tid >> 2) + 64 i: the swizzle term (voxel >> 2) & 3 does not depend on i, so the LDS offsets of a
+    // thread's chunks are loff0 + 4096 i (immediates), and only the last chunk can lie beyond the 720 of a plane
+    static_assert(NLD == 3 && KM_CHUNKS > 512 && KM_CHUNKS <= 768, "three chunks per thread, the third one partial");
+    const int loff0 = km_lds_off(tid >> 2, tid & 3);
+    const bool lval_last = tid + 512 < KM_CHUNKS;
+    const long plane_stride = (long)a.Hh * a.W * a.in_cs;
+    const unsigned plane_bytes = (unsigned)(plane_stride * 2 - a.in_co * 2);
+    const uint16_t* inb = a.in + (long)b * a.D * plane_stride + a.in_co;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int id = tid + 256 * i;
+        const int v = id >> 2, c = id & 3;
+        const int bh = v / SW_BW, bw = v - bh * SW_BW;
+        const int gh = h0 - 1 + bh, gw = w0 - 1 + bw;
+        const bool gval = id < KM_CHUNKS && (unsigned)gh < (unsigned)a.Hh && (unsigned)gw < (unsigned)a.W;
+        goff[i] = gval ? ((unsigned)(gh * a.W + gw) * (unsigned)a.in_cs + (unsigned)(c * 8)) * 2u : 0x7ffffff0u;
+    }
+    const int plane_hi = min(a.D - 1, dend);
+    auto fetch = [&](int plane, uint4 (&reg)[NLD]) {
+        const bool pv = plane >= 0 && plane <= plane_hi;                                         // wave-uniform
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint16_t*>(inb + (long)(pv ? plane : 0) * plane_stride), (short)0, pv ? (int)plane_bytes : 0, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+            reg[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)goff[i], 0, 0));
+    };
+    auto stash = [&](int ring, const uint4 (&reg)[NLD]) {
+        unsigned char* sp = smem + ring * KM_PB + loff0;
+        *reinterpret_cast<uint4*>(sp) = reg[0];
+        *reinterpret_cast<uint4*>(sp + 4096) = reg[1];
+        if (lval_last) *reinterpret_cast<uint4*>(sp + 8192) = reg[2];
+    };
+
+    // ---- epilogue constants: rows 16 + 4 half + k of the accumulator = channels 4 half + k of the finished plane ----
+    // (scale / bias / ReLU floor of the 8 channels wait in LDS behind the ring: 12 registers the MFMA loop needs more)
+    const int c0 = half * 4;
+    float* const epc = reinterpret_cast<float*>(smem + KM_NSLOT * KM_PB);
+    if (tid < 24) {
+        const int k = tid & 7, which = tid >> 3;
+        epc[tid] = which == 0 ? (a.scale ? a.scale[k] : 1.0f) : which == 1 ? (a.bias ? a.bias[k] : 0.0f) : (a.floor ? a.floor[k] : 0.0f);
+    }
+    const int oh = h0 + row0 + rr, ow = w0 + px;
+    const bool pix_ok = oh < a.Hh && ow < a.W;
+    const long vrow = ((long)b * a.D * a.Hh + oh) * a.W + ow;
+    const long vplane = (long)a.Hh * a.W;
+    // the residual of output plane od is requested an iteration before its epilogue (SKIP only): the store then waits for nothing
+    auto fetch_skip = [&](int od) -> uint2 {
+        uint2 sv = make_uint2(0u, 0u);
+        if (SKIP && pix_ok && od >= dbeg && od < dend)
+            sv = *reinterpret_cast<const uint2*>(a.skip + (vrow + od * vplane) * a.skip_cs + a.skip_co + c0);
+        return sv;
+    };
+    auto epilogue = [&](int od, float d0, float d1, float d2, float d3, const uint2 sv) {
+        if (!pix_ok) return;
+        const long vox = vrow + od * vplane;
+        float y[4] = {d0, d1, d2, d3};
+        const float4 sc4 = *reinterpret_cast<const float4*>(epc + c0), bi4 = *reinterpret_cast<const float4*>(epc + 8 + c0);
+        const float4 fl4 = *reinterpret_cast<const float4*>(epc + 16 + c0);
+        const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, bi[4] = {bi4.x, bi4.y, bi4.z, bi4.w}, fl[4] = {fl4.x, fl4.y, fl4.z, fl4.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            y[k] = fmaf(y[k], sc[k], bi[k]);
+            if (a.epi & PSCV_EPI_RELU_PRE) y[k] = relu_floor(y[k], fl[k]);
+        }
+        if (SKIP) {
+            y[0] += Half16<H>::lo(sv.x); y[1] += Half16<H>::hi(sv.x);
+            y[2] += Half16<H>::lo(sv.y); y[3] += Half16<H>::hi(sv.y);
+        }
+        if (a.epi & PSCV_EPI_RELU_POST) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) y[k] = relu_floor(y[k], 0.0f);
+        }
+        if (a.out_f32) {
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + vox * a.out_cs + a.out_co + c0) = make_float4(y[0], y[1], y[2], y[3]);
+        } else {
+            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.out) + vox * a.out_cs + a.out_co + c0) =
+                make_uint2(Half16<H>::pack(y[0], y[1]), Half16<H>::pack(y[2], y[3]));
+        }
+    };
+
+    // ---- prologue: plane dbeg-1 into slot 0, planes dbeg .. dbeg+PD-1 in flight in the register FIFO ----
+    uint4 nx[PD][NLD];
+    {
+        uint4 ra[NLD];
+        fetch(dbeg - 1, ra);
+#pragma unroll
+        for (int s = 0; s < PD; ++s) fetch(dbeg + s, nx[s]);
+        stash(0, ra);
+    }
+    __syncthreads();
+
+    sw_f32x16 acc;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.0f;
+    uint2 skv = make_uint2(0u, 0u);
+    int sl = 0;   // slot of plane p
+    for (int p0 = dbeg - 1; p0 <= dend; p0 += PD) {
+#pragma unroll
+        for (int s = 0; s < PD; ++s) {
+            const int p = p0 + s;
+            if (p > dend) break;                                     // workgroup-uniform
+            // plane p+1 (requested PD iterations ago) lands in the slot plane p-2 left (last read two iterations ago, two barriers since);
+            // its registers are refilled at once with plane p+1+PD
+            int sn = sl + 1;
+            sn = sn >= KM_NSLOT ? 0 : sn;
+            stash(sn, nx[s]);
+            const uint2 skc = skv;
+            skv = fetch_skip(p - 1);                                 // residual of the plane that finishes in the NEXT iteration
+            if (!KM_ABL(1) || p < dbeg) fetch(p + 1 + PD, nx[s]);
+            __builtin_amdgcn_sched_barrier(0);
+
+            // rows 16..23 hold output plane p-2, complete since the previous iteration; the blocks slide down one step
+            const float d0 = acc[8], d1 = acc[9], d2 = acc[10], d3 = acc[11];
+            acc[8] = acc[4]; acc[9] = acc[5]; acc[10] = acc[6]; acc[11] = acc[7];
+            acc[4] = acc[0]; acc[5] = acc[1]; acc[6] = acc[2]; acc[7] = acc[3];
+            acc[0] = 0.0f; acc[1] = 0.0f; acc[2] = 0.0f; acc[3] = 0.0f;
+
+            // 18 (tap, channel half) steps, B fragments three steps ahead of their MFMA (the accumulator chain is serial:
+            // one 32-cycle MFMA per step; an LDS read needs two to three of those to arrive)
+            const unsigned char* sp = smem + sl * KM_PB;
+            if (!KM_ABL(4)) {
+                constexpr int AH = 3;
+                uint4 xb[AH];
+#pragma unroll
+                for (int t = 0; t < AH; ++t) xb[t] = *reinterpret_cast<const uint4*>(sp + (boff[(t >> 1) / 3][(t >> 1) % 3] ^ ((t & 1) << 5)));
+#pragma unroll
+                for (int t = 0; t < 18; ++t) {
+                    acc = SwMfma32<H>::run(wf[t >> 1][t & 1], xb[t % AH], acc);
+                    if (t + AH < 18) {
+                        const int u = t + AH;
+                        xb[t % AH] = *reinterpret_cast<const uint4*>(sp + (boff[(u >> 1) / 3][(u >> 1) % 3] ^ ((u & 1) << 5)));
+                    }
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, AH, 0);
+#pragma unroll
+                for (int t = 0; t < 18; ++t) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (t + AH < 18) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
+
+            if (p - 2 >= dbeg && (!KM_ABL(2) || d0 == 123.456f)) epilogue(p - 2, d0, d1, d2, d3, skc);
+            sl = sn;
+            __syncthreads();
+        }
+    }
+    epilogue(dend - 1, acc[8], acc[9], acc[10], acc[11], skv);
+}
+
 // ---- narrow-input variant: C_in = 8 or 16, C_out = 8 (the Vis-MVSNet U-Net's full-resolution layers) ---------------------
 // Same sweep (8 x 16 pixel tile, 6-slot plane ring, two new planes per iteration prefetched under the MFMAs, plane-pair packed
 // rows), but with 16 / 32-byte voxels the 32-deep MFMA reduction spans PLANES instead of channels:
@@ -582,6 +821,43 @@ int pscv_conv3d_sweep8_launch(const void* in, int dtype, int in_cstride, int in_
     a.out_cs = out_cstride; a.out_co = out_coff; a.out_f32 = out_dtype == PSCV_F32;
     a.B = B; a.D = D; a.Hh = Hh; a.W = W; a.epi = epi_flags;
     PSCV_CHECK_ARG((long)Hh * W * in_cstride * 2 < 0x7fffffffL, "pscv_conv3d(sweep): an input plane of %d x %d x %d channels exceeds 2 GiB", Hh, W, in_cstride);
+    if (g_sweep_kdm) {   // kd-in-rows kernel: 3-slot ring, three (knob 2: four) workgroups per CU in one resident round
+#ifdef PSCV_ABLATE
+        a.in2_cs = g_fuse_c0;   // ablation flags: 1 no plane fetch, 2 no stores, 4 no LDS reads / MFMAs (scripts/dev/kdm_bench.py --ablate)
+#endif
+        a.nth = (Hh + 7) / 8;
+        a.ntw = (W + 15) / 16;
+        const long tiles = (long)B * a.nth * a.ntw;
+        const long slots = g_sweep_kdm >= 2 ? 1024 : 768;
+        const long ndc_want = tiles >= slots ? 1 : slots / tiles;
+        int dc = (int)((D + ndc_want - 1) / ndc_want);
+        dc = dc < 4 ? 4 : dc;
+        if (g_sweep_dc > 0) dc = g_sweep_dc;
+        dc = dc > D ? D : dc;
+        a.dc = dc;
+        a.ndc = (D + dc - 1) / dc;
+        const long nblk = tiles * a.ndc;
+        a.mg_th = fast_div_magic(a.nth); a.mg_tw = fast_div_magic(a.ntw); a.mg_dc = fast_div_magic(a.ndc);
+        if (nblk <= 0 || nblk > 0x7fffffffL) { set_error("pscv_conv3d(sweep): bad grid %ld", nblk); return -1; }
+        const int pd = g_sweep_kdm_pd > 0 ? g_sweep_kdm_pd : 1;
+        const int ti = (dtype == PSCV_BF16 ? 0 : 1) + (skip ? 2 : 0) + (pd >= 2 ? 4 : 0);
+        static bool kdm_attr[8] = {false, false, false, false, false, false, false, false};
+#define PSCV_KDM(I, HT, SK, PDV)                                                                                                  \
+        if (ti == I) {                                                                                                            \
+            if (!kdm_attr[I]) {                                                                                                   \
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_sweep8_kdm_kernel<HT, SK, PDV>),          \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, KM_LDS);                           \
+                if (e != hipSuccess) { set_error("pscv_conv3d(sweep): hipFuncSetAttribute: %s", hipGetErrorString(e)); return -2; } \
+                kdm_attr[I] = true;                                                                                               \
+            }                                                                                                                     \
+            hipLaunchKernelGGL((conv3d_sweep8_kdm_kernel<HT, SK, PDV>), dim3((unsigned)nblk), dim3(256), KM_LDS, st, a);          \
+            return 0;                                                                                                             \
+        }
+        PSCV_KDM(0, bf16_t, false, 1) PSCV_KDM(1, f16_t, false, 1) PSCV_KDM(2, bf16_t, true, 1) PSCV_KDM(3, f16_t, true, 1)
+        PSCV_KDM(4, bf16_t, false, 2) PSCV_KDM(5, f16_t, false, 2) PSCV_KDM(6, bf16_t, true, 2) PSCV_KDM(7, f16_t, true, 2)
+#undef PSCV_KDM
+        return -1;
+    }
     const bool tall = g_sweep_th16 && Hh >= 16;
     const int TH = tall ? 16 : 8;
     a.nth = (Hh + TH - 1) / TH;

@@ -247,6 +247,8 @@ static Knob g_warp_tiled = {1, KNOB_WARP_TILED};     // 1 (default): use the LDS
 extern Knob g_conv_small_tiles;   // conv3d.hip
 extern Knob g_sweep_th16;         // conv3d_sweep.hip
 extern Knob g_sweep_dc;
+extern Knob g_sweep_kdm;
+extern Knob g_sweep_kdm_pd;
 extern Knob g_sweepc_slots;
 extern Knob g_sweepc_pd;
 }
@@ -353,7 +355,7 @@ static Knob* find_knob(const char* key) {
     static const struct { const char* name; Knob* k; } table[] = {
         {"warp_lpv", &g_warp_lpv_override}, {"warp_ppd", &g_warp_ppd_override}, {"conv_small_tiles", &g_conv_small_tiles},
         {"warp_tiled", &g_warp_tiled}, {"warp_q2", &g_warp_q2}, {"c1_nb", &g_c1_nb}, {"c1_sweep", &g_c1_sweep},
-        {"sweep_th16", &g_sweep_th16}, {"sweep_dc", &g_sweep_dc}, {"sweepc_slots", &g_sweepc_slots}, {"sweepc_pd", &g_sweepc_pd},
+        {"sweep_th16", &g_sweep_th16}, {"sweep_dc", &g_sweep_dc}, {"sweep_kdm", &g_sweep_kdm}, {"sweep_kdm_pd", &g_sweep_kdm_pd}, {"sweepc_slots", &g_sweepc_slots}, {"sweepc_pd", &g_sweepc_pd},
         {"warp_bwd_direct", &g_warp_bwd_direct}, {"conv_s2_sweep", &g_conv_s2_sweep}, {"s2s_slots", &g_s2s_slots},
         {"warp_tile", &g_warp_tile}, {"fuse_c0", &g_fuse_c0}, {"conv2d_wlds", &g_conv2d_wlds}, {"conv_tall64", &g_conv_tall64}, {"block8_slots", &::g_block8_slots}, {"softargmin_small", &::g_softargmin_small}};
     for (const auto& e : table)
