@@ -514,3 +514,57 @@ def test_bench_sharded_legs_two_ranks_one_gpu():
     assert "reduce_scatter_tensor" in names       # the 16-bit shares of the fused volume of the source-view shard
     rs = max(c["bytes_per_rank"] for c in res[0]["view"]["collectives"] if c["collective"] == "reduce_scatter_tensor")
     assert rs == 256 * 144 * 200 * 8 * 2          # stage 1 of configuration 5: the 16-bit volume (118 MB), nothing wider
+
+
+# ---- RCCL itself on a one-GPU box: a world of ONE rank.  No byte crosses a link, but every collective the sharded models issue
+# (all_reduce, all_gather, reduce_scatter_tensor, the empty neighbour exchange) goes through the RCCL backend with device
+# tensors in the storage formats the models hand it -- backend-specific failures (an unsupported dtype, a host tensor, a
+# non-contiguous buffer, the dmabuf IPC setting) show up here and not only on the driver's multi-GPU node ------------------------
+def _rccl_one_rank_worker(port, q):
+    os.environ["PSCV_TEST_BACKEND"] = "nccl"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    _init(0, 1, port)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        from wild_deep_mvs_amd import dist as pd
+        dev = torch.device("cuda", 0)
+        assert dist.get_backend() == "nccl"
+        # the primitives on their own
+        x = torch.arange(24, dtype=torch.float32, device=dev).reshape(1, 6, 4).to(torch.float16)
+        ext, lo, a, b = pd.reduce_to_slab(x, 1, None, halo=2)
+        assert (lo, a, b) == (0, 0, 6) and torch.equal(ext, x)
+        rows = pd.gather_rows(torch.ones(1, 2, 3, 5, device=dev), 3, 3, None)
+        assert rows.shape == (1, 2, 3, 5)
+        # the three shardings of bench.py's "sharded" object, each against the unsharded run
+        res = bench.sharded_legs(dist, dev, 1, 0, reps=1, only=("mvsnet_depth", "depth", "view"))
+        q.put(res)
+    except Exception as e:      # (the parent must not wait for its queue time-out)
+        import traceback
+        q.put({"worker": {"error": traceback.format_exc()[-1500:]}})
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_rccl_backend_one_rank_runs_every_sharded_path():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_one_rank_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=300)
+    p.join(timeout=60)
+    assert "worker" not in res, res["worker"]["error"]
+    assert p.exitcode == 0, f"the rank process exited with code {p.exitcode}"
+    print("[rccl one rank]", res, flush=True)
+    assert res and set(res) == {"mvsnet_depth", "depth", "view"}, "a sharded leg did not run"
+    for mode, leg in res.items():
+        assert "error" not in leg, (mode, leg)
+        # a world of one: the same planes / views, merged through the partial-sum path (Vis depth shard: another summation order)
+        assert leg["depth_rel_l1_vs_unsharded"] <= 2e-4, (mode, leg["depth_rel_l1_vs_unsharded"])
+        if mode != "view":      # (a view group of one rank takes the unsharded branch)
+            assert leg["collectives"], f"{mode}: no collective went through RCCL"
