@@ -98,9 +98,13 @@ def time_config(cid: int, reps: int = 3) -> dict:
     with torch.no_grad():
         net.graph_replay = False
         dt_eager, out = timed()
-        with ops.EventTimer() as tm:
-            call()
-        detail = tm.detail()
+        detail = None
+        for _ in range(3):                               # three event passes, the one with the least GPU time is reported: a single
+            with ops.EventTimer() as tm:                 # pass once showed five launches of one layer at 10x their usual duration
+                call()                                   # (a shared box), which put that layer on top of a configuration's table
+            dtl = tm.detail()
+            if detail is None or sum(v["ms"] for v in dtl.values()) < sum(v["ms"] for v in detail.values()):
+                detail = dtl
         net.graph_replay = True
         dt, gout = timed()
         same = float((gout["depth"] - out["depth"]).abs().max())
