@@ -297,6 +297,8 @@ def parse_args(argv=None):
                                                           "the items of a batch on separate HIP streams (1 = one view at a time, as in rounds 1-2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the full-forward() timings / rooflines of BASELINE configurations 1-5")
+    ap.add_argument("--sharded-budget", type=float, default=300.0, help="N > 1: seconds the sharded legs may take before the headline line is "
+                    "printed without them (a stuck collective cannot be cancelled)")
     ap.add_argument("--no-sharded", action="store_true", help="N > 1: skip the depth-plane / source-view sharded legs (configurations 3 and 5)")
     ap.add_argument("--dtype", choices=sorted(DTYPES), default="f16",
                     help="16-bit HBM storage format (arithmetic is fp32); f16 is the engine default, see DESIGN.md section 5")
@@ -336,6 +338,33 @@ def spawn_ranks(args):
     rendezvous).  Under ``python -m torch.distributed.run`` WORLD_SIZE is already set and this is skipped."""
     import torch.multiprocessing as mp
     mp.spawn(_spawned_rank, args=(args, _free_port()), nprocs=args.gpus, join=True)
+
+
+def sharded_legs_bounded(dist, device, world, rank, budget_s, legs=None):
+    """``sharded_legs`` under a wall-clock budget.  The legs are the only part of an N > 1 run that exchanges data between GPUs
+    (RCCL point-to-point, reduce-scatter, all-gather); no multi-GPU node was available to exercise them before the driver's run,
+    and a stuck collective cannot be cancelled -- the process group's own time-out (10 min) ends the PROCESS, headline and all.
+    So the legs run in a helper thread; if it has not finished after ``budget_s`` seconds the caller gets
+    ``({"error": ...}, False)``, prints the already measured headline line and leaves with ``os._exit`` (no further collective,
+    no destroy: the group is wedged).  Returns ``(result, finished)``."""
+    import threading
+    box = {}
+
+    def work():
+        try:
+            if torch.cuda.is_available() and getattr(device, "type", "cpu") == "cuda":
+                torch.cuda.set_device(device)
+            box["res"] = (legs or sharded_legs)(dist, device, world, rank)
+        except BaseException as e:      # pragma: no cover
+            box["res"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+
+    th = threading.Thread(target=work, name="pscv-sharded-legs", daemon=True)
+    th.start()
+    th.join(budget_s)
+    if th.is_alive():
+        return {"error": f"the sharded legs did not finish within {budget_s:.0f} s on rank {rank}: a collective is stuck; the headline "
+                         "region (no collective in its data path) was measured before them and is unaffected"}, False
+    return box.get("res"), True
 
 
 def rendezvous(args):
@@ -486,9 +515,9 @@ def run(args):
     net.storage_dtype = DTYPES[args.dtype]
     graph = graphed
 
-    sharded = None
+    sharded, sharded_done = None, True
     if world > 1 and not args.no_sharded:
-        sharded = sharded_legs(dist, device, world, rank)
+        sharded, sharded_done = sharded_legs_bounded(dist, device, world, rank, args.sharded_budget)
 
     if rank == 0:
         total_ms = sum(ms for _, ms in kern.values())
@@ -568,6 +597,9 @@ def run(args):
             except Exception as e:   # pragma: no cover  (never lose the headline line to a side measurement)
                 line["other_configs"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         print(json.dumps(line), flush=True)
+    if not sharded_done:        # a wedged process group: nothing more can be agreed on; every rank leaves on its own
+        sys.stdout.flush()
+        os._exit(0)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

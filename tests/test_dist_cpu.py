@@ -190,3 +190,20 @@ def test_slab_axis_prefers_the_thicker_slab_and_refuses_thin_ones():
     assert pdist.slab_axis(16, 8, 2) == (1, 8)
     assert pdist.slab_axis(8, 12, 2) is None                # tiny fixture: replicated path
     assert pdist.slab_size(50, 4) == 14 and pdist.slab_size(50, 3) == 18
+
+
+def test_bench_sharded_legs_run_under_a_wall_clock_budget():
+    """bench.py's N > 1 sharded legs are the one part of the run that moves data between GPUs; a stuck collective there must not
+    cost the headline line: the legs run in a helper thread and the caller gets an error record after the budget."""
+    import sys
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    dev = torch.device("cpu")
+    ok, done = bench.sharded_legs_bounded(None, dev, 2, 0, 5.0, legs=lambda d, de, w, r: {"depth": {"speedup_vs_1gpu": 1.5}})
+    assert done and ok == {"depth": {"speedup_vs_1gpu": 1.5}}
+    t0 = time.time()
+    res, done = bench.sharded_legs_bounded(None, dev, 2, 1, 0.3, legs=lambda d, de, w, r: time.sleep(30))
+    assert not done and "did not finish" in res["error"] and "rank 1" in res["error"] and time.time() - t0 < 5
+    res, done = bench.sharded_legs_bounded(None, dev, 2, 0, 5.0, legs=lambda d, de, w, r: 1 / 0)
+    assert done and res["error"].startswith("ZeroDivisionError")
