@@ -295,6 +295,9 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=3, help="reference views per step and GPU (each with its own 4 source views): the engine runs "
                                                           "the items of a batch on separate HIP streams (1 = one view at a time, as in rounds 1-2)")
+    ap.add_argument("--batch-mode", choices=["streams", "batched"], default="streams",
+                    help="how the views of a step are launched: 'streams' = each view's 13 launches on its own HIP stream (eager; up to 4 views), "
+                         "'batched' = one launch per layer for the whole batch on one stream, replayed as a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the full-forward() timings / rooflines of BASELINE configurations 1-5")
     ap.add_argument("--sharded-budget", type=float, default=300.0, help="N > 1: seconds the sharded legs may take before the headline line is "
@@ -419,6 +422,9 @@ def run(args):
         _lib.set_tuning(k, int(v))
     net, sd, feats, feats_cl, proj_d, dv_d, proj, dv = build_inputs(device, rank, DTYPES[args.dtype], args.batch)
     NB = args.batch
+    if args.batch_mode == "batched":
+        net.batch_streams = False
+    streams_mode = net.batch_streams and 2 <= NB <= net.MAX_BATCH_STREAMS
 
     def timed_region(dtype_name, feats_cl_, steps):
         """W warm-up steps, then exactly `steps` steps between barrier + synchronize on both sides; then the same steps once
@@ -436,7 +442,7 @@ def run(args):
             # a batch of several views runs its items on separate streams with EAGER launches: forked into a hipGraph the same
             # step replays wrongly on ROCm 7.2 once inputs change (MVSNet._hot_path_streams), and the host keeps ahead of the
             # GPU anyway (~40 launches per ~1 ms step)
-            if not args.eager and NB == 1:
+            if not args.eager and (NB == 1 or not streams_mode):
                 # the 13-launch step is launch-gap bound between its small kernels: capture it once, replay it
                 try:
                     graph = torch.cuda.CUDAGraph()
@@ -564,7 +570,8 @@ def run(args):
                       (f"; the {NB} views of a step run on {NB} HIP streams: one view's vector-ALU-bound warp beside another's MFMA / "
                        "memory-bound U-Net, same kernels and bit-equal outputs (MVSNet._hot_path_streams; eager because ROCm 7.2 replays "
                        "multi-branch graphs of this path wrongly on changing inputs), so a step is SHORTER than the sum of its kernels' "
-                       "stand-alone durations below" if NB > 1 else "") +
+                       "stand-alone durations below" if streams_mode else
+                       f"; the {NB} views of a step share ONE launch per layer (batched grids, one stream)" if NB > 1 else "") +
                       f"; kernels_us / roofline: HIP events of an eager pass of the same {args.steps} steps, one view after the other on one "
                       f"stream (each launch timed alone; {elapsed_eager / args.steps * 1e3:.3f} ms/step that way)",
             "one_view_at_a_time": None if one_view is None else {"ms_per_view": one_view * 1e3, "value": world * VOX / one_view, "unit": "voxels/s",
