@@ -88,6 +88,10 @@ int pscv_abi_version(void);
  *   "sweepc_slots" resident-workgroup target that sizes the depth chunks of the 8|16 -> 8 depth-sweep conv (0 = 768)
  *   "sweepc_pd" prefetch distance in iterations (1..3) of the same kernel (0 = 1)
  *   "sweep_th16" 1: the 32->8 depth-sweep conv uses 16-row tiles / 512 threads; 0 (default): 8-row tiles / 256 threads
+ *   "sweep_kdm" 1: the 32->8 depth-sweep conv runs the kd-in-rows formulation (32x32x16 MFMAs whose rows hold the three depth
+ *               taps; one input plane per iteration, 3-slot ring, three workgroups per CU) with depth chunks sized for 768 resident
+ *               workgroups; 2: sized for 1024; 0 (default): the plane-pair kernel.  Same products, another fp32 summation order
+ *               (1e-4 apart before the 16-bit store).  "sweep_kdm_pd": planes in flight per workgroup of that kernel, 1 (default) | 2
  *   "warp_bwd_direct" 1: pscv_warp_cost_bwd issues one global float atomic per tap; 0 (default): accumulates per-workgroup
  *               LDS patches and flushes them coalesced
  *   "c1_sweep"  1 (default): 1-channel heads with 8 input channels and at least three 6-plane blocks per depth chunk run the
