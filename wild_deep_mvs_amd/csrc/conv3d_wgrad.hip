@@ -45,9 +45,13 @@ struct WgradArgs {
     int ntz, nty, ntx, ntiles;
 };
 
+// P2D (TZ = 1): single-plane volumes, i.e. the 2-D layers of the feature extractors run as D = 1: the z taps 0 and 2 only ever meet
+// zero padding, so one Q plane is staged, the waves split the 9 (ty, tx) taps of kernel slice tz = 1, and the tile is 8 rows of
+// one plane instead of 4 rows of two (with D = 1 half of a two-plane tile is padding): 6x fewer MFMAs per pixel.
 template <int S, int TZ, int TY, int NB> struct WgGeom {
+    static constexpr bool P2D = TZ == 1;
     static constexpr int NV = TZ * TY * 16;                 // P voxels per tile
-    static constexpr int QZ = S * (TZ - 1) + 3, QY = S * (TY - 1) + 3, QX = S * 15 + 3;
+    static constexpr int QZ = P2D ? 1 : S * (TZ - 1) + 3, QY = S * (TY - 1) + 3, QX = S * 15 + 3;
     static constexpr int PAS = NV * 2 + 16;                 // bytes per P channel row (odd number of 16-byte slots)
     static constexpr int QBS = QZ * QY * 32 + 16;           // bytes per Q channel block
     static constexpr int QTS = 16 * NB * QBS;               // bytes per x-tap copy of Q
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
             constexpr int CCH = 2 * NB;                         // 8-channel chunks of this block's b slice
             constexpr int NCH = G::QZ * G::QY * G::QX * CCH;
             constexpr int BATCH = 4;
-            const int oz = S * z0 - 1, oy = S * y0 - 1, ox0 = S * x0 - 1;
+            const int oz = G::P2D ? S * z0 : S * z0 - 1, oy = S * y0 - 1, ox0 = S * x0 - 1;
             for (int c0 = 0; c0 < NCH; c0 += 256 * BATCH) {
                 uint4 val[BATCH];
 #pragma unroll
@@ -155,11 +159,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
             const int x8 = chunk & 1, yl = (chunk >> 1) % TY, zl = (chunk >> 1) / TY;
             const uint4 af = *reinterpret_cast<const uint4*>(p_lds + n * G::PAS + ((zl * TY + yl) * 16 + x8 * 8) * 2);
 #pragma unroll
-            for (int ti = 0; ti < 7; ++ti) {
-                const int tap = wave + 4 * ti;
-                if (tap < 27) {
+            for (int ti = 0; ti < (G::P2D ? 3 : 7); ++ti) {
+                const int tap = G::P2D ? 9 + wave + 4 * ti : wave + 4 * ti;        // P2D: the nine taps of kernel slice tz = 1
+                if (tap < (G::P2D ? 18 : 27)) {
                     const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
-                    const unsigned char* qrow = q_lds + tx * G::QTS + (((S * zl + tz) * G::QY + (S * yl + ty)) * 16 + x8 * 8) * 2;
+                    const int qz = G::P2D ? 0 : S * zl + tz;
+                    const unsigned char* qrow = q_lds + tx * G::QTS + ((qz * G::QY + (S * yl + ty)) * 16 + x8 * 8) * 2;
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {
                         const uint4 bf = *reinterpret_cast<const uint4*>(qrow + (nb * 16 + n) * G::QBS);
@@ -174,9 +179,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     // ---- partial sums of this workgroup: part[blockIdx.x][tap][a][b] (lane (n, g) holds a = 4g..4g+3, b = n) ----
     float* part = a.part + (long)blockIdx.x * 27 * a.ca16 * a.cb16;
 #pragma unroll
-    for (int ti = 0; ti < 7; ++ti) {
-        const int tap = wave + 4 * ti;
-        if (tap < 27) {
+    for (int ti = 0; ti < (G::P2D ? 3 : 7); ++ti) {
+        const int tap = G::P2D ? 9 + wave + 4 * ti : wave + 4 * ti;
+        if (tap < (G::P2D ? 18 : 27)) {
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -190,7 +195,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
 // nblk / 16 partials, then the slices are combined through LDS in slice order): the per-output chain of dependent L2 reads
 // is 16x shorter than one thread per output.
 __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restrict__ part, int nblk, int ca, int cb, int ca16, int cb16,
-                                                           float* __restrict__ dw, int accumulate) {
+                                                           float* __restrict__ dw, int accumulate, int plane2d) {
     __shared__ float red[16][17];
     const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
     const int i = blockIdx.x * 16 + c;
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restri
     const int b = i % cb, r_ = i / cb;
     const int aa = r_ % ca, t = r_ / ca;
     const int o = (aa * cb + b) * 27 + t;         // dw[a][b][t]
-    if (i < n) {
+    if (i < n && !(plane2d && t / 9 != 1)) {        // (single-plane volumes: only kernel slice tz = 1 was computed, the others are zero)
         const long off = ((long)t * ca16 + aa) * cb16 + b;
         const long stride = 27L * ca16 * cb16;
         int k = g;
@@ -225,6 +230,7 @@ struct WgPlan { int tz, ty, nb, ntz, nty, ntx, ntiles, nblk, ny, ca16, cb16; };
 static WgPlan wgrad_plan(int B, int Dp, int Hp, int Wp, int ca, int cb, int stride) {
     WgPlan p;
     p.tz = 2; p.ty = stride == 1 ? 4 : 2;
+    if (Dp == 1 && stride == 1) { p.tz = 1; p.ty = 8; }          // 2-D layers (P2D)
     p.ca16 = wg_ceil(ca, 16) * 16; p.cb16 = wg_ceil(cb, 16) * 16;
     p.nb = (p.cb16 % 32 == 0) ? 2 : 1;
     p.ntz = wg_ceil(Dp, p.tz); p.nty = wg_ceil(Hp, p.ty); p.ntx = wg_ceil(Wp, 16);
@@ -284,14 +290,15 @@ extern "C" int pscv_conv3d_wgrad(const void* p, int p_cstride, int p_coff, int c
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int rc;
 #define PSCV_WG(HT)                                                                       \
-    if (stride == 1) rc = pl.nb == 2 ? wgrad_launch<HT, 1, 2, 4, 2>(a, pl, st) : wgrad_launch<HT, 1, 2, 4, 1>(a, pl, st); \
+    if (pl.tz == 1) rc = pl.nb == 2 ? wgrad_launch<HT, 1, 1, 8, 2>(a, pl, st) : wgrad_launch<HT, 1, 1, 8, 1>(a, pl, st); \
+    else if (stride == 1) rc = pl.nb == 2 ? wgrad_launch<HT, 1, 2, 4, 2>(a, pl, st) : wgrad_launch<HT, 1, 2, 4, 1>(a, pl, st); \
     else rc = pl.nb == 2 ? wgrad_launch<HT, 2, 2, 2, 2>(a, pl, st) : wgrad_launch<HT, 2, 2, 2, 1>(a, pl, st);
     if (dtype == PSCV_BF16) { PSCV_WG(bf16_t) } else { PSCV_WG(f16_t) }
 #undef PSCV_WG
     if (rc) return rc;
     PSCV_CHECK_LAUNCH("pscv_conv3d_wgrad");
     const int n = 27 * ca * cb;
-    hipLaunchKernelGGL(wgrad_finish_kernel, dim3((n + 15) / 16), dim3(256), 0, st, workspace, pl.nblk, ca, cb, pl.ca16, pl.cb16, dw, accumulate);
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3((n + 15) / 16), dim3(256), 0, st, workspace, pl.nblk, ca, cb, pl.ca16, pl.cb16, dw, accumulate, pl.tz == 1 ? 1 : 0);
     PSCV_CHECK_LAUNCH("pscv_conv3d_wgrad(finish)");
     return 0;
 }
