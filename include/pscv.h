@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PSCV_ABI_VERSION 5
+#define PSCV_ABI_VERSION 6
 
 /* storage dtypes */
 #define PSCV_F32 0
@@ -400,6 +400,32 @@ int pscv_bn_bwd_reduce(const void* dact, const void* y, int dtype, long nvox, in
 int pscv_bn_bwd_apply(const void* dact, const void* y, int dtype, long nvox, int C, const float* scale,
                       const float* bias, int relu, const float* ca, const float* cb, const float* cc, void* dy,
                       void* stream);
+
+/*
+ * Grouped forms of the six BatchNorm entry points above (ABI 6): the tensor is `groups` consecutive slices of `nvox` voxels, and
+ * every slice has its OWN batch statistics and constants -- the views of a 2-D extractor batch, which the reference normalises
+ * one view at a time (models/MVSNet/model.py:101-107: `self.feature(img)` per view in train()), in one launch per pass.
+ *   pscv_bn_stats_grouped / pscv_bn_bwd_reduce_grouped   sums fp32 [groups][2][C]
+ *   pscv_bn_finalize_grouped    out fp32 [groups][4][C] = (scale, bias, mean, invstd) per group; the running statistics are updated
+ *                               once per group IN ORDER (the module saw `groups` forward calls), num_batches_tracked += groups
+ *   pscv_bn_bwd_coeffs_grouped  out fp32 [groups][5][C]; mean / invstd of group g at mean + g * stat_stride floats
+ *   pscv_bn_act_grouped / _bwd_reduce_grouped / _bwd_apply_grouped   constants of group g at scale + g * param_stride floats
+ *                               (ca / cb / cc: + g * coeff_stride); with finalize's layout param_stride = 4 C, coeff_stride = 5 C
+ * groups = 1 (strides unused) is exactly the plain form; d gamma / d beta of a shared BatchNorm are the sums over the groups.
+ */
+int pscv_bn_stats_grouped(const void* y, int dtype, long nvox, int groups, int C, float* workspace, float* sums, void* stream);
+int pscv_bn_finalize_grouped(const float* sums, long nvox, int groups, int C, const float* gamma, const float* beta, float eps,
+                             float momentum, float* running_mean, float* running_var, long long* num_batches_tracked, float* out,
+                             void* stream);
+int pscv_bn_act_grouped(const void* y, int dtype, long nvox, int groups, int C, const float* scale, const float* bias,
+                        int param_stride, int relu, const void* skip, void* out, void* stream);
+int pscv_bn_bwd_reduce_grouped(const void* dact, const void* y, int dtype, long nvox, int groups, int C, const float* scale,
+                               const float* bias, int param_stride, int relu, float* workspace, float* sums, void* stream);
+int pscv_bn_bwd_coeffs_grouped(const float* sums, const float* mean, const float* invstd, int stat_stride, const float* gamma,
+                               long nvox, int groups, int C, float* out, void* stream);
+int pscv_bn_bwd_apply_grouped(const void* dact, const void* y, int dtype, long nvox, int groups, int C, const float* scale,
+                              const float* bias, int param_stride, int relu, const float* ca, const float* cb, const float* cc,
+                              int coeff_stride, void* dy, void* stream);
 
 /*
  * Backward of softmax over D + the regression heads (models/MVSNet/model.py:207-209, module.py:174-178;

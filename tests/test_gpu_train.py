@@ -802,7 +802,7 @@ def test_feature_net_fn_against_module_autograd(dtype):
     gen = torch.Generator().manual_seed(4)
     img = torch.rand(2, 3, 64, 96, generator=gen).cuda()
     gout = torch.randn(2, 32, 16, 24, generator=gen).cuda()
-    out = T.FeatureNetFn.apply(fa, dtype, img, *T.FeatureNetFn.params(fa))
+    out = T.FeatureNetFn.apply(fa, dtype, 1, img, *T.FeatureNetFn.params(fa))
     out.backward(gout.permute(0, 2, 3, 1).to(dtype).contiguous())
     ref = fb(img)
     ref.backward(gout)
@@ -815,6 +815,43 @@ def test_feature_net_fn_against_module_autograd(dtype):
     for (k, a), (_, b_) in zip(fa.state_dict().items(), fb.state_dict().items()):
         if "running_" in k:
             check_close(f"stat {k}", a.cpu(), b_.cpu(), rel_l2=3e-2 if bf else 4e-3)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_feature_net_fn_grouped_equals_per_view_calls(dtype):
+    """All views of a sample in ONE FeatureNetFn pass (groups = views: pscv_bn_*_grouped, every view normalised with its own batch
+    statistics) against one pass per view on a copy of the module, the way the reference drives its extractor
+    (models/MVSNet/model.py:101-107): the same features per view bit for bit (same kernels per image, per-group statistics summed in
+    the same order), the running statistics after the V sequential updates, and every parameter gradient (sums over the views:
+    fp32 summation order differs, 1e-5)."""
+    from wild_deep_mvs_amd import synthetic, training as T
+    from wild_deep_mvs_amd.models.MVSNet.model import MVSNet
+    import copy
+    net = MVSNet("variance")
+    net.load_state_dict(synthetic.train_state_dict("mvsnet", synthetic.template_of(net), seed=0))
+    fa = net.feature.cuda().train()
+    fb = copy.deepcopy(fa)
+    nbt0 = int(fa.conv0.bn.num_batches_tracked)
+    gen = torch.Generator().manual_seed(9)
+    V, B = 3, 2
+    imgs = [torch.rand(B, 3, 40, 72, generator=gen).cuda() for _ in range(V)]
+    gouts = [torch.randn(B, 10, 18, 32, generator=gen).to(dtype).cuda() for _ in range(V)]
+    out = T.FeatureNetFn.apply(fa, dtype, V, torch.cat(imgs, 0), *T.FeatureNetFn.params(fa))
+    out.backward(torch.cat(gouts, 0))
+    refs = []
+    for img, go in zip(imgs, gouts):
+        o = T.FeatureNetFn.apply(fb, dtype, 1, img, *T.FeatureNetFn.params(fb))
+        o.backward(go)
+        refs.append(o.detach())
+    torch.cuda.synchronize()
+    assert torch.equal(out.detach(), torch.cat(refs, 0)), "grouped features differ from the per-view passes"
+    for (k, a), (_, b_) in zip(fa.state_dict().items(), fb.state_dict().items()):
+        if "running_" in k:
+            check_close(f"stat {k}", a.float().cpu(), b_.float().cpu(), rel_l2=1e-6)
+        if "num_batches_tracked" in k:
+            assert int(a) == int(b_) == nbt0 + V
+    for (k, pa), (_, pb) in zip(fa.named_parameters(), fb.named_parameters()):
+        check_close(f"grad {k}", pa.grad.float().cpu(), pb.grad.float().cpu(), rel_l2=2e-5)
 
 
 @pytest.mark.parametrize("dtype", DT)

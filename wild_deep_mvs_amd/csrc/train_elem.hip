@@ -48,6 +48,8 @@ __device__ __forceinline__ void block_reduce2(const float (&s0)[8], const float 
 // version used one thread per output walking all 1024 rows: 70 us of dependent L2 latency per call.)
 __global__ __launch_bounds__(256) void finish_partials_kernel(const float* __restrict__ partials, int nblk, int n, float* __restrict__ out) {
     __shared__ float red[16][17];
+    partials += (long)blockIdx.y * nblk * n;     // groups (blockIdx.y): each has its own run of partial rows and its own output row
+    out += (long)blockIdx.y * n;
     const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
     const int i = blockIdx.x * 16 + c;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -72,6 +74,10 @@ __global__ __launch_bounds__(256) void finish_partials_kernel(const float* __res
 // ---- batch statistics: sum and sum of squares per channel ---------------------------------------------------------
 template <typename H, int CG>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const uint4* __restrict__ y, long nchunk, float* __restrict__ partials, int C) {
+    // groups (blockIdx.y): the statistics of group g cover chunks [g nchunk, (g + 1) nchunk) -- the views of a 2-D extractor batch,
+    // each normalised with its own batch statistics like the reference's per-view calls (models/MVSNet/model.py:101-107)
+    y += (long)blockIdx.y * nchunk;
+    partials += (long)blockIdx.y * gridDim.x * 2 * C;
     float s0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const long stride = (long)gridDim.x * 256;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nchunk; i += stride) {
@@ -87,8 +93,11 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const uint4* __restrict__
 template <typename H>
 __global__ __launch_bounds__(256) void bn_act_kernel(const uint4* __restrict__ y, const float* __restrict__ scale,
                                                      const float* __restrict__ bias, const uint4* __restrict__ skip,
-                                                     uint4* __restrict__ out, long nchunk, int CG, int relu) {
+                                                     uint4* __restrict__ out, long nchunk, int CG, int relu, int pstride) {
     const int cg = threadIdx.x % CG;   // 256 and the grid stride are multiples of CG
+    y += (long)blockIdx.y * nchunk; out += (long)blockIdx.y * nchunk;           // groups: own slice, own constants
+    if (skip) skip += (long)blockIdx.y * nchunk;
+    scale += (long)blockIdx.y * pstride; bias += (long)blockIdx.y * pstride;
     float sc[8], bi[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { sc[j] = scale[cg * 8 + j]; bi[j] = bias[cg * 8 + j]; }
@@ -134,8 +143,11 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const uint4* __restrict__
 template <typename H, int CG>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint4* __restrict__ dact, const uint4* __restrict__ y,
                                                             const float* __restrict__ scale, const float* __restrict__ bias,
-                                                            long nchunk, float* __restrict__ partials, int C, int relu) {
+                                                            long nchunk, float* __restrict__ partials, int C, int relu, int pstride) {
     const int cg = threadIdx.x % CG;
+    dact += (long)blockIdx.y * nchunk; y += (long)blockIdx.y * nchunk;
+    scale += (long)blockIdx.y * pstride; bias += (long)blockIdx.y * pstride;
+    partials += (long)blockIdx.y * gridDim.x * 2 * C;
     float sc[8], bi[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { sc[j] = scale[cg * 8 + j]; bi[j] = bias[cg * 8 + j]; }
@@ -162,8 +174,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint4* __restri
                                                            const float* __restrict__ scale, const float* __restrict__ bias,
                                                            const float* __restrict__ ca, const float* __restrict__ cb,
                                                            const float* __restrict__ cc, uint4* __restrict__ dy, long nchunk,
-                                                           int CG, int relu) {
+                                                           int CG, int relu, int pstride, int cstride) {
     const int cg = threadIdx.x % CG;
+    dact += (long)blockIdx.y * nchunk; y += (long)blockIdx.y * nchunk; dy += (long)blockIdx.y * nchunk;
+    scale += (long)blockIdx.y * pstride; bias += (long)blockIdx.y * pstride;
+    ca += (long)blockIdx.y * cstride; cb += (long)blockIdx.y * cstride; cc += (long)blockIdx.y * cstride;
     float sc[8], bi[8], a[8], b[8], c[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -246,28 +261,33 @@ static int red_grid_for(long nchunk) {
 // (a Vis-MVSNet training step has 75 BatchNorm applications: ~2000 launches of 8-64-element ATen kernels were 10 % of its wall time) ----
 __global__ void bn_finalize_kernel(const float* __restrict__ sums, float nvox, const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float eps, float momentum, float* __restrict__ run_mean, float* __restrict__ run_var,
-                                   long long* __restrict__ batches, float* __restrict__ out, int C) {
+                                   long long* __restrict__ batches, float* __restrict__ out, int C, int groups) {
     const int c = threadIdx.x;
-    if (c == 0 && batches) *batches += 1;
+    if (c == 0 && batches) *batches += groups;
     if (c >= C) return;
-    const float mean = sums[c] / nvox;
-    const float var = fmaxf(sums[C + c] / nvox - mean * mean, 0.0f);
-    const float invstd = 1.0f / sqrtf(var + eps);
-    const float scale = (gamma ? gamma[c] : 1.0f) * invstd;
-    out[c] = scale;
-    out[C + c] = (beta ? beta[c] : 0.0f) - mean * scale;
-    out[2 * C + c] = mean;
-    out[3 * C + c] = invstd;
-    if (run_mean) {      // nn.BatchNorm3d in train(): running = (1 - m) running + m batch, unbiased variance
-        run_mean[c] = run_mean[c] * (1.0f - momentum) + mean * momentum;
-        run_var[c] = run_var[c] * (1.0f - momentum) + var * (nvox / fmaxf(nvox - 1.0f, 1.0f)) * momentum;
+    // groups in order: the module saw them as consecutive forward calls (one per view), each updating the running statistics
+    for (int g = 0; g < groups; ++g, sums += 2 * C, out += 4 * C) {
+        const float mean = sums[c] / nvox;
+        const float var = fmaxf(sums[C + c] / nvox - mean * mean, 0.0f);
+        const float invstd = 1.0f / sqrtf(var + eps);
+        const float scale = (gamma ? gamma[c] : 1.0f) * invstd;
+        out[c] = scale;
+        out[C + c] = (beta ? beta[c] : 0.0f) - mean * scale;
+        out[2 * C + c] = mean;
+        out[3 * C + c] = invstd;
+        if (run_mean) {      // nn.BatchNorm3d in train(): running = (1 - m) running + m batch, unbiased variance
+            run_mean[c] = run_mean[c] * (1.0f - momentum) + mean * momentum;
+            run_var[c] = run_var[c] * (1.0f - momentum) + var * (nvox / fmaxf(nvox - 1.0f, 1.0f)) * momentum;
+        }
     }
 }
 
 __global__ void bn_bwd_coeffs_kernel(const float* __restrict__ s, const float* __restrict__ mean, const float* __restrict__ invstd,
-                                     const float* __restrict__ gamma, float nvox, float* __restrict__ out, int C) {
+                                     const float* __restrict__ gamma, float nvox, float* __restrict__ out, int C, int mstride) {
     const int c = threadIdx.x;
     if (c >= C) return;
+    s += (long)blockIdx.x * 2 * C; out += (long)blockIdx.x * 5 * C;               // groups (blockIdx.x)
+    mean += (long)blockIdx.x * mstride; invstd += (long)blockIdx.x * mstride;
     const float s1 = s[c];                                        // sum dz       = d beta
     const float s2 = invstd[c] * (s[C + c] - mean[c] * s1);       // sum dz xhat  = d gamma
     const float k = (gamma ? gamma[c] : 1.0f) * invstd[c];
@@ -284,88 +304,115 @@ using namespace pscv;
 
 extern "C" long pscv_train_workspace_floats(void) { return (long)RED_BLOCKS * 2 * 64; }
 
-extern "C" int pscv_bn_stats(const void* y, int dtype, long nvox, int C, float* workspace, float* sums, void* stream) {
-    PSCV_CHECK_ARG(y && workspace && sums, "pscv_bn_stats: null pointer argument");
-    PSCV_CHECK_ARG(C == 8 || C == 16 || C == 32 || C == 64, "pscv_bn_stats: C=%d must be 8, 16, 32 or 64", C);
-    PSCV_CHECK_ARG(dtype == PSCV_BF16 || dtype == PSCV_F16, "pscv_bn_stats: dtype %d must be bf16 or fp16", dtype);
-    PSCV_CHECK_ARG(nvox > 0, "pscv_bn_stats: empty volume");
+// ---- grouped forms: `groups` consecutive slices of nvox voxels each, every group with its own statistics / constants (the views of
+// a 2-D extractor batch, normalised per view like the reference's per-view calls, models/MVSNet/model.py:101-107).  Constants of
+// group g start `param_stride` floats after those of group g - 1 (pscv_bn_finalize_grouped writes [groups][4][C]:
+// scale, bias, mean, invstd; pscv_bn_bwd_coeffs_grouped [groups][5][C]: ca, cb, cc, d gamma, d beta).  groups = 1 is the plain form.
+static int bn_check(const char* fn, const void* y, int dtype, long nvox, int groups, int C) {
+    PSCV_CHECK_ARG(y, "%s: null pointer argument", fn);
+    PSCV_CHECK_ARG(C == 8 || C == 16 || C == 32 || C == 64, "%s: C=%d must be 8, 16, 32 or 64", fn, C);
+    PSCV_CHECK_ARG(dtype == PSCV_BF16 || dtype == PSCV_F16, "%s: dtype %d must be bf16 or fp16", fn, dtype);
+    PSCV_CHECK_ARG(nvox > 0 && groups >= 1 && groups <= 256, "%s: empty volume or bad group count %d", fn, groups);
+    return 0;
+}
+static int red_grid_grouped(long nchunk, int groups) {
+    int nb = red_grid_for(nchunk);
+    const int cap = RED_BLOCKS / groups;           // the workspace holds RED_BLOCKS partial rows in total
+    return nb > cap ? (cap < 1 ? 1 : cap) : nb;
+}
+
+extern "C" int pscv_bn_stats_grouped(const void* y, int dtype, long nvox, int groups, int C, float* workspace, float* sums, void* stream) {
+    if (bn_check("pscv_bn_stats", y, dtype, nvox, groups, C)) return -1;
+    PSCV_CHECK_ARG(workspace && sums, "pscv_bn_stats: null pointer argument");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const long nchunk = nvox * (C / 8);
-    const int nb = red_grid_for(nchunk);
+    const int nb = red_grid_grouped(nchunk, groups);
     const uint4* yp = reinterpret_cast<const uint4*>(y);
+    const dim3 grid(nb, groups);
 #define PSCV_STATS(HT)                                                                                     \
     switch (C / 8) {                                                                                       \
-        case 1: hipLaunchKernelGGL((bn_stats_kernel<HT, 1>), dim3(nb), dim3(256), 0, st, yp, nchunk, workspace, C); break; \
-        case 2: hipLaunchKernelGGL((bn_stats_kernel<HT, 2>), dim3(nb), dim3(256), 0, st, yp, nchunk, workspace, C); break; \
-        case 4: hipLaunchKernelGGL((bn_stats_kernel<HT, 4>), dim3(nb), dim3(256), 0, st, yp, nchunk, workspace, C); break; \
-        default: hipLaunchKernelGGL((bn_stats_kernel<HT, 8>), dim3(nb), dim3(256), 0, st, yp, nchunk, workspace, C); break; \
+        case 1: hipLaunchKernelGGL((bn_stats_kernel<HT, 1>), grid, dim3(256), 0, st, yp, nchunk, workspace, C); break; \
+        case 2: hipLaunchKernelGGL((bn_stats_kernel<HT, 2>), grid, dim3(256), 0, st, yp, nchunk, workspace, C); break; \
+        case 4: hipLaunchKernelGGL((bn_stats_kernel<HT, 4>), grid, dim3(256), 0, st, yp, nchunk, workspace, C); break; \
+        default: hipLaunchKernelGGL((bn_stats_kernel<HT, 8>), grid, dim3(256), 0, st, yp, nchunk, workspace, C); break; \
     }
     if (dtype == PSCV_BF16) { PSCV_STATS(bf16_t) } else { PSCV_STATS(f16_t) }
 #undef PSCV_STATS
     PSCV_CHECK_LAUNCH("pscv_bn_stats");
-    hipLaunchKernelGGL(finish_partials_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, st, workspace, nb, 2 * C, sums);
+    hipLaunchKernelGGL(finish_partials_kernel, dim3((2 * C + 15) / 16, groups), dim3(256), 0, st, workspace, nb, 2 * C, sums);
     PSCV_CHECK_LAUNCH("pscv_bn_stats(finish)");
     return 0;
 }
+extern "C" int pscv_bn_stats(const void* y, int dtype, long nvox, int C, float* workspace, float* sums, void* stream) {
+    return pscv_bn_stats_grouped(y, dtype, nvox, 1, C, workspace, sums, stream);
+}
 
-extern "C" int pscv_bn_act(const void* y, int dtype, long nvox, int C, const float* scale, const float* bias, int relu,
-                           const void* skip, void* out, void* stream) {
-    PSCV_CHECK_ARG(y && scale && bias && out, "pscv_bn_act: null pointer argument");
-    PSCV_CHECK_ARG(C == 8 || C == 16 || C == 32 || C == 64, "pscv_bn_act: C=%d must be 8, 16, 32 or 64", C);
-    PSCV_CHECK_ARG(dtype == PSCV_BF16 || dtype == PSCV_F16, "pscv_bn_act: dtype %d must be bf16 or fp16", dtype);
-    PSCV_CHECK_ARG(nvox > 0, "pscv_bn_act: empty volume");
+extern "C" int pscv_bn_act_grouped(const void* y, int dtype, long nvox, int groups, int C, const float* scale, const float* bias,
+                                   int param_stride, int relu, const void* skip, void* out, void* stream) {
+    if (bn_check("pscv_bn_act", y, dtype, nvox, groups, C)) return -1;
+    PSCV_CHECK_ARG(scale && bias && out, "pscv_bn_act: null pointer argument");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const long nchunk = nvox * (C / 8);
-    const int nb = grid_for(nchunk);
+    const dim3 grid(grid_for(nchunk), groups);
     if (dtype == PSCV_BF16)
-        hipLaunchKernelGGL(bn_act_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const uint4*)y, scale, bias, (const uint4*)skip, (uint4*)out, nchunk, C / 8, relu);
+        hipLaunchKernelGGL(bn_act_kernel<bf16_t>, grid, dim3(256), 0, st, (const uint4*)y, scale, bias, (const uint4*)skip, (uint4*)out, nchunk, C / 8, relu, param_stride);
     else
-        hipLaunchKernelGGL(bn_act_kernel<f16_t>, dim3(nb), dim3(256), 0, st, (const uint4*)y, scale, bias, (const uint4*)skip, (uint4*)out, nchunk, C / 8, relu);
+        hipLaunchKernelGGL(bn_act_kernel<f16_t>, grid, dim3(256), 0, st, (const uint4*)y, scale, bias, (const uint4*)skip, (uint4*)out, nchunk, C / 8, relu, param_stride);
     PSCV_CHECK_LAUNCH("pscv_bn_act");
     return 0;
 }
+extern "C" int pscv_bn_act(const void* y, int dtype, long nvox, int C, const float* scale, const float* bias, int relu,
+                           const void* skip, void* out, void* stream) {
+    return pscv_bn_act_grouped(y, dtype, nvox, 1, C, scale, bias, 0, relu, skip, out, stream);
+}
 
-extern "C" int pscv_bn_bwd_reduce(const void* dact, const void* y, int dtype, long nvox, int C, const float* scale,
-                                  const float* bias, int relu, float* workspace, float* sums, void* stream) {
-    PSCV_CHECK_ARG(dact && y && scale && bias && workspace && sums, "pscv_bn_bwd_reduce: null pointer argument");
-    PSCV_CHECK_ARG(C == 8 || C == 16 || C == 32 || C == 64, "pscv_bn_bwd_reduce: C=%d must be 8, 16, 32 or 64", C);
-    PSCV_CHECK_ARG(dtype == PSCV_BF16 || dtype == PSCV_F16, "pscv_bn_bwd_reduce: dtype %d must be bf16 or fp16", dtype);
-    PSCV_CHECK_ARG(nvox > 0, "pscv_bn_bwd_reduce: empty volume");
+extern "C" int pscv_bn_bwd_reduce_grouped(const void* dact, const void* y, int dtype, long nvox, int groups, int C, const float* scale,
+                                          const float* bias, int param_stride, int relu, float* workspace, float* sums, void* stream) {
+    if (bn_check("pscv_bn_bwd_reduce", y, dtype, nvox, groups, C)) return -1;
+    PSCV_CHECK_ARG(dact && scale && bias && workspace && sums, "pscv_bn_bwd_reduce: null pointer argument");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const long nchunk = nvox * (C / 8);
-    const int nb = red_grid_for(nchunk);
+    const int nb = red_grid_grouped(nchunk, groups);
+    const dim3 grid(nb, groups);
     const uint4 *gp = (const uint4*)dact, *yp = (const uint4*)y;
 #define PSCV_RED(HT)                                                                                                              \
     switch (C / 8) {                                                                                                              \
-        case 1: hipLaunchKernelGGL((bn_bwd_reduce_kernel<HT, 1>), dim3(nb), dim3(256), 0, st, gp, yp, scale, bias, nchunk, workspace, C, relu); break; \
-        case 2: hipLaunchKernelGGL((bn_bwd_reduce_kernel<HT, 2>), dim3(nb), dim3(256), 0, st, gp, yp, scale, bias, nchunk, workspace, C, relu); break; \
-        case 4: hipLaunchKernelGGL((bn_bwd_reduce_kernel<HT, 4>), dim3(nb), dim3(256), 0, st, gp, yp, scale, bias, nchunk, workspace, C, relu); break; \
-        default: hipLaunchKernelGGL((bn_bwd_reduce_kernel<HT, 8>), dim3(nb), dim3(256), 0, st, gp, yp, scale, bias, nchunk, workspace, C, relu); break; \
+        case 1: hipLaunchKernelGGL((bn_bwd_reduce_kernel<HT, 1>), grid, dim3(256), 0, st, gp, yp, scale, bias, nchunk, workspace, C, relu, param_stride); break; \
+        case 2: hipLaunchKernelGGL((bn_bwd_reduce_kernel<HT, 2>), grid, dim3(256), 0, st, gp, yp, scale, bias, nchunk, workspace, C, relu, param_stride); break; \
+        case 4: hipLaunchKernelGGL((bn_bwd_reduce_kernel<HT, 4>), grid, dim3(256), 0, st, gp, yp, scale, bias, nchunk, workspace, C, relu, param_stride); break; \
+        default: hipLaunchKernelGGL((bn_bwd_reduce_kernel<HT, 8>), grid, dim3(256), 0, st, gp, yp, scale, bias, nchunk, workspace, C, relu, param_stride); break; \
     }
     if (dtype == PSCV_BF16) { PSCV_RED(bf16_t) } else { PSCV_RED(f16_t) }
 #undef PSCV_RED
     PSCV_CHECK_LAUNCH("pscv_bn_bwd_reduce");
-    hipLaunchKernelGGL(finish_partials_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, st, workspace, nb, 2 * C, sums);
+    hipLaunchKernelGGL(finish_partials_kernel, dim3((2 * C + 15) / 16, groups), dim3(256), 0, st, workspace, nb, 2 * C, sums);
     PSCV_CHECK_LAUNCH("pscv_bn_bwd_reduce(finish)");
     return 0;
 }
+extern "C" int pscv_bn_bwd_reduce(const void* dact, const void* y, int dtype, long nvox, int C, const float* scale,
+                                  const float* bias, int relu, float* workspace, float* sums, void* stream) {
+    return pscv_bn_bwd_reduce_grouped(dact, y, dtype, nvox, 1, C, scale, bias, 0, relu, workspace, sums, stream);
+}
 
+extern "C" int pscv_bn_bwd_apply_grouped(const void* dact, const void* y, int dtype, long nvox, int groups, int C, const float* scale,
+                                         const float* bias, int param_stride, int relu, const float* ca, const float* cb, const float* cc,
+                                         int coeff_stride, void* dy, void* stream) {
+    if (bn_check("pscv_bn_bwd_apply", y, dtype, nvox, groups, C)) return -1;
+    PSCV_CHECK_ARG(dact && scale && bias && ca && cb && cc && dy, "pscv_bn_bwd_apply: null pointer argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const long nchunk = nvox * (C / 8);
+    const dim3 grid(grid_for(nchunk), groups);
+    if (dtype == PSCV_BF16)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, grid, dim3(256), 0, st, (const uint4*)dact, (const uint4*)y, scale, bias, ca, cb, cc, (uint4*)dy, nchunk, C / 8, relu, param_stride, coeff_stride);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<f16_t>, grid, dim3(256), 0, st, (const uint4*)dact, (const uint4*)y, scale, bias, ca, cb, cc, (uint4*)dy, nchunk, C / 8, relu, param_stride, coeff_stride);
+    PSCV_CHECK_LAUNCH("pscv_bn_bwd_apply");
+    return 0;
+}
 extern "C" int pscv_bn_bwd_apply(const void* dact, const void* y, int dtype, long nvox, int C, const float* scale,
                                  const float* bias, int relu, const float* ca, const float* cb, const float* cc, void* dy,
                                  void* stream) {
-    PSCV_CHECK_ARG(dact && y && scale && bias && ca && cb && cc && dy, "pscv_bn_bwd_apply: null pointer argument");
-    PSCV_CHECK_ARG(C == 8 || C == 16 || C == 32 || C == 64, "pscv_bn_bwd_apply: C=%d must be 8, 16, 32 or 64", C);
-    PSCV_CHECK_ARG(dtype == PSCV_BF16 || dtype == PSCV_F16, "pscv_bn_bwd_apply: dtype %d must be bf16 or fp16", dtype);
-    PSCV_CHECK_ARG(nvox > 0, "pscv_bn_bwd_apply: empty volume");
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const long nchunk = nvox * (C / 8);
-    const int nb = grid_for(nchunk);
-    if (dtype == PSCV_BF16)
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const uint4*)dact, (const uint4*)y, scale, bias, ca, cb, cc, (uint4*)dy, nchunk, C / 8, relu);
-    else
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<f16_t>, dim3(nb), dim3(256), 0, st, (const uint4*)dact, (const uint4*)y, scale, bias, ca, cb, cc, (uint4*)dy, nchunk, C / 8, relu);
-    PSCV_CHECK_LAUNCH("pscv_bn_bwd_apply");
-    return 0;
+    return pscv_bn_bwd_apply_grouped(dact, y, dtype, nvox, 1, C, scale, bias, 0, relu, ca, cb, cc, 0, dy, stream);
 }
 
 extern "C" int pscv_softargmin_bwd(const float* logits, const float* depth, long depth_bstride, int depth_per_pixel,
@@ -400,23 +447,32 @@ extern "C" int pscv_relu_bwd(const void* dout, const void* out, int dtype, long 
     return 0;
 }
 
-extern "C" int pscv_bn_finalize(const float* sums, long nvox, int C, const float* gamma, const float* beta, float eps, float momentum,
-                                float* running_mean, float* running_var, long long* num_batches_tracked, float* out, void* stream) {
+extern "C" int pscv_bn_finalize_grouped(const float* sums, long nvox, int groups, int C, const float* gamma, const float* beta, float eps,
+                                        float momentum, float* running_mean, float* running_var, long long* num_batches_tracked,
+                                        float* out, void* stream) {
     using namespace pscv;
-    PSCV_CHECK_ARG(sums && out && nvox > 0 && C > 0 && C <= 1024, "pscv_bn_finalize: bad arguments");
+    PSCV_CHECK_ARG(sums && out && nvox > 0 && C > 0 && C <= 1024 && groups >= 1, "pscv_bn_finalize: bad arguments");
     PSCV_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "pscv_bn_finalize: running_mean and running_var go together");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3((C + 63) / 64 * 64), 0, reinterpret_cast<hipStream_t>(stream), sums, (float)nvox,
-                       gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, out, C);
+                       gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, out, C, groups);
     PSCV_CHECK_LAUNCH("pscv_bn_finalize");
     return 0;
 }
+extern "C" int pscv_bn_finalize(const float* sums, long nvox, int C, const float* gamma, const float* beta, float eps, float momentum,
+                                float* running_mean, float* running_var, long long* num_batches_tracked, float* out, void* stream) {
+    return pscv_bn_finalize_grouped(sums, nvox, 1, C, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, out, stream);
+}
 
-extern "C" int pscv_bn_bwd_coeffs(const float* sums, const float* mean, const float* invstd, const float* gamma, long nvox, int C,
-                                  float* out, void* stream) {
+extern "C" int pscv_bn_bwd_coeffs_grouped(const float* sums, const float* mean, const float* invstd, int stat_stride, const float* gamma,
+                                          long nvox, int groups, int C, float* out, void* stream) {
     using namespace pscv;
-    PSCV_CHECK_ARG(sums && mean && invstd && out && nvox > 0 && C > 0 && C <= 1024, "pscv_bn_bwd_coeffs: bad arguments");
-    hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3(1), dim3((C + 63) / 64 * 64), 0, reinterpret_cast<hipStream_t>(stream), sums, mean, invstd,
-                       gamma, (float)nvox, out, C);
+    PSCV_CHECK_ARG(sums && mean && invstd && out && nvox > 0 && C > 0 && C <= 1024 && groups >= 1, "pscv_bn_bwd_coeffs: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3(groups), dim3((C + 63) / 64 * 64), 0, reinterpret_cast<hipStream_t>(stream), sums, mean, invstd,
+                       gamma, (float)nvox, out, C, stat_stride);
     PSCV_CHECK_LAUNCH("pscv_bn_bwd_coeffs");
     return 0;
+}
+extern "C" int pscv_bn_bwd_coeffs(const float* sums, const float* mean, const float* invstd, const float* gamma, long nvox, int C,
+                                  float* out, void* stream) {
+    return pscv_bn_bwd_coeffs_grouped(sums, mean, invstd, 0, gamma, nvox, 1, C, out, stream);
 }

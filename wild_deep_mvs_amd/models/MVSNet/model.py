@@ -463,8 +463,12 @@ class MVSNet(ReplayHooks, nn.Module):
             # per-view extractor passes like the reference (model.py:101-107): each view normalises with its own batch
             # statistics; the 2-D extractor is upstream of the path and stays on PyTorch-ROCm autograd in training
             if self.feature_engine_train == "pscv":
+                # all views in ONE extractor pass: the views are the group axis of the BatchNorm statistics (each view its own,
+                # like the per-view calls of the reference), convolutions and weight gradients run over the whole stack
                 fparams = T.FeatureNetFn.params(self.feature)
-                feats = [T.FeatureNetFn.apply(self.feature, self.train_storage_dtype, img, *fparams) for img in imgs]
+                stack = torch.cat(list(imgs), 0)
+                fs = T.FeatureNetFn.apply(self.feature, self.train_storage_dtype, len(imgs), stack, *fparams)
+                feats = list(torch.split(fs, imgs[0].shape[0], 0))
             else:
                 feats = [self.feature(img) for img in imgs]
             depth, conf = self.hot_path_train(feats, proj, dv_ref, reference_frame)

@@ -1059,24 +1059,55 @@ def _vol16(x: torch.Tensor, what: str):
                         f"{x.dtype} {tuple(x.shape)}")
 
 
-def bn_stats(y: torch.Tensor) -> torch.Tensor:
-    """y [B,D,h,w,C] 16-bit -> fp32 [2,C]: per-channel sum and sum of squares over all voxels (pscv_bn_stats)."""
+def _group_vox(y: torch.Tensor, groups: int, what: str) -> int:
+    """Voxels per group of a contiguous volume whose leading (batch) axis holds ``groups`` equal consecutive slices."""
+    if groups < 1 or y.shape[0] % groups or not y.is_contiguous():
+        raise ValueError(f"pscv.{what}: {groups} groups need a contiguous volume whose batch axis ({y.shape[0]}) they divide")
+    return y.numel() // y.shape[4] // groups
+
+
+def _dev_rows(*ts: Optional[torch.Tensor]):
+    """Per-channel constants: device tensors whose channel axis is dense (a [C] vector, or [G,C] rows of a larger tensor)."""
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("pscv: the plane-sweep engine runs on MI355X only; got a CPU tensor")
+        if t.stride(-1) != 1 or (t.dim() == 1 and not t.is_contiguous()):
+            raise ValueError("pscv: per-channel constants must be dense along the channel axis")
+
+
+def _row_stride(a: torch.Tensor, b: torch.Tensor, groups: int, Cc: int, what: str, c: Optional[torch.Tensor] = None) -> int:
+    """Per-group constants handed over as [G,C] views of one [G,k,C] tensor: the float stride between groups (the same for all)."""
+    ts = [t for t in (a, b, c) if t is not None]
+    for t in ts:
+        if t.dtype != torch.float32 or t.shape != (groups, Cc) or t.stride(1) != 1 or t.stride(0) != ts[0].stride(0):
+            raise ValueError(f"pscv.{what}: per-group constants must be fp32 [groups,C] rows with one common group stride")
+    return int(ts[0].stride(0))
+
+
+def bn_stats(y: torch.Tensor, groups: int = 1) -> torch.Tensor:
+    """y [B,D,h,w,C] 16-bit -> fp32 [2,C]: per-channel sum and sum of squares over all voxels (pscv_bn_stats).  ``groups`` > 1:
+    the batch axis is ``groups`` consecutive slices with their own statistics (the views of a 2-D extractor batch) -> [groups,2,C]."""
     _dev(y)
     _vol16(y, "bn_stats")
     Cc = y.shape[4]
-    sums = torch.empty((2, Cc), dtype=torch.float32, device=y.device)
+    nv = _group_vox(y, groups, "bn_stats")
+    sums = torch.empty((2, Cc) if groups == 1 else (groups, 2, Cc), dtype=torch.float32, device=y.device)
     ws = _workspace(y.device, 0)
-    rc = _launch("bn_stats", lambda: L.lib().pscv_bn_stats(_p(y), _dt(y), y.numel() // Cc, Cc, _p(ws), _p(sums), _stream()))
+    rc = _launch("bn_stats", lambda: L.lib().pscv_bn_stats_grouped(_p(y), _dt(y), nv, groups, Cc, _p(ws), _p(sums), _stream()))
     L.check(rc, "pscv_bn_stats")
     return sums
 
 
 def bn_finalize(sums: torch.Tensor, nvox: int, bn) -> torch.Tensor:
     """sums fp32 [2,C] of ``bn_stats`` -> fp32 [4,C] = (scale, bias, mean, invstd) of a BatchNorm module in train(); updates its
-    running statistics and ``num_batches_tracked`` like nn.BatchNorm3d (pscv_bn_finalize, one launch)."""
+    running statistics and ``num_batches_tracked`` like nn.BatchNorm3d (pscv_bn_finalize, one launch).  Grouped sums [G,2,C]
+    (``nvox`` per group) -> [G,4,C]; the running statistics are updated once per group, in order, as G forward calls would."""
     _dev(sums)
-    Cc = sums.shape[1]
-    out = torch.empty((4, Cc), dtype=torch.float32, device=sums.device)
+    groups = 1 if sums.dim() == 2 else sums.shape[0]
+    Cc = sums.shape[-1]
+    out = torch.empty((4, Cc) if sums.dim() == 2 else (groups, 4, Cc), dtype=torch.float32, device=sums.device)
     track = bn.track_running_stats and bn.running_mean is not None
     if track and bn.momentum is None:
         raise NotImplementedError("pscv BatchNorm training: cumulative moving average (momentum=None) is not used by the reference")
@@ -1086,20 +1117,25 @@ def bn_finalize(sums: torch.Tensor, nvox: int, bn) -> torch.Tensor:
     if track and (rm.dtype != torch.float32 or rv.dtype != torch.float32):
         raise TypeError("pscv BatchNorm training: fp32 running statistics expected")
     nbt = bn.num_batches_tracked if track else None
-    rc = _launch("bn_finalize", lambda: L.lib().pscv_bn_finalize(_p(sums), int(nvox), Cc, _p(gamma), _p(beta), float(bn.eps),
-                                                                float(bn.momentum if track else 0.0), _p(rm), _p(rv), _p(nbt), _p(out),
-                                                                _stream()))
+    rc = _launch("bn_finalize", lambda: L.lib().pscv_bn_finalize_grouped(_p(sums), int(nvox), groups, Cc, _p(gamma), _p(beta), float(bn.eps),
+                                                                        float(bn.momentum if track else 0.0), _p(rm), _p(rv), _p(nbt), _p(out),
+                                                                        _stream()))
     L.check(rc, "pscv_bn_finalize")
     return out
 
 
 def bn_bwd_coeffs(sums: torch.Tensor, mean: torch.Tensor, invstd: torch.Tensor, gamma: Optional[torch.Tensor], nvox: int) -> torch.Tensor:
-    """sums fp32 [2,C] of ``bn_bwd_reduce`` -> fp32 [5,C] = (ca, cb, cc, d gamma, d beta) (pscv_bn_bwd_coeffs, one launch)."""
-    _dev(sums, mean, invstd, gamma)
-    Cc = sums.shape[1]
-    out = torch.empty((5, Cc), dtype=torch.float32, device=sums.device)
+    """sums fp32 [2,C] of ``bn_bwd_reduce`` -> fp32 [5,C] = (ca, cb, cc, d gamma, d beta) (pscv_bn_bwd_coeffs, one launch).
+    Grouped: sums [G,2,C], ``mean`` / ``invstd`` = rows 2 / 3 of ``bn_finalize``'s [G,4,C] (views) -> [G,5,C]."""
+    _dev(sums, gamma)
+    _dev_rows(mean, invstd)
+    groups = 1 if sums.dim() == 2 else sums.shape[0]
+    Cc = sums.shape[-1]
+    out = torch.empty((5, Cc) if sums.dim() == 2 else (groups, 5, Cc), dtype=torch.float32, device=sums.device)
     g = None if gamma is None else (gamma.detach() if gamma.dtype == torch.float32 else gamma.detach().float())
-    rc = _launch("bn_bwd_coeffs", lambda: L.lib().pscv_bn_bwd_coeffs(_p(sums), _p(mean), _p(invstd), _p(g), int(nvox), Cc, _p(out), _stream()))
+    sst = 0 if groups == 1 else _row_stride(mean, invstd, groups, Cc, "bn_bwd_coeffs")
+    rc = _launch("bn_bwd_coeffs", lambda: L.lib().pscv_bn_bwd_coeffs_grouped(_p(sums), _p(mean), _p(invstd), sst, _p(g), int(nvox), groups, Cc,
+                                                                            _p(out), _stream()))
     L.check(rc, "pscv_bn_bwd_coeffs")
     return out
 
@@ -1107,29 +1143,39 @@ def bn_bwd_coeffs(sums: torch.Tensor, mean: torch.Tensor, invstd: torch.Tensor, 
 def bn_act(y: torch.Tensor, scale: torch.Tensor, bias: torch.Tensor, *, relu, skip: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[relu](y * scale + bias) + skip on a 16-bit channels-last volume (pscv_bn_act).  ``relu``: False / True (before the
     skip add) / "post" (after it: the Vis BasicBlock)."""
-    _dev(y, scale, bias, skip)
+    _dev(y, skip)
+    _dev_rows(scale, bias)
     _vol16(y, "bn_act")
     if skip is not None and (skip.shape != y.shape or skip.dtype != y.dtype):
         raise ValueError("pscv.bn_act: skip must match y")
     Cc = y.shape[4]
+    groups = 1 if scale.dim() == 1 else scale.shape[0]          # grouped: scale / bias [G,C] (rows of bn_finalize's [G,4,C])
+    nv = _group_vox(y, groups, "bn_act") if groups > 1 else y.numel() // Cc
+    pst = 0 if groups == 1 else _row_stride(scale, bias, groups, Cc, "bn_act")
     out = torch.empty_like(y)
-    rc = _launch("bn_act", lambda: L.lib().pscv_bn_act(_p(y), _dt(y), y.numel() // Cc, Cc, _p(scale), _p(bias), 2 if relu == "post" else int(bool(relu)),
-                                                      _p(skip), _p(out), _stream()))
+    rc = _launch("bn_act", lambda: L.lib().pscv_bn_act_grouped(_p(y), _dt(y), nv, groups, Cc, _p(scale), _p(bias), pst,
+                                                              2 if relu == "post" else int(bool(relu)), _p(skip), _p(out), _stream()))
     L.check(rc, "pscv_bn_act")
     return out
 
 
 def bn_bwd_reduce(dact: torch.Tensor, y: torch.Tensor, scale: torch.Tensor, bias: torch.Tensor, *, relu: bool) -> torch.Tensor:
     """fp32 [2,C]: sum dz and sum dz*y with dz = dact * [y*scale+bias > 0] (pscv_bn_bwd_reduce)."""
-    _dev(dact, y, scale, bias)
+    _dev(dact, y)
+    _dev_rows(scale, bias)
     _vol16(y, "bn_bwd_reduce")
     if dact.shape != y.shape or dact.dtype != y.dtype:
         raise ValueError("pscv.bn_bwd_reduce: dact must match y")
     Cc = y.shape[4]
-    sums = torch.empty((2, Cc), dtype=torch.float32, device=y.device)
+    groups = 1 if scale.dim() == 1 else scale.shape[0]
+    nv = _group_vox(y, groups, "bn_bwd_reduce") if groups > 1 else y.numel() // Cc
+    pst = 0 if groups == 1 else _row_stride(scale, bias, groups, Cc, "bn_bwd_reduce")
+    if not dact.is_contiguous():
+        raise ValueError("pscv.bn_bwd_reduce: dact must be contiguous")
+    sums = torch.empty((2, Cc) if scale.dim() == 1 else (groups, 2, Cc), dtype=torch.float32, device=y.device)
     ws = _workspace(y.device, 0)
-    rc = _launch("bn_bwd_reduce", lambda: L.lib().pscv_bn_bwd_reduce(_p(dact), _p(y), _dt(y), y.numel() // Cc, Cc, _p(scale), _p(bias),
-                                                                    int(relu), _p(ws), _p(sums), _stream()))
+    rc = _launch("bn_bwd_reduce", lambda: L.lib().pscv_bn_bwd_reduce_grouped(_p(dact), _p(y), _dt(y), nv, groups, Cc, _p(scale), _p(bias), pst,
+                                                                            int(relu), _p(ws), _p(sums), _stream()))
     L.check(rc, "pscv_bn_bwd_reduce")
     return sums
 
@@ -1137,12 +1183,17 @@ def bn_bwd_reduce(dact: torch.Tensor, y: torch.Tensor, scale: torch.Tensor, bias
 def bn_bwd_apply(dact: torch.Tensor, y: torch.Tensor, scale: torch.Tensor, bias: torch.Tensor, ca: torch.Tensor, cb: torch.Tensor,
                  cc: torch.Tensor, *, relu: bool) -> torch.Tensor:
     """dy = ca * dz + cb * y + cc per channel (pscv_bn_bwd_apply)."""
-    _dev(dact, y, scale, bias, ca, cb, cc)
+    _dev(dact, y)
+    _dev_rows(scale, bias, ca, cb, cc)
     _vol16(y, "bn_bwd_apply")
     Cc = y.shape[4]
+    groups = 1 if scale.dim() == 1 else scale.shape[0]
+    nv = _group_vox(y, groups, "bn_bwd_apply") if groups > 1 else y.numel() // Cc
+    pst = 0 if groups == 1 else _row_stride(scale, bias, groups, Cc, "bn_bwd_apply")
+    cst = 0 if groups == 1 else _row_stride(ca, cb, groups, Cc, "bn_bwd_apply", cc)
     dy = torch.empty_like(y)
-    rc = _launch("bn_bwd_apply", lambda: L.lib().pscv_bn_bwd_apply(_p(dact), _p(y), _dt(y), y.numel() // Cc, Cc, _p(scale), _p(bias),
-                                                                  int(relu), _p(ca), _p(cb), _p(cc), _p(dy), _stream()))
+    rc = _launch("bn_bwd_apply", lambda: L.lib().pscv_bn_bwd_apply_grouped(_p(dact), _p(y), _dt(y), nv, groups, Cc, _p(scale), _p(bias), pst,
+                                                                          int(relu), _p(ca), _p(cb), _p(cc), cst, _p(dy), _stream()))
     L.check(rc, "pscv_bn_bwd_apply")
     return dy
 

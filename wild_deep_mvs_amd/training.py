@@ -534,12 +534,25 @@ def _cached_layer(net, tag, weight, dtype, make):
     return cache[key]
 
 
+def _bn_affine_grouped(bn, sums: torch.Tensor, nvox: int, groups: int) -> torch.Tensor:
+    """[G,4,C] = (scale, bias, mean, invstd) per group from grouped batch statistics [G,2,C]; a frozen BatchNorm (eval() inside a
+    training step) hands every group the running statistics."""
+    if not bn.training:
+        return torch.stack(_bn_frozen_affine(bn), 0).unsqueeze(0).expand(groups, -1, -1).contiguous()
+    return ops.bn_finalize(sums.view(groups, 2, -1), nvox, bn)
+
+
 class FeatureNetFn(torch.autograd.Function):
     """MVSNet's 2-D extractor (models/MVSNet/model.py:21-41: seven conv + BatchNorm2d + ReLU blocks, k3 s1 / k5 s2, and a
     final k3 conv with bias) in train() mode, forward and backward on the engine: raw MFMA conv2d, batch statistics, one
-    normalise + ReLU pass; backward = BatchNorm backward, weight gradient on the 3-D MFMA kernel (single plane; k5 s2 from
-    the four parity planes of the input), data gradient as the adjoint conv on the forward kernel (k5 s2: four parity
-    sub-convolutions).  ``forward(ctx, net, dtype, img [B,3,H,W], *params)`` -> [B,H/4,W/4,32] in ``dtype``."""
+    normalise + ReLU pass; backward = BatchNorm backward, weight gradient on the MFMA weight-gradient kernel (single-plane
+    mode; k5 s2 from the four parity planes of the input), data gradient as the adjoint conv on the forward kernel (k5 s2: four
+    parity sub-convolutions).  ``forward(ctx, net, dtype, groups, img [G*B,3,H,W], *params)`` -> [G*B,H/4,W/4,32] in ``dtype``.
+
+    ``groups``: the images are ``groups`` consecutive slices of B images, each normalised with its OWN batch statistics -- the
+    views of a sample, which the reference sends through the extractor one at a time (model.py:101-107), here in ONE launch per
+    pass (the convolutions and weight gradients do not care; the BatchNorm passes take a group axis, pscv_bn_*_grouped) and the
+    running statistics see the views in order.  groups = 1 is one plain call of the module."""
 
     @staticmethod
     def params(net) -> List[torch.Tensor]:
@@ -550,19 +563,21 @@ class FeatureNetFn(torch.autograd.Function):
         return ps + [net.feature.weight, net.feature.bias]
 
     @staticmethod
-    def forward(ctx, net, dtype, img, *params):
-        B, _, H, W = img.shape
+    def forward(ctx, net, dtype, groups, img, *params):
+        GB, _, H, W = img.shape
         if H % 4 or W % 4:
             raise ValueError("pscv FeatureNetFn: image height and width must be multiples of 4")
+        if groups < 1 or GB % groups:
+            raise ValueError(f"pscv FeatureNetFn: {GB} images do not split into {groups} groups")
         x = ops.image_to_channels_last8(img.detach(), dtype)
         saved = []
         for i, (ci, co, k, s_, p_) in enumerate(net.SPEC):
             blk = getattr(net, f"conv{i}")
             y = ops.conv2d(x, _cached_layer(net, f"f{i}", blk.conv.weight, dtype,
                                             lambda: ops.Conv2dLayer.build(blk.conv.weight, stride=s_, dtype=dtype)))
-            nvox = y.numel() // y.shape[3]
-            aff = _bn_affine(Block("", "", y, bn=blk.bn), ops.bn_stats(_v5(y)), nvox)
-            act = ops.bn_act(_v5(y), aff[0], aff[1], relu=True).squeeze(1)
+            nvox = y.numel() // y.shape[3] // groups
+            aff = _bn_affine_grouped(blk.bn, ops.bn_stats(_v5(y), groups), nvox, groups)
+            act = ops.bn_act(_v5(y), aff[:, 0], aff[:, 1], relu=True).squeeze(1)
             saved.append((x, y, aff, nvox))
             x = act
         out = ops.conv2d(x, ops.Conv2dLayer.build(net.feature.weight, stride=1, conv_bias=net.feature.bias, dtype=dtype))   # (bias may change alone)
@@ -581,13 +596,17 @@ class FeatureNetFn(torch.autograd.Function):
         for i in range(6, -1, -1):
             ci, co, k, s_, p_ = net.SPEC[i]
             blk = getattr(net, f"conv{i}")
-            x, y, (scale, bias, mean, invstd), nvox = saved[i]
-            dy, dg, db = _bn_backward(blk.bn, _v5(dact), _v5(y), (scale, bias, mean, invstd, nvox), relu=True)
-            dy = dy.squeeze(1)
+            x, y, aff, nvox = saved[i]
+            s = ops.bn_bwd_reduce(_v5(dact), _v5(y), aff[:, 0], aff[:, 1], relu=True)
+            cf = ops.bn_bwd_coeffs(s, aff[:, 2], aff[:, 3], blk.bn.weight, nvox)          # [G,5,C]
+            if not blk.bn.training:
+                cf[:, 1:3].zero_()
+            dy = ops.bn_bwd_apply(_v5(dact), _v5(y), aff[:, 0], aff[:, 1], cf[:, 0], cf[:, 1], cf[:, 2], relu=True).squeeze(1)
+            dgb = cf[:, 3:5].sum(0)                                                        # the views share the BatchNorm: gradients add
             cpad = x.shape[3]
             dw = _wgrad2d_k3(dy, x, co, cpad) if k == 3 else _wgrad2d_k5s2(dy, x, co, cpad)
             grads[id(blk.conv.weight)] = dw[:, :ci].to(blk.conv.weight.dtype)
-            grads[id(blk.bn.weight)], grads[id(blk.bn.bias)] = dg, db
+            grads[id(blk.bn.weight)], grads[id(blk.bn.bias)] = dgb[0].to(blk.bn.weight.dtype), dgb[1].to(blk.bn.bias.dtype)
             if i > 0:
                 if k == 3:
                     dact = ops.conv2d(dy, _cached_layer(net, f"d{i}", blk.conv.weight, dtype,
@@ -598,7 +617,7 @@ class FeatureNetFn(torch.autograd.Function):
                     for par, sub in enumerate(subs):
                         ops.conv2d(dy, sub, out=dact, parity=par)
         ctx.saved = None
-        return (None, None, None, *[grads[id(p)] for p in FeatureNetFn.params(net)])
+        return (None, None, None, None, *[grads[id(p)] for p in FeatureNetFn.params(net)])
 
 
 # --------------------------------------------------------------------------------------------
