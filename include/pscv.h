@@ -281,6 +281,9 @@ int pscv_fuse_finish(const float* partial, const float* wsum, int dtype, void* o
  *       0.1 = LeakyReLU(0.1) (models/CVP_MVSNet/models/modules.py:24-28), 1 = no activation.
  */
 long pscv_pack_conv2d_weights(const float* w, int c_in, int c_in_padded, int c_out, int ks, int dtype, uint16_t* packed);
+/* The same packing with `w` (fp32 [c_out][c_in][ks][ks]) and `packed` on the device, one launch on `stream`, no host round trip
+ * (ABI 6): what a training step uses to rebuild the extractor's forward and adjoint layers after an optimiser step. */
+int pscv_pack_conv2d_weights_device(const float* w, int c_in, int c_in_padded, int c_out, int ks, int dtype, uint16_t* packed, void* stream);
 int pscv_conv2d(const void* in, int dtype, const uint16_t* packed, const float* scale, const float* bias, void* out,
                 int out_dtype, int B, int Hi, int Wi, int c_in, int c_out, int ks, int stride, float neg_slope, void* stream);
 /*

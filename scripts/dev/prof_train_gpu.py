@@ -14,6 +14,8 @@ else:
     net = MVSNet("variance"); kw = {}; down = 4; key = "mvsnet"
 net.load_state_dict(synthetic.train_state_dict(key, synthetic.template_of(net), seed=0))
 net = net.cuda().train()
+if os.environ.get("PSCV_FE"):
+    net.feature_engine_train = os.environ["PSCV_FE"]      # MVSNet: 2-D extractor on the engine (training.FeatureNetFn)
 opt = torch.optim.Adam(net.parameters(), lr=1e-4)
 scene = synthetic.make_scene(1, V, H, W, seed=0)
 gt, mask = synthetic.train_target(scene, H // down, W // down)
@@ -36,7 +38,7 @@ tot = sum(e.device_time_total for e in ev) / 3e3
 print(f"{arch}: GPU kernel time per step {tot:.2f} ms")
 kern = [e for e in ev if not e.key.startswith(("aten::", "autograd::")) and "Backward" not in e.key and "Fn" not in e.key[-4:]]
 print(f"  kernels only: {sum(e.device_time_total for e in kern) / 3e3:.2f} ms in {sum(e.count for e in kern) // 3} launches per step")
-for e in sorted(kern, key=lambda e: -e.count)[:14]:
+for e in sorted(kern, key=lambda e: -e.device_time_total)[:22]:
     print(f"  x{e.count // 3:5d}  {e.device_time_total / 3e3:8.3f} ms  {e.key[:120]}")
 cpu = sorted(prof.key_averages(), key=lambda e: -e.count)[:14]
 for e in cpu:

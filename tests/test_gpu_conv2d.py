@@ -160,3 +160,19 @@ def test_image_prep_equals_interpolate_and_conversion(env, shape, dtype):
     assert v.data_ptr() == imgs.data_ptr() and torch.equal(v, torch.cat([imgs[:, i] for i in range(4)], 0))
     two = torch.randn(2, 4, 3, 8, 10, device="cuda")
     assert torch.equal(ops.batch_views([two[:, i] for i in range(4)]), torch.cat([two[:, i] for i in range(4)], 0))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_device_conv2d_weight_packing_equals_host_packing(dtype):
+    """pscv_pack_conv2d_weights_device (what Conv2dLayer.build uses for device weights: no host round trip per layer of a training
+    step) writes the same bits as the host loop, for every (c_in, padded c_in, c_out, k) family the extractors use."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from wild_deep_mvs_amd import ops
+    import numpy as np
+    g = torch.Generator().manual_seed(2)
+    for (co, ci, k) in [(8, 3, 3), (16, 8, 5), (32, 32, 3), (64, 64, 3), (32, 64, 1), (20, 16, 2), (128, 64, 3)]:
+        w = torch.randn(co, ci, k, k, generator=g)
+        host = torch.from_numpy(ops.pack_conv2d_weights(w, (ci + 7) // 8 * 8, dtype).view(np.int16))
+        dev = ops.Conv2dLayer.build(w.cuda(), stride=1, dtype=dtype).packed
+        assert dev.is_cuda and torch.equal(dev.cpu(), host), (co, ci, k)

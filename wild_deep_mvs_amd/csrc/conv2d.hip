@@ -625,6 +625,41 @@ extern "C" long pscv_pack_conv2d_weights(const float* w, int c_in, int c_in_padd
     return n;
 }
 
+// Same packing on the device (w and packed are device pointers): a training step rebuilds the packed forward and adjoint layers of
+// the 2-D extractor after every optimiser step, and the host version costs a device -> host copy (a stream synchronisation), a
+// host loop and an upload per layer -- 21 round trips per MVSNet training step.
+namespace pscv {
+__global__ void pack_conv2d_kernel(const float* __restrict__ w, int c_in, int c_in_padded, int c_out, int ntaps, int nt, int dtype, long n,
+                                   uint16_t* __restrict__ packed) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int j = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+    const long blk = idx >> 9;
+    const int t = (int)(blk % nt), s = (int)(blk / nt);
+    const int co = t * 16 + (lane & 15), k = s * 32 + (lane >> 4) * 8 + j;
+    const int tap = k / c_in_padded, ci = k % c_in_padded;
+    float v = 0.f;
+    if (co < c_out && tap < ntaps && ci < c_in) v = w[((long)co * c_in + ci) * ntaps + tap];
+    packed[idx] = dtype == PSCV_BF16 ? f32_to_bf16(v) : f32_to_f16_bits(v);
+}
+}  // namespace pscv
+
+extern "C" int pscv_pack_conv2d_weights_device(const float* w, int c_in, int c_in_padded, int c_out, int ks, int dtype, uint16_t* packed,
+                                               void* stream) {
+    using namespace pscv;
+    PSCV_CHECK_ARG(c_in > 0 && c_in <= c_in_padded && c_in_padded % 8 == 0 && c_out > 0 && (ks == 1 || ks == 2 || ks == 3 || ks == 5),
+                   "pscv_pack_conv2d_weights_device: bad layer %d(%d) -> %d, k=%d", c_in, c_in_padded, c_out, ks);
+    PSCV_CHECK_ARG(dtype == PSCV_BF16 || dtype == PSCV_F16, "pscv_pack_conv2d_weights_device: dtype %d must be bf16 or fp16", dtype);
+    PSCV_CHECK_ARG(w && packed, "pscv_pack_conv2d_weights_device: null pointer argument");
+    const int nt = (c_out + 15) / 16, ntaps = ks * ks;
+    const int nsteps = (ntaps * c_in_padded + 31) / 32;
+    const long n = (long)nsteps * nt * 64 * 8;
+    hipLaunchKernelGGL(pack_conv2d_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w, c_in,
+                       c_in_padded, c_out, ntaps, nt, dtype, n, packed);
+    PSCV_CHECK_LAUNCH("pscv_pack_conv2d_weights_device");
+    return 0;
+}
+
 extern "C" int pscv_conv2d_ex(const void* in, int dtype, const uint16_t* packed, const float* scale, const float* bias,
                               const void* skip, int skip_cstride, int skip_coff, void* out, int out_cstride, int out_coff,
                               int out_dtype, int B, int Hi, int Wi, int c_in, int c_out, int ks, int stride, int parity,

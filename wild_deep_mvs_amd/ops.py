@@ -295,7 +295,18 @@ class Conv2dLayer:
         device = device if device is not None else weight.device
         c_out, c_in, ks = int(weight.shape[0]), int(weight.shape[1]), int(weight.shape[2])
         c_pad = (c_in + 7) // 8 * 8
-        packed = torch.from_numpy(pack_conv2d_weights(weight, c_pad, dtype).view(np.int16)).to(device)
+        if weight.is_cuda and torch.device(device) == weight.device and weight.dim() == 4 and weight.shape[2] == weight.shape[3]:
+            # device-side packing (same bits): no device -> host copy, no stream synchronisation per layer
+            wd = weight.detach().to(torch.float32).contiguous()
+            n = L.lib().pscv_pack_conv2d_weights(None, c_in, c_pad, c_out, ks, _TORCH2PSCV.get(dtype, -1), None)
+            if n < 0:
+                L.check(int(n), "pscv_pack_conv2d_weights")
+            packed = torch.empty(int(n), dtype=torch.int16, device=weight.device)
+            with torch.cuda.device(weight.device):
+                L.check(L.lib().pscv_pack_conv2d_weights_device(_p(wd), c_in, c_pad, c_out, ks, _TORCH2PSCV[dtype], _p(packed), _stream()),
+                        "pscv_pack_conv2d_weights_device")
+        else:
+            packed = torch.from_numpy(pack_conv2d_weights(weight, c_pad, dtype).view(np.int16)).to(device)
         scale = bias = None
         if bn is not None:
             gamma, beta, mean, var = [t.detach().to(device, torch.float32) for t in bn]
