@@ -259,6 +259,13 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const WarpBwdArgs A) {
 // The statistic of the forward (variance: sum; soft-min: numerator / weights) and the upstream gradient of the four planes
 // live in registers across the view loop.
 constexpr int BT_TW = 16, BT_TH = 8, BT_PLN = 4, BT_TEXELS = 512;
+// -DPSCV_ABLATE builds read measurement flags from pscv_set_tuning("fuse_c0", bits): 1 no global flush atomics, 2 no LDS atomics,
+// 4 no phase-A re-sampling (results are wrong with any bit set; scripts/dev/wbwd_ablate.py)
+#ifdef PSCV_ABLATE
+#define BT_ABL(bit) (a.variant & (bit))
+#else
+#define BT_ABL(bit) false
+#endif
 
 template <typename TIn, typename TG, int C, int GEOM, int COST>
 __global__ __launch_bounds__(256) void warp_bwd_tile_kernel(const WarpBwdArgs A) {
@@ -292,7 +299,7 @@ __global__ __launch_bounds__(256) void warp_bwd_tile_kernel(const WarpBwdArgs A)
     }
     if (tid < a.n_src * 4) mm[tid >> 2][tid & 3] = (tid & 2) ? INT_MIN : INT_MAX;
     if (tid < a.n_src) mm[tid][4] = 0;
-    for (int i = tid; i < BT_TEXELS * TS; i += 256) patch[i] = 0;
+    if (!BT_ABL(128)) for (int i = tid; i < BT_TEXELS * TS; i += 256) patch[i] = 0;
     __syncthreads();
 
     const int hw = a.h * a.w;
@@ -355,7 +362,7 @@ __global__ __launch_bounds__(256) void warp_bwd_tile_kernel(const WarpBwdArgs A)
             int x0, y0;
             if (VAR) {
                 VecF<CPL> s1 = rf;
-                for (int v = 0; v < a.n_src; ++v) {
+                for (int v = 0; v < (BT_ABL(4) ? 0 : a.n_src); ++v) {
                     const VecF<CPL> wv = sample(v, dval[i], taps, x0, y0);
 #pragma unroll
                     for (int j = 0; j < CPL; ++j) { s1.v[j] += wv.v[j]; fmaxabs = fmaxf(fmaxabs, fabsf(wv.v[j])); }
@@ -475,7 +482,7 @@ __global__ __launch_bounds__(256) void warp_bwd_tile_kernel(const WarpBwdArgs A)
         // exact bounding box of the texels this workgroup's samples of view v touch
         int mnx = INT_MAX, mny = INT_MAX, mxx = INT_MIN, mxy = INT_MIN;
 #pragma unroll
-        for (int i = 0; i < BT_PLN; ++i) {
+        for (int i = 0; i < (BT_ABL(16) ? 0 : BT_PLN); ++i) {
             float ix, iy;
             sweep_index<GEOM>(cam_lds + v * PSCV_CAM_FLOATS, px, py, dval[i], a, ix, iy);
             const int x0 = (int)floorf(ix), y0 = (int)floorf(iy);
@@ -516,6 +523,7 @@ __global__ __launch_bounds__(256) void warp_bwd_tile_kernel(const WarpBwdArgs A)
             if ((unsigned)lx < (unsigned)bw && (unsigned)ly < (unsigned)bh) {
                 int* p = patch + (ly * bw + lx) * TS + choff;
                 const float ws_ = wgt * scale;
+                if (BT_ABL(2)) return;
 #pragma unroll
                 for (int j = 0; j < CPL; ++j) atomicAdd(p + j, __float2int_rn(gw.v[j] * ws_));
             } else {
@@ -529,6 +537,7 @@ __global__ __launch_bounds__(256) void warp_bwd_tile_kernel(const WarpBwdArgs A)
         for (int i = 0; i < BT_PLN; ++i) {
             Taps taps;
             int x0, y0;
+            if (BT_ABL(8)) continue;
             const VecF<CPL> wv = sample(v, dval[i], taps, x0, y0);
             VecF<CPL> gw;
             if (VAR) {
@@ -555,23 +564,36 @@ __global__ __launch_bounds__(256) void warp_bwd_tile_kernel(const WarpBwdArgs A)
         }
         __syncthreads();
         // flush (texel-major: a wave writes whole 128-byte runs) and re-zero what was used
-        const int nflush = bw * bh * C;
+        const int nflush = BT_ABL(32) ? 0 : bw * bh * C;
         for (int idx = tid; idx < nflush; idx += 256) {
             const int texel = idx / C, c = idx - texel * C;
             const int ly = texel / bw, lx = texel - ly * bw;
             int* p = patch + texel * TS + c;
             const int qv = *p;
             if (qv != 0) {
-                atomic_add_f32(dsrc_v + ((long)(by0 + ly) * a.ws + bx0 + lx) * C + c, (float)qv * inv_scale);
+                if (!BT_ABL(1)) atomic_add_f32(dsrc_v + ((long)(by0 + ly) * a.ws + bx0 + lx) * C + c, (float)qv * inv_scale);
                 *p = 0;
             }
         }
     }
 
-    if (COST != PSCV_COST_WARP_ONLY && A.dref && active) {
-        float* dr = A.dref + pix * C + choff;
+    // Reference-feature gradient of the tile: through LDS (the patch is free now) so that a wave's 64 lanes add to 64 CONSECUTIVE floats
+    // (two pixels x 32 channels = two full 128-byte lines).  Issued straight from the registers -- lane = (pixel, channel half), 16
+    // instructions with 64 lanes 64 bytes apart -- these 31 M adds (48 depth chunks meet on every pixel) ran at ~19 G lanes/s and
+    // were 1.67 ms of the kernel's 2.58 ms at the headline size (ablation: scripts/dev/wbwd_ablate.py); coalesced they are ~0.1 ms.
+    if (COST != PSCV_COST_WARP_ONLY && A.dref && !BT_ABL(64)) {
+        __syncthreads();                                  // the last view's flush (which reads and re-zeroes the patch) is complete
+        float* const stage = reinterpret_cast<float*>(patch);          // [BT_TW * BT_TH pixels][TS]: conflict-free both ways
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) atomic_add_f32(dr + j, gref.v[j]);
+        for (int j = 0; j < CPL; ++j) stage[pl * TS + choff + j] = active ? gref.v[j] : 0.0f;
+        __syncthreads();
+        float* const dref_b = A.dref + (long)b * hw * C;
+        for (int idx = tid; idx < BT_TW * BT_TH * C; idx += 256) {
+            const int p = idx / C, c = idx - p * C;
+            const int gx = tx_i * BT_TW + (p & (BT_TW - 1)), gy = ty_i * BT_TH + p / BT_TW;
+            const float v = stage[p * TS + c];
+            if (gx < a.w && gy < a.h && v != 0.0f) atomic_add_f32(dref_b + ((long)gy * a.w + gx) * C + c, v);
+        }
     }
     if (COST == PSCV_COST_SOFTMIN && A.dtemp) {
         float s = dtemp_acc;
@@ -591,6 +613,9 @@ static int bwd_tile_launch(WarpBwdArgs& A, int geom, int cost, hipStream_t st) {
     A.ntx = (a.w + BT_TW - 1) / BT_TW;
     A.nty = (a.h + BT_TH - 1) / BT_TH;
     a.npb_batch = A.ntx * A.nty;
+#ifdef PSCV_ABLATE
+    { extern Knob g_fuse_c0; a.variant = g_fuse_c0; }
+#endif
     a.ppd = BT_PLN;
     a.n_dchunks = (a.D + BT_PLN - 1) / BT_PLN;
     const long nblk = (long)a.npb_batch * a.B * a.n_dchunks;
