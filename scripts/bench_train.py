@@ -15,6 +15,9 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from wild_deep_mvs_amd import _lib as L  # noqa: E402
+if os.environ.get("PSCV_LIB"):
+    L.LIB_PATH = os.environ["PSCV_LIB"]      # A/B runs against another build of the library
 from wild_deep_mvs_amd import ops, synthetic  # noqa: E402
 from wild_deep_mvs_amd.models.MVSNet.model import MVSNet  # noqa: E402
 
@@ -89,7 +92,11 @@ def main():
     ap.add_argument("--no-pack-cache", action="store_true", help="rebuild every packed layer on every use (A/B of ops.PACK_CACHE)")
     ap.add_argument("--feature-engine", default="torch", choices=["torch", "pscv"],
                     help="2-D extractor in train(): PyTorch-ROCm autograd (fp32) or training.FeatureNetFn (engine, 16-bit activations)")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="pscv_set_tuning knob (measurement runs)")
     a = ap.parse_args()
+    for kv in a.tune:
+        k, v = kv.split("=")
+        L.set_tuning(k, int(v))
     dt = {"bf16": torch.bfloat16, "f16": torch.float16}[a.dtype]
     torch.cuda.set_device(0)
     ops.PACK_CACHE = not a.no_pack_cache

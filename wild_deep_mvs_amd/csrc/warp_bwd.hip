@@ -258,9 +258,13 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const WarpBwdArgs A) {
 // Taps that fall outside the (capacity-clipped) box take the direct global atomic, so any geometry stays correct.
 // The statistic of the forward (variance: sum; soft-min: numerator / weights) and the upstream gradient of the four planes
 // live in registers across the view loop.
-constexpr int BT_TW = 16, BT_TH = 8, BT_PLN = 4, BT_TEXELS = 512;
+constexpr int BT_TW = 16, BT_TH = 8, BT_PLN = 4;
+// patch capacity in texels: ~68 KB of LDS either way (two workgroups per CU): 512 texels of 32 channels, 1024 of 16 (CVP-MVSNet's per-pixel
+// hypotheses around a still noisy depth estimate spread a tile's samples over more texels than a plane sweep does)
+template <int C> constexpr int bt_texels() { return C <= 16 ? 1024 : 512; }
 // -DPSCV_ABLATE builds read measurement flags from pscv_set_tuning("fuse_c0", bits): 1 no global flush atomics, 2 no LDS atomics,
-// 4 no phase-A re-sampling (results are wrong with any bit set; scripts/dev/wbwd_ablate.py)
+// 4 no phase-A re-sampling, 8 no phase-B sampling, 16 no box, 32 no flush scan, 64 no reference-gradient adds, 128 no patch zeroing,
+// 256 no direct adds for taps outside the patch (results are wrong with any bit set; scripts/dev/wbwd_ablate.py)
 #ifdef PSCV_ABLATE
 #define BT_ABL(bit) (a.variant & (bit))
 #else
@@ -274,6 +278,7 @@ __global__ __launch_bounds__(256) void warp_bwd_tile_kernel(const WarpBwdArgs A)
     constexpr int CPL = C / LPV;
     constexpr int PIXB = C * (int)sizeof(TIn);
     constexpr int TS = C + 1;                   // patch floats per texel
+    constexpr int BT_TEXELS = bt_texels<C>();
     constexpr bool VAR = (COST == PSCV_COST_VARIANCE || COST == PSCV_COST_VARIANCE_CVP);
 
     extern __shared__ __attribute__((aligned(16))) int patch[];   // [BT_TEXELS][TS] fixed point
@@ -526,7 +531,7 @@ __global__ __launch_bounds__(256) void warp_bwd_tile_kernel(const WarpBwdArgs A)
                 if (BT_ABL(2)) return;
 #pragma unroll
                 for (int j = 0; j < CPL; ++j) atomicAdd(p + j, __float2int_rn(gw.v[j] * ws_));
-            } else {
+            } else if (!BT_ABL(256)) {
                 float* p = dsrc_v + o / sizeof(TIn);
 #pragma unroll
                 for (int j = 0; j < CPL; ++j) atomic_add_f32(p + j, gw.v[j] * wgt);
@@ -620,7 +625,7 @@ static int bwd_tile_launch(WarpBwdArgs& A, int geom, int cost, hipStream_t st) {
     a.n_dchunks = (a.D + BT_PLN - 1) / BT_PLN;
     const long nblk = (long)a.npb_batch * a.B * a.n_dchunks;
     if (nblk <= 0 || nblk > 0x7fffffffL) { set_error("pscv_warp_cost_bwd: bad grid size %ld", nblk); return -1; }
-    constexpr int LDS = BT_TEXELS * (C + 1) * 4;
+    constexpr int LDS = bt_texels<C>() * (C + 1) * 4;
 #define PSCV_BWDT(GEOMV, COSTV)                                                                                           \
     if (geom == GEOMV && cost == COSTV) {                                                                                 \
         auto kern = warp_bwd_tile_kernel<TIn, TG, C, GEOMV, COSTV>;                                                       \
