@@ -446,6 +446,10 @@ int pscv_softargmin_bwd(const float* logits, const float* depth, long depth_bstr
 /* dpre = dout * [out > 0]: backward of a ReLU applied AFTER a residual add (Vis BasicBlock, nn_utils.py:123-171; the
  * forward is pscv_bn_act with relu = 2).  16-bit channels-last volumes, C a multiple of 8. */
 int pscv_relu_bwd(const void* dout, const void* out, int dtype, long nvox, int C, void* dpre, void* stream);
+/* The same with a negative-side slope (ABI 6): dpre = dout * (out > 0 ? 1 : slope) -- the backward of LeakyReLU(slope), whose output
+ * has the sign of its input (CVP-MVSNet's 2-D pyramid: conv + LeakyReLU(0.1), models/CVP_MVSNet/models/modules.py:24-28); slope = 0 is
+ * pscv_relu_bwd. */
+int pscv_leaky_relu_bwd(const void* dout, const void* out, int dtype, long nvox, int C, float slope, void* dpre, void* stream);
 
 /*
  * Backward of pscv_fuse_pairs (normalise = 1): d interm_v = G w_v / W, d uncert_v = -w_v / W sum_{d,c} G (interm_v - fused)

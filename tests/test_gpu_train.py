@@ -855,6 +855,76 @@ def test_feature_net_fn_grouped_equals_per_view_calls(dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
+def test_feature_pyramid_fn_against_module_autograd(dtype):
+    """training.FeaturePyramidFn (CVP-MVSNet's nine-layer conv + LeakyReLU(0.1) tower on two pyramid levels, forward and backward on
+    the engine, all views as one batch) against the same module under PyTorch-ROCm autograd (fp32): both levels' features and every
+    weight / bias gradient (gradients of the two levels add up in the shared tower).  Nine stored 16-bit layers each way."""
+    from wild_deep_mvs_amd import synthetic, training as T
+    from wild_deep_mvs_amd.models.CVP_MVSNet.frontend import Frontend
+    import copy
+    net = Frontend()
+    net.load_state_dict(synthetic.train_state_dict("cvp", synthetic.template_of(net), seed=0))
+    fa = net.model.featurePyramid.cuda().train()
+    fb = copy.deepcopy(fa)
+    gen = torch.Generator().manual_seed(6)
+    img = torch.rand(3, 3, 48, 80, generator=gen).cuda()
+    gouts = [torch.randn(3, 16, 48, 80, generator=gen).cuda(), torch.randn(3, 16, 24, 40, generator=gen).cuda()]
+    outs = T.FeaturePyramidFn.apply(fa, dtype, 2, img, *T.FeaturePyramidFn.params(fa))
+    torch.autograd.backward(outs, [g.permute(0, 2, 3, 1).to(dtype).contiguous() for g in gouts])
+    refs = fb(img, 2)
+    torch.autograd.backward(refs, gouts)
+    torch.cuda.synchronize()
+    bf = dtype == torch.bfloat16
+    for lv, (o, r) in enumerate(zip(outs, refs)):
+        check_close(f"pyramid level {lv}", o.detach().float().permute(0, 3, 1, 2).cpu(), r.detach().cpu(), rel_l2=3e-2 if bf else 4e-3)
+    o_grads = {k: p.grad.detach().cpu() for k, p in fb.named_parameters()}
+    worst, cos, rows = _grad_report(f"FeaturePyramidFn {dtype} vs module autograd", fa, o_grads)
+    assert cos >= (0.97 if bf else 0.995), (cos, rows)
+    # only the finest level feeds a loss: the coarse level's gradient is None
+    fa.zero_grad(); fb.zero_grad()
+    outs = T.FeaturePyramidFn.apply(fa, dtype, 2, img, *T.FeaturePyramidFn.params(fa))
+    outs[0].backward(gouts[0].permute(0, 2, 3, 1).to(dtype).contiguous())
+    fb(img, 2)[0].backward(gouts[0])
+    worst, cos, rows = _grad_report(f"FeaturePyramidFn {dtype}, finest level only", fa, {k: p.grad.detach().cpu() for k, p in fb.named_parameters()})
+    assert cos >= (0.97 if bf else 0.995), (cos, rows)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_cvp_train_step_with_engine_pyramid(dtype):
+    """feature_engine_train = "pscv" on CVP-MVSNet: the whole training step (pyramid tower of all views included) on the engine,
+    against the step with the PyTorch-ROCm tower on the same weights and scene: depth of both levels, loss, and the direction of
+    the full gradient (a mixed-precision mode: nine more stored 16-bit layers in front of the sweep)."""
+    from wild_deep_mvs_amd import synthetic
+    from wild_deep_mvs_amd.models.CVP_MVSNet.frontend import Frontend
+    import copy
+    H, W, V, B = 64, 96, 3, 1
+    na = Frontend()
+    na.load_state_dict(synthetic.train_state_dict("cvp", synthetic.template_of(na), seed=0))
+    na = na.cuda().train()
+    na.train_storage_dtype = dtype
+    nb = copy.deepcopy(na)
+    na.feature_engine_train = "pscv"
+    scene = synthetic.make_scene(B, V, H, W, seed=3)
+    scene["t"] = scene["t"] * 8
+    args = [scene[k].cuda() for k in ("imgs", "K", "R", "t", "depth_min", "depth_max")]
+    gt, mask = synthetic.train_target(scene, H, W)
+    res = []
+    for net in (na, nb):
+        out = net(*args, nscale=2)
+        loss = synthetic.supervised_loss(out["depth"], gt.cuda(), mask.cuda(), scene["depth_min"].cuda(), scene["depth_max"].cuda())
+        loss.backward()
+        res.append((out, float(loss.detach())))
+    torch.cuda.synchronize()
+    bf = dtype == torch.bfloat16
+    for lv in range(2):
+        check_close(f"depth level {lv}, engine tower vs torch tower", res[0][0]["depth_est_list"][lv].detach().cpu(),
+                    res[1][0]["depth_est_list"][lv].detach().cpu(), rel_l1=4e-2 if bf else 8e-3)
+    assert abs(res[0][1] - res[1][1]) <= (1e-1 if bf else 3e-2) * abs(res[1][1]), (res[0][1], res[1][1])
+    worst, cos, rows = _grad_report(f"cvp + FeaturePyramidFn {dtype} vs torch tower", na, {k: p.grad.detach().cpu() for k, p in nb.named_parameters() if p.grad is not None})
+    assert cos >= (0.7 if bf else 0.95), (cos, rows)
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_mvsnet_train_step_with_engine_extractor(dtype):
     """feature_engine_train = "pscv": the whole MVSNet training step (2-D extractor included) on the engine.  A mixed-precision
     mode -- eight more stored 16-bit layers in front of the sweep -- so the bars against the fp32 oracle are those of the

@@ -588,6 +588,7 @@ static int c2_dispatch(Conv2dArgs& a, int c_in, int c_out, int ks, int stride, h
 #define PSCV_C2(CI, NTV, K, S) if (c_in == CI && ntw == NTV && ks == K && stride == S) return c2_launch<H, CI, NTV, K, S>(a, split, st);
     PSCV_C2(8, 1, 3, 1) PSCV_C2(16, 1, 3, 1) PSCV_C2(32, 2, 3, 1) PSCV_C2(16, 2, 3, 1) PSCV_C2(32, 1, 3, 1)
     PSCV_C2(8, 4, 3, 1) PSCV_C2(64, 4, 3, 1) PSCV_C2(64, 2, 3, 1)                       // CVP pyramid: 3->64, 64->64, 64->32
+    PSCV_C2(32, 4, 3, 1)                                                                // (its 64->32 layer's adjoint: 32->64, training)
     PSCV_C2(8, 1, 5, 2) PSCV_C2(16, 2, 5, 2) PSCV_C2(8, 2, 5, 2) PSCV_C2(16, 1, 5, 2)
     // Vis FeatExt: 1x1 shortcuts, k3 s2 down-sampling convs, 128-channel layers, 2x2 parity sub-convs of the deconvs
     PSCV_C2(16, 2, 1, 1) PSCV_C2(32, 4, 1, 2) PSCV_C2(64, 4, 1, 2)

@@ -35,6 +35,9 @@ template <> struct WMfma<f16_t> {
     }
 };
 
+#ifdef PSCV_ABLATE
+extern Knob g_fuse_c0;      // warp_cost.hip
+#endif
 struct WgradArgs {
     const uint16_t* p;
     const uint16_t* q;
@@ -43,7 +46,13 @@ struct WgradArgs {
     int ca, cb, ca16, cb16;
     int B, Dp, Hp, Wp, Dq, Hq, Wq;
     int ntz, nty, ntx, ntiles;
+    int abl;            // -DPSCV_ABLATE builds: measurement flags from pscv_set_tuning("fuse_c0", bits): 1 no P staging, 2 no Q loads, 4 no Q LDS writes, 8 no MFMA loop
 };
+#ifdef PSCV_ABLATE
+#define WG_ABL(bit) (a.abl & (bit))
+#else
+#define WG_ABL(bit) false
+#endif
 
 // P2D (TZ = 1): single-plane volumes, i.e. the 2-D layers of the feature extractors run as D = 1: the z taps 0 and 2 only ever meet
 // zero padding, so one Q plane is staged, the waves split the 9 (ty, tx) taps of kernel slice tz = 1, and the tile is 8 rows of
@@ -93,7 +102,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         {
             const uint16_t* pb = a.p + (long)b * a.Dp * a.Hp * a.Wp * a.p_cs + a.p_co;
             constexpr int NCH = G::NV * 2;
-            for (int c = tid; c < NCH; c += 256) {
+            for (int c = tid; c < (WG_ABL(1) ? 0 : NCH); c += 256) {
                 const int vox = c % G::NV, c8 = c / G::NV;
                 const int xl = vox & 15, yl = (vox >> 4) % TY, zl = (vox >> 4) / TY;
                 const int gz = z0 + zl, gy = y0 + yl, gx = x0 + xl;
@@ -125,13 +134,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
                     const int gz = oz + zl, gy = oy + yl, gx = ox0 + xl;
                     val[k] = make_uint4(0u, 0u, 0u, 0u);
                     if (c < NCH && (unsigned)gz < (unsigned)a.Dq && (unsigned)gy < (unsigned)a.Hq && (unsigned)gx < (unsigned)a.Wq &&
-                        b0 + cc * 8 < a.cb)
+                        b0 + cc * 8 < a.cb && !WG_ABL(2))
                         val[k] = *reinterpret_cast<const uint4*>(qb + (((long)gz * a.Hq + gy) * a.Wq + gx) * a.q_cs + b0 + cc * 8);
                 }
 #pragma unroll
                 for (int k = 0; k < BATCH; ++k) {
                     const int c = c0 + k * 256 + tid;
-                    if (c >= NCH) continue;
+                    if (c >= NCH || WG_ABL(4)) continue;
                     const int cc = c % CCH, v = c / CCH;
                     const int xl = v % G::QX, r = v / G::QX;
                     const int yl = r % G::QY, zl = r / G::QY;
@@ -154,7 +163,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
 
         // ---- contraction: this wave's taps x all k-steps ----
 #pragma unroll
-        for (int ks = 0; ks < G::KSTEPS; ++ks) {
+        for (int ks = 0; ks < (WG_ABL(8) ? 0 : G::KSTEPS); ++ks) {
             const int chunk = ks * 4 + g;
             const int x8 = chunk & 1, yl = (chunk >> 1) % TY, zl = (chunk >> 1) / TY;
             const uint4 af = *reinterpret_cast<const uint4*>(p_lds + n * G::PAS + ((zl * TY + yl) * 16 + x8 * 8) * 2);
@@ -287,6 +296,10 @@ extern "C" int pscv_conv3d_wgrad(const void* p, int p_cstride, int p_coff, int c
     a.B = B; a.Dp = Dp; a.Hp = Hp; a.Wp = Wp;
     a.Dq = stride * Dp; a.Hq = stride * Hp; a.Wq = stride * Wp;
     a.ntz = pl.ntz; a.nty = pl.nty; a.ntx = pl.ntx; a.ntiles = pl.ntiles;
+    a.abl = 0;
+#ifdef PSCV_ABLATE
+    a.abl = pscv::g_fuse_c0;
+#endif
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int rc;
 #define PSCV_WG(HT)                                                                       \

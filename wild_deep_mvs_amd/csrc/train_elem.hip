@@ -125,16 +125,17 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const uint4* __restrict__ y
 }
 
 // ---- backward of a ReLU applied AFTER a residual add: dpre = dout * [out > 0] ------------------------------------------
+// (slope = 0: ReLU; slope = 0.1: the LeakyReLU of CVP-MVSNet's 2-D pyramid, whose output has the sign of its input)
 template <typename H>
 __global__ __launch_bounds__(256) void relu_bwd_kernel(const uint4* __restrict__ dout, const uint4* __restrict__ out,
-                                                       uint4* __restrict__ dpre, long nchunk) {
+                                                       uint4* __restrict__ dpre, long nchunk, float slope) {
     const long stride = (long)gridDim.x * 256;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nchunk; i += stride) {
         float g[8], o[8];
         unpack8<H>(dout[i], g);
         unpack8<H>(out[i], o);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) g[j] = o[j] > 0.0f ? g[j] : 0.0f;
+        for (int j = 0; j < 8; ++j) g[j] = o[j] > 0.0f ? g[j] : g[j] * slope;
         dpre[i] = pack8<H>(g);
     }
 }
@@ -434,17 +435,21 @@ extern "C" int pscv_softargmin_bwd(const float* logits, const float* depth, long
     return 0;
 }
 
-extern "C" int pscv_relu_bwd(const void* dout, const void* out, int dtype, long nvox, int C, void* dpre, void* stream) {
-    PSCV_CHECK_ARG(dout && out && dpre, "pscv_relu_bwd: null pointer argument");
-    PSCV_CHECK_ARG(C % 8 == 0 && C > 0 && nvox > 0, "pscv_relu_bwd: bad sizes");
-    PSCV_CHECK_ARG(dtype == PSCV_BF16 || dtype == PSCV_F16, "pscv_relu_bwd: dtype %d must be bf16 or fp16", dtype);
+extern "C" int pscv_leaky_relu_bwd(const void* dout, const void* out, int dtype, long nvox, int C, float slope, void* dpre, void* stream) {
+    PSCV_CHECK_ARG(dout && out && dpre, "pscv_leaky_relu_bwd: null pointer argument");
+    PSCV_CHECK_ARG(C % 8 == 0 && C > 0 && nvox > 0, "pscv_leaky_relu_bwd: bad sizes");
+    PSCV_CHECK_ARG(slope >= 0.0f && slope <= 1.0f, "pscv_leaky_relu_bwd: slope %g outside [0,1]", (double)slope);
+    PSCV_CHECK_ARG(dtype == PSCV_BF16 || dtype == PSCV_F16, "pscv_leaky_relu_bwd: dtype %d must be bf16 or fp16", dtype);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const long nchunk = nvox * (C / 8);
     const int nb = grid_for(nchunk);
-    if (dtype == PSCV_BF16) hipLaunchKernelGGL(relu_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const uint4*)dout, (const uint4*)out, (uint4*)dpre, nchunk);
-    else hipLaunchKernelGGL(relu_bwd_kernel<f16_t>, dim3(nb), dim3(256), 0, st, (const uint4*)dout, (const uint4*)out, (uint4*)dpre, nchunk);
-    PSCV_CHECK_LAUNCH("pscv_relu_bwd");
+    if (dtype == PSCV_BF16) hipLaunchKernelGGL(relu_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const uint4*)dout, (const uint4*)out, (uint4*)dpre, nchunk, slope);
+    else hipLaunchKernelGGL(relu_bwd_kernel<f16_t>, dim3(nb), dim3(256), 0, st, (const uint4*)dout, (const uint4*)out, (uint4*)dpre, nchunk, slope);
+    PSCV_CHECK_LAUNCH("pscv_leaky_relu_bwd");
     return 0;
+}
+extern "C" int pscv_relu_bwd(const void* dout, const void* out, int dtype, long nvox, int C, void* dpre, void* stream) {
+    return pscv_leaky_relu_bwd(dout, out, dtype, nvox, C, 0.0f, dpre, stream);
 }
 
 extern "C" int pscv_bn_finalize_grouped(const float* sums, long nvox, int groups, int C, const float* gamma, const float* beta, float eps,

@@ -35,6 +35,14 @@ class Frontend(ReplayHooks, nn.Module):
     def feature_engine(self, name):
         self.model.feature_engine = name
 
+    @property
+    def feature_engine_train(self):
+        return self.model.feature_engine_train
+
+    @feature_engine_train.setter
+    def feature_engine_train(self, name):
+        self.model.feature_engine_train = name
+
     @replayable
     def forward(self, imgs, K, R, t, depth_min, depth_max, reference_frame=0, **kwargs):
         src_idx = [i for i in range(K.shape[1]) if i != reference_frame]

@@ -136,6 +136,9 @@ class network(nn.Module):
         # "torch" = PyTorch-ROCm in fp32, converted where the warp kernel reads them
         self.feature_engine = "pscv"
         self.train_storage_dtype = torch.bfloat16   # train(): bf16 activations / gradients by default (range), fp32 accumulation
+        # 2-D pyramid tower in train(): "torch" = PyTorch-ROCm autograd in fp32 (default, like MVSNet's extractor);
+        # "pscv" = training.FeaturePyramidFn: all views in one engine pass, 16-bit activations
+        self.feature_engine_train = "torch"
 
     def forward_train(self, ref_img, src_imgs, ref_in, src_in, ref_ex, src_ex, depth_min, depth_max, nscale):
         """train()-mode forward with autograd (reference net.py:96-229 with ``self.training``): 48 coarse planes, fixed
@@ -146,10 +149,22 @@ class network(nn.Module):
         the engine regresses the per-batch offsets and the ``depth_up +`` stays an autograd add."""
         nsrc = len(src_imgs)
         dt = self.train_storage_dtype
-        ref_pyr = self.featurePyramid(ref_img, nscale)
-        src_pyrs = [self.featurePyramid(s, nscale) for s in src_imgs]
-        ref_in_ms = conditionIntrinsics(ref_in, ref_img.shape, [f.shape for f in ref_pyr])
-        src_in_ms = torch.stack([conditionIntrinsics(src_in[:, i], ref_img.shape, [f.shape for f in src_pyrs[i]])
+        if self.feature_engine_train == "pscv":
+            # the tower of ALL views in one engine pass (training.FeaturePyramidFn: no BatchNorm, the views are batch items);
+            # channels-last 16-bit maps, which WarpCostFn takes as they are
+            Bn = ref_img.shape[0]
+            levels = T.FeaturePyramidFn.apply(self.featurePyramid, dt, nscale, torch.cat([ref_img] + list(src_imgs), 0),
+                                              *T.FeaturePyramidFn.params(self.featurePyramid))
+            per_view = [torch.split(lv, Bn, 0) for lv in levels]                       # [level][view]
+            ref_pyr = [pv[0] for pv in per_view]
+            src_pyrs = [[pv[1 + i] for pv in per_view] for i in range(nsrc)]
+            nchw = lambda f: (f.shape[0], f.shape[3], f.shape[1], f.shape[2])        # conditionIntrinsics reads [B,C,H,W] shapes
+        else:
+            ref_pyr = self.featurePyramid(ref_img, nscale)
+            src_pyrs = [self.featurePyramid(s, nscale) for s in src_imgs]
+            nchw = lambda f: tuple(f.shape)
+        ref_in_ms = conditionIntrinsics(ref_in, ref_img.shape, [nchw(f) for f in ref_pyr])
+        src_in_ms = torch.stack([conditionIntrinsics(src_in[:, i], ref_img.shape, [nchw(f) for f in src_pyrs[i]])
                                  for i in range(nsrc)]).permute(1, 0, 2, 3, 4)
         blocks = self.cost_reg_refine.train_blocks()
         params = T.RegressFn.block_params(blocks)

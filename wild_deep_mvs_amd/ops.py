@@ -1231,16 +1231,17 @@ def softargmin_bwd(logits: torch.Tensor, depth: Optional[torch.Tensor], grad_dep
     return out
 
 
-def relu_bwd(dout: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
-    """dout * [out > 0] on 16-bit channels-last volumes (pscv_relu_bwd): backward of a ReLU applied after a residual add."""
+def relu_bwd(dout: torch.Tensor, out: torch.Tensor, slope: float = 0.0) -> torch.Tensor:
+    """dout * [out > 0] on 16-bit channels-last volumes (pscv_relu_bwd): backward of a ReLU applied after a residual add.
+    ``slope`` > 0: dout * (out > 0 ? 1 : slope), the backward of LeakyReLU(slope) from its OUTPUT (pscv_leaky_relu_bwd)."""
     _dev(dout, out)
     _vol16(out, "relu_bwd")
     if dout.shape != out.shape or dout.dtype != out.dtype:
         raise ValueError("pscv.relu_bwd: dout must match out")
     Cc = out.shape[4]
     dpre = torch.empty_like(out)
-    rc = _launch("relu_bwd", lambda: L.lib().pscv_relu_bwd(_p(dout), _p(out), _dt(out), out.numel() // Cc, Cc, _p(dpre), _stream()))
-    L.check(rc, "pscv_relu_bwd")
+    rc = _launch("relu_bwd", lambda: L.lib().pscv_leaky_relu_bwd(_p(dout), _p(out), _dt(out), out.numel() // Cc, Cc, float(slope), _p(dpre), _stream()))
+    L.check(rc, "pscv_leaky_relu_bwd")
     return dpre
 
 

@@ -521,11 +521,11 @@ def _dgrad2d_k5s2_layers(w: torch.Tensor, dtype) -> List[ops.Conv2dLayer]:
     return subs
 
 
-def _cached_layer(net, tag, weight, dtype, make):
+def _cached_layer(net, tag, weight, dtype, make, extra=()):
     """Packed 2-D layers are built on the host (pscv_pack_conv2d_weights): keep them per (weight version, dtype) on the module so
     that the views of one step -- same weights -- do not repack (and synchronise) once per view."""
     cache = net.__dict__.setdefault("_pscv_train_layers", {})
-    key = (tag, ops.weights_epoch(), weight.data_ptr(), weight._version, dtype)
+    key = (tag, ops.weights_epoch(), weight.data_ptr(), weight._version, dtype) + tuple(extra)     # extra: e.g. a folded bias' version
     if key not in cache:
         # one live entry per tag: an optimiser step bumps weight._version, the previous step's packed layer goes here
         for k in [k for k in cache if k[0] == tag]:
@@ -618,6 +618,70 @@ class FeatureNetFn(torch.autograd.Function):
                         ops.conv2d(dy, sub, out=dact, parity=par)
         ctx.saved = None
         return (None, None, None, None, *[grads[id(p)] for p in FeatureNetFn.params(net)])
+
+
+class FeaturePyramidFn(torch.autograd.Function):
+    """CVP-MVSNet's 2-D pyramid tower (models/CVP_MVSNet/models/net.py:21-47: nine conv k3 + bias + LeakyReLU(0.1) layers, 3 -> 64
+    -> 64 -> 64 -> 32 -> 32 -> 32 -> 16 -> 16 -> 16, applied to the image and to its bilinear half-scale copies) in train()
+    mode, forward and backward on the engine, for ALL views at once (no BatchNorm: the views are plain batch items):
+    forward = the eval-mode launches (MFMA conv2d with the bias and the LeakyReLU fused) keeping every layer's output; backward per
+    level and layer = LeakyReLU backward from the stored OUTPUT (same sign as the input), bias gradient = per-channel sum,
+    weight gradient on the single-plane mode of the MFMA weight-gradient kernel, data gradient = the adjoint conv on the forward
+    kernel.  ``forward(ctx, tower, dtype, nscale, img [N,3,H,W], *params)`` -> nscale maps [N,H_l,W_l,16] in ``dtype``, finest
+    first; the image pyramid carries no gradient (net.py:44 detaches it)."""
+
+    SLOPE = 0.1
+
+    @staticmethod
+    def params(tower) -> List[torch.Tensor]:
+        ps = []
+        for n in tower._names:
+            ps += [getattr(tower, n)[0].weight, getattr(tower, n)[0].bias]
+        return ps
+
+    @staticmethod
+    def forward(ctx, tower, dtype, nscale, img, *params):
+        convs = [getattr(tower, n)[0] for n in tower._names]
+        layers = [_cached_layer(tower, f"p{i}", c.weight, dtype,
+                                lambda c=c: ops.Conv2dLayer.build(c.weight, stride=1, conv_bias=c.bias, leaky=FeaturePyramidFn.SLOPE, dtype=dtype),
+                                extra=(c.bias.data_ptr(), c.bias._version))          # (the bias is folded into the packed layer)
+                  for i, c in enumerate(convs)]
+        saved, outs = [], []
+        for x in ops.image_pyramid_cl8(img.detach(), nscale, dtype):
+            acts = [x]
+            for layer in layers:
+                acts.append(ops.conv2d(acts[-1], layer))
+            saved.append(acts)
+            outs.append(acts[-1])
+        ctx.tower, ctx.dtype, ctx.saved = tower, dtype, saved
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        tower, dtype, saved = ctx.tower, ctx.dtype, ctx.saved
+        convs = [getattr(tower, n)[0] for n in tower._names]
+        dW = [None] * len(convs)
+        dB = [None] * len(convs)
+        for acts, g in zip(saved, gs):
+            if g is None:
+                continue
+            g = g.contiguous().to(dtype)
+            for i in range(len(convs) - 1, -1, -1):
+                c = convs[i]
+                co, ci = int(c.weight.shape[0]), int(c.weight.shape[1])
+                x, out = acts[i], acts[i + 1]
+                dpre = ops.relu_bwd(_v5(g), _v5(out), FeaturePyramidFn.SLOPE).squeeze(1)
+                db = ops.bn_stats(_v5(dpre))[0]
+                dw = _wgrad2d_k3(dpre, x, co, x.shape[3])[:, :ci]
+                dW[i] = dw if dW[i] is None else dW[i] + dw
+                dB[i] = db if dB[i] is None else dB[i] + db
+                if i > 0:
+                    g = ops.conv2d(dpre, _cached_layer(tower, f"pd{i}", c.weight, dtype, lambda c=c: _dgrad2d_k3_layer(c.weight, dtype)))
+        ctx.saved = None
+        grads = []
+        for c, w_, b_ in zip(convs, dW, dB):
+            grads += [None if w_ is None else w_.to(c.weight.dtype), None if b_ is None else b_.to(c.bias.dtype)]
+        return (None, None, None, None, *grads)
 
 
 # --------------------------------------------------------------------------------------------
