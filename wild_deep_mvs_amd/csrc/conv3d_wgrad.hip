@@ -62,10 +62,15 @@ template <int S, int TZ, int TY, int NB> struct WgGeom {
     static constexpr int NV = TZ * TY * 16;                 // P voxels per tile
     static constexpr int QZ = P2D ? 1 : S * (TZ - 1) + 3, QY = S * (TY - 1) + 3, QX = S * 15 + 3;
     static constexpr int PAS = NV * 2 + 16;                 // bytes per P channel row (odd number of 16-byte slots)
-    static constexpr int QBS = QZ * QY * 32 + 16;           // bytes per Q channel block
-    static constexpr int QTS = 16 * NB * QBS;               // bytes per x-tap copy of Q
+    // stride 1 (round 3): ONE copy of Q, rows of QXP = 24 elements (18 used); the fragment of x-tap tx = elements 8 x8 + tx .. + 7 of a
+    // row is cut out of two aligned 16-byte reads with byte-align ops (tx = 1) or is a register renaming (tx = 2).  Stride 2 keeps the
+    // three pre-shifted, decimated copies.
+    static constexpr bool ONE = S == 1;
+    static constexpr int QXP = 24;
+    static constexpr int QBS = ONE ? QZ * QY * QXP * 2 + 16 : QZ * QY * 32 + 16;   // bytes per Q channel block
+    static constexpr int QTS = 16 * NB * QBS;               // bytes per copy of Q
     static constexpr int P_BYTES = 16 * PAS;
-    static constexpr int LDS = P_BYTES + 3 * QTS;
+    static constexpr int LDS = P_BYTES + (ONE ? 1 : 3) * QTS;
     static constexpr int KSTEPS = TZ * TY * 2 / 4;
     static_assert((TZ * TY * 2) % 4 == 0, "tile must hold whole k-steps");
     static_assert((PAS / 16) % 2 == 1 && (QBS / 16) % 2 == 1, "odd slot strides");
@@ -89,6 +94,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     for (int ti = 0; ti < 7; ++ti)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) acc[ti][nb] = wg_f32x4{0.f, 0.f, 0.f, 0.f};
+    // stride 1: a wave owns whole (tz, ty, b-tile) units -- unit u = wave + 4 i -> pair u / NB, b-tile u % NB -- and runs their three
+    // x-taps off ONE pair of aligned reads (two ds_read_b128 + four byte-align ops per three MFMAs)
+    constexpr int NPAIR = G::P2D ? 3 : 9, NU = NPAIR * NB, NUW = (NU + 3) / 4;
+    wg_f32x4 accu[G::ONE ? NUW : 1][3];
+#pragma unroll
+    for (int i = 0; i < (G::ONE ? NUW : 1); ++i)
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) accu[i][tx] = wg_f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         int t = tile;
@@ -116,7 +129,56 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
                     *reinterpret_cast<uint16_t*>(dst + j * G::PAS) = (uint16_t)(w4[j >> 1] >> ((j & 1) * 16));
             }
         }
-        // ---- stage Q, transposed, once per x-tap: q_lds[tx][channel][qz][qy][ox] = Q[.., S*(x0+ox) + tx - 1] ----
+        if constexpr (G::ONE) {
+            // ---- stage Q (stride 1), transposed, ONE copy: q_lds[channel][qz][qy][xe], xe <-> gx = x0 - 1 + xe.  A thread takes FOUR
+            // x-adjacent voxels of one 8-channel chunk (four 16-byte loads), transposes the 4 x 8 block in registers (16 v_perm_b32) and
+            // writes eight 8-byte runs: 2 LDS write instructions per 16 bytes of Q (the per-tap 2-byte stores of rounds 1-2 took 24, and
+            // were 45 % of the kernel: scripts/dev/wgrad_ablate.py) ----
+            const uint16_t* qb = a.q + (long)b * a.Dq * a.Hq * a.Wq * a.q_cs + a.q_co;
+            constexpr int CCH = 2 * NB, GPR = 5;                 // 8-channel chunks of this block's b slice; 4-voxel groups per row (20 >= 18)
+            constexpr int NG = G::QZ * G::QY * GPR * CCH;
+            constexpr int GB = 2;                                // groups in flight per thread
+            const int oz = G::P2D ? z0 : z0 - 1, oy = y0 - 1, ox0 = x0 - 1;
+            for (int g0 = 0; g0 < NG; g0 += 256 * GB) {
+                uint4 val[GB][4];
+#pragma unroll
+                for (int k = 0; k < GB; ++k) {
+                    const int gi = g0 + k * 256 + tid;
+                    const int cc = gi % CCH, r = gi / CCH;
+                    const int xg = r % GPR, row = r / GPR;
+                    const int yl = row % G::QY, zl = row / G::QY;
+                    const int gz = oz + zl, gy = oy + yl;
+                    const bool rok = gi < NG && (unsigned)gz < (unsigned)a.Dq && (unsigned)gy < (unsigned)a.Hq && b0 + cc * 8 < a.cb && !WG_ABL(2);
+                    const uint16_t* rp = qb + (((long)gz * a.Hq + gy) * a.Wq) * a.q_cs + b0 + cc * 8;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int gx = ox0 + xg * 4 + e;
+                        val[k][e] = make_uint4(0u, 0u, 0u, 0u);
+                        if (rok && (unsigned)gx < (unsigned)a.Wq) val[k][e] = *reinterpret_cast<const uint4*>(rp + (long)gx * a.q_cs);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < GB; ++k) {
+                    const int gi = g0 + k * 256 + tid;
+                    if (gi >= NG || WG_ABL(4)) continue;
+                    const int cc = gi % CCH, r = gi / CCH;
+                    const int xg = r % GPR, row = r / GPR;
+                    unsigned char* dst = q_lds + (cc * 8) * G::QBS + (row * G::QXP + xg * 4) * 2;
+                    const uint32_t w0[4] = {val[k][0].x, val[k][0].y, val[k][0].z, val[k][0].w};
+                    const uint32_t w1[4] = {val[k][1].x, val[k][1].y, val[k][1].z, val[k][1].w};
+                    const uint32_t w2[4] = {val[k][2].x, val[k][2].y, val[k][2].z, val[k][2].w};
+                    const uint32_t w3[4] = {val[k][3].x, val[k][3].y, val[k][3].z, val[k][3].w};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {                 // channel j = word j >> 1, half j & 1 of every voxel
+                        const uint32_t sel = (j & 1) ? 0x07060302u : 0x05040100u;
+                        const uint32_t lo = __builtin_amdgcn_perm(w1[j >> 1], w0[j >> 1], sel);
+                        const uint32_t hi = __builtin_amdgcn_perm(w3[j >> 1], w2[j >> 1], sel);
+                        *reinterpret_cast<uint2*>(dst + j * G::QBS) = make_uint2(lo, hi);
+                    }
+                }
+            }
+        } else {
+        // ---- stage Q (stride 2), transposed, once per x-tap: q_lds[tx][channel][qz][qy][ox] = Q[.., S*(x0+ox) + tx - 1] ----
         {
             const uint16_t* qb = a.q + (long)b * a.Dq * a.Hq * a.Wq * a.q_cs + a.q_co;
             constexpr int CCH = 2 * NB;                         // 8-channel chunks of this block's b slice
@@ -159,6 +221,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
                 }
             }
         }
+        }
         __syncthreads();
 
         // ---- contraction: this wave's taps x all k-steps ----
@@ -167,13 +230,32 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
             const int chunk = ks * 4 + g;
             const int x8 = chunk & 1, yl = (chunk >> 1) % TY, zl = (chunk >> 1) / TY;
             const uint4 af = *reinterpret_cast<const uint4*>(p_lds + n * G::PAS + ((zl * TY + yl) * 16 + x8 * 8) * 2);
+            if constexpr (G::ONE) {
 #pragma unroll
-            for (int ti = 0; ti < (G::P2D ? 3 : 7); ++ti) {
-                const int tap = G::P2D ? 9 + wave + 4 * ti : wave + 4 * ti;        // P2D: the nine taps of kernel slice tz = 1
-                if (tap < (G::P2D ? 18 : 27)) {
+                for (int i = 0; i < NUW; ++i) {
+                    const int u = wave + 4 * i;
+                    if (u < NU) {
+                        const int pair = u / NB, nb = u % NB;
+                        const int tz = G::P2D ? 1 : pair / 3, ty = pair % 3;
+                        const int qz = G::P2D ? 0 : zl + tz;
+                        const unsigned char* qrow = q_lds + (nb * 16 + n) * G::QBS + ((qz * G::QY + (yl + ty)) * G::QXP + x8 * 8) * 2;
+                        const uint4 c0 = *reinterpret_cast<const uint4*>(qrow);
+                        const uint4 c1 = *reinterpret_cast<const uint4*>(qrow + 16);
+                        const uint4 b1 = make_uint4(__builtin_amdgcn_alignbyte(c0.y, c0.x, 2), __builtin_amdgcn_alignbyte(c0.z, c0.y, 2),
+                                                    __builtin_amdgcn_alignbyte(c0.w, c0.z, 2), __builtin_amdgcn_alignbyte(c1.x, c0.w, 2));
+                        const uint4 b2 = make_uint4(c0.y, c0.z, c0.w, c1.x);
+                        accu[i][0] = WMfma<H>::run(af, c0, accu[i][0]);
+                        accu[i][1] = WMfma<H>::run(af, b1, accu[i][1]);
+                        accu[i][2] = WMfma<H>::run(af, b2, accu[i][2]);
+                    }
+                }
+            } else {
+#pragma unroll
+            for (int ti = 0; ti < 7; ++ti) {
+                const int tap = wave + 4 * ti;
+                if (tap < 27) {
                     const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
-                    const int qz = G::P2D ? 0 : S * zl + tz;
-                    const unsigned char* qrow = q_lds + tx * G::QTS + ((qz * G::QY + (S * yl + ty)) * 16 + x8 * 8) * 2;
+                    const unsigned char* qrow = q_lds + tx * G::QTS + (((S * zl + tz) * G::QY + (S * yl + ty)) * 16 + x8 * 8) * 2;
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {
                         const uint4 bf = *reinterpret_cast<const uint4*>(qrow + (nb * 16 + n) * G::QBS);
@@ -181,21 +263,38 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
                     }
                 }
             }
+            }
         }
         __syncthreads();
     }
 
     // ---- partial sums of this workgroup: part[blockIdx.x][tap][a][b] (lane (n, g) holds a = 4g..4g+3, b = n) ----
     float* part = a.part + (long)blockIdx.x * 27 * a.ca16 * a.cb16;
+    if constexpr (G::ONE) {
 #pragma unroll
-    for (int ti = 0; ti < (G::P2D ? 3 : 7); ++ti) {
-        const int tap = G::P2D ? 9 + wave + 4 * ti : wave + 4 * ti;
-        if (tap < (G::P2D ? 18 : 27)) {
+        for (int i = 0; i < NUW; ++i) {
+            const int u = wave + 4 * i;
+            if (u < NU) {
+                const int pair = u / NB, nb = u % NB;
+                const int tz = G::P2D ? 1 : pair / 3, ty = pair % 3;
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
+                for (int tx = 0; tx < 3; ++tx)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    part[((long)tap * a.ca16 + a0 + g * 4 + i) * a.cb16 + b0 + nb * 16 + n] = acc[ti][nb][i];
+                    for (int k = 0; k < 4; ++k)
+                        part[((long)((tz * 3 + ty) * 3 + tx) * a.ca16 + a0 + g * 4 + k) * a.cb16 + b0 + nb * 16 + n] = accu[i][tx][k];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int ti = 0; ti < 7; ++ti) {
+            const int tap = wave + 4 * ti;
+            if (tap < 27) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        part[((long)tap * a.ca16 + a0 + g * 4 + i) * a.cb16 + b0 + nb * 16 + n] = acc[ti][nb][i];
+            }
         }
     }
 }
