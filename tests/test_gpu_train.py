@@ -553,7 +553,7 @@ def test_vis_unet_fn_stepwise_against_autograd(dtype):
     params = T.VisUNetFn.params(holder)
     T.TRACE = {}
     try:
-        out = T.VisUNetFn.apply(holder, dtype, x_cl, *params)
+        out = T.VisUNetFn.apply(holder, dtype, 1, x_cl, *params)
         out.backward(ops.to_channels_last(gout.cuda(), dtype))
         torch.cuda.synchronize()
         f, b = T.TRACE["vis_unet"][0], T.TRACE["vis_unet_bwd"][0]
@@ -641,7 +641,7 @@ def test_frozen_batchnorm_submodule_in_a_training_step():
     params = T.VisUNetFn.params(holder)
     T.TRACE = {}
     try:
-        out = T.VisUNetFn.apply(holder, dtype, x_cl, *params)
+        out = T.VisUNetFn.apply(holder, dtype, 1, x_cl, *params)
         out.backward(ops.to_channels_last(gout.cuda(), dtype))
         torch.cuda.synchronize()
         f, b = T.TRACE["vis_unet"][0], T.TRACE["vis_unet_bwd"][0]
@@ -852,6 +852,42 @@ def test_feature_net_fn_grouped_equals_per_view_calls(dtype):
             assert int(a) == int(b_) == nbt0 + V
     for (k, pa), (_, pb) in zip(fa.named_parameters(), fb.named_parameters()):
         check_close(f"grad {k}", pa.grad.float().cpu(), pb.grad.float().cpu(), rel_l2=2e-5)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_vis_unet_fn_grouped_equals_per_view_calls(dtype):
+    """The pair U-Net of ALL source views in one VisUNetFn pass (groups = views: every view normalised with its own batch
+    statistics) against one pass per view on a copy of the module, the way the reference runs its pair branch
+    (models/VisMVSNet/model_cas.py:341-352): outputs bit for bit, running statistics, parameter gradients (sums over the views)."""
+    from wild_deep_mvs_amd import synthetic, training as T
+    from wild_deep_mvs_amd.models.VisMVSNet.frontend import Frontend
+    import copy
+    net = Frontend()
+    net.load_state_dict(synthetic.train_state_dict("vis", synthetic.template_of(net), seed=0))
+    ha = [m for m in net.modules() if hasattr(m, "reg") and hasattr(m, "reg_fuse")][0].reg.cuda().train()
+    hb = copy.deepcopy(ha)
+    gen = torch.Generator().manual_seed(12)
+    V, n, d, h, w = 3, 2, 8, 12, 20
+    xs = [(torch.randn(n, d, h, w, 8, generator=gen) * 0.5).to(dtype).cuda() for _ in range(V)]
+    gs = [(torch.randn(n, d, h, w, 8, generator=gen) * 0.1).to(dtype).cuda() for _ in range(V)]
+    xa = torch.cat(xs, 0).requires_grad_(True)
+    out = T.VisUNetFn.apply(ha, dtype, V, xa, *T.VisUNetFn.params(ha))
+    out.backward(torch.cat(gs, 0))
+    refs, dxs = [], []
+    for x, g in zip(xs, gs):
+        xr = x.clone().requires_grad_(True)
+        o = T.VisUNetFn.apply(hb, dtype, 1, xr, *T.VisUNetFn.params(hb))
+        o.backward(g)
+        refs.append(o.detach()); dxs.append(xr.grad)
+    torch.cuda.synchronize()
+    assert torch.equal(out.detach(), torch.cat(refs, 0)), "grouped pair U-Net differs from the per-view passes"
+    assert torch.equal(xa.grad, torch.cat(dxs, 0)), "grouped input gradient differs from the per-view passes"
+    for (k, a), (_, b_) in zip(ha.state_dict().items(), hb.state_dict().items()):
+        if "running_" in k:
+            check_close(f"stat {k}", a.float().cpu(), b_.float().cpu(), rel_l2=1e-6)
+    for (k, pa), (_, pb) in zip(ha.named_parameters(), hb.named_parameters()):
+        if pb.grad is not None:
+            check_close(f"grad {k}", pa.grad.float().cpu(), pb.grad.float().cpu(), rel_l2=3e-5)
 
 
 @pytest.mark.parametrize("dtype", DT)

@@ -305,16 +305,20 @@ class SingleStage(nn.Module):
         costs = T.WarpCostFn.apply(cams, planes.contiguous(), L.GEOM_HOMOG, L.COST_GROUPCORR, dt, None, ref_feat, *srcs_feat)
         reg_params = T.VisUNetFn.params(self.reg)
         interms, uncerts, pair_results = [], [], []
-        for i in range(len(srcs_feat)):
-            interm = T.VisUNetFn.apply(self.reg, dt, costs[i], *reg_params)
-            idx, ent, _ = T.ScoreHeadFn.apply(dt, None, interm, self.reg_pair.final_conv.weight)
+        # the pair branch of ALL source views in one pass per layer: the views are the group axis of the BatchNorm statistics (each
+        # view its own, like the reference's per-view calls), convolutions / weight gradients / the score head run over the stack
+        V = len(srcs_feat)
+        interm_all = T.VisUNetFn.apply(self.reg, dt, V, costs.reshape((V * n,) + tuple(costs.shape[2:])), *reg_params)
+        idx_all, ent_all, _ = T.ScoreHeadFn.apply(dt, None, interm_all, self.reg_pair.final_conv.weight)
+        per_view = lambda t_: t_.view((V, n) + tuple(t_.shape[1:])).unbind(0)         # (one stack in the backward, not V padded adds)
+        for interm, idx, ent in zip(per_view(interm_all), per_view(idx_all), per_view(ent_all)):
             est_depth = idx.unsqueeze(1) * depth_interval + depth_start                  # model_cas.py:348
             heads = self.uncert_net(ent.unsqueeze(1))
             pair_results.append([est_depth, heads])
             interms.append(interm)
             uncerts.append(heads[0].squeeze(1))
         fused = T.FusePairsFn.apply(len(interms), *interms, *uncerts)                    # model_cas.py:354-357,385-386
-        fu = T.VisUNetFn.apply(self.reg_fuse, dt, fused, *T.VisUNetFn.params(self.reg_fuse))
+        fu = T.VisUNetFn.apply(self.reg_fuse, dt, 1, fused, *T.VisUNetFn.params(self.reg_fuse))
         idx, _, conf = T.ScoreHeadFn.apply(dt, 2.0, fu, self.reg_fuse.final_conv.weight)
         est_depth = idx.unsqueeze(1) * depth_interval + depth_start                      # model_cas.py:404-405
         return est_depth, conf.unsqueeze(1), pair_results

@@ -296,17 +296,31 @@ class RegressFn(torch.autograd.Function):
 # --------------------------------------------------------------------------------------------------
 # Vis-MVSNet: residual-block U-Net, score heads, visibility-weighted fusion
 # --------------------------------------------------------------------------------------------------
-def _bn_stats_affine(bn: nn.BatchNorm3d, y: torch.Tensor):
-    """Batch statistics of a stored conv output -> (scale, bias, mean, invstd, nvox); updates the running statistics."""
-    nvox = y.numel() // y.shape[4]
-    scale, bias, mean, invstd = _bn_affine(Block("", "", y, bn=bn), ops.bn_stats(y), nvox)
-    return scale, bias, mean, invstd, nvox
+def _bn_stats_affine(bn: nn.BatchNorm3d, y: torch.Tensor, groups: int = 1):
+    """Batch statistics of a stored conv output -> (scale, bias, mean, invstd, nvox); updates the running statistics.  ``groups`` > 1:
+    the batch axis holds that many consecutive slices (the source views of a sample), each normalised with its own statistics like
+    the reference's per-view calls; the constants come back as [G,C] rows and ``nvox`` counts one group."""
+    if groups == 1:
+        nvox = y.numel() // y.shape[4]
+        scale, bias, mean, invstd = _bn_affine(Block("", "", y, bn=bn), ops.bn_stats(y), nvox)
+        return scale, bias, mean, invstd, nvox
+    nvox = y.numel() // y.shape[4] // groups
+    aff = _bn_affine_grouped(bn, ops.bn_stats(y, groups), nvox, groups)
+    return aff[:, 0], aff[:, 1], aff[:, 2], aff[:, 3], nvox
 
 
 def _bn_backward(bn: nn.BatchNorm3d, dz_src: torch.Tensor, y: torch.Tensor, saved, relu: bool):
-    """BatchNorm(+ReLU before any skip) backward on the engine: returns (dy, d gamma, d beta)."""
+    """BatchNorm(+ReLU before any skip) backward on the engine: returns (dy, d gamma, d beta); grouped constants ([G,C] rows of
+    ``_bn_stats_affine(..., groups)``) give per-group coefficients and gradients summed over the groups (one shared module)."""
     scale, bias, mean, invstd, nvox = saved
     s = ops.bn_bwd_reduce(dz_src, y, scale, bias, relu=relu)
+    if scale.dim() == 2:
+        co = ops.bn_bwd_coeffs(s, mean, invstd, bn.weight, nvox)                       # [G,5,C]
+        if not bn.training:
+            co[:, 1:3].zero_()
+        dy = ops.bn_bwd_apply(dz_src, y, scale, bias, co[:, 0], co[:, 1], co[:, 2], relu=relu)
+        dgb = co[:, 3:5].sum(0)
+        return dy, dgb[0].to(bn.weight.dtype), dgb[1].to(bn.bias.dtype)
     ca, cb, cc, s2, s1 = _bn_coeffs(bn, s, mean, invstd, nvox)
     dy = ops.bn_bwd_apply(dz_src, y, scale, bias, ca, cb, cc, relu=relu)
     return dy, s2.to(bn.weight.dtype), s1.to(bn.bias.dtype)
@@ -343,24 +357,27 @@ class VisUNetFn(torch.autograd.Function):
         return w3
 
     @staticmethod
-    def forward(ctx, holder, dtype, x, *params):
+    def forward(ctx, holder, dtype, groups, x, *params):
+        # groups > 1: the batch axis is that many consecutive slices -- the source views of a sample, whose pair U-Nets the reference
+        # runs one view at a time (model_cas.py:341-352) -- each with its own BatchNorm statistics, in ONE launch per layer
         b0, b1, dec = VisUNetFn.parts(holder)
         dev = x.device
+        _bsa = lambda bn, y: _bn_stats_affine(bn, y, groups)
         mk = lambda w, kind, tr=False: ops.Conv3dLayer.build(w, kind=kind, transposed=tr, device=dev, dtype=dtype)
         y1 = ops.conv3d(x, mk(b0.conv1.weight, L.CONV_S1))
-        a1 = _bn_stats_affine(b0.bn1, y1)
+        a1 = _bsa(b0.bn1, y1)
         t = ops.bn_act(y1, a1[0], a1[1], relu=True)
         y2 = ops.conv3d(t, mk(b0.conv2.weight, L.CONV_S1))
-        a2 = _bn_stats_affine(b0.bn2, y2)
+        a2 = _bsa(b0.bn2, y2)
         enc0 = ops.bn_act(y2, a2[0], a2[1], relu="post", skip=x)
         y3 = ops.conv3d(enc0, mk(b1.conv1.weight, L.CONV_S2))
-        a3 = _bn_stats_affine(b1.bn1, y3)
+        a3 = _bsa(b1.bn1, y3)
         t1 = ops.bn_act(y3, a3[0], a3[1], relu=True)
         y4 = ops.conv3d(enc0, mk(VisUNetFn._ds_weight(b1), L.CONV_S2))
-        a4 = _bn_stats_affine(b1.downsample[1], y4)
+        a4 = _bsa(b1.downsample[1], y4)
         ds = ops.bn_act(y4, a4[0], a4[1], relu=False)
         y5 = ops.conv3d(t1, mk(b1.conv2.weight, L.CONV_S1))
-        a5 = _bn_stats_affine(b1.bn2, y5)
+        a5 = _bsa(b1.bn2, y5)
         e1 = ops.bn_act(y5, a5[0], a5[1], relu="post", skip=ds)
         up = ops.conv3d(e1, mk(dec[0].weight, L.CONV_T2, True))
         cat = torch.cat([up, enc0], dim=4)                                   # deconv channels first (nn_utils.py:269-271)
@@ -406,7 +423,7 @@ class VisUNetFn(torch.autograd.Function):
         dt = ops.conv3d(dy2, mk(b0.conv2.weight, L.CONV_S1, True))
         dy1, dg1, db1 = _bn_backward(b0.bn1, dt, T_["y1"], a1, relu=True)
         dw_c1a = ops.conv3d_wgrad(dy1, T_["x"], ca=8, cb=8, stride=1)
-        dx = ops.conv3d(dy1, mk(b0.conv1.weight, L.CONV_S1, True), skip=dpre0) if ctx.needs_input_grad[2] else None
+        dx = ops.conv3d(dy1, mk(b0.conv1.weight, L.CONV_S1, True), skip=dpre0) if ctx.needs_input_grad[3] else None
         if TRACE is not None:
             TRACE.setdefault("vis_unet_bwd", []).append(dict(g=g, dcat=dcat, de1=de1, dpre=dpre, dy5=dy5, dt1=dt1, dy4=dy4, dy3=dy3,
                                                              denc0=denc0, dpre0=dpre0, dy2=dy2, dt=dt, dy1=dy1, dx=dx))
@@ -415,7 +432,7 @@ class VisUNetFn(torch.autograd.Function):
                  wd(dw_c1b, b1.conv1.weight), dg3, db3, wd(dw_ds, b1.downsample[0].weight), dg4, db4,
                  wd(dw_c2b, b1.conv2.weight), dg5, db5, wd(dw_dec, dec[0].weight), wd(dw_post, dec[1].weight)]
         ctx.t = None
-        return (None, None, dx, *grads)
+        return (None, None, None, dx, *grads)
 
 
 class ScoreHeadFn(torch.autograd.Function):
