@@ -15,6 +15,7 @@
 // A workgroup owns one 16-channel a-tile and NB 16-channel b-tiles (blockIdx.y) and walks voxel tiles persistently
 // (blockIdx.x, grid-stride); its 4 waves split the 27 taps, accumulators stay in registers across tiles.  Partial sums go
 // to a workspace [nblk][27][CA16][CB16] and a finishing kernel adds them in a fixed order: bit-reproducible, no atomics.
+#include <stdlib.h>
 #include "pscv_common.h"
 
 namespace pscv {
@@ -344,7 +345,18 @@ static WgPlan wgrad_plan(int B, int Dp, int Hp, int Wp, int ca, int cb, int stri
     p.ntz = wg_ceil(Dp, p.tz); p.nty = wg_ceil(Hp, p.ty); p.ntx = wg_ceil(Wp, 16);
     p.ntiles = B * p.ntz * p.nty * p.ntx;
     p.ny = (p.ca16 / 16) * (p.cb16 / (16 * p.nb));
-    int want = 1024 / p.ny;            // ~4 workgroups per CU in total
+    // ONE resident round of persistent workgroups: as many as the LDS tile lets a CU hold (at most 4), times 256 CUs.  (A fixed 1024
+    // left the 41 KB tiles of the two-b-tile stride-1 kernel -- three per CU -- with a third of a second round: conv0's gradient
+    // 380 -> 314 us at 768.)
+    const int lds = stride == 1 ? (p.tz == 1 ? (p.nb == 2 ? WgGeom<1, 1, 8, 2>::LDS : WgGeom<1, 1, 8, 1>::LDS)
+                                             : (p.nb == 2 ? WgGeom<1, 2, 4, 2>::LDS : WgGeom<1, 2, 4, 1>::LDS))
+                                : (p.nb == 2 ? WgGeom<2, 2, 2, 2>::LDS : WgGeom<2, 2, 2, 1>::LDS);
+    int per_cu = (160 * 1024) / (lds + 512);
+    per_cu = per_cu > 4 ? 4 : per_cu < 1 ? 1 : per_cu;
+    int want = 256 * per_cu / p.ny;
+#ifdef PSCV_ABLATE
+    if (const char* e = getenv("PSCV_WG_WANT")) want = atoi(e) / p.ny;
+#endif
     if (want < 1) want = 1;
     p.nblk = p.ntiles < want ? p.ntiles : want;
     return p;
