@@ -844,13 +844,21 @@ template <typename TIn, typename TOut, int COST>
 static int wl_launch(const WarpArgs& a, int nblk, hipStream_t st) {
     auto kern = warp_cost_lds_kernel<TIn, TOut, PSCV_GEOM_PROJ, COST>;
     static bool attr_done = false;
+    int lds = WL_LDS;
+#ifdef PSCV_ABLATE
+    {   // occupancy experiment (scripts/dev/wl_residency.py): pscv_set_tuning("fuse_c0", k) asks for k KiB of LDS on top, i.e. fewer
+        extern Knob g_fuse_c0;                                  // workgroups per CU with the same code
+        lds += 1024 * g_fuse_c0;
+        attr_done = false;
+    }
+#endif
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, WL_LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) { set_error("pscv_warp_cost(lds): hipFuncSetAttribute: %s", hipGetErrorString(e)); return -2; }
         attr_done = true;
     }
     const int tiles = a.B * ((a.h + WL_TH - 1) / WL_TH) * ((a.w + WL_T - 1) / WL_T);
-    hipLaunchKernelGGL(kern, dim3(8 * ((tiles + 7) / 8), a.n_dchunks), dim3(WL_THREADS), WL_LDS, st, a);
+    hipLaunchKernelGGL(kern, dim3(8 * ((tiles + 7) / 8), a.n_dchunks), dim3(WL_THREADS), lds, st, a);
     return 0;
 }
 
