@@ -58,7 +58,7 @@ struct WgradArgs {
 // P2D (TZ = 1): single-plane volumes, i.e. the 2-D layers of the feature extractors run as D = 1: the z taps 0 and 2 only ever meet
 // zero padding, so one Q plane is staged, the waves split the 9 (ty, tx) taps of kernel slice tz = 1, and the tile is 8 rows of
 // one plane instead of 4 rows of two (with D = 1 half of a two-plane tile is padding): 6x fewer MFMAs per pixel.
-template <int S, int TZ, int TY, int NB> struct WgGeom {
+template <int S, int TZ, int TY, int NB, int NA = 1> struct WgGeom {
     static constexpr bool P2D = TZ == 1;
     static constexpr int NV = TZ * TY * 16;                 // P voxels per tile
     static constexpr int QZ = P2D ? 1 : S * (TZ - 1) + 3, QY = S * (TY - 1) + 3, QX = S * 15 + 3;
@@ -70,16 +70,17 @@ template <int S, int TZ, int TY, int NB> struct WgGeom {
     static constexpr int QXP = 24;
     static constexpr int QBS = ONE ? QZ * QY * QXP * 2 + 16 : QZ * QY * 32 + 16;   // bytes per Q channel block
     static constexpr int QTS = 16 * NB * QBS;               // bytes per copy of Q
-    static constexpr int P_BYTES = 16 * PAS;
+    static constexpr int P_BYTES = 16 * NA * PAS;           // NA 16-channel a-tiles per workgroup (single-plane mode: 4 when c_a = 64)
     static constexpr int LDS = P_BYTES + (ONE ? 1 : 3) * QTS;
     static constexpr int KSTEPS = TZ * TY * 2 / 4;
     static_assert((TZ * TY * 2) % 4 == 0, "tile must hold whole k-steps");
     static_assert((PAS / 16) % 2 == 1 && (QBS / 16) % 2 == 1, "odd slot strides");
 };
 
-template <typename H, int S, int TZ, int TY, int NB>
+template <typename H, int S, int TZ, int TY, int NB, int NA = 1>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
-    using G = WgGeom<S, TZ, TY, NB>;
+    using G = WgGeom<S, TZ, TY, NB, NA>;
+    static_assert(NA == 1 || (G::ONE && G::P2D), "several a-tiles per workgroup: single-plane stride-1 mode only (accumulator budget)");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* p_lds = smem;
     unsigned char* q_lds = smem + G::P_BYTES;
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     const int n = lane & 15, g = lane >> 4;
     const int nbg = a.cb16 / (16 * NB);
     const int at = blockIdx.y / nbg, bg = blockIdx.y % nbg;
-    const int a0 = at * 16, b0 = bg * 16 * NB;
+    const int a0 = at * 16 * NA, b0 = bg * 16 * NB;
 
     wg_f32x4 acc[7][NB];
 #pragma unroll
@@ -98,11 +99,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     // stride 1: a wave owns whole (tz, ty, b-tile) units -- unit u = wave + 4 i -> pair u / NB, b-tile u % NB -- and runs their three
     // x-taps off ONE pair of aligned reads (two ds_read_b128 + four byte-align ops per three MFMAs)
     constexpr int NPAIR = G::P2D ? 3 : 9, NU = NPAIR * NB, NUW = (NU + 3) / 4;
-    wg_f32x4 accu[G::ONE ? NUW : 1][3];
+    // (single-plane mode with 64 a-channels: NA = 4 a-tiles share ONE staging of Q -- as (a-tile, b-group) workgroups every Q tile was
+    //  transposed four times)
+    wg_f32x4 accu[NA][G::ONE ? NUW : 1][3];
 #pragma unroll
-    for (int i = 0; i < (G::ONE ? NUW : 1); ++i)
+    for (int m = 0; m < NA; ++m)
 #pragma unroll
-        for (int tx = 0; tx < 3; ++tx) accu[i][tx] = wg_f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < (G::ONE ? NUW : 1); ++i)
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx) accu[m][i][tx] = wg_f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         int t = tile;
@@ -115,7 +120,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         // ---- stage P, transposed: p_lds[channel][voxel] ----
         {
             const uint16_t* pb = a.p + (long)b * a.Dp * a.Hp * a.Wp * a.p_cs + a.p_co;
-            constexpr int NCH = G::NV * 2;
+            constexpr int NCH = G::NV * 2 * NA;
             for (int c = tid; c < (WG_ABL(1) ? 0 : NCH); c += 256) {
                 const int vox = c % G::NV, c8 = c / G::NV;
                 const int xl = vox & 15, yl = (vox >> 4) % TY, zl = (vox >> 4) / TY;
@@ -245,9 +250,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
                         const uint4 b1 = make_uint4(__builtin_amdgcn_alignbyte(c0.y, c0.x, 2), __builtin_amdgcn_alignbyte(c0.z, c0.y, 2),
                                                     __builtin_amdgcn_alignbyte(c0.w, c0.z, 2), __builtin_amdgcn_alignbyte(c1.x, c0.w, 2));
                         const uint4 b2 = make_uint4(c0.y, c0.z, c0.w, c1.x);
-                        accu[i][0] = WMfma<H>::run(af, c0, accu[i][0]);
-                        accu[i][1] = WMfma<H>::run(af, b1, accu[i][1]);
-                        accu[i][2] = WMfma<H>::run(af, b2, accu[i][2]);
+#pragma unroll
+                        for (int m = 0; m < NA; ++m) {
+                            const uint4 afm = m == 0 ? af : *reinterpret_cast<const uint4*>(p_lds + (m * 16 + n) * G::PAS + ((zl * TY + yl) * 16 + x8 * 8) * 2);
+                            accu[m][i][0] = WMfma<H>::run(afm, c0, accu[m][i][0]);
+                            accu[m][i][1] = WMfma<H>::run(afm, b1, accu[m][i][1]);
+                            accu[m][i][2] = WMfma<H>::run(afm, b2, accu[m][i][2]);
+                        }
                     }
                 }
             } else {
@@ -279,10 +288,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
                 const int pair = u / NB, nb = u % NB;
                 const int tz = G::P2D ? 1 : pair / 3, ty = pair % 3;
 #pragma unroll
-                for (int tx = 0; tx < 3; ++tx)
+                for (int m = 0; m < NA; ++m)
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        part[((long)((tz * 3 + ty) * 3 + tx) * a.ca16 + a0 + g * 4 + k) * a.cb16 + b0 + nb * 16 + n] = accu[i][tx][k];
+                    for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            part[((long)((tz * 3 + ty) * 3 + tx) * a.ca16 + a0 + m * 16 + g * 4 + k) * a.cb16 + b0 + nb * 16 + n] = accu[m][i][tx][k];
             }
         }
     } else {
@@ -334,7 +345,7 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restri
 
 static inline int wg_ceil(int a, int b) { return (a + b - 1) / b; }
 
-struct WgPlan { int tz, ty, nb, ntz, nty, ntx, ntiles, nblk, ny, ca16, cb16; };
+struct WgPlan { int tz, ty, nb, na, ntz, nty, ntx, ntiles, nblk, ny, ca16, cb16; };
 
 static WgPlan wgrad_plan(int B, int Dp, int Hp, int Wp, int ca, int cb, int stride) {
     WgPlan p;
@@ -342,13 +353,15 @@ static WgPlan wgrad_plan(int B, int Dp, int Hp, int Wp, int ca, int cb, int stri
     if (Dp == 1 && stride == 1) { p.tz = 1; p.ty = 8; }          // 2-D layers (P2D)
     p.ca16 = wg_ceil(ca, 16) * 16; p.cb16 = wg_ceil(cb, 16) * 16;
     p.nb = (p.cb16 % 32 == 0) ? 2 : 1;
+    p.na = (p.tz == 1 && p.ca16 % 64 == 0) ? 4 : 1;          // single-plane mode: four a-tiles share one staging of Q
     p.ntz = wg_ceil(Dp, p.tz); p.nty = wg_ceil(Hp, p.ty); p.ntx = wg_ceil(Wp, 16);
     p.ntiles = B * p.ntz * p.nty * p.ntx;
-    p.ny = (p.ca16 / 16) * (p.cb16 / (16 * p.nb));
+    p.ny = (p.ca16 / (16 * p.na)) * (p.cb16 / (16 * p.nb));
     // ONE resident round of persistent workgroups: as many as the LDS tile lets a CU hold (at most 4), times 256 CUs.  (A fixed 1024
     // left the 41 KB tiles of the two-b-tile stride-1 kernel -- three per CU -- with a third of a second round: conv0's gradient
     // 380 -> 314 us at 768.)
-    const int lds = stride == 1 ? (p.tz == 1 ? (p.nb == 2 ? WgGeom<1, 1, 8, 2>::LDS : WgGeom<1, 1, 8, 1>::LDS)
+    const int lds = stride == 1 ? (p.tz == 1 ? (p.na == 4 ? (p.nb == 2 ? WgGeom<1, 1, 8, 2, 4>::LDS : WgGeom<1, 1, 8, 1, 4>::LDS)
+                                                            : (p.nb == 2 ? WgGeom<1, 1, 8, 2>::LDS : WgGeom<1, 1, 8, 1>::LDS))
                                              : (p.nb == 2 ? WgGeom<1, 2, 4, 2>::LDS : WgGeom<1, 2, 4, 1>::LDS))
                                 : (p.nb == 2 ? WgGeom<2, 2, 2, 2>::LDS : WgGeom<2, 2, 2, 1>::LDS);
     int per_cu = (160 * 1024) / (lds + 512);
@@ -362,11 +375,11 @@ static WgPlan wgrad_plan(int B, int Dp, int Hp, int Wp, int ca, int cb, int stri
     return p;
 }
 
-template <typename H, int S, int TZ, int TY, int NB>
+template <typename H, int S, int TZ, int TY, int NB, int NA = 1>
 static int wgrad_launch(const WgradArgs& a, const WgPlan& p, hipStream_t st) {
-    using G = WgGeom<S, TZ, TY, NB>;
+    using G = WgGeom<S, TZ, TY, NB, NA>;
     static_assert(G::LDS <= 160 * 1024, "wgrad tile does not fit the LDS");
-    auto kern = wgrad_kernel<H, S, TZ, TY, NB>;
+    auto kern = wgrad_kernel<H, S, TZ, TY, NB, NA>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
@@ -414,7 +427,8 @@ extern "C" int pscv_conv3d_wgrad(const void* p, int p_cstride, int p_coff, int c
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int rc;
 #define PSCV_WG(HT)                                                                       \
-    if (pl.tz == 1) rc = pl.nb == 2 ? wgrad_launch<HT, 1, 1, 8, 2>(a, pl, st) : wgrad_launch<HT, 1, 1, 8, 1>(a, pl, st); \
+    if (pl.tz == 1 && pl.na == 4) rc = pl.nb == 2 ? wgrad_launch<HT, 1, 1, 8, 2, 4>(a, pl, st) : wgrad_launch<HT, 1, 1, 8, 1, 4>(a, pl, st); \
+    else if (pl.tz == 1) rc = pl.nb == 2 ? wgrad_launch<HT, 1, 1, 8, 2>(a, pl, st) : wgrad_launch<HT, 1, 1, 8, 1>(a, pl, st); \
     else if (stride == 1) rc = pl.nb == 2 ? wgrad_launch<HT, 1, 2, 4, 2>(a, pl, st) : wgrad_launch<HT, 1, 2, 4, 1>(a, pl, st); \
     else rc = pl.nb == 2 ? wgrad_launch<HT, 2, 2, 2, 2>(a, pl, st) : wgrad_launch<HT, 2, 2, 2, 1>(a, pl, st);
     if (dtype == PSCV_BF16) { PSCV_WG(bf16_t) } else { PSCV_WG(f16_t) }
