@@ -13,6 +13,7 @@
 // return); the reference-feature gradient is accumulated over the block's depth planes in registers first.
 // Same block / lane mapping and XCD-banded block order as the forward (warp_cost.hip).
 #include <limits.h>
+#include <type_traits>
 
 #include "warp_common.h"
 
@@ -284,6 +285,7 @@ __global__ __launch_bounds__(256) void warp_bwd_tile_kernel(const WarpBwdArgs A)
     extern __shared__ __attribute__((aligned(16))) int patch[];   // [BT_TEXELS][TS] fixed point
     __shared__ float cam_lds[PSCV_MAX_SRC * PSCV_CAM_FLOATS];
     __shared__ int mm[PSCV_MAX_SRC][5];   // (min x, min y, max x, max y, bits of the magnitude bound)
+    __shared__ int mm2[4];                // box of one row group when the tile's box exceeds the patch (sub-passes)
     __shared__ float red_lds[4];
 
     const int nwg = gridDim.x;
@@ -507,14 +509,18 @@ __global__ __launch_bounds__(256) void warp_bwd_tile_kernel(const WarpBwdArgs A)
             atomicMax(&mm[v][4], bbits);
         }
         __syncthreads();   // also: the previous view's flush (which re-zeroes the patch) is complete
-        const int bx0 = max(mm[v][0], 0), by0 = max(mm[v][1], 0);
-        const int bx1 = (mm[v][2] == INT_MIN) ? -1 : min(mm[v][2] + 1, a.ws - 1);
-        const int by1 = (mm[v][3] == INT_MIN) ? -1 : min(mm[v][3] + 1, a.hs - 1);
+        int bx0 = max(mm[v][0], 0), by0 = max(mm[v][1], 0);
+        int bx1 = (mm[v][2] == INT_MIN) ? -1 : min(mm[v][2] + 1, a.ws - 1);
+        int by1 = (mm[v][3] == INT_MIN) ? -1 : min(mm[v][3] + 1, a.hs - 1);
         int bw = max(bx1 - bx0 + 1, 0), bh = max(by1 - by0 + 1, 0);
-        if (bw * bh > BT_TEXELS) {            // clip to the patch capacity: the rest goes straight to global memory
-            if (bw > BT_TEXELS) bw = BT_TEXELS;
-            bh = BT_TEXELS / bw;
-        }
+        // A box beyond the patch capacity (CVP-MVSNet's per-pixel hypotheses around a noisy depth estimate; strongly zoomed views):
+        // instead of clipping it -- every tap outside takes scattered global atomics, 16 per lane and tap, ~20 G lanes/s -- the
+        // tile's rows are processed in 2 or 4 sub-passes (row groups of 4 / 2), each with its own box, scatter and flush.
+#ifndef BT_SUB_X10
+#define BT_SUB_X10 10      // sub-passes from (BT_SUB_X10 / 10) x the capacity on: below that the clipped box + a few direct taps is cheaper
+#endif
+        const int area10 = bw * bh * 10;
+        const int nsub = area10 <= BT_TEXELS * BT_SUB_X10 ? 1 : (area10 <= 2 * BT_TEXELS * BT_SUB_X10 ? 2 : 4);      // (workgroup-uniform: from mm[v])
         float* dsrc_v = A.dsrc[v] + img_elems;
         // fixed-point scale 2^(20 - exponent(bound)): |value * scale| < 2^21, and 2^21 * 512 adds stays inside int32
         const int bexp = ((mm[v][4] >> 23) & 255) - 127;
@@ -522,6 +528,14 @@ __global__ __launch_bounds__(256) void warp_bwd_tile_kernel(const WarpBwdArgs A)
         const float scale = __uint_as_float((unsigned)(127 + sexp) << 23);
         const float inv_scale = __uint_as_float((unsigned)(127 - sexp) << 23);
 
+        // one scatter + flush pass over the lanes that are `mine` (ALL: every lane, the common case -- compiled without the per-lane
+        // test, which would otherwise sit between the four planes' gathers and serialise their latencies: +70 % on the whole kernel)
+        auto scatter_flush = [&](auto allc, const bool mine) {
+        constexpr bool ALL = decltype(allc)::value;
+        if (bw * bh > BT_TEXELS) {            // still beyond the capacity: clip, the rest goes straight to global memory
+            if (bw > BT_TEXELS) bw = BT_TEXELS;
+            bh = BT_TEXELS / bw;
+        }
         auto put = [&](int tx, int ty, unsigned o, float wgt, const VecF<CPL>& gw) {
             if (wgt == 0.0f) return;
             const int lx = tx - bx0, ly = ty - by0;
@@ -542,7 +556,7 @@ __global__ __launch_bounds__(256) void warp_bwd_tile_kernel(const WarpBwdArgs A)
         for (int i = 0; i < BT_PLN; ++i) {
             Taps taps;
             int x0, y0;
-            if (BT_ABL(8)) continue;
+            if (BT_ABL(8) || (!ALL && !mine)) continue;      // (a lane is `mine` in exactly one sub-pass: its sums below are taken once)
             const VecF<CPL> wv = sample(v, dval[i], taps, x0, y0);
             VecF<CPL> gw;
             if (VAR) {
@@ -560,7 +574,7 @@ __global__ __launch_bounds__(256) void warp_bwd_tile_kernel(const WarpBwdArgs A)
             } else {
                 gw = G[i];
             }
-            if (dok[i]) {
+            if (dok[i] && (ALL || mine)) {
                 put(x0, y0, taps.o00, taps.w00, gw);
                 put(x0 + 1, y0, taps.o01, taps.w01, gw);
                 put(x0, y0 + 1, taps.o10, taps.w10, gw);
@@ -580,6 +594,46 @@ __global__ __launch_bounds__(256) void warp_bwd_tile_kernel(const WarpBwdArgs A)
                 *p = 0;
             }
         }
+        };
+        if (nsub == 1) {
+            scatter_flush(std::true_type{}, true);
+        } else {
+        for (int sub = 0; sub < nsub; ++sub) {
+        const bool mine = ((pl / BT_TW) * nsub) / BT_TH == sub;
+        {
+            // this row group's own box (same steps as above, over its lanes only)
+            if (tid < 4) mm2[tid] = (tid & 2) ? INT_MIN : INT_MAX;
+            __syncthreads();          // also: the previous sub-pass' flush is complete
+            int snx = INT_MAX, sny = INT_MAX, sxx = INT_MIN, sxy = INT_MIN;
+#pragma unroll
+            for (int i = 0; i < BT_PLN; ++i) {
+                float ix, iy;
+                sweep_index<GEOM>(cam_lds + v * PSCV_CAM_FLOATS, px, py, dval[i], a, ix, iy);
+                const int x0 = (int)floorf(ix), y0 = (int)floorf(iy);
+                if (mine && dok[i] && x0 >= -1 && x0 < a.ws && y0 >= -1 && y0 < a.hs) {
+                    snx = min(snx, x0); sny = min(sny, y0); sxx = max(sxx, x0); sxy = max(sxy, y0);
+                }
+            }
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) {
+                snx = min(snx, __shfl_xor(snx, m, 64)); sny = min(sny, __shfl_xor(sny, m, 64));
+                sxx = max(sxx, __shfl_xor(sxx, m, 64)); sxy = max(sxy, __shfl_xor(sxy, m, 64));
+            }
+            if ((tid & 63) == 0) {
+                atomicMin(&mm2[0], snx); atomicMin(&mm2[1], sny);
+                atomicMax(&mm2[2], sxx); atomicMax(&mm2[3], sxy);
+            }
+            __syncthreads();
+            bx0 = max(mm2[0], 0); by0 = max(mm2[1], 0);
+            bx1 = (mm2[2] == INT_MIN) ? -1 : min(mm2[2] + 1, a.ws - 1);
+            by1 = (mm2[3] == INT_MIN) ? -1 : min(mm2[3] + 1, a.hs - 1);
+            bw = max(bx1 - bx0 + 1, 0); bh = max(by1 - by0 + 1, 0);
+            __syncthreads();          // everybody has read mm2 before the next sub-pass resets it
+        }
+        scatter_flush(std::false_type{}, mine);
+        }   // sub-passes
+        }
+
     }
 
     // Reference-feature gradient of the tile: through LDS (the patch is free now) so that a wave's 64 lanes add to 64 CONSECUTIVE floats
