@@ -37,8 +37,7 @@ def other_arch(a, dt):
     net.load_state_dict(synthetic.train_state_dict(key, synthetic.template_of(net), seed=0))
     net = net.cuda().train()
     net.train_storage_dtype = dt
-    if a.arch == "cvp":
-        net.feature_engine_train = a.feature_engine      # the 2-D pyramid tower in train(): PyTorch-ROCm autograd or training.FeaturePyramidFn
+    net.feature_engine_train = a.feature_engine          # the 2-D extractor / pyramid tower in train(): PyTorch-ROCm autograd or the engine's nodes
     opt = torch.optim.Adam(net.parameters(), lr=1e-4)
     scene = synthetic.make_scene(a.batch, a.views, a.height, a.width, seed=0)
     if a.arch == "cvp":

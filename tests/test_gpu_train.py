@@ -891,6 +891,147 @@ def test_vis_unet_fn_grouped_equals_per_view_calls(dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
+def test_generic_2d_layer_nodes_against_aten_autograd(dtype):
+    """training.Conv2dFn (k3 s1 | k3 s2 | k1 s1 | k1 s2, up to 128 channels: weight gradients in 64-channel slices, stride-2 gradients
+    from parity planes / parity sub-convolutions), Deconv2dFn (ConvTranspose2d k3 s2 p1 op1) and BnAct2dFn (grouped batch-statistics
+    BatchNorm2d, ReLU before / after a skip add) against ATen autograd on identical 16-bit-exact operands."""
+    from wild_deep_mvs_amd import ops, training as T
+    g = torch.Generator().manual_seed(77)
+    cl = lambda v: v.permute(0, 2, 3, 1).to(dtype).contiguous().cuda()
+    cf = lambda v: v.float().permute(0, 3, 1, 2).cpu()
+    holder = torch.nn.Module()
+    N, H, W = 2, 16, 24
+    for tag, (ci, co, k, s_) in enumerate([(32, 32, 3, 1), (64, 128, 3, 2), (128, 128, 3, 1), (32, 64, 3, 2), (16, 32, 1, 1), (64, 128, 1, 2),
+                                           (128, 64, 3, 1), (128, 32, 3, 1)]):
+        w = (torch.randn(co, ci, k, k, generator=g) * 0.1).to(dtype).float().requires_grad_(True)
+        x = torch.randn(N, ci, H, W, generator=g).to(dtype).float().requires_grad_(True)
+        y = F.conv2d(x, w, None, stride=s_, padding=k // 2)
+        dy = (torch.randn(y.shape, generator=g) * 0.5).to(dtype).float()
+        y.backward(dy)
+        xe = cl(x.detach()).requires_grad_(True)
+        we = w.detach().cuda().requires_grad_(True)
+        ye = T.Conv2dFn.apply(holder, f"t{tag}", dtype, s_, xe, we)
+        ye.backward(cl(dy))
+        ulp = 2 ** -8 if dtype == torch.bfloat16 else 2 ** -11
+        check_close(f"conv k{k}s{s_} {ci}->{co} y", cf(ye.detach()), y.detach(), rel_l2=2 * ulp)
+        check_close(f"conv k{k}s{s_} {ci}->{co} dW", we.grad.cpu(), w.grad, rel_l2=3e-5)
+        check_close(f"conv k{k}s{s_} {ci}->{co} dX", cf(xe.grad), x.grad, rel_l2=2 * ulp)
+    for tag, (ci, co) in enumerate([(128, 64), (64, 32)]):
+        w = (torch.randn(ci, co, 3, 3, generator=g) * 0.1).to(dtype).float().requires_grad_(True)
+        x = torch.randn(N, ci, H // 2, W // 2, generator=g).to(dtype).float().requires_grad_(True)
+        y = F.conv_transpose2d(x, w, None, stride=2, padding=1, output_padding=1)
+        dy = (torch.randn(y.shape, generator=g) * 0.5).to(dtype).float()
+        y.backward(dy)
+        xe = cl(x.detach()).requires_grad_(True)
+        we = w.detach().cuda().requires_grad_(True)
+        ye = T.Deconv2dFn.apply(holder, f"u{tag}", dtype, xe, we)
+        ye.backward(cl(dy))
+        ulp = 2 ** -8 if dtype == torch.bfloat16 else 2 ** -11
+        check_close(f"deconv {ci}->{co} y", cf(ye.detach()), y.detach(), rel_l2=2 * ulp)
+        check_close(f"deconv {ci}->{co} dW", we.grad.cpu(), w.grad, rel_l2=3e-5)
+        check_close(f"deconv {ci}->{co} dX", cf(xe.grad), x.grad, rel_l2=2 * ulp)
+    # BatchNorm + ReLU (+ skip) with two groups = two separate module calls
+    for C, relu, with_skip in ((128, "post", True), (32, "pre", False), (64, None, False)):
+        bn_e, bn_r = torch.nn.BatchNorm2d(C).cuda().train(), torch.nn.BatchNorm2d(C).train()
+        with torch.no_grad():
+            bn_r.weight.copy_(torch.rand(C, generator=g) + 0.5); bn_r.bias.copy_(torch.randn(C, generator=g) * 0.2)
+            bn_e.weight.copy_(bn_r.weight); bn_e.bias.copy_(bn_r.bias)
+        y = torch.randn(4, C, 8, 12, generator=g).to(dtype).float().requires_grad_(True)
+        sk = torch.randn(4, C, 8, 12, generator=g).to(dtype).float().requires_grad_(True) if with_skip else None
+        outs = []
+        for gi in range(2):        # the reference: one module call per view
+            z = bn_r(y[2 * gi:2 * gi + 2])
+            z = F.relu(z) if relu == "pre" else z
+            z = z + sk[2 * gi:2 * gi + 2] if with_skip else z
+            outs.append(F.relu(z) if relu == "post" else z)
+        out = torch.cat(outs, 0)
+        dout = torch.randn(out.shape, generator=g).to(dtype).float()
+        out.backward(dout)
+        ye = cl(y.detach()).requires_grad_(True)
+        ske = cl(sk.detach()).requires_grad_(True) if with_skip else None
+        oe = T.BnAct2dFn.apply(bn_e, 2, relu, ye, ske, bn_e.weight, bn_e.bias)
+        oe.backward(cl(dout))
+        ulp = 2 ** -8 if dtype == torch.bfloat16 else 2 ** -11
+        check_close(f"bn{C} {relu} out", cf(oe.detach()), out.detach(), rel_l2=2 * ulp)
+        check_close(f"bn{C} {relu} dy", cf(ye.grad), y.grad, rel_l2=4 * ulp)
+        check_close(f"bn{C} {relu} dgamma", bn_e.weight.grad.cpu(), bn_r.weight.grad, rel_l2=4 * ulp)
+        check_close(f"bn{C} {relu} dbeta", bn_e.bias.grad.cpu(), bn_r.bias.grad, rel_l2=4 * ulp)
+        if with_skip:
+            check_close(f"bn{C} {relu} dskip", cf(ske.grad), sk.grad, rel_l2=2 * ulp)
+        check_close(f"bn{C} running_mean", bn_e.running_mean.cpu(), bn_r.running_mean, rel_l2=2 * ulp)
+        check_close(f"bn{C} running_var", bn_e.running_var.cpu(), bn_r.running_var, rel_l2=2 * ulp)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_vis_featext_forward_train_against_module_autograd(dtype):
+    """FeatExt.forward_train (Vis-MVSNet's 2-D residual U-Net in train() mode built from the engine's layer nodes, all views in one
+    pass with per-view BatchNorm statistics) against the module under PyTorch-ROCm autograd called once per view (fp32): the three
+    feature maps, every parameter gradient (direction of the whole vector), the running statistics."""
+    from wild_deep_mvs_amd import synthetic
+    from wild_deep_mvs_amd.models.VisMVSNet.frontend import Frontend
+    import copy
+    net = Frontend()
+    net.load_state_dict(synthetic.train_state_dict("vis", synthetic.template_of(net), seed=0))
+    fa = net.model.feat_ext.cuda().train()
+    fb = copy.deepcopy(fa)
+    gen = torch.Generator().manual_seed(8)
+    V, B, H, W = 3, 1, 64, 96
+    imgs = [torch.rand(B, 3, H, W, generator=gen).cuda() for _ in range(V)]
+    gouts = [[torch.randn(B, 32, H // s_, W // s_, generator=gen).cuda() for s_ in (8, 4, 2)] for _ in range(V)]
+    outs = fa.forward_train(torch.cat(imgs, 0), V, dtype)
+    torch.autograd.backward(outs, [torch.cat([gouts[v][k] for v in range(V)], 0).permute(0, 2, 3, 1).to(dtype).contiguous() for k in range(3)])
+    refs = []
+    for v in range(V):
+        r = fb(imgs[v])
+        torch.autograd.backward(r, gouts[v])
+        refs.append([t_.detach() for t_ in r])
+    torch.cuda.synchronize()
+    bf = dtype == torch.bfloat16
+    for k in range(3):
+        check_close(f"FeatExt map {k}", outs[k].detach().float().permute(0, 3, 1, 2).cpu(), torch.cat([refs[v][k] for v in range(V)], 0).cpu(),
+                    rel_l2=6e-2 if bf else 8e-3)
+    worst, cos, rows = _grad_report(f"FeatExt.forward_train {dtype} vs module autograd", fa, {k: p.grad.detach().cpu() for k, p in fb.named_parameters()})
+    assert cos >= (0.9 if bf else 0.99), (cos, rows)
+    for (k, a_), (_, b_) in zip(fa.state_dict().items(), fb.state_dict().items()):
+        if "running_" in k:
+            check_close(f"stat {k}", a_.float().cpu(), b_.float().cpu(), rel_l2=6e-2 if bf else 8e-3)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_vis_train_step_with_engine_extractor(dtype):
+    """feature_engine_train = "pscv" on Vis-MVSNet: the whole training step (2-D extractor of all views included) on the engine against
+    the step with the PyTorch-ROCm extractor on the same weights and scene: final depth, loss, direction of the full gradient."""
+    from wild_deep_mvs_amd import synthetic
+    from wild_deep_mvs_amd.models.VisMVSNet.frontend import Frontend
+    import copy
+    H, W, V, B = 64, 96, 3, 1
+    kw = dict(depth_nums=[16, 8, 4], interval_scales=[2.0, 1.0, 0.5])
+    na = Frontend()
+    na.load_state_dict(synthetic.train_state_dict("vis", synthetic.template_of(na), seed=0))
+    na.depth_nums, na.interval_scales = kw["depth_nums"], kw["interval_scales"]
+    na = na.cuda().train()
+    na.train_storage_dtype = dtype
+    nb = copy.deepcopy(na)
+    na.feature_engine_train = "pscv"
+    scene = synthetic.make_scene(B, V, H, W, seed=4)
+    args = [scene[k].cuda() for k in ("imgs", "K", "R", "t", "depth_min", "depth_max")]
+    gt, mask = synthetic.train_target(scene, H // 2, W // 2)
+    res = []
+    for net in (na, nb):
+        out = net(*args, **kw)
+        loss = synthetic.vis_supervised_loss(out, gt.cuda(), mask.cuda(), args[4], args[5], V)
+        loss.backward()
+        res.append((out["depth"].detach().cpu(), float(loss.detach())))
+    torch.cuda.synchronize()
+    bf = dtype == torch.bfloat16
+    check_close("final depth, engine extractor vs torch extractor", res[0][0], res[1][0], rel_l1=5e-2 if bf else 1e-2)
+    assert abs(res[0][1] - res[1][1]) <= (1.5e-1 if bf else 4e-2) * abs(res[1][1]), (res[0][1], res[1][1])
+    grads = {k: p.grad.detach().cpu() for k, p in nb.named_parameters() if p.grad is not None}
+    worst, cos, rows = _grad_report(f"vis + engine FeatExt {dtype} vs torch extractor", na, grads)
+    assert cos >= (0.6 if bf else 0.9), (cos, rows)
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_feature_pyramid_fn_against_module_autograd(dtype):
     """training.FeaturePyramidFn (CVP-MVSNet's nine-layer conv + LeakyReLU(0.1) tower on two pyramid levels, forward and backward on
     the engine, all views as one batch) against the same module under PyTorch-ROCm autograd (fp32): both levels' features and every

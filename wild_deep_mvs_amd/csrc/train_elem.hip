@@ -303,7 +303,7 @@ __global__ void bn_bwd_coeffs_kernel(const float* __restrict__ s, const float* _
 
 using namespace pscv;
 
-extern "C" long pscv_train_workspace_floats(void) { return (long)RED_BLOCKS * 2 * 64; }
+extern "C" long pscv_train_workspace_floats(void) { return (long)RED_BLOCKS * 2 * 128; }
 
 // ---- grouped forms: `groups` consecutive slices of nvox voxels each, every group with its own statistics / constants (the views of
 // a 2-D extractor batch, normalised per view like the reference's per-view calls, models/MVSNet/model.py:101-107).  Constants of
@@ -311,7 +311,7 @@ extern "C" long pscv_train_workspace_floats(void) { return (long)RED_BLOCKS * 2 
 // scale, bias, mean, invstd; pscv_bn_bwd_coeffs_grouped [groups][5][C]: ca, cb, cc, d gamma, d beta).  groups = 1 is the plain form.
 static int bn_check(const char* fn, const void* y, int dtype, long nvox, int groups, int C) {
     PSCV_CHECK_ARG(y, "%s: null pointer argument", fn);
-    PSCV_CHECK_ARG(C == 8 || C == 16 || C == 32 || C == 64, "%s: C=%d must be 8, 16, 32 or 64", fn, C);
+    PSCV_CHECK_ARG(C == 8 || C == 16 || C == 32 || C == 64 || C == 128, "%s: C=%d must be 8, 16, 32, 64 or 128", fn, C);
     PSCV_CHECK_ARG(dtype == PSCV_BF16 || dtype == PSCV_F16, "%s: dtype %d must be bf16 or fp16", fn, dtype);
     PSCV_CHECK_ARG(nvox > 0 && groups >= 1 && groups <= 256, "%s: empty volume or bad group count %d", fn, groups);
     return 0;
@@ -335,7 +335,8 @@ extern "C" int pscv_bn_stats_grouped(const void* y, int dtype, long nvox, int gr
         case 1: hipLaunchKernelGGL((bn_stats_kernel<HT, 1>), grid, dim3(256), 0, st, yp, nchunk, workspace, C); break; \
         case 2: hipLaunchKernelGGL((bn_stats_kernel<HT, 2>), grid, dim3(256), 0, st, yp, nchunk, workspace, C); break; \
         case 4: hipLaunchKernelGGL((bn_stats_kernel<HT, 4>), grid, dim3(256), 0, st, yp, nchunk, workspace, C); break; \
-        default: hipLaunchKernelGGL((bn_stats_kernel<HT, 8>), grid, dim3(256), 0, st, yp, nchunk, workspace, C); break; \
+        case 8: hipLaunchKernelGGL((bn_stats_kernel<HT, 8>), grid, dim3(256), 0, st, yp, nchunk, workspace, C); break; \
+        default: hipLaunchKernelGGL((bn_stats_kernel<HT, 16>), grid, dim3(256), 0, st, yp, nchunk, workspace, C); break; \
     }
     if (dtype == PSCV_BF16) { PSCV_STATS(bf16_t) } else { PSCV_STATS(f16_t) }
 #undef PSCV_STATS
@@ -381,7 +382,8 @@ extern "C" int pscv_bn_bwd_reduce_grouped(const void* dact, const void* y, int d
         case 1: hipLaunchKernelGGL((bn_bwd_reduce_kernel<HT, 1>), grid, dim3(256), 0, st, gp, yp, scale, bias, nchunk, workspace, C, relu, param_stride); break; \
         case 2: hipLaunchKernelGGL((bn_bwd_reduce_kernel<HT, 2>), grid, dim3(256), 0, st, gp, yp, scale, bias, nchunk, workspace, C, relu, param_stride); break; \
         case 4: hipLaunchKernelGGL((bn_bwd_reduce_kernel<HT, 4>), grid, dim3(256), 0, st, gp, yp, scale, bias, nchunk, workspace, C, relu, param_stride); break; \
-        default: hipLaunchKernelGGL((bn_bwd_reduce_kernel<HT, 8>), grid, dim3(256), 0, st, gp, yp, scale, bias, nchunk, workspace, C, relu, param_stride); break; \
+        case 8: hipLaunchKernelGGL((bn_bwd_reduce_kernel<HT, 8>), grid, dim3(256), 0, st, gp, yp, scale, bias, nchunk, workspace, C, relu, param_stride); break; \
+        default: hipLaunchKernelGGL((bn_bwd_reduce_kernel<HT, 16>), grid, dim3(256), 0, st, gp, yp, scale, bias, nchunk, workspace, C, relu, param_stride); break; \
     }
     if (dtype == PSCV_BF16) { PSCV_RED(bf16_t) } else { PSCV_RED(f16_t) }
 #undef PSCV_RED

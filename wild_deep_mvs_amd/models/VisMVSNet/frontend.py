@@ -16,6 +16,9 @@ class Frontend(ReplayHooks, nn.Module):
         # 2-D extractor: "pscv" = the residual U-Net on MFMA conv2d launches writing the warp kernel's channels-last 16-bit
         # layout directly (default); "torch" = PyTorch-ROCm in fp32, converted where the warp kernel reads it
         self.feature_engine = "pscv"
+        # the 2-D extractor in train(): "torch" = PyTorch-ROCm autograd in fp32 (default); "pscv" = FeatExt.forward_train: all views in one
+        # engine pass (grouped BatchNorm statistics), 16-bit activations
+        self.feature_engine_train = "torch"
 
     @property
     def storage_dtype(self):
@@ -85,8 +88,15 @@ class Frontend(ReplayHooks, nn.Module):
                 # batch statistics), on PyTorch-ROCm autograd (upstream of the path); the stages are the engine's autograd nodes
                 if grp is not None:
                     raise NotImplementedError("pscv Vis-MVSNet: the source-view shard is an inference path")
-                ref_feats = self.model.feat_ext(imgs[reference_frame])
-                src_feats = [self.model.feat_ext(imgs[i]) for i in src_idx]
+                if getattr(self, "feature_engine_train", "torch") == "pscv":
+                    # the extractor of ALL views in one engine pass (FeatExt.forward_train: grouped BatchNorm statistics, one per view)
+                    packs = [torch.chunk(f, v, 0) for f in self.model.feat_ext.forward_train(torch.cat([imgs[i] for i in order], 0), v,
+                                                                                              self.train_storage_dtype)]
+                    ref_feats = tuple(p[0] for p in packs)
+                    src_feats = [tuple(p[j + 1] for p in packs) for j in range(len(src_idx))]
+                else:
+                    ref_feats = self.model.feat_ext(imgs[reference_frame])
+                    src_feats = [self.model.feat_ext(imgs[i]) for i in src_idx]
             engine = self.feature_engine == "pscv" and not self.training
             fe = (lambda x: self.model.feat_ext.forward_engine(x, self.storage_dtype)) if engine else self.model.feat_ext
             for st in (self.model.stage1, self.model.stage2, self.model.stage3):
@@ -119,7 +129,8 @@ class Frontend(ReplayHooks, nn.Module):
                 if k > 0:
                     # NB: like the reference, the offset uses the ATTRIBUTE self.interval_scales, not the kwarg
                     # (frontend.py:76-78,89-91)
-                    fhw = tuple(ref_feats[k].shape[1:3]) if engine else tuple(ref_feats[k].shape[2:])
+                    cl_feats = engine or (self.training and self.feature_engine_train == "pscv")      # channels-last maps [n,h,w,C]
+                    fhw = tuple(ref_feats[k].shape[1:3]) if cl_feats else tuple(ref_feats[k].shape[2:])
                     start = F.interpolate(ests[-1].detach(), size=fhw, mode='bilinear',
                                           align_corners=False) - depth_nums[k] * di * self.interval_scales[k] / 2
                 stage_taps = {} if taps is not None else None

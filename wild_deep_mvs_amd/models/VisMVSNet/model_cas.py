@@ -100,6 +100,48 @@ def _bn_tuple(bn):
     return (bn.weight, bn.bias, bn.running_mean, bn.running_var)
 
 
+def _featext_forward_train(self, x: torch.Tensor, groups: int, dtype: torch.dtype):
+    """FeatExt in train() mode on the engine (``feature_engine_train = "pscv"``): the same graph as ``forward`` (reference
+    model_cas.py:18-35, nn_utils.py:123-171,194-278) built from the engine's autograd nodes -- ``training.Conv2dFn`` / ``Deconv2dFn`` /
+    ``BnAct2dFn`` on channels-last 16-bit maps; shortcuts and the decoder's concat are torch autograd's -- for ALL views at once:
+    x [groups * B, 3, H, W] view-major, every BatchNorm normalising each view with its own batch statistics (the reference's per-view
+    calls, frontend.py:59-61).  Returns the three maps [groups * B, h, w, 32] (1/8, 1/4, 1/2) in ``dtype``."""
+    C2, D2, BA = T.Conv2dFn.apply, T.Deconv2dFn.apply, T.BnAct2dFn.apply
+    tag = [0]
+
+    def conv(y, m, stride):
+        tag[0] += 1
+        return C2(self, tag[0], dtype, stride, y, m.weight)
+
+    def bnact(y, bn, relu, skip=None):
+        return BA(bn, groups, relu, y, skip, bn.weight, bn.bias)
+
+    def block(y, b):
+        t = bnact(conv(y, b.conv1, b.stride), b.bn1, "pre")
+        sc = y if b.downsample is None else bnact(conv(y, b.downsample[0], b.stride), b.downsample[1], None)
+        return bnact(conv(t, b.conv2, 1), b.bn2, "post", sc)
+
+    y = bnact(conv(ops.image_to_channels_last8(x.detach(), dtype), self.init_conv[0], 2), self.init_conv[1], "pre")
+    skips = []
+    for seq in self.unet.enc_blocks.values():
+        for b in seq:
+            y = block(y, b)
+        skips.append(y)
+    outs = [y]
+    for i, parts in enumerate(self.unet.dec_blocks.values()):
+        tag[0] += 1
+        up = D2(self, tag[0], dtype, y, parts[0].weight)
+        y = conv(torch.cat([up, skips[-2 - i]], 3), parts[1], 1)                      # [deconv | skip] (nn_utils.py:269-271)
+        if len(parts) == 3:
+            for b in parts[2]:
+                y = block(y, b)
+        outs.append(y)
+    return tuple(conv(o, c, 1) for o, c in zip(outs[-3:], (self.final_conv_1, self.final_conv_2, self.final_conv_3)))
+
+
+FeatExt.forward_train = _featext_forward_train
+
+
 class _RegUNet(nn.Module):
     """Holder + engine executor of ``UNet(8, 1, 0, 4, [], [8, 16], [], tag, dim=3)`` (nn_utils.py:194-278)."""
 
@@ -294,8 +336,11 @@ class SingleStage(nn.Module):
         index + entropy and the visibility-weighted fusion are the engine's autograd nodes (training.WarpCostFn / VisUNetFn /
         ScoreHeadFn / FusePairsFn); the 2-D ``UncertNet`` on the entropy map stays on PyTorch-ROCm autograd.  The homographies
         carry no gradient (homography.py:25,92,110)."""
-        n, _, h, w = ref_feat.shape
         dt = self.train_storage_dtype
+        if ref_feat.dtype == dt and dt != torch.float32:          # channels-last 16-bit maps from the engine's extractor (FeatExt.forward_train)
+            n, h, w, _ = ref_feat.shape
+        else:
+            n, _, h, w = ref_feat.shape
         if depth_num % 2 or h % 2 or w % 2:
             raise ValueError(f"Vis U-Net needs even d,h,w (got {depth_num},{h},{w}), as in the reference")
         steps = torch.arange(depth_num, dtype=torch.float32, device=ref_feat.device).view(1, depth_num, 1, 1)

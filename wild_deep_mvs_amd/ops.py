@@ -1065,8 +1065,8 @@ def _workspace(device, nfloats: int) -> torch.Tensor:
 
 
 def _vol16(x: torch.Tensor, what: str):
-    if x.dtype not in HALF_DTYPES or x.dim() != 5 or x.shape[4] not in (8, 16, 32, 64):
-        raise TypeError(f"pscv.{what}: a 16-bit channels-last volume [B,D,h,w,C] with C in 8/16/32/64 is expected, got "
+    if x.dtype not in HALF_DTYPES or x.dim() != 5 or x.shape[4] not in (8, 16, 32, 64, 128):
+        raise TypeError(f"pscv.{what}: a 16-bit channels-last volume [B,D,h,w,C] with C in 8/16/32/64/128 is expected, got "
                         f"{x.dtype} {tuple(x.shape)}")
 
 

@@ -702,6 +702,161 @@ class FeaturePyramidFn(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------------------------
+# generic 2-D layer nodes (Vis-MVSNet's FeatExt in train(): a residual U-Net whose graph -- shortcuts, the decoder's concat -- is left
+# to torch autograd; every convolution, BatchNorm pass and their backward passes are engine launches on channels-last 16-bit maps)
+# --------------------------------------------------------------------------------------------
+def _wgrad_k3_sliced(dy: torch.Tensor, x: torch.Tensor, co: int, ci: int) -> torch.Tensor:
+    """[co,ci,3,3] weight gradient of a k3 s1 p1 conv from dy [N,H,W,co'] and x [N,H,W,ci']; more than 64 channels on either side run
+    as 64-channel slices of the same tensors (channel offsets of the weight-gradient kernel)."""
+    p5, q5 = _v5(dy), _v5(x)
+    if co <= 64 and ci <= 64:
+        return ops.conv3d_wgrad(p5, q5, ca=co, cb=ci, stride=1)[:, :, 1]
+    dw = torch.empty((co, ci, 3, 3), dtype=torch.float32, device=dy.device)
+    for a0 in range(0, co, 64):
+        for b0 in range(0, ci, 64):
+            ca, cb = min(64, co - a0), min(64, ci - b0)
+            dw[a0:a0 + ca, b0:b0 + cb] = ops.conv3d_wgrad(p5, q5, ca=ca, cb=cb, stride=1, p_coff=a0, q_coff=b0)[:, :, 1]
+    return dw
+
+
+_S2_TAP = {1: (0, 1), 0: (1, 0), 2: (1, 1)}     # kernel index of a k3 s2 p1 conv -> (input parity, tap of the stride-1 gradient on that parity plane)
+
+
+def _wgrad_k3s2(dy: torch.Tensor, x: torch.Tensor, co: int, ci: int) -> torch.Tensor:
+    """k3 s2 p1: y[o] = sum_k w[k] x[2o + k - 1]; x[2o] / x[2o -+ 1] are taps of the input's parity planes, so the gradient is assembled
+    from four stride-1 3x3 weight gradients (dy against x[:, a::2, b::2])."""
+    g = {(a, b): _wgrad_k3_sliced(dy, x[:, a::2, b::2, :].contiguous(), co, ci) for a in (0, 1) for b in (0, 1)}
+    dw = torch.empty((co, ci, 3, 3), dtype=torch.float32, device=dy.device)
+    for ky in range(3):
+        for kx in range(3):
+            (py, ty), (px, tx) = _S2_TAP[ky], _S2_TAP[kx]
+            dw[:, :, ky, kx] = g[(py, px)][:, :, ty, tx]
+    return dw
+
+
+class Conv2dFn(torch.autograd.Function):
+    """Bias-free Conv2d (k3 s1 | k3 s2 | k1 s1 | k1 s2 | k5 s2, the reference's paddings) on channels-last 16-bit maps, forward and
+    backward on the engine.  ``forward(ctx, holder, tag, dtype, stride, x [N,H,W,Ci'], w [Co,Ci,k,k])``; packed layers are cached on
+    ``holder`` under ``tag`` per weight version."""
+
+    @staticmethod
+    def forward(ctx, holder, tag, dtype, stride, x, w):
+        k = int(w.shape[2])
+        y = ops.conv2d(x, _cached_layer(holder, f"c{tag}", w, dtype, lambda: ops.Conv2dLayer.build(w, stride=stride, dtype=dtype)))
+        ctx.meta = (holder, tag, dtype, int(stride), k)
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        holder, tag, dtype, stride, k = ctx.meta
+        x, w = ctx.saved_tensors
+        co, ci = int(w.shape[0]), int(w.shape[1])
+        g = g.contiguous()
+        cpad = x.shape[3]
+        if k == 3 and stride == 1:
+            dw = _wgrad_k3_sliced(g, x, co, cpad)
+        elif k == 3:
+            dw = _wgrad_k3s2(g, x, co, cpad)
+        elif k == 1:
+            xs = x if stride == 1 else x[:, ::2, ::2, :].contiguous()
+            dw = _wgrad_k3_sliced(g, xs, co, cpad)[:, :, 1:2, 1:2]
+        else:
+            dw = _wgrad2d_k5s2(g, x, co, cpad)
+        dw = dw[:, :ci].to(w.dtype)
+        dx = None
+        if ctx.needs_input_grad[4]:
+            if k == 3 and stride == 1:
+                dx = ops.conv2d(g, _cached_layer(holder, f"d{tag}", w, dtype, lambda: _dgrad2d_k3_layer(w, dtype)))
+            elif k == 1 and stride == 1:
+                def mk():
+                    w3 = torch.zeros((co, ci, 3, 3), dtype=torch.float32, device=w.device)
+                    w3[:, :, 1, 1] = w.detach().float()[:, :, 0, 0]
+                    return _dgrad2d_k3_layer(w3, dtype)
+                dx = ops.conv2d(g, _cached_layer(holder, f"d{tag}", w, dtype, mk))
+            elif k == 3:          # adjoint of a stride-2 conv = ConvTranspose2d(k3, s2, p1, op1) with the same weight: four parity sub-convs
+                subs = _cached_layer(holder, f"d{tag}", w, dtype,
+                                     lambda: [ops.Conv2dLayer.build(w_, stride=1, dtype=dtype) for w_ in ops.deconv2d_parity_weights(w)])
+                dx = torch.empty_like(x)
+                for par, sub in enumerate(subs):
+                    ops.conv2d(g, sub, out=dx, parity=par)
+            elif k == 1:          # strided 1x1: the gradient lands on the even pixels only (centre tap of a k3 parity-0 sub-conv)
+                def mk():
+                    w3 = torch.zeros((ci, co, 3, 3), dtype=torch.float32, device=w.device)
+                    w3[:, :, 1, 1] = w.detach().float()[:, :, 0, 0].t()
+                    return ops.Conv2dLayer.build(w3, stride=1, dtype=dtype)
+                dx = torch.zeros_like(x)
+                ops.conv2d(g, _cached_layer(holder, f"d{tag}", w, dtype, mk), out=dx, parity=0)
+            else:
+                raise NotImplementedError("pscv Conv2dFn: no data gradient for k5 s2 (the extractors' first layer reads the image)")
+        return None, None, None, None, dx, dw
+
+
+class Deconv2dFn(torch.autograd.Function):
+    """Bias-free ConvTranspose2d(k3, s2, p1, output_padding 1) on channels-last 16-bit maps: forward = four parity sub-convolutions,
+    data gradient = the k3 s2 conv with the same weight, weight gradient from the parity planes of the output gradient.
+    ``forward(ctx, holder, tag, dtype, x [N,H,W,Ci], w [Ci,Co,3,3])`` -> [N,2H,2W,Co]."""
+
+    @staticmethod
+    def forward(ctx, holder, tag, dtype, x, w):
+        subs = _cached_layer(holder, f"u{tag}", w, dtype,
+                             lambda: [ops.Conv2dLayer.build(w_, stride=1, dtype=dtype) for w_ in ops.deconv2d_parity_weights(w)])
+        N, H, W, _ = x.shape
+        out = torch.empty((N, 2 * H, 2 * W, int(w.shape[1])), dtype=dtype, device=x.device)
+        for par, sub in enumerate(subs):
+            ops.conv2d(x, sub, out=out, parity=par)
+        ctx.meta = (holder, tag, dtype)
+        ctx.save_for_backward(x, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        holder, tag, dtype = ctx.meta
+        x, w = ctx.saved_tensors
+        ci, co = int(w.shape[0]), int(w.shape[1])
+        g = g.contiguous()
+        # dw[ci,co,k] = sum_i x[i,ci] g[2i + k - 1, co]: the stride-2 gradient with x in the role of "dy" and g in the role of "x"
+        dw = _wgrad_k3s2(x, g, ci, co).to(w.dtype)
+        dx = None
+        if ctx.needs_input_grad[3]:
+            dx = ops.conv2d(g, _cached_layer(holder, f"ud{tag}", w, dtype, lambda: ops.Conv2dLayer.build(w, stride=2, dtype=dtype)))
+        return None, None, None, dx, dw
+
+
+class BnAct2dFn(torch.autograd.Function):
+    """``[relu](bn(y)) [+ skip]`` / ``relu(bn(y) + skip)`` of a raw conv output y [N,H,W,C] (16-bit channels-last) with batch-statistics
+    BatchNorm2d over ``groups`` consecutive slices of the batch (the views: each its own statistics), forward and backward on the
+    engine.  ``relu``: "pre" (before the skip add), "post" (after it: BasicBlock), None.
+    ``forward(ctx, bn, groups, relu, y, skip, gamma, beta)``."""
+
+    @staticmethod
+    def forward(ctx, bn, groups, relu, y, skip, gamma, beta):
+        y5 = _v5(y)
+        nvox = y5.numel() // y5.shape[4] // groups
+        aff = _bn_affine_grouped(bn, ops.bn_stats(y5, groups), nvox, groups)
+        out = ops.bn_act(y5, aff[:, 0], aff[:, 1], relu=True if relu == "pre" else ("post" if relu == "post" else False),
+                         skip=None if skip is None else _v5(skip.contiguous())).squeeze(1)
+        ctx.meta = (bn, relu, nvox, skip is not None)
+        ctx.save_for_backward(y, out if relu == "post" else y, aff)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        bn, relu, nvox, has_skip = ctx.meta
+        y, out, aff = ctx.saved_tensors
+        g = g.contiguous()
+        dpre = ops.relu_bwd(_v5(g), _v5(out)).squeeze(1) if relu == "post" else g
+        s = ops.bn_bwd_reduce(_v5(dpre), _v5(y), aff[:, 0], aff[:, 1], relu=relu == "pre")
+        cf = ops.bn_bwd_coeffs(s, aff[:, 2], aff[:, 3], bn.weight, nvox)
+        if not bn.training:
+            cf[:, 1:3].zero_()
+        dy = ops.bn_bwd_apply(_v5(dpre), _v5(y), aff[:, 0], aff[:, 1], cf[:, 0], cf[:, 1], cf[:, 2], relu=relu == "pre").squeeze(1)
+        dgb = cf[:, 3:5].sum(0)
+        return (None, None, None, dy, dpre if has_skip else None,
+                dgb[0].to(bn.weight.dtype) if bn.weight is not None else None, dgb[1].to(bn.bias.dtype) if bn.bias is not None else None)
+
+
+# --------------------------------------------------------------------------------------------
 # unsupervised photometric loss (SURVEY 8f-4; models/trainer.py:209-278, utils/ssimLoss.py)
 # --------------------------------------------------------------------------------------------
 class PhotoWarpFn(torch.autograd.Function):
