@@ -368,7 +368,7 @@ long pscv_train_workspace_floats(void);
 /*
  * Per-channel batch statistics of a channels-last 16-bit volume: sums[0][c] = sum y, sums[1][c] = sum y^2 over all
  * nvox voxels (BatchNorm3d in train(): models/MVSNet/module.py:41-58 normalise with the statistics of the batch).
- * Two-phase, fixed summation order (bit-reproducible).  sums: device fp32 [2][C].  C in {8,16,32,64}.
+ * Two-phase, fixed summation order (bit-reproducible).  sums: device fp32 [2][C].  C in {8,16,32,64,128} (128: ABI 6, the Vis-MVSNet extractor's widest layers).
  */
 int pscv_bn_stats(const void* y, int dtype, long nvox, int C, float* workspace, float* sums, void* stream);
 
