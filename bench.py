@@ -298,6 +298,7 @@ def parse_args(argv=None):
     ap.add_argument("--batch-mode", choices=["streams", "batched"], default="streams",
                     help="how the views of a step are launched: 'streams' = each view's 13 launches on its own HIP stream (eager; up to 4 views), "
                          "'batched' = one launch per layer for the whole batch on one stream, replayed as a hipGraph")
+    ap.add_argument("--no-training", action="store_true", help="skip the two MVSNet training-step timings (scripts/bench_train.py) reported under 'training'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the full-forward() timings / rooflines of BASELINE configurations 1-5")
     ap.add_argument("--sharded-budget", type=float, default=300.0, help="N > 1: seconds the sharded legs may take before the headline line is "
@@ -341,6 +342,26 @@ def spawn_ranks(args):
     rendezvous).  Under ``python -m torch.distributed.run`` WORLD_SIZE is already set and this is skipped."""
     import torch.multiprocessing as mp
     mp.spawn(_spawned_rank, args=(args, _free_port()), nprocs=args.gpus, join=True)
+
+
+def training_steps():
+    """MVSNet training step (5 views 512x640, D = 192, B = 1, bf16 storage) through scripts/bench_train.py, once per 2-D extractor;
+    never costs the headline line (errors are reported in place)."""
+    import subprocess
+    out = {}
+    for fe in ("torch", "pscv"):
+        try:
+            r = subprocess.run([sys.executable, os.path.join(REPO, "scripts", "bench_train.py"), "--feature-engine", fe, "--steps", "5", "--warmup", "3"],
+                               capture_output=True, text=True, timeout=180, cwd=REPO)
+            d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+            top = sorted(d["pscv_kernels_us_per_step"].items(), key=lambda kv: -kv[1])[:5]
+            out[f"extractor_{fe}"] = {"ms_per_step": d["ms_per_step"], "voxels_per_s": d["value"], "engine_kernels_ms": d["pscv_kernels_total_ms"],
+                                      "top_kernels_us": dict(top)}
+        except Exception as e:   # pragma: no cover
+            out[f"extractor_{fe}"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    out["what"] = ("MVSNet, 5 views 512x640, D=192, B=1, bf16 storage: forward in train() + loss.backward() + Adam per step; extractor_torch = the "
+                   "2-D extractor on PyTorch-ROCm autograd (default), extractor_pscv = net.feature_engine_train = 'pscv' (all views in one engine pass)")
+    return out
 
 
 def sharded_legs_bounded(dist, device, world, rank, budget_s, legs=None):
@@ -603,6 +624,12 @@ def run(args):
                 line["other_configs"] = [run_configs.time_config(c) for c in (1, 2, 3, 4, 5)]
             except Exception as e:   # pragma: no cover  (never lose the headline line to a side measurement)
                 line["other_configs"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        # row f-1 of the scope table (the backward of the path): one MVSNet training step at the headline size, forward in train() +
+        # loss.backward() + Adam, with the PyTorch-ROCm 2-D extractor (the default) and with the extractor on the engine too; each in
+        # its own process (scripts/bench_train.py), after the headline region
+        line["training"] = None
+        if world == 1 and not args.no_training and not args.no_other_configs:      # (measurement children pass --no-other-configs)
+            line["training"] = training_steps()
         print(json.dumps(line), flush=True)
     if not sharded_done:        # a wedged process group: nothing more can be agreed on; every rank leaves on its own
         sys.stdout.flush()
