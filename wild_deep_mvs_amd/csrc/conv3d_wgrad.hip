@@ -293,7 +293,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
                     for (int tx = 0; tx < 3; ++tx)
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
-                            part[((long)((tz * 3 + ty) * 3 + tx) * a.ca16 + a0 + m * 16 + g * 4 + k) * a.cb16 + b0 + nb * 16 + n] = accu[m][i][tx][k];
+                            if (a0 + m * 16 + g * 4 + k < a.ca && b0 + nb * 16 + n < a.cb)      // (the finishing kernel reads the valid [ca][cb] block only:
+                                part[((long)((tz * 3 + ty) * 3 + tx) * a.ca16 + a0 + m * 16 + g * 4 + k) * a.cb16 + b0 + nb * 16 + n] = accu[m][i][tx][k];   // 8 x 8 layers wrote 4x that)
             }
         }
     } else {
@@ -305,7 +306,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
                 for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        part[((long)tap * a.ca16 + a0 + g * 4 + i) * a.cb16 + b0 + nb * 16 + n] = acc[ti][nb][i];
+                        if (a0 + g * 4 + i < a.ca && b0 + nb * 16 + n < a.cb)
+                            part[((long)tap * a.ca16 + a0 + g * 4 + i) * a.cb16 + b0 + nb * 16 + n] = acc[ti][nb][i];
             }
         }
     }
