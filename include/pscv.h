@@ -450,6 +450,10 @@ int pscv_relu_bwd(const void* dout, const void* out, int dtype, long nvox, int C
  * has the sign of its input (CVP-MVSNet's 2-D pyramid: conv + LeakyReLU(0.1), models/CVP_MVSNet/models/modules.py:24-28); slope = 0 is
  * pscv_relu_bwd. */
 int pscv_leaky_relu_bwd(const void* dout, const void* out, int dtype, long nvox, int C, float slope, void* dpre, void* stream);
+/* The same pass that also returns sums[0][c] = sum over the voxels of the STORED dpre (fp32 [2][C], row 1 = 0): the bias gradient of a
+ * conv + bias + LeakyReLU layer without a second read of dpre.  workspace: pscv_train_workspace_floats() floats.  C in {8,...,128}. */
+int pscv_leaky_relu_bwd_sum(const void* dout, const void* out, int dtype, long nvox, int C, float slope, void* dpre, float* workspace,
+                            float* sums, void* stream);
 
 /*
  * Backward of pscv_fuse_pairs (normalise = 1): d interm_v = G w_v / W, d uncert_v = -w_v / W sum_{d,c} G (interm_v - fused)

@@ -140,6 +140,29 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const uint4* __restrict__
     }
 }
 
+// the same pass that also returns sum_voxels dpre per channel (the bias gradient of a conv + bias + LeakyReLU layer: CVP-MVSNet's 2-D
+// pyramid; a separate statistics pass re-read dpre: ~1 ms of its training step)
+template <typename H, int CG>
+__global__ __launch_bounds__(256) void relu_bwd_sum_kernel(const uint4* __restrict__ dout, const uint4* __restrict__ out,
+                                                           uint4* __restrict__ dpre, long nchunk, float slope, float* __restrict__ partials, int C) {
+    float s0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nchunk; i += stride) {
+        float g[8], o[8];
+        unpack8<H>(dout[i], g);
+        unpack8<H>(out[i], o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] = o[j] > 0.0f ? g[j] : g[j] * slope;
+        const uint4 pk = pack8<H>(g);
+        dpre[i] = pk;
+        float r[8];
+        unpack8<H>(pk, r);                       // the sum of what was STORED (what the weight-gradient and adjoint launches read)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s0[j] += r[j];
+    }
+    block_reduce2<CG>(s0, s1, partials, C);
+}
+
 // ---- backward, pass 1: dz = dact * [z > 0];  sums of dz and dz * y per channel --------------------------------------
 template <typename H, int CG>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint4* __restrict__ dact, const uint4* __restrict__ y,
@@ -448,6 +471,30 @@ extern "C" int pscv_leaky_relu_bwd(const void* dout, const void* out, int dtype,
     if (dtype == PSCV_BF16) hipLaunchKernelGGL(relu_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const uint4*)dout, (const uint4*)out, (uint4*)dpre, nchunk, slope);
     else hipLaunchKernelGGL(relu_bwd_kernel<f16_t>, dim3(nb), dim3(256), 0, st, (const uint4*)dout, (const uint4*)out, (uint4*)dpre, nchunk, slope);
     PSCV_CHECK_LAUNCH("pscv_leaky_relu_bwd");
+    return 0;
+}
+extern "C" int pscv_leaky_relu_bwd_sum(const void* dout, const void* out, int dtype, long nvox, int C, float slope, void* dpre,
+                                       float* workspace, float* sums, void* stream) {
+    if (bn_check("pscv_leaky_relu_bwd_sum", out, dtype, nvox, 1, C)) return -1;
+    PSCV_CHECK_ARG(dout && dpre && workspace && sums, "pscv_leaky_relu_bwd_sum: null pointer argument");
+    PSCV_CHECK_ARG(slope >= 0.0f && slope <= 1.0f, "pscv_leaky_relu_bwd_sum: slope %g outside [0,1]", (double)slope);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const long nchunk = nvox * (C / 8);
+    const int nb = red_grid_for(nchunk);
+    const uint4 *gp = (const uint4*)dout, *op = (const uint4*)out;
+#define PSCV_RBS(HT)                                                                                                              \
+    switch (C / 8) {                                                                                                              \
+        case 1: hipLaunchKernelGGL((relu_bwd_sum_kernel<HT, 1>), dim3(nb), dim3(256), 0, st, gp, op, (uint4*)dpre, nchunk, slope, workspace, C); break; \
+        case 2: hipLaunchKernelGGL((relu_bwd_sum_kernel<HT, 2>), dim3(nb), dim3(256), 0, st, gp, op, (uint4*)dpre, nchunk, slope, workspace, C); break; \
+        case 4: hipLaunchKernelGGL((relu_bwd_sum_kernel<HT, 4>), dim3(nb), dim3(256), 0, st, gp, op, (uint4*)dpre, nchunk, slope, workspace, C); break; \
+        case 8: hipLaunchKernelGGL((relu_bwd_sum_kernel<HT, 8>), dim3(nb), dim3(256), 0, st, gp, op, (uint4*)dpre, nchunk, slope, workspace, C); break; \
+        default: hipLaunchKernelGGL((relu_bwd_sum_kernel<HT, 16>), dim3(nb), dim3(256), 0, st, gp, op, (uint4*)dpre, nchunk, slope, workspace, C); break; \
+    }
+    if (dtype == PSCV_BF16) { PSCV_RBS(bf16_t) } else { PSCV_RBS(f16_t) }
+#undef PSCV_RBS
+    PSCV_CHECK_LAUNCH("pscv_leaky_relu_bwd_sum");
+    hipLaunchKernelGGL(finish_partials_kernel, dim3((2 * C + 15) / 16, 1), dim3(256), 0, st, workspace, nb, 2 * C, sums);
+    PSCV_CHECK_LAUNCH("pscv_leaky_relu_bwd_sum(finish)");
     return 0;
 }
 extern "C" int pscv_relu_bwd(const void* dout, const void* out, int dtype, long nvox, int C, void* dpre, void* stream) {

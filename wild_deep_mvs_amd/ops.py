@@ -1231,6 +1231,23 @@ def softargmin_bwd(logits: torch.Tensor, depth: Optional[torch.Tensor], grad_dep
     return out
 
 
+def relu_bwd_sum(dout: torch.Tensor, out: torch.Tensor, slope: float = 0.0):
+    """``relu_bwd`` that also returns the per-channel sum of the stored result (fp32 [C]): the bias gradient of a conv + bias +
+    (Leaky)ReLU layer in the same pass (pscv_leaky_relu_bwd_sum)."""
+    _dev(dout, out)
+    _vol16(out, "relu_bwd_sum")
+    if dout.shape != out.shape or dout.dtype != out.dtype:
+        raise ValueError("pscv.relu_bwd_sum: dout must match out")
+    Cc = out.shape[4]
+    dpre = torch.empty_like(out)
+    sums = torch.empty((2, Cc), dtype=torch.float32, device=out.device)
+    ws = _workspace(out.device, 0)
+    rc = _launch("relu_bwd_sum", lambda: L.lib().pscv_leaky_relu_bwd_sum(_p(dout), _p(out), _dt(out), out.numel() // Cc, Cc, float(slope), _p(dpre),
+                                                                         _p(ws), _p(sums), _stream()))
+    L.check(rc, "pscv_leaky_relu_bwd_sum")
+    return dpre, sums[0]
+
+
 def relu_bwd(dout: torch.Tensor, out: torch.Tensor, slope: float = 0.0) -> torch.Tensor:
     """dout * [out > 0] on 16-bit channels-last volumes (pscv_relu_bwd): backward of a ReLU applied after a residual add.
     ``slope`` > 0: dout * (out > 0 ? 1 : slope), the backward of LeakyReLU(slope) from its OUTPUT (pscv_leaky_relu_bwd)."""

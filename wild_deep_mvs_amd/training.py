@@ -687,8 +687,8 @@ class FeaturePyramidFn(torch.autograd.Function):
                 c = convs[i]
                 co, ci = int(c.weight.shape[0]), int(c.weight.shape[1])
                 x, out = acts[i], acts[i + 1]
-                dpre = ops.relu_bwd(_v5(g), _v5(out), FeaturePyramidFn.SLOPE).squeeze(1)
-                db = ops.bn_stats(_v5(dpre))[0]
+                dpre, db = ops.relu_bwd_sum(_v5(g), _v5(out), FeaturePyramidFn.SLOPE)       # LeakyReLU backward + bias gradient in one pass
+                dpre = dpre.squeeze(1)
                 dw = _wgrad2d_k3(dpre, x, co, x.shape[3])[:, :ci]
                 dW[i] = dw if dW[i] is None else dW[i] + dw
                 dB[i] = db if dB[i] is None else dB[i] + db
