@@ -55,3 +55,27 @@ def check_close(name, got, ref, *, max_abs=None, rel_l2=None, rel_l1=None):
     if rel_l1 is not None:
         assert s["rel_l1"] <= rel_l1, line
     return s
+
+
+def retry_infra(fn):
+    """Two ranks sharing one GPU box: a rendezvous / spawn hiccup (a result queue that stays empty, a rank process that dies before it
+    reports) is retried ONCE after a pause -- the driver runs this suite with -x on a shared box, where one such hiccup was seen in ~10
+    full runs.  Numerical assertions are never retried."""
+    import functools
+    import queue as _queue
+    import time as _time
+
+    @functools.wraps(fn)
+    def wrapper(*a, **k):
+        try:
+            return fn(*a, **k)
+        except _queue.Empty as e:
+            reason = f"empty result queue ({e!r})"
+        except AssertionError as e:
+            if "exited with code" not in str(e):
+                raise
+            reason = str(e)
+        print(f"[dist test] infrastructure failure, retrying once: {reason}", flush=True)
+        _time.sleep(5)
+        return fn(*a, **k)
+    return wrapper

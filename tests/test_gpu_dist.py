@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from _util import load_golden, t
+from _util import load_golden, retry_infra as _retry_infra, t
 
 pytestmark = pytest.mark.gpu
 
@@ -57,6 +57,7 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(300)
+@_retry_infra
 def test_vis_source_view_shard_two_ranks_one_gpu():
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
@@ -134,6 +135,7 @@ def _single_worker(q):
 
 
 @pytest.mark.timeout(300)
+@_retry_infra
 def test_mvsnet_training_under_ddp_two_ranks_one_gpu():
     """train.py wraps the model in DistributedDataParallel over a gloo group (train.py:52-59,136).  The engine's autograd
     nodes hand every parameter its gradient through autograd, so DDP's reducer averages them like any other module's: both
@@ -190,6 +192,7 @@ def _mvs_shard_worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(300)
+@_retry_infra
 def test_mvsnet_source_view_shard_variance_reduce_two_ranks_one_gpu():
     """MVSNet variance cost volume with the source views spread over two ranks (rank 0: reference + sources 0, 2; rank 1:
     source 1): fp32 partial sums (pscv_warp_cost PSCV_COST_VARIANCE_PARTIAL), one all-reduce, pscv_variance_finish -- against
@@ -258,6 +261,7 @@ def _vis_depth_shard_worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(300)
+@_retry_infra
 def test_vis_depth_plane_shard_two_ranks_one_gpu():
     """BASELINE configuration 3 in miniature: Vis-MVSNet with the depth planes of every stage sharded over two ranks (stage 1:
     96 planes -> 48 owned + a 16-plane halo; stage 2: 48 -> 24 + halo; the 8-plane stage falls inside the halo and is computed
@@ -332,6 +336,7 @@ def _vis_view_slab_worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(300)
+@_retry_infra
 def test_vis_view_shard_slab_regfuse_two_ranks_one_gpu():
     """Source-view shard with the reduce-scatter form of the fusion (reference model_cas.py:354-357,385-405 across
     ranks): 5 views 256x320, stages (d,h,w) = (32,32,40), (16,64,80), (8,128,160) over two ranks -> stage 1 cuts DEPTH slabs
@@ -407,6 +412,7 @@ def _mvsnet_depth_shard_worker(rank, world, port, cases, q):
 
 
 @pytest.mark.timeout(300)
+@_retry_infra
 def test_mvsnet_depth_plane_shard_with_halo_exchange_two_ranks_one_gpu():
     """Depth-plane shard of the WHOLE MVSNet hot path, regulariser included (SURVEY 8e's recommended shard; reference
     models/MVSNet/model.py:43-84,109-139,207-215 across ranks): each rank warps planes [a - 2, b + 2) itself, the 11 U-Net layers
@@ -487,6 +493,7 @@ def _bench_sharded_worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(600)
+@_retry_infra
 def test_bench_sharded_legs_two_ranks_one_gpu():
     """``bench.py --gpus N``'s ``sharded`` object: configuration 2 through MVSNet's depth-plane shard (per-layer halo exchange),
     configuration 3 through the Vis depth-plane shard and configuration 5 through the source-view shard, each against the
@@ -549,6 +556,7 @@ def _rccl_one_rank_worker(port, q):
 
 
 @pytest.mark.timeout(600)
+@_retry_infra
 def test_rccl_backend_one_rank_runs_every_sharded_path():
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
