@@ -355,24 +355,23 @@ def conv2d(x: torch.Tensor, layer: Conv2dLayer, *, out_dtype: Optional[torch.dty
     return out
 
 
+_PARITY_K = {}
+
+
 def deconv2d_parity_weights(weight: torch.Tensor):
     """ConvTranspose2d(k3, s2, p1, op1) weight [Ci,Co,3,3] -> four Conv2d weights [Co,Ci,2,2], index 2*py+px: output pixel
     (2i+py, 2j+px) = sum over taps (ty, tx) of W[py,px][:, :, ty, tx] x[i+ty, j+tx].  Along a dim, parity 0 takes input i with
     kernel index 1; parity 1 takes input i with kernel index 2 and input i+1 with kernel index 0."""
     w = weight.detach().float()
     ci, co = w.shape[:2]
-    kidx = {0: (1, None), 1: (2, 0)}     # parity -> kernel index for tap 0 (input i), tap 1 (input i+1)
-    outs = []
-    for py in (0, 1):
-        for px in (0, 1):
-            sub = torch.zeros((co, ci, 2, 2), dtype=torch.float32, device=w.device)
-            for ty in (0, 1):
-                for tx in (0, 1):
-                    ky, kx = kidx[py][ty], kidx[px][tx]
-                    if ky is not None and kx is not None:
-                        sub[:, :, ty, tx] = w[:, :, ky, kx].t()
-            outs.append(sub)
-    return outs
+    # kernel index per (parity, tap): parity 0 -> (1, none), parity 1 -> (2, 0); "none" reads a zero plane appended at index 3.
+    # One indexed gather for all four sub-weights (16 slice assignments before: a training step rebuilds these per layer)
+    wp = torch.nn.functional.pad(w, (0, 1, 0, 1))                                   # [ci,co,4,4], row / column 3 = zeros
+    k = _PARITY_K.get(w.device)
+    if k is None:
+        k = _PARITY_K[w.device] = torch.tensor([[1, 3], [2, 0]], dtype=torch.long, device=w.device)
+    W = wp[:, :, k[:, :, None, None], k[None, None, :, :]]                          # [ci,co,py,ty,px,tx]
+    return [W[:, :, py, :, px, :].transpose(0, 1).contiguous() for py in (0, 1) for px in (0, 1)]
 
 
 def image_to_channels_last8(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:

@@ -500,19 +500,22 @@ def _wgrad2d_k3(dy: torch.Tensor, x: torch.Tensor, co: int, ci: int) -> torch.Te
     return ops.conv3d_wgrad(_v5(dy), _v5(x), ca=co, cb=ci, stride=1)[:, :, 1]
 
 
+_K5_IDX = {}
+
+
 def _wgrad2d_k5s2(dy: torch.Tensor, x: torch.Tensor, co: int, ci: int) -> torch.Tensor:
     """Weight gradient of a k5 s2 p2 Conv2d: x[2o + k - 2] with k = 2 t + a is tap t - 1 of the input's parity plane
-    x_a[i] = x[2i + a], so the 5x5 gradient is assembled from four stride-1 3x3 weight gradients."""
-    dw = torch.zeros((co, ci, 5, 5), dtype=torch.float32, device=dy.device)
-    for a in (0, 1):
-        for b in (0, 1):
-            g = _wgrad2d_k3(dy, x[:, a::2, b::2, :].contiguous(), co, ci)
-            ty = [t for t in range(3) if 2 * t + a <= 4]
-            tx = [t for t in range(3) if 2 * t + b <= 4]
-            for t1 in ty:
-                for t2 in tx:
-                    dw[:, :, 2 * t1 + a, 2 * t2 + b] = g[:, :, t1, t2]
-    return dw
+    x_a[i] = x[2i + a], so the 5x5 gradient is assembled from four stride-1 3x3 weight gradients -- with one indexed gather
+    (kernel index k -> parity k % 2, tap k // 2)."""
+    G = torch.stack([_wgrad2d_k3(dy, x[:, a::2, b::2, :].contiguous(), co, ci) for a in (0, 1) for b in (0, 1)])       # [4,co,ci,3,3]
+    idx = _K5_IDX.get(dy.device)
+    if idx is None:
+        P = [[(ky % 2) * 2 + (kx % 2) for kx in range(5)] for ky in range(5)]
+        TY = [[ky // 2 for kx in range(5)] for ky in range(5)]
+        TX = [[kx // 2 for kx in range(5)] for ky in range(5)]
+        idx = _K5_IDX[dy.device] = tuple(torch.tensor(t_, dtype=torch.long, device=dy.device) for t_ in (P, TY, TX))
+    P, TY, TX = idx
+    return G[P, :, :, TY, TX].permute(2, 3, 0, 1).contiguous()                       # [5,5,co,ci] -> [co,ci,5,5]
 
 
 def _dgrad2d_k3_layer(w: torch.Tensor, dtype) -> ops.Conv2dLayer:
@@ -524,18 +527,14 @@ def _dgrad2d_k5s2_layers(w: torch.Tensor, dtype) -> List[ops.Conv2dLayer]:
     """Adjoint of a k5 s2 p2 Conv2d [Co,Ci,5,5] (= ConvTranspose2d k5 s2 p2 op1) as four stride-1 3x3 sub-convolutions, one per
     output parity: dx[2i + a] = sum_m dy[i + m] w[k = a + 2 - 2m], m = -1, 0, +1 (k = 5 does not exist: zero)."""
     wf = w.detach().float()
-    co, ci = wf.shape[:2]
-    subs = []
-    for a in (0, 1):
-        for b in (0, 1):
-            sub = torch.zeros((ci, co, 3, 3), dtype=torch.float32, device=wf.device)
-            for ty in range(3):
-                for tx in range(3):
-                    ky, kx = a + 2 - 2 * (ty - 1), b + 2 - 2 * (tx - 1)
-                    if 0 <= ky <= 4 and 0 <= kx <= 4:
-                        sub[:, :, ty, tx] = wf[:, :, ky, kx].t()
-            subs.append(ops.Conv2dLayer.build(sub, stride=1, dtype=dtype))
-    return subs
+    # kernel index per (parity a, tap t): k = a + 4 - 2 t, none (a zero plane appended at index 5) outside 0..4; one indexed gather
+    wp = torch.nn.functional.pad(wf, (0, 1, 0, 1))                                  # [co,ci,6,6]
+    k = _K5_IDX.get(("d", wf.device))
+    if k is None:
+        k = _K5_IDX[("d", wf.device)] = torch.tensor([[a + 4 - 2 * t_ if 0 <= a + 4 - 2 * t_ <= 4 else 5 for t_ in range(3)] for a in (0, 1)],
+                                                     dtype=torch.long, device=wf.device)
+    W = wp[:, :, k[:, :, None, None], k[None, None, :, :]]                          # [co,ci,a,ty,b,tx]
+    return [ops.Conv2dLayer.build(W[:, :, a, :, b, :].transpose(0, 1).contiguous(), stride=1, dtype=dtype) for a in (0, 1) for b in (0, 1)]
 
 
 def _cached_layer(net, tag, weight, dtype, make, extra=()):
