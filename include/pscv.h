@@ -284,6 +284,10 @@ long pscv_pack_conv2d_weights(const float* w, int c_in, int c_in_padded, int c_o
 /* The same packing with `w` (fp32 [c_out][c_in][ks][ks]) and `packed` on the device, one launch on `stream`, no host round trip
  * (ABI 6): what a training step uses to rebuild the extractor's forward and adjoint layers after an optimiser step. */
 int pscv_pack_conv2d_weights_device(const float* w, int c_in, int c_in_padded, int c_out, int ks, int dtype, uint16_t* packed, void* stream);
+/* adjoint = 1: `w` is the FORWARD layer's weight [c_in][c_out][ks][ks] (this layer's input channels are its output channels) and the
+ * packed layer is its adjoint -- channel axes swapped, taps flipped: the data gradient of a stride-1 conv runs on the forward kernel. */
+int pscv_pack_conv2d_weights_device_ex(const float* w, int c_in, int c_in_padded, int c_out, int ks, int dtype, int adjoint, uint16_t* packed,
+                                       void* stream);
 int pscv_conv2d(const void* in, int dtype, const uint16_t* packed, const float* scale, const float* bias, void* out,
                 int out_dtype, int B, int Hi, int Wi, int c_in, int c_out, int ks, int stride, float neg_slope, void* stream);
 /*

@@ -35,7 +35,7 @@ EXPORTS = ("pscv_last_error", "pscv_abi_version", "pscv_set_tuning", "pscv_proj_
            "pscv_photo_warp", "pscv_photo_warp_bwd", "pscv_ssim", "pscv_ssim_bwd", "pscv_bn_finalize", "pscv_bn_bwd_coeffs", "pscv_cvp_cams", "pscv_homography_warp", "pscv_prob_softargmin", "pscv_prob_softargmin_workspace",
            "pscv_set_tuning_thread", "pscv_get_tuning", "pscv_conv3d_cat2", "pscv_uncert_net", "pscv_head_index_entropy", "pscv_image_prep", "pscv_conv3d_block8",
            "pscv_bn_stats_grouped", "pscv_bn_finalize_grouped", "pscv_bn_act_grouped", "pscv_bn_bwd_reduce_grouped", "pscv_bn_bwd_coeffs_grouped",
-           "pscv_bn_bwd_apply_grouped", "pscv_pack_conv2d_weights_device", "pscv_leaky_relu_bwd", "pscv_leaky_relu_bwd_sum")
+           "pscv_bn_bwd_apply_grouped", "pscv_pack_conv2d_weights_device", "pscv_leaky_relu_bwd", "pscv_leaky_relu_bwd_sum", "pscv_pack_conv2d_weights_device_ex")
 
 
 class PscvMissingError(RuntimeError):
@@ -132,6 +132,8 @@ def _declare(lib):
     lib.pscv_leaky_relu_bwd_sum.argtypes = [vp, vp, i, l, i, f, vp, vp, vp, vp]
     lib.pscv_leaky_relu_bwd.restype = i
     lib.pscv_leaky_relu_bwd.argtypes = [vp, vp, i, l, i, f, vp, vp]
+    lib.pscv_pack_conv2d_weights_device_ex.restype = i
+    lib.pscv_pack_conv2d_weights_device_ex.argtypes = [vp, i, i, i, i, i, i, vp, vp]
     lib.pscv_pack_conv2d_weights_device.restype = i
     lib.pscv_pack_conv2d_weights_device.argtypes = [vp, i, i, i, i, i, vp, vp]
     lib.pscv_bn_stats_grouped.restype = i

@@ -631,7 +631,7 @@ extern "C" long pscv_pack_conv2d_weights(const float* w, int c_in, int c_in_padd
 // host loop and an upload per layer -- 21 round trips per MVSNet training step.
 namespace pscv {
 __global__ void pack_conv2d_kernel(const float* __restrict__ w, int c_in, int c_in_padded, int c_out, int ntaps, int nt, int dtype, long n,
-                                   uint16_t* __restrict__ packed) {
+                                   uint16_t* __restrict__ packed, int adjoint) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     const int j = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
@@ -640,13 +640,16 @@ __global__ void pack_conv2d_kernel(const float* __restrict__ w, int c_in, int c_
     const int co = t * 16 + (lane & 15), k = s * 32 + (lane >> 4) * 8 + j;
     const int tap = k / c_in_padded, ci = k % c_in_padded;
     float v = 0.f;
-    if (co < c_out && tap < ntaps && ci < c_in) v = w[((long)co * c_in + ci) * ntaps + tap];
+    // adjoint: w is the weight [c_in][c_out][k][k] of the FORWARD layer (c_in of this layer = its output channels); the adjoint conv
+    // swaps the channel axes and flips the taps -- read in place instead of flip / transpose / contiguous launches per layer and step
+    if (co < c_out && tap < ntaps && ci < c_in)
+        v = adjoint ? w[((long)ci * c_out + co) * ntaps + (ntaps - 1 - tap)] : w[((long)co * c_in + ci) * ntaps + tap];
     packed[idx] = dtype == PSCV_BF16 ? f32_to_bf16(v) : f32_to_f16_bits(v);
 }
 }  // namespace pscv
 
-extern "C" int pscv_pack_conv2d_weights_device(const float* w, int c_in, int c_in_padded, int c_out, int ks, int dtype, uint16_t* packed,
-                                               void* stream) {
+extern "C" int pscv_pack_conv2d_weights_device_ex(const float* w, int c_in, int c_in_padded, int c_out, int ks, int dtype, int adjoint,
+                                                  uint16_t* packed, void* stream) {
     using namespace pscv;
     PSCV_CHECK_ARG(c_in > 0 && c_in <= c_in_padded && c_in_padded % 8 == 0 && c_out > 0 && (ks == 1 || ks == 2 || ks == 3 || ks == 5),
                    "pscv_pack_conv2d_weights_device: bad layer %d(%d) -> %d, k=%d", c_in, c_in_padded, c_out, ks);
@@ -656,9 +659,13 @@ extern "C" int pscv_pack_conv2d_weights_device(const float* w, int c_in, int c_i
     const int nsteps = (ntaps * c_in_padded + 31) / 32;
     const long n = (long)nsteps * nt * 64 * 8;
     hipLaunchKernelGGL(pack_conv2d_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w, c_in,
-                       c_in_padded, c_out, ntaps, nt, dtype, n, packed);
+                       c_in_padded, c_out, ntaps, nt, dtype, n, packed, adjoint ? 1 : 0);
     PSCV_CHECK_LAUNCH("pscv_pack_conv2d_weights_device");
     return 0;
+}
+extern "C" int pscv_pack_conv2d_weights_device(const float* w, int c_in, int c_in_padded, int c_out, int ks, int dtype, uint16_t* packed,
+                                               void* stream) {
+    return pscv_pack_conv2d_weights_device_ex(w, c_in, c_in_padded, c_out, ks, dtype, 0, packed, stream);
 }
 
 extern "C" int pscv_conv2d_ex(const void* in, int dtype, const uint16_t* packed, const float* scale, const float* bias,

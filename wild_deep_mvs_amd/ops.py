@@ -289,11 +289,18 @@ class Conv2dLayer:
     @staticmethod
     def build(weight: torch.Tensor, *, stride: int, device=None, bn: Optional[Sequence[torch.Tensor]] = None,
               bn_eps: float = 1e-5, conv_bias: Optional[torch.Tensor] = None, relu: bool = False,
-              leaky: Optional[float] = None, dtype: torch.dtype = torch.float16) -> "Conv2dLayer":
+              leaky: Optional[float] = None, dtype: torch.dtype = torch.float16, adjoint: bool = False) -> "Conv2dLayer":
         """``bn`` = (gamma, beta, running_mean, running_var) folds an eval-mode BatchNorm2d into the epilogue;
-        ``relu`` / ``leaky`` (negative slope) select the fused activation."""
+        ``relu`` / ``leaky`` (negative slope) select the fused activation.  ``adjoint``: ``weight`` is a stride-1 FORWARD layer's
+        [Co,Ci,k,k] and the result is its adjoint (Co -> Ci, taps flipped), packed straight from that tensor on the device."""
         device = device if device is not None else weight.device
-        c_out, c_in, ks = int(weight.shape[0]), int(weight.shape[1]), int(weight.shape[2])
+        if adjoint:
+            if not (weight.is_cuda and torch.device(device) == weight.device):
+                return Conv2dLayer.build(weight.detach().float().flip(2, 3).transpose(0, 1).contiguous(), stride=stride, device=device, bn=bn,
+                                         bn_eps=bn_eps, conv_bias=conv_bias, relu=relu, leaky=leaky, dtype=dtype)
+            c_in, c_out, ks = int(weight.shape[0]), int(weight.shape[1]), int(weight.shape[2])
+        else:
+            c_out, c_in, ks = int(weight.shape[0]), int(weight.shape[1]), int(weight.shape[2])
         c_pad = (c_in + 7) // 8 * 8
         if weight.is_cuda and torch.device(device) == weight.device and weight.dim() == 4 and weight.shape[2] == weight.shape[3]:
             # device-side packing (same bits): no device -> host copy, no stream synchronisation per layer
@@ -303,8 +310,8 @@ class Conv2dLayer:
                 L.check(int(n), "pscv_pack_conv2d_weights")
             packed = torch.empty(int(n), dtype=torch.int16, device=weight.device)
             with torch.cuda.device(weight.device):
-                L.check(L.lib().pscv_pack_conv2d_weights_device(_p(wd), c_in, c_pad, c_out, ks, _TORCH2PSCV[dtype], _p(packed), _stream()),
-                        "pscv_pack_conv2d_weights_device")
+                L.check(L.lib().pscv_pack_conv2d_weights_device_ex(_p(wd), c_in, c_pad, c_out, ks, _TORCH2PSCV[dtype], int(adjoint), _p(packed),
+                                                                   _stream()), "pscv_pack_conv2d_weights_device")
         else:
             packed = torch.from_numpy(pack_conv2d_weights(weight, c_pad, dtype).view(np.int16)).to(device)
         scale = bias = None

@@ -520,7 +520,7 @@ def _wgrad2d_k5s2(dy: torch.Tensor, x: torch.Tensor, co: int, ci: int) -> torch.
 
 def _dgrad2d_k3_layer(w: torch.Tensor, dtype) -> ops.Conv2dLayer:
     """Adjoint of a k3 s1 p1 Conv2d [Co,Ci,3,3]: the same conv kernel on the channel-swapped, tap-flipped weight."""
-    return ops.Conv2dLayer.build(w.detach().float().flip(2, 3).transpose(0, 1).contiguous(), stride=1, dtype=dtype)
+    return ops.Conv2dLayer.build(w, stride=1, dtype=dtype, adjoint=True)        # (packed in place from the forward weight: no flip / transpose launches)
 
 
 def _dgrad2d_k5s2_layers(w: torch.Tensor, dtype) -> List[ops.Conv2dLayer]:
