@@ -4,6 +4,8 @@ from __future__ import annotations
 
 from typing import Dict, Optional
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -138,7 +140,8 @@ class network(nn.Module):
         self.train_storage_dtype = torch.bfloat16   # train(): bf16 activations / gradients by default (range), fp32 accumulation
         # 2-D pyramid tower in train(): "torch" = PyTorch-ROCm autograd in fp32 (default, like MVSNet's extractor);
         # "pscv" = training.FeaturePyramidFn: all views in one engine pass, 16-bit activations
-        self.feature_engine_train = "torch"
+        self.feature_engine_train_dtype = None       # 16-bit format of the engine tower's activations in train() (None: fp16)
+        self.feature_engine_train = os.environ.get("PSCV_FEATURE_ENGINE_TRAIN", "torch")
 
     def forward_train(self, ref_img, src_imgs, ref_in, src_in, ref_ex, src_ex, depth_min, depth_max, nscale):
         """train()-mode forward with autograd (reference net.py:96-229 with ``self.training``): 48 coarse planes, fixed
@@ -153,8 +156,11 @@ class network(nn.Module):
             # the tower of ALL views in one engine pass (training.FeaturePyramidFn: no BatchNorm, the views are batch items);
             # channels-last 16-bit maps, which WarpCostFn takes as they are
             Bn = ref_img.shape[0]
-            levels = T.FeaturePyramidFn.apply(self.featurePyramid, dt, nscale, torch.cat([ref_img] + list(src_imgs), 0),
+            fdt = self.feature_engine_train_dtype or torch.float16      # the tower's own 16-bit format (fp16: see MVSNet.forward), then the sweep's
+            levels = T.FeaturePyramidFn.apply(self.featurePyramid, fdt, nscale, torch.cat([ref_img] + list(src_imgs), 0),
                                               *T.FeaturePyramidFn.params(self.featurePyramid))
+            if fdt != dt:
+                levels = [lv.to(dt) for lv in levels]
             per_view = [torch.split(lv, Bn, 0) for lv in levels]                       # [level][view]
             ref_pyr = [pv[0] for pv in per_view]
             src_pyrs = [[pv[1 + i] for pv in per_view] for i in range(nsrc)]

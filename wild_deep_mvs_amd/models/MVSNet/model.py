@@ -11,6 +11,8 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional, Sequence
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -254,7 +256,8 @@ class MVSNet(ReplayHooks, nn.Module):
         # before the path; "pscv" = training.FeatureNetFn (forward and backward on the engine's conv2d / weight-gradient /
         # BatchNorm kernels with 16-bit stored activations: a mixed-precision speed mode, eight more 16-bit roundings in front
         # of the sweep -- depth moves by ~2e-3 (fp16) / ~2e-2 (bf16) relative on the training fixtures)
-        self.feature_engine_train = "torch"
+        self.feature_engine_train_dtype = None       # 16-bit format of the engine extractor's activations in train() (None: fp16)
+        self.feature_engine_train = os.environ.get("PSCV_FEATURE_ENGINE_TRAIN", "torch")
         # source-view shard: with a torch.distributed group set here (``set_view_group``), rank r warps
         # source views r, r+G, ... only and contributes fp32 partial sums (sum f, sum f^2; rank 0 adds the reference view);
         # one all-reduce (RCCL) and pscv_variance_finish give every rank the full cost volume.  The reference has no
@@ -467,7 +470,13 @@ class MVSNet(ReplayHooks, nn.Module):
                 # like the per-view calls of the reference), convolutions and weight gradients run over the whole stack
                 fparams = T.FeatureNetFn.params(self.feature)
                 stack = torch.cat(list(imgs), 0)
-                fs = T.FeatureNetFn.apply(self.feature, self.train_storage_dtype, len(imgs), stack, *fparams)
+                # the extractor's own 16-bit format: fp16 by default -- its BatchNorm-normalised activations need no bf16 range, and 40 Adam
+                # steps on one sample end at the PyTorch-ROCm extractor's loss with fp16 activations (3.24 vs 3.25) but not with bf16
+                # ones (3.78 vs 3.37; scripts/dev/train_curve.py); the maps are converted to the sweep's format at the end
+                fdt = self.feature_engine_train_dtype or torch.float16
+                fs = T.FeatureNetFn.apply(self.feature, fdt, len(imgs), stack, *fparams)
+                if fdt != self.train_storage_dtype:
+                    fs = fs.to(self.train_storage_dtype)
                 feats = list(torch.split(fs, imgs[0].shape[0], 0))
             else:
                 feats = [self.feature(img) for img in imgs]

@@ -1,4 +1,6 @@
 """Drop-in for the reference's ``models/VisMVSNet/frontend.py``: common ``forward()`` -> 3-stage Vis cascade."""
+import os
+
 import torch
 from torch import nn
 from torch.nn import functional as F
@@ -18,7 +20,7 @@ class Frontend(ReplayHooks, nn.Module):
         self.feature_engine = "pscv"
         # the 2-D extractor in train(): "torch" = PyTorch-ROCm autograd in fp32 (default); "pscv" = FeatExt.forward_train: all views in one
         # engine pass (grouped BatchNorm statistics), 16-bit activations
-        self.feature_engine_train = "torch"
+        self.feature_engine_train = os.environ.get("PSCV_FEATURE_ENGINE_TRAIN", "torch")
 
     @property
     def storage_dtype(self):
@@ -90,8 +92,11 @@ class Frontend(ReplayHooks, nn.Module):
                     raise NotImplementedError("pscv Vis-MVSNet: the source-view shard is an inference path")
                 if getattr(self, "feature_engine_train", "torch") == "pscv":
                     # the extractor of ALL views in one engine pass (FeatExt.forward_train: grouped BatchNorm statistics, one per view)
-                    packs = [torch.chunk(f, v, 0) for f in self.model.feat_ext.forward_train(torch.cat([imgs[i] for i in order], 0), v,
-                                                                                              self.train_storage_dtype)]
+                    fdt = getattr(self, "feature_engine_train_dtype", None) or torch.float16     # the extractor's own 16-bit format (fp16: see
+                    maps = self.model.feat_ext.forward_train(torch.cat([imgs[i] for i in order], 0), v, fdt)   # MVSNet.forward), then the sweep's
+                    if fdt != self.train_storage_dtype:
+                        maps = [m.to(self.train_storage_dtype) for m in maps]
+                    packs = [torch.chunk(f, v, 0) for f in maps]
                     ref_feats = tuple(p[0] for p in packs)
                     src_feats = [tuple(p[j + 1] for p in packs) for j in range(len(src_idx))]
                 else:
