@@ -229,37 +229,65 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint4* __restri
 //   depth   = sum_d p_d depth_d            g_depth p_d (depth_d - depth)                 models/MVSNet/model.py:207-209
 //   index   = sum_d p_d d                  g_index p_d (d - index)                       models/VisMVSNet/nn_utils.py:453-466
 //   entropy = -sum_d p_d log clamp(p_d, 1e-9, 1)   g_ent p_d (a_d - sum_k p_k a_k), a_d = -(log clamp(p_d) + [p_d > 1e-9])   nn_utils.py:469-470
-// One lane per pixel walks D three times (max, sums, write); reads and writes are coalesced across the wave.
+// 32 pixels x 8 depth slices per workgroup, three LDS meetings of the slices (max; sum; expectations); reads and writes are coalesced.
 // Output: the gradient volume in the conv engine's layout, [B,D,h,w,8] 16-bit with the value in channel 0 and
 // channels 1-7 zero (the 1-channel heads' backward then runs on the 8-channel MFMA kernels).
+// 256 threads = 32 x-adjacent pixels x 8 depth slices (the forward kernel's decomposition): a thread walks D / 8 planes per pass and the
+// slices meet in LDS three times (max; sum e; the expectations).  One lane per pixel over all of D -- 20 K lanes at the headline size,
+// 80 workgroups on 256 CUs, four dependent passes -- took 166 us.
+constexpr int SB_PX = 32, SB_NS = 8;
 template <typename H>
 __global__ __launch_bounds__(256) void softargmin_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ depth,
                                                              long depth_bstride, int depth_per_pixel,
                                                              const float* __restrict__ gdepth, const float* __restrict__ gindex,
                                                              const float* __restrict__ gentropy, uint4* __restrict__ dl8, int B,
                                                              int D, int hw) {
-    const long p = (long)blockIdx.x * 256 + threadIdx.x;
-    if (p >= (long)B * hw) return;
+    __shared__ float sh[3][SB_NS][SB_PX];
+    const int px = threadIdx.x % SB_PX, sl = threadIdx.x / SB_PX;
+    const long npix = (long)B * hw;
+    long p = (long)blockIdx.x * SB_PX + px;
+    const bool active = p < npix;
+    p = active ? p : npix - 1;
     const int b = (int)(p / hw);
     const int pix = (int)(p - (long)b * hw);
     const float* lp = logits + (long)b * D * hw + pix;
     const float* dp = gdepth ? depth + (long)b * depth_bstride + (depth_per_pixel ? pix : 0) : nullptr;
     const long dstep = depth_per_pixel ? hw : 1;
+    const int per = (D + SB_NS - 1) / SB_NS;
+    const int d0 = sl * per, d1 = min(D, d0 + per);
+    auto reduce = [&](int k, float v, bool is_max) -> float {
+        sh[k][sl][px] = v;
+        __syncthreads();
+        float r = sh[k][0][px];
+#pragma unroll
+        for (int i = 1; i < SB_NS; ++i) r = is_max ? fmaxf(r, sh[k][i][px]) : r + sh[k][i][px];      // fixed order: every slice gets the same bits
+        return r;
+    };
     float m = -INFINITY;
-    for (int d = 0; d < D; ++d) m = fmaxf(m, lp[(long)d * hw]);
+#pragma unroll 4
+    for (int d = d0; d < d1; ++d) m = fmaxf(m, lp[(long)d * hw]);
+    m = reduce(0, m, true);
     float z = 0.0f;
-    for (int d = 0; d < D; ++d) z += __expf(lp[(long)d * hw] - m);
-    const float inv = 1.0f / z;
+#pragma unroll 4
+    for (int d = d0; d < d1; ++d) z += __expf(lp[(long)d * hw] - m);
+    const float inv = 1.0f / reduce(1, z, false);
     float e_depth = 0.0f, e_index = 0.0f, e_a = 0.0f;
-    for (int d = 0; d < D; ++d) {
+#pragma unroll 4
+    for (int d = d0; d < d1; ++d) {
         const float pd = __expf(lp[(long)d * hw] - m) * inv;
         if (gdepth) e_depth = fmaf(pd, dp[d * dstep], e_depth);
         e_index = fmaf(pd, (float)d, e_index);
         if (gentropy) e_a = fmaf(pd, -(__logf(fminf(fmaxf(pd, 1e-9f), 1.0f)) + (pd > 1e-9f ? 1.0f : 0.0f)), e_a);
     }
+    __syncthreads();                         // (the three tables are reused below)
+    e_index = reduce(0, e_index, false);
+    if (gdepth) e_depth = reduce(1, e_depth, false);
+    if (gentropy) e_a = reduce(2, e_a, false);
+    if (!active) return;
     const float gd = gdepth ? gdepth[p] : 0.0f, gi = gindex ? gindex[p] : 0.0f, ge = gentropy ? gentropy[p] : 0.0f;
     uint4* op = dl8 + (long)b * D * hw + pix;
-    for (int d = 0; d < D; ++d) {
+#pragma unroll 4
+    for (int d = d0; d < d1; ++d) {
         const float pd = __expf(lp[(long)d * hw] - m) * inv;
         float v = gi * ((float)d - e_index);
         if (gdepth) v = fmaf(gd, dp[d * dstep] - e_depth, v);
@@ -451,7 +479,7 @@ extern "C" int pscv_softargmin_bwd(const float* logits, const float* depth, long
     PSCV_CHECK_ARG(dtype == PSCV_BF16 || dtype == PSCV_F16, "pscv_softargmin_bwd: dtype %d must be bf16 or fp16", dtype);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const long npix = (long)B * h * w;
-    const int nb = (int)((npix + 255) / 256);
+    const int nb = (int)((npix + SB_PX - 1) / SB_PX);
     if (dtype == PSCV_BF16)
         hipLaunchKernelGGL(softargmin_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, logits, depth, depth_bstride, depth_per_pixel, grad_depth, grad_index, grad_entropy, (uint4*)dlogits8, B, D, h * w);
     else
