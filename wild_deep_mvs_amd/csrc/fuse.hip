@@ -78,17 +78,26 @@ struct FuseBwdArgs {
     int n_src, B, D, hw;
 };
 
+// 256 threads = 32 x-adjacent pixels x 8 depth slices: a thread walks D / 8 planes and the per-view sums of the slices meet in LDS at the
+// end (fixed order).  One lane per pixel over all planes left the coarse stages (5 120 pixels x 64 planes) with 20 workgroups.
+constexpr int FB_PX = 32, FB_NS = 8;
 template <typename H>
 __global__ __launch_bounds__(256) void fuse_pairs_bwd_kernel(const FuseBwdArgs a) {
-    const long p = (long)blockIdx.x * 256 + threadIdx.x;
-    if (p >= (long)a.B * a.hw) return;
+    __shared__ float sh[PSCV_MAX_SRC][FB_NS][FB_PX];
+    const int px = threadIdx.x % FB_PX, sl = threadIdx.x / FB_PX;
+    const long npix = (long)a.B * a.hw;
+    long p = (long)blockIdx.x * FB_PX + px;
+    const bool active = p < npix;
+    p = active ? p : npix - 1;
     const int b = (int)(p / a.hw);
     const int pf = (int)(p - (long)b * a.hw);
     float w[PSCV_MAX_SRC], acc[PSCV_MAX_SRC];
     float wsum = 0.f;
     for (int v = 0; v < a.n_src; ++v) { w[v] = expf(-a.uncert[v][p]); wsum += w[v]; acc[v] = 0.f; }
     const float inv = 1.0f / wsum;
-    for (int d = 0; d < a.D; ++d) {
+    const int per = (a.D + FB_NS - 1) / FB_NS;
+    const int d0 = sl * per, d1 = min(a.D, d0 + per);
+    for (int d = d0; d < d1; ++d) {
         const long vox = ((long)b * a.D + d) * a.hw + pf;
         const f32x8 G = Elem<H>::load8(reinterpret_cast<const H*>(a.g) + vox * 8);
         float fused[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -108,10 +117,19 @@ __global__ __launch_bounds__(256) void fuse_pairs_bwd_kernel(const FuseBwdArgs a
 #pragma unroll
             for (int j = 0; j < 8; ++j) { gi = fmaf(G.v[j], x.v[j], gi); o.v[j] = G.v[j] * s; }
             acc[v] += gi - gf;
-            Elem<H>::store8(reinterpret_cast<H*>(a.dinterm[v]) + vox * 8, o);
+            if (active) Elem<H>::store8(reinterpret_cast<H*>(a.dinterm[v]) + vox * 8, o);
         }
     }
-    for (int v = 0; v < a.n_src; ++v) a.duncert[v][p] = -w[v] * inv * acc[v];
+    for (int v = 0; v < a.n_src; ++v) sh[v][sl][px] = acc[v];
+    __syncthreads();
+    if (sl == 0 && active) {
+        for (int v = 0; v < a.n_src; ++v) {
+            float t = sh[v][0][px];
+#pragma unroll
+            for (int i = 1; i < FB_NS; ++i) t += sh[v][i][px];
+            a.duncert[v][p] = -w[v] * inv * t;
+        }
+    }
 }
 
 // second half of a source-view-sharded variance: out = sum2 / N - mean^2 after the cross-rank all-reduce of the partial sums
@@ -163,7 +181,7 @@ extern "C" int pscv_fuse_pairs_bwd(const void* const* interm, const float* const
     for (int i = 0; i < n_src; ++i) PSCV_CHECK_ARG(interm[i] && uncert[i] && dinterm[i] && duncert[i], "pscv_fuse_pairs_bwd: null view %d", i);
     a.g = grad_fused; a.n_src = n_src; a.B = B; a.D = D; a.hw = h * w;
     const long npix = (long)B * h * w;
-    const unsigned nblk = (unsigned)((npix + 255) / 256);
+    const unsigned nblk = (unsigned)((npix + FB_PX - 1) / FB_PX);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == PSCV_BF16) hipLaunchKernelGGL(fuse_pairs_bwd_kernel<bf16_t>, dim3(nblk), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(fuse_pairs_bwd_kernel<f16_t>, dim3(nblk), dim3(256), 0, st, a);
