@@ -24,6 +24,14 @@ def _init(rank, world, port):
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
+        # The ranks of these tests SHARE cuda:0.  MVSNet's LDS-staged warp kernel is not reproducible while a second PROCESS runs
+        # the same kernels on the same GPU (isolated in round 3 with scripts/dev/contention_repro.py: one vector register of the
+        # lanes 48-63 of a wave is wrong for one plane, in ~3 % of the forwards; never with one process per GPU -- the deployment
+        # model -- with several streams of one process, or next to unrelated work of another process).  The
+        # sharding logic under test is independent of which warp kernel runs, so the shared-GPU ranks use the direct-tap kernel;
+        # the LDS-staged kernel keeps its own single-process tests (bit-equal to the direct kernel, test_gpu_warp_cost.py).
+        from wild_deep_mvs_amd import _lib as L
+        L.set_tuning("warp_tiled", 0)
 
 
 def _free_port():
