@@ -5,8 +5,9 @@ A step = one pass of the hot path (fused warp + variance cost volume -> 3-D U-Ne
 softmax / depth regression / confidence) over one batch of synthetic input that is already resident in
 HBM: BASELINE.json configs[1] = MVSNet, 1 ref + 4 src views, 512x640 images (128x160x32 feature maps),
 D = 192 planes, bf16 storage / fp32 accumulation.  3 932 160 cost-volume voxels per reference view; a batch is
---batch reference views (default 3, each with its own source views; the engine runs the items of a batch on
-separate HIP streams; --batch 1 = one view at a time as in rounds 1-2, also reported in every line).
+--batch reference views (default 3, each with its own source views; one launch per layer for the whole batch on one
+stream, replayed as a hipGraph; --batch-mode streams = the items on separate HIP streams, the round-3 experiment;
+--batch 1 = one view at a time as in rounds 1-2, also reported in every line).
 
 Multi-GPU (--gpus N, one process per GPU): reference views are independent objects, so each rank sweeps its own
 view (global batch = N) with no data-path collective -> weak scaling.  Ranks come either from a launcher
@@ -294,8 +295,8 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=3, help="reference views per step and GPU (each with its own 4 source views): the engine runs "
-                                                          "the items of a batch on separate HIP streams (1 = one view at a time, as in rounds 1-2)")
-    ap.add_argument("--batch-mode", choices=["streams", "batched"], default="streams",
+                                                          "the items of a batch as one launch per layer (1 = one view at a time, as in rounds 1-2)")
+    ap.add_argument("--batch-mode", choices=["streams", "batched"], default="batched",
                     help="how the views of a step are launched: 'streams' = each view's 13 launches on its own HIP stream (eager; up to 4 views), "
                          "'batched' = one launch per layer for the whole batch on one stream, replayed as a hipGraph")
     ap.add_argument("--no-training", action="store_true", help="skip the two MVSNet training-step timings (scripts/bench_train.py) reported under 'training'")
@@ -443,8 +444,10 @@ def run(args):
         _lib.set_tuning(k, int(v))
     net, sd, feats, feats_cl, proj_d, dv_d, proj, dv = build_inputs(device, rank, DTYPES[args.dtype], args.batch)
     NB = args.batch
-    if args.batch_mode == "batched":
-        net.batch_streams = False
+    # "batched" (default since the end of round 3): the LDS-staged warp kernel is not reproducible while conv kernels of another
+    # stream run next to it, so the headline step keeps the views of a batch on ONE stream; "streams" is
+    # the round-3 experiment (the model then sweeps with the direct-tap kernels)
+    net.batch_streams = args.batch_mode == "streams"
     streams_mode = net.batch_streams and 2 <= NB <= net.MAX_BATCH_STREAMS
 
     def timed_region(dtype_name, feats_cl_, steps):
@@ -589,9 +592,9 @@ def run(args):
                        "voxels_per_step_per_gpu": NB * VOX, "parallelism": f"reference-view shard x{world}, no collective"},
             "timing": ("hipGraph replay of the step" if graph else "eager launches") +
                       (f"; the {NB} views of a step run on {NB} HIP streams: one view's vector-ALU-bound warp beside another's MFMA / "
-                       "memory-bound U-Net, same kernels and bit-equal outputs (MVSNet._hot_path_streams; eager because ROCm 7.2 replays "
-                       "multi-branch graphs of this path wrongly on changing inputs), so a step is SHORTER than the sum of its kernels' "
-                       "stand-alone durations below" if streams_mode else
+                       "memory-bound U-Net (MVSNet._hot_path_streams: eager, and with the DIRECT-TAP warp kernels -- the LDS-staged one is not "
+                       "reproducible next to another stream's conv kernels, DESIGN.md section 6), so a step is SHORTER than the sum of "
+                       "its kernels' stand-alone durations below" if streams_mode else
                        f"; the {NB} views of a step share ONE launch per layer (batched grids, one stream)" if NB > 1 else "") +
                       f"; kernels_us / roofline: HIP events of an eager pass of the same {args.steps} steps, one view after the other on one "
                       f"stream (each launch timed alone; {elapsed_eager / args.steps * 1e3:.3f} ms/step that way)",

@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 ORDER = ("features", "cost_volume", "conv0", "conv2", "conv4", "conv6", "up7", "up9", "up11", "logits", "depth")
 
 
-def worker(rank, iters, size, q, tune, notaps=False, bar=None, views=5):
+def worker(rank, iters, size, q, tune, notaps=False, bar=None, views=5, partner="forward", stop=None):
     from wild_deep_mvs_amd import _lib as L
     if os.environ.get("PSCV_LIB"):
         L.LIB_PATH = os.environ["PSCV_LIB"]      # A/B runs against another build of the library
@@ -34,6 +34,33 @@ def worker(rank, iters, size, q, tune, notaps=False, bar=None, views=5):
     with torch.no_grad():
         net(scene["imgs"], scene["K"], scene["R"], scene["t"], scene["depth_min"], scene["depth_max"])      # weights packed, library loaded
     torch.cuda.synchronize()
+    if rank > 0 and partner != "forward":
+        # partner process: only one part of the forward, in a loop, until the victim (proc 0) is done
+        from wild_deep_mvs_amd import ops
+        from wild_deep_mvs_amd.models.MVSNet.model import build_proj_matrices
+        with torch.no_grad():
+            feats = net.extract_features_cl([scene["imgs"][:, i] for i in range(views)])
+            sk = scene["K"].clone(); sk[:, :, :2] /= 4
+            proj = build_proj_matrices(sk, scene["R"], scene["t"])
+            steps = torch.arange(D, device=dev, dtype=torch.float32).view(1, 1, -1)
+            dv = (scene["depth_min"].unsqueeze(-1) + ((scene["depth_max"] - scene["depth_min"]) / (D - 1)).unsqueeze(-1) * steps)[:, 0].float().contiguous()
+            cams = ops.proj_cams_device(proj.float().contiguous(), 0)
+            cost = net.build_cost_volume(feats[0], feats[1:], None, None, dv, cams)
+            torch.cuda.synchronize()
+            bar.wait()
+            n = 0
+            while not stop.is_set():
+                for _ in range(10):
+                    if partner == "warp":
+                        net.build_cost_volume(feats[0], feats[1:], None, None, dv, cams)
+                    elif partner == "reg":
+                        net.cost_regularization(cost, None, regress=dv)
+                    else:
+                        net.extract_features_cl([scene["imgs"][:, i] for i in range(views)])
+                torch.cuda.synchronize()
+                n += 10
+        q.put([f"proc {rank}: partner '{partner}' ran {n} launches-groups"])
+        return
     if bar is not None:
         bar.wait()                  # the processes must OVERLAP on the GPU: start the loops together
     for it in range(iters):
@@ -85,6 +112,8 @@ def worker(rank, iters, size, q, tune, notaps=False, bar=None, views=5):
             if len(lines) < 12:
                 lines.append(f"proc {rank} it {it}: first differing: {bad[0]}; all: {[b.split(' ')[0] for b in bad]}")
     lines.append(f"proc {rank}: {iters} iterations, first-differing histogram {hist}")
+    if stop is not None and rank == 0:
+        stop.set()
     q.put(lines)
 
 
@@ -106,6 +135,8 @@ def main():
     ap.add_argument("--size", default="512x640x192")
     ap.add_argument("--tune", nargs="*", default=[])
     ap.add_argument("--views", type=int, default=5)
+    ap.add_argument("--partner", choices=["forward", "warp", "reg", "features"], default="forward",
+                    help="what the processes other than proc 0 run: the whole forward, or one part of it in a loop")
     ap.add_argument("--no-taps", action="store_true", help="the plain forward (fused tail, intermediates freed as it goes); only the depth map is compared")
     args = ap.parse_args()
     size = tuple(int(v) for v in args.size.split("x"))
@@ -116,7 +147,7 @@ def main():
     lp = ctx.Process(target=load, args=(stop, bar, args.load)) if args.load else None
     if lp:
         lp.start()
-    procs = [ctx.Process(target=worker, args=(r, args.iters, size, q, args.tune, args.no_taps, bar, args.views)) for r in range(args.procs)]
+    procs = [ctx.Process(target=worker, args=(r, args.iters, size, q, args.tune, args.no_taps, bar, args.views, args.partner, stop)) for r in range(args.procs)]
     for p in procs:
         p.start()
     for _ in procs:
