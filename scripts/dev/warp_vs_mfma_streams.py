@@ -105,6 +105,15 @@ def main():
                         pos = sorted({(y % 4, x % 8) for _, y, x in vox})
                         chans = sorted({int(c) % 8 for c in (d > 0).nonzero()[:, 3].tolist()})
                         same_in = all(torch.equal(a, b) for a, b in zip(keep, list(feats) + [cams, dv]))
+                        per = {}
+                        for dd, y, x in vox:
+                            per.setdefault((y // 4, x // 8, y % 4), set()).add(dd)
+                        ex = [(k, sorted(v)) for k, v in list(per.items())[:6]]
+                        nch = {}
+                        dn = (d > 0)
+                        for dd, y, x in vox[:400]:
+                            n = int(dn[dd, y, x].sum()); nch[n] = nch.get(n, 0) + 1
+                        print(f"   planes per (tile row, tile col, row in tile): {ex}; bad channels per bad voxel (histogram over 400): {nch}", flush=True)
                         print(f"   bad launch: {len(vox)} voxels, in-tile (row, col) positions {pos}, channel index mod 8 {chans}, inputs unchanged {same_in}", flush=True)
     print(f"one process, partner stream '{args.partner}', tune {args.tune}: {bad} of {args.iters} warp launches differ from the first (max abs {worst:.3e})", flush=True)
 
