@@ -83,7 +83,8 @@ int pscv_abi_version(void);
  *   "warp_tiled" 1 (default; -1 restores it): pscv_warp_cost stages the source patches of a reference tile in LDS as fp32
  *               where it applies (C = 32, 16-bit features, per-batch planes, PROJ geometry, 1-4 source views, variance /
  *               softmin) -- same bits as the direct-gather kernels; 0: always the direct-gather kernels.  "warp_lpv" != 0
- *               also selects the direct kernel.  Set 0 before launching the engine on SEVERAL STREAMS or from several PROCESSES on one GPU
+ *               also selects the direct kernel.  2: the same kernel compiled WITHOUT packed fp32 instructions (same stored bits, ~7 % slower).
+ *               Set 2 (or 0) before launching the engine on SEVERAL STREAMS or from several PROCESSES on one GPU
  *               (the LDS-staged kernel returns wrong voxels while the engine's conv kernels run beside it
  *               on another stream / in another process; launches on one stream, one process per GPU, are unaffected).
  *   "sweep_dc"  depth planes per workgroup of the depth-sweep convs (0 = default heuristic)

@@ -261,6 +261,9 @@ extern Knob g_s2s_slots;
 static Knob g_warp_q2 = {1, KNOB_WARP_Q2};        // 1: 32-channel 16-bit sweeps use the quad-mapped kernel (warp_cost_q2.hip)
 int warp_cost_q2_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, int out_dtype, int ppd_override, hipStream_t st);
 int warp_cost_tiled_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, int out_dtype, int ppd_override, hipStream_t st);
+// the same kernel compiled without packed fp32 instructions ("warp_tiled" = 2; warp_cost_tiled.hip, Makefile): for launches that
+// overlap other streams' / processes' conv kernels
+int warp_cost_tiled_nopk_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, int out_dtype, int ppd_override, hipStream_t st);
 
 // Instantiated (geometry, cost) pairs: the variance / softmin statistics belong to the PROJ models (MVSNet,
 // CVP), group-wise correlation to the HOMOG model (Vis); the plain warp exists for both.
@@ -434,7 +437,8 @@ extern "C" int pscv_warp_cost(const void* ref, const void* const* srcs, int n_sr
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int rc;
     if (g_warp_tiled && g_warp_lpv_override == 0 && cost != PSCV_COST_VARIANCE_PARTIAL) {
-        rc = warp_cost_tiled_try(a, C, geom, cost, in_dtype, out_dtype, g_warp_ppd_override, st);
+        rc = g_warp_tiled == 2 ? warp_cost_tiled_nopk_try(a, C, geom, cost, in_dtype, out_dtype, g_warp_ppd_override, st)
+                               : warp_cost_tiled_try(a, C, geom, cost, in_dtype, out_dtype, g_warp_ppd_override, st);
         if (rc < 0) return rc;
         if (rc == 0) {
             PSCV_CHECK_LAUNCH("pscv_warp_cost(tiled)");

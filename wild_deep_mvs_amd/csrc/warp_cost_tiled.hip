@@ -40,6 +40,17 @@
 
 #include "warp_common.h"
 
+// WL_NOPK: the Makefile compiles this file a second time (warp_cost_tiled_nopk.o) WITHOUT packed fp32 instructions
+// (-target-feature -packed-fp32-ops) under other names; pscv_set_tuning("warp_tiled", 2) selects that build.  Reason (DESIGN.md
+// section 6): next to another stream's / process's LDS + MFMA conv waves the v_pk_*_f32 instructions of this kernel's blend -- fed
+// by ds_read_b128 results -- were seen to return stale halves in the lanes 48-63 of a wave; the scalar build is clean there
+// (0 of 400 overlapped launches against 150-390), ~7 % slower.  Same source, same fp32 operation chain, same stored bits.
+#ifdef WL_NOPK
+#define warp_cost_lds_kernel warp_cost_lds_nopk_kernel
+#define warp_cost_tiled_try warp_cost_tiled_nopk_try
+#define wl_prof wl_prof_nopk
+#endif
+
 namespace pscv {
 
 #ifndef WL_TILE_H
@@ -797,6 +808,16 @@ __global__ __launch_bounds__(WL_THREADS, WL_MIN_WAVES) void warp_cost_lds_kernel
 #undef WL_VIEW
 
         float o[8];
+#ifdef WL_NOPK
+        // the packed build's rounding, spelled out (its compiler emits mul, mul, fma / mul, mul, fma for these two expressions)
+        if (COST == PSCV_COST_VARIANCE) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = fmaf(invN, q[j], -__fmul_rn(invN2, __fmul_rn(s[j], s[j])));
+        } else if (COST == PSCV_COST_VARIANCE_CVP) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float m = __fmul_rn(invN, s[j]); o[j] = fmaf(invN, q[j], -__fmul_rn(m, m)); }
+        } else
+#endif
         if (COST == PSCV_COST_VARIANCE) {
             const wl_f2 n1 = wl_f2{invN, invN}, n2 = wl_f2{invN2, invN2};
 #pragma unroll
@@ -896,6 +917,7 @@ int warp_cost_tiled_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, in
 
 }  // namespace pscv
 
+#ifndef WL_NOPK
 // occupancy the runtime computes for the f16 variance instantiation (development aid; scripts/dev/wl_occupancy.py)
 extern "C" int pscv_debug_wl_occupancy(int* blocks_per_cu, int* lds_bytes, int* threads) {
     auto kern = pscv::warp_cost_lds_kernel<pscv::f16_t, pscv::f16_t, PSCV_GEOM_PROJ, PSCV_COST_VARIANCE>;
@@ -904,6 +926,7 @@ extern "C" int pscv_debug_wl_occupancy(int* blocks_per_cu, int* lds_bytes, int* 
     *threads = pscv::WL_THREADS;
     return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, kern, pscv::WL_THREADS, pscv::WL_LDS);
 }
+#endif
 
 #ifdef WL_PROFILE
 // sums over the first n_blocks blocks of the last launch

@@ -272,7 +272,7 @@ class MVSNet(ReplayHooks, nn.Module):
         # batch items of the eval-mode hot path on separate HIP streams (``_hot_path_streams``).  OFF by default since the end of
         # round 3: the LDS-staged warp kernel returns wrong voxels while the regulariser's conv kernels of ANOTHER stream run on
         # the same GPU; the batched launches on one stream have the same throughput under graph replay.
-        # When switched on, the stream mode sweeps with the direct-tap kernels, which are reproducible under that overlap.
+        # When switched on, the stream mode sweeps with the kernel's build without packed fp32 instructions, which is reproducible there.
         self.batch_streams = False
 
     # -- upstream ---------------------------------------------------------------------------
@@ -423,8 +423,9 @@ class MVSNet(ReplayHooks, nn.Module):
         outs = []
         # one item's warp overlaps another item's conv kernels here: the LDS-staged warp kernel is NOT reproducible under that
         # overlap (39 of 40 three-view steps differed from the sequential forward, up to 8e-2 of the depth
-        # range), the direct-tap kernels are -> this thread's launches use them for the duration of the fork
-        L.set_tuning_thread("warp_tiled", 0, True)
+        # range); its build without packed fp32 instructions ("warp_tiled" = 2, same stored bits, ~7 % slower) is -> this thread's
+        # launches use that build for the duration of the fork
+        L.set_tuning_thread("warp_tiled", 2, True)
         try:
             for b in range(B):
                 st = streams[b]
@@ -433,7 +434,7 @@ class MVSNet(ReplayHooks, nn.Module):
                     fb = [f[b:b + 1] for f in features_cl]                      # contiguous views of one batch item
                     outs.append(self.hot_path(fb, proj[b:b + 1], depth_values[b:b + 1].contiguous(), reference_frame))   # (B = 1: the plain path)
         finally:
-            L.set_tuning_thread("warp_tiled", 0, False)
+            L.set_tuning_thread("warp_tiled", 2, False)
         for st in streams[:B]:
             main.wait_stream(st)
         return torch.cat([o[0] for o in outs], 0), torch.cat([o[1] for o in outs], 0)
