@@ -446,7 +446,7 @@ def run(args):
     NB = args.batch
     # "batched" (default since the end of round 3): the LDS-staged warp kernel is not reproducible while conv kernels of another
     # stream run next to it, so the headline step keeps the views of a batch on ONE stream; "streams" is
-    # the round-3 experiment (the model then sweeps with the direct-tap kernels)
+    # the round-3 experiment (the model then sweeps with the warp kernel's scalar build, "warp_tiled" = 2)
     net.batch_streams = args.batch_mode == "streams"
     streams_mode = net.batch_streams and 2 <= NB <= net.MAX_BATCH_STREAMS
 
@@ -592,8 +592,8 @@ def run(args):
                        "voxels_per_step_per_gpu": NB * VOX, "parallelism": f"reference-view shard x{world}, no collective"},
             "timing": ("hipGraph replay of the step" if graph else "eager launches") +
                       (f"; the {NB} views of a step run on {NB} HIP streams: one view's vector-ALU-bound warp beside another's MFMA / "
-                       "memory-bound U-Net (MVSNet._hot_path_streams: eager, and with the DIRECT-TAP warp kernels -- the LDS-staged one is not "
-                       "reproducible next to another stream's conv kernels, DESIGN.md section 6), so a step is SHORTER than the sum of "
+                       "memory-bound U-Net (MVSNet._hot_path_streams: eager, and with the LDS-staged warp kernel's build WITHOUT packed fp32 instructions -- the "
+                       "default build is not reproducible next to another stream's conv kernels, DESIGN.md section 6), so a step is SHORTER than the sum of "
                        "its kernels' stand-alone durations below" if streams_mode else
                        f"; the {NB} views of a step share ONE launch per layer (batched grids, one stream)" if NB > 1 else "") +
                       f"; kernels_us / roofline: HIP events of an eager pass of the same {args.steps} steps, one view after the other on one "
