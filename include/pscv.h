@@ -80,13 +80,12 @@ int pscv_abi_version(void);
  *               planes per quad); 0: always the generic kernel.  "warp_lpv" != 0 also selects the generic kernel.
  *   "warp_lpv"  lanes sharing one voxel in the generic pscv_warp_cost kernel (1, 2 or 4 for C=32; 0 = default)
  *   "warp_ppd"  depth planes per workgroup in pscv_warp_cost (0 = default: 8 direct kernels, 32 LDS-staged kernel)
- *   "warp_tiled" 1 (default; -1 restores it): pscv_warp_cost stages the source patches of a reference tile in LDS as fp32
- *               where it applies (C = 32, 16-bit features, per-batch planes, PROJ geometry, 1-4 source views, variance /
+ *   "warp_tiled" 1 (default; -1 restores it; 2 = the same): pscv_warp_cost stages the source patches of a reference tile in LDS
+ *               as fp32 where it applies (C = 32, 16-bit features, per-batch planes, PROJ geometry, 1-4 source views, variance /
  *               softmin) -- same bits as the direct-gather kernels; 0: always the direct-gather kernels.  "warp_lpv" != 0
- *               also selects the direct kernel.  2: the same kernel compiled WITHOUT packed fp32 instructions (same stored bits, ~7 % slower).
- *               Set 2 (or 0) before launching the engine on SEVERAL STREAMS or from several PROCESSES on one GPU
- *               (the LDS-staged kernel returns wrong voxels while the engine's conv kernels run beside it
- *               on another stream / in another process; launches on one stream, one process per GPU, are unaffected).
+ *               also selects the direct kernel.  3: DIAGNOSTIC ONLY -- the same kernel compiled with packed fp32 instructions
+ *               (same stored bits, ~7 % faster alone), which returns wrong voxels while other kernels share its CUs
+ *               (scripts/ubench/lds_pk_overlap.hip); nothing in the engine selects it.
  *   "sweep_dc"  depth planes per workgroup of the depth-sweep convs (0 = default heuristic)
  *   "sweepc_slots" resident-workgroup target that sizes the depth chunks of the 8|16 -> 8 depth-sweep conv (0 = 768)
  *   "sweepc_pd" prefetch distance in iterations (1..3) of the same kernel (0 = 1)

@@ -24,13 +24,9 @@ def _init(rank, world, port):
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        # The ranks of these tests SHARE cuda:0.  The default (packed fp32) build of MVSNet's LDS-staged warp kernel returns wrong
-        # voxels while another process's / stream's conv kernels run on the same GPU (isolated at the end of round 3:
-        # scripts/dev/contention_repro.py, warp_vs_mfma_streams.py) -- this test failed one full-suite run in
-        # six through it.  Processes that share a GPU select the kernel's build without packed fp32 instructions (same stored
-        # bits, clean in 600 + 180 two- / three-process forwards), as pscv.h tells such callers to.
-        from wild_deep_mvs_amd import _lib as L
-        L.set_tuning("warp_tiled", 2)
+        # The ranks of these tests SHARE cuda:0 and run with DEFAULT tuning: every kernel of the engine is bit-stable next to another
+        # process's kernels (round 3 found the packed-fp32 build of the LDS-staged warp kernel was not -- DESIGN.md section 6 -- and
+        # round 4 made its scalar build the one the library launches).
 
 
 def _free_port():

@@ -219,3 +219,48 @@ def test_unchanged_caller_gets_graph_replay(env, architecture):
         assert not torch.equal(ref3["depth"], ref2["depth"])
         clone = copy.deepcopy(net)
         assert torch.equal(call(clone, scenes[2])["depth"], ref3["depth"])
+
+
+def test_in_forward_replay_is_gated_on_autograd_and_stops_thrashing(env):
+    """Round-3 advisor findings on graph.replayable: (b) an eval-mode call with autograd ENABLED must stay eager on every call
+    (it used to return detached clones from the second call on); (a) a signature the LRU evicted repeatedly (more alternating input
+    shapes than MAX_GRAPHS_PER_MODEL) stops being captured; the autocast state and the stream are part of the key."""
+    from wild_deep_mvs_amd import graph as G, synthetic
+    from wild_deep_mvs_amd.models.MVSNet.model import MVSNet
+    net = MVSNet("variance")
+    net.load_state_dict(synthetic.sharpened_state_dict("mvsnet", synthetic.template_of(net), seed=0))
+    net = net.cuda().eval()
+    net.num_depth = 16
+    mk = lambda h, w, s=0: {k: v.cuda() for k, v in synthetic.make_scene(1, 3, h, w, seed=s).items()}
+    call = lambda sc: net(sc["imgs"], sc["K"], sc["R"], sc["t"], sc["depth_min"], sc["depth_max"])
+    sc = mk(64, 96)
+    for _ in range(3):                                   # autograd on (the default outside no_grad): never captured
+        call(sc)
+    assert net not in G._REPLAY or not G._REPLAY[net]["graphs"]
+    with torch.no_grad():
+        ref = call(sc)
+        for _ in range(3):
+            assert torch.equal(call(sc)["depth"], ref["depth"])
+        state = G._REPLAY[net]
+        assert len(state["graphs"]) == 1
+        with torch.autocast("cuda", dtype=torch.float16):
+            call(sc)
+        assert len(state["seen"]) == 2, "the autocast state is part of the signature"
+        # five alternating shapes against MAX_GRAPHS_PER_MODEL = 3: after two evictions a signature stays eager
+        shapes = [(64, 96), (64, 128), (96, 96), (96, 128), (64, 160)]
+        scenes = [mk(h, w) for h, w in shapes]
+        want = []
+        net.graph_replay = False
+        for s in scenes:
+            want.append(call(s)["depth"].clone())
+        net.graph_replay = True
+        for rnd in range(8):
+            for s, wnt in zip(scenes, want):
+                assert torch.equal(call(s)["depth"], wnt)
+        assert len(state["graphs"]) <= G.MAX_GRAPHS_PER_MODEL
+        assert state["failed"], "thrashing signatures were parked on the eager path"
+        captures_before = dict(state["evicted"])
+        for rnd in range(3):
+            for s in scenes:
+                call(s)
+        assert state["evicted"] == captures_before, "no further capture / eviction churn once the thrashing signatures are parked"

@@ -307,3 +307,31 @@ def test_fused_pair_head_equals_head_plus_softargmin(env, shape, force, dtype):
     want_idx = (p * torch.arange(D, dtype=torch.float64).view(1, D, 1, 1)).sum(1)
     check_close(f"fused head entropy vs fp64 {shape}", ent.cpu(), want_ent.float(), max_abs=2e-5, rel_l2=5e-6)
     check_close(f"fused head index vs fp64 {shape}", idx.cpu(), want_idx.float(), max_abs=2e-4, rel_l2=2e-6)
+
+
+def test_frozen_uncert_net_keeps_the_gradient_path(env):
+    """Round-3 advisor finding: `UncertNet.forward` took its fused forward-only launch whenever the sub-module was in eval mode.
+    A frozen (`.eval()`) UncertNet inside a training step receives an entropy that requires grad (`SingleStage.forward_train`);
+    the fused launch returned a tensor without grad_fn and the gradient to the entropy / pair branch was dropped silently.
+    Now: fused launch only when nothing needs a gradient; both branches agree."""
+    L, ops, synthetic, Frontend, OV = env
+    from wild_deep_mvs_amd.models.VisMVSNet.model_cas import UncertNet
+    torch.manual_seed(0)
+    un = UncertNet(1).cuda().eval()
+    for bn in (un.conv1[1], un.conv2[1]):
+        bn.running_mean.normal_(0, 0.1); bn.running_var.uniform_(0.5, 1.5)
+    x = torch.rand(2, 1, 40, 56, device="cuda")
+    with torch.no_grad():
+        fused = un(x)[0]
+    assert fused.grad_fn is None
+    xg = x.clone().requires_grad_(True)
+    out = un(xg)[0]
+    assert out.requires_grad and out.grad_fn is not None, "eval-mode UncertNet fed an input that requires grad must stay differentiable"
+    out.sum().backward()
+    assert xg.grad is not None and float(xg.grad.abs().sum()) > 0
+    assert all(p.grad is not None for p in un.parameters())
+    check_close("fused launch vs differentiable branch", fused.cpu(), out.detach().cpu(), max_abs=2e-5 * max(1.0, float(out.abs().max())))
+    for p in un.parameters():
+        p.requires_grad_(False)
+    y = un(x)[0]                      # grad mode on, but nothing requires grad: the fused launch again
+    assert y.grad_fn is None and torch.equal(y, fused)

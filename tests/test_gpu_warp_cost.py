@@ -180,18 +180,18 @@ def test_tiled_kernel_equals_direct_kernel(env, baseline_scale, shape, V, D, cos
     dv = dvals[:, 0].contiguous().cuda()
     code = {"variance": L.COST_VARIANCE, "softmin": L.COST_SOFTMIN, "variance_cvp": L.COST_VARIANCE_CVP}[cost_name]
     outs = []
-    for tiled in (1, 0, 2):
+    for tiled in (1, 0, 3):
         L.set_tuning("warp_tiled", tiled)
         try:
             outs.append(ops.warp_cost(fcl[0], fcl[1:], cams, dv, cost=code, temp=0.7, out_dtype=torch.float16).float().cpu())
         finally:
             L.set_tuning("warp_tiled", -1)
-    # "warp_tiled" = 2: the LDS-staged kernel compiled without packed fp32 instructions (for launches that overlap other streams'
-    # conv kernels) stores the same bits as the default build
+    # "warp_tiled" = 3: the LDS-staged kernel compiled WITH packed fp32 instructions (the diagnostic build of the overlap defect,
+    # DESIGN.md section 6; launched alone here) stores the same bits as the default scalar build
     # (variance modes: bit for bit, their final expression is spelled out; soft-min: its exp / reciprocal chain may contract
     # differently without the packed forms -> the bound of the direct-kernel comparison below)
     if cost_name != "softmin":
-        assert torch.equal(outs[2], outs[0]), f"scalar build differs from the packed build on {int((outs[2] != outs[0]).sum())} values"
+        assert torch.equal(outs[2], outs[0]), f"packed build differs from the scalar build on {int((outs[2] != outs[0]).sum())} values"
     else:
         check_close(f"scalar vs packed build {cost_name}", outs[2], outs[0], max_abs=2 ** -10 * float(outs[0].abs().max()), rel_l2=2e-5)
     s = check_close(f"tiled vs direct {cost_name} baseline x{baseline_scale} {shape}", outs[0], outs[1],

@@ -50,15 +50,39 @@ _lock = threading.Lock()
 _lib = None
 
 
-def build(verbose: bool = False) -> str:
-    """Compile libpscv.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    cmd = ["make", "-C", CSRC, "-j4"]
+STAMP_PATH = os.path.join(CSRC, ".build_stamp")
+
+
+def source_hash() -> str:
+    """sha256 over every file the library is compiled from (csrc/*.hip|h|cpp, the Makefile, include/pscv.h)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".cpp")) or f == "Makefile")
+    for path in [os.path.join(CSRC, f) for f in files] + [os.path.join(os.path.dirname(_HERE), "include", "pscv.h")]:
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def build(verbose: bool = False, force: bool = False) -> str:
+    """Compile libpscv.so for gfx950 with hipcc (cross-compiles without a GPU).  File times do not survive a copy of the tree, so
+    the decision is by CONTENT: the sources' hash is stored next to the objects (csrc/.build_stamp); a library built from other
+    sources (or none) is rebuilt from scratch with `make -B`, otherwise `make` only links what is missing.  Prints which happened."""
+    want = source_hash()
+    have = open(STAMP_PATH).read().strip() if os.path.exists(STAMP_PATH) else ""
+    fresh = force or have != want or not os.path.exists(LIB_PATH)
+    cmd = ["make", "-C", CSRC, "-j8"] + (["-B"] if fresh else [])
     res = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or res.returncode != 0:
         print(res.stdout)
         print(res.stderr)
     if res.returncode != 0:
         raise RuntimeError("building libpscv.so failed")
+    with open(STAMP_PATH, "w") as fh:
+        fh.write(want + "\n")
+    print(f"[pscv build] {'full rebuild (make -B): sources changed or no stamp' if fresh else 'up to date: sources match the stamp of the built library'}"
+          f" [{want[:12]}]", flush=True)
     return LIB_PATH
 
 

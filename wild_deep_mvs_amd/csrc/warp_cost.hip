@@ -242,8 +242,8 @@ __global__ __launch_bounds__(256, 4) void warp_cost_kernel(const WarpArgs a) {
 // ---- host side ---------------------------------------------------------------------------------
 static Knob g_warp_lpv_override = {0, KNOB_WARP_LPV};  // 0 = default heuristic; set through pscv_set_tuning("warp_lpv", n)
 static Knob g_warp_ppd_override = {0, KNOB_WARP_PPD};
-static Knob g_warp_tiled = {1, KNOB_WARP_TILED};     // 1 (default): use the LDS-staged kernel (warp_cost_tiled.hip) where it applies: fp32 patches,
-                                 // full-rate fp32 blend; 129 us vs 166 us for the quad kernel inside the headline step, same bits
+static Knob g_warp_tiled = {1, KNOB_WARP_TILED};     // 1 (default; 2 = the same): the LDS-staged kernel (warp_cost_tiled.hip) where it applies: fp32
+                                 // patches, scalar fp32 blend, same bits as the direct kernels; 0: direct kernels; 3: its packed-fp32 build (diagnostic)
 extern Knob g_conv_small_tiles;   // conv3d.hip
 extern Knob g_sweep_th16;         // conv3d_sweep.hip
 extern Knob g_sweep_dc;
@@ -261,9 +261,9 @@ extern Knob g_s2s_slots;
 static Knob g_warp_q2 = {1, KNOB_WARP_Q2};        // 1: 32-channel 16-bit sweeps use the quad-mapped kernel (warp_cost_q2.hip)
 int warp_cost_q2_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, int out_dtype, int ppd_override, hipStream_t st);
 int warp_cost_tiled_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, int out_dtype, int ppd_override, hipStream_t st);
-// the same kernel compiled without packed fp32 instructions ("warp_tiled" = 2; warp_cost_tiled.hip, Makefile): for launches that
-// overlap other streams' / processes' conv kernels
-int warp_cost_tiled_nopk_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, int out_dtype, int ppd_override, hipStream_t st);
+// the same kernel compiled WITH packed fp32 instructions ("warp_tiled" = 3; warp_cost_tiled.hip, Makefile): diagnostic build of the
+// co-scheduling defect, not safe beside other kernels
+int warp_cost_tiled_pk_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, int out_dtype, int ppd_override, hipStream_t st);
 
 // Instantiated (geometry, cost) pairs: the variance / softmin statistics belong to the PROJ models (MVSNet,
 // CVP), group-wise correlation to the HOMOG model (Vis); the plain warp exists for both.
@@ -437,7 +437,7 @@ extern "C" int pscv_warp_cost(const void* ref, const void* const* srcs, int n_sr
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int rc;
     if (g_warp_tiled && g_warp_lpv_override == 0 && cost != PSCV_COST_VARIANCE_PARTIAL) {
-        rc = g_warp_tiled == 2 ? warp_cost_tiled_nopk_try(a, C, geom, cost, in_dtype, out_dtype, g_warp_ppd_override, st)
+        rc = g_warp_tiled == 3 ? warp_cost_tiled_pk_try(a, C, geom, cost, in_dtype, out_dtype, g_warp_ppd_override, st)
                                : warp_cost_tiled_try(a, C, geom, cost, in_dtype, out_dtype, g_warp_ppd_override, st);
         if (rc < 0) return rc;
         if (rc == 0) {

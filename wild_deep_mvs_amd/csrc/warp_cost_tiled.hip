@@ -40,15 +40,17 @@
 
 #include "warp_common.h"
 
-// WL_NOPK: the Makefile compiles this file a second time (warp_cost_tiled_nopk.o) WITHOUT packed fp32 instructions
-// (-target-feature -packed-fp32-ops) under other names; pscv_set_tuning("warp_tiled", 2) selects that build.  Reason (DESIGN.md
-// section 6): next to another stream's / process's LDS + MFMA conv waves the v_pk_*_f32 instructions of this kernel's blend -- fed
-// by ds_read_b128 results -- were seen to return stale halves in the lanes 48-63 of a wave; the scalar build is clean there
-// (0 of 400 overlapped launches against 150-390), ~7 % slower.  Same source, same fp32 operation chain, same stored bits.
-#ifdef WL_NOPK
-#define warp_cost_lds_kernel warp_cost_lds_nopk_kernel
-#define warp_cost_tiled_try warp_cost_tiled_nopk_try
-#define wl_prof wl_prof_nopk
+// Two builds of this file (Makefile).  The PRODUCT build (warp_cost_tiled.o) is compiled WITHOUT packed fp32 instructions
+// (-target-feature -packed-fp32-ops): next to another stream's / process's LDS + MFMA conv waves the v_pk_*_f32 instructions of the
+// blend were seen to leave stale values in lanes 48-63 of a wave (scripts/ubench/lds_pk_overlap.hip); the
+// scalar build is bit-stable there (0 of 400 overlapped launches against 150-390) and is what pscv_warp_cost launches.
+// WL_PK: the packed-fp32 build (warp_cost_tiled_pk.o), kept under other names as a DIAGNOSTIC for that defect only
+// (pscv_set_tuning("warp_tiled", 3); ~7 % faster alone, NOT safe beside other kernels).  Same source, same fp32 operation chain,
+// same stored bits.
+#ifdef WL_PK
+#define warp_cost_lds_kernel warp_cost_lds_pk_kernel
+#define warp_cost_tiled_try warp_cost_tiled_pk_try
+#define wl_prof wl_prof_pk
 #endif
 
 namespace pscv {
@@ -63,6 +65,8 @@ constexpr int WL_PG = WL_TH / 2;             // pixel groups (waves per plane pa
 constexpr int WL_ARENA = WL_TH == 8 ? 638 : 318;   // staged texels per block (all views): 80 / 40 KiB of fp32
 constexpr int WL_HI = WL_ARENA * 64;         // byte offset of the "hi" channel plane
 constexpr int WL_MAX_SRC = 4;                // source views of this kernel = lanes of a quad (others: quad kernel)
+constexpr int WL_STAGE_ROWS = 8;             // box rows one wave stages (one load batch)
+constexpr int WL_BOX_H = WL_STAGE_ROWS * (WL_THREADS / 64 / WL_MAX_SRC);   // tallest box the staging phase covers: 8 (4-row tile) / 16
 constexpr int WL_TABLE = 2 * WL_HI;          // per-view box records written by wave 0: 4 x {X0, Y0, X1, Y1, base, pitch, mode, -}
 constexpr int WL_LDS = WL_TABLE + WL_MAX_SRC * 32 + 32;
 static_assert(WL_LDS <= (WL_TH == 8 ? 81920 : 40960), "two / four blocks per CU");
@@ -524,7 +528,7 @@ __global__ __launch_bounds__(WL_THREADS, WL_MIN_WAVES) void warp_cost_lds_kernel
                     const int bw = cX1 - cX0 + 1, bh = cY1 - cY0 + 1;
                     pitch = (bw + 3) & ~3;   // a multiple of 4: the quads of a ds_read_b128 lane group stay conflict-free across rows
                     if (outside) mode = WL_ZERO;
-                    else if (bw <= 16 && bh <= 16 && used + pitch * bh <= WL_ARENA) mode = inside ? WL_FAST : WL_GEN;
+                    else if (bw <= 16 && bh <= WL_BOX_H && used + pitch * bh <= WL_ARENA) mode = inside ? WL_FAST : WL_GEN;
                 }
             }
             if (lane == 0) {
@@ -604,10 +608,10 @@ __global__ __launch_bounds__(WL_THREADS, WL_MIN_WAVES) void warp_cost_lds_kernel
         for (int t = 1; t < WL_MAX_SRC; ++t)
             if (k == t) srcp = a.src[t];
         if (mode == WL_FAST || mode == WL_GEN) {
-            const int bw = X1 - X0 + 1, bh = Y1 - Y0 + 1;      // both <= 16
+            const int bw = X1 - X0 + 1, bh = Y1 - Y0 + 1;      // bw <= 16, bh <= WL_BOX_H
             // eight row loads per wave, issued as one branch-free batch (clamped addresses; only the LDS writes are
             // predicated): a per-row `if` in front of each load costs a full memory round trip per row
-            constexpr int RU = 8;
+            constexpr int RU = WL_STAGE_ROWS;
             const int cl = min(lane, bw * 4 - 1);          // 16-byte chunk of a row
             const bool mine = lane < bw * 4;
             const TIn* col = reinterpret_cast<const TIn*>(srcp) + (((long)b * a.hs + Y0) * a.ws + X0) * C + cl * 8;
@@ -808,7 +812,7 @@ __global__ __launch_bounds__(WL_THREADS, WL_MIN_WAVES) void warp_cost_lds_kernel
 #undef WL_VIEW
 
         float o[8];
-#ifdef WL_NOPK
+#ifndef WL_PK
         // the packed build's rounding, spelled out (its compiler emits mul, mul, fma / mul, mul, fma for these two expressions)
         if (COST == PSCV_COST_VARIANCE) {
 #pragma unroll
@@ -917,7 +921,7 @@ int warp_cost_tiled_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, in
 
 }  // namespace pscv
 
-#ifndef WL_NOPK
+#ifndef WL_PK
 // occupancy the runtime computes for the f16 variance instantiation (development aid; scripts/dev/wl_occupancy.py)
 extern "C" int pscv_debug_wl_occupancy(int* blocks_per_cu, int* lds_bytes, int* threads) {
     auto kern = pscv::warp_cost_lds_kernel<pscv::f16_t, pscv::f16_t, PSCV_GEOM_PROJ, PSCV_COST_VARIANCE>;

@@ -215,43 +215,58 @@ def _requires_grad(x) -> bool:
     return False
 
 
+MAX_EVICTIONS_PER_SIGNATURE = 2     # a signature the LRU dropped this often stays eager (alternating > MAX_GRAPHS_PER_MODEL shapes)
+
+
 def replayable(forward):
-    """Decorator of a mirror's ``forward``: in eval mode, for CUDA inputs that carry no gradient, replay a hipGraph of the
-    forward from the second call of a signature on.  Falls through to the eager forward in train() mode, under an outer capture
-    (GraphedModel, bench.py), with ``taps=`` (a dict the caller wants filled), with CPU inputs, with a torch.distributed group
-    attached, when autograd is on and an input requires grad, and when ``self.graph_replay`` is False."""
+    """Decorator of a mirror's ``forward``: in eval mode, for CUDA inputs, WITH AUTOGRAD OFF (`torch.no_grad()` /
+    `inference_mode`, as the reference's eval loops run it -- depthmap_eval.py:100-106, evaluation/run_depthmaps.py:53-57), replay a
+    hipGraph of the forward from the second call of a signature on.  Falls through to the eager forward in train() mode, whenever
+    autograd is enabled (an eval-mode call under grad returns a graph-connected result on EVERY call, not only the first), under an
+    outer capture (GraphedModel, bench.py), with ``taps=`` (a dict the caller wants filled), with CPU inputs, with a
+    torch.distributed group attached, and when
+    ``self.graph_replay`` is False.  The key also holds the autocast state.  A signature evicted MAX_EVICTIONS_PER_SIGNATURE times
+    by the LRU (more alternating input shapes than MAX_GRAPHS_PER_MODEL, e.g. a mixed-resolution eval set) is not captured
+    again: a capture costs three forwards.  Eager fall-backs run OUTSIDE the model's replay lock."""
 
     @functools.wraps(forward)
     def wrapper(self, *args, **kwargs):
         if (self.training or not getattr(self, "graph_replay", True) or kwargs.get("taps") is not None
                 or not torch.cuda.is_available() or torch.cuda.is_current_stream_capturing()
-                or _has_cpu_tensor(args) or _has_cpu_tensor(kwargs)
-                or (torch.is_grad_enabled() and (_requires_grad(args) or _requires_grad(kwargs)))):
+                or torch.is_grad_enabled()
+                or _has_cpu_tensor(args) or _has_cpu_tensor(kwargs)):
             return forward(self, *args, **kwargs)
         state = _REPLAY.get(self)        # (kept outside the module: a lock and HIP graphs must not be deep-copied / pickled with it)
         if state is None:
-            state = _REPLAY[self] = {"lock": threading.Lock(), "seen": OrderedDict(), "graphs": OrderedDict(), "failed": set()}
+            state = _REPLAY[self] = {"lock": threading.Lock(), "seen": OrderedDict(), "graphs": OrderedDict(), "failed": set(),
+                                     "evicted": {}}
         okey = _options_key(self, state)
         if okey is None:
             return forward(self, *args, **kwargs)
         # + the tuning-knob generation and the upper-case switches of the model's own module (models.MVSNet.model.FUSED_TAIL)
         from . import _lib
         flags = tuple((k, v) for k, v in sys.modules[type(self).__module__].__dict__.items() if k.isupper() and isinstance(v, _SIMPLE))
-        key = (_sig(args), _sig(kwargs), okey, torch.cuda.current_device(), _lib.TUNING_GEN, flags)
+        autocast = (torch.is_autocast_enabled(), str(torch.get_autocast_gpu_dtype()) if torch.is_autocast_enabled() else "")
+        key = (_sig(args), _sig(kwargs), okey, torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream, _lib.TUNING_GEN,
+               flags, autocast)
+        eager = False
         with state["lock"]:
+            wkey = None
+            entry = None
             if key in state["failed"]:
-                return forward(self, *args, **kwargs)
-            wkey = _fast_weights_key(self, state)
-            entry = state["graphs"].get(key)
-            if entry is not None and entry[3] != wkey:                     # weights changed since the capture
-                del state["graphs"][key]
-                entry = None
-            if entry is None:
-                if key not in state["seen"]:                                # first sight of this signature: eager
+                eager = True
+            else:
+                wkey = _fast_weights_key(self, state)
+                entry = state["graphs"].get(key)
+                if entry is not None and entry[3] != wkey:                     # weights changed since the capture
+                    del state["graphs"][key]
+                    entry = None
+                if entry is None and key not in state["seen"]:                  # first sight of this signature: eager
                     state["seen"][key] = True
                     while len(state["seen"]) > 64:
                         state["seen"].popitem(last=False)
-                    return forward(self, *args, **kwargs)
+                    eager = True
+            if not eager and entry is None:
                 static_args, static_kwargs = _clone_static(args), _clone_static(kwargs)
                 try:
                     with torch.no_grad():
@@ -267,18 +282,24 @@ def replayable(forward):
                 except Exception:                                           # not capturable here: stay eager for this signature
                     state["failed"].add(key)
                     torch.cuda.synchronize()
-                    return forward(self, *args, **kwargs)
-                entry = (graph, (static_args, static_kwargs), static_out, wkey)
-                state["graphs"][key] = entry
-                while len(state["graphs"]) > MAX_GRAPHS_PER_MODEL:
-                    state["graphs"].popitem(last=False)
-            else:
+                    eager = True
+                else:
+                    entry = (graph, (static_args, static_kwargs), static_out, wkey)
+                    state["graphs"][key] = entry
+                    while len(state["graphs"]) > MAX_GRAPHS_PER_MODEL:
+                        old_key, _ = state["graphs"].popitem(last=False)
+                        n = state["evicted"][old_key] = state["evicted"].get(old_key, 0) + 1
+                        if n >= MAX_EVICTIONS_PER_SIGNATURE:
+                            state["failed"].add(old_key)                    # thrashing: this signature stays eager from now on
+            elif not eager:
                 state["graphs"].move_to_end(key)
-            graph, (static_args, static_kwargs), static_out, _ = entry
-            _copy_in(static_args, args)
-            _copy_in(static_kwargs, kwargs)
-            graph.replay()
-            return _clone_out(static_out)
+            if not eager:
+                graph, (static_args, static_kwargs), static_out, _ = entry
+                _copy_in(static_args, args)
+                _copy_in(static_kwargs, kwargs)
+                graph.replay()
+                return _clone_out(static_out)
+        return forward(self, *args, **kwargs)                                # eager fall-backs run without the lock
 
     wrapper.eager = forward
     return wrapper

@@ -421,20 +421,14 @@ class MVSNet(ReplayHooks, nn.Module):
         main = torch.cuda.current_stream(dev)
         depth_values = depth_values.to(torch.float32)
         outs = []
-        # one item's warp overlaps another item's conv kernels here: the LDS-staged warp kernel is NOT reproducible under that
-        # overlap (39 of 40 three-view steps differed from the sequential forward, up to 8e-2 of the depth
-        # range); its build without packed fp32 instructions ("warp_tiled" = 2, same stored bits, ~7 % slower) is -> this thread's
-        # launches use that build for the duration of the fork
-        L.set_tuning_thread("warp_tiled", 2, True)
-        try:
-            for b in range(B):
-                st = streams[b]
-                st.wait_stream(main)
-                with torch.cuda.stream(st):
-                    fb = [f[b:b + 1] for f in features_cl]                      # contiguous views of one batch item
-                    outs.append(self.hot_path(fb, proj[b:b + 1], depth_values[b:b + 1].contiguous(), reference_frame))   # (B = 1: the plain path)
-        finally:
-            L.set_tuning_thread("warp_tiled", 2, False)
+        # one item's warp overlaps another item's conv kernels here; every kernel of the engine is bit-stable under that overlap
+        # (tests/test_gpu_overlap.py; the LDS-staged warp kernel ships as its scalar-fp32 build for this reason)
+        for b in range(B):
+            st = streams[b]
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                fb = [f[b:b + 1] for f in features_cl]                      # contiguous views of one batch item
+                outs.append(self.hot_path(fb, proj[b:b + 1], depth_values[b:b + 1].contiguous(), reference_frame))   # (B = 1: the plain path)
         for st in streams[:B]:
             main.wait_stream(st)
         return torch.cat([o[0] for o in outs], 0), torch.cat([o[1] for o in outs], 0)

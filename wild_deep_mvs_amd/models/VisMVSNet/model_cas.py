@@ -282,8 +282,11 @@ class UncertNet(nn.Module):
         return self._prm
 
     def forward(self, x):
-        if not self.training and x.is_cuda and x.dtype == torch.float32 and len(self.head_convs) == 1:
-            # eval hot path: the three convolutions, two BatchNorms and the residual add in ONE launch (csrc/uncert_net.hip)
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if not self.training and not needs_grad and x.is_cuda and x.dtype == torch.float32 and len(self.head_convs) == 1:
+            # eval hot path: the three convolutions, two BatchNorms and the residual add in ONE launch (csrc/uncert_net.hip).
+            # Forward-only: a frozen (.eval()) UncertNet inside a training step -- SingleStage.forward_train feeds it an entropy
+            # that requires grad -- takes the differentiable branch below, or the gradient to the entropy / pair branch is lost.
             n, _, h, w = x.shape
             return [ops.uncert_net(x.reshape(n, h, w).contiguous(), self.engine_params()).view(n, 1, h, w)]
         out = self.conv2(self.conv1(x))

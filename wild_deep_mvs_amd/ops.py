@@ -815,7 +815,16 @@ def softargmin(logits: torch.Tensor, depth: Optional[torch.Tensor] = None, *, wa
     return {k: v for k, v in o.items() if v is not None}
 
 
-_tail_ws: dict = {}
+_tail_ws: dict = {}       # (device, stream) -> fp32 scratch: launches on different streams must not share partial-sum buffers
+
+
+def _tail_workspace(device, n: int) -> torch.Tensor:
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _tail_ws.get(key)
+    if ws is None or ws.numel() < n:
+        ws = torch.empty(n, dtype=torch.float32, device=device)
+        _tail_ws[key] = ws
+    return ws
 
 
 def prob_softargmin(x: torch.Tensor, layer: "Conv3dLayer", depth: torch.Tensor, *, in_coff: int = 0, want_conf: bool = True):
@@ -830,10 +839,7 @@ def prob_softargmin(x: torch.Tensor, layer: "Conv3dLayer", depth: torch.Tensor, 
     if tuple(depth.shape) != (B, D) or D < 18:
         return None
     n = int(L.lib().pscv_prob_softargmin_workspace(B, D, H, W))
-    ws = _tail_ws.get(x.device)
-    if ws is None or ws.numel() < n:
-        ws = torch.empty(n, dtype=torch.float32, device=x.device)
-        _tail_ws[x.device] = ws
+    ws = _tail_workspace(x.device, n)
     logits = torch.empty((B, D, H, W), dtype=torch.float32, device=x.device)
     o_depth = torch.empty((B, H, W), dtype=torch.float32, device=x.device)
     o_conf = torch.empty((B, H, W), dtype=torch.float32, device=x.device) if want_conf else None
@@ -862,10 +868,7 @@ def head_index_entropy(x: torch.Tensor, layer: "Conv3dLayer", index: torch.Tenso
         if t_.dtype != torch.float32 or tuple(t_.shape) != (B, H, W) or not t_.is_contiguous():
             raise ValueError("pscv.head_index_entropy: index / entropy must be contiguous fp32 [B,h,w] tensors")
     n = int(L.lib().pscv_prob_softargmin_workspace(B, D, H, W))
-    ws = _tail_ws.get(x.device)
-    if ws is None or ws.numel() < n:
-        ws = torch.empty(n, dtype=torch.float32, device=x.device)
-        _tail_ws[x.device] = ws
+    ws = _tail_workspace(x.device, n)
     scores = torch.empty((B, D, H, W), dtype=torch.float32, device=x.device) if want_scores else None
     rc = _launch("head_index_entropy", lambda: L.lib().pscv_head_index_entropy(
         _p(x), _dt(x), cs, 0, _p(layer.packed), _p(layer.scale), _p(layer.bias), _p(layer.floor), layer.c_in, layer.epi,
@@ -1062,11 +1065,13 @@ _train_ws = {}
 
 
 def _workspace(device, nfloats: int) -> torch.Tensor:
-    """Per-device fp32 scratch for the two-phase reductions, grown on demand (stream-ordered reuse)."""
-    ws = _train_ws.get(device)
+    """fp32 scratch for the two-phase reductions, one per (device, stream), grown on demand: reuse is ordered by the stream, and
+    launches on different streams (round-3 advisor finding: the batch stream mode) never share a partial-sum buffer."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _train_ws.get(key)
     if ws is None or ws.numel() < nfloats:
         ws = torch.empty(max(int(nfloats), int(L.lib().pscv_train_workspace_floats())), dtype=torch.float32, device=device)
-        _train_ws[device] = ws
+        _train_ws[key] = ws
     return ws
 
 
