@@ -155,6 +155,15 @@ template <int PK> static long run(const char* tag, int launches, int rounds, boo
     return bad_launches;
 }
 
+// the victim as a library entry (scripts/dev/pk_probe.py launches it beside the engine's real conv0 through tests/test_gpu_overlap.py's harness):
+//   hipcc --offload-arch=gfx950 -O3 -shared -fPIC -o liblpo.so lds_pk_overlap.hip
+extern "C" int lpo_victim(float* out, int rounds, int pk, void* stream) {
+    if (pk) victim<1><<<NWG, WG, LDS_FLOATS * 4, (hipStream_t)stream>>>(out, rounds);
+    else victim<0><<<NWG, WG, LDS_FLOATS * 4, (hipStream_t)stream>>>(out, rounds);
+    return (int)hipGetLastError();
+}
+extern "C" long lpo_out_floats(void) { return (long)NWG * WG * 16; }
+
 int main(int argc, char** argv) {
     const int launches = argc > 1 ? atoi(argv[1]) : 200, rounds = argc > 2 ? atoi(argv[2]) : 96;
     run<1>("packed", launches, rounds, false);

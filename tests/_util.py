@@ -16,6 +16,11 @@ def t(a):
     return torch.from_numpy(np.ascontiguousarray(a))
 
 
+def golden_rig(g) -> str:
+    """Camera rig a golden file was generated with (`synthetic.make_cameras(rig=...)`; files older than round 4: "probe")."""
+    return str(g["rig"]) if "rig" in g else "probe"
+
+
 def bf16_round(x: torch.Tensor) -> torch.Tensor:
     """fp32 tensor with values rounded to bf16 (what the engine stores)."""
     return x.to(torch.bfloat16).to(torch.float32)

@@ -60,7 +60,7 @@ def save(name, **arrays):
 
 
 # --------------------------------------------------------------------------
-def gen_mvsnet(aggregation: str, tag: str, *, H=64, W=96, V=3, D=16, seed=0, behind_view=-1, scene_seed=0):
+def gen_mvsnet(aggregation: str, tag: str, *, H=64, W=96, V=3, D=16, seed=0, behind_view=-1, scene_seed=0, rig="probe"):
     sys.path.insert(0, REPO)
     from wild_deep_mvs_amd import synthetic
     from models.MVSNet.model import MVSNet  # reference
@@ -72,7 +72,7 @@ def gen_mvsnet(aggregation: str, tag: str, *, H=64, W=96, V=3, D=16, seed=0, beh
     sd = synthetic.sharpened_state_dict("mvsnet", synthetic.template_of(net), seed=seed)
     net.load_state_dict(sd, strict=True)
     net.eval()
-    scene = synthetic.make_scene(1, V, H, W, seed=scene_seed, behind_view=behind_view)
+    scene = synthetic.make_scene(1, V, H, W, seed=scene_seed, behind_view=behind_view, rig=rig)
 
     with torch.no_grad():
         out = net(scene["imgs"], scene["K"], scene["R"], scene["t"], scene["depth_min"], scene["depth_max"])
@@ -110,7 +110,7 @@ def gen_mvsnet(aggregation: str, tag: str, *, H=64, W=96, V=3, D=16, seed=0, beh
     print(f"[{tag}] max prob mean {prob.max(1)[0].mean():.3f}, logit std over D {logits.squeeze(1).std(1).mean():.3f}, "
           f"cost abs mean {cost.abs().mean():.4f}, depth range {out['depth'].min():.3f}..{out['depth'].max():.3f}")
     save(f"{tag}.npz",
-         meta=np.array([H, W, V, D, seed, scene_seed, behind_view], dtype=np.int64),
+         meta=np.array([H, W, V, D, seed, scene_seed, behind_view], dtype=np.int64), rig=np.array(rig),
          features=np.stack([np32(f) for f in feats]),
          proj=np32(proj), depth_values=np32(depth_values),
          warped_planes=np.array(PLANES, dtype=np.int64),
@@ -547,6 +547,8 @@ def main():
         "mvsnet": lambda: gen_mvsnet("variance", "mvsnet_tiny"),
         "mvsnet_behind": lambda: gen_mvsnet("variance", "mvsnet_behind", V=4, behind_view=2, scene_seed=5),
         "mvsnet_s": lambda: gen_mvsnet("softmin", "mvsnet_s_tiny", seed=1),
+        # the DTU-like rig (synthetic.make_cameras(rig="dtu"): depth 425..905, cameras on an arc, tilted epipolar lines), 5 views
+        "mvsnet_dtu": lambda: gen_mvsnet("variance", "mvsnet_dtu_tiny", V=5, scene_seed=2, rig="dtu"),
         "mvsnet_cfg1": gen_mvsnet_cfg1,
         "mvsnet_train": lambda: gen_mvsnet_train("variance", "mvsnet_train"),
         "mvsnet_s_train": lambda: gen_mvsnet_train("softmin", "mvsnet_s_train", seed=1),

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from _util import bf16_round, check_close, load_golden, t
+from _util import bf16_round, check_close, golden_rig, load_golden, t
 
 pytestmark = pytest.mark.gpu
 
@@ -88,7 +88,7 @@ def test_feature_net_engine_vs_reference_features(env, dtype):
 @pytest.mark.parametrize("feature_engine", ["pscv", "torch"])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("fname,agg", [("mvsnet_tiny.npz", "variance"), ("mvsnet_behind.npz", "variance"),
-                                        ("mvsnet_s_tiny.npz", "softmin")])
+                                        ("mvsnet_dtu_tiny.npz", "variance"), ("mvsnet_s_tiny.npz", "softmin")])
 def test_forward_depth_parity_with_reference(env, fname, agg, dtype, feature_engine):
     """forward(imgs, K, R, t, depth_min, depth_max) -> depth within 1e-3 relative L1 of the reference's
     fp32 PyTorch path (BASELINE.json north_star) with fp16 storage / fp32 accumulation (see DEPTH_TOL for bf16),
@@ -99,7 +99,7 @@ def test_forward_depth_parity_with_reference(env, fname, agg, dtype, feature_eng
     net, sd = _model(env, agg, seed, dtype)
     net.feature_engine = feature_engine
     net.num_depth = D
-    scene = synthetic.make_scene(1, V, H, W, seed=scene_seed, behind_view=behind)
+    scene = synthetic.make_scene(1, V, H, W, seed=scene_seed, behind_view=behind, rig=golden_rig(g))
     dev = {k: v.cuda() for k, v in scene.items()}
     taps = {}
     out = net(dev["imgs"], dev["K"], dev["R"], dev["t"], dev["depth_min"], dev["depth_max"], taps=taps)

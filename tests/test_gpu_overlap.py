@@ -141,20 +141,20 @@ def test_groupcorr_homog_warp_is_bit_stable_beside_conv0(env, soak):
 
 # (name, c_in, c_out, kind, input D,H,W, with skip, tuning) -- one entry per conv3d kernel of csrc/
 CONV3D_CASES = [
-    ("sweep8 32->8", 32, 8, "S1", (96, 128, 160), False, {}),
-    ("sweep8_kdm 32->8", 32, 8, "S1", (96, 128, 160), False, {"sweep_kdm": 1}),
-    ("sweep_s2 8->16", 8, 16, "S2", (192, 128, 160), False, {}),
-    ("sweep_s2 8->32 (Vis block + shortcut)", 8, 32, "S2", (64, 256, 320), False, {}),
-    ("brick S1 16->16", 16, 16, "S1", (96, 64, 80), False, {}),
-    ("brick S2 16->32", 16, 32, "S2", (96, 64, 80), False, {}),
-    ("brick S1 32->32", 32, 32, "S1", (96, 64, 80), False, {}),
-    ("brick S2 32->64", 32, 64, "S2", (96, 64, 80), False, {}),
+    ("sweep8 32->8", 32, 8, "S1", (192, 128, 160), False, {}),
+    ("sweep8_kdm 32->8", 32, 8, "S1", (192, 128, 160), False, {"sweep_kdm": 1}),
+    ("sweep_s2 8->16", 8, 16, "S2", (192, 256, 320), False, {}),
+    ("sweep_s2 8->32 (Vis block + shortcut)", 8, 32, "S2", (128, 256, 320), False, {}),
+    ("brick S1 16->16", 16, 16, "S1", (192, 128, 160), False, {}),
+    ("brick S2 16->32", 16, 32, "S2", (192, 128, 160), False, {}),
+    ("brick S1 32->32", 32, 32, "S1", (128, 64, 80), False, {}),
+    ("brick S2 32->64", 32, 64, "S2", (192, 64, 80), False, {}),
     ("brick S1 64->64", 64, 64, "S1", (48, 64, 80), False, {}),
-    ("brick T2 64->32", 64, 32, "T2", (24, 32, 40), True, {}),
-    ("brick T2 32->16", 32, 16, "T2", (48, 32, 40), True, {}),
-    ("t2p8 16->8", 16, 8, "T2", (96, 64, 80), True, {}),
-    ("c1_sweep 8->1", 8, 1, "S1", (192, 128, 160), False, {}),
-    ("c1 8->1", 8, 1, "S1", (192, 128, 160), False, {"c1_sweep": 0}),
+    ("brick T2 64->32", 64, 32, "T2", (48, 48, 40), True, {}),
+    ("brick T2 32->16", 32, 16, "T2", (96, 64, 40), True, {}),
+    ("t2p8 16->8", 16, 8, "T2", (96, 128, 160), True, {}),
+    ("c1_sweep 8->1", 8, 1, "S1", (192, 256, 160), False, {}),
+    ("c1 8->1", 8, 1, "S1", (192, 256, 160), False, {"c1_sweep": 0}),
     ("sweepc 8->8", 8, 8, "S1", (64, 256, 320), True, {}),
     ("sweepc 16->8", 16, 8, "S1", (64, 256, 320), False, {}),
 ]
@@ -199,8 +199,8 @@ def test_block8_and_cat2_sweeps_are_bit_stable_beside_conv0(env, soak):
     assert bad == 0
 
 
-CONV2D_CASES = [("k3 s1 8->8", 8, 8, 3, 1, (5, 512, 640)), ("k5 s2 8->16", 8, 16, 5, 2, (5, 512, 640)), ("k3 s1 32->32", 32, 32, 3, 1, (5, 128, 160)),
-                ("wlds k3 s1 64->64", 64, 64, 3, 1, (1, 1024, 1280)), ("k1 s1 32->32", 32, 32, 1, 1, (5, 256, 320))]
+CONV2D_CASES = [("k3 s1 8->8", 8, 8, 3, 1, (15, 512, 640)), ("k5 s2 8->16", 8, 16, 5, 2, (20, 512, 640)), ("k3 s1 32->32", 32, 32, 3, 1, (20, 128, 160)),
+                ("wlds k3 s1 64->64", 64, 64, 3, 1, (1, 1024, 1280))]
 
 
 @pytest.mark.parametrize("name,cin,cout,ks,stride,bhw", CONV2D_CASES, ids=[c[0].replace(" ", "_").replace("->", "to") for c in CONV2D_CASES])
@@ -243,7 +243,8 @@ def test_backward_kernels_are_stable_beside_conv0(env, soak):
     p = (torch.randn(1, 96, 128, 160, 8, generator=g) * 0.5).to(torch.float16).cuda()
     q = (torch.randn(1, 96, 128, 160, 32, generator=g) * 0.5).to(torch.float16).cuda()
     assert soak.run("conv3d_wgrad 8x32", lambda: ops.conv3d_wgrad(p, q, ca=8, cb=32, stride=1))[0] == 0
-    assert soak.run("bn_stats", lambda: ops.bn_stats(q))[0] == 0
+    q2 = q.repeat(2, 1, 1, 1, 1)
+    assert soak.run("bn_stats", lambda: ops.bn_stats(q2))[0] == 0
     fcl, cams, dv = _warp_inputs(ops, synthetic, 5, 32, 128, 160, 48, torch.float16)
     go = (torch.randn(1, 48, 128, 160, 32, generator=g) * 0.1).to(torch.float16).cuda()
 

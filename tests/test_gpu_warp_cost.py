@@ -22,7 +22,7 @@ def _cl(x, dtype):
     return ops.to_channels_last(x.cuda(), dtype)
 
 
-@pytest.mark.parametrize("fname", ["mvsnet_tiny.npz", "mvsnet_behind.npz"])
+@pytest.mark.parametrize("fname", ["mvsnet_tiny.npz", "mvsnet_behind.npz", "mvsnet_dtu_tiny.npz"])
 def test_warp_only_fp32_matches_reference_golden(env, fname):
     L, ops, O = env
     g = load_golden(fname)
@@ -59,7 +59,7 @@ def test_homo_warping_function_api(env):
 
 
 @pytest.mark.parametrize("fname,agg", [("mvsnet_tiny.npz", "variance"), ("mvsnet_behind.npz", "variance"),
-                                        ("mvsnet_s_tiny.npz", "softmin")])
+                                        ("mvsnet_dtu_tiny.npz", "variance"), ("mvsnet_s_tiny.npz", "softmin")])
 def test_cost_volume_fp32_matches_reference_golden(env, fname, agg):
     L, ops, O = env
     g = load_golden(fname)
@@ -180,20 +180,14 @@ def test_tiled_kernel_equals_direct_kernel(env, baseline_scale, shape, V, D, cos
     dv = dvals[:, 0].contiguous().cuda()
     code = {"variance": L.COST_VARIANCE, "softmin": L.COST_SOFTMIN, "variance_cvp": L.COST_VARIANCE_CVP}[cost_name]
     outs = []
-    for tiled in (1, 0, 3):
+    for tiled in (1, 0):
         L.set_tuning("warp_tiled", tiled)
         try:
             outs.append(ops.warp_cost(fcl[0], fcl[1:], cams, dv, cost=code, temp=0.7, out_dtype=torch.float16).float().cpu())
         finally:
             L.set_tuning("warp_tiled", -1)
-    # "warp_tiled" = 3: the LDS-staged kernel compiled WITH packed fp32 instructions (the diagnostic build of the overlap defect,
-    # DESIGN.md section 6; launched alone here) stores the same bits as the default scalar build
-    # (variance modes: bit for bit, their final expression is spelled out; soft-min: its exp / reciprocal chain may contract
-    # differently without the packed forms -> the bound of the direct-kernel comparison below)
-    if cost_name != "softmin":
-        assert torch.equal(outs[2], outs[0]), f"packed build differs from the scalar build on {int((outs[2] != outs[0]).sum())} values"
-    else:
-        check_close(f"scalar vs packed build {cost_name}", outs[2], outs[0], max_abs=2 ** -10 * float(outs[0].abs().max()), rel_l2=2e-5)
+    # (the packed-fp32 build of the LDS-staged kernel, "warp_tiled" = 3, is a diagnostic of the defect of DESIGN.md section 6 and not
+    #  part of any correctness test: tests/test_gpu_overlap.py reports what it does)
     s = check_close(f"tiled vs direct {cost_name} baseline x{baseline_scale} {shape}", outs[0], outs[1],
                     max_abs=2 ** -10 * float(outs[1].abs().max()), rel_l2=2e-5)
     assert float(outs[1].abs().max()) > 0

@@ -25,7 +25,7 @@ def _mvsnet_template(aggregation):
     return synthetic.template_of(MVSNet(aggregation))
 
 
-CASES = [("mvsnet_tiny.npz", "variance"), ("mvsnet_behind.npz", "variance"), ("mvsnet_s_tiny.npz", "softmin")]
+CASES = [("mvsnet_tiny.npz", "variance"), ("mvsnet_behind.npz", "variance"), ("mvsnet_dtu_tiny.npz", "variance"), ("mvsnet_s_tiny.npz", "softmin")]
 
 
 @pytest.mark.parametrize("fname,agg", CASES)
@@ -33,7 +33,7 @@ def test_mvsnet_stage_boundaries(golden_dir, fname, agg):
     g = _load(golden_dir, fname)
     H, W, V, D, seed, scene_seed, behind = [int(x) for x in g["meta"]]
     sd = synthetic.sharpened_state_dict("mvsnet", _mvsnet_template(agg), seed=seed)
-    scene = synthetic.make_scene(1, V, H, W, seed=scene_seed, behind_view=behind)
+    scene = synthetic.make_scene(1, V, H, W, seed=scene_seed, behind_view=behind, rig=str(g["rig"]) if "rig" in g else "probe")
 
     taps = {}
     with torch.no_grad():
@@ -60,7 +60,7 @@ def test_mvsnet_stage_boundaries(golden_dir, fname, agg):
         assert np.abs(g["warped"][behind - 1]).max() == 0.0
 
 
-@pytest.mark.parametrize("fname,agg", CASES[:2])
+@pytest.mark.parametrize("fname,agg", CASES[:3])
 def test_homo_warping_against_reference(golden_dir, fname, agg):
     g = _load(golden_dir, fname)
     feats, proj, dv = _t(g["features"]), _t(g["proj"]), _t(g["depth_values"])[:, 0]

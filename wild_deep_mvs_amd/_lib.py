@@ -12,7 +12,7 @@ import subprocess
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpscv.so")
+LIB_PATH = os.environ.get("PSCV_LIB") or os.path.join(_HERE, "libpscv.so")     # (PSCV_LIB: A/B builds of scripts/dev)
 CSRC = os.path.join(_HERE, "csrc")
 
 # mirror of include/pscv.h

@@ -112,7 +112,8 @@ template <bool MAX> __device__ __forceinline__ float wl_wave_reduce(float x) {
 }
 
 // eight fp32 channels x four taps -> eight blended channels; t = {00lo, 00hi, 01lo, 01hi, 10lo, 10hi, 11lo, 11hi}
-__device__ __forceinline__ void wl_blend8(const float4 (&t)[8], const float (&w)[4], float (&o)[8]) {
+typedef float wl_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void wl_blend8(const wl_f4 (&t)[8], const float (&w)[4], float (&o)[8]) {
     o[0] = t[0].x * w[0]; o[1] = t[0].y * w[0]; o[2] = t[0].z * w[0]; o[3] = t[0].w * w[0];
     o[4] = t[1].x * w[0]; o[5] = t[1].y * w[0]; o[6] = t[1].z * w[0]; o[7] = t[1].w * w[0];
 #pragma unroll
@@ -122,6 +123,35 @@ __device__ __forceinline__ void wl_blend8(const float4 (&t)[8], const float (&w)
         o[4] = fmaf(t[2 * k + 1].x, w[k], o[4]); o[5] = fmaf(t[2 * k + 1].y, w[k], o[5]);
         o[6] = fmaf(t[2 * k + 1].z, w[k], o[6]); o[7] = fmaf(t[2 * k + 1].w, w[k], o[7]);
     }
+}
+
+// Diagnostic variants of the packed build (built by scripts/dev/pk_variants.sh, never part of libpscv.so):
+//   WL_FIX_NOP  full lgkmcnt wait + 16 idle cycles between the tap reads and the packed blend
+//   WL_FIX_MOV  every tap register passes through a (non-packed) v_mov_b32 before its packed consumer
+//   WL_FIX_B64  the tap pieces are read as two ds_read_b64 instead of one ds_read_b128
+__device__ __forceinline__ void wl_fix(wl_f4 (&t)[8]) {
+#if defined(WL_FIX_NOP) || defined(WL_FIX_B64)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]));
+#endif
+#ifdef WL_FIX_NOP
+    asm volatile("s_nop 7\n s_nop 7" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]));
+#endif
+#ifdef WL_FIX_MOV
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        asm volatile("v_mov_b32 %0, %0\n v_mov_b32 %1, %1\n v_mov_b32 %2, %2\n v_mov_b32 %3, %3" : "+v"(t[k].x), "+v"(t[k].y), "+v"(t[k].z), "+v"(t[k].w));
+#endif
+}
+__device__ __forceinline__ wl_f4 wl_tap(const unsigned char* lsm, unsigned off) {
+#ifdef WL_FIX_B64
+    const unsigned a = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)lsm + off;
+    wl_f2 lo, hi;
+    asm volatile("ds_read_b64 %0, %1" : "=v"(lo) : "v"(a));
+    asm volatile("ds_read_b64 %0, %1 offset:8" : "=v"(hi) : "v"(a));
+    return wl_f4{lo.x, lo.y, hi.x, hi.y};
+#else
+    return *reinterpret_cast<const wl_f4*>(lsm + off);
+#endif
 }
 
 // fp16 stores saturate at +-65504 like every other kernel of the engine (pscv_common.h), but through the MODE.FP16_OVFL bit the
@@ -214,7 +244,6 @@ __device__ __forceinline__ WlC wl_coords(const WlLane& L, float dval, const Warp
 // fences and the wait; the compiler's own waitcnt pass does not see these requests, so wl_wait_taps() is what orders their use:
 // LDS returns data in order, hence "at most N requests outstanding" = everything older than the youngest N has arrived, and the
 // awaited registers pass THROUGH the wait statement so that no consumer can be scheduled above it.
-typedef float wl_f4 __attribute__((ext_vector_type(4)));
 template <int OFF> __device__ __forceinline__ wl_f4 wl_ds_read16(unsigned addr) {
     wl_f4 v;
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
@@ -742,40 +771,46 @@ __global__ __launch_bounds__(WL_THREADS, WL_MIN_WAVES) void warp_cost_lds_kernel
             }
         }
 
+#if defined(WL_FIX_NOP) || defined(WL_FIX_MOV) || defined(WL_FIX_B64)
+#define WL_FIX(t) wl_fix(t);
+#else
+#define WL_FIX(t)
+#endif
 #define WL_VIEW(K, CTRL)                                                                                                  \
         if (K < n_src && (bMode[K] != WL_ZERO || !VAR)) {                                                                  \
             float wv[8];                                                                                                   \
             if (bMode[K] == WL_ZERO) {                                                                                     \
                 _Pragma("unroll") for (int j = 0; j < 8; ++j) wv[j] = 0.0f;                                                \
             } else {                                                                                                       \
-                float4 t[8];                                                                                               \
+                wl_f4 t[8];                                                                                                \
                 float w[4];                                                                                                \
                 if (bMode[K] != WL_DIRECT) {                                                                               \
                     w[0] = wl_dpp_f<CTRL>(w00); w[1] = wl_dpp_f<CTRL>(w01); w[2] = wl_dpp_f<CTRL>(w10); w[3] = wl_dpp_f<CTRL>(w11); \
                     const unsigned a00 = (unsigned)wl_dpp_i<CTRL>(E) + chb;                                               \
                     if (bMode[K] == WL_FAST) {                                                                             \
                         const unsigned a10 = a00 + ((unsigned)bPitch[K] << 6);                                            \
-                        t[0] = *reinterpret_cast<const float4*>(lsm + a00);                                               \
-                        t[1] = *reinterpret_cast<const float4*>(lsm + a00 + WL_HI);                                       \
-                        t[2] = *reinterpret_cast<const float4*>(lsm + a00 + 64);                                          \
-                        t[3] = *reinterpret_cast<const float4*>(lsm + a00 + 64 + WL_HI);                                  \
-                        t[4] = *reinterpret_cast<const float4*>(lsm + a10);                                               \
-                        t[5] = *reinterpret_cast<const float4*>(lsm + a10 + WL_HI);                                       \
-                        t[6] = *reinterpret_cast<const float4*>(lsm + a10 + 64);                                          \
-                        t[7] = *reinterpret_cast<const float4*>(lsm + a10 + 64 + WL_HI);                                  \
+                        t[0] = wl_tap(lsm, a00);                                               \
+                        t[1] = wl_tap(lsm, a00 + WL_HI);                                       \
+                        t[2] = wl_tap(lsm, a00 + 64);                                          \
+                        t[3] = wl_tap(lsm, a00 + 64 + WL_HI);                                  \
+                        t[4] = wl_tap(lsm, a10);                                               \
+                        t[5] = wl_tap(lsm, a10 + WL_HI);                                       \
+                        t[6] = wl_tap(lsm, a10 + 64);                                          \
+                        t[7] = wl_tap(lsm, a10 + 64 + WL_HI);                                  \
                     } else {                                                                                               \
                         const unsigned a01 = a00 + (unsigned)wl_dpp_i<CTRL>(DX);                                          \
                         const unsigned a10 = a00 + (unsigned)wl_dpp_i<CTRL>(DY);                                          \
                         const unsigned a11 = a10 + (a01 - a00);                                                            \
-                        t[0] = *reinterpret_cast<const float4*>(lsm + a00);                                               \
-                        t[1] = *reinterpret_cast<const float4*>(lsm + a00 + WL_HI);                                       \
-                        t[2] = *reinterpret_cast<const float4*>(lsm + a01);                                               \
-                        t[3] = *reinterpret_cast<const float4*>(lsm + a01 + WL_HI);                                       \
-                        t[4] = *reinterpret_cast<const float4*>(lsm + a10);                                               \
-                        t[5] = *reinterpret_cast<const float4*>(lsm + a10 + WL_HI);                                       \
-                        t[6] = *reinterpret_cast<const float4*>(lsm + a11);                                               \
-                        t[7] = *reinterpret_cast<const float4*>(lsm + a11 + WL_HI);                                       \
+                        t[0] = wl_tap(lsm, a00);                                               \
+                        t[1] = wl_tap(lsm, a00 + WL_HI);                                       \
+                        t[2] = wl_tap(lsm, a01);                                               \
+                        t[3] = wl_tap(lsm, a01 + WL_HI);                                       \
+                        t[4] = wl_tap(lsm, a10);                                               \
+                        t[5] = wl_tap(lsm, a10 + WL_HI);                                       \
+                        t[6] = wl_tap(lsm, a11);                                               \
+                        t[7] = wl_tap(lsm, a11 + WL_HI);                                       \
                     }                                                                                                      \
+                    WL_FIX(t)                                                                                              \
                 } else {                                                                                                   \
                     /* general path, direct global taps: behind-camera test, grid clamp, zero padding  module.py:146-166 */ \
                     const float* cam = a.cams + ((long)K * a.B + b) * PSCV_CAM_FLOATS;                                    \
@@ -797,8 +832,8 @@ __global__ __launch_bounds__(WL_THREADS, WL_MIN_WAVES) void warp_cost_lds_kernel
                     const uint4 g[4] = {*reinterpret_cast<const uint4*>(img + tp.o00), *reinterpret_cast<const uint4*>(img + tp.o01), \
                                         *reinterpret_cast<const uint4*>(img + tp.o10), *reinterpret_cast<const uint4*>(img + tp.o11)}; \
                     _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                        \
-                        t[2 * k] = make_float4(Half16<TIn>::lo(g[k].x), Half16<TIn>::hi(g[k].x), Half16<TIn>::lo(g[k].y), Half16<TIn>::hi(g[k].y)); \
-                        t[2 * k + 1] = make_float4(Half16<TIn>::lo(g[k].z), Half16<TIn>::hi(g[k].z), Half16<TIn>::lo(g[k].w), Half16<TIn>::hi(g[k].w)); \
+                        t[2 * k] = wl_f4{Half16<TIn>::lo(g[k].x), Half16<TIn>::hi(g[k].x), Half16<TIn>::lo(g[k].y), Half16<TIn>::hi(g[k].y)}; \
+                        t[2 * k + 1] = wl_f4{Half16<TIn>::lo(g[k].z), Half16<TIn>::hi(g[k].z), Half16<TIn>::lo(g[k].w), Half16<TIn>::hi(g[k].w)}; \
                     }                                                                                                      \
                 }                                                                                                          \
                 wl_blend8(t, w, wv);                                                                                       \

@@ -29,32 +29,65 @@ import torch
 # --------------------------------------------------------------------------
 # cameras / scenes
 # --------------------------------------------------------------------------
-def make_cameras(B: int, V: int, H: int, W: int, *, depth_min: float = 2.0,
-                 depth_max: float = 6.0, behind_view: int = -1,
+def make_cameras(B: int, V: int, H: int, W: int, *, depth_min: float = None,
+                 depth_max: float = None, behind_view: int = -1, rig: str = "probe",
                  dtype=torch.float32) -> Dict[str, torch.Tensor]:
-    """Pinhole rig: reference camera at identity, source ``v`` rotated about the
+    """Two pinhole rigs.
+
+    ``rig="probe"`` (default; depth 2..6): reference camera at identity, source ``v`` rotated about the
     y axis by ``0.05 v (-1)^v`` rad and shifted ``0.1 v (-1)^v`` along x.
+
+    ``rig="dtu"`` (depth 425..905 = 425 + 192 x 2.5, reference ``data/dtu_yao.py:109``): the geometry of
+    Yao's DTU training set -- focal length 2.26 W (1446 px at 640), cameras on an arc around an object
+    point 660 mm in front of the reference camera, looking at it: source ``v`` is rotated about the
+    vertical axis through that point by ``5 ceil(v/2) (-1)^v`` degrees (baselines 58 / 115 mm) and tilted
+    by ``1.5 v (-1)^(v//2)`` degrees about the horizontal axis, so epipolar lines are not image rows and
+    one plane step moves a sample by 0.13-0.27 feature texels (0.03-0.1 in the probe rig).
 
     ``behind_view >= 0`` turns that source camera around (rotation by ~pi about
     y) so that every reference ray lands behind it -- the ``q_z <= 0`` branch of
     the warp (reference ``models/MVSNet/module.py:147-150``).
     """
+    if rig not in ("probe", "dtu"):
+        raise ValueError(f"unknown rig {rig!r}")
+    if depth_min is None:
+        depth_min = 2.0 if rig == "probe" else 425.0
+    if depth_max is None:
+        depth_max = 6.0 if rig == "probe" else 905.0
     K = torch.zeros(B, V, 3, 3, dtype=dtype)
     R = torch.zeros(B, V, 3, 3, dtype=dtype)
     t = torch.zeros(B, V, 3, 1, dtype=dtype)
     for b in range(B):
         for v in range(V):
-            f = 0.9 * W * (1.0 + 0.02 * v + 0.01 * b)
-            K[b, v] = torch.tensor([[f, 0.0, W / 2.0 + 0.5 * v],
-                                    [0.0, f, H / 2.0 - 0.25 * v],
-                                    [0.0, 0.0, 1.0]], dtype=dtype)
             sgn = -1.0 if v % 2 else 1.0
-            a = 0.05 * v * sgn + 0.01 * b
-            if v == behind_view:
-                a = math.pi - 0.1
-            ca, sa = math.cos(a), math.sin(a)
-            R[b, v] = torch.tensor([[ca, 0.0, sa], [0.0, 1.0, 0.0], [-sa, 0.0, ca]], dtype=dtype)
-            t[b, v] = torch.tensor([[0.1 * v * sgn], [0.02 * v], [0.0]], dtype=dtype)
+            if rig == "probe":
+                f = 0.9 * W * (1.0 + 0.02 * v + 0.01 * b)
+                K[b, v] = torch.tensor([[f, 0.0, W / 2.0 + 0.5 * v],
+                                        [0.0, f, H / 2.0 - 0.25 * v],
+                                        [0.0, 0.0, 1.0]], dtype=dtype)
+                a = 0.05 * v * sgn + 0.01 * b
+                if v == behind_view:
+                    a = math.pi - 0.1
+                ca, sa = math.cos(a), math.sin(a)
+                R[b, v] = torch.tensor([[ca, 0.0, sa], [0.0, 1.0, 0.0], [-sa, 0.0, ca]], dtype=dtype)
+                t[b, v] = torch.tensor([[0.1 * v * sgn], [0.02 * v], [0.0]], dtype=dtype)
+            else:
+                f = 2.2595 * W * (1.0 + 0.002 * v)
+                K[b, v] = torch.tensor([[f, 0.0, W / 2.0 + 11.6 * W / 640.0 + 0.5 * v],
+                                        [0.0, f, H / 2.0 + 9.5 * H / 512.0 - 0.25 * v],
+                                        [0.0, 0.0, 1.0]], dtype=dtype)
+                zc = 660.0 + 5.0 * b
+                th = math.radians(5.0 * ((v + 1) // 2)) * sgn + 0.002 * b
+                ph = math.radians(1.5 * v) * (-1.0 if (v // 2) % 2 else 1.0)
+                if v == behind_view:
+                    th = math.pi - 0.1
+                ct, st_, cp, sp = math.cos(th), math.sin(th), math.cos(ph), math.sin(ph)
+                Ry = torch.tensor([[ct, 0.0, st_], [0.0, 1.0, 0.0], [-st_, 0.0, ct]], dtype=torch.float64)
+                Rx = torch.tensor([[1.0, 0.0, 0.0], [0.0, cp, -sp], [0.0, sp, cp]], dtype=torch.float64)
+                Rv = Rx @ Ry
+                pivot = torch.tensor([[0.0], [0.0], [zc]], dtype=torch.float64)
+                R[b, v] = Rv.to(dtype)
+                t[b, v] = (pivot - Rv @ pivot).to(dtype)          # x_cam = Rv (x - pivot) + pivot: every camera sees the pivot at (0, 0, zc)
     dmin = torch.full((B, V), float(depth_min), dtype=dtype)
     dmax = torch.full((B, V), float(depth_max), dtype=dtype)
     return {"K": K, "R": R, "t": t, "depth_min": dmin, "depth_max": dmax}
@@ -101,8 +134,8 @@ def make_filter_scene(V: int, H: int, W: int, *, seed: int = 0, behind_view: int
     return {"depth": maps[0], "src_depth": maps[1:], "K": K, "R": R, "t": t}
 
 
-def make_scene(B: int, V: int, H: int, W: int, *, seed: int = 0, depth_min: float = 2.0,
-               depth_max: float = 6.0, behind_view: int = -1) -> Dict[str, torch.Tensor]:
+def make_scene(B: int, V: int, H: int, W: int, *, seed: int = 0, depth_min: float = None,
+               depth_max: float = None, behind_view: int = -1, rig: str = "probe") -> Dict[str, torch.Tensor]:
     """Full sample dict with smooth-ish random images in [0, 1)."""
     rng = np.random.default_rng(seed)
     # low-frequency content + noise so that the 2D feature nets see structure
@@ -111,7 +144,7 @@ def make_scene(B: int, V: int, H: int, W: int, *, seed: int = 0, depth_min: floa
     smooth = torch.nn.functional.interpolate(coarse_t, size=(H, W), mode="bilinear", align_corners=False)
     noise = torch.from_numpy(rng.random((B * V, 3, H, W), dtype=np.float32))
     imgs = (0.7 * smooth + 0.3 * noise).reshape(B, V, 3, H, W).contiguous()
-    out = make_cameras(B, V, H, W, depth_min=depth_min, depth_max=depth_max, behind_view=behind_view)
+    out = make_cameras(B, V, H, W, depth_min=depth_min, depth_max=depth_max, behind_view=behind_view, rig=rig)
     out["imgs"] = imgs
     return out
 
