@@ -135,6 +135,82 @@ def build_inputs(device, rank: int, dtype, batch: int = 1):
     return net, sd, feats, feats_cl, proj.to(device), dv.to(device).contiguous(), proj, dv
 
 
+def geometry_probe(net, device, dtype, reps: int = 20):
+    """The headline workload on BOTH camera rigs of `synthetic.make_cameras`: "probe" (what the bench line is
+    measured on: depth 2..6, sources rotated about y and shifted along x, 0.03-0.1 feature texels per plane) and "dtu" (depth
+    425..905 as data/dtu_yao.py:109, cameras on an arc with tilt, 0.14-0.32 texels per plane, oblique epipolar lines).  Per rig: the
+    warp + cost launch alone (HIP events, mean of `reps`), one eager hot path, and the LDS-staged kernel's staging-mode histogram
+    -- per (workgroup, source view): FAST = box staged, no masks; GEN = staged, clipped at the image border; DIRECT = box too
+    large for the LDS budget or a corner behind the camera: global taps; ZERO = box outside the image, the view contributes 0."""
+    import ctypes
+    from wild_deep_mvs_amd import _lib
+    out = {}
+    for rig in ("probe", "dtu"):
+        cams = synthetic.make_cameras(1, V, IMG_H, IMG_W, rig=rig)
+        Ks = cams["K"].clone()
+        Ks[:, :, :2] /= 4
+        proj = build_proj_matrices(Ks, cams["R"], cams["t"]).to(device)
+        steps = torch.arange(D, dtype=torch.float32).view(1, -1)
+        dv = (cams["depth_min"][:, :1] + (cams["depth_max"][:, :1] - cams["depth_min"][:, :1]) / (D - 1) * steps).to(device).contiguous()
+        feats = synthetic.make_features(1, V, C, h, w, seed=7)
+        fcl = [ops.to_channels_last(feats[i].to(device), dtype) for i in range(V)]
+        cam_blocks = ops.proj_cams_device(proj.float().contiguous(), 0)
+        warp = lambda: ops.warp_cost(fcl[0], fcl[1:], cam_blocks, dv, cost=_lib.COST_VARIANCE, out_dtype=dtype)
+        hist = torch.zeros(16, dtype=torch.int32, device=device)
+        fn = _lib.lib().pscv_debug_wl_mode_hist
+        fn.argtypes, fn.restype = [ctypes.c_void_p], None
+        fn(hist.data_ptr())
+        try:
+            warp()
+            torch.cuda.synchronize()
+        finally:
+            fn(None)
+        hm = hist.view(4, 4).cpu().tolist()
+        total = max(1, sum(hm[0]))
+        names = ("DIRECT", "GEN", "FAST", "ZERO")
+        modes = {names[m]: round(sum(hm[v][m] for v in range(V - 1)) / (total * (V - 1)), 4) for m in range(4)}
+        for _ in range(3):
+            warp()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            warp()
+        e1.record()
+        torch.cuda.synchronize()
+        warp_us = e0.elapsed_time(e1) * 1e3 / reps
+        with torch.no_grad():
+            for _ in range(2):
+                net.hot_path(fcl, proj, dv)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                net.hot_path(fcl, proj, dv)
+            torch.cuda.synchronize()
+            path_ms = (time.perf_counter() - t0) / reps * 1e3
+        _lib.set_tuning("warp_tiled", 0)          # the direct-gather (quad) kernel on the same launch: geometry-independent taps
+        try:
+            for _ in range(3):
+                warp()
+            e0.record()
+            for _ in range(reps):
+                warp()
+            e1.record()
+            torch.cuda.synchronize()
+            quad_us = e0.elapsed_time(e1) * 1e3 / reps
+        finally:
+            _lib.set_tuning("warp_tiled", -1)
+        out[rig] = {"warp_cost_us": round(warp_us, 1), "warp_cost_hbm_frac": round(algorithmic_bytes("warp_cost[0]") / (warp_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                    "warp_cost_us_direct_gather_kernel": round(quad_us, 1),
+                    "hot_path_eager_ms_per_view": round(path_ms, 4), "staging_modes_share_of_block_views": modes,
+                    "staging_modes_per_view": [dict(zip(names, hm[v])) for v in range(V - 1)]}
+    out["note"] = ("the headline line is measured on the probe rig; on the DTU-like rig the boxes of a 32-plane chunk exceed the kernel's 16 x 8 texel / "
+                   "LDS budget for the wide-baseline views, which then take global taps (DIRECT): stand-alone launch times of both warp kernels are "
+                   "given per rig (`pscv_set_tuning(\"warp_tiled\", 0)` selects the direct-gather kernel for wide-baseline rigs); a per-block "
+                   "split of the chunk into 2-4 plane ranges was built and measured in round 4 (DIRECT 43 % -> 12 %, 215 -> 219 us: the extra "
+                   "box / staging / barrier phases cost what the staged taps saved) and not kept")
+    return out
+
+
 REF_CONTAINER = {"seconds": 3.47, "voxels_per_s": VOX / 3.47, "threads": 8,
                  "what": "the reference's own eval path (/root/reference models/MVSNet/model.py:109-139,74-84,207-209) on the same "
                          "inputs in the build container (8 vCPU), median of 3; the oracle's streaming path took 2.95 s there with "
@@ -444,9 +520,9 @@ def run(args):
         _lib.set_tuning(k, int(v))
     net, sd, feats, feats_cl, proj_d, dv_d, proj, dv = build_inputs(device, rank, DTYPES[args.dtype], args.batch)
     NB = args.batch
-    # "batched" (default since the end of round 3): the LDS-staged warp kernel is not reproducible while conv kernels of another
-    # stream run next to it, so the headline step keeps the views of a batch on ONE stream; "streams" is
-    # the round-3 experiment (the model then sweeps with the warp kernel's scalar build, "warp_tiled" = 2)
+    # "batched" (default): the views of a batch share one launch per layer on ONE stream, replayed as a hipGraph; "streams" runs
+    # them on separate HIP streams (eager).  Every kernel is bit-stable under that overlap since round 4 (the LDS-staged warp
+    # kernel ships as its scalar-fp32 build; tests/test_gpu_overlap.py)
     net.batch_streams = args.batch_mode == "streams"
     streams_mode = net.batch_streams and 2 <= NB <= net.MAX_BATCH_STREAMS
 
@@ -589,11 +665,13 @@ def run(args):
             "config": {"workload": "MVSNet variance, 1 ref + 4 src views, 512x640 images (128x160x32 features), D=192, "
                                    f"features resident in HBM -> depth + confidence; a step = a batch of {NB} reference view(s) per GPU, "
                                    "each with its own 4 source views", "global_batch": world * NB, "batch_per_gpu": NB,
-                       "voxels_per_step_per_gpu": NB * VOX, "parallelism": f"reference-view shard x{world}, no collective"},
+                       "voxels_per_step_per_gpu": NB * VOX, "parallelism": f"reference-view shard x{world}, no collective",
+                       # like-for-like with rounds 1-2 (whose step was ONE reference view): the same path, one view per replay
+                       "one_view_at_a_time_ms": None if one_view is None else one_view * 1e3,
+                       "one_view_at_a_time_voxels_per_s": None if one_view is None else world * VOX / one_view},
             "timing": ("hipGraph replay of the step" if graph else "eager launches") +
                       (f"; the {NB} views of a step run on {NB} HIP streams: one view's vector-ALU-bound warp beside another's MFMA / "
-                       "memory-bound U-Net (MVSNet._hot_path_streams: eager, and with the LDS-staged warp kernel's build WITHOUT packed fp32 instructions -- the "
-                       "default build is not reproducible next to another stream's conv kernels, DESIGN.md section 6), so a step is SHORTER than the sum of "
+                       "memory-bound U-Net (MVSNet._hot_path_streams: eager), so a step is SHORTER than the sum of "
                        "its kernels' stand-alone durations below" if streams_mode else
                        f"; the {NB} views of a step share ONE launch per layer (batched grids, one stream)" if NB > 1 else "") +
                       f"; kernels_us / roofline: HIP events of an eager pass of the same {args.steps} steps, one view after the other on one "
@@ -618,6 +696,12 @@ def run(args):
         # all five BASELINE configurations in their single-GPU forms (parity cases of tests/test_gpu_fullsize.py, not bench lines):
         # driver-timed ms of the full forward() called like the reference's scripts call it (in-forward hipGraph replay and eager),
         # with the three heaviest kernels of each against their rooflines; after the headline region
+        line["alt_geometry"] = None
+        if world == 1 and not args.no_other_configs:
+            try:
+                line["alt_geometry"] = geometry_probe(net, device, DTYPES[args.dtype])
+            except Exception as e:   # pragma: no cover
+                line["alt_geometry"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         line["sharded"] = sharded
         line["other_configs"] = None
         if world == 1 and not args.no_other_configs:

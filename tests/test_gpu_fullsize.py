@@ -73,6 +73,76 @@ def test_config1_mvsnet_s_matches_reference_golden(gpu, dtype):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# configuration (2): MVSNet (variance), 1 ref + 4 src, 512x640, D = 192 -- THE headline size, on windows against the oracle
+# ---------------------------------------------------------------------------------------------------------------------
+MVS_MARGIN = 30      # receptive radius of MVSNet's CostRegNet in the image plane (and along D: the depth axis is never cropped)
+
+
+@pytest.mark.parametrize("rig", ["probe", "dtu"])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_mvsnet_fullsize_matches_oracle_on_windows(gpu, dtype, rig):
+    """5 x 512x640, D = 192 (h x w = 128 x 160, 3.9 M voxels): the size at which the LDS-staged warp kernel runs 32-plane chunks with
+    four staged views, conv0 its 64-plane sweeps, the head its plane-ring sweep.  Both camera rigs of `synthetic.make_cameras`
+    (the probe rig the bench runs and the DTU-like one: depth 425..905, tilted epipolar lines, 0.13-0.3 texels per plane).
+    On two windows of reference pixels (image corner, interior), with the engine's own 16-bit feature maps as the oracle's input:
+      * warp + variance: pointwise in the reference pixel -> the WHOLE window, every plane, to one rounding of the stored value;
+      * logits (fp32 oracle U-Net on the engine's cost-volume window), depth and confidence: beyond the U-Net's +-30 pixel reach
+        from the artificial window borders (sides that are the image border keep their zero padding and are compared to the edge)."""
+    L, ops, synthetic = gpu
+    from wild_deep_mvs_amd.models.MVSNet.model import MVSNet
+    from oracle import mvsnet as O
+    V, H, W, D = 5, 512, 640, 192
+    net = MVSNet("variance")
+    sd = synthetic.sharpened_state_dict("mvsnet", synthetic.template_of(net), seed=0)
+    net.load_state_dict(sd, strict=True)
+    net.storage_dtype, net.num_depth, net.graph_replay = dtype, D, False
+    net = net.cuda().eval()
+    scene = synthetic.make_scene(1, V, H, W, seed=2, rig=rig)
+    dev = {k: v.cuda() for k, v in scene.items()}
+    assert L.get_tuning("warp_tiled") == 1
+    taps = {}
+    with torch.no_grad():
+        out = net(dev["imgs"], dev["K"], dev["R"], dev["t"], dev["depth_min"], dev["depth_max"], taps=taps)
+        feats_cl = net.extract_features_cl([dev["imgs"][:, i] for i in range(V)])
+    h, w = H // 4, W // 4
+    assert tuple(out["depth"].shape) == (1, h, w) and torch.isfinite(out["depth"]).all()
+    feats = [f.float().permute(0, 3, 1, 2).contiguous().cpu() for f in feats_cl]            # the engine's stored (16-bit) maps
+    proj, dvals = O.mvsnet_cameras(scene["K"], scene["R"], scene["t"], scene["depth_min"], scene["depth_max"], D)
+    dv = dvals[:, 0]
+    cost = taps["cost_volume"].float().permute(0, 4, 1, 2, 3).cpu()                         # [1,32,D,h,w]
+    logits = taps["logits"].cpu()                                                            # [1,D,h,w]
+    ulp = 2 ** -8 if dtype == torch.bfloat16 else 2 ** -11
+    win = 80
+    bf = dtype == torch.bfloat16
+    for (y0, x0) in ((0, 0), (24, 40), (h - win, w - win)):
+        shift = torch.eye(4)
+        shift[0, 2], shift[1, 2] = -float(x0), -float(y0)
+        ref_proj = shift @ proj[:, 0]                                                        # a pinhole crop = a shifted principal point
+        with torch.no_grad():
+            warped = [O.homo_warping(feats[i], proj[:, i], ref_proj, dv, (win, win)) for i in range(1, V)]
+            o_cost = O.variance_cost(feats[0][:, :, y0:y0 + win, x0:x0 + win].contiguous(), warped)
+        e_cost = cost[:, :, :, y0:y0 + win, x0:x0 + win]
+        s = check_close(f"cfg2 {rig} {dtype} cost volume window ({y0},{x0})", e_cost, o_cost, rel_l2=1.2 * ulp)
+        assert s["max_abs"] <= 2 * ulp * s["ref_max"] + 1e-4, s
+        with torch.no_grad():
+            o_logits = O.cost_reg_net(e_cost.contiguous(), sd).squeeze(1)
+            _, o_depth, o_conf = O.regress(o_logits, dv)
+        ya = 0 if y0 == 0 else MVS_MARGIN
+        xa = 0 if x0 == 0 else MVS_MARGIN
+        yb = win if y0 + win == h else win - MVS_MARGIN
+        xb = win if x0 + win == w else win - MVS_MARGIN
+        sel = (slice(None), slice(None), slice(ya, yb), slice(xa, xb))
+        check_close(f"cfg2 {rig} {dtype} logits window ({y0},{x0})", logits[:, :, y0:y0 + win, x0:x0 + win][sel], o_logits[sel],
+                    rel_l2=2e-2 if bf else 3e-3)
+        sel2 = sel[1:]
+        e_depth = out["depth"].cpu()[:, y0:y0 + win, x0:x0 + win]
+        sd_ = check_close(f"cfg2 {rig} {dtype} depth window ({y0},{x0})", e_depth[sel2], o_depth[sel2])
+        assert sd_["rel_l1"] <= (WINDOW_BARS[dtype]["depth"] if bf else 1e-3), sd_
+        e_conf = out["photometric_confidence"].cpu()[:, y0:y0 + win, x0:x0 + win]
+        check_close(f"cfg2 {rig} {dtype} confidence window ({y0},{x0})", e_conf[sel2], o_conf[sel2], rel_l1=8e-2 if bf else 2e-2)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # configurations (3) and (5): Vis-MVSNet at 5-view 512x640 [192,32,16] and 9-view 1152x1600 [256,32,16]
 # ---------------------------------------------------------------------------------------------------------------------
 VIS_CONFIGS = {

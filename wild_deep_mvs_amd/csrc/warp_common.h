@@ -21,6 +21,7 @@ struct WarpArgs {
     float temp;
     float sx, sy;        // index scale: PROJ 1, HOMOG (W-1)/W
     float xlo, xhi, ylo, yhi;  // clamp of the pixel index implied by the reference's grid clamp
+    int* mode_hist;      // development aid of the LDS-staged kernel (pscv_debug_wl_mode_hist): [view][mode] counters of its per-(block, view) staging modes; null = off
 };
 
 template <int N> struct VecF { float v[N]; };

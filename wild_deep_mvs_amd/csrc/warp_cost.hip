@@ -409,6 +409,7 @@ extern "C" int pscv_warp_cost(const void* ref, const void* const* srcs, int n_sr
     // taps are addressed with 24-bit texel indices and 32-bit byte offsets inside one source image
     PSCV_CHECK_ARG((long)hs * ws < (1L << 24) && (long)hs * ws * C * 4 < (1L << 32), "pscv_warp_cost: source map %dx%dx%d too large", hs, ws, C);
     WarpArgs a;
+    a.mode_hist = nullptr;
     a.ref = ref;
     for (int i = 0; i < PSCV_MAX_SRC; ++i) a.src[i] = i < n_src ? srcs[i] : nullptr;
     for (int i = 0; i < n_src; ++i) PSCV_CHECK_ARG(srcs[i], "pscv_warp_cost: srcs[%d] is null", i);

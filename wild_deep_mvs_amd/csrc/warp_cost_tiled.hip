@@ -183,267 +183,12 @@ constexpr int WL_GEN = 1;      // box clipped at the image border: LDS taps, gen
 constexpr int WL_FAST = 2;     // box strictly inside the image: LDS taps, no masks / clamps
 constexpr int WL_ZERO = 3;     // box entirely outside the image: every tap is zero padding, the view contributes f = 0
 
-// ---- software-pipelined sweep (round 3) --------------------------------------------------------------------------------
-// Counters of the round-2 sweep (profiles/README.md): vector ALU ~50 % and LDS ~50-60 % busy, i.e. a sweep round took
-// the SUM of its LDS time and its vector-ALU time.  Per (voxel, view) a wave issued 8 ds_read_b128, waited for them, blended;
-// the per-view mode branches kept the compiler from moving anything across views, and 16 waves in that rhythm fall into step:
-// all queue on the LDS (8 reads x 16 waves = 512 LDS cycles), then all blend.  Here the views that are staged are compacted
-// into slots 0..NV-1 once per block (NV and the clipped / unclipped flavour become template parameters, so the loop body is
-// straight-line code), and a wave requests the taps of slot j + 1 -- after the last slot: slot 0 of its NEXT voxel -- BEFORE it
-// blends slot j, out of a second register buffer: LDS latency and queueing hide under the wave's own FMAs.
-struct WlLane {             // sweep constants of a lane: its pixel's ray terms in the view of its quad slot, that view's box
-    float rx, ry, rz, tx, ty, tz;
-    int mX0, mY0, mX1, mY1, mpitch, meb;
-};
-struct WlC { float w00, w01, w10, w11; int E, DX, DY; };
-
-// sample position of (pixel, plane) in the lane's view -> bilinear weights, byte offset E of the top-left tap in the arena and
-// (GEN) the byte steps to the right / lower taps.  Same operations as the round-2 loop (bit-identical).
-template <bool GEN>
-__device__ __forceinline__ WlC wl_coords(const WlLane& L, float dval, const WarpArgs& a) {
-    // no implicit contraction in here: the pixel index hx / hz is the reference's grid coordinate and must be ROUNDED before its
-    // floor and fraction are taken (left alone, the compiler forms fx = fma(hx, inv_z, -floor(ix)): other weights, other bits);
-    // the explicit fmaf()s are the direct kernels' operations
-#pragma clang fp contract(off)
-    WlC c;
-    const float hx = fmaf(L.rx, dval, L.tx), hy = fmaf(L.ry, dval, L.ty), hz = fmaf(L.rz, dval, L.tz);
-    const float inv_z = __builtin_amdgcn_rcpf(hz);
-    float ix = hx * inv_z, iy = hy * inv_z;
-    if (GEN) {   // (a staged box has every corner in front of the camera: no behind-camera test)
-        ix = __builtin_amdgcn_fmed3f(ix, a.xlo, a.xhi);      // grid clamp  module.py:151-155
-        iy = __builtin_amdgcn_fmed3f(iy, a.ylo, a.yhi);
-    }
-    const float x0f = floorf(ix), y0f = floorf(iy);
-    const float fx = ix - x0f, fy = iy - y0f;
-    const float gx = 1.0f - fx, gy = 1.0f - fy;
-    c.w00 = gx * gy; c.w01 = fx * gy; c.w10 = gx * fy; c.w11 = fx * fy;
-    const int x0 = (int)x0f, y0 = (int)y0f;
-    c.DX = 64; c.DY = L.mpitch << 6;
-    if (GEN) {
-        // zero padding: a tap outside the image has weight 0 and is read from the nearest staged texel instead
-        const int x1 = x0 + 1, y1 = y0 + 1;
-        const bool vx0 = (unsigned)x0 < (unsigned)a.ws, vx1 = (unsigned)x1 < (unsigned)a.ws;
-        const bool vy0 = (unsigned)y0 < (unsigned)a.hs, vy1 = (unsigned)y1 < (unsigned)a.hs;
-        c.w00 = (vx0 && vy0) ? c.w00 : 0.0f; c.w01 = (vx1 && vy0) ? c.w01 : 0.0f;
-        c.w10 = (vx0 && vy1) ? c.w10 : 0.0f; c.w11 = (vx1 && vy1) ? c.w11 : 0.0f;
-        const int xc0 = med3_i32(x0, L.mX0, L.mX1), xc1 = med3_i32(x1, L.mX0, L.mX1);
-        const int yc0 = med3_i32(y0, L.mY0, L.mY1), yc1 = med3_i32(y1, L.mY0, L.mY1);
-        c.E = (__mul24(yc0, L.mpitch) + xc0 + L.meb) << 6;
-        c.DX = (xc1 - xc0) << 6;
-        c.DY = __mul24(yc1 - yc0, L.mpitch) << 6;
-    } else {
-        c.E = (__mul24(y0, L.mpitch) + x0 + L.meb) << 6;
-    }
-    return c;
-}
-
-// request the eight 16-byte tap pieces of slot J (weights and tap address broadcast from quad lane J)
-// Tap requests and the wait for them are inline assembly: plain LDS loads are hoisted to the top of the voxel by the DAG builder
-// (it does not order them against sched_barrier -> all 4 x 32 tap registers live at once -> scratch), volatile loads lose their
-// address space and become flat loads with a wait behind each.  `asm volatile` keeps program order among the requests, the
-// fences and the wait; the compiler's own waitcnt pass does not see these requests, so wl_wait_taps() is what orders their use:
-// LDS returns data in order, hence "at most N requests outstanding" = everything older than the youngest N has arrived, and the
-// awaited registers pass THROUGH the wait statement so that no consumer can be scheduled above it.
-template <int OFF> __device__ __forceinline__ wl_f4 wl_ds_read16(unsigned addr) {
-    wl_f4 v;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-    return v;
-}
-template <int N> __device__ __forceinline__ void wl_wait_taps(wl_f4 (&t)[8]) {
-    asm volatile("s_waitcnt lgkmcnt(%8)"
-                 : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7])
-                 : "n"(N));
-}
-
-// request the eight 16-byte tap pieces of slot J (weights and tap address broadcast from quad lane J); lds0 = LDS address of lsm
-template <int J, bool GEN>
-__device__ __forceinline__ void wl_issue(unsigned lds0, const WlC& c, unsigned chb, unsigned pitch64, wl_f4 (&t)[8], float (&w)[4]) {
-    constexpr int CTRL = J * 0x55;
-    w[0] = wl_dpp_f<CTRL>(c.w00); w[1] = wl_dpp_f<CTRL>(c.w01); w[2] = wl_dpp_f<CTRL>(c.w10); w[3] = wl_dpp_f<CTRL>(c.w11);
-    const unsigned a00 = (unsigned)wl_dpp_i<CTRL>(c.E) + chb + lds0;
-    if constexpr (!GEN) {
-        const unsigned a10 = a00 + pitch64;
-        t[0] = wl_ds_read16<0>(a00);
-        t[1] = wl_ds_read16<WL_HI>(a00);
-        t[2] = wl_ds_read16<64>(a00);
-        t[3] = wl_ds_read16<64 + WL_HI>(a00);
-        t[4] = wl_ds_read16<0>(a10);
-        t[5] = wl_ds_read16<WL_HI>(a10);
-        t[6] = wl_ds_read16<64>(a10);
-        t[7] = wl_ds_read16<64 + WL_HI>(a10);
-    } else {
-        const unsigned a01 = a00 + (unsigned)wl_dpp_i<CTRL>(c.DX);
-        const unsigned a10 = a00 + (unsigned)wl_dpp_i<CTRL>(c.DY);
-        const unsigned a11 = a10 + (a01 - a00);
-        t[0] = wl_ds_read16<0>(a00);
-        t[1] = wl_ds_read16<WL_HI>(a00);
-        t[2] = wl_ds_read16<0>(a01);
-        t[3] = wl_ds_read16<WL_HI>(a01);
-        t[4] = wl_ds_read16<0>(a10);
-        t[5] = wl_ds_read16<WL_HI>(a10);
-        t[6] = wl_ds_read16<0>(a11);
-        t[7] = wl_ds_read16<WL_HI>(a11);
-    }
-}
-
-// eight fp32 channels x four taps -> eight blended channels as four channel PAIRS: explicit two-wide vector arithmetic so that the
-// blend is 4 v_pk_mul_f32 + 12 v_pk_fma_f32 (one issue slot per two lanes-FMAs; the same IEEE operation chain per channel as
-// wl_blend8, hence the same bits).  Plain v_fmac_f32 measured 3.25 cycles per wave-instruction, a packed FMA ~4 for two.
-__device__ __forceinline__ wl_f2 wl_lo2(const wl_f4& v) { return __builtin_shufflevector(v, v, 0, 1); }
-__device__ __forceinline__ wl_f2 wl_hi2(const wl_f4& v) { return __builtin_shufflevector(v, v, 2, 3); }
-__device__ __forceinline__ void wl_blend8v(const wl_f4 (&t)[8], const float (&w)[4], wl_f2 (&o)[4]) {
-    const wl_f2 w0 = wl_f2{w[0], w[0]};
-    o[0] = wl_lo2(t[0]) * w0; o[1] = wl_hi2(t[0]) * w0; o[2] = wl_lo2(t[1]) * w0; o[3] = wl_hi2(t[1]) * w0;
-#pragma unroll
-    for (int k = 1; k < 4; ++k) {
-        const wl_f2 wk = wl_f2{w[k], w[k]};
-        o[0] = __builtin_elementwise_fma(wl_lo2(t[2 * k]), wk, o[0]);
-        o[1] = __builtin_elementwise_fma(wl_hi2(t[2 * k]), wk, o[1]);
-        o[2] = __builtin_elementwise_fma(wl_lo2(t[2 * k + 1]), wk, o[2]);
-        o[3] = __builtin_elementwise_fma(wl_hi2(t[2 * k + 1]), wk, o[3]);
-    }
-}
-
-template <bool B, typename T> __device__ __forceinline__ T& wl_pick(T& x, T& y) {
-    if constexpr (B) return y; else return x;
-}
-
-struct WlSweep {            // wave-uniform / per-lane invariants of a block's sweep
-    unsigned lds0;          // LDS address of the arena
-    char* out;              // + batch item + this lane's voxel column and channel group
-    unsigned long plane_bytes;
-    unsigned pitch64[WL_MAX_SRC];   // per slot: box pitch << 6
-    unsigned chb;
-    float invN, invN2, temp;
-    int d0, d1;
-    bool active;
-};
-
-// one voxel of this quad: slots 0..NV-1; slot J blends out of buffer (P0 + J) & 1 while the next slot's taps are in flight
-template <typename TOut, int COST, int NV, bool GEN, int P0>
-__device__ __forceinline__ void wl_voxel(const WarpArgs& a, const WlSweep& S, const WlLane& L, const wl_f2 (&rf)[4], float dlane,
-                                         int d, WlC& c, wl_f4 (&tA)[8], wl_f4 (&tB)[8], float (&wA)[4], float (&wB)[4]) {
-    constexpr bool VAR = COST == PSCV_COST_VARIANCE || COST == PSCV_COST_VARIANCE_CVP;
-    wl_f2 s[4], q[4];           // variance: sum, sum of squares; softmin: sum e*diff (s only); channel pairs
-    float sum_e = 0.0f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (VAR) { s[j] = rf[j]; q[j] = rf[j] * rf[j]; }       // the sums start at the reference feature  model.py:121-123
-        else { s[j] = wl_f2{0.0f, 0.0f}; q[j] = wl_f2{0.0f, 0.0f}; }
-    }
-    WlC cn = c;
-    auto slot = [&](auto jc) {
-        constexpr int J = decltype(jc)::value;
-        if constexpr (J < NV) {
-            constexpr bool CB = ((P0 + J) & 1) != 0;
-            wl_f4 (&tc)[8] = wl_pick<CB>(tA, tB);
-            wl_f4 (&tn)[8] = wl_pick<!CB>(tA, tB);
-            float (&wc)[4] = wl_pick<CB>(wA, wB);
-            float (&wn)[4] = wl_pick<!CB>(wA, wB);
-            if constexpr (J + 1 < NV) {
-                wl_issue<J + 1, GEN>(S.lds0, c, S.chb, S.pitch64[J + 1], tn, wn);
-            } else {
-                // slot 0 of this wave's next voxel; behind the last voxel the same plane is requested once more (8 reads nobody
-                // uses): a branch here would merge two definitions of the tap registers = 32 register copies per voxel
-                const int dn = min(d + 2, S.d1 - 1);
-                const float dv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dlane), dn - S.d0));
-                cn = wl_coords<GEN>(L, dv, a);
-                wl_issue<0, GEN>(S.lds0, cn, S.chb, S.pitch64[0], tn, wn);
-            }
-            wl_wait_taps<8>(tc);
-            // the scheduler would otherwise hoist the tap requests of ALL later slots up here (they only depend on c): 4 x 32
-            // tap registers live at once.  Nothing crosses these fences: requests of the next slot above, this slot's FMAs below
-            __builtin_amdgcn_sched_barrier(0);
-            wl_f2 wv[4];
-            wl_blend8v(tc, wc, wv);
-            if (VAR) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { s[j] += wv[j]; q[j] = __builtin_elementwise_fma(wv[j], wv[j], q[j]); }
-            } else {   // SOFTMIN  model.py:141-173
-                wl_f2 df[4];
-                float part = 0.0f;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const wl_f2 t = rf[j] - wv[j];
-                    df[j] = t * t;
-                    part += df[j][0]; part += df[j][1];
-                }
-                part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64);
-                const float e = __expf(-S.temp * part);
-                sum_e += e;
-                const wl_f2 e2 = wl_f2{e, e};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) s[j] = __builtin_elementwise_fma(e2, df[j], s[j]);
-            }
-            // pin: the sums pass through an (empty) volatile statement, so this slot's FMAs cannot sink below the requests
-            // the next slot issues (pure arithmetic is otherwise placed next to its last use: the end of the voxel)
-            asm volatile("" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(sum_e));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    slot(std::integral_constant<int, 0>{});
-    slot(std::integral_constant<int, 1>{});
-    slot(std::integral_constant<int, 2>{});
-    slot(std::integral_constant<int, 3>{});
-    float o[8];
-    if (COST == PSCV_COST_VARIANCE) {
-        const wl_f2 n1 = wl_f2{S.invN, S.invN}, n2 = wl_f2{S.invN2, S.invN2};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const wl_f2 t = (s[j] * s[j]) * n2;
-            const wl_f2 r = __builtin_elementwise_fma(q[j], n1, -t);      // = what `q n1 - (s s) n2` contracts to in the round-2 loop
-            o[2 * j] = r[0]; o[2 * j + 1] = r[1];
-        }
-    } else if (COST == PSCV_COST_VARIANCE_CVP) {
-        const wl_f2 n1 = wl_f2{S.invN, S.invN};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const wl_f2 m = s[j] * n1;
-            const wl_f2 r = q[j] * n1 - m * m;
-            o[2 * j] = r[0]; o[2 * j + 1] = r[1];
-        }
-    } else {
-        const float inv = 1.0f / (sum_e + 1e-6f);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { o[2 * j] = s[j][0] * inv; o[2 * j + 1] = s[j][1] * inv; }
-    }
-    if (S.active) wl_store8<TOut>(S.out + (unsigned long)d * S.plane_bytes, o);
-    c = cn;
-}
-
-template <typename TOut, int COST, int NV, bool GEN>
-__device__ __forceinline__ void wl_sweep_pipe(const WarpArgs& a, const WlSweep& S, const WlLane& L, const wl_f2 (&rf)[4], float dlane,
-                                              int dstart) {
-    wl_f4 tA[8], tB[8];
-    float wA[4], wB[4];
-    int d = dstart;
-    if (d >= S.d1) return;
-    WlC c = wl_coords<GEN>(L, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dlane), d - S.d0)), a);
-    wl_issue<0, GEN>(S.lds0, c, S.chb, S.pitch64[0], tA, wA);
-    // two voxels per trip: with an odd slot count the buffer of slot 0 alternates from voxel to voxel
-    while (true) {
-        wl_voxel<TOut, COST, NV, GEN, 0>(a, S, L, rf, dlane, d, c, tA, tB, wA, wB);
-        d += 2;
-        if (d >= S.d1) break;
-        wl_voxel<TOut, COST, NV, GEN, NV & 1>(a, S, L, rf, dlane, d, c, tA, tB, wA, wB);
-        d += 2;
-        if (d >= S.d1) break;
-    }
-}
+// (The software-pipelined sweep of round 3 -- next view's taps requested out of a second register buffer before the current view is
+//  blended; 164 VGPRs = three workgroups per CU; 2 % faster in the same binary, 5 % slower than the plain loop at 101 VGPRs -- was removed
+//  from this file in round 4; commit cb456f1 and docs/DESIGN_notes_r1-r3.md hold the code and the measurement.)
 
 template <typename TIn, typename TOut, int GEOM, int COST>
-// WL_PIPELINED (A/B builds: bash scripts/dev/ab_build.sh pipe warp_cost_tiled.hip -DWL_PIPELINED) compiles the round-3
-// software-pipelined sweep in.  It needs 164 VGPRs = three workgroups per CU; in the SAME binary it beats the plain loop by 2 %
-// (115.6 vs 118.5 us in the step), but the plain loop ALONE compiles to 101 VGPRs = four workgroups per CU and runs 109.8 us
-// against 115.3 us (two alternating pairs of runs on one box): four simple waves per SIMD hide the LDS latency better than three
-// pipelined ones, and the sweep is VALU-bound either way.  The default build is therefore the plain loop; the pipelined code
-// stays as the record of the experiment (bit-equal: `scripts/wbench.py --variants 0 1` on that build, 0 of 125 829 120 values differ).
-#ifdef WL_PIPELINED
-#define WL_MIN_WAVES 3
-#else
-#define WL_MIN_WAVES 4
-#endif
-__global__ __launch_bounds__(WL_THREADS, WL_MIN_WAVES) void warp_cost_lds_kernel(const WarpArgs a) {
+__global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const WarpArgs a) {
     constexpr int C = 32, PIXB = 64;
     constexpr int OB = (int)sizeof(TOut);
     constexpr bool VAR = COST == PSCV_COST_VARIANCE || COST == PSCV_COST_VARIANCE_CVP;
@@ -564,6 +309,7 @@ __global__ __launch_bounds__(WL_THREADS, WL_MIN_WAVES) void warp_cost_lds_kernel
                 int4* row = reinterpret_cast<int4*>(table + k * 8);
                 row[0] = make_int4(cX0, cY0, cX1, cY1);
                 row[1] = make_int4(used, pitch, mode, 0);
+                if (a.mode_hist && k < n_src) atomicAdd(a.mode_hist + k * 4 + mode, 1);     // (bench.py's mode histogram; off in product launches)
             }
             if (mode == WL_FAST || mode == WL_GEN) used += pitch * (cY1 - cY0 + 1);
         }
@@ -582,43 +328,7 @@ __global__ __launch_bounds__(WL_THREADS, WL_MIN_WAVES) void warp_cost_lds_kernel
         bMode[k] = __builtin_amdgcn_readfirstlane(r1.z);
         any_gen = any_gen || bMode[k] == WL_GEN;
     }
-    // staged views compacted into slots (pipelined sweep): quad lane j computes the sample position in view vl[j]
-    int vl[WL_MAX_SRC] = {0, 0, 0, 0}, n_act = 0;
-    bool any_direct = false, any_zero = false;
-#pragma unroll
-    for (int k = 0; k < WL_MAX_SRC; ++k) {
-        if (k < n_src) {
-            const bool staged = bMode[k] == WL_FAST || bMode[k] == WL_GEN;
-            any_direct = any_direct || bMode[k] == WL_DIRECT;
-            any_zero = any_zero || bMode[k] == WL_ZERO;
-            if (staged) {
-#pragma unroll
-                for (int j = 0; j < WL_MAX_SRC; ++j)
-                    if (j == n_act) vl[j] = k;
-                ++n_act;
-            }
-        }
-    }
-#pragma unroll
-    for (int j = 1; j < WL_MAX_SRC; ++j)
-        if (j >= n_act) vl[j] = vl[n_act > 0 ? n_act - 1 : 0];
-    // a soft-min sweep needs the zero-padded views too (their weight e is not zero); blocks with a direct-tap view keep the
-    // general loop.  a.variant == 1 forces the round-2 loop everywhere (measurement)
-#ifdef WL_PIPELINED
-    const bool pipe = a.variant != 1 && !any_direct && n_act >= 1 && (VAR || !any_zero);
-#else
-    const bool pipe = false;
-#endif
-    const int sel = pipe ? (l == 0 ? vl[0] : l == 1 ? vl[1] : l == 2 ? vl[2] : vl[3]) : l;
-    if (pipe) {   // this lane's ray terms were loaded for view l: fetch those of view sel from quad lane sel
-        const int src_lane = ((lane & ~3) | sel) << 2;
-        rx = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane, __builtin_bit_cast(int, rx)));
-        ry = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane, __builtin_bit_cast(int, ry)));
-        rz = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane, __builtin_bit_cast(int, rz)));
-        tx = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane, __builtin_bit_cast(int, tx)));
-        ty_ = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane, __builtin_bit_cast(int, ty_)));
-        tz = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane, __builtin_bit_cast(int, tz)));
-    }
+    const int sel = l;
     const int4 mr0 = *reinterpret_cast<const int4*>(table + sel * 8), mr1 = *reinterpret_cast<const int4*>(table + sel * 8 + 4);
     const int mX0 = mr0.x, mY0 = mr0.y, mX1 = mr0.z, mY1 = mr0.w, mpitch = mr1.y;
     const int meb = mr1.x - mY0 * mpitch - mX0;    // texel index = y * pitch + x + meb
@@ -677,37 +387,8 @@ __global__ __launch_bounds__(WL_THREADS, WL_MIN_WAVES) void warp_cost_lds_kernel
     __builtin_amdgcn_s_setprio(0);
     WL_STAMP(4)
 
-    // ---- 5a. pipelined sweep: every contributing view is staged (the common case) ----
-#ifdef WL_PIPELINED
-    if (pipe) {
-        WlSweep S;
-        S.lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lsm;
-        S.out = out + (unsigned long)b * a.D * plane_bytes + lane_out;
-        S.plane_bytes = plane_bytes;
-#pragma unroll
-        for (int j = 0; j < WL_MAX_SRC; ++j) {
-            const int v = vl[j];
-            S.pitch64[j] = (unsigned)(v == 0 ? bPitch[0] : v == 1 ? bPitch[1] : v == 2 ? bPitch[2] : bPitch[3]) << 6;
-        }
-        S.chb = chb; S.invN = invN; S.invN2 = invN2; S.temp = a.temp; S.d0 = d0; S.d1 = d1; S.active = active;
-        const WlLane Ln = {rx, ry, rz, tx, ty_, tz, mX0, mY0, mX1, mY1, mpitch, meb};
-        const int dstart = d0 + wave / WL_PG;
-        const wl_f2 rf2[4] = {wl_f2{rf[0], rf[1]}, wl_f2{rf[2], rf[3]}, wl_f2{rf[4], rf[5]}, wl_f2{rf[6], rf[7]}};
-        switch (n_act * 2 + (any_gen ? 1 : 0)) {
-            case 2: wl_sweep_pipe<TOut, COST, 1, false>(a, S, Ln, rf2, dlane, dstart); break;
-            case 3: wl_sweep_pipe<TOut, COST, 1, true>(a, S, Ln, rf2, dlane, dstart); break;
-            case 4: wl_sweep_pipe<TOut, COST, 2, false>(a, S, Ln, rf2, dlane, dstart); break;
-            case 5: wl_sweep_pipe<TOut, COST, 2, true>(a, S, Ln, rf2, dlane, dstart); break;
-            case 6: wl_sweep_pipe<TOut, COST, 3, false>(a, S, Ln, rf2, dlane, dstart); break;
-            case 7: wl_sweep_pipe<TOut, COST, 3, true>(a, S, Ln, rf2, dlane, dstart); break;
-            case 8: wl_sweep_pipe<TOut, COST, 4, false>(a, S, Ln, rf2, dlane, dstart); break;
-            default: wl_sweep_pipe<TOut, COST, 4, true>(a, S, Ln, rf2, dlane, dstart); break;
-        }
-    }
-#endif
-
-    // ---- 5b. general sweep (round 2): one voxel per quad and step, all source views, per-view mode branches ----
-    int d1_eff = pipe ? d0 : d1;
+    // ---- 5. sweep: one voxel per quad and step, all source views, per-view mode branches ----
+    int d1_eff = d1;
 #ifdef WL_PROFILE
     const bool wl_skip = a.temp == -12345.0f;   // (phase timing of the staging alone)
     if (wl_skip) d1_eff = d0;
@@ -879,6 +560,14 @@ __global__ __launch_bounds__(WL_THREADS, WL_MIN_WAVES) void warp_cost_lds_kernel
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = s[j] * inv;
         }
+#ifndef WL_PK
+        // The stored value is the fp32 result ROUNDED to fp32, then to 16 bits -- what "compute in fp32, store 16-bit" means and what
+        // the direct kernels do.  Without this the compiler folds the last fma and the conversion into v_fma_mixlo/hi_f16 (ONE rounding
+        // of the exact fma): 0.01-0.4 % of the stored values then differ by one fp16 ulp from the direct kernels' (round 4: found when
+        // the scalar build became the default and the bit-equality tests against the direct kernels failed).
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(o[j]));
+#endif
         if (active) wl_store8<TOut>(out + ((unsigned long)b * a.D + d) * plane_bytes + lane_out, o);
     }
     WL_STAMP(5)
@@ -933,6 +622,7 @@ static int wl_dispatch(const WarpArgs& a, int cost, int nblk, hipStream_t st) {
 // Returns 0 if launched, 1 if this configuration is not covered by the LDS-staged kernel (the caller uses the quad /
 // generic direct kernels), negative on error.
 extern Knob g_warp_tile;   // warp_cost.hip
+static int* g_wl_mode_hist = nullptr;   // set by pscv_debug_wl_mode_hist (development aid, not thread-safe)
 
 int warp_cost_tiled_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, int out_dtype, int ppd_override, hipStream_t st) {
     if (C != 32 || a.depth_per_pixel || geom != PSCV_GEOM_PROJ || (in_dtype != PSCV_F16 && in_dtype != PSCV_BF16)) return 1;
@@ -946,6 +636,7 @@ int warp_cost_tiled_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, in
     a.ppd = ppd;
     a.n_dchunks = (a.D + ppd - 1) / ppd;
     a.variant = g_warp_tile;
+    a.mode_hist = g_wl_mode_hist;
     const long nblk = tiles * a.n_dchunks;
     if (nblk <= 0 || nblk > 0x7fffffffL) { set_error("pscv_warp_cost(lds): bad grid %ld", nblk); return -1; }
     if (in_dtype == PSCV_F16) return out_dtype == PSCV_F32 ? wl_dispatch<f16_t, float>(a, cost, (int)nblk, st)
@@ -957,6 +648,9 @@ int warp_cost_tiled_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, in
 }  // namespace pscv
 
 #ifndef WL_PK
+// Development aid (bench.py's `alt_geometry` / mode histogram): while `hist` (16 device ints, [view 0..3][DIRECT, GEN, FAST, ZERO]) is
+// set, every launch of the LDS-staged kernel from this process adds its per-(workgroup, view) staging modes to it; null turns it off.
+extern "C" void pscv_debug_wl_mode_hist(int* hist) { pscv::g_wl_mode_hist = hist; }
 // occupancy the runtime computes for the f16 variance instantiation (development aid; scripts/dev/wl_occupancy.py)
 extern "C" int pscv_debug_wl_occupancy(int* blocks_per_cu, int* lds_bytes, int* threads) {
     auto kern = pscv::warp_cost_lds_kernel<pscv::f16_t, pscv::f16_t, PSCV_GEOM_PROJ, PSCV_COST_VARIANCE>;
