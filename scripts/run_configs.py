@@ -118,6 +118,18 @@ def time_config(cid: int, reps: int = 3) -> dict:
            "ms_per_forward_eager": dt_eager * 1e3, "replay_max_abs_diff_vs_eager": same,
            "engine_kernel_ms_eager_pass": gpu_ms, "engine_launches": sum(v["launches"] for v in detail.values()),
            "roofline": kernel_rooflines(detail)}
+    if cid == 4:
+        # BASELINE.json names "per-level D = 48" for this configuration: the reference's TRAIN-mode plane count of the coarsest level
+        # (net.py:126-127); its eval mode -- what the line above times -- sweeps 96.  The same forward with 48 coarse planes:
+        with torch.no_grad():
+            net.model.coarse_planes_eval = 48
+            dt48, out48 = timed()
+            net.model.coarse_planes_eval = 96
+        vox48 = cfg["vox"]() - 48 * 64 * 80
+        res["coarse_48_planes"] = {"ms_per_forward": dt48 * 1e3, "voxels": vox48, "voxels_per_s": vox48 / dt48,
+                                   "finite": bool(torch.isfinite(out48["depth"]).all()),
+                                   "what": "the reference's train-mode coarse plane count (BASELINE.json's 'per-level D=48') in the eval forward"}
+        del out48
     del net, out, gout, dev
     torch.cuda.empty_cache()
     return res

@@ -134,6 +134,9 @@ class network(nn.Module):
         self.cost_reg_refine = CostRegNet()
         self.nscale = 2
         self.storage_dtype = torch.float16
+        # fronto-parallel planes of the coarsest level in eval mode: 96 like the reference (net.py:126-127, `48 if self.training else
+        # 96`); BASELINE.json's configuration 4 names the train-mode count 48 -- set this to 48 to run that case in eval mode
+        self.coarse_planes_eval = 96
         # 2-D pyramid tower: "pscv" = MFMA conv2d launches writing channels-last 16-bit maps (default);
         # "torch" = PyTorch-ROCm in fp32, converted where the warp kernel reads them
         self.feature_engine = "pscv"
@@ -232,7 +235,7 @@ class network(nn.Module):
 
             # coarsest level: fronto-parallel sweep, 96 planes in eval mode (net.py:126-127)
             hypos = calSweepingDepthHypo(None if fast_cams else ref_in_ms[:, -1], None if fast_cams else src_in_ms[:, 0, -1], ref_ex, src_ex,
-                                         depth_min, depth_max, nhypothesis_init=96).to(torch.float32).contiguous()
+                                         depth_min, depth_max, nhypothesis_init=int(self.coarse_planes_eval)).to(torch.float32).contiguous()
             cams = warp_cams[-1] if fast_cams else _cams(ref_in_ms[:, -1], [src_in_ms[:, i, -1] for i in range(nsrc)], ref_ex,
                                                          [src_ex[:, i] for i in range(nsrc)])
             cost = ops.warp_cost(cl(ref_pyr[-1]), [cl(p[-1]) for p in src_pyrs],
