@@ -5,9 +5,9 @@ A step = one pass of the hot path (fused warp + variance cost volume -> 3-D U-Ne
 softmax / depth regression / confidence) over one batch of synthetic input that is already resident in
 HBM: BASELINE.json configs[1] = MVSNet, 1 ref + 4 src views, 512x640 images (128x160x32 feature maps),
 D = 192 planes, bf16 storage / fp32 accumulation.  3 932 160 cost-volume voxels per reference view; a batch is
---batch reference views (default 3, each with its own source views; one launch per layer for the whole batch on one
-stream, replayed as a hipGraph; --batch-mode streams = the items on separate HIP streams, the round-3 experiment;
---batch 1 = one view at a time as in rounds 1-2, also reported in every line).
+--batch reference views (default 3, each with its own source views; --batch-mode streams, the default: each view's launches on
+its own HIP stream, forked and joined INSIDE one replayed hipGraph; --batch-mode batched = one launch per layer for the whole
+batch on one stream, replayed as a hipGraph; --batch 1 = one view at a time as in rounds 1-2, also reported in every line).
 
 Multi-GPU (--gpus N, one process per GPU): reference views are independent objects, so each rank sweeps its own
 view (global batch = N) with no data-path collective -> weak scaling.  Ranks come either from a launcher
@@ -272,6 +272,10 @@ SHARDED = {
     # BASELINE configuration 3: Vis-MVSNet 5-view 512x640, depth planes [192,32,16] sharded over the ranks (LSE-merged heads)
     "depth": dict(config=3, model="vis", V=5, H=512, W=640, kw=dict(depth_nums=[192, 32, 16], interval_scales=[128 / 192, 1, 0.5]),
                   vox=192 * 64 * 80 + 32 * 128 * 160 + 16 * 256 * 320, setter="set_depth_group"),
+    # the same configuration with NO replicated stage (round 4): stage 1 by depth planes, the per-pixel stages 2-3 by image rows
+    # (SingleStage.forward_row_shard: slab + recomputed 16-row halo, one all-gather of the small output maps per stage)
+    "depth_rows": dict(config=3, model="vis", V=5, H=512, W=640, kw=dict(depth_nums=[192, 32, 16], interval_scales=[128 / 192, 1, 0.5]),
+                       vox=192 * 64 * 80 + 32 * 128 * 160 + 16 * 256 * 320, setter="set_depth_row_groups"),
     # BASELINE configuration 5: Vis-MVSNet 9-view 1152x1600 [256,32,16], the 8 source views sharded over the ranks (16-bit shares of
     # the visibility-weighted sums reduce-scattered into depth / row slabs, slab-sharded RegFuse: the "RCCL variance reduce" of that model)
     "view": dict(config=5, model="vis", V=9, H=1152, W=1600, kw=dict(depth_nums=[256, 32, 16], interval_scales=[0.5, 1, 0.5]),
@@ -372,8 +376,8 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=3, help="reference views per step and GPU (each with its own 4 source views): the engine runs "
                                                           "the items of a batch as one launch per layer (1 = one view at a time, as in rounds 1-2)")
-    ap.add_argument("--batch-mode", choices=["streams", "batched"], default="batched",
-                    help="how the views of a step are launched: 'streams' = each view's 13 launches on its own HIP stream (eager; up to 4 views), "
+    ap.add_argument("--batch-mode", choices=["streams", "batched"], default="streams",
+                    help="how the views of a step are launched: 'streams' (default) = each view's 13 launches on its own HIP stream, forked inside the replayed graph (up to 4 views), "
                          "'batched' = one launch per layer for the whole batch on one stream, replayed as a hipGraph")
     ap.add_argument("--no-training", action="store_true", help="skip the two MVSNet training-step timings (scripts/bench_train.py) reported under 'training'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -539,10 +543,9 @@ def run(args):
                 depth, conf = step()
             torch.cuda.synchronize()
             graph = None
-            # a batch of several views runs its items on separate streams with EAGER launches: forked into a hipGraph the same
-            # step replays wrongly on ROCm 7.2 once inputs change (MVSNet._hot_path_streams), and the host keeps ahead of the
-            # GPU anyway (~40 launches per ~1 ms step)
-            if not args.eager and (NB == 1 or not streams_mode):
+            # the step is captured once and replayed; with --batch-mode streams the per-view fork / join is part of the graph (parallel
+            # branches: correct on changing inputs since round 4, tests/test_gpu_mvsnet.py, scripts/dev/streams_graph_probe.py)
+            if not args.eager:
                 # the 13-launch step is launch-gap bound between its small kernels: capture it once, replay it
                 try:
                     graph = torch.cuda.CUDAGraph()
@@ -670,9 +673,9 @@ def run(args):
                        "one_view_at_a_time_ms": None if one_view is None else one_view * 1e3,
                        "one_view_at_a_time_voxels_per_s": None if one_view is None else world * VOX / one_view},
             "timing": ("hipGraph replay of the step" if graph else "eager launches") +
-                      (f"; the {NB} views of a step run on {NB} HIP streams: one view's vector-ALU-bound warp beside another's MFMA / "
-                       "memory-bound U-Net (MVSNet._hot_path_streams: eager), so a step is SHORTER than the sum of "
-                       "its kernels' stand-alone durations below" if streams_mode else
+                      (f"; the {NB} views of a step run on {NB} HIP streams forked inside the replayed graph: one view's vector-ALU-bound warp "
+                       "beside another's MFMA / memory-bound U-Net (MVSNet._hot_path_streams), so a step is SHORTER than the sum of its "
+                       "kernels' stand-alone durations below" if streams_mode else
                        f"; the {NB} views of a step share ONE launch per layer (batched grids, one stream)" if NB > 1 else "") +
                       f"; kernels_us / roofline: HIP events of an eager pass of the same {args.steps} steps, one view after the other on one "
                       f"stream (each launch timed alone; {elapsed_eager / args.steps * 1e3:.3f} ms/step that way)",

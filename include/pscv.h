@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PSCV_ABI_VERSION 6
+#define PSCV_ABI_VERSION 7
 
 /* storage dtypes */
 #define PSCV_F32 0
@@ -86,6 +86,8 @@ int pscv_abi_version(void);
  *               also selects the direct kernel.  3: DIAGNOSTIC ONLY -- the same kernel compiled with packed fp32 instructions
  *               (same stored bits, ~7 % faster alone), which returns wrong voxels while other kernels share its CUs
  *               (scripts/ubench/lds_pk_overlap.hip); nothing in the engine selects it.
+ *   "warp_lds_pad" KiB of LDS the LDS-staged warp kernel requests on top of its need (0 = default): fewer workgroups per CU with
+ *               the same code (occupancy / stream co-residency experiments)
  *   "sweep_dc"  depth planes per workgroup of the depth-sweep convs (0 = default heuristic)
  *   "sweepc_slots" resident-workgroup target that sizes the depth chunks of the 8|16 -> 8 depth-sweep conv (0 = 768)
  *   "sweepc_pd" prefetch distance in iterations (1..3) of the same kernel (0 = 1)
@@ -151,6 +153,18 @@ int pscv_homog_cams(const float* ref_cam, const float* src_cams, int B, int n_sr
 int pscv_warp_cost(const void* ref, const void* const* srcs, int n_src, const float* cams, const float* depth,
                    long depth_bstride, int depth_per_pixel, int geom, int cost, float temp, void* out, int B, int C,
                    int h, int w, int hs, int ws, int D, int in_dtype, int out_dtype, void* stream);
+
+/*
+ * pscv_warp_cost on a ROW SLAB of the reference image (ABI 7; the row-sharded Vis-MVSNet stages of a multi-GPU forward,
+ * wild_deep_mvs_amd/models/VisMVSNet/model_cas.py forward_row_shard): `ref`, a per-pixel `depth` and `out` hold rows
+ * [ref_y0, ref_y0 + h) of the full reference grid, the cameras are those of the WHOLE image, and every reference pixel is
+ * evaluated at the coordinates (x, y + ref_y0) it has there -- the same fp32 operations on the same values as the
+ * whole-image launch, so the slab's voxels are bit-identical to the corresponding rows of pscv_warp_cost's output.
+ * ref_y0 = 0 is pscv_warp_cost.
+ */
+int pscv_warp_cost_rows(const void* ref, const void* const* srcs, int n_src, const float* cams, const float* depth,
+                        long depth_bstride, int depth_per_pixel, int geom, int cost, float temp, void* out, int B, int C,
+                        int h, int w, int hs, int ws, int D, int in_dtype, int out_dtype, int ref_y0, void* stream);
 
 /*
  * Second half of a source-view-sharded variance cost volume (MVSNet / CVP-MVSNet): after the all-reduce of the

@@ -298,6 +298,93 @@ def test_vis_depth_plane_shard_two_ranks_one_gpu():
         assert rel <= 1e-3
 
 
+def _vis_row_shard_worker(rank, world, port, q):
+    _init(rank, world, port)
+    try:
+        from wild_deep_mvs_amd import synthetic
+        from wild_deep_mvs_amd.models.VisMVSNet.frontend import Frontend
+        dev = torch.device("cuda", rank if os.environ.get("PSCV_TEST_BACKEND") == "nccl" else 0)
+        net = Frontend()
+        net.load_state_dict(synthetic.sharpened_state_dict("vis", synthetic.template_of(net), seed=0))
+        net = net.to(dev).eval()
+        kw = dict(depth_nums=[64, 16, 8], interval_scales=[2.0, 2.0, 1.0])
+        net.depth_nums, net.interval_scales = kw["depth_nums"], kw["interval_scales"]
+        scene = {k: v.to(dev) for k, v in synthetic.make_scene(1, 4, 384, 320, seed=2).items()}       # stage heights 48 / 96 / 192
+        args = (scene["imgs"], scene["K"], scene["R"], scene["t"], scene["depth_min"], scene["depth_max"])
+        stages = (net.model.stage1, net.model.stage2, net.model.stage3)
+        calls, hooks = [], []
+        for st in stages:
+            hooks.append(st.register_forward_pre_hook(lambda m, a, k: calls.append((a, k)), with_kwargs=True))
+        with torch.no_grad():
+            want = net(*args, **kw)                                          # unsharded, same process
+        for h in hooks:
+            h.remove()
+        flat = lambda o: [o[0], o[1]] + [p[0] for p in o[2]] + [p[1][0] for p in o[2]]
+        per_stage = []
+        with torch.no_grad():
+            for st, (a, k) in zip(stages, calls):                            # (1) every stage on exactly the inputs of the unsharded run
+                ref = flat(st(*a, **k))
+                st.row_group = dist.group.WORLD
+                got = flat(st(*a, **k))
+                st.row_group = None
+                per_stage.append([((got[0] - ref[0]).abs().mean() / ref[0].abs().mean()).item()] +
+                                 [(got[1] - ref[1]).abs().mean().item(), ((got[1] - ref[1]).abs() > 1e-3).float().mean().item()] +
+                                 [(g - r).abs().max().item() / max(r.abs().max().item(), 1e-30) for g, r in zip(got[2:], ref[2:])])
+            # (2) the whole cascade with NO stage replicated: stage 1 (64 planes) by depth planes, the per-pixel stages 2-3 by rows
+            # (+ the 2-D extractor sharded by views: each rank extracts two of the four views, one all-gather per scale)
+            net.set_depth_row_groups(dist.group.WORLD)
+            out = net(*args, **kw)
+        rel = ((out["depth"] - want["depth"]).abs().mean() / want["depth"].abs().mean()).item()
+        pair_rel = max(((g[0] - w[0]).abs().max() / w[0].abs().max()).item() for g, w in zip(out["depth_pair_list"][0], want["depth_pair_list"][0]))
+        q.put((rank, per_stage, rel, pair_rel))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@_retry_infra
+def test_vis_row_slab_shard_two_ranks_one_gpu():
+    """Round 4 (the round-3 review: the depth-plane shard leaves the cascade's stages 2-3 -- 32 / 16 per-pixel planes -- replicated):
+    `SingleStage.forward_row_shard` runs a whole stage on the rank's image rows + a recomputed 16-row halo (reference map, per-pixel
+    depth starts and principal point cropped to the slab; one all-gather of the owned rows of the small output maps).  Stage by stage
+    on the inputs of the unsharded run: the slab's cost volume is bit-identical to the unsharded rows (`pscv_warp_cost_rows`,
+    tests/test_gpu_warp_cost.py); pair depths / uncertainties and the fused depth are held to the bars of the depth-plane shard
+    (1e-4 max / 2e-4 rel-L1: a smaller volume may select another conv kernel variant = another fp32 summation order in front of a
+    16-bit rounding), the +-2-plane window probability in the mean.  Then the
+    cascade with stage 1 depth-sharded and stages 2-3 row-sharded -- no stage replicated -- against the unsharded forward."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_vis_row_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0, f"a rank process exited with code {p.exitcode}"
+    for rank, per_stage, rel, pair_rel in res:
+        for si, errs in enumerate(per_stage):
+            print(f"[parity] row-slab shard rank {rank} stage {si + 1}: depth rel-L1 {errs[0]:.2e}, window prob mean abs {errs[1]:.2e} "
+                  f"(moved > 1e-3: {errs[2]:.2e}), pair depth / uncertainty max rel " + " ".join(f"{e:.1e}" for e in errs[3:]), flush=True)
+            n_pairs = (len(errs) - 3) // 2
+            assert errs[0] <= 2e-4 and errs[1] <= 2e-4 and errs[2] <= 1e-2
+            # measured: stages 1-2 0.0 on every pair map; the finest stage 1-2e-5 (depths) / 2e-4 (log-uncertainties, max norm)
+            assert max(errs[3:3 + n_pairs]) <= 1e-4 and max(errs[3 + n_pairs:]) <= 1e-3
+        print(f"[parity] row-slab shard rank {rank}: cascade (stage 1 by planes, stages 2-3 by rows) depth rel-L1 vs unsharded {rel:.3e}, "
+              f"finest-stage pair depths max rel {pair_rel:.2e}", flush=True)
+        assert rel <= 1e-3
+
+
+@pytest.mark.skipif(not torch.cuda.is_available() or torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: 2+ MI355X")
+@pytest.mark.timeout(300)
+def test_vis_row_slab_shard_two_ranks_nccl(monkeypatch):
+    monkeypatch.setenv("PSCV_TEST_BACKEND", "nccl")
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    test_vis_row_slab_shard_two_ranks_one_gpu()
+
+
 def _vis_view_slab_worker(rank, world, port, q):
     _init(rank, world, port)
     try:
@@ -489,7 +576,7 @@ def _bench_sharded_worker(rank, world, port, q):
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         import bench
         dev = torch.device("cuda", rank if os.environ.get("PSCV_TEST_BACKEND") == "nccl" else 0)
-        res = bench.sharded_legs(dist, dev, world, rank, reps=1, only=("mvsnet_depth", "depth", "view"))
+        res = bench.sharded_legs(dist, dev, world, rank, reps=1, only=("mvsnet_depth", "depth", "depth_rows", "view"))
         q.put((rank, res))
     finally:
         dist.destroy_process_group()
@@ -513,7 +600,7 @@ def test_bench_sharded_legs_two_ranks_one_gpu():
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    assert res[1] is None and set(res[0]) == {"mvsnet_depth", "depth", "view"}
+    assert res[1] is None and set(res[0]) == {"mvsnet_depth", "depth", "depth_rows", "view"}
     for mode, r in res[0].items():
         assert "error" not in r, r
         print(f"[bench sharded] {mode}: 1 GPU {r['ms_per_forward_1gpu']:.2f} ms, 2 ranks {r['ms_per_forward_sharded']:.2f} ms, "
@@ -548,7 +635,7 @@ def _rccl_one_rank_worker(port, q):
         rows = pd.gather_rows(torch.ones(1, 2, 3, 5, device=dev), 3, 3, None)
         assert rows.shape == (1, 2, 3, 5)
         # the three shardings of bench.py's "sharded" object, each against the unsharded run
-        res = bench.sharded_legs(dist, dev, 1, 0, reps=1, only=("mvsnet_depth", "depth", "view"))
+        res = bench.sharded_legs(dist, dev, 1, 0, reps=1, only=("mvsnet_depth", "depth", "depth_rows", "view"))
         q.put(res)
     except Exception as e:      # (the parent must not wait for its queue time-out)
         import traceback
@@ -572,7 +659,7 @@ def test_rccl_backend_one_rank_runs_every_sharded_path():
     assert "worker" not in res, res["worker"]["error"]
     assert p.exitcode == 0, f"the rank process exited with code {p.exitcode}"
     print("[rccl one rank]", res, flush=True)
-    assert res and set(res) == {"mvsnet_depth", "depth", "view"}, "a sharded leg did not run"
+    assert res and set(res) == {"mvsnet_depth", "depth", "depth_rows", "view"}, "a sharded leg did not run"
     for mode, leg in res.items():
         assert "error" not in leg, (mode, leg)
         # a world of one: the same planes / views, merged through the partial-sum path (Vis depth shard: another summation order)

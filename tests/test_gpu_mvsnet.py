@@ -238,15 +238,16 @@ def test_batch_items_on_separate_streams_equal_the_one_item_runs(env, B):
     """``MVSNet._hot_path_streams``: the reference views of a batch run on their own HIP streams (one item's VALU-bound warp
     beside another's MFMA / memory-bound U-Net), eager launches only.  The inputs CHANGE from call to call (a stale read or a
     race between the streams must show): depth and confidence equal the one-item runs bit for bit on every one of eight
-    calls, and the stream-less batched launches (``batch_streams = False``) to fp32 order.  Under a hipGraph capture the
-    forward must NOT fork (multi-branch graphs of this path replay wrongly on ROCm 7.2 when inputs change): a captured forward
-    replayed on changing inputs equals the eager result bit for bit."""
+    calls, and the stream-less batched launches (``batch_streams = False``) to fp32 order.  Under a hipGraph capture the fork
+    becomes parallel branches of the graph (``batch_streams_capture``, default since round 4): six replays on CHANGING inputs equal
+    the one-item runs bit for bit -- round 3 saw such graphs replay wrongly; the cause was the packed warp build's overlap defect
+     -- and with ``batch_streams_capture = False`` the captured forward does not fork and equals the batched run."""
     L, ops, synthetic, MVSNet, O = env
     net = MVSNet("variance")
     net.load_state_dict(synthetic.sharpened_state_dict("mvsnet", synthetic.template_of(net), seed=0))
     net = net.cuda().eval()
     net.num_depth, net.graph_replay = 32, False
-    net.batch_streams = True          # (opt-in since round 3: the stream mode sweeps with the direct-tap kernels, DESIGN.md section 6)
+    net.batch_streams = True          # (opt-in: a caller's batch otherwise runs as one launch per layer on the caller's stream)
     keys = ("imgs", "K", "R", "t", "depth_min", "depth_max")
 
     def batch_of(seed0):
@@ -264,22 +265,31 @@ def test_batch_items_on_separate_streams_equal_the_one_item_runs(env, B):
                 assert torch.equal(got["depth"][b], singles[b]["depth"][0]), (it, b)
                 assert torch.equal(got["photometric_confidence"][b], singles[b]["photometric_confidence"][0]), (it, b)
             assert float((plain["depth"] - got["depth"]).abs().max()) <= 1e-5 * float(got["depth"].abs().max())
-        # captured: no fork inside the graph; replays on changing inputs are right
-        scenes, batch = batch_of(100)
-        static = {k: batch[k].clone() for k in keys}
-        for _ in range(2):
-            net(*[static[k] for k in keys])
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            out = net(*[static[k] for k in keys])
-        for rep in range(6):
-            scenes, batch = batch_of(200 + 5 * rep)
-            for k in keys:
-                static[k].copy_(batch[k])
-            g.replay()
+        for fork in (True, False):
+            # captured: the fork is part of the graph (or, fork = False, the plain batched launches); replays on changing inputs are right
+            net.batch_streams_capture = fork
+            scenes, batch = batch_of(100)
+            static = {k: batch[k].clone() for k in keys}
+            for _ in range(2):
+                net(*[static[k] for k in keys])
             torch.cuda.synchronize()
-            net.batch_streams = False
-            want = net(*[batch[k] for k in keys])
-            net.batch_streams = True
-            assert torch.equal(out["depth"], want["depth"]) and torch.equal(out["photometric_confidence"], want["photometric_confidence"]), rep
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = net(*[static[k] for k in keys])
+            for rep in range(6):
+                scenes, batch = batch_of(200 + 5 * rep)
+                for k in keys:
+                    static[k].copy_(batch[k])
+                g.replay()
+                torch.cuda.synchronize()
+                net.batch_streams = False
+                if fork:
+                    singles = [net(*[sc[k].cuda() for k in keys]) for sc in scenes]
+                    ok = all(torch.equal(out["depth"][b], singles[b]["depth"][0]) and
+                             torch.equal(out["photometric_confidence"][b], singles[b]["photometric_confidence"][0]) for b in range(B))
+                else:
+                    want = net(*[batch[k] for k in keys])
+                    ok = torch.equal(out["depth"], want["depth"]) and torch.equal(out["photometric_confidence"], want["photometric_confidence"])
+                net.batch_streams = True
+                assert ok, (fork, rep)
+        net.batch_streams_capture = True

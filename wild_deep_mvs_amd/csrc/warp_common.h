@@ -21,6 +21,8 @@ struct WarpArgs {
     float temp;
     float sx, sy;        // index scale: PROJ 1, HOMOG (W-1)/W
     float xlo, xhi, ylo, yhi;  // clamp of the pixel index implied by the reference's grid clamp
+    int ref_y0;          // row of the FULL reference image the first row of this launch is (pscv_warp_cost_rows: a row slab computes with the
+                         // pixel coordinates it has in the whole image); 0 for whole-image launches
     int* mode_hist;      // development aid of the LDS-staged kernel (pscv_debug_wl_mode_hist): [view][mode] counters of its per-(block, view) staging modes; null = off
 };
 

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256, 4) void warp_cost_kernel(const WarpArgs a) {
     const int y = pflat / a.w;
     const int x = pflat - y * a.w;
     const float off = (GEOM == PSCV_GEOM_HOMOG) ? 0.5f : 0.0f;   // homography.py:78-79 half-pixel centres
-    const float px = (float)x + off, py = (float)y + off;
+    const float px = (float)x + off, py = (float)(y + a.ref_y0) + off;
 
     // Depth-independent part of the warp, once per (pixel, view) instead of once per (plane, view):
     //   PROJ   q = rot (x, y, 1) * d + trans         -> rot (x, y, 1)                        module.py:138-144
@@ -348,6 +348,7 @@ static int launch_channels(WarpArgs& a, int C, int geom, int cost, hipStream_t s
 namespace pscv {
 Knob g_warp_tile = {0, KNOB_WARP_TILE};       // warp_cost_tiled.hip variants (measurement)
 Knob g_fuse_c0 = {0, KNOB_FUSE_C0};           // reserved: fused warp -> conv0 experiment
+Knob g_warp_lds_pad = {0, KNOB_WARP_LDS_PAD};       // KiB of LDS the LDS-staged warp kernel requests on top of its need (fewer workgroups per CU)
 extern Knob g_conv2d_wlds;                    // conv2d.hip
 extern Knob g_conv_tall64;                    // conv3d.hip
 }
@@ -360,7 +361,7 @@ static Knob* find_knob(const char* key) {
         {"warp_tiled", &g_warp_tiled}, {"warp_q2", &g_warp_q2}, {"c1_nb", &g_c1_nb}, {"c1_sweep", &g_c1_sweep},
         {"sweep_th16", &g_sweep_th16}, {"sweep_dc", &g_sweep_dc}, {"sweep_kdm", &g_sweep_kdm}, {"sweep_kdm_pd", &g_sweep_kdm_pd}, {"sweepc_slots", &g_sweepc_slots}, {"sweepc_pd", &g_sweepc_pd},
         {"warp_bwd_direct", &g_warp_bwd_direct}, {"conv_s2_sweep", &g_conv_s2_sweep}, {"s2s_slots", &g_s2s_slots},
-        {"warp_tile", &g_warp_tile}, {"fuse_c0", &g_fuse_c0}, {"conv2d_wlds", &g_conv2d_wlds}, {"conv_tall64", &g_conv_tall64}, {"block8_slots", &::g_block8_slots}, {"softargmin_small", &::g_softargmin_small}};
+        {"warp_tile", &g_warp_tile}, {"fuse_c0", &g_fuse_c0}, {"warp_lds_pad", &g_warp_lds_pad}, {"conv2d_wlds", &g_conv2d_wlds}, {"conv_tall64", &g_conv_tall64}, {"block8_slots", &::g_block8_slots}, {"softargmin_small", &::g_softargmin_small}};
     for (const auto& e : table)
         if (!strcmp(key, e.name)) return e.k;
     return nullptr;
@@ -399,7 +400,16 @@ extern "C" int pscv_warp_cost(const void* ref, const void* const* srcs, int n_sr
                               const float* depth, long depth_bstride, int depth_per_pixel, int geom, int cost,
                               float temp, void* out, int B, int C, int h, int w, int hs, int ws, int D, int in_dtype,
                               int out_dtype, void* stream) {
+    return pscv_warp_cost_rows(ref, srcs, n_src, cams, depth, depth_bstride, depth_per_pixel, geom, cost, temp, out, B, C, h, w, hs, ws, D,
+                               in_dtype, out_dtype, 0, stream);
+}
+
+extern "C" int pscv_warp_cost_rows(const void* ref, const void* const* srcs, int n_src, const float* cams,
+                                   const float* depth, long depth_bstride, int depth_per_pixel, int geom, int cost,
+                                   float temp, void* out, int B, int C, int h, int w, int hs, int ws, int D, int in_dtype,
+                                   int out_dtype, int ref_y0, void* stream) {
     using namespace pscv;
+    PSCV_CHECK_ARG(ref_y0 >= 0 && ref_y0 < (1 << 20), "pscv_warp_cost_rows: ref_y0=%d", ref_y0);
     PSCV_CHECK_ARG(n_src >= 1 && n_src <= PSCV_MAX_SRC, "pscv_warp_cost: n_src=%d outside [1,%d]", n_src, PSCV_MAX_SRC);
     PSCV_CHECK_ARG(srcs && cams && depth && out, "pscv_warp_cost: null pointer argument");
     PSCV_CHECK_ARG(cost == PSCV_COST_WARP_ONLY || cost == PSCV_COST_VARIANCE_PARTIAL || ref, "pscv_warp_cost: ref is required for cost mode %d", cost);
@@ -410,6 +420,7 @@ extern "C" int pscv_warp_cost(const void* ref, const void* const* srcs, int n_sr
     PSCV_CHECK_ARG((long)hs * ws < (1L << 24) && (long)hs * ws * C * 4 < (1L << 32), "pscv_warp_cost: source map %dx%dx%d too large", hs, ws, C);
     WarpArgs a;
     a.mode_hist = nullptr;
+    a.ref_y0 = ref_y0;
     a.ref = ref;
     for (int i = 0; i < PSCV_MAX_SRC; ++i) a.src[i] = i < n_src ? srcs[i] : nullptr;
     for (int i = 0; i < n_src; ++i) PSCV_CHECK_ARG(srcs[i], "pscv_warp_cost: srcs[%d] is null", i);

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256, 4) void warp_cost_q2_kernel(const WarpArgs a) 
     const int y = pflat / a.w;
     const int x = pflat - y * a.w;
     const float off = (GEOM == PSCV_GEOM_HOMOG) ? 0.5f : 0.0f;   // homography.py:78-79 half-pixel centres
-    const float px = (float)x + off, py = (float)y + off;
+    const float px = (float)x + off, py = (float)(y + a.ref_y0) + off;
 
     // depth-independent ray terms once per (pixel, view); the four lanes of a quad write identical values and only
     // their own wave reads the slot back (program order suffices)

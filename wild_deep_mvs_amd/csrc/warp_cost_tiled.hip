@@ -242,7 +242,7 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
     x = min(x, a.w - 1); y = min(y, a.h - 1);
     const int hw = a.h * a.w;
     const int pflat = y * a.w + x;
-    const float px = (float)x, py = (float)y;
+    const float px = (float)x, py = (float)(y + a.ref_y0);
     const unsigned chb = (unsigned)l * 16u;
     float rx, ry, rz, tx, ty_, tz;     // view l: depth-independent ray terms rot (x, y, 1) and the translation
     {
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
         const float dmin = wl_wave_reduce<false>(dlane), dmax = wl_wave_reduce<true>(dlane);   // (planes need not be monotone)
         const int corner = lane & 7;
         const float cx = (corner & 1) ? (float)min(x0t + WL_T - 1, a.w - 1) : (float)x0t;
-        const float cy = (corner & 2) ? (float)min(y0t + WL_TH - 1, a.h - 1) : (float)y0t;
+        const float cy = (float)(((corner & 2) ? min(y0t + WL_TH - 1, a.h - 1) : y0t) + a.ref_y0);
         const float d = (corner & 4) ? dmax : dmin;
         int used = 0;
 #pragma unroll
@@ -593,16 +593,12 @@ template <typename TIn, typename TOut, int COST>
 static int wl_launch(const WarpArgs& a, int nblk, hipStream_t st) {
     auto kern = warp_cost_lds_kernel<TIn, TOut, PSCV_GEOM_PROJ, COST>;
     static bool attr_done = false;
-    int lds = WL_LDS;
-#ifdef PSCV_ABLATE
-    {   // occupancy experiment (scripts/dev/wl_residency.py): pscv_set_tuning("fuse_c0", k) asks for k KiB of LDS on top, i.e. fewer
-        extern Knob g_fuse_c0;                                  // workgroups per CU with the same code
-        lds += 1024 * g_fuse_c0;
-        attr_done = false;
-    }
-#endif
+    // "warp_lds_pad" (KiB, measurement knob): ask for more LDS than the kernel needs = fewer workgroups per CU with the same code --
+    // the occupancy experiment of scripts/dev/wl_residency.py and the stream-mode co-residency runs (room for another stream's conv0)
+    extern Knob g_warp_lds_pad;
+    const int lds = min(WL_LDS + 1024 * max(0, (int)g_warp_lds_pad), 160 * 1024);
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { set_error("pscv_warp_cost(lds): hipFuncSetAttribute: %s", hipGetErrorString(e)); return -2; }
         attr_done = true;
     }

@@ -269,10 +269,12 @@ class MVSNet(ReplayHooks, nn.Module):
         # boundary plane with each neighbour, the softmax over D is merged from log-sum-exp partials.  Strong scaling of ONE
         # reference view; pays off when a rank's share of the regulariser outweighs ~10 point-to-point latencies
         self.depth_group = None
-        # batch items of the eval-mode hot path on separate HIP streams (``_hot_path_streams``).  OFF by default since the end of
-        # round 3: the LDS-staged warp kernel returns wrong voxels while the regulariser's conv kernels of ANOTHER stream run on
-        # the same GPU; the batched launches on one stream have the same throughput under graph replay.
-        # When switched on, the stream mode sweeps with the kernel's build without packed fp32 instructions, which is reproducible there.
+        # batch items of the eval-mode hot path on separate HIP streams (``_hot_path_streams``): off by default (a caller's batch runs as
+        # one launch per layer on the caller's stream); bench.py switches it on.  Every kernel is bit-stable under that overlap since
+        # round 4 (tests/test_gpu_overlap.py).  ``batch_streams_capture``: under a hipGraph capture the fork becomes parallel branches
+        # of the graph -- correct on replay with changing inputs since the warp kernel ships as its scalar build (round 3 saw wrong
+        # replays and blamed ROCm; it was the packed build's overlap defect), 3 % faster than the batched graph at three views.
+        self.batch_streams_capture = True
         self.batch_streams = False
 
     # -- upstream ---------------------------------------------------------------------------
@@ -385,7 +387,7 @@ class MVSNet(ReplayHooks, nn.Module):
             return self._hot_path_depth_shard(features_cl, proj, depth_values, reference_frame)
         B = features_cl[0].shape[0]
         if (2 <= B <= self.MAX_BATCH_STREAMS and self.batch_streams and taps is None and self.view_group is None and features_cl[0].is_cuda
-                and not torch.cuda.is_current_stream_capturing()):
+                and (not torch.cuda.is_current_stream_capturing() or self.batch_streams_capture)):
             return self._hot_path_streams(features_cl, proj, depth_values, reference_frame)
         V = len(features_cl)
         src_idx = [i for i in range(V) if i != reference_frame]
@@ -405,13 +407,12 @@ class MVSNet(ReplayHooks, nn.Module):
         item b therefore runs on its own HIP stream (fork from / join into the caller's stream), so that one item's warp shares
         the chip with another item's U-Net: measured at the headline size with eager launches, two views 0.673-0.693 ms against
         0.725-0.740 ms for the batched launches on one stream, three views ~0.33 ms per view (`scripts/dev/graph_branch_toy.py`,
-        `bench.py`), outputs bit-equal to the one-item runs (tests/test_gpu_mvsnet.py).  EAGER ONLY: under a hipGraph capture the
-        items would become parallel branches of the graph, and ROCm 7.2 replays such graphs of this path WRONGLY as soon as the
-        inputs change between replays (`scripts/dev/graph_branch_probe.py`, `graph_branch_bisect.py`: a branch's cost volume is
-        exact while the branch ends there and off by 0.4 once a conv node follows it; a toy graph of element-wise kernels
-        replays fine) -- with static inputs the error is invisible, which is how a bench would never notice.  So a capturing
-        stream takes the plain batched launches (`hot_path` checks), and the host's launch rate (39 launches per 3-view step)
-        is far from binding at this size.  At most MAX_BATCH_STREAMS items; `net.batch_streams = False` turns it off."""
+        `bench.py`), outputs bit-equal to the one-item runs (tests/test_gpu_mvsnet.py).  Under a hipGraph capture the items become
+        parallel branches of the graph (``batch_streams_capture``): round 3 saw such graphs replay WRONGLY once inputs changed and blamed
+        ROCm 7.2; the cause was the overlap defect of the packed warp build.  With the scalar build 12 of 12
+        replays on changing inputs equal the one-item runs bit for bit (`scripts/dev/streams_graph_probe.py`, tests/test_gpu_mvsnet.py)
+        and the forked graph is the fastest form of the three-view step (0.973 ms against 1.007 batched, 1.075 eager streams).
+        At most MAX_BATCH_STREAMS items; `net.batch_streams = False` turns it off."""
         B = features_cl[0].shape[0]
         dev = features_cl[0].device
         pool = self.__dict__.setdefault("_side_streams", {})

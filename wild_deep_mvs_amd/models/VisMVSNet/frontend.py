@@ -50,6 +50,29 @@ class Frontend(ReplayHooks, nn.Module):
         for st in (self.model.stage1, self.model.stage2, self.model.stage3):
             st.depth_group = group
 
+    feature_shard_group = None     # see set_depth_row_groups
+
+    def set_row_group(self, group, stages=(2, 3)):
+        """Shard the image ROWS of the given cascade stages (1-based; default: the per-pixel stages 2 and 3, whose 32 / 16 planes
+        leave nothing to shard along depth) over a torch.distributed group; the other stages are left as they are.  Combined with
+        ``set_stage_depth_group(group, stages=(1,))`` no stage of configuration 3 runs replicated."""
+        for k, st in enumerate((self.model.stage1, self.model.stage2, self.model.stage3), start=1):
+            if k in stages:
+                st.row_group = group
+
+    def set_depth_row_groups(self, group):
+        """The shard of configuration 3 with no replicated stage (round 4): stage 1 (64-192 fronto-parallel planes) by depth planes,
+        the per-pixel stages 2-3 (32 / 16 planes) by image rows.  ``None`` removes both."""
+        self.set_stage_depth_group(group, stages=(1,))
+        self.set_row_group(group, stages=(2, 3))
+        self.feature_shard_group = group          # the 2-D extractor too: rank r extracts views r, r + G, ...; one all-gather per scale
+
+    def set_stage_depth_group(self, group, stages=(1,)):
+        """``set_depth_group`` for selected stages only (1-based)."""
+        for k, st in enumerate((self.model.stage1, self.model.stage2, self.model.stage3), start=1):
+            if k in stages:
+                st.depth_group = group
+
     def fill_cam_array(self, K, R, t, start_depth, depth_interval):
         b = K.shape[0]
         cam = torch.zeros((b, 2, 4, 4), device=K.device)
@@ -106,8 +129,30 @@ class Frontend(ReplayHooks, nn.Module):
             fe = (lambda x: self.model.feat_ext.forward_engine(x, self.storage_dtype)) if engine else self.model.feat_ext
             for st in (self.model.stage1, self.model.stage2, self.model.stage3):
                 st._channels_last_features = engine
+            fgrp = getattr(self, "feature_shard_group", None)
             if self.training:
                 pass
+            elif fgrp is not None and grp is None and engine and len({tuple(i.shape) for i in imgs}) == 1:
+                # depth / row shards need every view's maps on every rank: extract V / G views here, all-gather the rest (16-bit
+                # channels-last maps, 6.9 MB per view at 512x640) instead of running the whole extractor G times over
+                import torch.distributed as dist
+                world, rank = dist.get_world_size(fgrp), dist.get_rank(fgrp)
+                slots = (v + world - 1) // world
+                mine = [j for j in range(v) if j % world == rank]
+                maps = fe(torch.cat([imgs[order[j]] for j in mine], 0)) if mine else None
+                per_scale = []
+                for k in range(3):
+                    if maps is not None:
+                        shp = (slots * n,) + tuple(maps[k].shape[1:])
+                        buf = maps[k].new_zeros(shp)
+                        buf[:len(mine) * n] = maps[k]
+                    else:   # (more ranks than views: this rank only joins the collective; shapes from an empty extractor pass are not
+                        raise ValueError("feature shard: more ranks than views")          # available, so refuse -- 2-9 views, <= 8 ranks)
+                    got = [torch.empty_like(buf) for _ in range(world)]
+                    dist.all_gather(got, buf.contiguous(), group=fgrp)
+                    per_scale.append([got[j % world][(j // world) * n:(j // world + 1) * n] for j in range(v)])
+                ref_feats = tuple(per_scale[k][0] for k in range(3))
+                src_feats = [tuple(per_scale[k][j + 1] for k in range(3)) for j in range(len(src_idx))]
             elif grp is None and len({tuple(i.shape) for i in imgs}) == 1:
                 # all views through the 2-D extractor as one batch (same result as the per-view loop in eval mode)
                 if imgs_all is not None and reference_frame == 0:

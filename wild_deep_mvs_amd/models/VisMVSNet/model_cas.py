@@ -315,11 +315,17 @@ class SingleStage(nn.Module):
         # the planes it owns plus a 16-plane halo per side (the pair U-Net + head and the fuse U-Net + head each reach 8
         # planes), and the softmax over D is merged from per-rank partials.  The reference has no counterpart.
         self.depth_group = None
+        # row-slab shard (round 4; the cascade's stages 2-3 have 32 / 16 planes per-pixel: nothing to shard along depth): with a
+        # group set here, rank r runs the WHOLE stage -- warp, pair U-Nets, UncertNet, fusion, fuse U-Net, heads -- on the image rows
+        # it owns plus a recomputed 16-row halo per side (pair U-Net + head and fuse U-Net + head reach 8 rows each), with the
+        # reference feature map, the per-pixel depth starts and the reference principal point cropped to the slab; the only
+        # communication is ONE all-gather of the owned rows of the stage's small output maps.  The reference has no counterpart.
+        self.row_group = None
         # pair branch: RegPair's head, soft_argmin and the entropy as one launch (pscv_head_index_entropy); False = the head
         # and pscv_softargmin as two launches with the fp32 score volume in between (the entropy then keeps the reference's clamp)
         self.fused_pair_head = True
 
-    def build_cost_volume(self, ref, ref_cam, srcs, srcs_cam, depth_num, depth_start, depth_interval, s_scale):
+    def build_cost_volume(self, ref, ref_cam, srcs, srcs_cam, depth_num, depth_start, depth_interval, s_scale, ref_y0: int = 0):
         """Pair-wise group-correlation volumes of ALL source views in one fused launch: [n_src,n,d,h,w,8]
         (reference model_cas.py:176-186 + groupwise_correlation at :340)."""
         cl = getattr(self, "_channels_last_features", False)     # the HIP extractor already wrote [n,h,w,32] 16-bit maps
@@ -331,7 +337,7 @@ class SingleStage(nn.Module):
         ref_cl = ref.contiguous() if cl else ops.to_channels_last(ref, self.storage_dtype)
         srcs_cl = [s.contiguous() if cl else ops.to_channels_last(s, self.storage_dtype) for s in srcs]
         return ops.warp_cost(ref_cl, srcs_cl, cams, planes.contiguous(), geom=L.GEOM_HOMOG, cost=L.COST_GROUPCORR,
-                             out_dtype=self.storage_dtype)
+                             out_dtype=self.storage_dtype, ref_y0=ref_y0)
 
     def forward_train(self, ref_feat, ref_cam, srcs_feat, srcs_cam, depth_num, depth_start, depth_interval, s_scale):
         """One cascade stage in train() mode with autograd (reference model_cas.py:303-420 under ``loss.backward()``): the
@@ -476,6 +482,50 @@ class SingleStage(nn.Module):
         est_depth = idx.unsqueeze(1) * depth_interval + depth_start
         return est_depth, conf.unsqueeze(1), pair_results
 
+    ROW_HALO = 16        # rows a stage's outputs depend on beyond their own: pair U-Net + head 8, fuse U-Net + head 8
+
+    def forward_row_shard(self, ref_feat, ref_cam, srcs_feat, srcs_cam, depth_num, depth_start, depth_interval, s_scale):
+        """Eval-mode stage with the IMAGE ROWS sharded over ``self.row_group`` (every plane on every rank).  Rank r owns rows
+        [ra, rb) (boundaries multiples of 4: the U-Net's stride-2 level sees the slab in the phase it has in the image) and runs the
+        unsharded stage on rows [ra - 16, rb + 16) clipped to the image: the reference feature map and the per-pixel depth starts are
+        cropped, the cameras stay those of the whole image and the warp evaluates slab row y at (x, y + slab origin)
+        (`pscv_warp_cost_rows`: the cost volume of the slab is bit-identical to those rows of the unsharded one; the source maps stay
+        whole).  Values more than 16 rows inside an artificial border therefore equal the unsharded ones; rows at the image border
+        keep their zero padding.  One all-gather per stage of the owned rows of (depth, probability, pair depths, pair
+        uncertainties): (2 + 2 n_src) maps of h x w floats in all."""
+        import torch.distributed as dist
+        from ... import dist as pdist
+        grp = self.row_group
+        world, rank = dist.get_world_size(grp), dist.get_rank(grp)
+        cl = getattr(self, "_channels_last_features", False)
+        h = ref_feat.shape[1] if cl else ref_feat.shape[2]
+        if h % 4:
+            raise ValueError(f"row shard: the stage height {h} must be a multiple of 4")
+        bounds = [pdist.plane_shard(h, world, r, multiple=4) for r in range(world)]
+        ra, rb = bounds[rank]
+        if rb <= ra:
+            raise ValueError(f"row shard: {world} ranks for {h} rows leaves rank {rank} without a 4-row block")
+        ea, eb = max(0, ra - self.ROW_HALO), min(h, rb + self.ROW_HALO)
+        ref_slab = (ref_feat[:, ea:eb] if cl else ref_feat[:, :, ea:eb]).contiguous()
+        start = depth_start if depth_start.shape[-2] == 1 else depth_start[:, :, ea:eb].contiguous()
+        self._row_y0 = ea               # the warp evaluates slab row y at (x, y + ea) with the WHOLE image's cameras: same bits as unsharded
+        try:
+            est, prob, pairs = self.forward((ref_slab, ref_cam, srcs_feat, srcs_cam), depth_num, depth_start_override=start,
+                                            depth_interval_override=depth_interval, s_scale=s_scale)
+        finally:
+            self._row_y0 = None
+        maps = [est, prob] + [m for ed, hd in pairs for m in (ed, hd[0])]                    # each [n,1,slab rows,w]
+        mine = torch.cat([m[:, :, ra - ea:rb - ea].to(torch.float32) for m in maps], dim=1)  # [n, 2 + 2 n_src, owned rows, w]
+        rows_max = max(b - a for a, b in bounds)
+        padded = mine.new_zeros(mine.shape[:2] + (rows_max, mine.shape[3]))
+        padded[:, :, :rb - ra] = mine
+        gathered = [torch.empty_like(padded) for _ in range(world)]
+        dist.all_gather(gathered, padded.contiguous(), group=grp)
+        full = torch.cat([g[:, :, :b - a] for g, (a, b) in zip(gathered, bounds)], dim=2)   # [n, 2 + 2 n_src, h, w]
+        est_full, prob_full = full[:, 0:1], full[:, 1:2]
+        pair_results = [[full[:, 2 + 2 * i:3 + 2 * i], [full[:, 3 + 2 * i:4 + 2 * i]]] for i in range(len(pairs))]
+        return est_full, prob_full, pair_results
+
     def forward(self, sample, depth_num, upsample=False, mem=False, mode='soft', depth_start_override=None,
                 depth_interval_override=None, s_scale=1, taps: Optional[dict] = None):
         if mem or mode != 'soft' or upsample:
@@ -486,6 +536,10 @@ class SingleStage(nn.Module):
         depth_interval = ref_cam[:, 1:2, 3:4, 1:2] if depth_interval_override is None else depth_interval_override
         if self.training:
             return self.forward_train(ref_feat, ref_cam, srcs_feat, srcs_cam, depth_num, depth_start, depth_interval, s_scale)
+        if self.row_group is not None and getattr(self, "_row_y0", None) is None:
+            if self.view_group is not None or self.depth_group is not None:
+                raise NotImplementedError("pscv Vis-MVSNet: one shard per stage (rows, depth planes or source views)")
+            return self.forward_row_shard(ref_feat, ref_cam, srcs_feat, srcs_cam, depth_num, depth_start, depth_interval, s_scale)
         if self.depth_group is not None:
             if self.view_group is not None:
                 raise NotImplementedError("pscv Vis-MVSNet: choose the depth-plane shard or the source-view shard, not both")
@@ -499,7 +553,8 @@ class SingleStage(nn.Module):
         srcs_feat, srcs_cam = [srcs_feat[i] for i in mine], [srcs_cam[i] for i in mine]
         if not mine:
             raise ValueError("view shard: more ranks than source views")
-        costs = self.build_cost_volume(ref_feat, ref_cam, srcs_feat, srcs_cam, depth_num, depth_start, depth_interval, s_scale)
+        costs = self.build_cost_volume(ref_feat, ref_cam, srcs_feat, srcs_cam, depth_num, depth_start, depth_interval, s_scale,
+                                       ref_y0=getattr(self, "_row_y0", None) or 0)
         interms, uncerts, pair_results = [], [], []
         # the pair branch of ALL source views as ONE batch per layer (the views share `reg` / `reg_pair`, and the fused warp
         # launch already wrote their volumes back to back: [n_src, n, d, h, w, 8] -> [n_src * n, d, h, w, 8]): 7 + 1 + 1 launches

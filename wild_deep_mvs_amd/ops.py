@@ -466,10 +466,12 @@ def geo_filter(depth: torch.Tensor, src_depth: Sequence[torch.Tensor], cams: tor
 def warp_cost(ref: Optional[torch.Tensor], srcs: Sequence[torch.Tensor], cams: torch.Tensor, depth: torch.Tensor, *,
               geom: int = L.GEOM_PROJ, cost: int = L.COST_VARIANCE, temp: float = 0.0,
               ref_hw: Optional[Sequence[int]] = None, out_dtype: torch.dtype = torch.bfloat16,
-              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+              out: Optional[torch.Tensor] = None, ref_y0: int = 0) -> torch.Tensor:
     """ref [B,h,w,C] (None for WARP_ONLY), srcs n x [B,hs,ws,C], cams [n,B,18] fp32,
     depth [B,D] or [B,D,h,w] fp32  ->  cost volume [B,D,h,w,C]
-    (GROUPCORR: [n,B,D,h,w,C/4]; WARP_ONLY: [n,B,D,h,w,C])."""
+    (GROUPCORR: [n,B,D,h,w,C/4]; WARP_ONLY: [n,B,D,h,w,C]).  ``ref_y0`` > 0: ``ref`` / per-pixel ``depth`` / the result are rows
+    [ref_y0, ref_y0 + h) of a larger reference grid whose cameras ``cams`` are (pscv_warp_cost_rows: bit-identical to those rows of
+    the whole-image launch)."""
     srcs = list(srcs)
     _dev(ref, cams, depth, *srcs)
     B, hs, ws, Cc = srcs[0].shape
@@ -507,9 +509,9 @@ def warp_cost(ref: Optional[torch.Tensor], srcs: Sequence[torch.Tensor], cams: t
     elif tuple(out.shape) != shape or not out.is_contiguous():
         raise ValueError("pscv.warp_cost: bad `out` tensor")
     ptrs = (C.c_void_p * n)(*[s.data_ptr() for s in srcs])
-    rc = _launch(f"warp_cost[{cost}]", lambda: L.lib().pscv_warp_cost(
+    rc = _launch(f"warp_cost[{cost}]", lambda: L.lib().pscv_warp_cost_rows(
         _p(ref), ptrs, n, _p(cams), _p(depth), bstride, int(per_pixel), geom, cost, float(temp), _p(out), B, Cc, h, w,
-        hs, ws, D, _dt(srcs[0]), _dt(out), _stream()),
+        hs, ws, D, _dt(srcs[0]), _dt(out), int(ref_y0), _stream()),
         # feature maps once + the volume once; per (voxel, view, channel) 4 blend FMAs + the cost statistic (2 FMAs)
         cost=lambda: (float((n + (ref is not None)) * B * hs * ws * Cc * srcs[0].element_size() + out.numel() * out.element_size()),
                       2.0 * 6 * n * B * D * h * w * Cc))
