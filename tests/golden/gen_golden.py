@@ -12,7 +12,7 @@ be re-created from ``wild_deep_mvs_amd.synthetic`` (the fixture records the
 generator arguments instead); every stage boundary of the reference's hot path is
 stored as fp32 arrays (tiny problem sizes; per-view warped volumes keep 3 planes).
 
-Usage:  python tests/golden/gen_golden.py [--only mvsnet|mvsnet_s|mvsnet_train|mvsnet_s_train|vis|cvp|filter|photo|api]
+Usage:  python tests/golden/gen_golden.py [--only mvsnet|mvsnet_s|mvsnet_dtu|mvsnet_train|mvsnet_s_train|vis|cvp|refframe|filter|photo|api]
 """
 from __future__ import annotations
 
@@ -379,6 +379,41 @@ def gen_cvp(tag, *, H=32, W=48, V=3, nscale=2, seed=0, scene_seed=0, baseline_sc
 PLANES96 = [0, 40, 95]
 
 
+def gen_refframe(tag="refframe_tiny"):
+    """The three reference models called with a LIST of per-view images (test-mode loaders, data/md_yao.py:126) and
+    `reference_frame != 0`: depth maps only.  MVSNet ref 1 of 3 views, Vis-MVSNet ref 2 of 4, CVP-MVSNet ref 1 of 3."""
+    sys.path.insert(0, REPO)
+    from wild_deep_mvs_amd import synthetic
+    from models.MVSNet.model import MVSNet
+    from models.VisMVSNet.frontend import Frontend as VisFrontend
+    from models.CVP_MVSNet.frontend import Frontend as CvpFrontend
+    arrays = {}
+    torch.manual_seed(0)
+    with torch.no_grad():
+        net = MVSNet("variance"); net.num_depth = 16
+        net.load_state_dict(synthetic.sharpened_state_dict("mvsnet", synthetic.template_of(net), seed=0), strict=True); net.eval()
+        sc = synthetic.make_scene(1, 3, 64, 96, seed=0)
+        out = net([sc["imgs"][:, i] for i in range(3)], sc["K"], sc["R"], sc["t"], sc["depth_min"], sc["depth_max"], reference_frame=1)
+        arrays["mvsnet_depth"], arrays["mvsnet_meta"] = np32(out["depth"]), np.array([64, 96, 3, 16, 0, 0, 1], dtype=np.int64)
+        net = VisFrontend()
+        net.load_state_dict(synthetic.sharpened_state_dict("vis", synthetic.template_of(net), seed=0), strict=True); net.eval()
+        net.depth_nums, net.interval_scales = [16, 8, 4], [8.0, 4.0, 2.0]
+        sc = synthetic.make_scene(1, 4, 64, 96, seed=6)
+        out = net([sc["imgs"][:, i] for i in range(4)], sc["K"], sc["R"], sc["t"], sc["depth_min"], sc["depth_max"], reference_frame=2,
+                  depth_nums=[16, 8, 4], interval_scales=[8.0, 4.0, 2.0])
+        arrays["vis_depth"], arrays["vis_meta"] = np32(out["depth"]), np.array([64, 96, 4, 0, 6, 2], dtype=np.int64)
+        net = CvpFrontend()
+        net.load_state_dict(synthetic.sharpened_state_dict("cvp", synthetic.template_of(net), seed=0), strict=True); net.eval()
+        net.model.nscale = 2
+        sc = synthetic.make_scene(1, 3, 32, 48, seed=0)
+        sc["t"] = sc["t"] * 8
+        out = net([sc["imgs"][:, i] for i in range(3)], sc["K"], sc["R"], sc["t"], sc["depth_min"], sc["depth_max"], reference_frame=1, nscale=2)
+        arrays["cvp_depth"], arrays["cvp_meta"] = np32(out["depth"]), np.array([32, 48, 3, 2, 0, 0, 8, 1], dtype=np.int64)
+    print(f"[{tag}] depth ranges: mvsnet {arrays['mvsnet_depth'].min():.3f}..{arrays['mvsnet_depth'].max():.3f}, "
+          f"vis {arrays['vis_depth'].min():.3f}..{arrays['vis_depth'].max():.3f}, cvp {arrays['cvp_depth'].min():.3f}..{arrays['cvp_depth'].max():.3f}")
+    save(f"{tag}.npz", **arrays)
+
+
 def gen_cvp_train(tag, *, H=64, W=96, V=3, nscale=2, seed=0, scene_seed=0, baseline_scale=8, B=2):
     """One training step of the reference's CVP-MVSNet in train() mode (48 coarse planes, fixed halving refinement
     intervals, batch-statistics BatchNorm, the regulariser called once per pyramid level), supervised loss over
@@ -556,6 +591,7 @@ def main():
         "vis_train": lambda: gen_vis_train("vis_train"),
         "cvp": lambda: gen_cvp("cvp_tiny"),
         "cvp_train": lambda: gen_cvp_train("cvp_train"),
+        "refframe": gen_refframe,
         "keys": gen_state_dict_keys,
         "filter": lambda: (gen_filter("filter_tiny", V=6, behind_view=4, half_res_view=3, near_view=2),
                            gen_filter("filter_upsample", V=4, seed=3, upsample=True, downscale=2, num_consistent=2)),

@@ -165,3 +165,26 @@ def test_cvp_graphed_forward_replays_equal_eager(env):
         for i in range(nscale):
             assert torch.equal(got["depth_est_list"][i], want["depth_est_list"][i]), (r, i)
     assert len(gnet._graphs) == 1
+
+
+def test_cvp_list_input_and_reference_frame(env):
+    """List input (test-mode loaders) and reference_frame != 0 through the CVP mirror (frontend.py:10-38), against the oracle."""
+    L, ops, synthetic, Frontend = env
+    from oracle import cvpmvsnet as OC
+    g = load_golden("cvp_tiny.npz")
+    scene, nscale, seed = cvp_scene(g)
+    net = Frontend()
+    sd = synthetic.sharpened_state_dict("cvp", synthetic.template_of(net), seed=seed)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    dev = {k: v.cuda() for k, v in scene.items()}
+    V = scene["imgs"].shape[1]
+    with torch.no_grad():
+        out = net([dev["imgs"][:, i] for i in range(V)], dev["K"], dev["R"], dev["t"], dev["depth_min"], dev["depth_max"],
+                  reference_frame=1, nscale=nscale)
+        ref = OC.forward(scene["imgs"], scene["K"], scene["R"], scene["t"], scene["depth_min"], scene["depth_max"], sd, nscale=nscale,
+                         reference_frame=1)
+    s = check_close("cvp reference_frame=1 depth vs oracle", out["depth"].cpu(), ref["depth"])
+    assert s["rel_l1"] <= 1e-3, s
+    s = check_close("cvp reference_frame=1 depth vs the reference's own output", out["depth"].cpu(), t(load_golden("refframe_tiny.npz")["cvp_depth"]))
+    assert s["rel_l1"] <= 1e-3, s

@@ -147,6 +147,12 @@ def test_list_input_and_reference_frame(env):
                         num_depth=16, reference_frame=1)
     s = check_close("reference_frame=1 depth", out["depth"].cpu(), ref["depth"])
     assert s["rel_l1"] <= 1e-3
+    # ... and against the depth map the REFERENCE produced for this call shape (tests/golden/gen_golden.py --only refframe: scene seed 0)
+    scene0 = {k: v.cuda() for k, v in synthetic.make_scene(1, 3, 64, 96, seed=0).items()}
+    out0 = net(list(torch.unbind(scene0["imgs"], 1)), scene0["K"], scene0["R"], scene0["t"], scene0["depth_min"], scene0["depth_max"],
+               reference_frame=1)
+    s = check_close("reference_frame=1 depth vs the reference's own output", out0["depth"].cpu(), t(load_golden("refframe_tiny.npz")["mvsnet_depth"]))
+    assert s["rel_l1"] <= 1e-3
 
 
 def test_training_mode_runs_on_the_engine(env):

@@ -335,3 +335,27 @@ def test_frozen_uncert_net_keeps_the_gradient_path(env):
         p.requires_grad_(False)
     y = un(x)[0]                      # grad mode on, but nothing requires grad: the fused launch again
     assert y.grad_fn is None and torch.equal(y, fused)
+
+
+def test_vis_list_input_and_reference_frame(env):
+    """Test-mode loaders hand `imgs` as a LIST of per-view tensors (data/md_yao.py:126) and any view may be the reference
+    (frontend.py: `reference_frame`): the mirror against the oracle with reference_frame = 2, list input, fp16."""
+    L, ops, synthetic, Frontend, OV = env
+    net, sd = _net(env, 0, torch.float16)
+    kw = dict(depth_nums=[16, 8, 4], interval_scales=[8.0, 4.0, 2.0])
+    net.depth_nums, net.interval_scales = kw["depth_nums"], kw["interval_scales"]
+    scene = synthetic.make_scene(1, 4, 64, 96, seed=6)
+    dev = {k: v.cuda() for k, v in scene.items()}
+    with torch.no_grad():
+        out = net([dev["imgs"][:, i] for i in range(4)], dev["K"], dev["R"], dev["t"], dev["depth_min"], dev["depth_max"],
+                  reference_frame=2, **kw)
+        ref = OV.forward(scene["imgs"], scene["K"], scene["R"], scene["t"], scene["depth_min"], scene["depth_max"], sd,
+                         depth_nums=kw["depth_nums"], interval_scales=kw["interval_scales"], attr_interval_scales=kw["interval_scales"],
+                         reference_frame=2)
+        base = net(dev["imgs"], dev["K"], dev["R"], dev["t"], dev["depth_min"], dev["depth_max"], reference_frame=0, **kw)
+    s = check_close("vis reference_frame=2 depth vs oracle", out["depth"].cpu(), ref["depth"])
+    assert s["rel_l1"] <= 1e-3, s
+    s = check_close("vis reference_frame=2 depth vs the reference's own output", out["depth"].cpu(), t(load_golden("refframe_tiny.npz")["vis_depth"]))
+    assert s["rel_l1"] <= 1e-3, s
+    assert len(out["depth_pair_list"]) == 3 and len(out["depth_pair_list"][0]) == 3
+    assert not torch.equal(out["depth"], base["depth"]), "another reference view is another depth map"

@@ -102,3 +102,27 @@ def test_confidence_window_definition():
     pp = torch.nn.functional.pad(p, (0, 0, 0, 0, 1, 2))
     want = sum(torch.gather(pp, 1, (idx + k).unsqueeze(1)).squeeze(1) for k in range(4))
     np.testing.assert_allclose(conf.numpy(), want.numpy(), atol=1e-6)
+
+
+def test_reference_frame_and_list_input_against_reference(golden_dir):
+    """`reference_frame != 0` with list input through all three oracles against depth maps the REFERENCE produced for the same call
+    (tests/golden/gen_golden.py --only refframe): MVSNet ref 1 of 3, Vis-MVSNet ref 2 of 4, CVP-MVSNet ref 1 of 3."""
+    from oracle import cvpmvsnet as OC, vismvsnet as OV
+    from wild_deep_mvs_amd.models.CVP_MVSNet.frontend import Frontend as CvpFrontend
+    from wild_deep_mvs_amd.models.VisMVSNet.frontend import Frontend as VisFrontend
+    g = _load(golden_dir, "refframe_tiny.npz")
+    with torch.no_grad():
+        sc = synthetic.make_scene(1, 3, 64, 96, seed=0)
+        sd = synthetic.sharpened_state_dict("mvsnet", _mvsnet_template("variance"), seed=0)
+        out = O.forward(sc["imgs"], sc["K"], sc["R"], sc["t"], sc["depth_min"], sc["depth_max"], sd, num_depth=16, reference_frame=1)
+        np.testing.assert_allclose(out["depth"].numpy(), g["mvsnet_depth"], atol=2e-5, rtol=0)
+        sc = synthetic.make_scene(1, 4, 64, 96, seed=6)
+        sd = synthetic.sharpened_state_dict("vis", synthetic.template_of(VisFrontend()), seed=0)
+        out = OV.forward(sc["imgs"], sc["K"], sc["R"], sc["t"], sc["depth_min"], sc["depth_max"], sd, depth_nums=[16, 8, 4],
+                         interval_scales=[8.0, 4.0, 2.0], attr_interval_scales=[8.0, 4.0, 2.0], reference_frame=2)
+        np.testing.assert_allclose(out["depth"].numpy(), g["vis_depth"], atol=5e-5, rtol=0)
+        sc = synthetic.make_scene(1, 3, 32, 48, seed=0)
+        sc["t"] = sc["t"] * 8
+        sd = synthetic.sharpened_state_dict("cvp", synthetic.template_of(CvpFrontend()), seed=0)
+        out = OC.forward(sc["imgs"], sc["K"], sc["R"], sc["t"], sc["depth_min"], sc["depth_max"], sd, nscale=2, reference_frame=1)
+        np.testing.assert_allclose(out["depth"].numpy(), g["cvp_depth"], atol=5e-5, rtol=0)
