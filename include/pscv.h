@@ -83,9 +83,10 @@ int pscv_abi_version(void);
  *   "warp_tiled" 1 (default; -1 restores it; 2 = the same): pscv_warp_cost stages the source patches of a reference tile in LDS
  *               as fp32 where it applies (C = 32, 16-bit features, per-batch planes, PROJ geometry, 1-4 source views, variance /
  *               softmin) -- same bits as the direct-gather kernels; 0: always the direct-gather kernels.  "warp_lpv" != 0
- *               also selects the direct kernel.  3: DIAGNOSTIC ONLY -- the same kernel compiled with packed fp32 instructions
- *               (same stored bits, ~7 % faster alone), which returns wrong voxels while other kernels share its CUs
- *               (scripts/ubench/lds_pk_overlap.hip); nothing in the engine selects it.
+ *               also selects the direct kernel.  3: DIAGNOSTIC ONLY -- the same kernel with the SLP vectorizer's packed fp32
+ *               instructions (same stored bits, ~3 % faster alone), which returns wrong voxels while MFMA kernels run on another
+ *               stream: `v_pk_*_f32` with the op_sel bit of src1 set is unreliable there (DESIGN.md section 7,
+ *               scripts/ubench/lds_pk_overlap.hip, scripts/lint_isa.py); nothing in the engine selects it.
  *   "warp_lds_pad" KiB of LDS the LDS-staged warp kernel requests on top of its need (0 = default): fewer workgroups per CU with
  *               the same code (occupancy / stream co-residency experiments)
  *   "sweep_dc"  depth planes per workgroup of the depth-sweep convs (0 = default heuristic)

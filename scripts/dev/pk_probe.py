@@ -68,7 +68,7 @@ def main():
         b1, _, _ = soak.run(f"scalar build {h}x{w} beside conv0", run, launches=80)
     L.set_tuning("warp_tiled", -1)
     # the stand-alone victim beside the REAL conv0
-    lpo = C.CDLL(os.path.join(REPO, "scripts", "ubench", "liblpo.so"))
+    lpo = C.CDLL(os.environ.get("LPO_LIB") or os.path.join(REPO, "scripts", "ubench", "liblpo.so"))
     lpo.lpo_victim.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lpo.lpo_out_floats.restype = C.c_long
     n = lpo.lpo_out_floats()

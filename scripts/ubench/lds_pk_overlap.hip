@@ -8,6 +8,8 @@
 // (b) the launch made alone; mismatches are counted per 16-lane group.
 //   hipcc --offload-arch=gfx950 -O3 -o lds_pk_overlap lds_pk_overlap.hip && ./lds_pk_overlap [launches=200] [rounds=96]
 //   variants: -DFIX_NOP (s_nop 7 x2 behind the wait)  -DFIX_B64 (ds_read_b64 x2 per tap piece)  -DFIX_MOV (v_mov_b32 of each pair's low half)
+//             -DOPSEL_HI (one weight broadcast from the HIGH half of a register pair, `op_sel:[0,1,0]`: the operand form round 4's
+//             bisect of the real kernel isolated -- scripts/dev/pk_variants.sh eblend / eblendhi)
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
@@ -64,12 +66,19 @@ template <int PK> __global__ __launch_bounds__(WG, 4) void victim(float* out, in
                 const f2 lo = (j & 1) ? f2{t[j >> 1].z, t[j >> 1].w} : f2{t[j >> 1].x, t[j >> 1].y};
                 asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(o[j]) : "v"(lo), "v"(f2{w[0], w[0]}));
             }
+            const f2 w21 = f2{w[2], w[1]};       // OPSEL_HI: two weights in ONE register pair, like the SLP vectorizer packs them
 #pragma unroll
             for (int k = 1; k < 4; ++k)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const f4 tt = t[2 * k + (j >> 1)];
                     const f2 lo = (j & 1) ? f2{tt.z, tt.w} : f2{tt.x, tt.y};
+#ifdef OPSEL_HI
+                    // tap 1 broadcasts the HIGH half of the pair into both result lanes (op_sel:[0,1,0]): THE form that fails
+                    if (k == 1) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(o[j]) : "v"(lo), "v"(w21));
+                    else if (k == 2) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(o[j]) : "v"(lo), "v"(w21));
+                    else
+#endif
                     asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(o[j]) : "v"(lo), "v"(f2{w[k], w[k]}));
                 }
 #pragma unroll
@@ -153,6 +162,44 @@ template <int PK> static long run(const char* tag, int launches, int rounds, boo
            tag, PK, (int)with_partner, cpu_bad, 4096 * 16, bad_launches, launches, bad_vals, hist[0], hist[1], hist[2], hist[3]);
     CK(hipFree(out)); CK(hipFree(pout));
     return bad_launches;
+}
+
+// Second victim (round 4), no LDS at all: packed fp32 instructions whose LOW result lane selects the HIGH half of one source pair
+// (`op_sel` bit set), each checked IN the kernel against plain v_mul / v_add / v_fma of the same operands; mismatches are counted per
+// 16-lane group.  Row order of errs[9][4]: v_pk_mov_b32 [1,0]; v_pk_mul_f32 [1,0], [0,1]; v_pk_add_f32 [1,0], [0,1];
+// v_pk_fma_f32 [1,0,0], [0,1,0], [0,0,1]; and v_pk_fma_f32 op_sel_hi:[1,0,1] (the HIGH lane reading a LOW half: the safe broadcast).
+#define OPSEL_CASE(row, pk_asm, lo_expr, hi_expr)                                                                          \
+    { f2 d; asm volatile(pk_asm : "=v"(d) : "v"(a), "v"(b), "v"(c));                                                     \
+      const float lo = lo_expr, hi = hi_expr;                                                                              \
+      bad[row] += (__float_as_uint(d.x) != __float_as_uint(lo)) || (__float_as_uint(d.y) != __float_as_uint(hi)); }
+__device__ __forceinline__ float s_mul(float x, float y) { float r; asm volatile("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
+__device__ __forceinline__ float s_add(float x, float y) { float r; asm volatile("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
+__device__ __forceinline__ float s_fma(float x, float y, float z) { asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(z) : "v"(x), "v"(y)); return z; }
+__global__ __launch_bounds__(WG, 4) void opsel_victim(unsigned* errs, int rounds) {
+    const unsigned gtid = blockIdx.x * WG + threadIdx.x;
+    const int grp = (threadIdx.x & 63) >> 4;
+    unsigned bad[9] = {};
+    for (int r = 0; r < rounds; ++r) {
+        f2 a = f2{pat(gtid * 7u + r), pat(gtid * 11u + r + 1)}, b = f2{pat(gtid * 13u + r + 2), pat(gtid * 17u + r + 3)};
+        f2 c = f2{pat(gtid * 19u + r + 4), pat(gtid * 23u + r + 5)};
+        asm volatile("" : "+v"(a), "+v"(b), "+v"(c));
+        OPSEL_CASE(0, "v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]", a.y, b.x)
+        OPSEL_CASE(1, "v_pk_mul_f32 %0, %1, %2 op_sel:[1,0]", s_mul(a.y, b.x), s_mul(a.y, b.y))
+        OPSEL_CASE(2, "v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]", s_mul(a.x, b.y), s_mul(a.y, b.y))
+        OPSEL_CASE(3, "v_pk_add_f32 %0, %1, %2 op_sel:[1,0]", s_add(a.y, b.x), s_add(a.y, b.y))
+        OPSEL_CASE(4, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1]", s_add(a.x, b.y), s_add(a.y, b.y))
+        OPSEL_CASE(5, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0]", s_fma(a.y, b.x, c.x), s_fma(a.y, b.y, c.y))
+        OPSEL_CASE(6, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0]", s_fma(a.x, b.y, c.x), s_fma(a.y, b.y, c.y))
+        OPSEL_CASE(7, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1]", s_fma(a.x, b.x, c.y), s_fma(a.y, b.y, c.y))
+        OPSEL_CASE(8, "v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]", s_fma(a.x, b.x, c.x), s_fma(a.y, b.x, c.y))
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+        if (bad[k]) atomicAdd(errs + 4 * k + grp, bad[k]);
+}
+extern "C" int lpo_opsel_victim(unsigned* errs36, int rounds, void* stream) {
+    opsel_victim<<<NWG, WG, 0, (hipStream_t)stream>>>(errs36, rounds);
+    return (int)hipGetLastError();
 }
 
 // the victim as a library entry (scripts/dev/pk_probe.py launches it beside the engine's real conv0 through tests/test_gpu_overlap.py's harness):

@@ -266,3 +266,36 @@ def test_harness_reports_the_packed_build(env, soak):
     finally:
         L.set_tuning("warp_tiled", -1)
     print(f"[overlap] packed build: {bad} of {LAUNCHES} overlapped launches differ (worst rel {worst:.2e})")
+
+
+def test_report_the_platform_defect_with_the_minimal_reproducer(env, soak):
+    """Diagnostic, never fails: the LDS-free, self-checking victims of scripts/ubench/lds_pk_overlap.hip (`opsel_victim`: packed fp32
+    instructions with one op_sel bit set, each result checked in the kernel against plain v_mul / v_add / v_fma) beside conv0.  Round 4
+    measured: millions of wrong LOW results in lanes 48-63 for the forms whose op_sel bit of SRC1 is set (v_pk_mul_f32 op_sel:[0,1],
+    v_pk_add_f32 op_sel:[0,1], v_pk_fma_f32 op_sel:[0,1,0]); 0 for src0 / src2 selectors, op_sel_hi forms, v_pk_mov_b32; 0 for every
+    form when launched alone.  scripts/lint_isa.py keeps the failing forms out of libpscv.so."""
+    import ctypes as C
+    import os
+    L, ops, synthetic = env
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "ubench", "liblpo.so")
+    if not os.path.exists(path):
+        pytest.skip("scripts/ubench/liblpo.so not built (python -c 'import __graft_entry__ as g; g.build()')")
+    lpo = C.CDLL(path)
+    lpo.lpo_opsel_victim.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    names = ["v_pk_mov_b32 op_sel:[1,0]", "v_pk_mul_f32 op_sel:[1,0]", "v_pk_mul_f32 op_sel:[0,1]", "v_pk_add_f32 op_sel:[1,0]", "v_pk_add_f32 op_sel:[0,1]",
+             "v_pk_fma_f32 op_sel:[1,0,0]", "v_pk_fma_f32 op_sel:[0,1,0]", "v_pk_fma_f32 op_sel:[0,0,1]", "v_pk_fma_f32 op_sel_hi:[1,0,1]"]
+    for partner in (False, True):
+        errs = torch.zeros(36, dtype=torch.int32, device="cuda")
+        for it in range(40):
+            if partner:
+                with torch.cuda.stream(soak.sb):
+                    for _ in range(3):
+                        ops.conv3d(soak.px, soak.player)
+            with torch.cuda.stream(soak.sa):
+                assert lpo.lpo_opsel_victim(errs.data_ptr(), 400, soak.sa.cuda_stream) == 0
+            torch.cuda.synchronize()
+        e = errs.cpu().tolist()
+        print(f"[op_sel reproducer] conv0 on a second stream: {partner}; wrong results per 16-lane group (lanes 0-15 / 16-31 / 32-47 / 48-63), "
+              "40 launches x 1 M threads x 400 rounds:", flush=True)
+        for k, nm in enumerate(names):
+            print(f"[op_sel reproducer]    {nm:32s} {e[4 * k:4 * k + 4]}", flush=True)

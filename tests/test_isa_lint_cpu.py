@@ -1,0 +1,38 @@
+"""The built library contains no packed fp32 instruction of the form that is unreliable on this MI355X pool beside MFMA kernels
+(`v_pk_{mul,add,fma}_f32` with the op_sel bit of src1 set; DESIGN.md section 7, scripts/lint_isa.py).  Runs the ISA lint on
+`wild_deep_mvs_amd/libpscv.so` -- a compiler upgrade or a new kernel that brings the form back fails here, on the CPU."""
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "scripts"))
+
+
+def test_library_has_no_packed_fp32_with_a_src1_high_half_selector():
+    import lint_isa
+    from wild_deep_mvs_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libpscv.so not built")
+    if not os.path.exists(os.path.join(lint_isa.LLVM, "llvm-objdump")):
+        pytest.skip("llvm-objdump not available")
+    bad, seen = lint_isa.findings(_lib.LIB_PATH)
+    assert seen > 10000, f"only {seen} packed instructions found: did the disassembly work?"
+    assert not bad, "\n".join(f"{sym}: {ins}" for sym, ins in bad[:20])
+
+
+def test_the_lint_sees_the_diagnostic_kernel():
+    """The packed diagnostic build of the warp kernel DOES contain the form (that is why it fails beside conv0): the lint must find it
+    when that kernel is not exempted -- i.e. the pattern matching works on real disassembly."""
+    import lint_isa
+    from wild_deep_mvs_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH) or not os.path.exists(os.path.join(lint_isa.LLVM, "llvm-objdump")):
+        pytest.skip("needs the built library and llvm-objdump")
+    saved = lint_isa.ALLOWED_KERNELS
+    lint_isa.ALLOWED_KERNELS = ()
+    try:
+        bad, _ = lint_isa.findings(_lib.LIB_PATH)
+    finally:
+        lint_isa.ALLOWED_KERNELS = saved
+    assert bad and all("warp_cost_lds_pk_kernel" in sym for sym, _ in bad), sorted({s for s, _ in bad})[:5]

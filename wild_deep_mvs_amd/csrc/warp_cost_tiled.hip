@@ -113,7 +113,49 @@ template <bool MAX> __device__ __forceinline__ float wl_wave_reduce(float x) {
 
 // eight fp32 channels x four taps -> eight blended channels; t = {00lo, 00hi, 01lo, 01hi, 10lo, 10hi, 11lo, 11hi}
 typedef float wl_f4 __attribute__((ext_vector_type(4)));
+// WL_X_BLEND / WL_X_SUMS / WL_X_FINAL (diagnostic builds of the PACKED kernel, scripts/dev/pk_variants.sh): that part of the sweep is
+// forced onto scalar fp32 instructions (inline assembly: the SLP vectorizer cannot pair them) while the rest keeps its packed forms
+// -- which packed instructions does the overlap defect need?
+__device__ __forceinline__ float wl_mul_s(float a, float b) { float r; asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float wl_fma_s(float a, float b, float c) { asm("v_fma_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b)); return c; }
+__device__ __forceinline__ float wl_add_s(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float wl_sub_s(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ void wl_blend8(const wl_f4 (&t)[8], const float (&w)[4], float (&o)[8]) {
+#ifdef WL_E_BLEND      // (diagnostic, with -fno-slp-vectorize: ONLY the blend on explicit two-wide arithmetic = v_pk_mul_f32 / v_pk_fma_f32)
+    {
+        wl_f2 p[4];
+        const wl_f2 w0 = wl_f2{w[0], w[0]};
+        p[0] = wl_f2{t[0].x, t[0].y} * w0; p[1] = wl_f2{t[0].z, t[0].w} * w0; p[2] = wl_f2{t[1].x, t[1].y} * w0; p[3] = wl_f2{t[1].z, t[1].w} * w0;
+#ifdef WL_E_BLEND_HI   // the SLP build's operand form: w[2] and w[1] share ONE register pair, tap 1 broadcasts its HIGH half (op_sel:[0,1,0])
+        wl_f2 w21 = wl_f2{w[2], w[1]};
+        asm volatile("" : "+v"(w21));          // (keeps the two weights in one pair)
+#endif
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+#ifdef WL_E_BLEND_HI
+            const wl_f2 wk = k == 1 ? __builtin_shufflevector(w21, w21, 1, 1) : k == 2 ? __builtin_shufflevector(w21, w21, 0, 0) : wl_f2{w[k], w[k]};
+#else
+            const wl_f2 wk = wl_f2{w[k], w[k]};
+#endif
+            p[0] = __builtin_elementwise_fma(wl_f2{t[2 * k].x, t[2 * k].y}, wk, p[0]);
+            p[1] = __builtin_elementwise_fma(wl_f2{t[2 * k].z, t[2 * k].w}, wk, p[1]);
+            p[2] = __builtin_elementwise_fma(wl_f2{t[2 * k + 1].x, t[2 * k + 1].y}, wk, p[2]);
+            p[3] = __builtin_elementwise_fma(wl_f2{t[2 * k + 1].z, t[2 * k + 1].w}, wk, p[3]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o[2 * j] = p[j][0]; o[2 * j + 1] = p[j][1]; }
+        return;
+    }
+#endif
+#ifdef WL_X_BLEND
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = wl_mul_s(t[j >> 2][j & 3], w[0]);
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = wl_fma_s(t[2 * k + (j >> 2)][j & 3], w[k], o[j]);
+    return;
+#endif
     o[0] = t[0].x * w[0]; o[1] = t[0].y * w[0]; o[2] = t[0].z * w[0]; o[3] = t[0].w * w[0];
     o[4] = t[1].x * w[0]; o[5] = t[1].y * w[0]; o[6] = t[1].z * w[0]; o[7] = t[1].w * w[0];
 #pragma unroll
@@ -279,12 +321,21 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
             if (k < n_src) {
                 typedef const __attribute__((address_space(4))) float* wl_cf;
                 wl_cf cam = (wl_cf)(a.cams + ((long)k * a.B + b) * PSCV_CAM_FLOATS);
+#ifdef WL_X_BOX      // (diagnostic: the box arithmetic of wave 0 on scalar fp32 instructions, see wl_mul_s)
+                const float ax = wl_add_s(wl_fma_s(cam[1], cy, wl_mul_s(cam[0], cx)), cam[2]);
+                const float ay = wl_add_s(wl_fma_s(cam[4], cy, wl_mul_s(cam[3], cx)), cam[5]);
+                const float az = wl_add_s(wl_fma_s(cam[7], cy, wl_mul_s(cam[6], cx)), cam[8]);
+                const float hx = wl_fma_s(ax, d, cam[9]), hy = wl_fma_s(ay, d, cam[10]), hz = wl_fma_s(az, d, cam[11]);
+                const float inv_z = __builtin_amdgcn_rcpf(hz);
+                const float u = wl_mul_s(hx, inv_z), v = wl_mul_s(hy, inv_z);
+#else
                 const float ax = fmaf(cam[1], cy, cam[0] * cx) + cam[2];
                 const float ay = fmaf(cam[4], cy, cam[3] * cx) + cam[5];
                 const float az = fmaf(cam[7], cy, cam[6] * cx) + cam[8];
                 const float hx = fmaf(ax, d, cam[9]), hy = fmaf(ay, d, cam[10]), hz = fmaf(az, d, cam[11]);
                 const float inv_z = __builtin_amdgcn_rcpf(hz);
                 const float u = hx * inv_z, v = hy * inv_z;
+#endif
                 const float okf = (hz > 1e-6f && fabsf(u) < 1e6f && fabsf(v) < 1e6f) ? 1.0f : 0.0f;   // also rejects NaN
                 const float umin = wl_reduce8<false>(u), umax = wl_reduce8<true>(u);
                 const float vmin = wl_reduce8<false>(v), vmax = wl_reduce8<true>(v);
@@ -405,7 +456,18 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
         auto accumulate = [&](const float (&wv)[8]) {
             if (VAR) {
 #pragma unroll
+#ifdef WL_X_SUMS
+                for (int j = 0; j < 8; ++j) { s[j] = wl_add_s(s[j], wv[j]); q[j] = wl_fma_s(wv[j], wv[j], q[j]); }
+#elif defined(WL_E_SUMS)   // (diagnostic, with -fno-slp-vectorize: ONLY the two sums on explicit two-wide arithmetic)
+                for (int j = 0; j < 4; ++j) {
+                    const wl_f2 v2 = wl_f2{wv[2 * j], wv[2 * j + 1]};
+                    const wl_f2 s2 = wl_f2{s[2 * j], s[2 * j + 1]} + v2;
+                    const wl_f2 q2 = __builtin_elementwise_fma(v2, v2, wl_f2{q[2 * j], q[2 * j + 1]});
+                    s[2 * j] = s2[0]; s[2 * j + 1] = s2[1]; q[2 * j] = q2[0]; q[2 * j + 1] = q2[1];
+                }
+#else
                 for (int j = 0; j < 8; ++j) { s[j] += wv[j]; q[j] = fmaf(wv[j], wv[j], q[j]); }
+#endif
             } else {   // SOFTMIN  model.py:141-173
                 float df[8], part = 0.0f;
 #pragma unroll
@@ -423,17 +485,30 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
         float w00, w01, w10, w11;
         int E, DX = 64, DY = mpitch << 6;
         {
+#ifdef WL_X_COORDS      // (diagnostic: the per-trip coordinate arithmetic on scalar fp32 instructions, see wl_mul_s)
+            const float dvv = dval;
+            const float hx = wl_fma_s(rx, dvv, tx), hy = wl_fma_s(ry, dvv, ty_), hz = wl_fma_s(rz, dvv, tz);
+            const float inv_z = __builtin_amdgcn_rcpf(hz);
+            float ix = wl_mul_s(hx, inv_z), iy = wl_mul_s(hy, inv_z);
+#else
             const float hx = fmaf(rx, dval, tx), hy = fmaf(ry, dval, ty_), hz = fmaf(rz, dval, tz);
             const float inv_z = __builtin_amdgcn_rcpf(hz);
             float ix = hx * inv_z, iy = hy * inv_z;
+#endif
             if (any_gen) {   // (a staged box has every corner in front of the camera: no behind-camera test)
                 ix = __builtin_amdgcn_fmed3f(ix, a.xlo, a.xhi);      // grid clamp  module.py:151-155
                 iy = __builtin_amdgcn_fmed3f(iy, a.ylo, a.yhi);
             }
             const float x0f = floorf(ix), y0f = floorf(iy);
+#ifdef WL_X_COORDS
+            const float fx = wl_sub_s(ix, x0f), fy = wl_sub_s(iy, y0f);
+            const float gx = wl_sub_s(1.0f, fx), gy = wl_sub_s(1.0f, fy);
+            w00 = wl_mul_s(gx, gy); w01 = wl_mul_s(fx, gy); w10 = wl_mul_s(gx, fy); w11 = wl_mul_s(fx, fy);
+#else
             const float fx = ix - x0f, fy = iy - y0f;
             const float gx = 1.0f - fx, gy = 1.0f - fy;
             w00 = gx * gy; w01 = fx * gy; w10 = gx * fy; w11 = fx * fy;
+#endif
             const int x0 = (int)x0f, y0 = (int)y0f;
             if (any_gen) {
                 // zero padding: a tap outside the image has weight 0 and is read from the nearest staged texel instead
@@ -528,7 +603,7 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
 #undef WL_VIEW
 
         float o[8];
-#ifndef WL_PK
+#if !defined(WL_PK) || defined(WL_X_FINAL)
         // the packed build's rounding, spelled out (its compiler emits mul, mul, fma / mul, mul, fma for these two expressions)
         if (COST == PSCV_COST_VARIANCE) {
 #pragma unroll
