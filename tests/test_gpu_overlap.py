@@ -299,3 +299,40 @@ def test_report_the_platform_defect_with_the_minimal_reproducer(env, soak):
               "40 launches x 1 M threads x 400 rounds:", flush=True)
         for k, nm in enumerate(names):
             print(f"[op_sel reproducer]    {nm:32s} {e[4 * k:4 * k + 4]}", flush=True)
+
+
+def test_post_path_and_loss_kernels_are_bit_stable_beside_conv0(env, soak):
+    """The kernels in which the ISA lint found the unreliable packed form in round 3's build (geo_filter, photo_warp, cvp_cams: now
+    compiled with -fno-slp-vectorize), plus their neighbours: SSIM forward, the photometric warp's backward, calDepthHypo."""
+    L, ops, synthetic = env
+    # geometric filter: 1152 x 1600, ten source views (evaluation/filtering.py:60-85)
+    sc = synthetic.make_filter_scene(11, 1152, 1600, seed=2)
+    cams = ops.geo_filter_cams(sc["K"], sc["R"], sc["t"]).cuda()
+    depth, src = sc["depth"].cuda(), [d.cuda() for d in sc["src_depth"]]
+    assert soak.run("geo_filter 1152x1600 x 10 views", lambda: ops.geo_filter(depth, src, cams, want_counts=True))[0] == 0
+    # photometric warp + its backward + SSIM (models/trainer.py:209-278, utils/ssimLoss.py)
+    pc = synthetic.make_photo_case(2, 5, 512, 640, seed=3)
+    from wild_deep_mvs_amd.models.MVSNet.model import build_proj_matrices
+    proj = build_proj_matrices(pc["K"], pc["R"], pc["t"]).cuda().float()
+    inv_ref = ops.inv_proj4x4(proj[:, 0]).contiguous()
+    srcs = pc["imgs"][:, 1:].cuda().contiguous()
+    d0 = pc["depths"][0].cuda().contiguous()
+    pw = lambda: tuple(v for v in ops.photo_warp(srcs, d0, inv_ref, proj[:, 1:].contiguous(), want_z=True, want_flows=True).values() if v is not None)
+    assert soak.run("photo_warp 2 x 4 sources 512x640", pw)[0] == 0
+    gw = torch.rand(2, 4, 3, 512, 640, device="cuda")
+    assert soak.run("photo_warp_bwd", lambda: ops.photo_warp_bwd(srcs, d0, inv_ref, proj[:, 1:].contiguous(), gw))[0] == 0
+    a, b = torch.rand(2, 3, 512, 640, device="cuda"), torch.rand(8, 3, 512, 640, device="cuda")
+    assert soak.run("ssim 8 x 3 x 512x640", lambda: ops.ssim(a, b))[0] == 0
+    # CVP: camera blocks of all levels in one launch + calDepthHypo at 1024 x 1280
+    B, V, H, W = 1, 5, 1024, 1280
+    cs = synthetic.make_scene(B, V, 64, 80, seed=4)            # (cameras only; the images are not used)
+    row = torch.tensor([0., 0., 0., 1.])
+    ref_ex = torch.cat((torch.cat((cs["R"][:, 0], cs["t"][:, 0] * 8), 2), row.view(1, 1, 4).expand(B, 1, 4)), 1).cuda()
+    src_ex = torch.cat((torch.cat((cs["R"][:, 1:], cs["t"][:, 1:] * 8), 3), row.view(1, 1, 1, 4).expand(B, V - 1, 1, 4)), 2).cuda()
+    K = cs["K"].cuda() * torch.tensor([16.0, 16.0, 1.0], device="cuda").view(1, 1, 3, 1)
+    cc = lambda: ops.cvp_cams(K[:, 0], K[:, 1:], ref_ex, src_ex, [1.0, 2.0, 4.0, 8.0, 16.0])
+    assert soak.run("cvp_cams 5 levels", cc, launches=96)[0] == 0
+    _, hypo_cams = ops.cvp_cams(K[:, 0], K[:, 1:], ref_ex, src_ex, [1.0, 2.0, 4.0, 8.0, 16.0])
+    dmap = (2.5 + 3.0 * torch.rand(B, H, W)).cuda()
+    fb = torch.full((B,), 4.0 / 128, device="cuda")
+    assert soak.run("cvp_depth_hypos 1024x1280", lambda: ops.cvp_depth_hypos(dmap, hypo_cams[0], fb))[0] == 0
