@@ -12,6 +12,8 @@ from __future__ import annotations
 
 from typing import Dict, Optional
 
+import contextlib
+
 import torch
 import torch.nn as nn
 
@@ -570,20 +572,37 @@ class SingleStage(nn.Module):
         # per-pair `index * interval + start` (model_cas.py:348) is two launches per stage and the UncertNet reads its batch in place
         index_all = torch.empty((n_s * n_b, h, w), dtype=torch.float32, device=costs.device)
         entropy_all = torch.empty((n_s * n_b, h, w), dtype=torch.float32, device=costs.device)
-        for g0 in range(0, n_s, group):
+        # PAIR_STREAMS > 1 (round 4 experiment; default 1): the per-view passes of a stage are independent until the fusion, so
+        # consecutive groups may run on separate HIP streams (forked from / joined into the caller's stream; under the forward's
+        # hipGraph capture they become parallel branches of the graph) -- the ramp of one view's kernels under the tail of another's
+        n_streams = min(int(getattr(self, "PAIR_STREAMS", 1)), (n_s + group - 1) // group) if taps is None and costs.is_cuda else 1
+        if n_streams > 1:
+            pool = self.__dict__.setdefault("_pair_streams", {})
+            side = pool.get(costs.device)
+            if side is None or len(side) < n_streams:
+                side = pool[costs.device] = [torch.cuda.Stream(device=costs.device) for _ in range(n_streams)]
+            main_stream = torch.cuda.current_stream(costs.device)
+            for st in side[:n_streams]:
+                st.wait_stream(main_stream)
+        for gi, g0 in enumerate(range(0, n_s, group)):
             g1 = min(n_s, g0 + group)
-            interm_all = self.reg(costs[g0:g1].view(((g1 - g0) * n_b,) + tuple(costs.shape[2:])))
-            idx_g, ent_g = index_all[g0 * n_b:g1 * n_b], entropy_all[g0 * n_b:g1 * n_b]
-            # head + expected index + entropy in ONE pass over the pair volume; the fp32 scores exist only for `taps`
-            score_all = self.reg_pair.head_index_entropy(interm_all, idx_g, ent_g, want_scores=taps is not None) if self.fused_pair_head else None
-            if score_all is None:
-                score_all = self.reg_pair(interm_all)                                  # fp32 [views * n, d, h, w]
-                ops.softargmin(score_all, None, want_index=True, want_entropy=True, into={"index": idx_g, "entropy": ent_g})
+            ctx = torch.cuda.stream(side[gi % n_streams]) if n_streams > 1 else contextlib.nullcontext()
+            with ctx:
+                interm_all = self.reg(costs[g0:g1].view(((g1 - g0) * n_b,) + tuple(costs.shape[2:])))
+                idx_g, ent_g = index_all[g0 * n_b:g1 * n_b], entropy_all[g0 * n_b:g1 * n_b]
+                # head + expected index + entropy in ONE pass over the pair volume; the fp32 scores exist only for `taps`
+                score_all = self.reg_pair.head_index_entropy(interm_all, idx_g, ent_g, want_scores=taps is not None) if self.fused_pair_head else None
+                if score_all is None:
+                    score_all = self.reg_pair(interm_all)                                  # fp32 [views * n, d, h, w]
+                    ops.softargmin(score_all, None, want_index=True, want_entropy=True, into={"index": idx_g, "entropy": ent_g})
             for i in range(g0, g1):
                 sl = slice((i - g0) * n_b, (i - g0 + 1) * n_b)
                 interms.append(interm_all[sl])
                 if taps is not None and i == 0:
                     taps.update(cost0=costs[0], interm0=interm_all[sl], score0=score_all[sl], entropy0=entropy_all[:n_b])
+        if n_streams > 1:
+            for st in side[:n_streams]:
+                main_stream.wait_stream(st)
         est_all = index_all.view(n_s, n_b, 1, h, w) * depth_interval + depth_start       # [n_b,1,1,1] / [n_b,1,h,w] broadcast
         # the 2-D UncertNet (eval-mode BatchNorm: per-sample) runs ONCE on the entropy maps of all pairs stacked along the batch
         # axis: one fused launch per stage (csrc/uncert_net.hip); same values
