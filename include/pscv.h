@@ -87,6 +87,10 @@ int pscv_abi_version(void);
  *               instructions (same stored bits, ~3 % faster alone), which returns wrong voxels while MFMA kernels run on another
  *               stream: `v_pk_*_f32` with the op_sel bit of src1 set is unreliable there (DESIGN.md section 7,
  *               scripts/ubench/lds_pk_overlap.hip, scripts/lint_isa.py); nothing in the engine selects it.
+ *               4: the lane-owns-voxel kernel (csrc/warp_cost_lv.hip; variance costs; same stored bits): 14 % fewer vector-ALU
+ *               instructions and 2 % less time than the default on narrow-baseline rigs, ~2x slower where boxes do not fit the
+ *               LDS arena (wide baselines) -- an alternative, not the default.
+ *   "warp_tile" test aids of the lane-owns-voxel kernel (0 = off): 7 = every block on its general path, 8 = no stores, 9 = no taps
  *   "warp_lds_pad" KiB of LDS the LDS-staged warp kernel requests on top of its need (0 = default): fewer workgroups per CU with
  *               the same code (occupancy / stream co-residency experiments)
  *   "sweep_dc"  depth planes per workgroup of the depth-sweep convs (0 = default heuristic)
@@ -104,8 +108,6 @@ int pscv_abi_version(void);
  *   "conv_s2_sweep"  1 (default): stride-2 layers with 8 input channels and <= 32 output channels on volumes of >= 64 Ki output
  *               voxels run the stride-2 depth-sweep kernel; 0: always the brick kernel; 2: the sweep at any size (same packed weights, same result up to
  *               fp32 summation order).  "s2s_slots": resident-workgroup target that sizes its depth chunks (0 = 768)
- *   "warp_tile"  builds with -DWL_PIPELINED only (the software-pipelined sweep of the LDS-staged warp kernel, round 3): 0 = that
- *               sweep wherever every contributing view is staged, 1 = the plain loop (same bits); no effect in the default build
  *   "conv2d_wlds"  1 (default): 64-channel k3 s1 2-D layers with 32 | 64 output channels and >= 512 tiles run the persistent
  *               kernel that keeps the layer's packed weights in LDS; 0: always conv2d_kernel; 2: at any size (same bits)
  *   "conv_small_tiles"  1 (default): small volumes use 1x4x16 tiles with the output channels split over

@@ -102,7 +102,8 @@ def _warp_inputs(ops, synthetic, V, C, h, w, D, dtype, seed=3):
     return fcl, cams, dv
 
 
-WARP_CASES = [("lds variance", 1, "variance", 32, False), ("lds softmin", 1, "softmin", 32, False), ("quad variance", 0, "variance", 32, False),
+WARP_CASES = [("lds variance", 1, "variance", 32, False), ("lds softmin", 1, "softmin", 32, False), ("lane-owner variance", 4, "variance", 32, False),
+              ("quad variance", 0, "variance", 32, False),
               ("quad per-pixel planes", 1, "variance", 32, True), ("generic 16 channels", 1, "variance_cvp", 16, False)]
 
 

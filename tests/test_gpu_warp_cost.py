@@ -193,6 +193,49 @@ def test_tiled_kernel_equals_direct_kernel(env, baseline_scale, shape, V, D, cos
     assert float(outs[1].abs().max()) > 0
 
 
+@pytest.mark.parametrize("dtype,out_dtype", [(torch.float16, torch.float16), (torch.bfloat16, torch.bfloat16), (torch.float16, torch.float32)])
+@pytest.mark.parametrize("cost_name", ["variance", "variance_cvp"])
+@pytest.mark.parametrize("baseline_scale,shape,V,D", [(1.0, (64, 80), 5, 24), (1.0, (37, 53), 5, 24), (12.0, (64, 80), 5, 24),
+                                                      (1.0, (40, 56), 2, 7), (3.0, (48, 48), 4, 50), (1.0, (128, 160), 5, 64)])
+def test_lane_owner_kernel_equals_direct_kernel(env, baseline_scale, shape, V, D, cost_name, dtype, out_dtype):
+    """The lane-owns-voxel kernel (warp_cost_lv.hip, `warp_tiled` = 4: channel-chunk planar boxes with their zero padding staged,
+    straight-line sweep per count of staged views, stores transposed across the rows of a wave) stores the SAME BITS as the
+    direct-gather kernel: fast path and -- `warp_tile` = 7 -- every block forced onto its general path (per-chunk positions, per-lane
+    global taps for views that are not staged).  Cases as for the quad-owner kernel: everything staged, image sizes the 8 x 4 tile
+    does not divide, boxes clipped at the border / outside the image, a 12x wider baseline (boxes that do not fit, corners behind the
+    camera), one source view, odd plane counts (the unpaired last plane of a trip) and more planes than one chunk; fp32 output
+    takes the un-transposed stores."""
+    L, ops, O = env
+    from wild_deep_mvs_amd import synthetic
+    from oracle.mvsnet import mvsnet_cameras
+    h, w = shape
+    B, C = 2, 32
+    feats = synthetic.make_features(B, V, C, h, w, seed=13)
+    cam = synthetic.make_cameras(B, V, 4 * h, 4 * w)
+    cam["t"] = cam["t"] * baseline_scale
+    proj, dvals = mvsnet_cameras(cam["K"], cam["R"], cam["t"], cam["depth_min"], cam["depth_max"], D)
+    cams = ops.proj_cams_device(proj.cuda().contiguous(), 0)
+    fcl = [ops.to_channels_last(feats[i].cuda(), dtype) for i in range(V)]
+    dv = dvals[:, 0].contiguous().cuda()
+    code = {"variance": L.COST_VARIANCE, "variance_cvp": L.COST_VARIANCE_CVP}[cost_name]
+    outs = {}
+    for name, tiled, tile in (("lane-owner", 4, 0), ("lane-owner, general path", 4, 7), ("direct", 0, 0)):
+        L.set_tuning("warp_tiled", tiled)
+        L.set_tuning("warp_tile", tile)
+        try:
+            outs[name] = ops.warp_cost(fcl[0], fcl[1:], cams, dv, cost=code, out_dtype=out_dtype)
+        finally:
+            L.set_tuning("warp_tiled", -1)
+            L.set_tuning("warp_tile", 0)
+    torch.cuda.synchronize()
+    want = outs["direct"]
+    assert float(want.float().abs().max()) > 0
+    for name in ("lane-owner", "lane-owner, general path"):
+        ne = int((outs[name] != want).sum())
+        assert ne == 0, (f"{name} vs direct, {cost_name} baseline x{baseline_scale} {shape}: {ne} of {want.numel()} values differ, "
+                         f"max abs {float((outs[name].float() - want.float()).abs().max()):.3e}")
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("cost_name", ["variance", "variance_cvp", "softmin", "warp_only", "groupcorr", "warp_only_homog"])
 @pytest.mark.parametrize("baseline_scale,shape,D,per_pixel", [(1.0, (64, 80), 24, False), (1.0, (37, 53), 23, True),
@@ -347,7 +390,7 @@ def test_staged_kernel_inf_inputs_stay_inf(env):
     assert torch.equal(staged[~bad], direct[~bad])
 
 
-@pytest.mark.parametrize("case", ["lds_variance", "quad_variance", "quad_per_pixel", "generic_16ch", "homog_groupcorr"])
+@pytest.mark.parametrize("case", ["lds_variance", "lane_owner_variance", "quad_variance", "quad_per_pixel", "generic_16ch", "homog_groupcorr"])
 def test_row_slab_launch_equals_the_rows_of_the_whole_image_launch(env, case):
     """`pscv_warp_cost_rows` (ABI 7; the row-sharded Vis-MVSNet stages): a launch on rows [y0, y0 + hs) of the reference grid -- cropped
     reference map and per-pixel planes, the cameras of the WHOLE image, `ref_y0 = y0` -- stores bit for bit the rows of the whole-image
@@ -377,7 +420,7 @@ def test_row_slab_launch_equals_the_rows_of_the_whole_image_launch(env, case):
         if case == "quad_per_pixel":
             dv = (dv.view(B, D, 1, 1) * (1.0 + 0.01 * torch.rand(B, 1, h, w, device="cuda"))).contiguous()
         kw = dict(cost=L.COST_VARIANCE_CVP if case == "generic_16ch" else L.COST_VARIANCE)
-    L.set_tuning("warp_tiled", 0 if case == "quad_variance" else 1)
+    L.set_tuning("warp_tiled", 0 if case == "quad_variance" else 4 if case == "lane_owner_variance" else 1)
     try:
         full = ops.warp_cost(fcl[0], fcl[1:], cams, dv, out_dtype=torch.float16, **kw)
         for y0, hs_ in ((0, 20), (13, 25), (30, 22)):

@@ -264,6 +264,8 @@ int warp_cost_tiled_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, in
 // the same kernel compiled WITH packed fp32 instructions ("warp_tiled" = 3; warp_cost_tiled.hip, Makefile): diagnostic build of the
 // co-scheduling defect, not safe beside other kernels
 int warp_cost_tiled_pk_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, int out_dtype, int ppd_override, hipStream_t st);
+// the lane-owns-voxel kernel ("warp_tiled" = 4; warp_cost_lv.hip): variance costs
+int warp_cost_lv_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, int out_dtype, int ppd_override, hipStream_t st);
 
 // Instantiated (geometry, cost) pairs: the variance / softmin statistics belong to the PROJ models (MVSNet,
 // CVP), group-wise correlation to the HOMOG model (Vis); the plain warp exists for both.
@@ -449,8 +451,11 @@ extern "C" int pscv_warp_cost_rows(const void* ref, const void* const* srcs, int
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int rc;
     if (g_warp_tiled && g_warp_lpv_override == 0 && cost != PSCV_COST_VARIANCE_PARTIAL) {
-        rc = g_warp_tiled == 3 ? warp_cost_tiled_pk_try(a, C, geom, cost, in_dtype, out_dtype, g_warp_ppd_override, st)
-                               : warp_cost_tiled_try(a, C, geom, cost, in_dtype, out_dtype, g_warp_ppd_override, st);
+        rc = 1;
+        if (g_warp_tiled == 4) rc = warp_cost_lv_try(a, C, geom, cost, in_dtype, out_dtype, g_warp_ppd_override, st);
+        if (rc == 1)
+            rc = g_warp_tiled == 3 ? warp_cost_tiled_pk_try(a, C, geom, cost, in_dtype, out_dtype, g_warp_ppd_override, st)
+                                   : warp_cost_tiled_try(a, C, geom, cost, in_dtype, out_dtype, g_warp_ppd_override, st);
         if (rc < 0) return rc;
         if (rc == 0) {
             PSCV_CHECK_LAUNCH("pscv_warp_cost(tiled)");

@@ -39,6 +39,7 @@
 #include <type_traits>
 
 #include "warp_common.h"
+#include "warp_lds.h"
 
 // Two builds of this file (Makefile).  The PRODUCT build (warp_cost_tiled.o) is compiled WITHOUT packed fp32 instructions
 // (-target-feature -packed-fp32-ops): next to another stream's / process's LDS + MFMA conv waves the v_pk_*_f32 instructions of the
@@ -64,7 +65,6 @@ constexpr int WL_THREADS = 64 * WL_TH;       // a wave = 2 tile rows x 8 pixels;
 constexpr int WL_PG = WL_TH / 2;             // pixel groups (waves per plane parity)
 constexpr int WL_ARENA = WL_TH == 8 ? 638 : 318;   // staged texels per block (all views): 80 / 40 KiB of fp32
 constexpr int WL_HI = WL_ARENA * 64;         // byte offset of the "hi" channel plane
-constexpr int WL_MAX_SRC = 4;                // source views of this kernel = lanes of a quad (others: quad kernel)
 constexpr int WL_STAGE_ROWS = 8;             // box rows one wave stages (one load batch)
 constexpr int WL_BOX_H = WL_STAGE_ROWS * (WL_THREADS / 64 / WL_MAX_SRC);   // tallest box the staging phase covers: 8 (4-row tile) / 16
 constexpr int WL_TABLE = 2 * WL_HI;          // per-view box records written by wave 0: 4 x {X0, Y0, X1, Y1, base, pitch, mode, -}
@@ -82,37 +82,7 @@ __device__ unsigned int wl_prof[WL_PROF_BLOCKS * 16];
 #define WL_STAMP(i)
 #endif
 
-// quad broadcast: every lane of a quad reads quad lane CTRL & 3.  (bound_ctrl with full row / bank masks: no lane keeps its
-// old value, so the compiler needs no copy of the source in front of the move.)
-template <int CTRL> __device__ __forceinline__ int wl_dpp_i(int x) { return __builtin_amdgcn_mov_dpp(x, CTRL, 0xf, 0xf, true); }
-template <int CTRL> __device__ __forceinline__ float wl_dpp_f(float x) {
-    return __builtin_bit_cast(float, wl_dpp_i<CTRL>(__builtin_bit_cast(int, x)));
-}
-
-
-// min / max over groups of 8 lanes (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror) and over the whole wave (+ row_mirror,
-// row_bcast15, row_bcast31; the result is read from lane 63): vector-ALU DPP modifiers instead of LDS-crossbar shuffles
-template <bool MAX> __device__ __forceinline__ float wl_mm(float a, float b) { return MAX ? fmaxf(a, b) : fminf(a, b); }
-template <bool MAX, int CTRL, int ROWMASK = 0xf> __device__ __forceinline__ float wl_red_step(float x) {
-    const int xi = __builtin_bit_cast(int, x);
-    const float y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(xi, xi, CTRL, ROWMASK, 0xf, false));
-    return wl_mm<MAX>(x, y);
-}
-template <bool MAX> __device__ __forceinline__ float wl_reduce8(float x) {
-    x = wl_red_step<MAX, 0xB1>(x);     // quad_perm [1,0,3,2]
-    x = wl_red_step<MAX, 0x4E>(x);     // quad_perm [2,3,0,1]
-    return wl_red_step<MAX, 0x141>(x); // row_half_mirror
-}
-template <bool MAX> __device__ __forceinline__ float wl_wave_reduce(float x) {
-    x = wl_reduce8<MAX>(x);
-    x = wl_red_step<MAX, 0x140>(x);          // row_mirror: all 16 lanes of a row
-    x = wl_red_step<MAX, 0x142, 0xa>(x);     // row_bcast15 into rows 1 and 3
-    x = wl_red_step<MAX, 0x143, 0xc>(x);     // row_bcast31 into rows 2 and 3
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
-}
-
 // eight fp32 channels x four taps -> eight blended channels; t = {00lo, 00hi, 01lo, 01hi, 10lo, 10hi, 11lo, 11hi}
-typedef float wl_f4 __attribute__((ext_vector_type(4)));
 // WL_X_BLEND / WL_X_SUMS / WL_X_FINAL (diagnostic builds of the PACKED kernel, scripts/dev/pk_variants.sh): that part of the sweep is
 // forced onto scalar fp32 instructions (inline assembly: the SLP vectorizer cannot pair them) while the rest keeps its packed forms
 // -- which packed instructions does the overlap defect need?
@@ -196,19 +166,6 @@ __device__ __forceinline__ wl_f4 wl_tap(const unsigned char* lsm, unsigned off) 
 #endif
 }
 
-// fp16 stores saturate at +-65504 like every other kernel of the engine (pscv_common.h), but through the MODE.FP16_OVFL bit the
-// kernel sets at its start ("an overflowed FP16 result is clamped to +-MAX_FP16 ... preserving true INF"): the per-element
-// v_med3_f32 clamp of pack_f16x2 costs 8 vector-ALU instructions per voxel here, 5 % of the sweep
-template <typename TOut> __device__ __forceinline__ uint32_t wl_pack2(float lo, float hi) {
-    if constexpr (Half16<TOut>::dtype == PSCV_F16) {
-        h2_t v;
-        v[0] = (_Float16)lo;
-        v[1] = (_Float16)hi;
-        return __builtin_bit_cast(uint32_t, v);
-    } else {
-        return Half16<TOut>::pack(lo, hi);
-    }
-}
 template <typename TOut> __device__ __forceinline__ void wl_store8(char* p, const float (&o)[8]) {
     if constexpr (sizeof(TOut) == 4) {
         *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
@@ -218,12 +175,6 @@ template <typename TOut> __device__ __forceinline__ void wl_store8(char* p, cons
                                                    wl_pack2<TOut>(o[4], o[5]), wl_pack2<TOut>(o[6], o[7]));
     }
 }
-
-// per-(block, view) staging mode, wave-uniform
-constexpr int WL_DIRECT = 0;   // not staged (a corner at / behind the source camera, or the box does not fit): global taps
-constexpr int WL_GEN = 1;      // box clipped at the image border: LDS taps, general (zero-padding) weights
-constexpr int WL_FAST = 2;     // box strictly inside the image: LDS taps, no masks / clamps
-constexpr int WL_ZERO = 3;     // box entirely outside the image: every tap is zero padding, the view contributes f = 0
 
 // (The software-pipelined sweep of round 3 -- next view's taps requested out of a second register buffer before the current view is
 //  blended; 164 VGPRs = three workgroups per CU; 2 % faster in the same binary, 5 % slower than the plain loop at 101 VGPRs -- was removed
@@ -693,7 +644,11 @@ static int wl_dispatch(const WarpArgs& a, int cost, int nblk, hipStream_t st) {
 // Returns 0 if launched, 1 if this configuration is not covered by the LDS-staged kernel (the caller uses the quad /
 // generic direct kernels), negative on error.
 extern Knob g_warp_tile;   // warp_cost.hip
-static int* g_wl_mode_hist = nullptr;   // set by pscv_debug_wl_mode_hist (development aid, not thread-safe)
+#ifdef WL_PK
+extern int* g_wl_mode_hist;
+#else
+int* g_wl_mode_hist = nullptr;   // set by pscv_debug_wl_mode_hist (development aid, not thread-safe; shared with warp_cost_lv.hip)
+#endif
 
 int warp_cost_tiled_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, int out_dtype, int ppd_override, hipStream_t st) {
     if (C != 32 || a.depth_per_pixel || geom != PSCV_GEOM_PROJ || (in_dtype != PSCV_F16 && in_dtype != PSCV_BF16)) return 1;
