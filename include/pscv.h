@@ -90,7 +90,7 @@ int pscv_abi_version(void);
  *               4: the lane-owns-voxel kernel (csrc/warp_cost_lv.hip; variance costs; same stored bits): 14 % fewer vector-ALU
  *               instructions and 2 % less time than the default on narrow-baseline rigs, ~2x slower where boxes do not fit the
  *               LDS arena (wide baselines) -- an alternative, not the default.
- *   "warp_tile" test aids of the lane-owns-voxel kernel (0 = off): 7 = every block on its general path, 8 = no stores, 9 = no taps
+ *   "warp_tile" test aids of the lane-owns-voxel kernel (0 = off): 7 = every block on its general path; ablations: 8 = no stores, 9 = no taps, 10 = neither
  *   "warp_lds_pad" KiB of LDS the LDS-staged warp kernel requests on top of its need (0 = default): fewer workgroups per CU with
  *               the same code (occupancy / stream co-residency experiments)
  *   "sweep_dc"  depth planes per workgroup of the depth-sweep convs (0 = default heuristic)

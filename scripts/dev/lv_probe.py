@@ -63,7 +63,7 @@ def main():
                     L.set_tuning("warp_tiled", -1)
             if "--ablate" in sys.argv:
                 outb = torch.empty((1, D, bench.h, bench.w, 32), dtype=dtype, device=dev)
-                for name, v in (("full", 0), ("no stores", 8), ("no taps / blend (staging + stores only)", 9)):
+                for name, v in (("full", 0), ("no stores", 8), ("no taps / blend (staging + stores only)", 9), ("no taps, no stores (box + staging only)", 10)):
                     L.set_tuning("warp_tiled", 4); L.set_tuning("warp_tile", v)
                     ts = [time_us(lambda: ops.warp_cost(fcl[0], fcl[1:], cams, dv_d, cost=L.COST_VARIANCE, out=outb), 30, 5) for _ in range(5)]
                     L.set_tuning("warp_tiled", -1); L.set_tuning("warp_tile", 0)

@@ -39,7 +39,10 @@
 // and SIMD whichever kernel issues it (clock ~1.8 GHz under this load), box + staging + stores alone take 55 us of the launch, and
 // neither a second prefetch step, four blocks per CU (LV_OCC = 4: 122 us, its smaller arena sends 5 % of the blocks to the general
 // path) nor three-address v_fma_f32 moved it.  On the DTU-like rig 60-90 % of the blocks have a view that does not fit and the
-// launch takes 327 us (quad-owner 175, direct gather 160): hence not the default.
+// launch takes 327 us (quad-owner 175, direct gather 160): hence not the default.  Ablations ("warp_tile" = 8 / 9 / 10): without
+// stores 103 us; without taps and blend 56 us; box phase + staging (+ the reference-only variance) alone 50 us, i.e. the per-block
+// fixed phases are NOT hidden behind the other blocks' sweeps (the quad-owner kernel's box + staging alone: 20 us at four blocks
+// per CU).  Starting the first generation of blocks staggered changed nothing (114 us either way).
 //
 // Semantics and citations are those of warp_cost.hip (reference: models/MVSNet/module.py:130-166, model.py:109-139).
 #include <type_traits>
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(LV_THREADS) __attribute__((amdgpu_waves_per_eu(LV_O
         }
     }
 
-    if (a.variant == 9) nv = 0;     // ("warp_tile" = 9: no taps, no blend -- box phase, staging, reference variance and stores only; an ablation)
+    if (a.variant == 9 || a.variant == 10) nv = 0;     // ("warp_tile" = 9: no taps, no blend -- box phase, staging, reference variance and stores only; 10: nor stores; ablations)
     // ---- 3. stage the boxes, 16-bit -> fp32, channel-chunk planar: wave k stages view k ----
     {
         const int k = wave;
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(LV_THREADS) __attribute__((amdgpu_waves_per_eu(LV_O
         st_pp |= vp << v;
         st_off[v] = (unsigned)(min(vy, a.h - 1) * a.w + min(vx, a.w - 1)) * (C * 2) + (unsigned)(lane >> 4) * 16u;
     }
-    if (a.variant == 8) st_act = 0;     // ("warp_tile" = 8: no stores, an ablation)
+    if (a.variant == 8 || a.variant == 10) st_act = 0;     // ("warp_tile" = 8: no stores, an ablation)
     const float invN = 1.0f / (float)(n_src + 1);
     const float invN2 = 1.0f / ((float)(n_src + 1) * (float)(n_src + 1));
     char* const out = reinterpret_cast<char*>(a.out);
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(LV_THREADS) __attribute__((amdgpu_waves_per_eu(LV_O
         // (keeps r * r of the loop-invariant reference feature out of 32 more registers)
 #pragma unroll
         for (int i = 0; i < C; ++i) asm volatile("" : "+v"(rf[i]));
-        const bool active = active_px && 2 * t + pp < nd && a.variant != 8;     // ("warp_tile" = 8: no stores, an ablation)
+        const bool active = active_px && 2 * t + pp < nd && a.variant != 8 && a.variant != 10;     // ("warp_tile" = 8: no stores, an ablation)
         const int d = d0 + min(2 * t + pp, nd - 1);
         char* const vox = out + ((unsigned long)b * a.D + d) * plane_bytes + lane_out;
 
