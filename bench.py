@@ -187,27 +187,32 @@ def geometry_probe(net, device, dtype, reps: int = 20):
                 net.hot_path(fcl, proj, dv)
             torch.cuda.synchronize()
             path_ms = (time.perf_counter() - t0) / reps * 1e3
-        _lib.set_tuning("warp_tiled", 0)          # the direct-gather (quad) kernel on the same launch: geometry-independent taps
-        try:
-            for _ in range(3):
-                warp()
-            e0.record()
-            for _ in range(reps):
-                warp()
-            e1.record()
-            torch.cuda.synchronize()
-            quad_us = e0.elapsed_time(e1) * 1e3 / reps
-        finally:
-            _lib.set_tuning("warp_tiled", -1)
+        alt_us = {}
+        for key, tiled in (("direct_gather", 0), ("lane_owner", 4)):     # 0: geometry-independent global taps; 4: csrc/warp_cost_lv.hip (optional)
+            _lib.set_tuning("warp_tiled", tiled)
+            try:
+                for _ in range(3):
+                    warp()
+                e0.record()
+                for _ in range(reps):
+                    warp()
+                e1.record()
+                torch.cuda.synchronize()
+                alt_us[key] = e0.elapsed_time(e1) * 1e3 / reps
+            finally:
+                _lib.set_tuning("warp_tiled", -1)
+        quad_us = alt_us["direct_gather"]
         out[rig] = {"warp_cost_us": round(warp_us, 1), "warp_cost_hbm_frac": round(algorithmic_bytes("warp_cost[0]") / (warp_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                    "warp_cost_us_direct_gather_kernel": round(quad_us, 1),
+                    "warp_cost_us_direct_gather_kernel": round(quad_us, 1), "warp_cost_us_lane_owner_kernel": round(alt_us["lane_owner"], 1),
                     "hot_path_eager_ms_per_view": round(path_ms, 4), "staging_modes_share_of_block_views": modes,
                     "staging_modes_per_view": [dict(zip(names, hm[v])) for v in range(V - 1)]}
     out["note"] = ("the headline line is measured on the probe rig; on the DTU-like rig the boxes of a 32-plane chunk exceed the kernel's 16 x 8 texel / "
                    "LDS budget for the wide-baseline views, which then take global taps (DIRECT): stand-alone launch times of both warp kernels are "
                    "given per rig (`pscv_set_tuning(\"warp_tiled\", 0)` selects the direct-gather kernel for wide-baseline rigs); a per-block "
                    "split of the chunk into 2-4 plane ranges was built and measured in round 4 (DIRECT 43 % -> 12 %, 215 -> 219 us: the extra "
-                   "box / staging / barrier phases cost what the staged taps saved) and not kept")
+                   "box / staging / barrier phases cost what the staged taps saved) and not kept; `warp_cost_us_lane_owner_kernel` is the optional "
+                   "lane-owns-voxel kernel (`warp_tiled` = 4; same bits; these stand-alone times come after each other, not interleaved: "
+                   "profiles/r04_warp_lane_owner.txt has the interleaved A/B)")
     return out
 
 
