@@ -149,86 +149,94 @@ __global__ __launch_bounds__(LV_THREADS) __attribute__((amdgpu_waves_per_eu(LV_O
         }
     }
 
-    // ---- 1. wave 0: texel box per view from the 8 corner projections (see warp_cost_tiled.hip for the argument) ----
-    if (wave == 0) {
+    // ---- 1. wave k: texel box of source view k from the 8 corner projections (see warp_cost_tiled.hip for the argument) ----
+    if (wave < WL_MAX_SRC) {
+        const int k = wave;
         const float dmin = wl_wave_reduce<false>(dlane), dmax = wl_wave_reduce<true>(dlane);
         const int corner = lane & 7;
         const float cx = (corner & 1) ? (float)min(x0t + LV_T - 1, a.w - 1) : (float)x0t;
         const float cy = (float)(((corner & 2) ? min(y0t + LV_TH - 1, a.h - 1) : y0t) + a.ref_y0);
         const float d = (corner & 4) ? dmax : dmin;
-        int used = 0;
-#pragma unroll
-        for (int k = 0; k < WL_MAX_SRC; ++k) {
-            int cX0 = 0, cY0 = 0, cX1 = 1, cY1 = 1, pitch = 2, mode = WL_ZERO;
-            if (k < n_src) {
-                lv_cf cam = (lv_cf)(a.cams + ((long)k * a.B + b) * PSCV_CAM_FLOATS);
-                const float ax = fmaf(cam[1], cy, cam[0] * cx) + cam[2];
-                const float ay = fmaf(cam[4], cy, cam[3] * cx) + cam[5];
-                const float az = fmaf(cam[7], cy, cam[6] * cx) + cam[8];
-                const float hx = fmaf(ax, d, cam[9]), hy = fmaf(ay, d, cam[10]), hz = fmaf(az, d, cam[11]);
-                const float inv_z = __builtin_amdgcn_rcpf(hz);
-                const float u = hx * inv_z, v = hy * inv_z;
-                const float okf = (hz > 1e-6f && fabsf(u) < 1e6f && fabsf(v) < 1e6f) ? 1.0f : 0.0f;   // also rejects NaN
-                const float umin = wl_reduce8<false>(u), umax = wl_reduce8<true>(u);
-                const float vmin = wl_reduce8<false>(v), vmax = wl_reduce8<true>(v);
-                const bool ok = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wl_reduce8<false>(okf))) != 0;
-                const float sl = 1.0f / 32.0f;     // slack for the per-pixel evaluation's different rounding (maps <= 16384 texels)
-                const int X0 = __builtin_amdgcn_readfirstlane((int)floorf(umin - sl)), X1 = __builtin_amdgcn_readfirstlane((int)floorf(umax + sl)) + 1;
-                const int Y0 = __builtin_amdgcn_readfirstlane((int)floorf(vmin - sl)), Y1 = __builtin_amdgcn_readfirstlane((int)floorf(vmax + sl)) + 1;
-                mode = WL_DIRECT;
-                if (ok) {
-                    const bool outside = X1 < 0 || Y1 < 0 || X0 > a.ws - 1 || Y0 > a.hs - 1;
-                    const bool inside = X0 >= 0 && Y0 >= 0 && X1 <= a.ws - 1 && Y1 <= a.hs - 1;
-                    // the staged box carries two texels of zero padding beyond each clipped border: a sample whose top-left tap
-                    // lies further out is clamped onto the padding, where both its taps of that axis are zero (module.py:160-166)
-                    cX0 = max(X0, -2); cX1 = min(X1, a.ws + 1); cY0 = max(Y0, -2); cY1 = min(Y1, a.hs + 1);
-                    const int bw = cX1 - cX0 + 1, bh = cY1 - cY0 + 1;
-                    pitch = bw;                    // (no padding of the rows: the lanes of an LDS pass read along ONE box row)
-                    if (outside) mode = WL_ZERO;
-                    else if (bw <= LV_BOX_W && bh <= LV_BOX_H && used + pitch * bh <= LV_ARENA) mode = inside ? WL_FAST : WL_GEN;
-                }
+        int cX0 = 0, cY0 = 0, cX1 = 1, cY1 = 1, pitch = 2, mode = WL_ZERO;      // mode: WL_FAST / WL_GEN here = "if the arena has room"
+        if (k < n_src) {
+            lv_cf cam = (lv_cf)(a.cams + ((long)k * a.B + b) * PSCV_CAM_FLOATS);
+            const float ax = fmaf(cam[1], cy, cam[0] * cx) + cam[2];
+            const float ay = fmaf(cam[4], cy, cam[3] * cx) + cam[5];
+            const float az = fmaf(cam[7], cy, cam[6] * cx) + cam[8];
+            const float hx = fmaf(ax, d, cam[9]), hy = fmaf(ay, d, cam[10]), hz = fmaf(az, d, cam[11]);
+            const float inv_z = __builtin_amdgcn_rcpf(hz);
+            const float u = hx * inv_z, v = hy * inv_z;
+            const float okf = (hz > 1e-6f && fabsf(u) < 1e6f && fabsf(v) < 1e6f) ? 1.0f : 0.0f;   // also rejects NaN
+            const float umin = wl_reduce8<false>(u), umax = wl_reduce8<true>(u);
+            const float vmin = wl_reduce8<false>(v), vmax = wl_reduce8<true>(v);
+            const bool ok = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wl_reduce8<false>(okf))) != 0;
+            const float sl = 1.0f / 32.0f;     // slack for the per-pixel evaluation's different rounding (maps <= 16384 texels)
+            const int X0 = __builtin_amdgcn_readfirstlane((int)floorf(umin - sl)), X1 = __builtin_amdgcn_readfirstlane((int)floorf(umax + sl)) + 1;
+            const int Y0 = __builtin_amdgcn_readfirstlane((int)floorf(vmin - sl)), Y1 = __builtin_amdgcn_readfirstlane((int)floorf(vmax + sl)) + 1;
+            mode = WL_DIRECT;
+            if (ok) {
+                const bool outside = X1 < 0 || Y1 < 0 || X0 > a.ws - 1 || Y0 > a.hs - 1;
+                const bool inside = X0 >= 0 && Y0 >= 0 && X1 <= a.ws - 1 && Y1 <= a.hs - 1;
+                // the staged box carries two texels of zero padding beyond each clipped border: a sample whose top-left tap
+                // lies further out is clamped onto the padding, where both its taps of that axis are zero (module.py:160-166)
+                cX0 = max(X0, -2); cX1 = min(X1, a.ws + 1); cY0 = max(Y0, -2); cY1 = min(Y1, a.hs + 1);
+                const int bw = cX1 - cX0 + 1, bh = cY1 - cY0 + 1;
+                pitch = bw;                    // (no padding of the rows: the lanes of an LDS pass read along ONE box row)
+                if (outside) mode = WL_ZERO;
+                else if (bw <= LV_BOX_W && bh <= LV_BOX_H) mode = inside ? WL_FAST : WL_GEN;
             }
-            if (lane == 0) {
-                int4* row = reinterpret_cast<int4*>(table + k * 8);
-                row[0] = make_int4(cX0, cY0, cX1, cY1);
-                row[1] = make_int4(used, pitch, mode, 0);
-                if (a.mode_hist && k < n_src) atomicAdd(a.mode_hist + k * 4 + mode, 1);
-            }
-            if (mode == WL_FAST || mode == WL_GEN) used += pitch * (cY1 - cY0 + 1);
+        }
+        if (lane == 0) {
+            int4* row = reinterpret_cast<int4*>(table + k * 8);
+            row[0] = make_int4(cX0, cY0, cX1, cY1);
+            row[1] = make_int4(0, pitch, mode, 0);
         }
     }
     __syncthreads();
 
-    // ---- 2. every wave: the box records -> scalar registers; the staged views, in view order, fill slots 0 .. nv-1 ----
-    int bMode[WL_MAX_SRC], bP[WL_MAX_SRC], bE0[WL_MAX_SRC];
+    // ---- 2. every wave: the box records -> scalar registers; arena allocation greedy in view order (a view whose box does not fit next
+    //         to the earlier ones is not staged), the same in every wave; the staged views, in view order, fill slots 0 .. nv-1 ----
+    int bMode[WL_MAX_SRC], bP[WL_MAX_SRC], bE0[WL_MAX_SRC], bBase[WL_MAX_SRC];
     int nv = 0, sView[WL_MAX_SRC] = {0, 0, 0, 0}, sP[WL_MAX_SRC] = {0, 0, 0, 0}, sE0[WL_MAX_SRC] = {0, 0, 0, 0};
     bool sGen[WL_MAX_SRC] = {false, false, false, false}, any_direct = a.variant == 7;     // ("warp_tile" = 7: every block on the general path, a test aid)
+    {
+        int used = 0;
 #pragma unroll
-    for (int k = 0; k < WL_MAX_SRC; ++k) {
-        const int4 r0 = *reinterpret_cast<const int4*>(table + k * 8), r1 = *reinterpret_cast<const int4*>(table + k * 8 + 4);
-        const int X0 = __builtin_amdgcn_readfirstlane(r0.x), Y0 = __builtin_amdgcn_readfirstlane(r0.y);
-        const int vbase = __builtin_amdgcn_readfirstlane(r1.x);
-        bP[k] = __builtin_amdgcn_readfirstlane(r1.y);
-        bMode[k] = k < n_src ? __builtin_amdgcn_readfirstlane(r1.z) : WL_ZERO;
-        bE0[k] = ((vbase - Y0 * bP[k] - X0) << 4) + (int)lds0;      // LDS byte address of texel (x, y), chunk 0 = (y * pitch + x) * 16 + bE0
-        any_direct = any_direct || bMode[k] == WL_DIRECT;
-        if (bMode[k] == WL_FAST || bMode[k] == WL_GEN) {
+        for (int k = 0; k < WL_MAX_SRC; ++k) {
+            const int4 r0 = *reinterpret_cast<const int4*>(table + k * 8), r1 = *reinterpret_cast<const int4*>(table + k * 8 + 4);
+            const int X0 = __builtin_amdgcn_readfirstlane(r0.x), Y0 = __builtin_amdgcn_readfirstlane(r0.y);
+            const int Y1 = __builtin_amdgcn_readfirstlane(r0.w);
+            bP[k] = __builtin_amdgcn_readfirstlane(r1.y);
+            int mode = k < n_src ? __builtin_amdgcn_readfirstlane(r1.z) : WL_ZERO;
+            const int need = bP[k] * (Y1 - Y0 + 1);
+            if ((mode == WL_FAST || mode == WL_GEN) && used + need > LV_ARENA) mode = WL_DIRECT;
+            bBase[k] = used;
+            if (mode == WL_FAST || mode == WL_GEN) used += need;
+            bMode[k] = mode;
+            if (a.mode_hist && k < n_src && tid == 0) atomicAdd(a.mode_hist + k * 4 + mode, 1);
+            bE0[k] = ((bBase[k] - Y0 * bP[k] - X0) << 4) + (int)lds0;      // LDS byte address of texel (x, y), chunk 0 = (y * pitch + x) * 16 + bE0
+            any_direct = any_direct || mode == WL_DIRECT;
+            if (mode == WL_FAST || mode == WL_GEN) {
 #pragma unroll
-            for (int jj = 0; jj < WL_MAX_SRC; ++jj)
-                if (jj == nv) { sView[jj] = k; sP[jj] = bP[k]; sE0[jj] = bE0[k]; sGen[jj] = bMode[k] == WL_GEN; }
-            ++nv;
+                for (int jj = 0; jj < WL_MAX_SRC; ++jj)
+                    if (jj == nv) { sView[jj] = k; sP[jj] = bP[k]; sE0[jj] = bE0[k]; sGen[jj] = mode == WL_GEN; }
+                ++nv;
+            }
         }
     }
-
     if (a.variant == 9 || a.variant == 10) nv = 0;     // ("warp_tile" = 9: no taps, no blend -- box phase, staging, reference variance and stores only; 10: nor stores; ablations)
+
     // ---- 3. stage the boxes, 16-bit -> fp32, channel-chunk planar: wave k stages view k ----
     {
         const int k = wave;
-        const int4 f0 = *reinterpret_cast<const int4*>(table + k * 8), f1 = *reinterpret_cast<const int4*>(table + k * 8 + 4);
+        const int4 f0 = *reinterpret_cast<const int4*>(table + k * 8);
         const int sX0 = __builtin_amdgcn_readfirstlane(f0.x), sY0 = __builtin_amdgcn_readfirstlane(f0.y);
         const int sX1 = __builtin_amdgcn_readfirstlane(f0.z), sY1 = __builtin_amdgcn_readfirstlane(f0.w);
-        const int sP16 = __builtin_amdgcn_readfirstlane(f1.y) << 4, sMode = __builtin_amdgcn_readfirstlane(f1.z);
-        const int sBase = (__builtin_amdgcn_readfirstlane(f1.x) << 4) - sY0 * sP16 - (sX0 << 4);
+        int sP16 = bP[0] << 4, sMode = bMode[0], sBase = bBase[0];
+#pragma unroll
+        for (int t = 1; t < WL_MAX_SRC; ++t)
+            if (k == t) { sP16 = bP[t] << 4; sMode = bMode[t]; sBase = bBase[t]; }
+        sBase = (sBase << 4) - sY0 * sP16 - (sX0 << 4);
         const void* srcp = a.src[0];
 #pragma unroll
         for (int t = 1; t < WL_MAX_SRC; ++t)

@@ -259,91 +259,101 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
     //         8 points.  The camera blocks come through the SCALAR cache (constant address space: the vector memory path is
     //         busy with the cost-volume stores of the other waves and answers in thousands of cycles); lanes = corners;
     //         min / max by DPP; arena allocation greedy in view order, all in scalar registers. ----
-    if (wave == 0) {
-        const float dmin = wl_wave_reduce<false>(dlane), dmax = wl_wave_reduce<true>(dlane);   // (planes need not be monotone)
+    if (wave < WL_MAX_SRC) {      // wave k: the box of source view k (round 4: the four views side by side instead of one after the other in wave 0)
+        const int k = wave;
+        // (depth range: a wave reduction of the per-lane planes; reading the planes through the scalar cache instead -- s_load_dwordx8
+        //  runs, v_min / v_max -- was measured 2 % slower, round 4; planes need not be monotone)
+        const float dmin = wl_wave_reduce<false>(dlane), dmax = wl_wave_reduce<true>(dlane);
         const int corner = lane & 7;
         const float cx = (corner & 1) ? (float)min(x0t + WL_T - 1, a.w - 1) : (float)x0t;
         const float cy = (float)(((corner & 2) ? min(y0t + WL_TH - 1, a.h - 1) : y0t) + a.ref_y0);
         const float d = (corner & 4) ? dmax : dmin;
-        int used = 0;
-#pragma unroll
-        for (int k = 0; k < WL_MAX_SRC; ++k) {
-            int cX0 = 0, cY0 = 0, cX1 = -1, cY1 = -1, pitch = 4, mode = WL_ZERO;
-            if (k < n_src) {
-                typedef const __attribute__((address_space(4))) float* wl_cf;
-                wl_cf cam = (wl_cf)(a.cams + ((long)k * a.B + b) * PSCV_CAM_FLOATS);
-#ifdef WL_X_BOX      // (diagnostic: the box arithmetic of wave 0 on scalar fp32 instructions, see wl_mul_s)
-                const float ax = wl_add_s(wl_fma_s(cam[1], cy, wl_mul_s(cam[0], cx)), cam[2]);
-                const float ay = wl_add_s(wl_fma_s(cam[4], cy, wl_mul_s(cam[3], cx)), cam[5]);
-                const float az = wl_add_s(wl_fma_s(cam[7], cy, wl_mul_s(cam[6], cx)), cam[8]);
-                const float hx = wl_fma_s(ax, d, cam[9]), hy = wl_fma_s(ay, d, cam[10]), hz = wl_fma_s(az, d, cam[11]);
-                const float inv_z = __builtin_amdgcn_rcpf(hz);
-                const float u = wl_mul_s(hx, inv_z), v = wl_mul_s(hy, inv_z);
+        int cX0 = 0, cY0 = 0, cX1 = -1, cY1 = -1, pitch = 4, mode = WL_ZERO;      // mode: WL_FAST / WL_GEN here = "if the arena has room"
+        if (k < n_src) {
+            typedef const __attribute__((address_space(4))) float* wl_cf;
+            wl_cf cam = (wl_cf)(a.cams + ((long)k * a.B + b) * PSCV_CAM_FLOATS);
+#ifdef WL_X_BOX      // (diagnostic: the box arithmetic on scalar fp32 instructions, see wl_mul_s)
+            const float ax = wl_add_s(wl_fma_s(cam[1], cy, wl_mul_s(cam[0], cx)), cam[2]);
+            const float ay = wl_add_s(wl_fma_s(cam[4], cy, wl_mul_s(cam[3], cx)), cam[5]);
+            const float az = wl_add_s(wl_fma_s(cam[7], cy, wl_mul_s(cam[6], cx)), cam[8]);
+            const float hx = wl_fma_s(ax, d, cam[9]), hy = wl_fma_s(ay, d, cam[10]), hz = wl_fma_s(az, d, cam[11]);
+            const float inv_z = __builtin_amdgcn_rcpf(hz);
+            const float u = wl_mul_s(hx, inv_z), v = wl_mul_s(hy, inv_z);
 #else
-                const float ax = fmaf(cam[1], cy, cam[0] * cx) + cam[2];
-                const float ay = fmaf(cam[4], cy, cam[3] * cx) + cam[5];
-                const float az = fmaf(cam[7], cy, cam[6] * cx) + cam[8];
-                const float hx = fmaf(ax, d, cam[9]), hy = fmaf(ay, d, cam[10]), hz = fmaf(az, d, cam[11]);
-                const float inv_z = __builtin_amdgcn_rcpf(hz);
-                const float u = hx * inv_z, v = hy * inv_z;
+            const float ax = fmaf(cam[1], cy, cam[0] * cx) + cam[2];
+            const float ay = fmaf(cam[4], cy, cam[3] * cx) + cam[5];
+            const float az = fmaf(cam[7], cy, cam[6] * cx) + cam[8];
+            const float hx = fmaf(ax, d, cam[9]), hy = fmaf(ay, d, cam[10]), hz = fmaf(az, d, cam[11]);
+            const float inv_z = __builtin_amdgcn_rcpf(hz);
+            const float u = hx * inv_z, v = hy * inv_z;
 #endif
-                const float okf = (hz > 1e-6f && fabsf(u) < 1e6f && fabsf(v) < 1e6f) ? 1.0f : 0.0f;   // also rejects NaN
-                const float umin = wl_reduce8<false>(u), umax = wl_reduce8<true>(u);
-                const float vmin = wl_reduce8<false>(v), vmax = wl_reduce8<true>(v);
-                const bool ok = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wl_reduce8<false>(okf))) != 0;
-                // slack of 1/32 texel: the per-pixel fp32 evaluation (different rounding, 1-ulp rcp on both sides) differs
-                // from the corners' by < 2e-6 relative, i.e. < 1/32 for maps up to 16384 texels wide (larger ones are refused)
-                const float sl = 1.0f / 32.0f;
-                const int X0 = __builtin_amdgcn_readfirstlane((int)floorf(umin - sl)), X1 = __builtin_amdgcn_readfirstlane((int)floorf(umax + sl)) + 1;
-                const int Y0 = __builtin_amdgcn_readfirstlane((int)floorf(vmin - sl)), Y1 = __builtin_amdgcn_readfirstlane((int)floorf(vmax + sl)) + 1;
-                mode = WL_DIRECT;
-                if (ok) {
-                    const bool outside = X1 < 0 || Y1 < 0 || X0 > a.ws - 1 || Y0 > a.hs - 1;
-                    const bool inside = X0 >= 0 && Y0 >= 0 && X1 <= a.ws - 1 && Y1 <= a.hs - 1;
-                    cX0 = max(X0, 0); cX1 = min(X1, a.ws - 1); cY0 = max(Y0, 0); cY1 = min(Y1, a.hs - 1);
-                    const int bw = cX1 - cX0 + 1, bh = cY1 - cY0 + 1;
-                    pitch = (bw + 3) & ~3;   // a multiple of 4: the quads of a ds_read_b128 lane group stay conflict-free across rows
-                    if (outside) mode = WL_ZERO;
-                    else if (bw <= 16 && bh <= WL_BOX_H && used + pitch * bh <= WL_ARENA) mode = inside ? WL_FAST : WL_GEN;
-                }
+            const float okf = (hz > 1e-6f && fabsf(u) < 1e6f && fabsf(v) < 1e6f) ? 1.0f : 0.0f;   // also rejects NaN
+            const float umin = wl_reduce8<false>(u), umax = wl_reduce8<true>(u);
+            const float vmin = wl_reduce8<false>(v), vmax = wl_reduce8<true>(v);
+            const bool ok = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wl_reduce8<false>(okf))) != 0;
+            // slack of 1/32 texel: the per-pixel fp32 evaluation (different rounding, 1-ulp rcp on both sides) differs
+            // from the corners' by < 2e-6 relative, i.e. < 1/32 for maps up to 16384 texels wide (larger ones are refused)
+            const float sl = 1.0f / 32.0f;
+            const int X0 = __builtin_amdgcn_readfirstlane((int)floorf(umin - sl)), X1 = __builtin_amdgcn_readfirstlane((int)floorf(umax + sl)) + 1;
+            const int Y0 = __builtin_amdgcn_readfirstlane((int)floorf(vmin - sl)), Y1 = __builtin_amdgcn_readfirstlane((int)floorf(vmax + sl)) + 1;
+            mode = WL_DIRECT;
+            if (ok) {
+                const bool outside = X1 < 0 || Y1 < 0 || X0 > a.ws - 1 || Y0 > a.hs - 1;
+                const bool inside = X0 >= 0 && Y0 >= 0 && X1 <= a.ws - 1 && Y1 <= a.hs - 1;
+                cX0 = max(X0, 0); cX1 = min(X1, a.ws - 1); cY0 = max(Y0, 0); cY1 = min(Y1, a.hs - 1);
+                const int bw = cX1 - cX0 + 1, bh = cY1 - cY0 + 1;
+                pitch = (bw + 3) & ~3;   // a multiple of 4: the quads of a ds_read_b128 lane group stay conflict-free across rows
+                if (outside) mode = WL_ZERO;
+                else if (bw <= 16 && bh <= WL_BOX_H) mode = inside ? WL_FAST : WL_GEN;
             }
-            if (lane == 0) {
-                int4* row = reinterpret_cast<int4*>(table + k * 8);
-                row[0] = make_int4(cX0, cY0, cX1, cY1);
-                row[1] = make_int4(used, pitch, mode, 0);
-                if (a.mode_hist && k < n_src) atomicAdd(a.mode_hist + k * 4 + mode, 1);     // (bench.py's mode histogram; off in product launches)
-            }
-            if (mode == WL_FAST || mode == WL_GEN) used += pitch * (cY1 - cY0 + 1);
+        }
+        if (lane == 0) {
+            int4* row = reinterpret_cast<int4*>(table + k * 8);
+            row[0] = make_int4(cX0, cY0, cX1, cY1);
+            row[1] = make_int4(0, pitch, mode, 0);
         }
     }
     WL_STAMP(1)
     __syncthreads();
     WL_STAMP(2)
 
-    // ---- 2. every wave: modes / pitches of the four views -> scalar registers; this lane's view -> vector registers ----
-    int bPitch[WL_MAX_SRC], bMode[WL_MAX_SRC];
+    // ---- 2. every wave: the four records -> scalar registers; arena allocation greedy in view order (a view whose box does not fit
+    //         next to the earlier ones takes global taps), the same in every wave; this lane's view -> vector registers ----
+    int bPitch[WL_MAX_SRC], bMode[WL_MAX_SRC], bBase[WL_MAX_SRC], bX0[WL_MAX_SRC], bY0[WL_MAX_SRC], bX1[WL_MAX_SRC], bY1[WL_MAX_SRC];
     bool any_gen = false;
+    {
+        int used = 0;
 #pragma unroll
-    for (int k = 0; k < WL_MAX_SRC; ++k) {
-        const int4 r1 = *reinterpret_cast<const int4*>(table + k * 8 + 4);
-        bPitch[k] = __builtin_amdgcn_readfirstlane(r1.y);
-        bMode[k] = __builtin_amdgcn_readfirstlane(r1.z);
-        any_gen = any_gen || bMode[k] == WL_GEN;
+        for (int k = 0; k < WL_MAX_SRC; ++k) {
+            const int4 r0 = *reinterpret_cast<const int4*>(table + k * 8), r1 = *reinterpret_cast<const int4*>(table + k * 8 + 4);
+            bX0[k] = __builtin_amdgcn_readfirstlane(r0.x); bY0[k] = __builtin_amdgcn_readfirstlane(r0.y);
+            bX1[k] = __builtin_amdgcn_readfirstlane(r0.z); bY1[k] = __builtin_amdgcn_readfirstlane(r0.w);
+            bPitch[k] = __builtin_amdgcn_readfirstlane(r1.y);
+            int mode = __builtin_amdgcn_readfirstlane(r1.z);
+            const int need = bPitch[k] * (bY1[k] - bY0[k] + 1);
+            if ((mode == WL_FAST || mode == WL_GEN) && used + need > WL_ARENA) mode = WL_DIRECT;
+            bBase[k] = used;
+            if (mode == WL_FAST || mode == WL_GEN) used += need;
+            bMode[k] = mode;
+            any_gen = any_gen || mode == WL_GEN;
+            if (a.mode_hist && k < n_src && tid == 0) atomicAdd(a.mode_hist + k * 4 + mode, 1);     // (bench.py's mode histogram; off in product launches)
+        }
     }
     const int sel = l;
-    const int4 mr0 = *reinterpret_cast<const int4*>(table + sel * 8), mr1 = *reinterpret_cast<const int4*>(table + sel * 8 + 4);
-    const int mX0 = mr0.x, mY0 = mr0.y, mX1 = mr0.z, mY1 = mr0.w, mpitch = mr1.y;
-    const int meb = mr1.x - mY0 * mpitch - mX0;    // texel index = y * pitch + x + meb
+    int mX0 = bX0[0], mY0 = bY0[0], mX1 = bX1[0], mY1 = bY1[0], mpitch = bPitch[0], mbase = bBase[0];
+#pragma unroll
+    for (int k = 1; k < WL_MAX_SRC; ++k)
+        if (sel == k) { mX0 = bX0[k]; mY0 = bY0[k]; mX1 = bX1[k]; mY1 = bY1[k]; mpitch = bPitch[k]; mbase = bBase[k]; }
+    const int meb = mbase - mY0 * mpitch - mX0;    // texel index = y * pitch + x + meb
 
     // ---- 3. stage the boxes, 16-bit -> fp32 on the way: waves 2k, 2k+1 take the even / odd rows of view k's box ----
     {
         constexpr int WPV = WL_THREADS / 64 / WL_MAX_SRC;   // waves per view: 2 (even / odd rows) or 1
         const int k = wave / WPV;
-        const int4 f0 = *reinterpret_cast<const int4*>(table + k * 8), f1 = *reinterpret_cast<const int4*>(table + k * 8 + 4);
-        const int X0 = __builtin_amdgcn_readfirstlane(f0.x), Y0 = __builtin_amdgcn_readfirstlane(f0.y);
-        const int X1 = __builtin_amdgcn_readfirstlane(f0.z), Y1 = __builtin_amdgcn_readfirstlane(f0.w);
-        const int vbase = __builtin_amdgcn_readfirstlane(f1.x), pitch = __builtin_amdgcn_readfirstlane(f1.y);
-        const int mode = __builtin_amdgcn_readfirstlane(f1.z);
+        int X0 = bX0[0], Y0 = bY0[0], X1 = bX1[0], Y1 = bY1[0], vbase = bBase[0], pitch = bPitch[0], mode = bMode[0];
+#pragma unroll
+        for (int t = 1; t < WL_MAX_SRC; ++t)
+            if (k == t) { X0 = bX0[t]; Y0 = bY0[t]; X1 = bX1[t]; Y1 = bY1[t]; vbase = bBase[t]; pitch = bPitch[t]; mode = bMode[t]; }
         const void* srcp = a.src[0];
 #pragma unroll
         for (int t = 1; t < WL_MAX_SRC; ++t)
