@@ -91,6 +91,10 @@ int pscv_abi_version(void);
  *               instructions and 2 % less time than the default on narrow-baseline rigs, ~2x slower where boxes do not fit the
  *               LDS arena (wide baselines) -- an alternative, not the default.
  *   "warp_tile" test aids of the lane-owns-voxel kernel (0 = off): 7 = every block on its general path; ablations: 8 = no stores, 9 = no taps, 10 = neither
+ *   "warp_gc_lds" 1 (default): group-wise correlation volumes (C = 32, 16-bit, HOMOG geometry, maps of >= 21 x 21 texels) over PER-BATCH
+ *               planes run the LDS-staged kernel (csrc/warp_gc_lv.hip; 1.8x the quad kernel on the stage-1 shape of BASELINE
+ *               configuration 5; values equal to one 16-bit ulp); 2: per-pixel planes too (slower when the per-pixel depths of a tile
+ *               spread widely: boxes that do not fit the LDS take slow global taps); 0: always the quad kernel
  *   "warp_lds_pad" KiB of LDS the LDS-staged warp kernel requests on top of its need (0 = default): fewer workgroups per CU with
  *               the same code (occupancy / stream co-residency experiments)
  *   "sweep_dc"  depth planes per workgroup of the depth-sweep convs (0 = default heuristic)

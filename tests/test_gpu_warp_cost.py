@@ -289,6 +289,51 @@ def test_quad_kernel_equals_generic_kernel(env, baseline_scale, shape, D, per_pi
                 max_abs=ulp * float(outs[1].abs().max()), rel_l2=ulp / 16)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("baseline_scale,shape,V,D,per_pixel", [(1.0, (64, 80), 5, 24, False), (1.0, (37, 53), 4, 23, True), (12.0, (40, 48), 4, 7, False),
+                                                              (1.0, (72, 100), 9, 40, False), (1.0, (48, 64), 3, 32, True), (3.0, (48, 48), 7, 16, True)])
+def test_lds_staged_groupcorr_equals_quad_kernel(env, baseline_scale, shape, V, D, per_pixel, dtype):
+    """The LDS-staged group-correlation kernel (warp_gc_lv.hip, `warp_gc_lds`) against the quad kernel on the same taps:
+    HOMOG geometry with per-batch and per-pixel planes (the Vis-MVSNet stages), 2-8 source views (groups of four per launch), image
+    sizes the 8 x 4 tile does not divide, odd plane counts, a wide baseline (clipped boxes, boxes outside the image, views that do not
+    fit and take global taps) and -- `warp_tile` = 7 -- nothing staged at all.  The warp runs the same fp32 chain in both kernels;
+    the group sums may differ in the last fp32 bit, so the stored values agree to one 16-bit ulp of the volume's scale and nearly all
+    are equal."""
+    L, ops, O = env
+    from wild_deep_mvs_amd import synthetic
+    import oracle.vismvsnet as OV
+    h, w = shape
+    B, C = 2, 32
+    feats = synthetic.make_features(B, V, C, h, w, seed=21)
+    cam = synthetic.make_cameras(B, V, 4 * h, 4 * w)
+    cam["t"] = cam["t"] * baseline_scale
+    di = (cam["depth_max"] - cam["depth_min"]) / D
+    arr = [OV.fill_cam_array(cam["K"][:, i], cam["R"][:, i], cam["t"][:, i], cam["depth_min"][:, i], di[:, i]) for i in range(V)]
+    cams = ops.homog_cams_device(arr[0].cuda(), [a.cuda() for a in arr[1:]], 1.0 / 4)
+    fcl = [ops.to_channels_last(feats[i].cuda(), dtype) for i in range(V)]
+    dv = (cam["depth_min"][:, :1] + di[:, :1] * torch.arange(D, dtype=torch.float32).view(1, D)).contiguous()
+    if per_pixel:
+        gen = torch.Generator().manual_seed(1)
+        dv = (dv.view(B, D, 1, 1) * (1.0 + 0.05 * torch.rand(B, 1, h, w, generator=gen))).contiguous()
+    outs = {}
+    assert L.get_tuning("warp_gc_lds") == 1          # (default: per-batch planes on the staged kernel, per-pixel planes on the quad kernel)
+    for name, gc, tile in (("staged", 2, 0), ("staged kernel, nothing staged", 2, 7), ("quad", 0, 0)):
+        L.set_tuning("warp_gc_lds", gc)
+        L.set_tuning("warp_tile", tile)
+        try:
+            outs[name] = ops.warp_cost(fcl[0], fcl[1:], cams, dv.cuda(), geom=L.GEOM_HOMOG, cost=L.COST_GROUPCORR, out_dtype=dtype).float().cpu()
+        finally:
+            L.set_tuning("warp_gc_lds", 1)
+            L.set_tuning("warp_tile", 0)
+    want = outs["quad"]
+    assert tuple(want.shape) == (V - 1, B, D, h, w, 8) and float(want.abs().max()) > 0
+    ulp = 2 ** -7 if dtype == torch.bfloat16 else 2 ** -10
+    for name in ("staged", "staged kernel, nothing staged"):
+        check_close(f"groupcorr {name} vs quad {dtype} baseline x{baseline_scale} {shape} V={V} D={D} per_pixel={per_pixel}", outs[name], want,
+                    max_abs=ulp * float(want.abs().max()), rel_l2=ulp / 16)
+        assert float((outs[name] != want).float().mean()) < 0.02, f"{name}: {float((outs[name] != want).float().mean()):.4f} of the values differ"
+
+
 def test_staged_kernel_fp16_stores_saturate(env):
     """fp16 cost volumes saturate at +-65504 instead of becoming inf (every kernel of the engine does; the LDS-staged warp
     kernel gets it from the MODE.FP16_OVFL bit instead of a per-element clamp): features of magnitude ~300 give variances up

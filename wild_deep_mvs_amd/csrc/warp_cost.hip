@@ -242,6 +242,7 @@ __global__ __launch_bounds__(256, 4) void warp_cost_kernel(const WarpArgs a) {
 // ---- host side ---------------------------------------------------------------------------------
 static Knob g_warp_lpv_override = {0, KNOB_WARP_LPV};  // 0 = default heuristic; set through pscv_set_tuning("warp_lpv", n)
 static Knob g_warp_ppd_override = {0, KNOB_WARP_PPD};
+static Knob g_warp_gc_lds = {1, KNOB_WARP_GC_LDS};   // 1 (default): group-correlation volumes over per-batch planes on the LDS-staged kernel (warp_gc_lv.hip); 2: per-pixel planes too; 0: quad kernel
 static Knob g_warp_tiled = {1, KNOB_WARP_TILED};     // 1 (default; 2 = the same): the LDS-staged kernel (warp_cost_tiled.hip) where it applies: fp32
                                  // patches, scalar fp32 blend, same bits as the direct kernels; 0: direct kernels; 3: its packed-fp32 build (diagnostic)
 extern Knob g_conv_small_tiles;   // conv3d.hip
@@ -266,6 +267,8 @@ int warp_cost_tiled_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, in
 int warp_cost_tiled_pk_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, int out_dtype, int ppd_override, hipStream_t st);
 // the lane-owns-voxel kernel ("warp_tiled" = 4; warp_cost_lv.hip): variance costs
 int warp_cost_lv_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, int out_dtype, int ppd_override, hipStream_t st);
+// group-wise correlation, LDS-staged (warp_gc_lv.hip)
+int warp_gc_lv_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, int out_dtype, int ppd_override, hipStream_t st);
 
 // Instantiated (geometry, cost) pairs: the variance / softmin statistics belong to the PROJ models (MVSNet,
 // CVP), group-wise correlation to the HOMOG model (Vis); the plain warp exists for both.
@@ -360,7 +363,7 @@ namespace pscv {
 static Knob* find_knob(const char* key) {
     static const struct { const char* name; Knob* k; } table[] = {
         {"warp_lpv", &g_warp_lpv_override}, {"warp_ppd", &g_warp_ppd_override}, {"conv_small_tiles", &g_conv_small_tiles},
-        {"warp_tiled", &g_warp_tiled}, {"warp_q2", &g_warp_q2}, {"c1_nb", &g_c1_nb}, {"c1_sweep", &g_c1_sweep},
+        {"warp_tiled", &g_warp_tiled}, {"warp_gc_lds", &g_warp_gc_lds}, {"warp_q2", &g_warp_q2}, {"c1_nb", &g_c1_nb}, {"c1_sweep", &g_c1_sweep},
         {"sweep_th16", &g_sweep_th16}, {"sweep_dc", &g_sweep_dc}, {"sweep_kdm", &g_sweep_kdm}, {"sweep_kdm_pd", &g_sweep_kdm_pd}, {"sweepc_slots", &g_sweepc_slots}, {"sweepc_pd", &g_sweepc_pd},
         {"warp_bwd_direct", &g_warp_bwd_direct}, {"conv_s2_sweep", &g_conv_s2_sweep}, {"s2s_slots", &g_s2s_slots},
         {"warp_tile", &g_warp_tile}, {"fuse_c0", &g_fuse_c0}, {"warp_lds_pad", &g_warp_lds_pad}, {"conv2d_wlds", &g_conv2d_wlds}, {"conv_tall64", &g_conv_tall64}, {"block8_slots", &::g_block8_slots}, {"softargmin_small", &::g_softargmin_small}};
@@ -453,6 +456,7 @@ extern "C" int pscv_warp_cost_rows(const void* ref, const void* const* srcs, int
     if (g_warp_tiled && g_warp_lpv_override == 0 && cost != PSCV_COST_VARIANCE_PARTIAL) {
         rc = 1;
         if (g_warp_tiled == 4) rc = warp_cost_lv_try(a, C, geom, cost, in_dtype, out_dtype, g_warp_ppd_override, st);
+        if (rc == 1 && g_warp_gc_lds && (g_warp_gc_lds >= 2 || !depth_per_pixel)) rc = warp_gc_lv_try(a, C, geom, cost, in_dtype, out_dtype, g_warp_ppd_override, st);
         if (rc == 1)
             rc = g_warp_tiled == 3 ? warp_cost_tiled_pk_try(a, C, geom, cost, in_dtype, out_dtype, g_warp_ppd_override, st)
                                    : warp_cost_tiled_try(a, C, geom, cost, in_dtype, out_dtype, g_warp_ppd_override, st);

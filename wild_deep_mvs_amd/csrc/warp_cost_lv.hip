@@ -49,51 +49,9 @@
 
 #include "warp_common.h"
 #include "warp_lds.h"
+#include "warp_lv.h"
 
 namespace pscv {
-
-constexpr int LV_T = 8, LV_TH = 4;           // tile of reference pixels
-constexpr int LV_THREADS = 256;              // 4 waves; a wave trip = 32 pixels x 2 planes
-#ifndef LV_OCC
-#define LV_OCC 3                             // blocks per CU (= waves per SIMD): 3 -> 52 KiB arena, 168 registers; 4 -> 39.5 KiB, 128
-#endif
-constexpr int LV_ARENA = LV_OCC == 3 ? 416 : 316;   // staged texels per block (all views), fp32
-constexpr int LV_PLANE = LV_ARENA * 16;      // bytes of one channel-chunk plane
-constexpr int LV_TABLE = 8 * LV_PLANE;       // per-view box records written by wave 0
-constexpr int LV_LDS = LV_TABLE + WL_MAX_SRC * 32 + 32;
-constexpr int LV_BOX_W = 32, LV_BOX_H = 16;  // largest box the staging phase covers (one wave per view, batches of 8 rows x 16 texels)
-static_assert(LV_OCC * LV_LDS <= 160 * 1024, "LV_OCC blocks per CU");
-static_assert(7 * LV_PLANE + 16 < 65536, "chunk planes within the immediate offset of ds_read");
-
-typedef const __attribute__((address_space(4))) float* lv_cf;   // camera blocks through the scalar cache
-typedef const __attribute__((address_space(3))) wl_f4* lv_lp;   // a tap in LDS, by absolute byte address
-
-// (address + constant in one expression: the constant lands in the instruction's offset field)
-__device__ __forceinline__ wl_f4 lv_tap(unsigned addr, int off) { return *reinterpret_cast<lv_lp>(addr + (unsigned)off); }
-
-__device__ __forceinline__ void lv_blend(const wl_f4& t00, const wl_f4& t01, const wl_f4& t10, const wl_f4& t11, const float (&w)[4], float (&wv)[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) wv[i] = fmaf(t11[i], w[3], fmaf(t10[i], w[2], fmaf(t01[i], w[1], t00[i] * w[0])));
-}
-
-// The voxel of lane L in a wave trip: LDS pass g (= half wave x index parity of the quad of lanes) is pixel row g of the tile; its 16
-// lanes are 8 pixels x 2 planes.
-__device__ __forceinline__ void lv_voxel_of(int L, int& prow, int& pcol, int& pp) {
-    const int q3 = (L >> 2) & 7;
-    const int j16 = ((q3 >> 1) << 2) | (L & 3);
-    prow = ((L >> 5) << 1) | (__builtin_popcount(q3) & 1); pcol = j16 & 7; pp = j16 >> 3;
-}
-
-// 4 x 4 transpose across the four 16-lane rows of a wave (gfx950 row swaps): in: x[p] = piece p of the voxel each lane owns;
-// out: x[v] in lane (row r, column c) = piece r of the voxel of lane (row v, column c).
-//   v_permlane32_swap a, b : a = [a0 a1 b0 b1], b = [a2 a3 b2 b3]      v_permlane16_swap a, b : a = [a0 b0 a2 b2], b = [a1 b1 a3 b3]
-__device__ __forceinline__ void lv_row_transpose(uint32_t (&x)[4]) {
-    auto s02 = __builtin_amdgcn_permlane32_swap(x[0], x[2], false, false);
-    auto s13 = __builtin_amdgcn_permlane32_swap(x[1], x[3], false, false);
-    auto t01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
-    auto t23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
-    x[0] = t01[0]; x[1] = t01[1]; x[2] = t23[0]; x[3] = t23[1];
-}
 
 template <typename TIn, typename TOut, int COST>
 __global__ __launch_bounds__(LV_THREADS) __attribute__((amdgpu_waves_per_eu(LV_OCC, LV_OCC))) void warp_cost_lv_kernel(const WarpArgs a) {
