@@ -123,8 +123,10 @@ def test_warp_cost_kernels_are_bit_stable_beside_conv0(env, soak, name, tiled, c
     assert bad == 0
 
 
-def test_groupcorr_homog_warp_is_bit_stable_beside_conv0(env, soak):
-    """Vis-MVSNet's sweep: HOMOG geometry, group-wise correlation, 4 source views (quad kernel)."""
+@pytest.mark.parametrize("kernel", ["lds", "quad"])
+def test_groupcorr_homog_warp_is_bit_stable_beside_conv0(env, soak, kernel):
+    """Vis-MVSNet's sweep: HOMOG geometry, group-wise correlation, 4 source views, per-batch planes: the LDS-staged kernel
+    (warp_gc_lv.hip, the default for these planes) and the quad kernel (per-pixel planes, `warp_gc_lds` = 0)."""
     L, ops, synthetic = env
     from oracle import vismvsnet as OV
     V, H, W, D = 5, 512, 640, 64
@@ -135,8 +137,13 @@ def test_groupcorr_homog_warp_is_bit_stable_beside_conv0(env, soak):
     feats = synthetic.make_features(1, V, 32, H // 2, W // 2, seed=4)
     fcl = [ops.to_channels_last(feats[i].cuda(), torch.float16) for i in range(V)]
     planes = (cams[0][:, 1, 3, 0].view(1, 1) + di[:, :1] * 2.0 * torch.arange(D, dtype=torch.float32).view(1, D)).contiguous().cuda()
-    bad, _, _ = soak.run("warp_cost groupcorr HOMOG", lambda: ops.warp_cost(fcl[0], fcl[1:], blocks, planes, geom=L.GEOM_HOMOG,
-                                                                           cost=L.COST_GROUPCORR, out_dtype=torch.float16))
+    assert L.get_tuning("warp_gc_lds") == 1
+    L.set_tuning("warp_gc_lds", 1 if kernel == "lds" else 0)
+    try:
+        bad, _, _ = soak.run(f"warp_cost groupcorr HOMOG ({kernel})", lambda: ops.warp_cost(fcl[0], fcl[1:], blocks, planes, geom=L.GEOM_HOMOG,
+                                                                                          cost=L.COST_GROUPCORR, out_dtype=torch.float16))
+    finally:
+        L.set_tuning("warp_gc_lds", 1)
     assert bad == 0
 
 

@@ -435,7 +435,8 @@ def test_staged_kernel_inf_inputs_stay_inf(env):
     assert torch.equal(staged[~bad], direct[~bad])
 
 
-@pytest.mark.parametrize("case", ["lds_variance", "lane_owner_variance", "quad_variance", "quad_per_pixel", "generic_16ch", "homog_groupcorr"])
+@pytest.mark.parametrize("case", ["lds_variance", "lane_owner_variance", "quad_variance", "quad_per_pixel", "generic_16ch", "homog_groupcorr", "homog_groupcorr_lds",
+                                  "homog_groupcorr_lds_per_pixel"])
 def test_row_slab_launch_equals_the_rows_of_the_whole_image_launch(env, case):
     """`pscv_warp_cost_rows` (ABI 7; the row-sharded Vis-MVSNet stages): a launch on rows [y0, y0 + hs) of the reference grid -- cropped
     reference map and per-pixel planes, the cameras of the WHOLE image, `ref_y0 = y0` -- stores bit for bit the rows of the whole-image
@@ -448,14 +449,15 @@ def test_row_slab_launch_equals_the_rows_of_the_whole_image_launch(env, case):
     feats = synthetic.make_features(B, V, C, h, w, seed=5)
     fcl = [ops.to_channels_last(feats[i].cuda(), torch.float16) for i in range(V)]
     kw = {}
-    if case == "homog_groupcorr":
+    if case.startswith("homog_groupcorr"):
         from oracle import vismvsnet as OV
         sc = synthetic.make_scene(B, V, 4 * h, 4 * w, seed=2)
         di = (sc["depth_max"] - sc["depth_min"]) / 128
         cams_v = [OV.fill_cam_array(sc["K"][:, i], sc["R"][:, i], sc["t"][:, i], sc["depth_min"][:, i], di[:, i]) for i in range(V)]
         cams = ops.homog_cams_device(cams_v[0].cuda(), [c.cuda() for c in cams_v[1:]], 0.25)
         dv = (cams_v[0][:, 1, 3, 0].view(B, 1) + di[:, :1] * 4.0 * torch.arange(D, dtype=torch.float32).view(1, D)).contiguous().cuda()
-        dv = (dv.view(B, D, 1, 1) + 0.02 * torch.rand(B, 1, h, w, device="cuda")).contiguous()              # per-pixel starts like stages 2-3
+        if case != "homog_groupcorr_lds":
+            dv = (dv.view(B, D, 1, 1) + 0.02 * torch.rand(B, 1, h, w, device="cuda")).contiguous()          # per-pixel starts like stages 2-3
         kw = dict(geom=L.GEOM_HOMOG, cost=L.COST_GROUPCORR)
     else:
         cam = synthetic.make_cameras(B, V, 4 * h, 4 * w)
@@ -466,6 +468,7 @@ def test_row_slab_launch_equals_the_rows_of_the_whole_image_launch(env, case):
             dv = (dv.view(B, D, 1, 1) * (1.0 + 0.01 * torch.rand(B, 1, h, w, device="cuda"))).contiguous()
         kw = dict(cost=L.COST_VARIANCE_CVP if case == "generic_16ch" else L.COST_VARIANCE)
     L.set_tuning("warp_tiled", 0 if case == "quad_variance" else 4 if case == "lane_owner_variance" else 1)
+    L.set_tuning("warp_gc_lds", 2 if case.startswith("homog_groupcorr_lds") else 0)      # (the LDS-staged group-correlation kernel, per-batch and per-pixel planes)
     try:
         full = ops.warp_cost(fcl[0], fcl[1:], cams, dv, out_dtype=torch.float16, **kw)
         for y0, hs_ in ((0, 20), (13, 25), (30, 22)):
@@ -477,3 +480,4 @@ def test_row_slab_launch_equals_the_rows_of_the_whole_image_launch(env, case):
             assert torch.equal(slab, want), f"{case}: slab at row {y0} differs from the whole-image launch on {int((slab != want).sum())} values"
     finally:
         L.set_tuning("warp_tiled", -1)
+        L.set_tuning("warp_gc_lds", 1)
