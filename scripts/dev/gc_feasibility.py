@@ -26,6 +26,9 @@ def time_us(run, steps=20, warm=5):
 
 
 dev = torch.device("cuda", 0)
+for a_ in sys.argv[1:]:
+    if a_.startswith("--ppd="):
+        L.set_tuning("warp_ppd", int(a_[6:]))
 V, D, h, w = 9, 256, 144, 200
 cm = synthetic.make_cameras(1, V, 8 * h, 8 * w)
 Ks = cm["K"].clone()
