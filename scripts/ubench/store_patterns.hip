@@ -4,6 +4,8 @@
 //   1  lane l, store j : byte 1024 j + 16 l          (fully contiguous)
 //   2  lane (r = l >> 4, c = l & 15), store j : voxel 16 j + c, piece r    (the four pieces of a voxel in lanes c, c+16, c+32, c+48)
 //   3  lane l, store j : voxel 16 j + (l >> 2), piece l & 3               (a quad of lanes writes one voxel = pattern 1's addresses)
+// Build: hipcc -O3 --offload-arch=gfx950 -shared -fPIC -o scripts/ubench/libsp.so scripts/ubench/store_patterns.hip; run: scripts/dev/store_patterns.py
+// (round 4, MI355X, 251 MB: pattern 0 72.6 us; patterns 1, 2, 3 36.5-36.7 us -- profiles/r04_warp_lane_owner.txt).
 // Pattern 0 also comes as "0s": the four stores spread over the kernel's run time instead of back to back.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
