@@ -334,6 +334,63 @@ def test_lds_staged_groupcorr_equals_quad_kernel(env, baseline_scale, shape, V, 
         assert float((outs[name] != want).float().mean()) < 0.02, f"{name}: {float((outs[name] != want).float().mean()):.4f} of the values differ"
 
 
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_lds_staged_kernels_on_random_rigs(env, seed):
+    """Seeded random draws of what the staged kernels decide on -- image size (tile multiples or not), view and plane counts, baseline
+    (0.5x .. 20x: everything staged .. boxes that do not fit, samples behind the camera), camera rig, storage format: the variance
+    volume of the quad-owner (default) and lane-owner kernels equals the direct-gather kernel's bit for bit; the group-correlation
+    volume of the staged kernel (per-batch and per-pixel planes) agrees with the quad kernel's to one 16-bit ulp."""
+    L, ops, O = env
+    from wild_deep_mvs_amd import synthetic
+    from oracle.mvsnet import mvsnet_cameras
+    import oracle.vismvsnet as OV
+    rng = np.random.default_rng(1000 + seed)
+    B, V = int(rng.integers(1, 3)), int(rng.integers(2, 6))
+    h, w = int(rng.integers(21, 90)), int(rng.integers(21, 110))
+    D = int(rng.integers(3, 70))
+    scale = float(np.exp(rng.uniform(np.log(0.5), np.log(20.0))))
+    rig = "dtu" if rng.random() < 0.4 else "probe"
+    dtype = torch.bfloat16 if rng.random() < 0.4 else torch.float16
+    per_pixel = bool(rng.random() < 0.5)
+    feats = synthetic.make_features(B, V, 32, h, w, seed=seed)
+    cam = synthetic.make_cameras(B, V, 4 * h, 4 * w, rig=rig)
+    cam["t"] = cam["t"] * scale
+    proj, dvals = mvsnet_cameras(cam["K"], cam["R"], cam["t"], cam["depth_min"], cam["depth_max"], D)
+    fcl = [ops.to_channels_last(feats[i].cuda(), dtype) for i in range(V)]
+    tag = f"seed {seed}: B={B} V={V} {h}x{w} D={D} baseline x{scale:.2f} {rig} {dtype} per_pixel={per_pixel}"
+    # variance (PROJ geometry, per-batch planes)
+    cams = ops.proj_cams_device(proj.cuda().contiguous(), 0)
+    dv = dvals[:, 0].contiguous().cuda()
+    outs = {}
+    for name, tiled in (("quad-owner", 1), ("lane-owner", 4), ("direct", 0)):
+        L.set_tuning("warp_tiled", tiled)
+        try:
+            outs[name] = ops.warp_cost(fcl[0], fcl[1:], cams, dv, cost=L.COST_VARIANCE, out_dtype=dtype)
+        finally:
+            L.set_tuning("warp_tiled", -1)
+    for name in ("quad-owner", "lane-owner"):
+        ne = int((outs[name] != outs["direct"]).sum())
+        assert ne == 0, f"{tag}: variance, {name} vs direct: {ne} of {outs['direct'].numel()} values differ"
+    # group correlation (HOMOG geometry)
+    di = (cam["depth_max"] - cam["depth_min"]) / D
+    arr = [OV.fill_cam_array(cam["K"][:, i], cam["R"][:, i], cam["t"][:, i], cam["depth_min"][:, i], di[:, i]) for i in range(V)]
+    hc = ops.homog_cams_device(arr[0].cuda(), [a.cuda() for a in arr[1:]], 1.0 / 4)
+    planes = (cam["depth_min"][:, :1] + di[:, :1] * torch.arange(D, dtype=torch.float32).view(1, D)).contiguous()
+    if per_pixel:
+        gen = torch.Generator().manual_seed(seed)
+        planes = (planes.view(B, D, 1, 1) * (1.0 + 0.03 * torch.rand(B, 1, h, w, generator=gen))).contiguous()
+    gouts = {}
+    for name, gc in (("staged", 2), ("quad", 0)):
+        L.set_tuning("warp_gc_lds", gc)
+        try:
+            gouts[name] = ops.warp_cost(fcl[0], fcl[1:], hc, planes.cuda(), geom=L.GEOM_HOMOG, cost=L.COST_GROUPCORR, out_dtype=dtype).float().cpu()
+        finally:
+            L.set_tuning("warp_gc_lds", 1)
+    ulp = 2 ** -7 if dtype == torch.bfloat16 else 2 ** -10
+    scale_v = max(float(gouts["quad"].abs().max()), 1e-6)
+    check_close(f"{tag}: groupcorr staged vs quad", gouts["staged"], gouts["quad"], max_abs=ulp * scale_v, rel_l2=ulp / 16 if scale_v > 1e-3 else None)
+
+
 def test_staged_kernel_fp16_stores_saturate(env):
     """fp16 cost volumes saturate at +-65504 instead of becoming inf (every kernel of the engine does; the LDS-staged warp
     kernel gets it from the MODE.FP16_OVFL bit instead of a per-element clamp): features of magnitude ~300 give variances up
