@@ -529,9 +529,10 @@ def run(args):
         _lib.set_tuning(k, int(v))
     net, sd, feats, feats_cl, proj_d, dv_d, proj, dv = build_inputs(device, rank, DTYPES[args.dtype], args.batch)
     NB = args.batch
-    # "batched" (default): the views of a batch share one launch per layer on ONE stream, replayed as a hipGraph; "streams" runs
-    # them on separate HIP streams (eager).  Every kernel is bit-stable under that overlap since round 4 (the LDS-staged warp
-    # kernel ships as its scalar-fp32 build; tests/test_gpu_overlap.py)
+    # "streams" (default): every view of the step on its own HIP stream, forked and joined INSIDE the captured hipGraph (parallel
+    # branches of one replayed graph); "batched": the views share one launch per layer on one stream.  Every kernel is bit-stable
+    # under that overlap (the LDS-staged warp kernel ships as its scalar-fp32 build; tests/test_gpu_overlap.py),
+    # and the timed region ends with a bit-equality check of the replayed graph against eager launches on fresh inputs
     net.batch_streams = args.batch_mode == "streams"
     streams_mode = net.batch_streams and 2 <= NB <= net.MAX_BATCH_STREAMS
 
@@ -610,13 +611,31 @@ def run(args):
                 except Exception:   # pragma: no cover
                     one_view = None
             gc.enable()
+            # the replayed (forked) graph on FRESH inputs against eager one-item launches on one stream, bit for bit: a fast step
+            # that replays wrongly must not yield a headline (round 3 saw that with the packed warp build)
+            graph_ok = None
+            if graph is not None:
+                saved = [f.clone() for f in feats_cl_]
+                for f in feats_cl_:
+                    f.copy_(torch.roll(f, shifts=(3, 5), dims=(1, 2)))
+                graph.replay()
+                torch.cuda.synchronize()
+                d_graph = depth.clone()
+                d_eager = torch.cat([item(b)[0] for b in range(NB)], 0)
+                torch.cuda.synchronize()
+                graph_ok = bool(torch.equal(d_graph, d_eager))
+                for f, sv in zip(feats_cl_, saved):
+                    f.copy_(sv)
+                graph.replay()
+                torch.cuda.synchronize()
         assert torch.isfinite(depth).all()
+        assert graph_ok is not False, "the replayed hipGraph of the step differs from eager launches on fresh inputs"
         t_max = torch.tensor([elapsed], device=device, dtype=torch.float64)
         if dist is not None:
             dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-        return float(t_max.item()), tm, depth.clone(), graph is not None, elapsed_eager, one_view
+        return float(t_max.item()), tm, depth.clone(), graph is not None, elapsed_eager, one_view, graph_ok
 
-    elapsed, tm, depth, graphed, elapsed_eager, one_view = timed_region(args.dtype, feats_cl, args.steps)
+    elapsed, tm, depth, graphed, elapsed_eager, one_view, graph_ok = timed_region(args.dtype, feats_cl, args.steps)
     kern = {k: v for k, v in tm.summary().items() if k != "proj_cams"}
     if args.dump_events and rank == 0:
         with open(args.dump_events, "w") as f:
@@ -625,7 +644,7 @@ def run(args):
     # the other 16-bit storage format on the same workload (BASELINE.json names bf16; same bytes, same MFMA rate)
     alt_name = "bf16" if args.dtype == "f16" else "f16"
     feats_alt = [ops.to_channels_last(feats[i].to(device), DTYPES[alt_name]) for i in range(V)]
-    alt_elapsed, alt_tm, alt_depth, _, _, alt_one_view = timed_region(alt_name, feats_alt, args.steps)
+    alt_elapsed, alt_tm, alt_depth, _, _, alt_one_view, _ = timed_region(alt_name, feats_alt, args.steps)
     net.storage_dtype = DTYPES[args.dtype]
     graph = graphed
 
@@ -686,6 +705,8 @@ def run(args):
                       f"stream (each launch timed alone; {elapsed_eager / args.steps * 1e3:.3f} ms/step that way)",
             "one_view_at_a_time": None if one_view is None else {"ms_per_view": one_view * 1e3, "value": world * VOX / one_view, "unit": "voxels/s",
                                                                  "what": "the step of rounds 1-2: one reference view per replay on one stream"},
+            "graph_replay_equals_eager_on_fresh_inputs": graph_ok,
+            "value_bf16": None,      # filled below: the same step in bf16 storage, the format BASELINE configuration 2 names
             "roofline": roof,
             "roofline_mfma": roof_mfma,
             "kernels_us": {k: round(ms / n * 1e3, 2) for k, (n, ms) in sorted(kern.items(), key=lambda kv: -kv[1][1])},
@@ -695,6 +716,7 @@ def run(args):
                        "one_view_at_a_time_ms": None if alt_one_view is None else alt_one_view * 1e3,
                        "ms_per_step": alt_elapsed / args.steps * 1e3,
                        "kernels_us": {k: round(ms / n * 1e3, 2) for k, (n, ms) in sorted(alt_kern.items(), key=lambda kv: -kv[1][1])}}
+        line["value_bf16"] = line["alt"]["value"] if alt_name == "bf16" else line["value"]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"], rel = cpu_baseline(sd, feats, proj, dv, {args.dtype: depth, alt_name: alt_depth})
             line["depth_rel_l1_vs_oracle"] = rel[args.dtype]

@@ -83,10 +83,8 @@ int pscv_abi_version(void);
  *   "warp_tiled" 1 (default; -1 restores it; 2 = the same): pscv_warp_cost stages the source patches of a reference tile in LDS
  *               as fp32 where it applies (C = 32, 16-bit features, per-batch planes, PROJ geometry, 1-4 source views, variance /
  *               softmin) -- same bits as the direct-gather kernels; 0: always the direct-gather kernels.  "warp_lpv" != 0
- *               also selects the direct kernel.  3: DIAGNOSTIC ONLY -- the same kernel with the SLP vectorizer's packed fp32
- *               instructions (same stored bits, ~3 % faster alone), which returns wrong voxels while MFMA kernels run on another
- *               stream: `v_pk_*_f32` with the op_sel bit of src1 set is unreliable there (DESIGN.md section 7,
- *               scripts/ubench/lds_pk_overlap.hip, scripts/lint_isa.py); nothing in the engine selects it.
+ *               also selects the direct kernel.  (The kernel is built without packed fp32 instructions: `v_pk_*_f32` with
+ *               the op_sel bit of src1 set is unreliable beside MFMA kernels of another stream)
  *               4: the lane-owns-voxel kernel (csrc/warp_cost_lv.hip; variance costs; same stored bits): 14 % fewer vector-ALU
  *               instructions and 2 % less time than the default on narrow-baseline rigs, ~2x slower where boxes do not fit the
  *               LDS arena (wide baselines) -- an alternative, not the default.

@@ -252,6 +252,14 @@ def _vis_depth_shard_worker(rank, world, port, q):
                 ref = flat(st(*a, **k))
                 st.depth_group = dist.group.WORLD
                 got = flat(st(*a, **k))
+                # the halo really covers the stage's receptive field: eight more halo rows change nothing on the owned rows
+                halo = type(st).ROW_HALO
+                type(st).ROW_HALO = halo + 8
+                st.row_group = dist.group.WORLD
+                wider = flat(st(*a, **k))
+                st.row_group = None
+                type(st).ROW_HALO = halo
+                halo_err.append(max(((w_ - g).abs().max() / max(g.abs().max().item(), 1e-30)).item() for w_, g in zip(wider, got)))
                 per_stage.append([((got[0] - ref[0]).abs().mean() / ref[0].abs().mean()).item()] +
                                  [(got[1] - ref[1]).abs().mean().item(), ((got[1] - ref[1]).abs() > 1e-3).float().mean().item()] +
                                  [(g - r).abs().max().item() / max(r.abs().max().item(), 1e-30) for g, r in zip(got[2:], ref[2:])])
@@ -320,13 +328,21 @@ def _vis_row_shard_worker(rank, world, port, q):
         for h in hooks:
             h.remove()
         flat = lambda o: [o[0], o[1]] + [p[0] for p in o[2]] + [p[1][0] for p in o[2]]
-        per_stage = []
+        per_stage, halo_err = [], []
         with torch.no_grad():
             for st, (a, k) in zip(stages, calls):                            # (1) every stage on exactly the inputs of the unsharded run
                 ref = flat(st(*a, **k))
                 st.row_group = dist.group.WORLD
                 got = flat(st(*a, **k))
                 st.row_group = None
+                # the halo really covers the stage's receptive field: eight more halo rows change nothing on the owned rows
+                halo = type(st).ROW_HALO
+                type(st).ROW_HALO = halo + 8
+                st.row_group = dist.group.WORLD
+                wider = flat(st(*a, **k))
+                st.row_group = None
+                type(st).ROW_HALO = halo
+                halo_err.append(max(((w_ - g).abs().max() / max(g.abs().max().item(), 1e-30)).item() for w_, g in zip(wider, got)))
                 per_stage.append([((got[0] - ref[0]).abs().mean() / ref[0].abs().mean()).item()] +
                                  [(got[1] - ref[1]).abs().mean().item(), ((got[1] - ref[1]).abs() > 1e-3).float().mean().item()] +
                                  [(g - r).abs().max().item() / max(r.abs().max().item(), 1e-30) for g, r in zip(got[2:], ref[2:])])
@@ -336,7 +352,7 @@ def _vis_row_shard_worker(rank, world, port, q):
             out = net(*args, **kw)
         rel = ((out["depth"] - want["depth"]).abs().mean() / want["depth"].abs().mean()).item()
         pair_rel = max(((g[0] - w[0]).abs().max() / w[0].abs().max()).item() for g, w in zip(out["depth_pair_list"][0], want["depth_pair_list"][0]))
-        q.put((rank, per_stage, rel, pair_rel))
+        q.put((rank, per_stage, rel, pair_rel, halo_err))
     finally:
         dist.destroy_process_group()
 
@@ -345,7 +361,7 @@ def _vis_row_shard_worker(rank, world, port, q):
 @_retry_infra
 def test_vis_row_slab_shard_two_ranks_one_gpu():
     """Round 4 (the round-3 review: the depth-plane shard leaves the cascade's stages 2-3 -- 32 / 16 per-pixel planes -- replicated):
-    `SingleStage.forward_row_shard` runs a whole stage on the rank's image rows + a recomputed 16-row halo (reference map, per-pixel
+    `SingleStage.forward_row_shard` runs a whole stage on the rank's image rows + a recomputed ROW_HALO = 20-row halo (reference map, per-pixel
     depth starts and principal point cropped to the slab; one all-gather of the owned rows of the small output maps).  Stage by stage
     on the inputs of the unsharded run: the slab's cost volume is bit-identical to the unsharded rows (`pscv_warp_cost_rows`,
     tests/test_gpu_warp_cost.py); pair depths / uncertainties and the fused depth are held to the bars of the depth-plane shard
@@ -364,7 +380,12 @@ def test_vis_row_slab_shard_two_ranks_one_gpu():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0, f"a rank process exited with code {p.exitcode}"
-    for rank, per_stage, rel, pair_rel in res:
+    for rank, per_stage, rel, pair_rel, halo_err in res:
+        # ROW_HALO vs ROW_HALO + 8: every output map (fused depth, window probability, pair depths, pair uncertainties), max norm.
+        # With the 16-row halo of round 4 (UncertNet's 3 rows missing) the rows next to the slab boundary moved; now only a different
+        # conv kernel variant for the taller slab may move a value by a rounding.
+        print(f"[parity] row-slab shard rank {rank}: halo {20} vs {28} rows, max rel per stage " + " ".join(f"{e:.1e}" for e in halo_err), flush=True)
+        assert max(halo_err) <= 2e-4, halo_err
         for si, errs in enumerate(per_stage):
             print(f"[parity] row-slab shard rank {rank} stage {si + 1}: depth rel-L1 {errs[0]:.2e}, window prob mean abs {errs[1]:.2e} "
                   f"(moved > 1e-3: {errs[2]:.2e}), pair depth / uncertainty max rel " + " ".join(f"{e:.1e}" for e in errs[3:]), flush=True)

@@ -75,6 +75,7 @@ def test_config1_mvsnet_s_matches_reference_golden(gpu, dtype):
 # ---------------------------------------------------------------------------------------------------------------------
 # configuration (2): MVSNet (variance), 1 ref + 4 src, 512x640, D = 192 -- THE headline size, on windows against the oracle
 # ---------------------------------------------------------------------------------------------------------------------
+MVS_BF16_WINDOW_DEPTH = 1.25e-3
 MVS_MARGIN = 30      # receptive radius of MVSNet's CostRegNet in the image plane (and along D: the depth axis is never cropped)
 
 
@@ -137,9 +138,48 @@ def test_mvsnet_fullsize_matches_oracle_on_windows(gpu, dtype, rig):
         sel2 = sel[1:]
         e_depth = out["depth"].cpu()[:, y0:y0 + win, x0:x0 + win]
         sd_ = check_close(f"cfg2 {rig} {dtype} depth window ({y0},{x0})", e_depth[sel2], o_depth[sel2])
-        assert sd_["rel_l1"] <= (WINDOW_BARS[dtype]["depth"] if bf else 1e-3), sd_
+        # windows are 80 x 80 samples of the map: fp16 at the north-star bar; bf16 sits AT the bar on whole maps (asserted <= 1e-3 in
+        # test_mvsnet_config2_end_to_end_depth_meets_1e3_in_fp16_and_bf16), single windows measured 4.4e-4 ... 1.05e-3 (round 4)
+        assert sd_["rel_l1"] <= (MVS_BF16_WINDOW_DEPTH if bf else 1e-3), sd_
         e_conf = out["photometric_confidence"].cpu()[:, y0:y0 + win, x0:x0 + win]
         check_close(f"cfg2 {rig} {dtype} confidence window ({y0},{x0})", e_conf[sel2], o_conf[sel2], rel_l1=8e-2 if bf else 2e-2)
+
+
+@pytest.mark.parametrize("rig", ["probe", "dtu"])
+def test_mvsnet_config2_end_to_end_depth_meets_1e3_in_fp16_and_bf16(gpu, rig):
+    """BASELINE.json's parity clause at BASELINE configuration 2 itself, whole maps, COMPOUNDED over every stage: 5-view 128 x 160 x 32
+    feature maps (the resident inputs of bench.py's timed region), D = 192 -> depth, the engine in fp16 storage AND in bf16 storage
+    (the format configuration 2 names) against the fp32 oracle's hot path on the same inputs: relative L1 <= 1e-3 for both.
+    Measured in round 4 by bench.py only (fp16 8.7e-5, bf16 7.4e-4); a bf16 regression to 5e-3 would have passed the suite."""
+    L, ops, synthetic = gpu
+    from wild_deep_mvs_amd.models.MVSNet.model import MVSNet, build_proj_matrices
+    from oracle import mvsnet as O
+    V, H, W, D, C = 5, 512, 640, 192, 32
+    h, w = H // 4, W // 4
+    net = MVSNet("variance")
+    sd = synthetic.sharpened_state_dict("mvsnet", synthetic.template_of(net), seed=0)
+    net.load_state_dict(sd, strict=True)
+    net.num_depth = D
+    net = net.cuda().eval()
+    cams = synthetic.make_cameras(1, V, H, W, rig=rig)
+    Ks = cams["K"].clone()
+    Ks[:, :, :2] /= 4
+    proj = build_proj_matrices(Ks, cams["R"], cams["t"])
+    steps = torch.arange(D, dtype=torch.float32).view(1, -1)
+    dv = cams["depth_min"][:, :1] + (cams["depth_max"][:, :1] - cams["depth_min"][:, :1]) / (D - 1) * steps
+    feats = synthetic.make_features(1, V, C, h, w, seed=5)
+    with torch.no_grad():
+        o_depth, _ = O.hot_path([feats[i] for i in range(V)], proj, dv.unsqueeze(1).expand(-1, V, -1), sd, streaming=True)
+        rel = {}
+        for dtype in (torch.float16, torch.bfloat16):
+            net.storage_dtype = dtype
+            fcl = [ops.to_channels_last(feats[i].cuda(), dtype) for i in range(V)]
+            depth, _ = net.hot_path(fcl, proj.cuda(), dv.cuda().contiguous())
+            assert torch.isfinite(depth).all()
+            rel[dtype] = _rel_l1(depth.float().cpu(), o_depth)
+    print(f"[parity] cfg2 {rig} end-to-end depth rel-L1 vs fp32 oracle: fp16 {rel[torch.float16]:.3e}, bf16 {rel[torch.bfloat16]:.3e}", flush=True)
+    assert rel[torch.float16] <= 1e-3, rel
+    assert rel[torch.bfloat16] <= 1e-3, rel
 
 
 # ---------------------------------------------------------------------------------------------------------------------

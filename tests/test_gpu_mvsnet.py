@@ -219,7 +219,7 @@ def test_stream_mode_equals_the_sequential_forward_at_the_headline_size(env):
     """Three reference views of 5 x 512x640, D = 192 on three HIP streams: here one view's warp really overlaps another view's
     conv kernels for ~100 us at a time, the condition under which the LDS-staged warp kernel was found NOT reproducible at the
     end of round 3 (39 of 40 such steps differed from the sequential forward by up to 8e-2 of the depth range; DESIGN.md
-    section 6).  Round 4: the kernel ships as its scalar-fp32 build (the packed build is a diagnostic, "warp_tiled" = 3), so with
+    section 6).  Since round 4 the kernel ships as its scalar-fp32 build, so with
     DEFAULT tuning every step equals the one-stream forward bit for bit."""
     L, ops, synthetic, MVSNet, O = env
     net = MVSNet("variance")

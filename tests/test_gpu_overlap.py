@@ -2,8 +2,8 @@
 (conv0 at the headline size: LDS ring + MFMA, the partner that exposed the defect of DESIGN.md section 6) runs on a second
 stream, must store the SAME BITS as its solo launch -- `include/pscv.h` promises "re-entrant per stream".  >= 200 launches per
 family at sizes of ~50 us and more, through the C ABI with DEFAULT tuning.  (Round 3 found the packed-fp32 build of the LDS-staged
-warp kernel wrong under exactly this overlap; round 4 ships its scalar build.  The last test runs the packed build -- now a
-diagnostic, "warp_tiled" = 3 -- through the same harness and REPORTS what it sees, so a log shows the harness is sensitive.)"""
+warp kernel wrong under exactly this overlap; the kernel ships as its scalar build.  The last test runs the stand-alone reproducer
+of the instruction-level cause and REPORTS what this box shows.)"""
 import numpy as np
 import pytest
 import torch
@@ -260,20 +260,6 @@ def test_backward_kernels_are_stable_beside_conv0(env, soak):
         dref, dsrcs, _ = ops.warp_cost_bwd(fcl[0], fcl[1:], cams, dv, go, cost=L.COST_VARIANCE)
         return (dref,) + tuple(dsrcs)
     assert soak.run("warp_cost_bwd variance", wb, launches=96, rel_tol=1e-5)[0] == 0
-
-
-def test_harness_reports_the_packed_build(env, soak):
-    """Diagnostic, never fails: the packed-fp32 build of the LDS-staged warp kernel ("warp_tiled" = 3) through the same harness.
-    Round 3 measured 150-390 of 400 such launches wrong; whatever this box shows is printed for the log."""
-    L, ops, synthetic = env
-    fcl, cams, dv = _warp_inputs(ops, synthetic, 5, 32, 128, 160, 192, torch.float16)
-    L.set_tuning("warp_tiled", 3)
-    try:
-        bad, worst, _ = soak.run("warp_cost lds variance, PACKED build (diagnostic)", lambda: ops.warp_cost(fcl[0], fcl[1:], cams, dv, cost=L.COST_VARIANCE,
-                                                                                                         out_dtype=torch.float16))
-    finally:
-        L.set_tuning("warp_tiled", -1)
-    print(f"[overlap] packed build: {bad} of {LAUNCHES} overlapped launches differ (worst rel {worst:.2e})")
 
 
 def test_report_the_platform_defect_with_the_minimal_reproducer(env, soak):

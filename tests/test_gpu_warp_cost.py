@@ -186,8 +186,6 @@ def test_tiled_kernel_equals_direct_kernel(env, baseline_scale, shape, V, D, cos
             outs.append(ops.warp_cost(fcl[0], fcl[1:], cams, dv, cost=code, temp=0.7, out_dtype=torch.float16).float().cpu())
         finally:
             L.set_tuning("warp_tiled", -1)
-    # (the packed-fp32 build of the LDS-staged kernel, "warp_tiled" = 3, is a diagnostic of the defect of DESIGN.md section 6 and not
-    #  part of any correctness test: tests/test_gpu_overlap.py reports what it does)
     s = check_close(f"tiled vs direct {cost_name} baseline x{baseline_scale} {shape}", outs[0], outs[1],
                     max_abs=2 ** -10 * float(outs[1].abs().max()), rel_l2=2e-5)
     assert float(outs[1].abs().max()) > 0

@@ -15,24 +15,19 @@ def test_library_has_no_packed_fp32_with_a_src1_high_half_selector():
     from wild_deep_mvs_amd import _lib
     if not os.path.exists(_lib.LIB_PATH):
         pytest.skip("libpscv.so not built")
-    if not os.path.exists(os.path.join(lint_isa.LLVM, "llvm-objdump")):
+    if lint_isa.objdump() is None:
         pytest.skip("llvm-objdump not available")
     bad, seen = lint_isa.findings(_lib.LIB_PATH)
     assert seen > 10000, f"only {seen} packed instructions found: did the disassembly work?"
     assert not bad, "\n".join(f"{sym}: {ins}" for sym, ins in bad[:20])
 
 
-def test_the_lint_sees_the_diagnostic_kernel():
-    """The packed diagnostic build of the warp kernel DOES contain the form (that is why it fails beside conv0): the lint must find it
-    when that kernel is not exempted -- i.e. the pattern matching works on real disassembly."""
+def test_the_lint_sees_the_form_in_the_reproducer_library():
+    """Positive control: scripts/ubench/liblpo.so (the self-checking reproducer of the defect, built by __graft_entry__.build())
+    contains the form by construction -- the lint must find it there, i.e. the pattern matching works on real disassembly."""
     import lint_isa
-    from wild_deep_mvs_amd import _lib
-    if not os.path.exists(_lib.LIB_PATH) or not os.path.exists(os.path.join(lint_isa.LLVM, "llvm-objdump")):
-        pytest.skip("needs the built library and llvm-objdump")
-    saved = lint_isa.ALLOWED_KERNELS
-    lint_isa.ALLOWED_KERNELS = ()
-    try:
-        bad, _ = lint_isa.findings(_lib.LIB_PATH)
-    finally:
-        lint_isa.ALLOWED_KERNELS = saved
-    assert bad and all("warp_cost_lds_pk_kernel" in sym for sym, _ in bad), sorted({s for s, _ in bad})[:5]
+    lpo = os.path.join(REPO, "scripts", "ubench", "liblpo.so")
+    if not os.path.exists(lpo) or lint_isa.objdump() is None:
+        pytest.skip("needs scripts/ubench/liblpo.so (python __graft_entry__.py) and llvm-objdump")
+    bad, _ = lint_isa.findings(lpo)
+    assert bad and any("opsel_victim" in sym for sym, _ in bad), sorted({s for s, _ in bad})[:5]

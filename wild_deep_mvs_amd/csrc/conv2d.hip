@@ -526,11 +526,9 @@ static int c2w_launch(Conv2dArgs& a, hipStream_t st) {
     const long tiles = (long)a.B * a.nth * a.ntw;
     if (tiles <= 0 || tiles > 0x7fffffffL) { set_error("pscv_conv2d: bad grid %ld", tiles); return -1; }
     auto kern = conv2d_wlds_kernel<H, NT, CIN>;
-    static bool done = false;   // per instantiation
-    if (!done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    {
+        hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(kern), LDS);
         if (e != hipSuccess) { set_error("pscv_conv2d: hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e)); return -2; }
-        done = true;
     }
     static int n_cu = 0;
     if (!n_cu) {
@@ -558,11 +556,9 @@ static int c2_launch(Conv2dArgs& a, int n_split, hipStream_t st) {
     if (nblk <= 0 || nblk > 0x7fffffffL) { set_error("pscv_conv2d: bad grid %ld", nblk); return -1; }
     auto kern = conv2d_kernel<H, CIN, NT, KS, STRIDE>;
     if (LDS > 60000) {
-        static bool done = false;   // per instantiation
-        if (!done) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        {
+            hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(kern), LDS);
             if (e != hipSuccess) { set_error("pscv_conv2d: hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e)); return -2; }
-            done = true;
         }
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_split), dim3(256), LDS, st, a);

@@ -548,11 +548,9 @@ static int launch_conv(ConvArgs& a, int n_split, hipStream_t st) {
     const long nblk = (long)a.B * a.ntd * a.nth * a.ntw;
     if (nblk <= 0 || nblk > 0x7fffffffL) { set_error("pscv_conv3d: bad grid %ld", nblk); return -1; }
     auto kern = conv3d_kernel<H, CIN, NT, KIND, TD, TH>;
-    static bool attr_done = false;   // per instantiation
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    {
+        hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(kern), LDS);
         if (e != hipSuccess) { set_error("pscv_conv3d: hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e)); return -2; }
-        attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_split), dim3(256), LDS, st, a);
     return 0;

@@ -288,13 +288,11 @@ extern "C" int pscv_conv3d_block8(const void* in, int dtype, int in_cstride, int
     a.mg_th = fast_div_magic(a.nth); a.mg_tw = fast_div_magic(a.ntw); a.mg_dc = fast_div_magic(a.ndc);
     if (nblk <= 0 || nblk > 0x7fffffffL) { set_error("pscv_conv3d_block8: bad grid %ld", nblk); return -1; }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    static bool attr_done[2] = {false, false};
     const int di = dtype == PSCV_BF16 ? 0 : 1;
     const void* kern = di == 0 ? reinterpret_cast<const void*>(conv3d_block8_kernel<bf16_t>) : reinterpret_cast<const void*>(conv3d_block8_kernel<f16_t>);
-    if (!attr_done[di]) {
-        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, B8_LDS);
+    {
+        hipError_t e = ensure_dyn_lds(kern, B8_LDS);
         if (e != hipSuccess) { set_error("pscv_conv3d_block8: hipFuncSetAttribute: %s", hipGetErrorString(e)); return -2; }
-        attr_done[di] = true;
     }
     if (di == 0) hipLaunchKernelGGL(conv3d_block8_kernel<bf16_t>, dim3((unsigned)nblk), dim3(256), B8_LDS, st, a);
     else hipLaunchKernelGGL(conv3d_block8_kernel<f16_t>, dim3((unsigned)nblk), dim3(256), B8_LDS, st, a);

@@ -551,7 +551,7 @@ static int c1_launch(const C1Args& a, long nblk, hipStream_t st) {
     auto kern = conv3d_c1_kernel<H, CIN>;
     const size_t lds = (size_t)(a.nb * C1_P + 2) * C1_PS * CIN * 2;
     if (lds > 60000) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds);
         if (e != hipSuccess) { set_error("pscv_conv3d(c1): hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e)); return -2; }
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, a);

@@ -743,13 +743,10 @@ __global__ __launch_bounds__(256, (CIN == 8 && PD <= 2) ? 4 : (CIN == 8 || (PD =
 template <typename H, int CIN, int PD, int COUT = 8>
 static int sweepc_launch_t(pscv::SweepArgs& a, long nblk, hipStream_t st) {
     using namespace pscv;
-    static bool attr_done = false;
     constexpr int lds = ScGeom<CIN>::LDS;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_sweepc_kernel<H, CIN, PD, COUT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    {
+        hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(conv3d_sweepc_kernel<H, CIN, PD, COUT>), lds);
         if (e != hipSuccess) { set_error("pscv_conv3d(sweep): hipFuncSetAttribute: %s", hipGetErrorString(e)); return -2; }
-        attr_done = true;
     }
     hipLaunchKernelGGL((conv3d_sweepc_kernel<H, CIN, PD, COUT>), dim3((unsigned)nblk), dim3(256), lds, st, a);
     return 0;
@@ -841,14 +838,12 @@ int pscv_conv3d_sweep8_launch(const void* in, int dtype, int in_cstride, int in_
         if (nblk <= 0 || nblk > 0x7fffffffL) { set_error("pscv_conv3d(sweep): bad grid %ld", nblk); return -1; }
         const int pd = g_sweep_kdm_pd > 0 ? g_sweep_kdm_pd : 1;
         const int ti = (dtype == PSCV_BF16 ? 0 : 1) + (skip ? 2 : 0) + (pd >= 2 ? 4 : 0);
-        static bool kdm_attr[8] = {false, false, false, false, false, false, false, false};
 #define PSCV_KDM(I, HT, SK, PDV)                                                                                                  \
         if (ti == I) {                                                                                                            \
-            if (!kdm_attr[I]) {                                                                                                   \
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_sweep8_kdm_kernel<HT, SK, PDV>),          \
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, KM_LDS);                           \
+            {                                                                                                   \
+                hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(conv3d_sweep8_kdm_kernel<HT, SK, PDV>), \
+                                                   KM_LDS);                           \
                 if (e != hipSuccess) { set_error("pscv_conv3d(sweep): hipFuncSetAttribute: %s", hipGetErrorString(e)); return -2; } \
-                kdm_attr[I] = true;                                                                                               \
             }                                                                                                                     \
             hipLaunchKernelGGL((conv3d_sweep8_kdm_kernel<HT, SK, PDV>), dim3((unsigned)nblk), dim3(256), KM_LDS, st, a);          \
             return 0;                                                                                                             \
@@ -878,17 +873,15 @@ int pscv_conv3d_sweep8_launch(const void* in, int dtype, int in_cstride, int in_
     const long nblk = tiles * a.ndc;
     a.mg_th = fast_div_magic(a.nth); a.mg_tw = fast_div_magic(a.ntw); a.mg_dc = fast_div_magic(a.ndc);
     if (nblk <= 0 || nblk > 0x7fffffffL) { set_error("pscv_conv3d(sweep): bad grid %ld", nblk); return -1; }
-    static bool attr_done[4] = {false, false, false, false};
     const int ti = (dtype == PSCV_BF16 ? 0 : 1) + (tall ? 2 : 0);
     const void* kern = ti == 0 ? reinterpret_cast<const void*>(conv3d_sweep8_kernel<bf16_t, 8>)
                      : ti == 1 ? reinterpret_cast<const void*>(conv3d_sweep8_kernel<f16_t, 8>)
                      : ti == 2 ? reinterpret_cast<const void*>(conv3d_sweep8_kernel<bf16_t, 16>)
                                : reinterpret_cast<const void*>(conv3d_sweep8_kernel<f16_t, 16>);
     const int lds = tall ? SwGeom<16>::LDS : SwGeom<8>::LDS;
-    if (!attr_done[ti]) {
-        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    {
+        hipError_t e = ensure_dyn_lds(kern, lds);
         if (e != hipSuccess) { set_error("pscv_conv3d(sweep): hipFuncSetAttribute: %s", hipGetErrorString(e)); return -2; }
-        attr_done[ti] = true;
     }
     const dim3 grid((unsigned)nblk);
     if (ti == 0) hipLaunchKernelGGL((conv3d_sweep8_kernel<bf16_t, 8>), grid, dim3(256), lds, st, a);

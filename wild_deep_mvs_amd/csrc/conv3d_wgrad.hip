@@ -382,11 +382,9 @@ static int wgrad_launch(const WgradArgs& a, const WgPlan& p, hipStream_t st) {
     using G = WgGeom<S, TZ, TY, NB, NA>;
     static_assert(G::LDS <= 160 * 1024, "wgrad tile does not fit the LDS");
     auto kern = wgrad_kernel<H, S, TZ, TY, NB, NA>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+    {
+        hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(kern), G::LDS);
         if (e != hipSuccess) { set_error("pscv_conv3d_wgrad: hipFuncSetAttribute(%d B LDS): %s", G::LDS, hipGetErrorString(e)); return -2; }
-        attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3(p.nblk, p.ny), dim3(256), G::LDS, st, a);
     return 0;

@@ -3,9 +3,27 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "pscv_common.h"
 
 namespace pscv {
+
+hipError_t ensure_dyn_lds(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::unordered_map<unsigned long long, int> done;   // (kernel, device) -> largest size granted
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long key = (unsigned long long)reinterpret_cast<uintptr_t>(kernel) * 64ull + (unsigned)dev;   // (< 64 devices per process)
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = done.find(key);
+    if (it != done.end() && it->second >= bytes) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done[key] = bytes;
+    return e;
+}
 
 static thread_local char g_err[512] = "";
 

@@ -683,11 +683,9 @@ static int bwd_tile_launch(WarpBwdArgs& A, int geom, int cost, hipStream_t st) {
 #define PSCV_BWDT(GEOMV, COSTV)                                                                                           \
     if (geom == GEOMV && cost == COSTV) {                                                                                 \
         auto kern = warp_bwd_tile_kernel<TIn, TG, C, GEOMV, COSTV>;                                                       \
-        static bool attr_done = false;                                                                                    \
-        if (!attr_done) {                                                                                                 \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
+        {                                                                                                 \
+            hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(kern), LDS); \
             if (e != hipSuccess) { set_error("pscv_warp_cost_bwd: hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e)); return -2; } \
-            attr_done = true;                                                                                             \
         }                                                                                                                 \
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), LDS, st, A);                                            \
         return 0;                                                                                                         \

@@ -244,7 +244,7 @@ static Knob g_warp_lpv_override = {0, KNOB_WARP_LPV};  // 0 = default heuristic;
 static Knob g_warp_ppd_override = {0, KNOB_WARP_PPD};
 static Knob g_warp_gc_lds = {1, KNOB_WARP_GC_LDS};   // 1 (default): group-correlation volumes over per-batch planes on the LDS-staged kernel (warp_gc_lv.hip); 2: per-pixel planes too; 0: quad kernel
 static Knob g_warp_tiled = {1, KNOB_WARP_TILED};     // 1 (default; 2 = the same): the LDS-staged kernel (warp_cost_tiled.hip) where it applies: fp32
-                                 // patches, scalar fp32 blend, same bits as the direct kernels; 0: direct kernels; 3: its packed-fp32 build (diagnostic)
+                                 // patches, scalar fp32 blend, same bits as the direct kernels; 0: direct kernels; 4: lane-owns-voxel kernel
 extern Knob g_conv_small_tiles;   // conv3d.hip
 extern Knob g_sweep_th16;         // conv3d_sweep.hip
 extern Knob g_sweep_dc;
@@ -262,9 +262,6 @@ extern Knob g_s2s_slots;
 static Knob g_warp_q2 = {1, KNOB_WARP_Q2};        // 1: 32-channel 16-bit sweeps use the quad-mapped kernel (warp_cost_q2.hip)
 int warp_cost_q2_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, int out_dtype, int ppd_override, hipStream_t st);
 int warp_cost_tiled_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, int out_dtype, int ppd_override, hipStream_t st);
-// the same kernel compiled WITH packed fp32 instructions ("warp_tiled" = 3; warp_cost_tiled.hip, Makefile): diagnostic build of the
-// co-scheduling defect, not safe beside other kernels
-int warp_cost_tiled_pk_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, int out_dtype, int ppd_override, hipStream_t st);
 // the lane-owns-voxel kernel ("warp_tiled" = 4; warp_cost_lv.hip): variance costs
 int warp_cost_lv_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, int out_dtype, int ppd_override, hipStream_t st);
 // group-wise correlation, LDS-staged (warp_gc_lv.hip)
@@ -276,7 +273,7 @@ int warp_gc_lv_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, int out
 template <typename K>
 static int launch_one(K kern, const WarpArgs& a, int nblk, size_t ray_bytes, hipStream_t st) {
     if (ray_bytes > 60000) {   // rare (> 14 HOMOG views): not worth caching per kernel
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ray_bytes);
+        hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(kern), (int)ray_bytes);
         if (e != hipSuccess) { set_error("pscv_warp_cost: hipFuncSetAttribute(%zu B LDS): %s", ray_bytes, hipGetErrorString(e)); return -2; }
     }
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), ray_bytes, st, a);
@@ -458,8 +455,7 @@ extern "C" int pscv_warp_cost_rows(const void* ref, const void* const* srcs, int
         if (g_warp_tiled == 4) rc = warp_cost_lv_try(a, C, geom, cost, in_dtype, out_dtype, g_warp_ppd_override, st);
         if (rc == 1 && g_warp_gc_lds && (g_warp_gc_lds >= 2 || !depth_per_pixel)) rc = warp_gc_lv_try(a, C, geom, cost, in_dtype, out_dtype, g_warp_ppd_override, st);
         if (rc == 1)
-            rc = g_warp_tiled == 3 ? warp_cost_tiled_pk_try(a, C, geom, cost, in_dtype, out_dtype, g_warp_ppd_override, st)
-                                   : warp_cost_tiled_try(a, C, geom, cost, in_dtype, out_dtype, g_warp_ppd_override, st);
+            rc = warp_cost_tiled_try(a, C, geom, cost, in_dtype, out_dtype, g_warp_ppd_override, st);
         if (rc < 0) return rc;
         if (rc == 0) {
             PSCV_CHECK_LAUNCH("pscv_warp_cost(tiled)");

@@ -470,11 +470,9 @@ __global__ __launch_bounds__(LV_THREADS) __attribute__((amdgpu_waves_per_eu(LV_O
 template <typename TIn, typename TOut, int COST>
 static int lv_launch(const WarpArgs& a, hipStream_t st) {
     auto kern = warp_cost_lv_kernel<TIn, TOut, COST>;
-    static bool attr_done = false;     // (more than the 48 KiB a kernel may ask for without saying so)
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS);
+    {
+        hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(kern), LV_LDS);
         if (e != hipSuccess) { set_error("pscv_warp_cost(lv): hipFuncSetAttribute: %s", hipGetErrorString(e)); return -2; }
-        attr_done = true;
     }
     const int tiles = a.B * ((a.h + LV_TH - 1) / LV_TH) * ((a.w + LV_T - 1) / LV_T);
     hipLaunchKernelGGL(kern, dim3(8 * ((tiles + 7) / 8), a.n_dchunks), dim3(LV_THREADS), LV_LDS, st, a);

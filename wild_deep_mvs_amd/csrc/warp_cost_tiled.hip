@@ -41,19 +41,9 @@
 #include "warp_common.h"
 #include "warp_lds.h"
 
-// Two builds of this file (Makefile).  The PRODUCT build (warp_cost_tiled.o) is compiled WITHOUT packed fp32 instructions
-// (-target-feature -packed-fp32-ops): next to another stream's / process's LDS + MFMA conv waves the v_pk_*_f32 instructions of the
-// blend were seen to leave stale values in lanes 48-63 of a wave (scripts/ubench/lds_pk_overlap.hip); the
-// scalar build is bit-stable there (0 of 400 overlapped launches against 150-390) and is what pscv_warp_cost launches.
-// WL_PK: the packed-fp32 build (warp_cost_tiled_pk.o), kept under other names as a DIAGNOSTIC for that defect only
-// (pscv_set_tuning("warp_tiled", 3); ~7 % faster alone, NOT safe beside other kernels).  Same source, same fp32 operation chain,
-// same stored bits.
-#ifdef WL_PK
-#define warp_cost_lds_kernel warp_cost_lds_pk_kernel
-#define warp_cost_tiled_try warp_cost_tiled_pk_try
-#define wl_prof wl_prof_pk
-#endif
-
+// Built WITHOUT packed fp32 instructions (Makefile: -target-feature -packed-fp32-ops): v_pk_{mul,add,fma}_f32 with the op_sel bit of src1 set
+// return wrong low results in lanes 48-63 beside MFMA waves of another stream on this MI355X pool; the SLP vectorizer
+// emits that form for the blend below.  scripts/lint_isa.py keeps the form out of the library.
 namespace pscv {
 
 #ifndef WL_TILE_H
@@ -73,59 +63,8 @@ static_assert(WL_LDS <= (WL_TH == 8 ? 81920 : 40960), "two / four blocks per CU"
 
 typedef float wl_f2 __attribute__((ext_vector_type(2)));
 
-#ifdef WL_PROFILE
-// phase stamps kept in registers and written once per wave at the end (atomics per stamp perturbed the phases they timed)
-constexpr int WL_PROF_BLOCKS = 8192;
-__device__ unsigned int wl_prof[WL_PROF_BLOCKS * 16];
-#define WL_STAMP(i) { const unsigned long long t_ = __builtin_readcyclecounter(); t_acc[i] = (unsigned)(t_ - t_prev); t_prev = t_; }
-#else
-#define WL_STAMP(i)
-#endif
-
 // eight fp32 channels x four taps -> eight blended channels; t = {00lo, 00hi, 01lo, 01hi, 10lo, 10hi, 11lo, 11hi}
-// WL_X_BLEND / WL_X_SUMS / WL_X_FINAL (diagnostic builds of the PACKED kernel, scripts/dev/pk_variants.sh): that part of the sweep is
-// forced onto scalar fp32 instructions (inline assembly: the SLP vectorizer cannot pair them) while the rest keeps its packed forms
-// -- which packed instructions does the overlap defect need?
-__device__ __forceinline__ float wl_mul_s(float a, float b) { float r; asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ float wl_fma_s(float a, float b, float c) { asm("v_fma_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b)); return c; }
-__device__ __forceinline__ float wl_add_s(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ float wl_sub_s(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ void wl_blend8(const wl_f4 (&t)[8], const float (&w)[4], float (&o)[8]) {
-#ifdef WL_E_BLEND      // (diagnostic, with -fno-slp-vectorize: ONLY the blend on explicit two-wide arithmetic = v_pk_mul_f32 / v_pk_fma_f32)
-    {
-        wl_f2 p[4];
-        const wl_f2 w0 = wl_f2{w[0], w[0]};
-        p[0] = wl_f2{t[0].x, t[0].y} * w0; p[1] = wl_f2{t[0].z, t[0].w} * w0; p[2] = wl_f2{t[1].x, t[1].y} * w0; p[3] = wl_f2{t[1].z, t[1].w} * w0;
-#ifdef WL_E_BLEND_HI   // the SLP build's operand form: w[2] and w[1] share ONE register pair, tap 1 broadcasts its HIGH half (op_sel:[0,1,0])
-        wl_f2 w21 = wl_f2{w[2], w[1]};
-        asm volatile("" : "+v"(w21));          // (keeps the two weights in one pair)
-#endif
-#pragma unroll
-        for (int k = 1; k < 4; ++k) {
-#ifdef WL_E_BLEND_HI
-            const wl_f2 wk = k == 1 ? __builtin_shufflevector(w21, w21, 1, 1) : k == 2 ? __builtin_shufflevector(w21, w21, 0, 0) : wl_f2{w[k], w[k]};
-#else
-            const wl_f2 wk = wl_f2{w[k], w[k]};
-#endif
-            p[0] = __builtin_elementwise_fma(wl_f2{t[2 * k].x, t[2 * k].y}, wk, p[0]);
-            p[1] = __builtin_elementwise_fma(wl_f2{t[2 * k].z, t[2 * k].w}, wk, p[1]);
-            p[2] = __builtin_elementwise_fma(wl_f2{t[2 * k + 1].x, t[2 * k + 1].y}, wk, p[2]);
-            p[3] = __builtin_elementwise_fma(wl_f2{t[2 * k + 1].z, t[2 * k + 1].w}, wk, p[3]);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { o[2 * j] = p[j][0]; o[2 * j + 1] = p[j][1]; }
-        return;
-    }
-#endif
-#ifdef WL_X_BLEND
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = wl_mul_s(t[j >> 2][j & 3], w[0]);
-#pragma unroll
-    for (int k = 1; k < 4; ++k)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = wl_fma_s(t[2 * k + (j >> 2)][j & 3], w[k], o[j]);
-    return;
-#endif
     o[0] = t[0].x * w[0]; o[1] = t[0].y * w[0]; o[2] = t[0].z * w[0]; o[3] = t[0].w * w[0];
     o[4] = t[1].x * w[0]; o[5] = t[1].y * w[0]; o[6] = t[1].z * w[0]; o[7] = t[1].w * w[0];
 #pragma unroll
@@ -137,34 +76,7 @@ __device__ __forceinline__ void wl_blend8(const wl_f4 (&t)[8], const float (&w)[
     }
 }
 
-// Diagnostic variants of the packed build (built by scripts/dev/pk_variants.sh, never part of libpscv.so):
-//   WL_FIX_NOP  full lgkmcnt wait + 16 idle cycles between the tap reads and the packed blend
-//   WL_FIX_MOV  every tap register passes through a (non-packed) v_mov_b32 before its packed consumer
-//   WL_FIX_B64  the tap pieces are read as two ds_read_b64 instead of one ds_read_b128
-__device__ __forceinline__ void wl_fix(wl_f4 (&t)[8]) {
-#if defined(WL_FIX_NOP) || defined(WL_FIX_B64)
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]));
-#endif
-#ifdef WL_FIX_NOP
-    asm volatile("s_nop 7\n s_nop 7" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]));
-#endif
-#ifdef WL_FIX_MOV
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-        asm volatile("v_mov_b32 %0, %0\n v_mov_b32 %1, %1\n v_mov_b32 %2, %2\n v_mov_b32 %3, %3" : "+v"(t[k].x), "+v"(t[k].y), "+v"(t[k].z), "+v"(t[k].w));
-#endif
-}
-__device__ __forceinline__ wl_f4 wl_tap(const unsigned char* lsm, unsigned off) {
-#ifdef WL_FIX_B64
-    const unsigned a = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)lsm + off;
-    wl_f2 lo, hi;
-    asm volatile("ds_read_b64 %0, %1" : "=v"(lo) : "v"(a));
-    asm volatile("ds_read_b64 %0, %1 offset:8" : "=v"(hi) : "v"(a));
-    return wl_f4{lo.x, lo.y, hi.x, hi.y};
-#else
-    return *reinterpret_cast<const wl_f4*>(lsm + off);
-#endif
-}
+__device__ __forceinline__ wl_f4 wl_tap(const unsigned char* lsm, unsigned off) { return *reinterpret_cast<const wl_f4*>(lsm + off); }
 
 template <typename TOut> __device__ __forceinline__ void wl_store8(char* p, const float (&o)[8]) {
     if constexpr (sizeof(TOut) == 4) {
@@ -213,11 +125,6 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
     const float* const depth_b = a.depth + (long)b * a.depth_bstride;
     const int n_src = a.n_src;
     int* const table = reinterpret_cast<int*>(lsm + WL_TABLE);
-#ifdef WL_PROFILE
-    unsigned long long t_prev = __builtin_readcyclecounter();
-    const unsigned long long t_begin = t_prev;
-    unsigned t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
 
     // depth planes of the chunk: lane i holds plane d0 + i (<= 64 planes per chunk)
     const float dlane = depth_b[min(d0 + lane, d1 - 1)];
@@ -252,7 +159,6 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
         for (int j = 0; j < 8; ++j) rf[j] = t.v[j];
     }
 
-    WL_STAMP(0)
     // ---- 1. wave 0: texel box per view from the 8 corner projections (tile corners x depth extremes of the chunk): for a
     //         fixed plane the warp is a homography (convex sets stay convex while z > 0), for a fixed pixel the sample moves
     //         monotonically along its epipolar line, so every sample of the (tile, chunk) lies in the bounding box of these
@@ -272,21 +178,12 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
         if (k < n_src) {
             typedef const __attribute__((address_space(4))) float* wl_cf;
             wl_cf cam = (wl_cf)(a.cams + ((long)k * a.B + b) * PSCV_CAM_FLOATS);
-#ifdef WL_X_BOX      // (diagnostic: the box arithmetic on scalar fp32 instructions, see wl_mul_s)
-            const float ax = wl_add_s(wl_fma_s(cam[1], cy, wl_mul_s(cam[0], cx)), cam[2]);
-            const float ay = wl_add_s(wl_fma_s(cam[4], cy, wl_mul_s(cam[3], cx)), cam[5]);
-            const float az = wl_add_s(wl_fma_s(cam[7], cy, wl_mul_s(cam[6], cx)), cam[8]);
-            const float hx = wl_fma_s(ax, d, cam[9]), hy = wl_fma_s(ay, d, cam[10]), hz = wl_fma_s(az, d, cam[11]);
-            const float inv_z = __builtin_amdgcn_rcpf(hz);
-            const float u = wl_mul_s(hx, inv_z), v = wl_mul_s(hy, inv_z);
-#else
             const float ax = fmaf(cam[1], cy, cam[0] * cx) + cam[2];
             const float ay = fmaf(cam[4], cy, cam[3] * cx) + cam[5];
             const float az = fmaf(cam[7], cy, cam[6] * cx) + cam[8];
             const float hx = fmaf(ax, d, cam[9]), hy = fmaf(ay, d, cam[10]), hz = fmaf(az, d, cam[11]);
             const float inv_z = __builtin_amdgcn_rcpf(hz);
             const float u = hx * inv_z, v = hy * inv_z;
-#endif
             const float okf = (hz > 1e-6f && fabsf(u) < 1e6f && fabsf(v) < 1e6f) ? 1.0f : 0.0f;   // also rejects NaN
             const float umin = wl_reduce8<false>(u), umax = wl_reduce8<true>(u);
             const float vmin = wl_reduce8<false>(v), vmax = wl_reduce8<true>(v);
@@ -313,9 +210,7 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
             row[1] = make_int4(0, pitch, mode, 0);
         }
     }
-    WL_STAMP(1)
     __syncthreads();
-    WL_STAMP(2)
 
     // ---- 2. every wave: the four records -> scalar registers; arena allocation greedy in view order (a view whose box does not fit
     //         next to the earlier ones takes global taps), the same in every wave; this lane's view -> vector registers ----
@@ -388,7 +283,6 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
         }
     }
 
-    WL_STAMP(3)
     const float invN = 1.0f / (float)(n_src + 1);
     const float invN2 = 1.0f / ((float)(n_src + 1) * (float)(n_src + 1));
     char* const out = reinterpret_cast<char*>(a.out);
@@ -397,15 +291,9 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
     const unsigned long img_bytes = (unsigned long)b * a.hs * a.ws * PIXB;
     __syncthreads();
     __builtin_amdgcn_s_setprio(0);
-    WL_STAMP(4)
 
     // ---- 5. sweep: one voxel per quad and step, all source views, per-view mode branches ----
-    int d1_eff = d1;
-#ifdef WL_PROFILE
-    const bool wl_skip = a.temp == -12345.0f;   // (phase timing of the staging alone)
-    if (wl_skip) d1_eff = d0;
-#endif
-    for (int d = d0 + wave / WL_PG; d < d1_eff; d += 2) {
+    for (int d = d0 + wave / WL_PG; d < d1; d += 2) {
         const float dval = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dlane), d - d0));
         float s[8], q[8];          // variance: sum, sum of squares; softmin: sum e*diff (s only)
         float sum_e = 0.0f;
@@ -417,18 +305,7 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
         auto accumulate = [&](const float (&wv)[8]) {
             if (VAR) {
 #pragma unroll
-#ifdef WL_X_SUMS
-                for (int j = 0; j < 8; ++j) { s[j] = wl_add_s(s[j], wv[j]); q[j] = wl_fma_s(wv[j], wv[j], q[j]); }
-#elif defined(WL_E_SUMS)   // (diagnostic, with -fno-slp-vectorize: ONLY the two sums on explicit two-wide arithmetic)
-                for (int j = 0; j < 4; ++j) {
-                    const wl_f2 v2 = wl_f2{wv[2 * j], wv[2 * j + 1]};
-                    const wl_f2 s2 = wl_f2{s[2 * j], s[2 * j + 1]} + v2;
-                    const wl_f2 q2 = __builtin_elementwise_fma(v2, v2, wl_f2{q[2 * j], q[2 * j + 1]});
-                    s[2 * j] = s2[0]; s[2 * j + 1] = s2[1]; q[2 * j] = q2[0]; q[2 * j + 1] = q2[1];
-                }
-#else
                 for (int j = 0; j < 8; ++j) { s[j] += wv[j]; q[j] = fmaf(wv[j], wv[j], q[j]); }
-#endif
             } else {   // SOFTMIN  model.py:141-173
                 float df[8], part = 0.0f;
 #pragma unroll
@@ -446,30 +323,17 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
         float w00, w01, w10, w11;
         int E, DX = 64, DY = mpitch << 6;
         {
-#ifdef WL_X_COORDS      // (diagnostic: the per-trip coordinate arithmetic on scalar fp32 instructions, see wl_mul_s)
-            const float dvv = dval;
-            const float hx = wl_fma_s(rx, dvv, tx), hy = wl_fma_s(ry, dvv, ty_), hz = wl_fma_s(rz, dvv, tz);
-            const float inv_z = __builtin_amdgcn_rcpf(hz);
-            float ix = wl_mul_s(hx, inv_z), iy = wl_mul_s(hy, inv_z);
-#else
             const float hx = fmaf(rx, dval, tx), hy = fmaf(ry, dval, ty_), hz = fmaf(rz, dval, tz);
             const float inv_z = __builtin_amdgcn_rcpf(hz);
             float ix = hx * inv_z, iy = hy * inv_z;
-#endif
             if (any_gen) {   // (a staged box has every corner in front of the camera: no behind-camera test)
                 ix = __builtin_amdgcn_fmed3f(ix, a.xlo, a.xhi);      // grid clamp  module.py:151-155
                 iy = __builtin_amdgcn_fmed3f(iy, a.ylo, a.yhi);
             }
             const float x0f = floorf(ix), y0f = floorf(iy);
-#ifdef WL_X_COORDS
-            const float fx = wl_sub_s(ix, x0f), fy = wl_sub_s(iy, y0f);
-            const float gx = wl_sub_s(1.0f, fx), gy = wl_sub_s(1.0f, fy);
-            w00 = wl_mul_s(gx, gy); w01 = wl_mul_s(fx, gy); w10 = wl_mul_s(gx, fy); w11 = wl_mul_s(fx, fy);
-#else
             const float fx = ix - x0f, fy = iy - y0f;
             const float gx = 1.0f - fx, gy = 1.0f - fy;
             w00 = gx * gy; w01 = fx * gy; w10 = gx * fy; w11 = fx * fy;
-#endif
             const int x0 = (int)x0f, y0 = (int)y0f;
             if (any_gen) {
                 // zero padding: a tap outside the image has weight 0 and is read from the nearest staged texel instead
@@ -488,11 +352,6 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
             }
         }
 
-#if defined(WL_FIX_NOP) || defined(WL_FIX_MOV) || defined(WL_FIX_B64)
-#define WL_FIX(t) wl_fix(t);
-#else
-#define WL_FIX(t)
-#endif
 #define WL_VIEW(K, CTRL)                                                                                                  \
         if (K < n_src && (bMode[K] != WL_ZERO || !VAR)) {                                                                  \
             float wv[8];                                                                                                   \
@@ -527,7 +386,6 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
                         t[6] = wl_tap(lsm, a11);                                               \
                         t[7] = wl_tap(lsm, a11 + WL_HI);                                       \
                     }                                                                                                      \
-                    WL_FIX(t)                                                                                              \
                 } else {                                                                                                   \
                     /* general path, direct global taps: behind-camera test, grid clamp, zero padding  module.py:146-166 */ \
                     const float* cam = a.cams + ((long)K * a.B + b) * PSCV_CAM_FLOATS;                                    \
@@ -564,7 +422,6 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
 #undef WL_VIEW
 
         float o[8];
-#if !defined(WL_PK) || defined(WL_X_FINAL)
         // the packed build's rounding, spelled out (its compiler emits mul, mul, fma / mul, mul, fma for these two expressions)
         if (COST == PSCV_COST_VARIANCE) {
 #pragma unroll
@@ -573,7 +430,6 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float m = __fmul_rn(invN, s[j]); o[j] = fmaf(invN, q[j], -__fmul_rn(m, m)); }
         } else
-#endif
         if (COST == PSCV_COST_VARIANCE) {
             const wl_f2 n1 = wl_f2{invN, invN}, n2 = wl_f2{invN2, invN2};
 #pragma unroll
@@ -596,47 +452,26 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = s[j] * inv;
         }
-#ifndef WL_PK
         // The stored value is the fp32 result ROUNDED to fp32, then to 16 bits -- what "compute in fp32, store 16-bit" means and what
         // the direct kernels do.  Without this the compiler folds the last fma and the conversion into v_fma_mixlo/hi_f16 (ONE rounding
         // of the exact fma): 0.01-0.4 % of the stored values then differ by one fp16 ulp from the direct kernels' (round 4: found when
         // the scalar build became the default and the bit-equality tests against the direct kernels failed).
 #pragma unroll
         for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(o[j]));
-#endif
         if (active) wl_store8<TOut>(out + ((unsigned long)b * a.D + d) * plane_bytes + lane_out, o);
     }
-    WL_STAMP(5)
-#ifdef WL_PROFILE
-    if (lane == 0 && (wave == 0 || wave == WL_THREADS / 64 - 1)) {
-        const int blk = blockIdx.x + gridDim.x * blockIdx.y;
-        if (blk < WL_PROF_BLOCKS)
-            for (int i = 0; i < 6; ++i) wl_prof[blk * 16 + (wave ? 8 : 0) + i] = t_acc[i];
-        if (blk < WL_PROF_BLOCKS) {   // absolute begin / end stamps (low 32 bits) and the hardware slot of this wave
-            unsigned hwid;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-            unsigned xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            wl_prof[blk * 16 + (wave ? 8 : 0) + 6] = (unsigned)t_begin;
-            wl_prof[blk * 16 + (wave ? 8 : 0) + 7] = (unsigned)t_prev;
-            if (wave == 0) { wl_prof[blk * 16 + 0] = hwid; } else { wl_prof[blk * 16 + 8] = xcc; }
-        }
-    }
-#endif
 }
 
 template <typename TIn, typename TOut, int COST>
 static int wl_launch(const WarpArgs& a, int nblk, hipStream_t st) {
     auto kern = warp_cost_lds_kernel<TIn, TOut, PSCV_GEOM_PROJ, COST>;
-    static bool attr_done = false;
     // "warp_lds_pad" (KiB, measurement knob): ask for more LDS than the kernel needs = fewer workgroups per CU with the same code --
     // the occupancy experiment of scripts/dev/wl_residency.py and the stream-mode co-residency runs (room for another stream's conv0)
     extern Knob g_warp_lds_pad;
     const int lds = min(WL_LDS + 1024 * max(0, (int)g_warp_lds_pad), 160 * 1024);
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    {
+        hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024);
         if (e != hipSuccess) { set_error("pscv_warp_cost(lds): hipFuncSetAttribute: %s", hipGetErrorString(e)); return -2; }
-        attr_done = true;
     }
     const int tiles = a.B * ((a.h + WL_TH - 1) / WL_TH) * ((a.w + WL_T - 1) / WL_T);
     hipLaunchKernelGGL(kern, dim3(8 * ((tiles + 7) / 8), a.n_dchunks), dim3(WL_THREADS), lds, st, a);
@@ -654,11 +489,7 @@ static int wl_dispatch(const WarpArgs& a, int cost, int nblk, hipStream_t st) {
 // Returns 0 if launched, 1 if this configuration is not covered by the LDS-staged kernel (the caller uses the quad /
 // generic direct kernels), negative on error.
 extern Knob g_warp_tile;   // warp_cost.hip
-#ifdef WL_PK
-extern int* g_wl_mode_hist;
-#else
 int* g_wl_mode_hist = nullptr;   // set by pscv_debug_wl_mode_hist (development aid, not thread-safe; shared with warp_cost_lv.hip)
-#endif
 
 int warp_cost_tiled_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, int out_dtype, int ppd_override, hipStream_t st) {
     if (C != 32 || a.depth_per_pixel || geom != PSCV_GEOM_PROJ || (in_dtype != PSCV_F16 && in_dtype != PSCV_BF16)) return 1;
@@ -683,33 +514,15 @@ int warp_cost_tiled_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, in
 
 }  // namespace pscv
 
-#ifndef WL_PK
 // Development aid (bench.py's `alt_geometry` / mode histogram): while `hist` (16 device ints, [view 0..3][DIRECT, GEN, FAST, ZERO]) is
 // set, every launch of the LDS-staged kernel from this process adds its per-(workgroup, view) staging modes to it; null turns it off.
 extern "C" void pscv_debug_wl_mode_hist(int* hist) { pscv::g_wl_mode_hist = hist; }
 // occupancy the runtime computes for the f16 variance instantiation (development aid; scripts/dev/wl_occupancy.py)
 extern "C" int pscv_debug_wl_occupancy(int* blocks_per_cu, int* lds_bytes, int* threads) {
     auto kern = pscv::warp_cost_lds_kernel<pscv::f16_t, pscv::f16_t, PSCV_GEOM_PROJ, PSCV_COST_VARIANCE>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, pscv::WL_LDS);
+    (void)pscv::ensure_dyn_lds(reinterpret_cast<const void*>(kern), pscv::WL_LDS);
     *lds_bytes = pscv::WL_LDS;
     *threads = pscv::WL_THREADS;
     return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, kern, pscv::WL_THREADS, pscv::WL_LDS);
 }
-#endif
 
-#ifdef WL_PROFILE
-// sums over the first n_blocks blocks of the last launch
-extern "C" int pscv_debug_wl_raw(unsigned int* out, int n_blocks) {
-    if (n_blocks > pscv::WL_PROF_BLOCKS) n_blocks = pscv::WL_PROF_BLOCKS;
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pscv::wl_prof), (size_t)n_blocks * 16 * sizeof(unsigned int));
-}
-extern "C" int pscv_debug_wl_prof(unsigned long long* out16, int n_blocks) {
-    static unsigned int host[pscv::WL_PROF_BLOCKS * 16];
-    if (n_blocks > pscv::WL_PROF_BLOCKS) n_blocks = pscv::WL_PROF_BLOCKS;
-    hipMemcpyFromSymbol(host, HIP_SYMBOL(pscv::wl_prof), (size_t)n_blocks * 16 * sizeof(unsigned int));
-    for (int i = 0; i < 16; ++i) out16[i] = 0;
-    for (int b = 0; b < n_blocks; ++b)
-        for (int i = 0; i < 16; ++i) out16[i] += host[b * 16 + i];
-    return 0;
-}
-#endif

@@ -43,6 +43,11 @@ class Frontend(ReplayHooks, nn.Module):
     def feature_engine_train(self, name):
         self.model.feature_engine_train = name
 
+    def set_row_group(self, group):
+        """Shard the image rows of the refinement levels over a torch.distributed group (None = no sharding); see
+        ``network._refine_level_row_shard``."""
+        self.model.row_group = group
+
     @replayable
     def forward(self, imgs, K, R, t, depth_min, depth_max, reference_frame=0, **kwargs):
         src_idx = [i for i in range(K.shape[1]) if i != reference_frame]

@@ -145,6 +145,50 @@ class network(nn.Module):
         # "pscv" = training.FeaturePyramidFn: all views in one engine pass, 16-bit activations
         self.feature_engine_train_dtype = None       # 16-bit format of the engine tower's activations in train() (None: fp16)
         self.feature_engine_train = os.environ.get("PSCV_FEATURE_ENGINE_TRAIN", "torch")
+        # row-slab shard of the refinement levels (``Frontend.set_row_group``): with a torch.distributed group
+        # set here, rank r builds, regularises and regresses image rows [ra, rb) of every refinement level (8 per-pixel planes x
+        # H x W: 10.5 M voxels at 1024 x 1280, net.py:166-210) plus a recomputed ROW_HALO-row halo, and the ranks all-gather
+        # their rows of the level's depth (+ confidence on the last level).  The pyramid tower, the camera blocks, the per-pixel
+        # hypotheses (a pass over H x W pixels) and the small coarsest level stay replicated.  The reference has no counterpart.
+        self.row_group = None
+
+    # rows a refinement level's depth depends on beyond its own: the regulariser's receptive field in the image plane is +-17 voxels
+    # (conv0, conv0a 2; conv1 1; five 3x3x3 layers at half resolution 10; conv5^T 2; conv6^T 1; prob0 1 -- net.py:50-85, probed in
+    # SURVEY.md section 8e), rounded up to a multiple of 4: the stride-2 level then sees the slab in the phase it has in the image
+    ROW_HALO = 20
+
+    def _refine_level_row_shard(self, ref_map, src_maps, cams, hyp, want_conf):
+        """One refinement level (reference net.py:166-219) with the image rows sharded over ``self.row_group``.  ``ref_map`` [B,H,W,16]
+        channels-last, ``src_maps`` whole, ``cams`` of the whole image, ``hyp`` [B,8,H,W] per-pixel hypotheses.  The slab's cost
+        volume is bit-identical to those rows of the whole-image launch (`pscv_warp_cost_rows`: slab row y is evaluated at
+        (x, y + slab origin)); values ROW_HALO rows inside an artificial border equal the unsharded ones.  Returns the level's depth
+        [B,H,W] (and confidence [B,H,W] or None) on every rank: one all-gather of the owned rows."""
+        import torch.distributed as dist
+        from .... import dist as pdist
+        grp = self.row_group
+        world, rank = dist.get_world_size(grp), dist.get_rank(grp)
+        B, H, W, _ = ref_map.shape
+        bounds = [pdist.plane_shard(H, world, r, multiple=4) for r in range(world)]
+        ra, rb = bounds[rank]
+        ea, eb = max(0, ra - self.ROW_HALO), min(H, rb + self.ROW_HALO)
+        cost = ops.warp_cost(ref_map[:, ea:eb].contiguous(), src_maps, cams, hyp[:, :, ea:eb].contiguous(), geom=L.GEOM_PROJ,
+                             cost=L.COST_VARIANCE_CVP, out_dtype=self.storage_dtype, ref_y0=ea)
+        logits = self.cost_reg_refine(cost)
+        o = ops.softargmin(logits, hyp[:, :, ea:eb].contiguous(), want_conf=want_conf, conf_mode=0)
+        maps = [o["depth"]] + ([o["conf"]] if want_conf else [])
+        mine = torch.stack([m[:, ra - ea:rb - ea].to(torch.float32) for m in maps], dim=1)        # [B, 1 or 2, owned rows, W]
+        rows_max = max(b - a for a, b in bounds)
+        full = pdist.gather_rows(mine, rows_max * world, rows_max, grp)                              # equal blocks, tail-padded
+        full = torch.cat([full[:, :, r * rows_max:r * rows_max + (b - a)] for r, (a, b) in enumerate(bounds)], dim=2)
+        return full[:, 0].contiguous(), (full[:, 1].contiguous() if want_conf else None)
+
+    def _row_shard_applies(self, H: int) -> bool:
+        """Decided identically on every rank (from H and the group size only), before any collective: every rank must own at least
+        one 4-row block; smaller levels run replicated."""
+        if self.row_group is None or H % 4:
+            return False
+        import torch.distributed as dist
+        return H // 4 >= dist.get_world_size(self.row_group)
 
     def forward_train(self, ref_img, src_imgs, ref_in, src_in, ref_ex, src_ex, depth_min, depth_max, nscale):
         """train()-mode forward with autograd (reference net.py:96-229 with ``self.training``): 48 coarse planes, fixed
@@ -252,6 +296,13 @@ class network(nn.Module):
 
             for id_level, level in enumerate(range(nscale - 2, -1, -1)):
                 depth_up = F.interpolate(depth[None, :], size=None, scale_factor=2, mode='bicubic', align_corners=None).squeeze(0)
+                if fast_cams and taps is None and self._row_shard_applies(depth_up.shape[-2]):
+                    hyp = ops.cvp_depth_hypos(depth_up.to(torch.float32).contiguous(), hypo_cams[level], fallback)
+                    depth, conf = self._refine_level_row_shard(cl(ref_pyr[level]), [cl(p[level]) for p in src_pyrs], warp_cams[level], hyp,
+                                                               want_conf=level == 0)
+                    o = {"depth": depth, "conf": conf}
+                    depth_est_list.append(depth)
+                    continue
                 if fast_cams:
                     hyp = ops.cvp_depth_hypos(depth_up.to(torch.float32).contiguous(), hypo_cams[level], fallback)
                     cost = ops.warp_cost(cl(ref_pyr[level]), [cl(p[level]) for p in src_pyrs], warp_cams[level], hyp,

@@ -2,6 +2,7 @@
 import os
 
 import torch
+import torch.distributed
 from torch import nn
 from torch.nn import functional as F
 
@@ -132,22 +133,22 @@ class Frontend(ReplayHooks, nn.Module):
             fgrp = getattr(self, "feature_shard_group", None)
             if self.training:
                 pass
-            elif fgrp is not None and grp is None and engine and len({tuple(i.shape) for i in imgs}) == 1:
+            elif (fgrp is not None and grp is None and engine and len({tuple(i.shape) for i in imgs}) == 1
+                  and torch.distributed.get_world_size(fgrp) <= v):
+                # (more ranks than views -- e.g. 8 ranks, 5 views: EVERY rank takes the replicated extractor below instead; the
+                #  decision depends on (world, V) only, so all ranks agree before any collective is entered)
                 # depth / row shards need every view's maps on every rank: extract V / G views here, all-gather the rest (16-bit
                 # channels-last maps, 6.9 MB per view at 512x640) instead of running the whole extractor G times over
                 import torch.distributed as dist
                 world, rank = dist.get_world_size(fgrp), dist.get_rank(fgrp)
                 slots = (v + world - 1) // world
                 mine = [j for j in range(v) if j % world == rank]
-                maps = fe(torch.cat([imgs[order[j]] for j in mine], 0)) if mine else None
+                maps = fe(torch.cat([imgs[order[j]] for j in mine], 0))      # world <= V: every rank owns at least one view
                 per_scale = []
                 for k in range(3):
-                    if maps is not None:
-                        shp = (slots * n,) + tuple(maps[k].shape[1:])
-                        buf = maps[k].new_zeros(shp)
-                        buf[:len(mine) * n] = maps[k]
-                    else:   # (more ranks than views: this rank only joins the collective; shapes from an empty extractor pass are not
-                        raise ValueError("feature shard: more ranks than views")          # available, so refuse -- 2-9 views, <= 8 ranks)
+                    shp = (slots * n,) + tuple(maps[k].shape[1:])
+                    buf = maps[k].new_zeros(shp)
+                    buf[:len(mine) * n] = maps[k]
                     got = [torch.empty_like(buf) for _ in range(world)]
                     dist.all_gather(got, buf.contiguous(), group=fgrp)
                     per_scale.append([got[j % world][(j // world) * n:(j // world + 1) * n] for j in range(v)])

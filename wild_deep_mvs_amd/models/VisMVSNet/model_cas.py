@@ -313,6 +313,7 @@ class SingleStage(nn.Module):
         # source-view shard: True (default) = the fused volume is reduce-scattered into per-rank slabs and RegFuse runs on the
         # slab (+ recomputed halo); False = 16-bit all-reduce + replicated RegFuse at every stage (measurement / tests)
         self.view_slabs = True
+        self.view_reduce_fp32 = False   # source-view shard: reduce fp32 shares of the fused volume instead of 16-bit ones (2x the payload)
         # depth-plane shard: with a group set here, rank r sweeps, regularises and fuses only
         # the planes it owns plus a 16-plane halo per side (the pair U-Net + head and the fuse U-Net + head each reach 8
         # planes), and the softmax over D is merged from per-rank partials.  The reference has no counterpart.
@@ -426,17 +427,25 @@ class SingleStage(nn.Module):
         world = dist.get_world_size(grp)
         part, wsum = ops.fuse_pairs(interms, uncerts, normalise=False, want_wsum=True)
         dist.all_reduce(wsum, group=grp)                                               # sum_v w_v over ALL views
-        share = ops.fuse_finish(part, wsum, interms[0].dtype)                          # (sum_{v in rank} w_v interm_v) / sum_v w_v
+        store = interms[0].dtype
+        if self.view_reduce_fp32:
+            # fp32 shares: the cross-rank sum is ONE rounding to the storage format (after the reduction) instead of one per rank
+            # plus RCCL's 16-bit partial sums in ring / tree order -- twice the payload (round 5: tests/test_gpu_dist.py prints the
+            # 8-rank depth error with and without; 16-bit shares are the default, the budget SURVEY 8e counts)
+            share = part / wsum.view(wsum.shape[0], 1, wsum.shape[1], wsum.shape[2], 1)
+        else:
+            share = ops.fuse_finish(part, wsum, store)                                 # (sum_{v in rank} w_v interm_v) / sum_v w_v
         n, d, h, w, _ = share.shape
         plan = pdist.slab_axis(d, h, world) if self.view_slabs else None
         if plan is None:
-            dist.all_reduce(share, group=grp)                                          # 16-bit payload, replicated fuse net
+            dist.all_reduce(share, group=grp)                                          # 16-bit (or fp32) payload, replicated fuse net
+            share = share.to(store)
             score = self.reg_fuse(share)
             o = ops.softargmin(score, None, want_index=True, want_conf=True, conf_mode=1, window=2.0)
             return o["index"], o["conf"], share, score
         axis, S = plan
         ext, lo, a, b = pdist.reduce_to_slab(share, axis, grp)
-        score = self.reg_fuse(ext) if ext is not None else None                        # fp32 scores on the extended slab
+        score = self.reg_fuse(ext.to(store)) if ext is not None else None              # fp32 scores on the extended slab
         if axis == 1:
             if score is None:
                 score = torch.zeros((n, 0, h, w), dtype=torch.float32, device=share.device)
@@ -484,15 +493,19 @@ class SingleStage(nn.Module):
         est_depth = idx.unsqueeze(1) * depth_interval + depth_start
         return est_depth, conf.unsqueeze(1), pair_results
 
-    ROW_HALO = 16        # rows a stage's outputs depend on beyond their own: pair U-Net + head 8, fuse U-Net + head 8
+    # rows a stage's outputs depend on beyond their own: pair U-Net + head 8, the 2-D UncertNet between the pair branch and the fusion
+    # (three 3x3 convolutions over (h, w)) 3, fuse U-Net + head 8 = 19; rounded up to a multiple of 4 so that the stride-2 level of
+    # the U-Nets sees the slab in the phase it has in the image (round 5: was 16 -- the UncertNet rows were missing, so the 3 owned
+    # rows next to an interior slab boundary saw entropy rows contaminated by the artificial zero border)
+    ROW_HALO = 20
 
     def forward_row_shard(self, ref_feat, ref_cam, srcs_feat, srcs_cam, depth_num, depth_start, depth_interval, s_scale):
         """Eval-mode stage with the IMAGE ROWS sharded over ``self.row_group`` (every plane on every rank).  Rank r owns rows
         [ra, rb) (boundaries multiples of 4: the U-Net's stride-2 level sees the slab in the phase it has in the image) and runs the
-        unsharded stage on rows [ra - 16, rb + 16) clipped to the image: the reference feature map and the per-pixel depth starts are
+        unsharded stage on rows [ra - ROW_HALO, rb + ROW_HALO) clipped to the image: the reference feature map and the per-pixel depth starts are
         cropped, the cameras stay those of the whole image and the warp evaluates slab row y at (x, y + slab origin)
         (`pscv_warp_cost_rows`: the cost volume of the slab is bit-identical to those rows of the unsharded one; the source maps stay
-        whole).  Values more than 16 rows inside an artificial border therefore equal the unsharded ones; rows at the image border
+        whole).  Values ROW_HALO (>= 19) rows or more inside an artificial border therefore equal the unsharded ones; rows at the image border
         keep their zero padding.  One all-gather per stage of the owned rows of (depth, probability, pair depths, pair
         uncertainties): (2 + 2 n_src) maps of h x w floats in all."""
         import torch.distributed as dist
@@ -505,8 +518,9 @@ class SingleStage(nn.Module):
             raise ValueError(f"row shard: the stage height {h} must be a multiple of 4")
         bounds = [pdist.plane_shard(h, world, r, multiple=4) for r in range(world)]
         ra, rb = bounds[rank]
-        if rb <= ra:
-            raise ValueError(f"row shard: {world} ranks for {h} rows leaves rank {rank} without a 4-row block")
+        empty = [r for r, (a, b) in enumerate(bounds) if b <= a]
+        if empty:      # decided identically on EVERY rank, before any collective (a raise on the empty ranks only would wedge the others)
+            raise ValueError(f"row shard: {world} ranks for {h} rows leaves rank(s) {empty} without a 4-row block")
         ea, eb = max(0, ra - self.ROW_HALO), min(h, rb + self.ROW_HALO)
         ref_slab = (ref_feat[:, ea:eb] if cl else ref_feat[:, :, ea:eb]).contiguous()
         start = depth_start if depth_start.shape[-2] == 1 else depth_start[:, :, ea:eb].contiguous()
