@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PSCV_ABI_VERSION 7
+#define PSCV_ABI_VERSION 8
 
 /* storage dtypes */
 #define PSCV_F32 0
@@ -528,6 +528,25 @@ int pscv_warp_cost_bwd(const void* ref, const void* const* srcs, int n_src, cons
  */
 int pscv_cvp_depth_hypos(const float* depth, const double* cams, const float* fallback, unsigned long long* keys,
                          double* steps, float* hypos, int B, int H, int W, void* stream);
+
+/*
+ * Fused tail of the MVSNet regulariser as ONE depth sweep (ABI 8): transposed 3x3x3 convolution 16 -> 8 (stride 2, output_padding 1)
+ * + folded BatchNorm + ReLU + skip add, then the 1-channel 3x3x3 head on the result, which never leaves the CU -- the 8-channel
+ * full-resolution volume of the unfused path is neither written nor read.  Same operation chains as pscv_conv3d(kind T2P8)
+ * followed by pscv_conv3d(kind S1C1): the logits are bit-identical to the two launches.
+ * Replaces: conv11 (Sequential(ConvTranspose3d(16, 8), BatchNorm3d, ReLU)), `conv0 + conv11(x)` and `prob` of CostRegNet.forward,
+ *           models/MVSNet/model.py:67-72,81-82.
+ *   in        device 16-bit [B,Di,Hi,Wi,in_cstride], channels [in_coff, in_coff + 16)
+ *   packed_up device copy of pscv_pack_conv3d_weights(kind PSCV_CONV_T2P8); up_scale / up_bias / up_floor device fp32 [8] or null
+ *   skip      null or device 16-bit [B,2Di,2Hi,2Wi,skip_cstride] read at skip_coff (added after the first ReLU)
+ *   packed_head device copy of pscv_pack_conv3d_weights(kind PSCV_CONV_S1C1, c_in 8); hd_scale / hd_bias / hd_floor device fp32 [1] or null
+ *   logits    device fp32 out [B,2Di,2Hi,2Wi]
+ * Returns 0, or 1 when the shape is not covered (call the two layers), negative on error.
+ */
+int pscv_tail_sweep(const void* in, int dtype, int in_cstride, int in_coff, const uint16_t* packed_up, const float* up_scale,
+                    const float* up_bias, const float* up_floor, int up_epi, const void* skip, int skip_cstride, int skip_coff,
+                    const uint16_t* packed_head, const float* hd_scale, const float* hd_bias, const float* hd_floor, int hd_epi,
+                    float* logits, int B, int Di, int Hi, int Wi, void* stream);
 
 /*
  * Fused tail of the MVSNet regulariser: the 1-channel `prob` head (kind S1C1 packing, 8 input channels, depth-sweep variant) writes

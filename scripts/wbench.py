@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--ppd", type=int, nargs="*", default=[0])
     ap.add_argument("--views", type=int, default=5)
     ap.add_argument("--baseline-scale", type=float, default=1.0)
+    ap.add_argument("--rig", default="probe", help="probe | dtu (synthetic.make_cameras)")
     ap.add_argument("--variants", type=int, nargs="*", default=[0], help='values of the "warp_tile" knob to time on the LDS-staged kernel '
                                                                          "(0 = default pipelined sweep, 1 = the round-2 loop)")
     args = ap.parse_args()
@@ -45,11 +46,11 @@ def main():
     V, D, h, w = args.views, 192, 128, 160
     feats = synthetic.make_features(1, V, 32, h, w, seed=1)
     fcl = [ops.to_channels_last(feats[i].to(dev), dt) for i in range(V)]
-    cams = synthetic.make_cameras(1, V, 512, 640)
+    cams = synthetic.make_cameras(1, V, 512, 640, rig=args.rig)
     cams["t"] = cams["t"] * args.baseline_scale
     Ks = cams["K"].clone(); Ks[:, :, :2] /= 4
     proj = build_proj_matrices(Ks, cams["R"], cams["t"]).to(dev)
-    dv = torch.linspace(2.0, 6.0, D).view(1, D).to(dev)
+    dv = torch.linspace(float(cams["depth_min"][0, 0]), float(cams["depth_max"][0, 0]), D).view(1, D).to(dev)
     cm = ops.proj_cams([proj[:, i] for i in range(1, V)], proj[:, 0])
     nbytes = V * 32 * h * w * 2 + D * h * w * 32 * 2
     outs = {}
@@ -60,7 +61,17 @@ def main():
             for variant in (args.variants if tiled else [0]):
                 out = torch.empty(1, D, h, w, 32, dtype=dt, device=dev)
                 L.set_tuning("warp_tiled", tiled); L.set_tuning("warp_ppd", ppd); L.set_tuning("warp_tile", variant)
+                hist = torch.zeros(16, dtype=torch.int32, device=dev)
                 try:
+                    if tiled:
+                        import ctypes
+                        fn = L.lib().pscv_debug_wl_mode_hist
+                        fn.argtypes, fn.restype = [ctypes.c_void_p], None
+                        fn(hist.data_ptr())
+                        ops.warp_cost(fcl[0], fcl[1:], cm, dv, cost=L.COST_VARIANCE, out=out)
+                        torch.cuda.synchronize()
+                        fn(None)
+                        print("   staging modes per view [DIRECT, GEN, FAST, ZERO]:", hist.view(4, 4).tolist())
                     us = timeit(lambda: ops.warp_cost(fcl[0], fcl[1:], cm, dv, cost=L.COST_VARIANCE, out=out), args.reps)
                 finally:
                     L.set_tuning("warp_tiled", -1); L.set_tuning("warp_ppd", 0); L.set_tuning("warp_tile", 0)

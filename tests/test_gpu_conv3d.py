@@ -528,6 +528,61 @@ def test_fused_prob_softargmin_tail_equals_separate_launches(env, shape, dtype):
     check_close(f"fused tail depth vs softmax {shape}", fused["depth"].cpu(), (p * dv.double().view(2, D, 1, 1)).sum(1).float().cpu(), max_abs=2e-5 * 9.0)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("with_skip", [True, False])
+@pytest.mark.parametrize("shape", [(12, 8, 14), (9, 4, 14), (24, 8, 28), (7, 5, 9), (13, 12, 30), (96, 16, 20)])
+def test_tail_sweep_equals_the_two_layers(env, shape, with_skip, dtype):
+    """pscv_tail_sweep (round 5: conv11^T + BatchNorm + ReLU + skip add and the prob head as ONE depth sweep; the 8-channel
+    full-resolution volume lives in an LDS plane ring) against pscv_conv3d(T2P8) followed by pscv_conv3d(S1C1, depth-sweep variant)
+    on the same inputs: IDENTICAL logits (same MFMA chains, same epilogue operation order, same 16-bit rounding of the intermediate),
+    on input shapes (Di, Hi, Wi) that are / are not multiples of the tile (8 x 28 output pixels = 4 x 14 input voxels), of the
+    6-plane block and of the depth chunk, several chunks, batch of two, folded affine + ReLU + per-channel floor.  And against ATen.
+    Reference semantics: models/MVSNet/model.py:67-72,81-82."""
+    L, ops = env
+    g = torch.Generator().manual_seed(17 + sum(shape) + int(with_skip))
+    Di, Hi, Wi = shape
+    B = 2
+    x = bf16_round(torch.randn(B, 16, Di, Hi, Wi, generator=g))
+    wu = bf16_round(torch.randn(16, 8, 3, 3, 3, generator=g) / np.sqrt(27 * 16 / 8))
+    wh = bf16_round(torch.randn(1, 8, 3, 3, 3, generator=g) / np.sqrt(27 * 8))
+    bn = (torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g) * 0.1, torch.randn(8, generator=g) * 0.1, torch.rand(8, generator=g) + 0.5)
+    bias = torch.randn(1, generator=g)
+    skip = bf16_round(torch.randn(B, 8, 2 * Di, 2 * Hi, 2 * Wi, generator=g)) if with_skip else None
+    up = ops.Conv3dLayer.build(wu, kind=L.CONV_T2, transposed=True, device="cuda", bn=bn, relu=True, dtype=dtype)
+    head = ops.Conv3dLayer.build(wh, kind=L.CONV_S1, device="cuda", conv_bias=bias, dtype=dtype)
+    assert up.kind == L.CONV_T2P8 and head.kind == L.CONV_S1C1
+    xcl = ops.to_channels_last(x.cuda(), dtype)
+    scl = ops.to_channels_last(skip.cuda(), dtype) if with_skip else None
+    outs = {}
+    for nbk in (0, 2, 1):
+        L.set_tuning("tail_nbk", nbk)
+        try:
+            outs[nbk] = ops.tail_sweep(xcl, up, head, skip=scl)
+        finally:
+            L.set_tuning("tail_nbk", 0)
+        assert outs[nbk] is not None
+    u11 = ops.conv3d(xcl, up, skip=scl)
+    L.set_tuning("c1_sweep", 2)              # the depth-sweep variant of the head: the accumulation chains the fused kernel uses
+    try:
+        two = ops.conv3d(u11, head, out_dtype=torch.float32).view(B, 2 * Di, 2 * Hi, 2 * Wi)
+    finally:
+        L.set_tuning("c1_sweep", 1)
+    default = ops.conv3d(u11, head, out_dtype=torch.float32).view(B, 2 * Di, 2 * Hi, 2 * Wi)
+    torch.cuda.synchronize()
+    for nbk, o in outs.items():
+        assert torch.isfinite(o).all()
+        ne = int((o != two).sum())
+        assert ne == 0, f"tail_nbk={nbk}: {ne} of {o.numel()} logits differ from the two launches (max {float((o - two).abs().max()):.3e})"
+    check_close(f"tail sweep vs default head variant {shape}", outs[0].cpu(), default.cpu(), max_abs=1e-4)
+    # against ATen on the 16-bit-rounded operands (the intermediate rounded like the engine stores it)
+    scale = bn[0] / torch.sqrt(bn[3] + 1e-5)
+    y = F.conv_transpose3d(x, wu, stride=2, padding=1, output_padding=1) * scale.view(1, 8, 1, 1, 1) + (bn[1] - bn[2] * scale).view(1, 8, 1, 1, 1)
+    y = torch.relu(y) + (skip if with_skip else 0)
+    y = y.to(dtype).float()
+    ref = F.conv3d(y, wh, padding=1) + bias.view(1, 1, 1, 1, 1)
+    check_close(f"tail sweep vs ATen {shape} {dtype}", outs[0].cpu(), ref[:, 0], max_abs=3e-2 if dtype == torch.bfloat16 else 6e-3, rel_l2=4e-3 if dtype == torch.bfloat16 else 6e-4)
+
+
 @pytest.mark.parametrize("cin,cout,kind,shape", [(32, 8, 0, (16, 16, 32)),      # conv0's depth sweep
                                                   (8, 8, 0, (16, 16, 32)),       # narrow sweep
                                                   (8, 16, 1, (16, 16, 32)),      # stride-2 (brick at this size; sweep forced below)

@@ -94,6 +94,10 @@ def _deconv_block(ci: int, co: int) -> nn.Sequential:
 # the online softmax lengthen exactly that chain, while the stand-alone softargmin pass is latency bound with an idle vector ALU.
 # So the default stays off.
 FUSED_TAIL = False
+# conv11^T (+ BatchNorm, ReLU, skip) and the prob head as ONE depth sweep (ops.tail_sweep, csrc/conv3d_tail.hip; round 5): the
+# full-resolution 8-channel volume between them is neither written nor read; the logits are bit-identical to the two launches.
+# `taps` (tests, diagnostics) keep the two launches so that the intermediate volume exists.
+TAIL_SWEEP = True
 
 
 class CostRegNet(nn.Module):
@@ -168,9 +172,12 @@ class CostRegNet(nn.Module):
         c6 = ops.conv3d(ops.conv3d(c4, ly["conv5"]), ly["conv6"])
         u7 = ops.conv3d(c6, ly["conv7"], skip=c4)      # conv4 + relu(bn(deconv))     model.py:79
         u9 = ops.conv3d(u7, ly["conv9"], skip=c2)      # model.py:80
-        u11 = ops.conv3d(u9, ly["conv11"], skip=c0)    # model.py:81
-        fused = ops.prob_softargmin(u11, ly["prob"], regress) if regress is not None and FUSED_TAIL else None
-        logits = fused["logits"] if fused is not None else ops.conv3d(u11, ly["prob"], out_dtype=torch.float32).view(B, D, h, w)
+        fused = u11 = None
+        logits = ops.tail_sweep(u9, ly["conv11"], ly["prob"], skip=c0) if TAIL_SWEEP and taps is None else None   # model.py:81-82
+        if logits is None:
+            u11 = ops.conv3d(u9, ly["conv11"], skip=c0)    # model.py:81
+            fused = ops.prob_softargmin(u11, ly["prob"], regress) if regress is not None and FUSED_TAIL else None
+            logits = fused["logits"] if fused is not None else ops.conv3d(u11, ly["prob"], out_dtype=torch.float32).view(B, D, h, w)
         if taps is not None:
             taps.update(conv0=c0, conv2=c2, conv4=c4, conv6=c6, up7=u7, up9=u9, up11=u11)
         if regress is None:

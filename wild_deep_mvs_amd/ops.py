@@ -857,6 +857,32 @@ def prob_softargmin(x: torch.Tensor, layer: "Conv3dLayer", depth: torch.Tensor, 
     return out
 
 
+def tail_sweep(x: torch.Tensor, up: "Conv3dLayer", head: "Conv3dLayer", *, skip: Optional[torch.Tensor] = None, in_coff: int = 0,
+               skip_coff: int = 0) -> Optional[torch.Tensor]:
+    """Fused tail of the MVSNet regulariser (pscv_tail_sweep): x [B,Di,Hi,Wi,Cs] 16-bit -> transposed layer ``up`` (kind T2P8,
+    16 -> 8, + ``skip`` [B,2Di,2Hi,2Wi,*]) -> 1-channel head ``head`` (kind S1C1) -> fp32 logits [B,2Di,2Hi,2Wi]; the 8-channel
+    full-resolution volume is never stored.  Same bits as ``conv3d(conv3d(x, up, skip=skip), head, out_dtype=float32)``.
+    Returns None when the layers / shape are not covered (run the two layers then)."""
+    _dev(x, skip, up.packed, head.packed)
+    if (up.kind != L.CONV_T2P8 or head.kind != L.CONV_S1C1 or up.c_in != 16 or up.c_out != 8 or head.c_in != 8 or x.dim() != 5
+            or x.dtype != up.dtype or head.dtype != up.dtype or (skip is not None and skip.dtype != x.dtype)):
+        return None
+    B, Di, Hi, Wi, cs = x.shape
+    if skip is not None and tuple(skip.shape[:4]) != (B, 2 * Di, 2 * Hi, 2 * Wi):
+        raise ValueError(f"pscv.tail_sweep: skip has shape {tuple(skip.shape)}, expected [B,{2 * Di},{2 * Hi},{2 * Wi},*]")
+    logits = torch.empty((B, 2 * Di, 2 * Hi, 2 * Wi), dtype=torch.float32, device=x.device)
+    vox = B * 8 * Di * Hi * Wi
+    rc = _launch("tail_sweep", lambda: L.lib().pscv_tail_sweep(
+        _p(x), _dt(x), cs, in_coff, _p(up.packed), _p(up.scale), _p(up.bias), _p(up.floor), up.epi, _p(skip),
+        skip.shape[4] if skip is not None else 0, skip_coff, _p(head.packed), _p(head.scale), _p(head.bias), _p(head.floor), head.epi,
+        _p(logits), B, Di, Hi, Wi, _stream()),
+        cost=lambda: (vox // 8 * 32 + vox * (16 if skip is not None else 0) + vox * 4, 2.0 * vox * 27 * 8 + 2.0 * (vox // 8) * 27 * 16 * 8))
+    if rc == 1:
+        return None
+    L.check(rc, "pscv_tail_sweep")
+    return logits
+
+
 def head_index_entropy(x: torch.Tensor, layer: "Conv3dLayer", index: torch.Tensor, entropy: torch.Tensor, *, want_scores: bool = False):
     """Fused head of a Vis pair branch (pscv_head_index_entropy): x [B,D,h,w,8] 16-bit -> the 1-channel head ``layer`` (kind S1C1)
     -> expected plane index and entropy written into the caller's fp32 [B,h,w] tensors; the fp32 scores only with
