@@ -19,6 +19,11 @@
 //     test at all; box clipped at the border -> general zero-padding weights, taps clamped into the staged box; box
 //     entirely outside -> the view contributes f = 0 and is skipped (variance) -- 19 % of the voxel-views of the bench
 //     scene; a corner at / behind the camera or a box that does not fit -> direct global taps for that view;
+//   * adaptive split (round 5): the box phase computes, per view, the box of the whole 32-plane chunk AND of its two halves; a
+//     block in which some view's whole-chunk box does not fit (wide baselines: on the DTU-like rig a sample travels 0.3 texels
+//     per plane) sweeps the halves one after the other, each with its own staging phase, instead of taking global taps:
+//     DTU-like rig 176 -> 150 us (global-tap share of the (block, view) pairs 43 % -> 15 %), probe rig unchanged (122 -> 119 us),
+//     same stored bits (scripts/dev/warp_ab.py, interleaved);
 //   * one wave computes the boxes (cameras through the scalar cache) and publishes them through a 128-byte LDS table;
 //     the staging loads of a wave are one branch-free batch; this short phase runs at raised wave priority because the
 //     older workgroup of the CU, in its vector-ALU-bound sweep, would otherwise win every issue slot.
@@ -57,8 +62,9 @@ constexpr int WL_ARENA = WL_TH == 8 ? 638 : 318;   // staged texels per block (a
 constexpr int WL_HI = WL_ARENA * 64;         // byte offset of the "hi" channel plane
 constexpr int WL_STAGE_ROWS = 8;             // box rows one wave stages (one load batch)
 constexpr int WL_BOX_H = WL_STAGE_ROWS * (WL_THREADS / 64 / WL_MAX_SRC);   // tallest box the staging phase covers: 8 (4-row tile) / 16
-constexpr int WL_TABLE = 2 * WL_HI;          // per-view box records written by wave 0: 4 x {X0, Y0, X1, Y1, base, pitch, mode, -}
-constexpr int WL_LDS = WL_TABLE + WL_MAX_SRC * 32 + 32;
+constexpr int WL_TABLE = 2 * WL_HI;          // box records (16 B: X0 | Y0, X1 | Y1, pitch | mode as 16-bit pairs), [3 plane ranges][4 views]:
+                                             // range 0 = the whole chunk, 1 / 2 = its first / second half (adaptive split, round 5)
+constexpr int WL_LDS = WL_TABLE + 3 * WL_MAX_SRC * 16 + 32;
 static_assert(WL_LDS <= (WL_TH == 8 ? 81920 : 40960), "two / four blocks per CU");
 
 typedef float wl_f2 __attribute__((ext_vector_type(2)));
@@ -165,15 +171,27 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
     //         8 points.  The camera blocks come through the SCALAR cache (constant address space: the vector memory path is
     //         busy with the cost-volume stores of the other waves and answers in thousands of cycles); lanes = corners;
     //         min / max by DPP; arena allocation greedy in view order, all in scalar registers. ----
-    if (wave < WL_MAX_SRC) {      // wave k: the box of source view k (round 4: the four views side by side instead of one after the other in wave 0)
+    // Round 5: THREE boxes per view in the same phase -- the whole chunk (lanes 0-7 = its 8 corners), its first half (lanes 8-15) and
+    // its second half (lanes 16-23).  If a view's whole-chunk box does not fit (wide baselines: the sample travels 0.3 texels per
+    // plane on DTU-like rigs, 10 texels over 32 planes) the block sweeps the two halves one after the other, each with its own, half
+    // as long boxes, instead of taking global taps for that view: no extra box phase, one more staging phase for such blocks only.
+    const int nplanes = d1 - d0;
+    const int hsz = nplanes >= 4 ? ((nplanes / 2 + 1) & ~1) : nplanes;        // planes of the first half (even); no split below 4 planes
+    if (wave < WL_MAX_SRC) {      // wave k: the boxes of source view k
         const int k = wave;
-        // (depth range: a wave reduction of the per-lane planes; reading the planes through the scalar cache instead -- s_load_dwordx8
-        //  runs, v_min / v_max -- was measured 2 % slower, round 4; planes need not be monotone)
-        const float dmin = wl_wave_reduce<false>(dlane), dmax = wl_wave_reduce<true>(dlane);
+        // (depth ranges: wave reductions of the per-lane planes; planes need not be monotone)
+        const float inf = __builtin_inff();
+        const bool in1 = lane < hsz;
+        const float dmin1 = wl_wave_reduce<false>(in1 ? dlane : inf), dmax1 = wl_wave_reduce<true>(in1 ? dlane : -inf);
+        const float dmin2 = hsz < nplanes ? wl_wave_reduce<false>(in1 ? inf : dlane) : dmin1;
+        const float dmax2 = hsz < nplanes ? wl_wave_reduce<true>(in1 ? -inf : dlane) : dmax1;
+        const float dmin0 = fminf(dmin1, dmin2), dmax0 = fmaxf(dmax1, dmax2);
+        const int set = min(lane >> 3, 2);
         const int corner = lane & 7;
         const float cx = (corner & 1) ? (float)min(x0t + WL_T - 1, a.w - 1) : (float)x0t;
         const float cy = (float)(((corner & 2) ? min(y0t + WL_TH - 1, a.h - 1) : y0t) + a.ref_y0);
-        const float d = (corner & 4) ? dmax : dmin;
+        const float dlo = set == 0 ? dmin0 : set == 1 ? dmin1 : dmin2, dhi = set == 0 ? dmax0 : set == 1 ? dmax1 : dmax2;
+        const float d = (corner & 4) ? dhi : dlo;
         int cX0 = 0, cY0 = 0, cX1 = -1, cY1 = -1, pitch = 4, mode = WL_ZERO;      // mode: WL_FAST / WL_GEN here = "if the arena has room"
         if (k < n_src) {
             typedef const __attribute__((address_space(4))) float* wl_cf;
@@ -185,14 +203,15 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
             const float inv_z = __builtin_amdgcn_rcpf(hz);
             const float u = hx * inv_z, v = hy * inv_z;
             const float okf = (hz > 1e-6f && fabsf(u) < 1e6f && fabsf(v) < 1e6f) ? 1.0f : 0.0f;   // also rejects NaN
+            // (per 8-lane group = per plane range; every lane of a group holds the group's result)
             const float umin = wl_reduce8<false>(u), umax = wl_reduce8<true>(u);
             const float vmin = wl_reduce8<false>(v), vmax = wl_reduce8<true>(v);
-            const bool ok = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wl_reduce8<false>(okf))) != 0;
+            const bool ok = wl_reduce8<false>(okf) != 0.0f;
             // slack of 1/32 texel: the per-pixel fp32 evaluation (different rounding, 1-ulp rcp on both sides) differs
             // from the corners' by < 2e-6 relative, i.e. < 1/32 for maps up to 16384 texels wide (larger ones are refused)
             const float sl = 1.0f / 32.0f;
-            const int X0 = __builtin_amdgcn_readfirstlane((int)floorf(umin - sl)), X1 = __builtin_amdgcn_readfirstlane((int)floorf(umax + sl)) + 1;
-            const int Y0 = __builtin_amdgcn_readfirstlane((int)floorf(vmin - sl)), Y1 = __builtin_amdgcn_readfirstlane((int)floorf(vmax + sl)) + 1;
+            const int X0 = (int)floorf(umin - sl), X1 = (int)floorf(umax + sl) + 1;
+            const int Y0 = (int)floorf(vmin - sl), Y1 = (int)floorf(vmax + sl) + 1;
             mode = WL_DIRECT;
             if (ok) {
                 const bool outside = X1 < 0 || Y1 < 0 || X0 > a.ws - 1 || Y0 > a.hs - 1;
@@ -200,39 +219,62 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
                 cX0 = max(X0, 0); cX1 = min(X1, a.ws - 1); cY0 = max(Y0, 0); cY1 = min(Y1, a.hs - 1);
                 const int bw = cX1 - cX0 + 1, bh = cY1 - cY0 + 1;
                 pitch = (bw + 3) & ~3;   // a multiple of 4: the quads of a ds_read_b128 lane group stay conflict-free across rows
-                if (outside) mode = WL_ZERO;
+                if (outside) { mode = WL_ZERO; cX0 = 0; cY0 = 0; cX1 = -1; cY1 = -1; pitch = 4; }
                 else if (bw <= 16 && bh <= WL_BOX_H) mode = inside ? WL_FAST : WL_GEN;
-            }
+                else { cX0 = 0; cY0 = 0; cX1 = -1; cY1 = -1; pitch = 4; }      // (not staged: keep the record inside 16 bits)
+            } else { cX0 = 0; cY0 = 0; cX1 = -1; cY1 = -1; pitch = 4; }
         }
-        if (lane == 0) {
-            int4* row = reinterpret_cast<int4*>(table + k * 8);
-            row[0] = make_int4(cX0, cY0, cX1, cY1);
-            row[1] = make_int4(0, pitch, mode, 0);
-        }
+        if (corner == 0 && lane < 24)
+            *reinterpret_cast<uint4*>(table + (set * WL_MAX_SRC + k) * 4) =
+                make_uint4(((unsigned)cX0 & 0xffffu) | ((unsigned)cY0 << 16), ((unsigned)cX1 & 0xffffu) | ((unsigned)cY1 << 16),
+                           (unsigned)pitch | ((unsigned)mode << 16), 0u);
     }
     __syncthreads();
 
-    // ---- 2. every wave: the four records -> scalar registers; arena allocation greedy in view order (a view whose box does not fit
-    //         next to the earlier ones takes global taps), the same in every wave; this lane's view -> vector registers ----
+    // ---- 2. every wave: the records of a plane range -> scalar registers; arena allocation greedy in view order (a view whose box
+    //         does not fit next to the earlier ones takes global taps), the same in every wave; this lane's view -> vector registers ----
     int bPitch[WL_MAX_SRC], bMode[WL_MAX_SRC], bBase[WL_MAX_SRC], bX0[WL_MAX_SRC], bY0[WL_MAX_SRC], bX1[WL_MAX_SRC], bY1[WL_MAX_SRC];
     bool any_gen = false;
-    {
+    auto read_records = [&](int set) -> bool {           // returns whether any view of the launch takes global taps
         int used = 0;
+        bool direct = false;
+        any_gen = false;
 #pragma unroll
         for (int k = 0; k < WL_MAX_SRC; ++k) {
-            const int4 r0 = *reinterpret_cast<const int4*>(table + k * 8), r1 = *reinterpret_cast<const int4*>(table + k * 8 + 4);
-            bX0[k] = __builtin_amdgcn_readfirstlane(r0.x); bY0[k] = __builtin_amdgcn_readfirstlane(r0.y);
-            bX1[k] = __builtin_amdgcn_readfirstlane(r0.z); bY1[k] = __builtin_amdgcn_readfirstlane(r0.w);
-            bPitch[k] = __builtin_amdgcn_readfirstlane(r1.y);
-            int mode = __builtin_amdgcn_readfirstlane(r1.z);
+            const uint4 rec = *reinterpret_cast<const uint4*>(table + (set * WL_MAX_SRC + k) * 4);
+            const int rx = __builtin_amdgcn_readfirstlane((int)rec.x), ry = __builtin_amdgcn_readfirstlane((int)rec.y);
+            const int rz = __builtin_amdgcn_readfirstlane((int)rec.z);
+            bX0[k] = (short)(rx & 0xffff); bY0[k] = rx >> 16;
+            bX1[k] = (short)(ry & 0xffff); bY1[k] = ry >> 16;
+            bPitch[k] = rz & 0xffff;
+            int mode = rz >> 16;
             const int need = bPitch[k] * (bY1[k] - bY0[k] + 1);
             if ((mode == WL_FAST || mode == WL_GEN) && used + need > WL_ARENA) mode = WL_DIRECT;
             bBase[k] = used;
             if (mode == WL_FAST || mode == WL_GEN) used += need;
             bMode[k] = mode;
             any_gen = any_gen || mode == WL_GEN;
-            if (a.mode_hist && k < n_src && tid == 0) atomicAdd(a.mode_hist + k * 4 + mode, 1);     // (bench.py's mode histogram; off in product launches)
+            direct = direct || (k < n_src && mode == WL_DIRECT);
         }
+        return direct;
+    };
+    // whole chunk first; if a view would take global taps there, the two halves one after the other
+    // (pscv_set_tuning("warp_tile", 1) switches the split off: A/B runs, scripts/dev/warp_ab.py)
+    int nsub = 1;
+    if (read_records(0) && hsz < nplanes && a.variant != 1) nsub = 2;
+    for (int sub = 0; sub < nsub; ++sub) {
+    if (nsub == 2) {
+        if (sub) {
+            __syncthreads();                             // the first half's sweep is done with the arena
+            __builtin_amdgcn_s_setprio(3);               // (staging phase at raised priority, like the first one)
+        }
+        read_records(1 + sub);
+    }
+    const int s0 = d0 + (nsub == 2 && sub ? hsz : 0), s1 = nsub == 2 && !sub ? d0 + hsz : d1;
+    if (a.mode_hist && tid == 0) {                       // (bench.py's mode histogram, per swept plane range; off in product launches)
+#pragma unroll
+        for (int k = 0; k < WL_MAX_SRC; ++k)
+            if (k < n_src) atomicAdd(a.mode_hist + k * 4 + bMode[k], 1);
     }
     const int sel = l;
     int mX0 = bX0[0], mY0 = bY0[0], mX1 = bX1[0], mY1 = bY1[0], mpitch = bPitch[0], mbase = bBase[0];
@@ -293,7 +335,7 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
     __builtin_amdgcn_s_setprio(0);
 
     // ---- 5. sweep: one voxel per quad and step, all source views, per-view mode branches ----
-    for (int d = d0 + wave / WL_PG; d < d1; d += 2) {
+    for (int d = s0 + wave / WL_PG; d < s1; d += 2) {
         const float dval = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dlane), d - d0));
         float s[8], q[8];          // variance: sum, sum of squares; softmin: sum e*diff (s only)
         float sum_e = 0.0f;
@@ -460,6 +502,7 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
         for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(o[j]));
         if (active) wl_store8<TOut>(out + ((unsigned long)b * a.D + d) * plane_bytes + lane_out, o);
     }
+    }   // plane sub-range
 }
 
 template <typename TIn, typename TOut, int COST>
