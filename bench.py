@@ -54,6 +54,8 @@ def algorithmic_bytes(name: str) -> float:
         return 8 * VOX * 2 + VOX * 4
     if name.startswith("conv3d[8->16,k1]"):
         return 8 * VOX * 2 + 16 * (VOX // 8) * 2
+    if name.startswith("tail_sweep"):
+        return 16 * (VOX // 8) * 2 + 8 * VOX * 2 + VOX * 4          # read half-res 16ch + the 8-ch skip, write fp32 logits (no intermediate)
     if name.startswith("softargmin"):
         return VOX * 4 + 2 * h * w * 4
     return 0.0

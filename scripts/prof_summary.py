@@ -70,7 +70,7 @@ def traffic_json(root):
                 vals.setdefault(k, {})[cname] = v
     keymap = (("warp_cost_lds_kernel", "warp_cost[0]"), ("warp_cost_q2_kernel", "warp_cost[0]"), ("warp_cost_kernel", "warp_cost[0]"), ("conv3d_sweep8_kernel", "conv3d[32->8,k3]"),
               ("conv3d_c1_kernel", "conv3d[8->1,k4]"), ("conv3d_c1_sweep_kernel", "conv3d[8->1,k4]"), ("conv3d_sweep_s2_kernel", "conv3d[8->16,k1]"),
-              ("conv3d_t2p8_kernel", "conv3d[16->8,k5]"), ("softargmin_kernel", "softargmin"))
+              ("conv3d_t2p8_kernel", "conv3d[16->8,k5]"), ("conv3d_tail_kernel", "tail_sweep"), ("softargmin_kernel", "softargmin"))
     out = {}
     for k, d in vals.items():
         for sub, name in keymap:
