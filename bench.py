@@ -137,7 +137,34 @@ def build_inputs(device, rank: int, dtype, batch: int = 1):
     return net, sd, feats, feats_cl, proj.to(device), dv.to(device).contiguous(), proj, dv
 
 
-def geometry_probe(net, device, dtype, reps: int = 20):
+def rig_step(net, device, dtype, rig: str, nb: int, steps: int = 30):
+    """The headline step (a batch of `nb` reference views, hot path, one replayed hipGraph) on the camera rig `rig`: ms per step."""
+    cams = synthetic.make_cameras(nb, V, IMG_H, IMG_W, rig=rig)
+    Ks = cams["K"].clone()
+    Ks[:, :, :2] /= 4
+    proj = build_proj_matrices(Ks, cams["R"], cams["t"]).to(device)
+    st = torch.arange(D, dtype=torch.float32).view(1, -1)
+    dv = (cams["depth_min"][:, :1] + (cams["depth_max"][:, :1] - cams["depth_min"][:, :1]) / (D - 1) * st).to(device).contiguous()
+    feats = synthetic.make_features(nb, V, C, h, w, seed=11)
+    fcl = [ops.to_channels_last(feats[i].to(device), dtype) for i in range(V)]
+    with torch.no_grad():
+        for _ in range(3):
+            net.hot_path(fcl, proj, dv)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            net.hot_path(fcl, proj, dv)
+        for _ in range(10):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            g.replay()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+
+
+def geometry_probe(net, device, dtype, reps: int = 20, nb: int = 1):
     """The headline workload on BOTH camera rigs of `synthetic.make_cameras`: "probe" (what the bench line is
     measured on: depth 2..6, sources rotated about y and shifted along x, 0.03-0.1 feature texels per plane) and "dtu" (depth
     425..905 as data/dtu_yao.py:109, cameras on an arc with tilt, 0.14-0.32 texels per plane, oblique epipolar lines).  Per rig: the
@@ -204,17 +231,23 @@ def geometry_probe(net, device, dtype, reps: int = 20):
             finally:
                 _lib.set_tuning("warp_tiled", -1)
         quad_us = alt_us["direct_gather"]
-        out[rig] = {"warp_cost_us": round(warp_us, 1), "warp_cost_hbm_frac": round(algorithmic_bytes("warp_cost[0]") / (warp_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+        try:
+            step_ms = rig_step(net, device, dtype, rig, nb)
+        except Exception as e:   # pragma: no cover
+            step_ms = None
+        out[rig] = {"step_ms": None if step_ms is None else round(step_ms, 4), "views_per_step": nb,
+                    "value": None if step_ms is None else nb * VOX / (step_ms * 1e-3), "unit": "voxels/s",
+                    "warp_cost_us": round(warp_us, 1), "warp_cost_hbm_frac": round(algorithmic_bytes("warp_cost[0]") / (warp_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                     "warp_cost_us_direct_gather_kernel": round(quad_us, 1), "warp_cost_us_lane_owner_kernel": round(alt_us["lane_owner"], 1),
                     "hot_path_eager_ms_per_view": round(path_ms, 4), "staging_modes_share_of_block_views": modes,
                     "staging_modes_per_view": [dict(zip(names, hm[v])) for v in range(V - 1)]}
-    out["note"] = ("the headline line is measured on the probe rig; on the DTU-like rig the boxes of a 32-plane chunk exceed the kernel's 16 x 8 texel / "
-                   "LDS budget for the wide-baseline views, which then take global taps (DIRECT): stand-alone launch times of both warp kernels are "
-                   "given per rig (`pscv_set_tuning(\"warp_tiled\", 0)` selects the direct-gather kernel for wide-baseline rigs); a per-block "
-                   "split of the chunk into 2-4 plane ranges was built and measured in round 4 (DIRECT 43 % -> 12 %, 215 -> 219 us: the extra "
-                   "box / staging / barrier phases cost what the staged taps saved) and not kept; `warp_cost_us_lane_owner_kernel` is the optional "
-                   "lane-owns-voxel kernel (`warp_tiled` = 4; same bits; these stand-alone times come after each other, not interleaved: "
-                   "profiles/r04_warp_lane_owner.txt has the interleaved A/B)")
+    out["note"] = ("`value` / `step_ms`: the headline step (same batch, one replayed hipGraph) on each rig with DEFAULT tuning -- the top-level "
+                   "`value` is the probe rig's, `value_dtu_rig` repeats the DTU-like rig's.  On the DTU-like rig the source boxes of a 32-plane chunk "
+                   "exceed the LDS-staged kernel's 16 x 8 texel / arena budget for the wide-baseline views; since round 5 such a block sweeps its "
+                   "chunk as two 16-plane halves with their own boxes (three boxes per view from ONE box phase) instead of taking global taps "
+                   "(DIRECT): the histogram counts (swept plane range, view) pairs.  `warp_cost_us*`: stand-alone launches, one after the other "
+                   "(scripts/dev/warp_ab.py has the interleaved A/B: split 150 us, no split 176 us, direct-gather kernel 148 us on the DTU-like "
+                   "rig; 119 / 122 / 155 us on the probe rig)")
     return out
 
 
@@ -285,6 +318,10 @@ SHARDED = {
                        vox=192 * 64 * 80 + 32 * 128 * 160 + 16 * 256 * 320, setter="set_depth_row_groups"),
     # BASELINE configuration 5: Vis-MVSNet 9-view 1152x1600 [256,32,16], the 8 source views sharded over the ranks (16-bit shares of
     # the visibility-weighted sums reduce-scattered into depth / row slabs, slab-sharded RegFuse: the "RCCL variance reduce" of that model)
+    # BASELINE configuration 4: CVP-MVSNet 5-view 1024x1280, five pyramid levels; the image rows of the four refinement levels (8
+    # per-pixel planes each, 10.5 M voxels at the finest) sharded over the ranks (round 5: slab + 20-row recomputed halo, one all-gather
+    # of the level's depth rows; the coarsest level and the pyramid tower run replicated)
+    "cvp_rows": dict(config=4, model="cvp", V=5, H=1024, W=1280, kw=dict(nscale=5), vox=14417920, setter="set_row_group"),
     "view": dict(config=5, model="vis", V=9, H=1152, W=1600, kw=dict(depth_nums=[256, 32, 16], interval_scales=[0.5, 1, 0.5]),
                  vox=256 * 144 * 200 + 32 * 288 * 400 + 16 * 576 * 800, setter="set_view_group"),
 }
@@ -295,6 +332,10 @@ def _sharded_net(cfg, device):
         net = MVSNet("variance")
         net.load_state_dict(synthetic.sharpened_state_dict("mvsnet", synthetic.template_of(net), seed=0))
         net.num_depth = cfg["num_depth"]
+    elif cfg["model"] == "cvp":
+        from wild_deep_mvs_amd.models.CVP_MVSNet.frontend import Frontend as CvpFrontend
+        net = CvpFrontend()
+        net.load_state_dict(synthetic.sharpened_state_dict("cvp", synthetic.template_of(net), seed=0))
     else:
         from wild_deep_mvs_amd.models.VisMVSNet.frontend import Frontend
         net = Frontend()
@@ -708,6 +749,7 @@ def run(args):
             "one_view_at_a_time": None if one_view is None else {"ms_per_view": one_view * 1e3, "value": world * VOX / one_view, "unit": "voxels/s",
                                                                  "what": "the step of rounds 1-2: one reference view per replay on one stream"},
             "graph_replay_equals_eager_on_fresh_inputs": graph_ok,
+            "value_dtu_rig": None,   # filled below: the same step on the DTU-like camera rig (alt_geometry)
             "value_bf16": None,      # filled below: the same step in bf16 storage, the format BASELINE configuration 2 names
             "roofline": roof,
             "roofline_mfma": roof_mfma,
@@ -731,7 +773,8 @@ def run(args):
         line["alt_geometry"] = None
         if world == 1 and not args.no_other_configs:
             try:
-                line["alt_geometry"] = geometry_probe(net, device, DTYPES[args.dtype])
+                line["alt_geometry"] = geometry_probe(net, device, DTYPES[args.dtype], nb=NB)
+                line["value_dtu_rig"] = (line["alt_geometry"].get("dtu") or {}).get("value")
             except Exception as e:   # pragma: no cover
                 line["alt_geometry"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         line["sharded"] = sharded

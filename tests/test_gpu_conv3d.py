@@ -685,6 +685,7 @@ def test_tall_64_channel_tiles_equal_the_4x4_tiles(env, cout, shape, dtype):
     layer = ops.Conv3dLayer.build(w, kind=L.CONV_S1, device="cuda", dtype=dtype, bn=bn, relu=True)
     res = {}
     L.set_tuning("conv_small_tiles", 0)
+    L.set_tuning("conv_wide", 0)               # (both arms on the brick kernel)
     try:
         for tall in (0, 2):
             L.set_tuning("conv_tall64", tall)
@@ -692,6 +693,7 @@ def test_tall_64_channel_tiles_equal_the_4x4_tiles(env, cout, shape, dtype):
     finally:
         L.set_tuning("conv_tall64", 1)
         L.set_tuning("conv_small_tiles", 1)
+        L.set_tuning("conv_wide", 1)
     assert torch.equal(res[0][0], res[2][0]) and torch.equal(res[0][1], res[2][1])
     scale = bn[0] / torch.sqrt(bn[3] + 1e-5)
     ref = F.relu(F.conv3d(x.float().cpu().permute(0, 4, 1, 2, 3), w, padding=1) * scale.view(1, -1, 1, 1, 1) + (bn[1] - bn[2] * scale).view(1, -1, 1, 1, 1))
@@ -732,3 +734,41 @@ def test_fused_residual_block_equals_the_two_launches(env, shape, slots, dtype):
     # layers outside the depth-sweep family are declined
     l16 = ops.Conv3dLayer.build(torch.zeros(16, 8, 3, 3, 3), kind=L.CONV_S2, device="cuda", dtype=dtype)
     assert ops.conv3d_block8(x, l1, l16) is None
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("transposed", [False, True])
+@pytest.mark.parametrize("cin,cout,shape", [(64, 64, (6, 10, 21)), (64, 32, (9, 17, 40)), (32, 64, (4, 8, 16)), (32, 32, (5, 7, 33)),
+                                            (64, 64, (4, 64, 80))])
+def test_wide_kernel_equals_the_brick_kernel_and_aten(env, cin, cout, shape, transposed, dtype):
+    """Round 5: `conv3d_wide_kernel` (32 | 64 -> 32 | 64 stride-1 layers of CVP's regulariser on large volumes: 8-wave workgroups, the
+    weights through an LDS double buffer shared by the waves) against the brick kernel (`conv_wide` = 0): the same k-step order per
+    accumulator and the same epilogue chain -> IDENTICAL stored bits, 16-bit and fp32 outputs, with BatchNorm + ReLU + skip, ragged
+    sizes, batch of two, stride-1 transposed layers (CVP's conv5: the flipped kernel through the packing).  `conv_wide` = 2 runs the
+    wide kernel at any size (by default volumes with fewer than 512 tiles keep the brick kernel).  And against ATen."""
+    L, ops = env
+    D, H, W = shape
+    g = torch.Generator().manual_seed(cin + cout + D + int(transposed))
+    x = bf16_round(torch.randn(2, D, H, W, cin, generator=g)).cuda().to(dtype)
+    sk = bf16_round(torch.randn(2, D, H, W, cout, generator=g)).cuda().to(dtype)
+    w = bf16_round(torch.randn(*((cin, cout) if transposed else (cout, cin)), 3, 3, 3, generator=g) / np.sqrt(27 * cin))
+    bn = (torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1, torch.randn(cout, generator=g) * 0.1, torch.rand(cout, generator=g) + 0.5)
+    layer = ops.Conv3dLayer.build(w, kind=L.CONV_S1, transposed=transposed, device="cuda", dtype=dtype, bn=bn, relu=True)
+    res = {}
+    L.set_tuning("conv_small_tiles", 0)       # the brick kernel's row-split variant (the k-split small tiles sum in another order)
+    try:
+        for wide in (0, 2):
+            L.set_tuning("conv_wide", wide)
+            res[wide] = (ops.conv3d(x, layer, skip=sk), ops.conv3d(x, layer, out_dtype=torch.float32), ops.conv3d(x, layer))
+    finally:
+        L.set_tuning("conv_wide", 1)
+        L.set_tuning("conv_small_tiles", 1)
+    for a_, b_ in zip(res[0], res[2]):
+        assert torch.isfinite(b_.float()).all()
+        ne = int((a_ != b_).sum())
+        assert ne == 0, f"{ne} of {a_.numel()} values differ (max {float((a_.float() - b_.float()).abs().max()):.3e})"
+    scale = bn[0] / torch.sqrt(bn[3] + 1e-5)
+    xc = x.float().cpu().permute(0, 4, 1, 2, 3)
+    conv = F.conv_transpose3d(xc, w, stride=1, padding=1) if transposed else F.conv3d(xc, w, padding=1)
+    ref = F.relu(conv * scale.view(1, -1, 1, 1, 1) + (bn[1] - bn[2] * scale).view(1, -1, 1, 1, 1))
+    check_close(f"wide kernel {cin}->{cout} transposed={transposed} {dtype}", res[2][1].permute(0, 4, 1, 2, 3).cpu(), ref, max_abs=3e-3, rel_l2=2e-4)

@@ -589,7 +589,7 @@ def _bench_sharded_worker(rank, world, port, q):
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         import bench
         dev = torch.device("cuda", rank if os.environ.get("PSCV_TEST_BACKEND") == "nccl" else 0)
-        res = bench.sharded_legs(dist, dev, world, rank, reps=1, only=("mvsnet_depth", "depth", "depth_rows", "view"))
+        res = bench.sharded_legs(dist, dev, world, rank, reps=1, only=("mvsnet_depth", "depth", "depth_rows", "cvp_rows", "view"))
         q.put((rank, res))
     finally:
         dist.destroy_process_group()
@@ -613,7 +613,7 @@ def test_bench_sharded_legs_two_ranks_one_gpu():
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    assert res[1] is None and set(res[0]) == {"mvsnet_depth", "depth", "depth_rows", "view"}
+    assert res[1] is None and set(res[0]) == {"mvsnet_depth", "depth", "depth_rows", "cvp_rows", "view"}
     for mode, r in res[0].items():
         assert "error" not in r, r
         print(f"[bench sharded] {mode}: 1 GPU {r['ms_per_forward_1gpu']:.2f} ms, 2 ranks {r['ms_per_forward_sharded']:.2f} ms, "
@@ -648,7 +648,7 @@ def _rccl_one_rank_worker(port, q):
         rows = pd.gather_rows(torch.ones(1, 2, 3, 5, device=dev), 3, 3, None)
         assert rows.shape == (1, 2, 3, 5)
         # the three shardings of bench.py's "sharded" object, each against the unsharded run
-        res = bench.sharded_legs(dist, dev, 1, 0, reps=1, only=("mvsnet_depth", "depth", "depth_rows", "view"))
+        res = bench.sharded_legs(dist, dev, 1, 0, reps=1, only=("mvsnet_depth", "depth", "depth_rows", "cvp_rows", "view"))
         q.put(res)
     except Exception as e:      # (the parent must not wait for its queue time-out)
         import traceback
@@ -672,7 +672,7 @@ def test_rccl_backend_one_rank_runs_every_sharded_path():
     assert "worker" not in res, res["worker"]["error"]
     assert p.exitcode == 0, f"the rank process exited with code {p.exitcode}"
     print("[rccl one rank]", res, flush=True)
-    assert res and set(res) == {"mvsnet_depth", "depth", "depth_rows", "view"}, "a sharded leg did not run"
+    assert res and set(res) == {"mvsnet_depth", "depth", "depth_rows", "cvp_rows", "view"}, "a sharded leg did not run"
     for mode, leg in res.items():
         assert "error" not in leg, (mode, leg)
         # a world of one: the same planes / views, merged through the partial-sum path (Vis depth shard: another summation order)

@@ -620,6 +620,11 @@ int pscv_conv3d_sweep_s2_launch(const void* in, int dtype, int in_cstride, int i
                                 int out_cstride, int out_coff, int out_dtype, int B, int Di, int Hi, int Wi, int c_in, int c_out,
                                 int epi_flags, hipStream_t st);
 
+int pscv_conv3d_wide_launch(const void* in, int dtype, int in_cstride, int in_coff, const uint16_t* packed, const float* scale,
+                            const float* bias, const float* floor, const void* skip, int skip_cstride, int skip_coff, void* out,
+                            int out_cstride, int out_coff, int out_dtype, int B, int D, int Hh, int W, int c_in, int c_out, int epi_flags,
+                            hipStream_t st);
+
 int pscv_conv3d_c1_launch(const void* in, int dtype, int in_cstride, int in_coff, const uint16_t* packed,
                           const float* scale, const float* bias, const float* floor, const void* skip,
                           int skip_cstride, int skip_coff, void* out, int out_cstride, int out_coff, int out_dtype,
@@ -703,6 +708,13 @@ extern "C" int pscv_conv3d(const void* in, int dtype, int in_cstride, int in_cof
                                                    reinterpret_cast<hipStream_t>(stream));
         if (rc < 0) return rc;
         if (rc == 0) { PSCV_CHECK_LAUNCH("pscv_conv3d(s2 sweep)"); return 0; }
+    }
+    if (kind == PSCV_CONV_S1) {      // wide layers (32 | 64 -> 32 | 64) on large volumes: 8-wave workgroups, weights through LDS (conv3d_wide.hip)
+        const int rc = pscv_conv3d_wide_launch(in, dtype, in_cstride, in_coff, packed, scale, bias, floor, skip, skip_cstride, skip_coff, out,
+                                               out_cstride, out_coff, out_dtype, B, Di, Hi, Wi, c_in, c_out, epi_flags,
+                                               reinterpret_cast<hipStream_t>(stream));
+        if (rc < 0) return rc;
+        if (rc == 0) { PSCV_CHECK_LAUNCH("pscv_conv3d(wide)"); return 0; }
     }
     ConvArgs a;
     a.in = reinterpret_cast<const uint16_t*>(in);
