@@ -543,12 +543,18 @@ int pscv_cvp_depth_hypos(const float* depth, const double* cams, const float* fa
  *   skip      null or device 16-bit [B,2Di,2Hi,2Wi,skip_cstride] read at skip_coff (added after the first ReLU)
  *   packed_head device copy of pscv_pack_conv3d_weights(kind PSCV_CONV_S1C1, c_in 8); hd_scale / hd_bias / hd_floor device fp32 [1] or null
  *   logits    device fp32 out [B,2Di,2Hi,2Wi]
+ *   depth     null, or device fp32 planes (row b at depth + b * depth_bstride, 2Di entries): the sweep then also keeps the softmax
+ *             statistics of its logits per depth chunk and a merge launch writes out_depth [B,2Hi,2Wi] = sum softmax(logits) x depth
+ *             and, if out_conf is not null, the 4-plane photometric confidence (models/MVSNet/model.py:207-215) -- the separate
+ *             pscv_softargmin pass disappears; workspace: device fp32, pscv_tail_sweep_workspace(B, Di, Hi, Wi) floats
  * Returns 0, or 1 when the shape is not covered (call the two layers), negative on error.
  */
+long pscv_tail_sweep_workspace(int B, int Di, int Hi, int Wi);
 int pscv_tail_sweep(const void* in, int dtype, int in_cstride, int in_coff, const uint16_t* packed_up, const float* up_scale,
                     const float* up_bias, const float* up_floor, int up_epi, const void* skip, int skip_cstride, int skip_coff,
                     const uint16_t* packed_head, const float* hd_scale, const float* hd_bias, const float* hd_floor, int hd_epi,
-                    float* logits, int B, int Di, int Hi, int Wi, void* stream);
+                    float* logits, const float* depth, long depth_bstride, float* workspace, long workspace_floats,
+                    float* out_depth, float* out_conf, int B, int Di, int Hi, int Wi, void* stream);
 
 /*
  * Fused tail of the MVSNet regulariser: the 1-channel `prob` head (kind S1C1 packing, 8 input channels, depth-sweep variant) writes

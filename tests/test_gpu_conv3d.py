@@ -574,6 +574,20 @@ def test_tail_sweep_equals_the_two_layers(env, shape, with_skip, dtype):
         ne = int((o != two).sum())
         assert ne == 0, f"tail_nbk={nbk}: {ne} of {o.numel()} logits differ from the two launches (max {float((o - two).abs().max()):.3e})"
     check_close(f"tail sweep vs default head variant {shape}", outs[0].cpu(), default.cpu(), max_abs=1e-4)
+    # the regression folded into the sweep (per-chunk softmax statistics + one merge launch) against pscv_softargmin on the same logits:
+    # depth within 2e-6 of the depth range, confidence within 2e-5; batch items with different depth planes; several chunk counts
+    D2 = 2 * Di
+    dv = torch.stack([torch.linspace(2.0, 6.0, D2), torch.linspace(1.0, 9.0, D2)]).cuda().contiguous()
+    sep = ops.softargmin(two.contiguous(), dv, want_conf=True, conf_mode=0)
+    for nbk in (0, 2, 3):
+        L.set_tuning("tail_nbk", nbk)
+        try:
+            fz = ops.tail_sweep(xcl, up, head, skip=scl, regress=dv)
+        finally:
+            L.set_tuning("tail_nbk", 0)
+        assert isinstance(fz, dict) and torch.equal(fz["logits"], two)
+        check_close(f"tail sweep regression depth {shape} nbk={nbk}", fz["depth"].cpu(), sep["depth"].cpu(), max_abs=2e-6 * 9.0)
+        check_close(f"tail sweep regression confidence {shape} nbk={nbk}", fz["conf"].cpu(), sep["conf"].cpu(), max_abs=2e-5)
     # against ATen on the 16-bit-rounded operands (the intermediate rounded like the engine stores it)
     scale = bn[0] / torch.sqrt(bn[3] + 1e-5)
     y = F.conv_transpose3d(x, wu, stride=2, padding=1, output_padding=1) * scale.view(1, 8, 1, 1, 1) + (bn[1] - bn[2] * scale).view(1, 8, 1, 1, 1)

@@ -36,7 +36,7 @@ EXPORTS = ("pscv_last_error", "pscv_abi_version", "pscv_set_tuning", "pscv_proj_
            "pscv_set_tuning_thread", "pscv_get_tuning", "pscv_conv3d_cat2", "pscv_uncert_net", "pscv_head_index_entropy", "pscv_image_prep", "pscv_conv3d_block8",
            "pscv_bn_stats_grouped", "pscv_bn_finalize_grouped", "pscv_bn_act_grouped", "pscv_bn_bwd_reduce_grouped", "pscv_bn_bwd_coeffs_grouped",
            "pscv_bn_bwd_apply_grouped", "pscv_pack_conv2d_weights_device", "pscv_leaky_relu_bwd", "pscv_leaky_relu_bwd_sum", "pscv_pack_conv2d_weights_device_ex", "pscv_warp_cost_rows",
-           "pscv_tail_sweep")
+           "pscv_tail_sweep", "pscv_tail_sweep_workspace")
 
 
 class PscvMissingError(RuntimeError):
@@ -198,7 +198,9 @@ def _declare(lib):
     lib.pscv_prob_softargmin.restype = i
     lib.pscv_prob_softargmin.argtypes = [vp, i, i, i, vp, vp, vp, vp, i, i, vp, C.c_long, vp, vp, C.c_long, vp, vp, i, i, i, i, vp]
     lib.pscv_tail_sweep.restype = i
-    lib.pscv_tail_sweep.argtypes = [vp, i, i, i, vp, vp, vp, vp, i, vp, i, i, vp, vp, vp, vp, i, vp, i, i, i, i, vp]
+    lib.pscv_tail_sweep.argtypes = [vp, i, i, i, vp, vp, vp, vp, i, vp, i, i, vp, vp, vp, vp, i, vp, vp, l, vp, l, vp, vp, i, i, i, i, vp]
+    lib.pscv_tail_sweep_workspace.restype = C.c_long
+    lib.pscv_tail_sweep_workspace.argtypes = [i, i, i, i]
     lib.pscv_homography_warp.restype = i
     lib.pscv_homography_warp.argtypes = [vp, vp, i, vp, i, i, i, i, i, i, vp]
     lib.pscv_cvp_cams.restype = i

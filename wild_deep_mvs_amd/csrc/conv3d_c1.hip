@@ -644,6 +644,12 @@ static int c1_dispatch(const void* in, int dtype, int in_cstride, int in_coff, c
     return -1;
 }
 
+// merge launch for other producers of the same partials (conv3d_tail.hip)
+void pscv_softargmin_merge_launch(const float* part, const float* logits, int ndc, int B, int D, long hw, float* o_depth, float* o_conf, hipStream_t st) {
+    const long npix = (long)B * hw;
+    hipLaunchKernelGGL(pscv::softargmin_merge_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, part, logits, ndc, B, D, hw, o_depth, o_conf);
+}
+
 int pscv_conv3d_c1_launch(const void* in, int dtype, int in_cstride, int in_coff, const uint16_t* packed,
                           const float* scale, const float* bias, const float* floor, const void* skip, int skip_cstride, int skip_coff, void* out,
                           int out_cstride, int out_coff, int out_dtype, int B, int D, int Hh, int W, int c_in,

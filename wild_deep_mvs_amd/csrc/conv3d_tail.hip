@@ -61,6 +61,11 @@ struct TailArgs {
     int B, Di, Hi, Wi;
     int nth, ntw, ndc, nblocks;   // tiles along h (8 rows) and w (28 columns), depth chunks, 6-plane blocks of the volume
     unsigned mg_th, mg_tw, mg_dc;
+    // fused softmax statistics (FUSE instantiations; null = off): per (batch, depth chunk, pixel) the running max, the sum of exponentials,
+    // the sum of exp x depth plane and the sum of exp x plane index of the chunk's logits; softargmin_merge_kernel (conv3d_c1.hip) finishes
+    const float* depth;       // [B][D] planes, row stride depth_bstride
+    long depth_bstride;
+    float* part;              // [B][ndc][4][H][W]
 };
 
 constexpr int TL_TH = 8, TL_TW = 28;                 // output pixels per tile
@@ -71,7 +76,8 @@ constexpr int TL_IR = 7, TL_IC = 17, TL_VS = 48;     // staged input rows 4 s - 
 constexpr int TL_IPB = TL_IR * TL_IC * TL_VS;        // bytes per input ring plane
 constexpr int TL_ISLOT = 5;
 constexpr int TL_ICH = TL_IR * TL_IC * 2;            // 16-byte chunks per input plane (238)
-constexpr int TL_LDS = TL_NSLOT * TL_PB + TL_ISLOT * TL_IPB;
+constexpr int TL_DEPTHS = 96;                        // depth planes of a chunk kept in LDS by the FUSE instantiations (16 blocks of 6)
+constexpr int TL_LDS = TL_NSLOT * TL_PB + TL_ISLOT * TL_IPB + TL_DEPTHS * 4;
 constexpr int TL_P = 6;                              // output planes per consume block
 static_assert(TL_LDS <= 80 * 1024, "two workgroups per CU");
 
@@ -79,7 +85,7 @@ Knob g_tail_nbk = {0, KNOB_SPARE3};                  // pscv_set_tuning("tail_nb
 
 // UP_POST: the transposed layer has a ReLU after the skip add; HD_CLAMP: the head has any ReLU.  MVSNet's tail has neither: the
 // <H, false, false> instantiation carries no dead clamp instructions (a NaN-propagating clamp is a compare + select per value).
-template <typename H, bool UP_POST, bool HD_CLAMP>
+template <typename H, bool UP_POST, bool HD_CLAMP, bool FUSE>
 __global__ __launch_bounds__(256, 2) void conv3d_tail_kernel(const TailArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const ring = smem;                           // u11 planes
@@ -309,6 +315,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_tail_kernel(const TailArgs a) {
     // 4 (g >> 1) + (g & 1) and + 2 of the block's 8-plane window.  Logits through a buffer descriptor over this batch item's volume:
     // lane offset = (row, column, 4 g planes), scalar offset = the block's first plane + r.
     const int pA = 4 * (g >> 1) + (g & 1);
+    // FUSE: the chunk's depth planes in LDS (behind the two rings); running softmax statistics of this lane's own logits -- planes
+    // d0 + 4 g + r of the pixels (h0 + 2 wave + rr, w0 + 16 ct + n) -- merged across the lane groups g = 0, 1 once per chunk
+    float* const sdep = reinterpret_cast<float*>(smem + TL_NSLOT * TL_PB + TL_ISLOT * TL_IPB);
+    if (FUSE && tid < TL_DEPTHS) sdep[tid] = a.depth[(long)b * a.depth_bstride + min(dbeg + tid, D - 1)];      // (first read behind block 0's produce barrier)
+    float sM[2][2], sZ[2][2], sD[2][2], sI[2][2];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) { sM[rr][ct] = -__builtin_inff(); sZ[rr][ct] = 0.f; sD[rr][ct] = 0.f; sI[rr][ct] = 0.f; }
     const unsigned lg_plane_b = (unsigned)Hh * W * 4;
     const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<char*>(a.logits) + (unsigned long)b * D * lg_plane_b, (short)0, (int)((unsigned)D * lg_plane_b), 0x00020000);
@@ -356,13 +371,40 @@ __global__ __launch_bounds__(256, 2) void conv3d_tail_kernel(const TailArgs a) {
                 const int col = ct * 16 + n;
                 const bool ok = g < 2 && oh < Hh && col < TL_TW && w0 + col < W;
                 const unsigned voff = ((unsigned)(oh * W + w0 + col)) * 4u + (unsigned)(4 * g) * lg_plane_b;
+                float yv[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float y = fmaf(ct ? acc1[r] : acc0[r], e_scale, e_bias);
                     if (HD_CLAMP) y = clamp_lo(clamp_lo(y, lo_pre), lo_post);
+                    yv[r] = y;
                     const bool okr = ok && 4 * g + r < TL_P && d0 + 4 * g + r < D;
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), lrs, (int)(okr ? voff : 0x7ffffff0u),
                                                           (int)(soff0 + (unsigned)r * lg_plane_b), 0);
+                }
+                if (FUSE && g < 2) {
+                    // fold the block's logits (fp32, as stored) into the lane's statistics (conv3d_c1_sweep_kernel's FUSE = 1 update)
+                    bool okp[4];
+                    float lmax = -__builtin_inff();
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        okp[r] = 4 * g + r < TL_P && d0 + 4 * g + r < D;
+                        if (okp[r]) lmax = fmaxf(lmax, yv[r]);
+                    }
+                    if (lmax > -__builtin_inff()) {
+                        const float mo = sM[rr][ct], mn = fmaxf(mo, lmax);
+                        const float scl = mo > -__builtin_inff() ? __expf(mo - mn) : 0.0f;
+                        float z = sZ[rr][ct] * scl, sd = sD[rr][ct] * scl, si = sI[rr][ct] * scl;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if (okp[r]) {
+                                const float e = __expf(yv[r] - mn);
+                                z += e;
+                                sd = fmaf(e, sdep[min(k * TL_P + 4 * g + r, TL_DEPTHS - 1)], sd);
+                                si = fmaf(e, (float)(d0 + 4 * g + r), si);
+                            }
+                        }
+                        sM[rr][ct] = mn; sZ[rr][ct] = z; sD[rr][ct] = sd; sI[rr][ct] = si;
+                    }
                 }
             }
         }
@@ -379,17 +421,49 @@ __global__ __launch_bounds__(256, 2) void conv3d_tail_kernel(const TailArgs a) {
         islot0 = islot0 >= TL_ISLOT ? islot0 - TL_ISLOT : islot0;
         __syncthreads();                  // consume done (ring planes 6 k .. 6 k + 5 are free), input planes of block k + 1 staged
     }
+    if (FUSE) {
+        // merge the lane groups g = 0 (planes 0..3 of every block) and g = 1 (planes 4, 5): lane n + 16 -> lane n; lanes g = 0 write
+        const long hw = (long)Hh * W;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const float m1 = __shfl_down(sM[rr][ct], 16, 64), z1 = __shfl_down(sZ[rr][ct], 16, 64);
+                const float d1 = __shfl_down(sD[rr][ct], 16, 64), i1 = __shfl_down(sI[rr][ct], 16, 64);
+                const float m0 = sM[rr][ct], mn = fmaxf(m0, m1);
+                const float f0 = m0 > -__builtin_inff() ? __expf(m0 - mn) : 0.0f, f1 = m1 > -__builtin_inff() ? __expf(m1 - mn) : 0.0f;
+                const int oh = h0 + 2 * wave + rr, col = ct * 16 + n, ow = w0 + col;
+                if (g == 0 && oh < Hh && col < TL_TW && ow < W) {
+                    float* pp = a.part + (((long)b * a.ndc + dci) * 4) * hw + (long)oh * W + ow;
+                    pp[0] = mn;
+                    pp[hw] = sZ[rr][ct] * f0 + z1 * f1;
+                    pp[2 * hw] = sD[rr][ct] * f0 + d1 * f1;
+                    pp[3 * hw] = sI[rr][ct] * f0 + i1 * f1;
+                }
+            }
+    }
 }
 
 }  // namespace pscv
 
+void pscv_softargmin_merge_launch(const float* part, const float* logits, int ndc, int B, int D, long hw, float* o_depth, float* o_conf, hipStream_t st);
+
 // Fused tail.  Returns 0 if launched, 1 if this shape is not covered (the caller runs the two layers), negative on error.
+// depth != null: the sweep also keeps softmax statistics per depth chunk and a merge launch writes the regressed depth (and the 4-plane
+// photometric confidence) -- models/MVSNet/model.py:207-215; workspace: pscv_tail_sweep_workspace(B, Di, Hi, Wi) floats.
+extern "C" long pscv_tail_sweep_workspace(int B, int Di, int Hi, int Wi) {
+    const int nblocks = (2 * Di + pscv::TL_P - 1) / pscv::TL_P;
+    return (long)B * (nblocks / 2 > 0 ? nblocks / 2 : 1) * 4 * (2L * Hi) * (2L * Wi);      // at most one chunk per two blocks
+}
+
 extern "C" int pscv_tail_sweep(const void* in, int dtype, int in_cstride, int in_coff, const uint16_t* packed_up, const float* up_scale,
                                const float* up_bias, const float* up_floor, int up_epi, const void* skip, int skip_cstride, int skip_coff,
                                const uint16_t* packed_head, const float* hd_scale, const float* hd_bias, const float* hd_floor, int hd_epi,
-                               float* logits, int B, int Di, int Hi, int Wi, void* stream) {
+                               float* logits, const float* depth, long depth_bstride, float* workspace, long workspace_floats,
+                               float* out_depth, float* out_conf, int B, int Di, int Hi, int Wi, void* stream) {
     using namespace pscv;
     PSCV_CHECK_ARG(in && packed_up && packed_head && logits, "pscv_tail_sweep: null pointer argument");
+    PSCV_CHECK_ARG(!depth || (workspace && out_depth), "pscv_tail_sweep: the regression needs a workspace and an output");
     PSCV_CHECK_ARG(dtype == PSCV_BF16 || dtype == PSCV_F16, "pscv_tail_sweep: dtype %d", dtype);
     PSCV_CHECK_ARG(B > 0 && Di > 0 && Hi > 0 && Wi > 0, "pscv_tail_sweep: bad sizes");
     PSCV_CHECK_ARG(in_cstride >= in_coff + 16 && (!skip || skip_cstride >= skip_coff + 8), "pscv_tail_sweep: channel slices");
@@ -419,8 +493,15 @@ extern "C" int pscv_tail_sweep(const void* in, int dtype, int in_cstride, int in
     else {
         ndc = (int)(512 / tiles);
         if (ndc < 1) ndc = 1;
-        if (ndc > nblocks / 2) ndc = nblocks / 2 > 0 ? nblocks / 2 : 1;
     }
+    if (ndc > nblocks / 2) ndc = nblocks / 2 > 0 ? nblocks / 2 : 1;
+    const bool fuse = depth != nullptr;
+    if (fuse) {
+        // the chunk's depth planes sit in LDS (TL_DEPTHS): more chunks if a chunk would be longer
+        while ((nblocks + ndc - 1) / ndc * TL_P > TL_DEPTHS) ++ndc;
+        if ((long)B * ndc * 4 * (2L * Hi) * (2L * Wi) > workspace_floats) { set_error("pscv_tail_sweep: workspace of %ld floats is too small", workspace_floats); return -1; }
+    }
+    a.depth = depth; a.depth_bstride = depth_bstride; a.part = fuse ? workspace : nullptr;
     a.nblocks = nblocks;
     a.ndc = ndc;
     a.mg_th = fast_div_magic(a.nth); a.mg_tw = fast_div_magic(a.ntw); a.mg_dc = fast_div_magic(a.ndc);
@@ -429,15 +510,19 @@ extern "C" int pscv_tail_sweep(const void* in, int dtype, int in_cstride, int in
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool up_post = (up_epi & PSCV_EPI_RELU_POST) != 0, hd_clamp = (hd_epi & (PSCV_EPI_RELU_PRE | PSCV_EPI_RELU_POST)) != 0;
     const bool plain = !up_post && !hd_clamp;
-#define PSCV_TAIL_LAUNCH(HT, P, C)                                                                                     \
+#define PSCV_TAIL_LAUNCH(HT, P, C, F)                                                                                  \
     {                                                                                                                  \
-        hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(conv3d_tail_kernel<HT, P, C>), TL_LDS);            \
+        hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(conv3d_tail_kernel<HT, P, C, F>), TL_LDS);         \
         if (e != hipSuccess) { set_error("pscv_tail_sweep: hipFuncSetAttribute: %s", hipGetErrorString(e)); return -2; } \
-        hipLaunchKernelGGL((conv3d_tail_kernel<HT, P, C>), dim3((unsigned)nblk), dim3(256), TL_LDS, st, a);            \
+        hipLaunchKernelGGL((conv3d_tail_kernel<HT, P, C, F>), dim3((unsigned)nblk), dim3(256), TL_LDS, st, a);         \
     }
-    if (dtype == PSCV_BF16) { if (plain) PSCV_TAIL_LAUNCH(bf16_t, false, false) else PSCV_TAIL_LAUNCH(bf16_t, true, true) }
-    else { if (plain) PSCV_TAIL_LAUNCH(f16_t, false, false) else PSCV_TAIL_LAUNCH(f16_t, true, true) }
+#define PSCV_TAIL_DT(HT)                                                                                               \
+    if (plain) { if (fuse) PSCV_TAIL_LAUNCH(HT, false, false, true) else PSCV_TAIL_LAUNCH(HT, false, false, false) }   \
+    else { if (fuse) PSCV_TAIL_LAUNCH(HT, true, true, true) else PSCV_TAIL_LAUNCH(HT, true, true, false) }
+    if (dtype == PSCV_BF16) { PSCV_TAIL_DT(bf16_t) } else { PSCV_TAIL_DT(f16_t) }
+#undef PSCV_TAIL_DT
 #undef PSCV_TAIL_LAUNCH
+    if (fuse) pscv_softargmin_merge_launch(workspace, logits, ndc, B, D, (long)H * W, out_depth, out_conf, st);
     PSCV_CHECK_LAUNCH("pscv_tail_sweep");
     return 0;
 }

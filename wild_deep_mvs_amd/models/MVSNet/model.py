@@ -98,6 +98,11 @@ FUSED_TAIL = False
 # full-resolution 8-channel volume between them is neither written nor read; the logits are bit-identical to the two launches.
 # `taps` (tests, diagnostics) keep the two launches so that the intermediate volume exists.
 TAIL_SWEEP = True
+# ... and the softmax regression folded into that sweep (per-chunk statistics + one merge launch instead of the softargmin pass): built,
+# parity-tested (tests/test_gpu_conv3d.py: depth within 2e-6 of the range) and measured at the headline size: sweep + merge 62.4 us
+# against 44.7 + 12.9 us for the sweep and the stand-alone softargmin pass (the ~100 extra vector instructions per 6-plane block sit
+# in the consume phase's dependency chain, as with the round-2 prob + softargmin fusion) -> off by default.
+TAIL_SWEEP_REGRESS = False
 
 
 class CostRegNet(nn.Module):
@@ -172,8 +177,13 @@ class CostRegNet(nn.Module):
         c6 = ops.conv3d(ops.conv3d(c4, ly["conv5"]), ly["conv6"])
         u7 = ops.conv3d(c6, ly["conv7"], skip=c4)      # conv4 + relu(bn(deconv))     model.py:79
         u9 = ops.conv3d(u7, ly["conv9"], skip=c2)      # model.py:80
-        fused = u11 = None
-        logits = ops.tail_sweep(u9, ly["conv11"], ly["prob"], skip=c0) if TAIL_SWEEP and taps is None else None   # model.py:81-82
+        fused = u11 = logits = None
+        if TAIL_SWEEP and taps is None:                    # model.py:81-82 (+ 207-215 with the regression fused: TAIL_SWEEP_REGRESS)
+            r = ops.tail_sweep(u9, ly["conv11"], ly["prob"], skip=c0, regress=regress if TAIL_SWEEP_REGRESS else None)
+            if isinstance(r, dict):
+                fused, logits = r, r["logits"]
+            else:
+                logits = r
         if logits is None:
             u11 = ops.conv3d(u9, ly["conv11"], skip=c0)    # model.py:81
             fused = ops.prob_softargmin(u11, ly["prob"], regress) if regress is not None and FUSED_TAIL else None

@@ -858,29 +858,44 @@ def prob_softargmin(x: torch.Tensor, layer: "Conv3dLayer", depth: torch.Tensor, 
 
 
 def tail_sweep(x: torch.Tensor, up: "Conv3dLayer", head: "Conv3dLayer", *, skip: Optional[torch.Tensor] = None, in_coff: int = 0,
-               skip_coff: int = 0) -> Optional[torch.Tensor]:
+               skip_coff: int = 0, regress: Optional[torch.Tensor] = None, want_conf: bool = True):
     """Fused tail of the MVSNet regulariser (pscv_tail_sweep): x [B,Di,Hi,Wi,Cs] 16-bit -> transposed layer ``up`` (kind T2P8,
     16 -> 8, + ``skip`` [B,2Di,2Hi,2Wi,*]) -> 1-channel head ``head`` (kind S1C1) -> fp32 logits [B,2Di,2Hi,2Wi]; the 8-channel
     full-resolution volume is never stored.  Same bits as ``conv3d(conv3d(x, up, skip=skip), head, out_dtype=float32)``.
-    Returns None when the layers / shape are not covered (run the two layers then)."""
-    _dev(x, skip, up.packed, head.packed)
+    With ``regress`` = per-batch depth planes [B,2Di] the sweep also keeps softmax statistics and a merge launch regresses depth
+    (and the 4-plane confidence): returns {"logits", "depth", "conf"} -- no separate softargmin pass.  Returns None when the
+    layers / shape are not covered (run the two layers then)."""
+    _dev(x, skip, up.packed, head.packed, regress)
     if (up.kind != L.CONV_T2P8 or head.kind != L.CONV_S1C1 or up.c_in != 16 or up.c_out != 8 or head.c_in != 8 or x.dim() != 5
             or x.dtype != up.dtype or head.dtype != up.dtype or (skip is not None and skip.dtype != x.dtype)):
         return None
     B, Di, Hi, Wi, cs = x.shape
     if skip is not None and tuple(skip.shape[:4]) != (B, 2 * Di, 2 * Hi, 2 * Wi):
         raise ValueError(f"pscv.tail_sweep: skip has shape {tuple(skip.shape)}, expected [B,{2 * Di},{2 * Hi},{2 * Wi},*]")
+    if regress is not None and (regress.dtype != torch.float32 or tuple(regress.shape) != (B, 2 * Di)):
+        raise ValueError(f"pscv.tail_sweep: regress must be fp32 depth planes [B,{2 * Di}]")
     logits = torch.empty((B, 2 * Di, 2 * Hi, 2 * Wi), dtype=torch.float32, device=x.device)
+    ws = o_depth = o_conf = None
+    if regress is not None:
+        ws = _tail_workspace(x.device, int(L.lib().pscv_tail_sweep_workspace(B, Di, Hi, Wi)))
+        o_depth = torch.empty((B, 2 * Hi, 2 * Wi), dtype=torch.float32, device=x.device)
+        o_conf = torch.empty((B, 2 * Hi, 2 * Wi), dtype=torch.float32, device=x.device) if want_conf else None
     vox = B * 8 * Di * Hi * Wi
     rc = _launch("tail_sweep", lambda: L.lib().pscv_tail_sweep(
         _p(x), _dt(x), cs, in_coff, _p(up.packed), _p(up.scale), _p(up.bias), _p(up.floor), up.epi, _p(skip),
         skip.shape[4] if skip is not None else 0, skip_coff, _p(head.packed), _p(head.scale), _p(head.bias), _p(head.floor), head.epi,
-        _p(logits), B, Di, Hi, Wi, _stream()),
+        _p(logits), _p(regress), regress.stride(0) if regress is not None else 0, _p(ws), ws.numel() if ws is not None else 0,
+        _p(o_depth), _p(o_conf), B, Di, Hi, Wi, _stream()),
         cost=lambda: (vox // 8 * 32 + vox * (16 if skip is not None else 0) + vox * 4, 2.0 * vox * 27 * 8 + 2.0 * (vox // 8) * 27 * 16 * 8))
     if rc == 1:
         return None
     L.check(rc, "pscv_tail_sweep")
-    return logits
+    if regress is None:
+        return logits
+    out = {"logits": logits, "depth": o_depth}
+    if want_conf:
+        out["conf"] = o_conf
+    return out
 
 
 def head_index_entropy(x: torch.Tensor, layer: "Conv3dLayer", index: torch.Tensor, entropy: torch.Tensor, *, want_scores: bool = False):
