@@ -81,7 +81,7 @@ constexpr int TL_LDS = TL_NSLOT * TL_PB + TL_ISLOT * TL_IPB + TL_DEPTHS * 4;
 constexpr int TL_P = 6;                              // output planes per consume block
 static_assert(TL_LDS <= 80 * 1024, "two workgroups per CU");
 
-Knob g_tail_nbk = {0, KNOB_SPARE3};                  // pscv_set_tuning("tail_nbk", n): 6-plane blocks per depth chunk (0 = default heuristic)
+Knob g_tail_nbk = {0, KNOB_TAIL_NBK};                  // pscv_set_tuning("tail_nbk", n): 6-plane blocks per depth chunk (0 = default heuristic)
 
 // UP_POST: the transposed layer has a ReLU after the skip add; HD_CLAMP: the head has any ReLU.  MVSNet's tail has neither: the
 // <H, false, false> instantiation carries no dead clamp instructions (a NaN-propagating clamp is a compare + select per value).

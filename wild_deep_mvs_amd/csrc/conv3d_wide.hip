@@ -59,7 +59,7 @@ __host__ __device__ constexpr int wd_vs(int cin) { return cin == 32 ? 96 : cin *
 __host__ __device__ constexpr int wd_stage_steps(int cin) { return cin == 64 ? 6 : 9; }   // k-steps per weight stage (9 / 3 stages per layer)
 __host__ __device__ constexpr int wd_lds(int cin, int nt) { return ((WD_NVOX * wd_vs(cin) + 15) & ~15) + 2 * wd_stage_steps(cin) * nt * 1024; }
 
-Knob g_conv_wide = {1, KNOB_SPARE4};       // pscv_set_tuning("conv_wide", 0): these layers back on the brick kernel (A/B runs, bit comparison)
+Knob g_conv_wide = {1, KNOB_CONV_WIDE};       // pscv_set_tuning("conv_wide", 0): these layers back on the brick kernel (A/B runs, bit comparison)
 
 template <typename H, int CIN, int NT>
 __global__ __launch_bounds__(512, 2) void conv3d_wide_kernel(const WideArgs a) {
