@@ -168,7 +168,7 @@ def geometry_probe(net, device, dtype, reps: int = 20, nb: int = 1):
     """The headline workload on BOTH camera rigs of `synthetic.make_cameras`: "probe" (what the bench line is
     measured on: depth 2..6, sources rotated about y and shifted along x, 0.03-0.1 feature texels per plane) and "dtu" (depth
     425..905 as data/dtu_yao.py:109, cameras on an arc with tilt, 0.14-0.32 texels per plane, oblique epipolar lines).  Per rig: the
-    warp + cost launch alone (HIP events, mean of `reps`), one eager hot path, and the LDS-staged kernel's staging-mode histogram
+    warp + cost launch alone (HIP events; the three warp kernels interleaved, medians of five rounds), one eager hot path, and the LDS-staged kernel's staging-mode histogram
     -- per (workgroup, source view): FAST = box staged, no masks; GEN = staged, clipped at the image border; DIRECT = box too
     large for the LDS budget or a corner behind the camera: global taps; ZERO = box outside the image, the view contributes 0."""
     import ctypes
@@ -198,15 +198,29 @@ def geometry_probe(net, device, dtype, reps: int = 20, nb: int = 1):
         total = max(1, sum(hm[0]))
         names = ("DIRECT", "GEN", "FAST", "ZERO")
         modes = {names[m]: round(sum(hm[v][m] for v in range(V - 1)) / (total * (V - 1)), 4) for m in range(4)}
-        for _ in range(3):
-            warp()
+        # the three kernels INTERLEAVED over several rounds (round 0 = warm-up), medians: stand-alone launches one kernel after the
+        # other measured the clock ramp of whichever came first (round 4's line: 213.7 us for a kernel that an interleaved run puts at 176)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            warp()
-        e1.record()
-        torch.cuda.synchronize()
-        warp_us = e0.elapsed_time(e1) * 1e3 / reps
+        kernels = (("lds_staged", -1), ("direct_gather", 0), ("lane_owner", 4))   # -1: default; 0: geometry-independent global taps; 4: csrc/warp_cost_lv.hip
+        samples = {k: [] for k, _ in kernels}
+        try:
+            for rnd in range(6):
+                for key, tiled in kernels:
+                    _lib.set_tuning("warp_tiled", tiled)
+                    for _ in range(2):
+                        warp()
+                    e0.record()
+                    for _ in range(reps):
+                        warp()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    if rnd:
+                        samples[key].append(e0.elapsed_time(e1) * 1e3 / reps)
+        finally:
+            _lib.set_tuning("warp_tiled", -1)
+        med = lambda v: sorted(v)[len(v) // 2]
+        warp_us = med(samples["lds_staged"])
+        alt_us = {"direct_gather": med(samples["direct_gather"]), "lane_owner": med(samples["lane_owner"])}
         with torch.no_grad():
             for _ in range(2):
                 net.hot_path(fcl, proj, dv)
@@ -216,20 +230,6 @@ def geometry_probe(net, device, dtype, reps: int = 20, nb: int = 1):
                 net.hot_path(fcl, proj, dv)
             torch.cuda.synchronize()
             path_ms = (time.perf_counter() - t0) / reps * 1e3
-        alt_us = {}
-        for key, tiled in (("direct_gather", 0), ("lane_owner", 4)):     # 0: geometry-independent global taps; 4: csrc/warp_cost_lv.hip (optional)
-            _lib.set_tuning("warp_tiled", tiled)
-            try:
-                for _ in range(3):
-                    warp()
-                e0.record()
-                for _ in range(reps):
-                    warp()
-                e1.record()
-                torch.cuda.synchronize()
-                alt_us[key] = e0.elapsed_time(e1) * 1e3 / reps
-            finally:
-                _lib.set_tuning("warp_tiled", -1)
         quad_us = alt_us["direct_gather"]
         try:
             step_ms = rig_step(net, device, dtype, rig, nb)
@@ -245,9 +245,10 @@ def geometry_probe(net, device, dtype, reps: int = 20, nb: int = 1):
                    "`value` is the probe rig's, `value_dtu_rig` repeats the DTU-like rig's.  On the DTU-like rig the source boxes of a 32-plane chunk "
                    "exceed the LDS-staged kernel's 16 x 8 texel / arena budget for the wide-baseline views; since round 5 such a block sweeps its "
                    "chunk as two 16-plane halves with their own boxes (three boxes per view from ONE box phase) instead of taking global taps "
-                   "(DIRECT): the histogram counts (swept plane range, view) pairs.  `warp_cost_us*`: stand-alone launches, one after the other "
-                   "(scripts/dev/warp_ab.py has the interleaved A/B: split 150 us, no split 176 us, direct-gather kernel 148 us on the DTU-like "
-                   "rig; 119 / 122 / 155 us on the probe rig)")
+                   "(DIRECT): the histogram counts (swept plane range, view) pairs.  `warp_cost_us*`: stand-alone launches of the three warp kernels, "
+                   "interleaved, medians of five rounds (scripts/dev/warp_ab.py adds the no-split arm: split 150 us, no split 176 us, direct-gather "
+                   "kernel 148 us on the DTU-like rig; 119 / 122 / 155 us on the probe rig).  The DTU-like rig has 97 % of its (block, view) pairs inside "
+                   "the source images against 80 % on the probe rig (ZERO 0.03 / 0.18): more real work per voxel, not only larger boxes")
     return out
 
 
@@ -645,7 +646,9 @@ def run(args):
                     g1 = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g1, capture_error_mode="thread_local"):
                         item(0)
-                    g1.replay(); torch.cuda.synchronize()
+                    for _ in range(max(args.warmup, 1) * 8):       # the same warm-up as the headline region: clocks settled on this path
+                        g1.replay()
+                    torch.cuda.synchronize()
                     t2 = time.perf_counter()
                     for _ in range(steps):
                         g1.replay()
