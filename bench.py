@@ -425,6 +425,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=3, help="reference views per step and GPU (each with its own 4 source views): the engine runs "
                                                           "the items of a batch as one launch per layer (1 = one view at a time, as in rounds 1-2)")
+    ap.add_argument("--stagger", action="store_true", help="stream mode with warp-to-warp edges between the views (measured slower than lockstep: MVSNet.batch_stagger)")
     ap.add_argument("--batch-mode", choices=["streams", "batched"], default="streams",
                     help="how the views of a step are launched: 'streams' (default) = each view's 13 launches on its own HIP stream, forked inside the replayed graph (up to 4 views), "
                          "'batched' = one launch per layer for the whole batch on one stream, replayed as a hipGraph")
@@ -578,6 +579,7 @@ def run(args):
     # under that overlap (the LDS-staged warp kernel ships as its scalar-fp32 build; tests/test_gpu_overlap.py),
     # and the timed region ends with a bit-equality check of the replayed graph against eager launches on fresh inputs
     net.batch_streams = args.batch_mode == "streams"
+    net.batch_stagger = args.stagger
     streams_mode = net.batch_streams and 2 <= NB <= net.MAX_BATCH_STREAMS
 
     def timed_region(dtype_name, feats_cl_, steps):

@@ -293,6 +293,12 @@ class MVSNet(ReplayHooks, nn.Module):
         # replays and blamed ROCm; it was the packed build's overlap defect), 3 % faster than the batched graph at three views.
         self.batch_streams_capture = True
         self.batch_streams = False
+        # stream mode, staggered (round 5 experiment, OFF): item b + 1's warp + cost launch waits for item b's (an event edge between
+        # the streams; a graph edge under capture), so that the items do not run in lockstep -- three warps, then three conv0s ... --
+        # but one item's warp beside another's conv0 / tail.  Measured at the headline size, alternating: 0.977 / 0.975 ms staggered
+        # against 0.949 / 0.955 ms in lockstep: a warp launch fills every CU's LDS (4 x 40 KB), so another item's conv0 (70 KB per
+        # workgroup) cannot move in beside it anyway, and the stagger only delays the later items.
+        self.batch_stagger = False
 
     # -- upstream ---------------------------------------------------------------------------
     def extract_features(self, imgs: Sequence[torch.Tensor]) -> List[torch.Tensor]:
@@ -409,8 +415,13 @@ class MVSNet(ReplayHooks, nn.Module):
         V = len(features_cl)
         src_idx = [i for i in range(V) if i != reference_frame]
         cams = ops.proj_cams_device(proj.to(torch.float32).contiguous(), reference_frame)
+        gate = self.__dict__.get("_warp_gate")            # (wait for, record) events of the staggered stream mode, else None
+        if gate is not None and gate[0] is not None:
+            torch.cuda.current_stream().wait_event(gate[0])
         cost = self.build_cost_volume(features_cl[reference_frame], [features_cl[i] for i in src_idx],
                                       proj[:, reference_frame], [proj[:, i] for i in src_idx], depth_values, cams)
+        if gate is not None and gate[1] is not None:
+            gate[1].record(torch.cuda.current_stream())
         logits, o = self.cost_regularization(cost, taps, regress=depth_values.to(torch.float32).contiguous())
         if taps is not None:
             taps.update(cost_volume=cost, logits=logits)
@@ -441,12 +452,19 @@ class MVSNet(ReplayHooks, nn.Module):
         outs = []
         # one item's warp overlaps another item's conv kernels here; every kernel of the engine is bit-stable under that overlap
         # (tests/test_gpu_overlap.py; the LDS-staged warp kernel ships as its scalar-fp32 build for this reason)
+        prev_ev = None
         for b in range(B):
             st = streams[b]
             st.wait_stream(main)
             with torch.cuda.stream(st):
                 fb = [f[b:b + 1] for f in features_cl]                      # contiguous views of one batch item
-                outs.append(self.hot_path(fb, proj[b:b + 1], depth_values[b:b + 1].contiguous(), reference_frame))   # (B = 1: the plain path)
+                ev = torch.cuda.Event() if (self.batch_stagger and b + 1 < B) else None
+                self.__dict__["_warp_gate"] = (prev_ev, ev) if self.batch_stagger else None
+                try:
+                    outs.append(self.hot_path(fb, proj[b:b + 1], depth_values[b:b + 1].contiguous(), reference_frame))   # (B = 1: the plain path)
+                finally:
+                    self.__dict__["_warp_gate"] = None
+                prev_ev = ev
         for st in streams[:B]:
             main.wait_stream(st)
         return torch.cat([o[0] for o in outs], 0), torch.cat([o[1] for o in outs], 0)
