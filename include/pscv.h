@@ -90,7 +90,7 @@ int pscv_abi_version(void);
  *               LDS arena (wide baselines) -- an alternative, not the default.
  *   "warp_tile" test / measurement aids (0 = off).  LDS-staged kernel: 1 = no adaptive split (a 32-plane chunk whose source boxes do not
  *               fit the LDS arena is normally swept as two 16-plane halves with their own boxes instead of taking global taps).
- *               Lane-owns-voxel kernel: 7 = every block on its general path; ablations: 8 = no stores, 9 = no taps, 10 = neither
+ *               Lane-owns-voxel kernel: 2 = the same split (off by default there: slower on narrow baselines); 7 = every block on its general path; ablations: 8 = no stores, 9 = no taps, 10 = neither
  *   "warp_gc_lds" 1 (default): group-wise correlation volumes (C = 32, 16-bit, HOMOG geometry, maps of >= 21 x 21 texels) over PER-BATCH
  *               planes run the LDS-staged kernel (csrc/warp_gc_lv.hip; 1.8x the quad kernel on the stage-1 shape of BASELINE
  *               configuration 5; values equal to one 16-bit ulp); 2: per-pixel planes too (slower when the per-pixel depths of a tile

@@ -25,7 +25,8 @@ def main():
         dv = torch.linspace(float(cams["depth_min"][0, 0]), float(cams["depth_max"][0, 0]), D).view(1, D).to(dev)
         cm = ops.proj_cams([proj[:, i] for i in range(1, V)], proj[:, 0])
         out = torch.empty(1, D, h, w, 32, dtype=dt, device=dev)
-        cfgs = {"split": dict(warp_tiled=1, warp_tile=0), "no split": dict(warp_tiled=1, warp_tile=1), "direct gather": dict(warp_tiled=0, warp_tile=0)}
+        cfgs = {"split": dict(warp_tiled=1, warp_tile=0), "no split": dict(warp_tiled=1, warp_tile=1), "direct gather": dict(warp_tiled=0, warp_tile=0),
+                "lane owner, split": dict(warp_tiled=4, warp_tile=2), "lane owner, no split": dict(warp_tiled=4, warp_tile=0)}
         acc = {k: [] for k in cfgs}
         for r in range(rounds + 1):
             for name, kn in cfgs.items():

@@ -107,14 +107,25 @@ __global__ __launch_bounds__(LV_THREADS) __attribute__((amdgpu_waves_per_eu(LV_O
         }
     }
 
-    // ---- 1. wave k: texel box of source view k from the 8 corner projections (see warp_cost_tiled.hip for the argument) ----
+    // ---- 1. wave k: texel boxes of source view k from the 8 corner projections (see warp_cost_tiled.hip for the argument): the box of
+    //         the whole chunk (lanes 0-7), of its first half (lanes 8-15) and of its second half (lanes 16-23) -- round 5: a block in
+    //         which some view's whole-chunk box does not fit sweeps the two halves one after the other instead of its general path ----
+    const int nplanes = d1 - d0;
+    const int hsz = nplanes >= 4 ? ((nplanes / 2 + 1) & ~1) : nplanes;        // planes of the first half (even); no split below 4 planes
     if (wave < WL_MAX_SRC) {
         const int k = wave;
-        const float dmin = wl_wave_reduce<false>(dlane), dmax = wl_wave_reduce<true>(dlane);
+        const float inf = __builtin_inff();
+        const bool in1 = lane < hsz;
+        const float dmin1 = wl_wave_reduce<false>(in1 ? dlane : inf), dmax1 = wl_wave_reduce<true>(in1 ? dlane : -inf);
+        const float dmin2 = hsz < nplanes ? wl_wave_reduce<false>(in1 ? inf : dlane) : dmin1;
+        const float dmax2 = hsz < nplanes ? wl_wave_reduce<true>(in1 ? -inf : dlane) : dmax1;
+        const float dmin0 = fminf(dmin1, dmin2), dmax0 = fmaxf(dmax1, dmax2);
+        const int set = min(lane >> 3, 2);
         const int corner = lane & 7;
         const float cx = (corner & 1) ? (float)min(x0t + LV_T - 1, a.w - 1) : (float)x0t;
         const float cy = (float)(((corner & 2) ? min(y0t + LV_TH - 1, a.h - 1) : y0t) + a.ref_y0);
-        const float d = (corner & 4) ? dmax : dmin;
+        const float dlo = set == 0 ? dmin0 : set == 1 ? dmin1 : dmin2, dhi = set == 0 ? dmax0 : set == 1 ? dmax1 : dmax2;
+        const float d = (corner & 4) ? dhi : dlo;
         int cX0 = 0, cY0 = 0, cX1 = 1, cY1 = 1, pitch = 2, mode = WL_ZERO;      // mode: WL_FAST / WL_GEN here = "if the arena has room"
         if (k < n_src) {
             lv_cf cam = (lv_cf)(a.cams + ((long)k * a.B + b) * PSCV_CAM_FLOATS);
@@ -125,12 +136,12 @@ __global__ __launch_bounds__(LV_THREADS) __attribute__((amdgpu_waves_per_eu(LV_O
             const float inv_z = __builtin_amdgcn_rcpf(hz);
             const float u = hx * inv_z, v = hy * inv_z;
             const float okf = (hz > 1e-6f && fabsf(u) < 1e6f && fabsf(v) < 1e6f) ? 1.0f : 0.0f;   // also rejects NaN
-            const float umin = wl_reduce8<false>(u), umax = wl_reduce8<true>(u);
+            const float umin = wl_reduce8<false>(u), umax = wl_reduce8<true>(u);               // (per 8-lane group = per plane range)
             const float vmin = wl_reduce8<false>(v), vmax = wl_reduce8<true>(v);
-            const bool ok = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wl_reduce8<false>(okf))) != 0;
+            const bool ok = wl_reduce8<false>(okf) != 0.0f;
             const float sl = 1.0f / 32.0f;     // slack for the per-pixel evaluation's different rounding (maps <= 16384 texels)
-            const int X0 = __builtin_amdgcn_readfirstlane((int)floorf(umin - sl)), X1 = __builtin_amdgcn_readfirstlane((int)floorf(umax + sl)) + 1;
-            const int Y0 = __builtin_amdgcn_readfirstlane((int)floorf(vmin - sl)), Y1 = __builtin_amdgcn_readfirstlane((int)floorf(vmax + sl)) + 1;
+            const int X0 = (int)floorf(umin - sl), X1 = (int)floorf(umax + sl) + 1;
+            const int Y0 = (int)floorf(vmin - sl), Y1 = (int)floorf(vmax + sl) + 1;
             mode = WL_DIRECT;
             if (ok) {
                 const bool outside = X1 < 0 || Y1 < 0 || X0 > a.ws - 1 || Y0 > a.hs - 1;
@@ -144,13 +155,40 @@ __global__ __launch_bounds__(LV_THREADS) __attribute__((amdgpu_waves_per_eu(LV_O
                 else if (bw <= LV_BOX_W && bh <= LV_BOX_H) mode = inside ? WL_FAST : WL_GEN;
             }
         }
-        if (lane == 0) {
-            int4* row = reinterpret_cast<int4*>(table + k * 8);
+        if (corner == 0 && lane < 24) {
+            int4* row = reinterpret_cast<int4*>(table + (set * WL_MAX_SRC + k) * 8);
             row[0] = make_int4(cX0, cY0, cX1, cY1);
             row[1] = make_int4(0, pitch, mode, 0);
         }
     }
     __syncthreads();
+
+    // whole chunk first; with "warp_tile" = 2: if a view would not be staged there (its box is too large, or the arena is full), the two
+    // halves one after the other, each with its own boxes and staging.  Round 5, interleaved A/B: DTU-like rig 332 -> 187 us (the
+    // quad-owner kernel with the same split: 152 us), probe rig 114 -> 118 us (its 12 % of blocks with one unstaged view are cheaper
+    // on the general path than swept twice) -- so the split is OFF by default in this (optional) kernel.
+    int nsub = 1;
+    if (hsz < nplanes && a.variant == 2) {
+        int used = 0;
+        bool direct = false;
+#pragma unroll
+        for (int k = 0; k < WL_MAX_SRC; ++k) {
+            const int4 r0 = *reinterpret_cast<const int4*>(table + k * 8), r1 = *reinterpret_cast<const int4*>(table + k * 8 + 4);
+            int mode = k < n_src ? __builtin_amdgcn_readfirstlane(r1.z) : WL_ZERO;
+            const int need = __builtin_amdgcn_readfirstlane(r1.y) * (__builtin_amdgcn_readfirstlane(r0.w) - __builtin_amdgcn_readfirstlane(r0.y) + 1);
+            if ((mode == WL_FAST || mode == WL_GEN) && used + need > LV_ARENA) mode = WL_DIRECT;
+            if (mode == WL_FAST || mode == WL_GEN) used += need;
+            direct = direct || mode == WL_DIRECT;
+        }
+        if (direct) nsub = 2;
+    }
+    for (int sub = 0; sub < nsub; ++sub) {
+    const int tset = (nsub == 2 ? 1 + sub : 0) * WL_MAX_SRC * 8;          // this plane range's records in the table (ints)
+    const int s0 = d0 + (nsub == 2 && sub ? hsz : 0), s1 = nsub == 2 && !sub ? d0 + hsz : d1;
+    if (sub) {
+        __syncthreads();                                 // the first half's sweep is done with the arena
+        __builtin_amdgcn_s_setprio(3);
+    }
 
     // ---- 2. every wave: the box records -> scalar registers; arena allocation greedy in view order (a view whose box does not fit next
     //         to the earlier ones is not staged), the same in every wave; the staged views, in view order, fill slots 0 .. nv-1 ----
@@ -161,7 +199,7 @@ __global__ __launch_bounds__(LV_THREADS) __attribute__((amdgpu_waves_per_eu(LV_O
         int used = 0;
 #pragma unroll
         for (int k = 0; k < WL_MAX_SRC; ++k) {
-            const int4 r0 = *reinterpret_cast<const int4*>(table + k * 8), r1 = *reinterpret_cast<const int4*>(table + k * 8 + 4);
+            const int4 r0 = *reinterpret_cast<const int4*>(table + tset + k * 8), r1 = *reinterpret_cast<const int4*>(table + tset + k * 8 + 4);
             const int X0 = __builtin_amdgcn_readfirstlane(r0.x), Y0 = __builtin_amdgcn_readfirstlane(r0.y);
             const int Y1 = __builtin_amdgcn_readfirstlane(r0.w);
             bP[k] = __builtin_amdgcn_readfirstlane(r1.y);
@@ -187,7 +225,7 @@ __global__ __launch_bounds__(LV_THREADS) __attribute__((amdgpu_waves_per_eu(LV_O
     // ---- 3. stage the boxes, 16-bit -> fp32, channel-chunk planar: wave k stages view k ----
     {
         const int k = wave;
-        const int4 f0 = *reinterpret_cast<const int4*>(table + k * 8);
+        const int4 f0 = *reinterpret_cast<const int4*>(table + tset + k * 8);
         const int sX0 = __builtin_amdgcn_readfirstlane(f0.x), sY0 = __builtin_amdgcn_readfirstlane(f0.y);
         const int sX1 = __builtin_amdgcn_readfirstlane(f0.z), sY1 = __builtin_amdgcn_readfirstlane(f0.w);
         int sP16 = bP[0] << 4, sMode = bMode[0], sBase = bBase[0];
@@ -308,16 +346,16 @@ __global__ __launch_bounds__(LV_THREADS) __attribute__((amdgpu_waves_per_eu(LV_O
     };
 
     // ---- 4. sweep: a trip = the wave's 32 pixels on two adjacent planes ----
-    const int nd = d1 - d0;
+    const int nd = s1 - s0, sl0 = s0 - d0;
     for (int t = wave; 2 * t < nd; t += LV_THREADS / 64) {
-        const float dv0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dlane), 2 * t));
-        const float dv1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dlane), min(2 * t + 1, nd - 1)));
+        const float dv0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dlane), sl0 + 2 * t));
+        const float dv1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dlane), sl0 + min(2 * t + 1, nd - 1)));
         const float dval = pp ? dv1 : dv0;
         // (keeps r * r of the loop-invariant reference feature out of 32 more registers)
 #pragma unroll
         for (int i = 0; i < C; ++i) asm volatile("" : "+v"(rf[i]));
         const bool active = active_px && 2 * t + pp < nd && a.variant != 8 && a.variant != 10;     // ("warp_tile" = 8: no stores, an ablation)
-        const int d = d0 + min(2 * t + pp, nd - 1);
+        const int d = s0 + min(2 * t + pp, nd - 1);
         char* const vox = out + ((unsigned long)b * a.D + d) * plane_bytes + lane_out;
 
         if (!any_direct) {
@@ -338,7 +376,7 @@ __global__ __launch_bounds__(LV_THREADS) __attribute__((amdgpu_waves_per_eu(LV_O
                     w[jj][0] = gx * gy; w[jj][1] = fx * gy; w[jj][2] = gx * fy; w[jj][3] = fx * fy;
                     int x0 = (int)x0f, y0 = (int)y0f;
                     if (sGen[jj]) {      // top-left tap into the box (with its zero padding); the sample may lie anywhere
-                        const int4 r0 = *reinterpret_cast<const int4*>(table + sView[jj] * 8);
+                        const int4 r0 = *reinterpret_cast<const int4*>(table + tset + sView[jj] * 8);
                         x0 = med3_i32(x0, r0.x, r0.z - 1); y0 = med3_i32(y0, r0.y, r0.w - 1);
                     }
                     aT[jj] = (unsigned)((__mul24(y0, sP[jj]) + x0) * 16 + sE0[jj]);
@@ -385,7 +423,7 @@ __global__ __launch_bounds__(LV_THREADS) __attribute__((amdgpu_waves_per_eu(LV_O
             else if (nv == 1) chunks(std::integral_constant<int, 1>{});
             else chunks(std::integral_constant<int, 0>{});
             {
-                char* const plane0 = out + ((unsigned long)b * a.D + d0 + 2 * t) * plane_bytes;
+                char* const plane0 = out + ((unsigned long)b * a.D + s0 + 2 * t) * plane_bytes;
                 store_trip(plane0, plane0 + plane_bytes, 2 * t + 1 < nd);
             }
         } else {
@@ -420,7 +458,7 @@ __global__ __launch_bounds__(LV_THREADS) __attribute__((amdgpu_waves_per_eu(LV_O
                         const float fx = ix - x0f, fy = iy - y0f;
                         const float gx = 1.0f - fx, gy = 1.0f - fy;
                         ww[0] = gx * gy; ww[1] = fx * gy; ww[2] = gx * fy; ww[3] = fx * fy;
-                        const int4 r0 = *reinterpret_cast<const int4*>(table + k * 8);
+                        const int4 r0 = *reinterpret_cast<const int4*>(table + tset + k * 8);
                         const int x0 = med3_i32((int)x0f, r0.x, r0.z - 1), y0 = med3_i32((int)y0f, r0.y, r0.w - 1);   // (no-op for boxes inside the image)
                         const unsigned at = (unsigned)((__mul24(y0, P) + x0) * 16 + E0 + c * LV_PLANE);
                         const unsigned ab = at + (unsigned)(P << 4);
@@ -465,6 +503,7 @@ __global__ __launch_bounds__(LV_THREADS) __attribute__((amdgpu_waves_per_eu(LV_O
             }
         }
     }
+    }   // plane sub-range
 }
 
 template <typename TIn, typename TOut, int COST>

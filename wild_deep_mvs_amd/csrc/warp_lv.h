@@ -14,7 +14,7 @@ constexpr int LV_THREADS = 256;              // 4 waves; a wave trip = 32 pixels
 constexpr int LV_ARENA = LV_OCC == 3 ? 416 : 316;   // staged texels per block (all views), fp32
 constexpr int LV_PLANE = LV_ARENA * 16;      // bytes of one channel-chunk plane
 constexpr int LV_TABLE = 8 * LV_PLANE;       // per-view box records written by wave 0
-constexpr int LV_LDS = LV_TABLE + WL_MAX_SRC * 32 + 32;
+constexpr int LV_LDS = LV_TABLE + 3 * WL_MAX_SRC * 32 + 32;   // box records: [3 plane ranges (whole chunk, first half, second half)][4 views] x 32 B
 constexpr int LV_BOX_W = 32, LV_BOX_H = 16;  // largest box the staging phase covers (one wave per view, batches of 8 rows x 16 texels)
 static_assert(LV_OCC * LV_LDS <= 160 * 1024, "LV_OCC blocks per CU");
 static_assert(7 * LV_PLANE + 16 < 65536, "chunk planes within the immediate offset of ds_read");
