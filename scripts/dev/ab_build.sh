@@ -8,7 +8,8 @@ cd "$(dirname "$0")/../../wild_deep_mvs_amd/csrc"
 name=$1; files=$2; shift; shift
 OBJS=$(grep "^OBJS" Makefile | sed "s/OBJS *:= *//")
 for f in $files; do
-    o=/tmp/ab_${name}_${f%.hip}.o
+    mkdir -p ../../gpurun_out/ab
+    o=../../gpurun_out/ab/ab_${name}_${f%.hip}.o
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -w "$@" -c $f -o $o
     OBJS=$(echo "$OBJS" | sed "s#\b${f%.hip}.o#$o#")
 done

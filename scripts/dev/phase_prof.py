@@ -29,7 +29,7 @@ LAYERS = {
     "conv9": (32, 16, 2, 4, True, True, "conv"), "conv11": (16, 8, 2, 2, True, True, "t2p8"),
     "prob": (8, 1, 0, 1, False, False, "c1"),
     "conv0": (32, 8, 0, 1, False, False, "sweep"),     # slots: prologue | fetch issue | MFMA loop | epilogue | stash (waits for the planes) | barrier
-    "cvp64": (64, 64, 0, (4, 512, 640), False, False, "conv"),   # CVP refinement 64 -> 64 at 4 x 512 x 640 (4x4x16 tiles, all 4 N-tiles)
+    "cvp64": (64, 64, 0, (4, 512, 640), False, False, "wide"),   # CVP refinement 64 -> 64 at 4 x 512 x 640 (4x4x16 tiles, all 4 N-tiles)
 }
 NAMES = ["loads issued", "loads landed", "LDS write+sync", "MFMA loop", "epilogue", "drain"]
 lib = L.lib()

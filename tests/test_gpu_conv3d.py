@@ -771,22 +771,17 @@ def test_wide_kernel_equals_the_brick_kernel_and_aten(env, cin, cout, shape, tra
     res = {}
     L.set_tuning("conv_small_tiles", 0)       # the brick kernel's row-split variant (the k-split small tiles sum in another order)
     try:
-        for wide in (0, 2, 3):                # brick | the wide kernel at any size | 64 inputs: its variant with the reduction split over the wave halves
+        for wide in (0, 2):                   # brick | the wide kernel at any size
             L.set_tuning("conv_wide", wide)
             res[wide] = (ops.conv3d(x, layer, skip=sk), ops.conv3d(x, layer, out_dtype=torch.float32), ops.conv3d(x, layer))
     finally:
         L.set_tuning("conv_wide", 1)
         L.set_tuning("conv_small_tiles", 1)
-    for a_, b_ in zip(res[0], res[2]):
-        assert torch.isfinite(b_.float()).all()
-        ne = int((a_ != b_).sum())
-        assert ne == 0, f"{ne} of {a_.numel()} values differ (max {float((a_.float() - b_.float()).abs().max()):.3e})"
-    # "conv_wide" = 3, 64 inputs: (even k-steps) + (odd k-steps) -- fp32 rounding apart; 32 inputs: the same kernel as 2
-    for a_, b_ in zip(res[0], res[3]):
-        assert torch.isfinite(b_.float()).all()
-        if cin == 32:
-            assert torch.equal(a_, b_)
-    check_close(f"wide2 vs brick {cin}->{cout} fp32 out", res[3][1].cpu(), res[0][1].cpu(), max_abs=2e-5, rel_l2=2e-6)
+    for arm in (2,):
+        for a_, b_ in zip(res[0], res[arm]):
+            assert torch.isfinite(b_.float()).all()
+            ne = int((a_ != b_).sum())
+            assert ne == 0, f"conv_wide={arm}: {ne} of {a_.numel()} values differ (max {float((a_.float() - b_.float()).abs().max()):.3e})"
     scale = bn[0] / torch.sqrt(bn[3] + 1e-5)
     xc = x.float().cpu().permute(0, 4, 1, 2, 3)
     conv = F.conv_transpose3d(xc, w, stride=1, padding=1) if transposed else F.conv3d(xc, w, padding=1)
