@@ -47,7 +47,7 @@ struct Tp8Args {
 };
 
 constexpr int TP_TD = 2, TP_TH = 4, TP_BD = TP_TD + 1, TP_BH = TP_TH + 1, TP_BW = 17;
-constexpr int TP_VS = 48;   // 16 ch x 2 B + 16 B pad
+constexpr int TP_VS = 32;   // 16 ch x 2 B, no pad: conflict-free for the lane groups of ds_read_b128 (conv3d.hip, conv_vs; 48 was 2-way)
 PSCV_PROF_BUFFER(t2p8)
 
 template <typename H>

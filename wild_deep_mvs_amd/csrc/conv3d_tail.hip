@@ -72,7 +72,8 @@ constexpr int TL_TH = 8, TL_TW = 28;                 // output pixels per tile
 constexpr int TL_BR = TL_TH + 2, TL_BC = 32;         // u11 brick: rows 8 s - 1 .. 8 s + 8, columns 28 t - 2 .. 28 t + 29
 constexpr int TL_PB = TL_BR * TL_BC * 16;            // bytes per u11 ring plane
 constexpr int TL_NSLOT = 8;
-constexpr int TL_IR = 7, TL_IC = 17, TL_VS = 48;     // staged input rows 4 s - 1 .. 4 s + 5, columns 14 t - 1 .. 14 t + 15; 32 B + 16 B pad
+constexpr int TL_IR = 7, TL_IC = 17, TL_VS = 32;     // staged input rows 4 s - 1 .. 4 s + 5, columns 14 t - 1 .. 14 t + 15; 32 B, NO pad: voxels one
+                                                     // stride apart + chunk g & 1 are conflict-free at 2 mod 4 granules (conv3d.hip, conv_vs; 48 was 2-way)
 constexpr int TL_IPB = TL_IR * TL_IC * TL_VS;        // bytes per input ring plane
 constexpr int TL_ISLOT = 5;
 constexpr int TL_ICH = TL_IR * TL_IC * 2;            // 16-byte chunks per input plane (238)
