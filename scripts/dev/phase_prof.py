@@ -29,7 +29,8 @@ LAYERS = {
     "conv9": (32, 16, 2, 4, True, True, "conv"), "conv11": (16, 8, 2, 2, True, True, "t2p8"),
     "prob": (8, 1, 0, 1, False, False, "c1"),
     "conv0": (32, 8, 0, 1, False, False, "sweep"),     # slots: prologue | fetch issue | MFMA loop | epilogue | stash (waits for the planes) | barrier
-    "cvp64": (64, 64, 0, (4, 512, 640), False, False, "wide"),   # CVP refinement 64 -> 64 at 4 x 512 x 640 (4x4x16 tiles, all 4 N-tiles)
+    "cvp64": (64, 64, 0, (4, 512, 640), False, False, "wide"),
+    "cvp16": (16, 16, 0, (8, 1024, 1280), False, False, "conv"),   # CVP conv0a at the finest level (brick kernel, 4x4x16 tiles)   # CVP refinement 64 -> 64 at 4 x 512 x 640 (4x4x16 tiles, all 4 N-tiles)
 }
 NAMES = ["loads issued", "loads landed", "LDS write+sync", "MFMA loop", "epilogue", "drain"]
 lib = L.lib()
@@ -82,6 +83,7 @@ for name in sys.argv[1:] or list(LAYERS):
     print(f"   resident workgroups per CU (sum lifetimes / span / CUs): {(t1 - t0).sum() / span / ncu:.2f};  workgroup start times "
           f"p10 {np.percentile(t0, 10):.0f}  p50 {np.percentile(t0, 50):.0f}  p90 {np.percentile(t0, 90):.0f}  max {t0.max()};  end p50 "
           f"{np.percentile(t1, 50):.0f} max {t1.max()}")
+    print('   wave slot (HW_ID & 15) histogram:', np.bincount(r[:, 8] & 0xf, minlength=16).tolist())
     for k in np.unique(key)[:2]:
         m = key == k
         o = np.argsort(t0[m])
