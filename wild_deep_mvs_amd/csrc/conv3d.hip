@@ -474,6 +474,16 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
         for (int i = 0; i < MB; ++i)
 #pragma unroll
             for (int m = 0; m < NT; ++m) acc[i][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // skip values of the wave's rows, requested before the contraction (inside the epilogue every row waited for its own 8 bytes)
+        uint2 skp[MB][NT];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            const int mt = wave * MB + i;
+            const int od = t0d + mt / TH, oh = t0h + mt % TH;
+            const bool row_ok = od < a.Do && oh < a.Ho;         // wave-uniform
+#pragma unroll
+            for (int m = 0; m < NT; ++m) skp[i][m] = row_ok ? skip_fetch(skip_row(od, oh), 0, m) : make_uint2(0u, 0u);
+        }
 
 #pragma unroll
         for (int s = 0; s < NSTEPS; ++s) {
@@ -498,7 +508,7 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
             const int mt = wave * MB + i;
-            epilogue(acc[i], t0d + mt / TH, t0h + mt % TH, 0);
+            epilogue(acc[i], t0d + mt / TH, t0h + mt % TH, 0, skp[i]);
         }
         PSCV_STAMP(4)
     } else {
@@ -511,6 +521,18 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
             for (int i = 0; i < MB; ++i)
 #pragma unroll
                 for (int m = 0; m < NT; ++m) acc[i][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // the class's skip values are requested before its contraction (loaded inside the epilogue, every row waited for its own
+            // 8 bytes: 8 classes x MB dependent round trips per wave)
+            const int pd = (pc >> 2) & 1, ph = (pc >> 1) & 1, pw = pc & 1;
+            uint2 skp[MB][NT];
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                const int mt = wave * MB + i;
+                const int id = t0d + mt / TH, ih = t0h + mt % TH;
+                const bool in_ok = id < a.Di && ih < a.Hi;      // wave-uniform
+#pragma unroll
+                for (int m = 0; m < NT; ++m) skp[i][m] = in_ok ? skip_fetch(skip_row(2 * id + pd, 2 * ih + ph), pw, m) : make_uint2(0u, 0u);
+            }
 #pragma unroll
             for (int s = 0; s < 16; ++s) {   // 16 = max k-steps of a class (8 taps x C_in 64)
                 if (s < nsteps) {
@@ -528,13 +550,12 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvArgs a) {
                     }
                 }
             }
-            const int pd = (pc >> 2) & 1, ph = (pc >> 1) & 1, pw = pc & 1;
             PSCV_STAMP(3)
 #pragma unroll
             for (int i = 0; i < MB; ++i) {
                 const int mt = wave * MB + i;
                 const int id = t0d + mt / TH, ih = t0h + mt % TH;
-                if (id < a.Di && ih < a.Hi) epilogue(acc[i], 2 * id + pd, 2 * ih + ph, pw);
+                if (id < a.Di && ih < a.Hi) epilogue(acc[i], 2 * id + pd, 2 * ih + ph, pw, skp[i]);
             }
             PSCV_STAMP(4)
         }
