@@ -17,6 +17,7 @@
 // Replaces (fdarmon/wild_deep_mvs): CostRegNet.conv0 = ConvBnReLU3D(32, 8) models/MVSNet/model.py:46,75
 // (block definition models/MVSNet/module.py:41-48).
 #include "pscv_common.h"
+#include <type_traits>
 
 namespace pscv {
 
@@ -178,8 +179,11 @@ __global__ __launch_bounds__(32 * SW_TH, 2) void conv3d_sweep8_kernel(const Swee
     __syncthreads();
     PSCV_STAMP(0)
 
-    int ring = 0;   // slot holding plane d-1
-    for (int d = dbeg; d < dend; d += 2) {
+    // One plane pair; RING = the slot holding plane d - 1, a compile-time constant: the sweep below is unrolled over the ring's period
+    // (6 slots, 2 per pair), so every slot base is an immediate offset of its ds_read / ds_write (as a run-time ring index each of the
+    // 48 reads of a pair had its own v_add in front).
+    auto pair = [&](auto ringc, const int d) {
+        constexpr int RING = decltype(ringc)::value;
         // issue the next two planes (d+3, d+4) early; they land in LDS after this iteration's MFMAs
         uint4 na[NLD], nb[NLD];
         fetch(d + 3, na);
@@ -192,9 +196,8 @@ __global__ __launch_bounds__(32 * SW_TH, 2) void conv3d_sweep8_kernel(const Swee
         for (int r = 0; r < R; ++r) acc[r] = sw_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            int sl = ring + p;
-            sl = sl >= SW_NSLOT ? sl - SW_NSLOT : sl;
-            const unsigned char* sp = smem + sl * SW_PB;
+            constexpr int SL = (RING + 4 * SW_NSLOT) % SW_NSLOT;
+            const unsigned char* sp = smem + ((SL + p) % SW_NSLOT) * SW_PB;
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
@@ -241,16 +244,16 @@ __global__ __launch_bounds__(32 * SW_TH, 2) void conv3d_sweep8_kernel(const Swee
 
         PSCV_STAMP(3)
         // planes d+3, d+4 replace d-3, d-2 (last read one iteration ago, fenced by that iteration's barrier)
-        int s4 = ring + 4, s5 = ring + 5;
-        s4 = s4 >= SW_NSLOT ? s4 - SW_NSLOT : s4;
-        s5 = s5 >= SW_NSLOT ? s5 - SW_NSLOT : s5;
-        stash(s4, na);
-        stash(s5, nb);
+        stash((RING + 4) % SW_NSLOT, na);
+        stash((RING + 5) % SW_NSLOT, nb);
         PSCV_STAMP(4)
-        ring += 2;
-        ring = ring >= SW_NSLOT ? ring - SW_NSLOT : ring;
         __syncthreads();
         PSCV_STAMP(5)
+    };
+    for (int d = dbeg; d < dend; d += 6) {
+        pair(std::integral_constant<int, 0>{}, d);
+        if (d + 2 < dend) pair(std::integral_constant<int, 2>{}, d + 2);
+        if (d + 4 < dend) pair(std::integral_constant<int, 4>{}, d + 4);
     }
     PSCV_PROF_END(sweep, blockIdx.x)
 }
