@@ -596,7 +596,7 @@ def run(args):
             torch.cuda.synchronize()
             graph = None
             # the step is captured once and replayed; with --batch-mode streams the per-view fork / join is part of the graph (parallel
-            # branches: correct on changing inputs since round 4, tests/test_gpu_mvsnet.py, scripts/dev/streams_graph_probe.py)
+            # branches: correct on changing inputs since round 4, tests/test_gpu_mvsnet.py)
             if not args.eager:
                 # the 13-launch step is launch-gap bound between its small kernels: capture it once, replay it
                 try:

@@ -438,7 +438,7 @@ class MVSNet(ReplayHooks, nn.Module):
         `bench.py`), outputs bit-equal to the one-item runs (tests/test_gpu_mvsnet.py).  Under a hipGraph capture the items become
         parallel branches of the graph (``batch_streams_capture``): round 3 saw such graphs replay WRONGLY once inputs changed and blamed
         ROCm 7.2; the cause was the overlap defect of the packed warp build.  With the scalar build 12 of 12
-        replays on changing inputs equal the one-item runs bit for bit (`scripts/dev/streams_graph_probe.py`, tests/test_gpu_mvsnet.py)
+        replays on changing inputs equal the one-item runs bit for bit (tests/test_gpu_mvsnet.py)
         and the forked graph is the fastest form of the three-view step (0.973 ms against 1.007 batched, 1.075 eager streams).
         At most MAX_BATCH_STREAMS items; `net.batch_streams = False` turns it off."""
         B = features_cl[0].shape[0]
