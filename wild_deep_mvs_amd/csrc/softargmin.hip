@@ -33,7 +33,7 @@ template <> __device__ __forceinline__ float ldlogit<f16_t>(const f16_t* p) { re
 
 // 256 threads = PX pixels x NS depth slices: each thread reduces D/NS planes, the slices merge through LDS with
 // the log-sum-exp rule (the same rule the multi-GPU depth-plane shard uses across ranks).
-constexpr int SA_PX = 32, SA_NS = 8, SA_PMAX = 32;     // (16 x 16 and 64 x 4 tilings were measured in round 5: within 2 % of this one)
+constexpr int SA_PX = 32, SA_NS = 8, SA_PMAX = 32;     // (other pixel x slice tilings were measured in round 5: none faster)
 
 template <typename T>
 __global__ __launch_bounds__(256) void softargmin_kernel(const SoftArgs a) {
