@@ -669,7 +669,10 @@ def run(args):
                 graph.replay()
                 torch.cuda.synchronize()
                 d_graph = depth.clone()
-                d_eager = torch.cat([item(b)[0] for b in range(NB)], 0)
+                # (stream mode launches B = 1 grids: compared with one-item launches on one stream, i.e. without any overlap; the
+                #  batched mode picks other kernel variants at larger batches -- row-split instead of reduction-split tiles, another
+                #  summation order -- so its replay is compared with the same batched launches run eagerly)
+                d_eager = torch.cat([item(b)[0] for b in range(NB)], 0) if (streams_mode or NB == 1) else step()[0].clone()
                 torch.cuda.synchronize()
                 graph_ok = bool(torch.equal(d_graph, d_eager))
                 for f, sv in zip(feats_cl_, saved):
