@@ -114,6 +114,12 @@ int pscv_abi_version(void);
  *               fp32 summation order).  "s2s_slots": resident-workgroup target that sizes its depth chunks (0 = 768)
  *   "conv2d_wlds"  1 (default): 64-channel k3 s1 2-D layers with 32 | 64 output channels and >= 512 tiles run the persistent
  *               kernel that keeps the layer's packed weights in LDS; 0: always conv2d_kernel; 2: at any size (same bits)
+ *   "conv_wide"  1 (default): stride-1 3-D layers with 64 input and 32 | 64 output channels on volumes of >= 512 tiles (4 x 4 x 16
+ *               voxels) run the persistent 8-wave kernel with the weights through a shared LDS double buffer (csrc/conv3d_wide.hip;
+ *               same bits as the brick kernel); 0: always the brick kernel; 2: at any size, and the 32-input layers too
+ *   "conv_tall64"  1 (default): on the brick kernel, 64-input stride-1 layers take 4 x 8 x 16 tiles where the grid fills the chip;
+ *               0: 4 x 4 x 16; 2: at any size
+ *   "tail_nbk"  6-plane blocks per depth chunk of pscv_tail_sweep (0 = default: one resident round of workgroups)
  *   "conv_small_tiles"  1 (default): small volumes use 1x4x16 tiles with the output channels split over
  *               blockIdx.y; 0: always the large-tile variant */
 int pscv_set_tuning(const char* key, int value);
