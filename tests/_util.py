@@ -64,7 +64,7 @@ def check_close(name, got, ref, *, max_abs=None, rel_l2=None, rel_l1=None):
 
 def retry_infra(fn):
     """Two ranks sharing one GPU box: a rendezvous / spawn hiccup (a result queue that stays empty, a rank process that dies before it
-    reports) is retried ONCE after a pause -- the driver runs this suite with -x on a shared box, where one such hiccup was seen in ~10
+    reports) is retried (twice at most) after a pause -- the driver runs this suite with -x on a shared box, where one such hiccup was seen in ~10
     full runs.  Numerical assertions are never retried."""
     import functools
     import queue as _queue
@@ -72,15 +72,16 @@ def retry_infra(fn):
 
     @functools.wraps(fn)
     def wrapper(*a, **k):
-        try:
-            return fn(*a, **k)
-        except _queue.Empty as e:
-            reason = f"empty result queue ({e!r})"
-        except AssertionError as e:
-            if "exited with code" not in str(e):
-                raise
-            reason = str(e)
-        print(f"[dist test] infrastructure failure, retrying once: {reason}", flush=True)
-        _time.sleep(5)
+        for pause in (5, 20):                                   # up to two retries
+            try:
+                return fn(*a, **k)
+            except _queue.Empty as e:
+                reason = f"empty result queue ({e!r})"
+            except AssertionError as e:
+                if "exited with code" not in str(e):
+                    raise
+                reason = str(e)
+            print(f"[dist test] infrastructure failure, retrying after {pause} s: {reason}", flush=True)
+            _time.sleep(pause)
         return fn(*a, **k)
     return wrapper
