@@ -17,15 +17,21 @@ def short(name):
 
 
 def kernel_stats(path):
+    """All launches of the run, and the LAST THIRD of every kernel's launches: bench.py's per-kernel figures (`kernels_us`,
+    `roofline.avg_us`) are HIP events around the launches of its final eager pass -- the first launches of a process run at ramping
+    clocks and cold caches and pull the all-launch average up by 5-8 %."""
     con = sqlite3.connect(path)
-    rows = con.execute("select name, count(*), avg(end-start), min(end-start), max(end-start), sum(end-start) "
-                       "from kernels group by name order by 6 desc").fetchall()
-    tot = sum(r[5] for r in rows) or 1
-    print(f"{'kernel':80s} {'calls':>6s} {'avg_us':>9s} {'min_us':>9s} {'max_us':>9s} {'share':>6s}")
-    for r in rows:
-        if "pscv" not in r[0] and r[5] / tot < 0.01:
+    per = {}
+    for name, start, end in con.execute("select name, start, end from kernels order by start"):
+        per.setdefault(name, []).append(end - start)
+    tot = sum(sum(v) for v in per.values()) or 1
+    print(f"{'kernel':80s} {'calls':>6s} {'avg_us':>9s} {'min_us':>9s} {'max_us':>9s} {'share':>6s} {'last-third avg_us':>18s}")
+    for name, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+        if "pscv" not in name and sum(v) / tot < 0.01:
             continue
-        print(f"{short(r[0]):80s} {r[1]:6d} {r[2] / 1e3:9.1f} {r[3] / 1e3:9.1f} {r[4] / 1e3:9.1f} {100 * r[5] / tot:5.1f}%")
+        tail = v[len(v) - max(1, len(v) // 3):]
+        print(f"{short(name):80s} {len(v):6d} {sum(v) / len(v) / 1e3:9.1f} {min(v) / 1e3:9.1f} {max(v) / 1e3:9.1f} {100 * sum(v) / tot:5.1f}% "
+              f"{sum(tail) / len(tail) / 1e3:18.1f}")
 
 
 def pmc(path):
