@@ -164,6 +164,36 @@ def rig_step(net, device, dtype, rig: str, nb: int, steps: int = 30):
         return (time.perf_counter() - t0) / steps * 1e3
 
 
+def staging_modes(device, dtype, rig: str):
+    """Staging-mode histogram of ONE LDS-staged warp launch at the headline size on camera rig `rig`: (shares over all (workgroup,
+    plane range, source view) triples, per-view counts).  Modes: see ``geometry_probe``."""
+    import ctypes
+    from wild_deep_mvs_amd import _lib
+    cams = synthetic.make_cameras(1, V, IMG_H, IMG_W, rig=rig)
+    Ks = cams["K"].clone()
+    Ks[:, :, :2] /= 4
+    proj = build_proj_matrices(Ks, cams["R"], cams["t"]).to(device)
+    steps = torch.arange(D, dtype=torch.float32).view(1, -1)
+    dv = (cams["depth_min"][:, :1] + (cams["depth_max"][:, :1] - cams["depth_min"][:, :1]) / (D - 1) * steps).to(device).contiguous()
+    feats = synthetic.make_features(1, V, C, h, w, seed=7)
+    fcl = [ops.to_channels_last(feats[i].to(device), dtype) for i in range(V)]
+    cam_blocks = ops.proj_cams_device(proj.float().contiguous(), 0)
+    hist = torch.zeros(16, dtype=torch.int32, device=device)
+    fn = _lib.lib().pscv_debug_wl_mode_hist
+    fn.argtypes, fn.restype = [ctypes.c_void_p], None
+    fn(hist.data_ptr())
+    try:
+        ops.warp_cost(fcl[0], fcl[1:], cam_blocks, dv, cost=_lib.COST_VARIANCE, out_dtype=dtype)
+        torch.cuda.synchronize()
+    finally:
+        fn(None)
+    hm = hist.view(4, 4).cpu().tolist()
+    total = max(1, sum(hm[0]))
+    names = ("DIRECT", "GEN", "FAST", "ZERO")
+    return ({names[m]: round(sum(hm[v][m] for v in range(V - 1)) / (total * (V - 1)), 4) for m in range(4)},
+            [dict(zip(names, hm[v])) for v in range(V - 1)])
+
+
 def geometry_probe(net, device, dtype, reps: int = 20, nb: int = 1):
     """The headline workload on BOTH camera rigs of `synthetic.make_cameras`: "probe" (what the bench line is
     measured on: depth 2..6, sources rotated about y and shifted along x, 0.03-0.1 feature texels per plane) and "dtu" (depth
@@ -435,8 +465,11 @@ def parse_args(argv=None):
     ap.add_argument("--sharded-budget", type=float, default=300.0, help="N > 1: seconds the sharded legs may take before the headline line is "
                     "printed without them (a stuck collective cannot be cancelled)")
     ap.add_argument("--no-sharded", action="store_true", help="N > 1: skip the depth-plane / source-view sharded legs (configurations 3 and 5)")
-    ap.add_argument("--dtype", choices=sorted(DTYPES), default="f16",
-                    help="16-bit HBM storage format (arithmetic is fp32); f16 is the engine default, see DESIGN.md section 5")
+    ap.add_argument("--dtype", choices=sorted(DTYPES), default="bf16",
+                    help="16-bit HBM storage format of the headline line (arithmetic is fp32): bf16 = the format BASELINE.json configuration 2 "
+                         "names; the other format is measured too and reported under \"alt\"")
+    ap.add_argument("--repeats", type=int, default=5, help="the timed region (exactly --steps steps between barrier + synchronize) is run this "
+                    "many times; the line's value / ms_per_step is the MEDIAN region, min / median / max are in \"repeats\"")
     ap.add_argument("--dump-events", default=None, help="write every per-launch event duration to this file")
     ap.add_argument("--eager", action="store_true", help="time eager launches instead of hipGraph replays")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="pscv_set_tuning knob (measurement runs)")
@@ -620,17 +653,22 @@ def run(args):
             gc.disable()
             for _ in range(max(args.warmup, 1) * 8):
                 run()
-            if dist is not None:
-                dist.barrier()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                run()
-            torch.cuda.synchronize()
-            if dist is not None:
-                dist.barrier()
-            torch.cuda.synchronize()
-            elapsed = time.perf_counter() - t0
+            # the timed region -- exactly `steps` steps between barrier + synchronize on both sides -- `args.repeats` times back to back
+            # (box-to-box and run-to-run spread is +-4 %: one region of 20 steps = 19 ms cannot show a 3 % change); every rank times
+            # every region, the MAX over ranks is taken per region, the line reports the median region
+            regions = []
+            for _ in range(max(1, args.repeats)):
+                if dist is not None:
+                    dist.barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    run()
+                torch.cuda.synchronize()
+                if dist is not None:
+                    dist.barrier()
+                torch.cuda.synchronize()
+                regions.append(time.perf_counter() - t0)
             # per-kernel durations: the same launches (every batch item is launched on its own: B = 1 grids), but one item after
             # the other on ONE stream, so that a kernel's HIP events time it alone rather than beside another item's kernels
             item = lambda b: net.hot_path([f[b:b + 1] for f in feats_cl_], proj_d[b:b + 1], dv_d[b:b + 1])
@@ -681,12 +719,14 @@ def run(args):
                 torch.cuda.synchronize()
         assert torch.isfinite(depth).all()
         assert graph_ok is not False, "the replayed hipGraph of the step differs from eager launches on fresh inputs"
-        t_max = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t_max = torch.tensor(regions, device=device, dtype=torch.float64)
         if dist is not None:
             dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-        return float(t_max.item()), tm, depth.clone(), graph is not None, elapsed_eager, one_view, graph_ok
+        regions = [float(x) for x in t_max.tolist()]
+        elapsed = sorted(regions)[(len(regions) - 1) // 2]           # the median region (lower median for an even count)
+        return elapsed, tm, depth.clone(), graph is not None, elapsed_eager, one_view, graph_ok, regions
 
-    elapsed, tm, depth, graphed, elapsed_eager, one_view, graph_ok = timed_region(args.dtype, feats_cl, args.steps)
+    elapsed, tm, depth, graphed, elapsed_eager, one_view, graph_ok, regions = timed_region(args.dtype, feats_cl, args.steps)
     kern = {k: v for k, v in tm.summary().items() if k != "proj_cams"}
     if args.dump_events and rank == 0:
         with open(args.dump_events, "w") as f:
@@ -695,7 +735,7 @@ def run(args):
     # the other 16-bit storage format on the same workload (BASELINE.json names bf16; same bytes, same MFMA rate)
     alt_name = "bf16" if args.dtype == "f16" else "f16"
     feats_alt = [ops.to_channels_last(feats[i].to(device), DTYPES[alt_name]) for i in range(V)]
-    alt_elapsed, alt_tm, alt_depth, _, _, alt_one_view, _ = timed_region(alt_name, feats_alt, args.steps)
+    alt_elapsed, alt_tm, alt_depth, _, _, alt_one_view, _, alt_regions = timed_region(alt_name, feats_alt, args.steps)
     net.storage_dtype = DTYPES[args.dtype]
     graph = graphed
 
@@ -732,17 +772,31 @@ def run(args):
             roof_mfma = {"kernel": c0[0], "bound": "mfma", "achieved": fl / t0s / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": fl / t0s / 1e12 / MFMA_PEAK_TFLOPS, "avg_us": t0s * 1e6, "flops": fl,
                          "hbm_frac": algorithmic_bytes(c0[0]) / t0s / 1e9 / HBM_PEAK_GBS}
+        # how much of the sweep the rig gives away: share of the (workgroup, source view) pairs whose source box lies outside the
+        # source image (the view contributes 0 there and the LDS-staged kernel skips it); the DTU-like rig of `alt_geometry` has 0.03
+        zero_note = ""
+        try:
+            zs = staging_modes(device, DTYPES[args.dtype], "probe")[0]
+            zero_note = (f" ({zs['ZERO']:.2f} of its (tile, plane chunk, source view) pairs project outside the source image and are skipped; "
+                         "the DTU-like rig -- alt_geometry.dtu / value_dtu_rig -- has 0.03)")
+        except Exception as e:   # pragma: no cover
+            zero_note = f" (staging-mode histogram unavailable: {type(e).__name__})"
         line = {
             "metric": "cost-volume voxels/sec (BxDxHxW), MVSNet hot path", "value": world * NB * VOX * args.steps / elapsed,
             "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "dtype_note": "16-bit HBM storage and MFMA operands, fp32 accumulation.  BASELINE.json names bf16: same bytes and MFMA "
-                          "rate; its driver-timed line and full-size depth error are under \"alt\" (and vice versa with --dtype bf16). "
-                          "fp16 is the headline because bf16 storage sits at the 1e-3 parity bar (DESIGN.md section 3)",
+            "dtype_note": "16-bit HBM storage and MFMA operands, fp32 accumulation.  bf16 is the format BASELINE.json configuration 2 names "
+                          "(the default of this script since round 6); the other 16-bit format (same bytes, same MFMA rate) is measured in the "
+                          "same run and reported under \"alt\" with its own depth error",
+            "repeats": {"n": len(regions), "steps_per_region": args.steps, "ms_per_step_min": min(regions) / args.steps * 1e3,
+                        "ms_per_step_median": elapsed / args.steps * 1e3, "ms_per_step_max": max(regions) / args.steps * 1e3,
+                        "ms_per_step_all": [round(r / args.steps * 1e3, 4) for r in regions],
+                        "what": "the timed region (exactly `steps` steps between barrier + synchronize on both sides, max over ranks) "
+                                "run `n` times back to back; value / ms_per_step are the MEDIAN region"},
             "config": {"workload": "MVSNet variance, 1 ref + 4 src views, 512x640 images (128x160x32 features), D=192, "
                                    f"features resident in HBM -> depth + confidence; a step = a batch of {NB} reference view(s) per GPU, "
-                                   "each with its own 4 source views", "global_batch": world * NB, "batch_per_gpu": NB,
+                                   "each with its own 4 source views; synthetic camera rig 'probe'" + zero_note, "global_batch": world * NB, "batch_per_gpu": NB,
                        "voxels_per_step_per_gpu": NB * VOX, "parallelism": f"reference-view shard x{world}, no collective",
                        # like-for-like with rounds 1-2 (whose step was ONE reference view): the same path, one view per replay
                        "one_view_at_a_time_ms": None if one_view is None else one_view * 1e3,
@@ -766,7 +820,7 @@ def run(args):
         alt_kern = {k: v for k, v in alt_tm.summary().items() if k != "proj_cams"}
         line["alt"] = {"dtype": alt_name, "value": world * NB * VOX * args.steps / alt_elapsed, "unit": "voxels/s",
                        "one_view_at_a_time_ms": None if alt_one_view is None else alt_one_view * 1e3,
-                       "ms_per_step": alt_elapsed / args.steps * 1e3,
+                       "ms_per_step": alt_elapsed / args.steps * 1e3, "ms_per_step_all": [round(r / args.steps * 1e3, 4) for r in alt_regions],
                        "kernels_us": {k: round(ms / n * 1e3, 2) for k, (n, ms) in sorted(alt_kern.items(), key=lambda kv: -kv[1][1])}}
         line["value_bf16"] = line["alt"]["value"] if alt_name == "bf16" else line["value"]
         if world == 1 and not args.no_cpu_baseline:

@@ -3,7 +3,8 @@
 derived from the compiler's assembly (round-3 review, item 2 i).  Traces ONE trip of the loop along the common path -- all four
 source views staged, boxes strictly inside the image (mode FAST) -- by following the basic blocks in layout order and taking every
 conditional branch the way that path takes it: the blocks of the clipped (GEN: `v_med3_i32` clamps) and direct-tap (`global_load`)
-flavours are skipped.  Usage: python scripts/dev/isa_breakdown.py [--pk] > profiles/r04_warp_isa_breakdown.txt"""
+flavours are skipped.  Usage: python scripts/dev/isa_breakdown.py > profiles/r04_warp_isa_breakdown.txt
+(The packed diagnostic build `warp_cost_lds_pk_kernel` / `--pk` left the source in round 5.)"""
 import collections
 import os
 import re
@@ -14,12 +15,14 @@ REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 CSRC = os.path.join(REPO, "wild_deep_mvs_amd", "csrc")
 
 
-def asm(pk: bool):
-    flags = ["-DWL_PK"] if pk else ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+def asm(pk: bool = False):
+    if pk:
+        raise SystemExit("--pk: the packed diagnostic build of the warp kernel was removed in round 5")
+    flags = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
     out = "/tmp/wl_isa.s"
     subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", "-w"] + flags +
                    ["warp_cost_tiled.hip", "-o", out], cwd=CSRC, check=True)
-    name = "_ZN4pscv23warp_cost_lds_pk_kernelINS_5f16_tES1_Li0ELi0EEEvNS_8WarpArgsE" if pk else "_ZN4pscv20warp_cost_lds_kernelINS_5f16_tES1_Li0ELi0EEEvNS_8WarpArgsE"
+    name = "_ZN4pscv20warp_cost_lds_kernelINS_5f16_tES1_Li0ELi0EEEvNS_8WarpArgsE"
     lines, on = [], False
     for ln in open(out):
         if ln.startswith(name + ":"):

@@ -216,7 +216,7 @@ WINDOW_BARS = {torch.float16: dict(depth=1e-3, pair=2e-3, prob=3e-2, cvp_cost=3e
                torch.bfloat16: dict(depth=6e-3, pair=1.2e-2, prob=2e-1, cvp_cost=2.5e-2, cvp_logits=1.5e-1, cvp_depth=6e-3)}
 
 
-@pytest.mark.parametrize("cid,dtype", [(3, torch.float16), (5, torch.float16), (3, torch.bfloat16)])
+@pytest.mark.parametrize("cid,dtype", [(3, torch.float16), (5, torch.float16), (3, torch.bfloat16), (5, torch.bfloat16)])
 def test_vis_fullsize_stages_match_oracle_on_windows(gpu, cid, dtype):
     """Every cascade stage of the full-size run against ``oracle.vismvsnet.single_stage`` on two windows of the stage's
     reference pixels (image corner and an interior window): fused depth, window probability and every pair depth."""

@@ -530,13 +530,8 @@ static int c2w_launch(Conv2dArgs& a, hipStream_t st) {
         hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(kern), LDS);
         if (e != hipSuccess) { set_error("pscv_conv2d: hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e)); return -2; }
     }
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { set_error("pscv_conv2d: device query failed"); return -2; }
-        n_cu = prop.multiProcessorCount;
-    }
+    const int n_cu = device_cu_count();            // of the current device (cached per device)
+    if (n_cu <= 0) { set_error("pscv_conv2d: device query failed"); return -2; }
     const int per_cu = LDS <= 80 * 1024 ? 2 : 1;
     const long grid = tiles < (long)n_cu * per_cu ? tiles : (long)n_cu * per_cu;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C2W_THREADS), LDS, st, a, (int)tiles);

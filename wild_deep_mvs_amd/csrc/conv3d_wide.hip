@@ -335,14 +335,11 @@ static int widep_launch(const WideArgs& a, long nblk, hipStream_t st) {
     auto kern = conv3d_widep_kernel<H, CIN, NT>;
     hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(kern), LDS);
     if (e != hipSuccess) { set_error("pscv_conv3d(wide): hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e)); return -2; }
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { set_error("pscv_conv3d(wide): device query failed"); return -2; }
-        n_cu = prop.multiProcessorCount;
-    }
-    const long grid = nblk < n_cu ? nblk : (long)(n_cu & ~7);          // one workgroup per CU (a multiple of 8: the XCD-contiguous walk)
+    const int n_cu = device_cu_count();            // of the current device (several GPUs in one process: not a per-process constant)
+    if (n_cu <= 0) { set_error("pscv_conv3d(wide): device query failed"); return -2; }
+    // one workgroup per CU; a multiple of 8 where the device has that many (the XCD-contiguous walk), the kernel takes any grid
+    const long per_dev = n_cu >= 8 ? (long)(n_cu & ~7) : (long)n_cu;
+    const long grid = nblk < per_dev ? nblk : per_dev;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), LDS, st, a, (int)nblk);
     return 0;
 }

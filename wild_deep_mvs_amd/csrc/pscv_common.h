@@ -15,6 +15,7 @@ void set_error(const char* fmt, ...);
 // hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: set it once per (kernel, device, size), from
 // any host thread (pscv_host.cpp).  A process that launches on a second GPU, or a larger request later, sets it again.
 hipError_t ensure_dyn_lds(const void* kernel, int bytes);
+int device_cu_count();      // compute units of the current device (cached per device); <= 0 on error
 
 // Tuning knob (pscv_set_tuning): ONE process-wide value, seen by every host thread that launches -- PyTorch runs autograd's backward
 // on its own thread and DataParallel runs replicas on worker threads, so a knob set from the main thread must reach them --

@@ -3,6 +3,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <functional>
 #include <mutex>
 #include <unordered_map>
 
@@ -10,19 +11,63 @@
 
 namespace pscv {
 
+// Largest dynamic-LDS size granted per (kernel, device).  A launch first looks into a small per-thread cache (no lock, no map: the
+// common case of a launch-bound forward such as Vis-MVSNet's ~300 launches, or of several host threads launching on several
+// streams); only a miss takes the process-wide mutex and the map, whose key is the (kernel, device) PAIR.
+namespace {
+struct DynLdsKey {
+    const void* kernel;
+    int dev;
+    bool operator==(const DynLdsKey& o) const { return kernel == o.kernel && dev == o.dev; }
+};
+struct DynLdsHash {
+    size_t operator()(const DynLdsKey& k) const { return std::hash<const void*>()(k.kernel) * 31u + std::hash<int>()(k.dev); }
+};
+struct DynLdsSlot { const void* kernel; int dev; int bytes; };
+constexpr int DYN_LDS_SLOTS = 64;      // direct-mapped; a collision only costs the slow path
+thread_local DynLdsSlot g_dyn_lds_tl[DYN_LDS_SLOTS];
+}  // namespace
+
 hipError_t ensure_dyn_lds(const void* kernel, int bytes) {
-    static std::mutex mu;
-    static std::unordered_map<unsigned long long, int> done;   // (kernel, device) -> largest size granted
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    const unsigned long long key = (unsigned long long)reinterpret_cast<uintptr_t>(kernel) * 64ull + (unsigned)dev;   // (< 64 devices per process)
-    std::lock_guard<std::mutex> lk(mu);
-    auto it = done.find(key);
-    if (it != done.end() && it->second >= bytes) return hipSuccess;
-    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e == hipSuccess) done[key] = bytes;
-    return e;
+    DynLdsSlot& slot = g_dyn_lds_tl[(reinterpret_cast<uintptr_t>(kernel) >> 4 ^ (uintptr_t)dev * 0x9e37u) % DYN_LDS_SLOTS];
+    if (slot.kernel == kernel && slot.dev == dev && slot.bytes >= bytes) return hipSuccess;
+    static std::mutex mu;
+    static std::unordered_map<DynLdsKey, int, DynLdsHash> done;
+    int granted;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        const DynLdsKey key{kernel, dev};
+        auto it = done.find(key);
+        if (it == done.end() || it->second < bytes) {
+            e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e != hipSuccess) return e;
+            done[key] = bytes;
+            granted = bytes;
+        } else {
+            granted = it->second;
+        }
+    }
+    slot = DynLdsSlot{kernel, dev, granted};
+    return hipSuccess;
+}
+
+// Compute units of the CURRENT device (persistent kernels size their grids with it); cached per device, not per process.
+int device_cu_count() {
+    constexpr int MAXDEV = 64;
+    static int cached[MAXDEV];          // 0 = not queried yet; racing writers store the same value
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    if (dev >= 0 && dev < MAXDEV) {
+        const int c = __atomic_load_n(&cached[dev], __ATOMIC_RELAXED);
+        if (c > 0) return c;
+    }
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return -1;
+    if (dev >= 0 && dev < MAXDEV) __atomic_store_n(&cached[dev], n, __ATOMIC_RELAXED);
+    return n;
 }
 
 static thread_local char g_err[512] = "";

@@ -378,6 +378,9 @@ extern "C" int pscv_set_tuning(const char* key, int value) {
     PSCV_CHECK_ARG(key, "pscv_set_tuning: null key");
     Knob* k = find_knob(key);
     if (!k) { set_error("pscv_set_tuning: unknown key '%s'", key); return -1; }
+    // ("warp_tiled" = 3 selected the SLP-packed diagnostic build of the LDS-staged kernel, removed in round 5: refuse it rather than
+    //  silently measure the default kernel under its name)
+    if (!strcmp(key, "warp_tiled") && value == 3) { set_error("pscv_set_tuning: warp_tiled = 3 (packed diagnostic build) no longer exists"); return -1; }
     k->set(knob_value(key, value));
     return 0;
 }

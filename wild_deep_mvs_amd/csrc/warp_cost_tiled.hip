@@ -67,7 +67,6 @@ constexpr int WL_TABLE = 2 * WL_HI;          // box records (16 B: X0 | Y0, X1 |
 constexpr int WL_LDS = WL_TABLE + 3 * WL_MAX_SRC * 16 + 32;
 static_assert(WL_LDS <= (WL_TH == 8 ? 81920 : 40960), "two / four blocks per CU");
 
-typedef float wl_f2 __attribute__((ext_vector_type(2)));
 
 // eight fp32 channels x four taps -> eight blended channels; t = {00lo, 00hi, 01lo, 01hi, 10lo, 10hi, 11lo, 11hi}
 __device__ __forceinline__ void wl_blend8(const wl_f4 (&t)[8], const float (&w)[4], float (&o)[8]) {
@@ -471,24 +470,6 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
         } else if (COST == PSCV_COST_VARIANCE_CVP) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float m = __fmul_rn(invN, s[j]); o[j] = fmaf(invN, q[j], -__fmul_rn(m, m)); }
-        } else
-        if (COST == PSCV_COST_VARIANCE) {
-            const wl_f2 n1 = wl_f2{invN, invN}, n2 = wl_f2{invN2, invN2};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const wl_f2 s2 = wl_f2{s[2 * j], s[2 * j + 1]}, q2 = wl_f2{q[2 * j], q[2 * j + 1]};
-                const wl_f2 r = q2 * n1 - (s2 * s2) * n2;
-                o[2 * j] = r[0]; o[2 * j + 1] = r[1];
-            }
-        } else if (COST == PSCV_COST_VARIANCE_CVP) {
-            const wl_f2 n1 = wl_f2{invN, invN};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const wl_f2 s2 = wl_f2{s[2 * j], s[2 * j + 1]}, q2 = wl_f2{q[2 * j], q[2 * j + 1]};
-                const wl_f2 m = s2 * n1;
-                const wl_f2 r = q2 * n1 - m * m;
-                o[2 * j] = r[0]; o[2 * j + 1] = r[1];
-            }
         } else {
             const float inv = 1.0f / (sum_e + 1e-6f);
 #pragma unroll

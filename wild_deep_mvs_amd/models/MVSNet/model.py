@@ -401,9 +401,11 @@ class MVSNet(ReplayHooks, nn.Module):
                              temp=self._temp_val, out_dtype=ref_feature.dtype)
 
     def hot_path(self, features_cl: Sequence[torch.Tensor], proj: torch.Tensor, depth_values: torch.Tensor,
-                 reference_frame: int = 0, taps: Optional[dict] = None):
+                 reference_frame: int = 0, taps: Optional[dict] = None, _warp_gate=None):
         """features_cl: V channels-last maps [B,h,w,32]; proj [B,V,4,4]; depth_values [B,D] fp32 (reference view).
-        Returns (depth [B,h,w], photometric_confidence [B,h,w]) -- reference model.py:197-215."""
+        Returns (depth [B,h,w], photometric_confidence [B,h,w]) -- reference model.py:197-215.
+        ``_warp_gate`` = (event to wait for, event to record) around the warp + cost launch: the staggered stream mode's edges
+        between the views of a batch (``_hot_path_streams``); an argument, not instance state, so that the call is re-entrant."""
         if self.depth_group is not None:
             if self.view_group is not None or taps is not None:
                 raise NotImplementedError("pscv MVSNet: the depth-plane shard excludes the source-view shard and taps")
@@ -415,7 +417,7 @@ class MVSNet(ReplayHooks, nn.Module):
         V = len(features_cl)
         src_idx = [i for i in range(V) if i != reference_frame]
         cams = ops.proj_cams_device(proj.to(torch.float32).contiguous(), reference_frame)
-        gate = self.__dict__.get("_warp_gate")            # (wait for, record) events of the staggered stream mode, else None
+        gate = _warp_gate                                  # (wait for, record) events of the staggered stream mode, else None
         if gate is not None and gate[0] is not None:
             torch.cuda.current_stream().wait_event(gate[0])
         cost = self.build_cost_volume(features_cl[reference_frame], [features_cl[i] for i in src_idx],
@@ -459,11 +461,8 @@ class MVSNet(ReplayHooks, nn.Module):
             with torch.cuda.stream(st):
                 fb = [f[b:b + 1] for f in features_cl]                      # contiguous views of one batch item
                 ev = torch.cuda.Event() if (self.batch_stagger and b + 1 < B) else None
-                self.__dict__["_warp_gate"] = (prev_ev, ev) if self.batch_stagger else None
-                try:
-                    outs.append(self.hot_path(fb, proj[b:b + 1], depth_values[b:b + 1].contiguous(), reference_frame))   # (B = 1: the plain path)
-                finally:
-                    self.__dict__["_warp_gate"] = None
+                outs.append(self.hot_path(fb, proj[b:b + 1], depth_values[b:b + 1].contiguous(), reference_frame,    # (B = 1: the plain path)
+                                          _warp_gate=(prev_ev, ev) if self.batch_stagger else None))
                 prev_ev = ev
         for st in streams[:B]:
             main.wait_stream(st)

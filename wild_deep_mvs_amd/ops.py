@@ -356,8 +356,10 @@ def conv2d(x: torch.Tensor, layer: Conv2dLayer, *, out_dtype: Optional[torch.dty
         _p(x), _dt(x), _p(layer.packed), _p(layer.scale), _p(layer.bias), _p(skip), 0 if skip is None else skip.shape[3], skip_coff,
         _p(out), out.shape[3], out_coff, _dt(out), B, H, W, layer.c_in, layer.c_out, layer.ks, layer.stride, int(parity),
         float(layer.neg_slope), _stream()),
-        cost=lambda: _conv_cost(B * H * W, B * Ho * Wo, layer.c_in, layer.c_out, layer.ks * layer.ks, False, out.element_size(),
-                                skip is not None))
+        # a parity launch (one of the four k2 sub-convolutions of a stride-2 transposed conv) writes ONE output pixel per input pixel --
+        # a quarter of the 2H x 2W map it addresses -- so its output-side bytes and FLOPs count B*H*W pixels, not B*Ho*Wo
+        cost=lambda: _conv_cost(B * H * W, B * H * W if parity >= 0 else B * Ho * Wo, layer.c_in, layer.c_out, layer.ks * layer.ks, False,
+                                out.element_size(), skip is not None))
     L.check(rc, "pscv_conv2d")
     return out
 
