@@ -456,9 +456,11 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=3, help="reference views per step and GPU (each with its own 4 source views): the engine runs "
                                                           "the items of a batch as one launch per layer (1 = one view at a time, as in rounds 1-2)")
     ap.add_argument("--stagger", action="store_true", help="stream mode with warp-to-warp edges between the views (measured slower than lockstep: MVSNet.batch_stagger)")
-    ap.add_argument("--batch-mode", choices=["streams", "batched"], default="streams",
-                    help="how the views of a step are launched: 'streams' (default) = each view's 13 launches on its own HIP stream, forked inside the replayed graph (up to 4 views), "
-                         "'batched' = one launch per layer for the whole batch on one stream, replayed as a hipGraph")
+    ap.add_argument("--batch-mode", choices=["views", "streams", "batched"], default="views",
+                    help="how the views of a step are launched: 'views' (default, round 6) = one single-branch hipGraph per view, each replayed on its "
+                         "own HIP stream, consecutive steps not joined (wild_deep_mvs_amd.graph.ViewPipeline); 'streams' (rounds 3-5) = ONE hipGraph "
+                         "whose views are parallel branches (up to 4 views); 'batched' = one launch per layer for the whole batch on one stream, "
+                         "replayed as a hipGraph")
     ap.add_argument("--no-training", action="store_true", help="skip the two MVSNet training-step timings (scripts/bench_train.py) reported under 'training'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the full-forward() timings / rooflines of BASELINE configurations 1-5")
@@ -614,6 +616,9 @@ def run(args):
     net.batch_streams = args.batch_mode == "streams"
     net.batch_stagger = args.stagger
     streams_mode = net.batch_streams and 2 <= NB <= net.MAX_BATCH_STREAMS
+    # "views" (default since round 6): one single-branch hipGraph per view on its own stream, steps not joined (graph.ViewPipeline):
+    # the views drift out of phase, 0.894-0.907 against 0.918-0.927 ms for the forked graph (profiles/r06_step_schedule.txt)
+    views_mode = args.batch_mode == "views" and NB >= 2 and not args.eager
 
     def timed_region(dtype_name, feats_cl_, steps):
         """W warm-up steps, then exactly `steps` steps between barrier + synchronize on both sides; then the same steps once
@@ -630,7 +635,17 @@ def run(args):
             graph = None
             # the step is captured once and replayed; with --batch-mode streams the per-view fork / join is part of the graph (parallel
             # branches: correct on changing inputs since round 4, tests/test_gpu_mvsnet.py)
-            if not args.eager:
+            pipe = None
+            if views_mode:
+                from wild_deep_mvs_amd.graph import ViewPipeline
+                try:
+                    pipe = ViewPipeline(net, feats_cl_, proj_d, dv_d)
+                    graph = pipe
+                except Exception as e:   # pragma: no cover  (keeps an N-GPU run alive)
+                    print(f"[bench] per-view hipGraph capture failed ({e}); timing eager launches", file=sys.stderr)
+                    pipe = graph = None
+                    torch.cuda.synchronize()
+            elif not args.eager:
                 # the 13-launch step is launch-gap bound between its small kernels: capture it once, replay it
                 try:
                     graph = torch.cuda.CUDAGraph()
@@ -644,7 +659,7 @@ def run(args):
                     print(f"[bench] hipGraph capture failed ({e}); timing eager launches", file=sys.stderr)
                     graph = None
                     torch.cuda.synchronize()
-            run = graph.replay if graph is not None else step
+            run = pipe.step if pipe is not None else (graph.replay if graph is not None else step)
             # no cyclic-GC pause inside a timed region (a gen-2 collection with torch loaded costs ~40 ms) -- and none right in
             # front of it either: tens of ms of host work leave the GPU idle, its clocks fall, and the first timed steps ran at the
             # ramp (20 timed steps right behind the collection: 0.79 ms per 2-view step, steady state 0.69).  So: collect first,
@@ -664,6 +679,8 @@ def run(args):
                 t0 = time.perf_counter()
                 for _ in range(steps):
                     run()
+                if pipe is not None:
+                    depth, conf = pipe.results()        # join of the view streams + the last step's maps: inside the timed region
                 torch.cuda.synchronize()
                 if dist is not None:
                     dist.barrier()
@@ -704,18 +721,26 @@ def run(args):
                 saved = [f.clone() for f in feats_cl_]
                 for f in feats_cl_:
                     f.copy_(torch.roll(f, shifts=(3, 5), dims=(1, 2)))
-                graph.replay()
+                if pipe is not None:
+                    pipe.step()
+                    depth, conf = pipe.results()
+                else:
+                    graph.replay()
                 torch.cuda.synchronize()
                 d_graph = depth.clone()
                 # (stream mode launches B = 1 grids: compared with one-item launches on one stream, i.e. without any overlap; the
                 #  batched mode picks other kernel variants at larger batches -- row-split instead of reduction-split tiles, another
                 #  summation order -- so its replay is compared with the same batched launches run eagerly)
-                d_eager = torch.cat([item(b)[0] for b in range(NB)], 0) if (streams_mode or NB == 1) else step()[0].clone()
+                d_eager = torch.cat([item(b)[0] for b in range(NB)], 0) if (streams_mode or views_mode or NB == 1) else step()[0].clone()
                 torch.cuda.synchronize()
                 graph_ok = bool(torch.equal(d_graph, d_eager))
                 for f, sv in zip(feats_cl_, saved):
                     f.copy_(sv)
-                graph.replay()
+                if pipe is not None:
+                    pipe.step()
+                    depth, conf = pipe.results()
+                else:
+                    graph.replay()
                 torch.cuda.synchronize()
         assert torch.isfinite(depth).all()
         assert graph_ok is not False, "the replayed hipGraph of the step differs from eager launches on fresh inputs"
@@ -798,11 +823,16 @@ def run(args):
                                    f"features resident in HBM -> depth + confidence; a step = a batch of {NB} reference view(s) per GPU, "
                                    "each with its own 4 source views; synthetic camera rig 'probe'" + zero_note, "global_batch": world * NB, "batch_per_gpu": NB,
                        "voxels_per_step_per_gpu": NB * VOX, "parallelism": f"reference-view shard x{world}, no collective",
+                       "batch_mode": args.batch_mode if NB > 1 else "one view",
                        # like-for-like with rounds 1-2 (whose step was ONE reference view): the same path, one view per replay
                        "one_view_at_a_time_ms": None if one_view is None else one_view * 1e3,
                        "one_view_at_a_time_voxels_per_s": None if one_view is None else world * VOX / one_view},
             "timing": ("hipGraph replay of the step" if graph else "eager launches") +
-                      (f"; the {NB} views of a step run on {NB} HIP streams forked inside the replayed graph: one view's vector-ALU-bound warp "
+                      (f"; a step = one replay of each of {NB} single-branch hipGraphs (one per reference view), each on its own HIP stream; "
+                       "consecutive steps are not joined, so the views drift out of phase and one view's warp runs beside another's U-Net "
+                       "(wild_deep_mvs_amd.graph.ViewPipeline; the join of the streams and the last step's depth maps are inside the timed "
+                       "region); a step is SHORTER than the sum of its kernels' stand-alone durations below" if views_mode else
+                       f"; the {NB} views of a step run on {NB} HIP streams forked inside the replayed graph: one view's vector-ALU-bound warp "
                        "beside another's MFMA / memory-bound U-Net (MVSNet._hot_path_streams), so a step is SHORTER than the sum of its "
                        "kernels' stand-alone durations below" if streams_mode else
                        f"; the {NB} views of a step share ONE launch per layer (batched grids, one stream)" if NB > 1 else "") +

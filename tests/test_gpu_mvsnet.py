@@ -299,3 +299,41 @@ def test_batch_items_on_separate_streams_equal_the_one_item_runs(env, B):
                 net.batch_streams = True
                 assert ok, (fork, rep)
         net.batch_streams_capture = True
+
+
+@pytest.mark.parametrize("B,size", [(3, (128, 160, 32)), (3, (512, 640, 192))])
+def test_view_pipeline_free_running_steps_equal_the_one_item_runs(env, B, size):
+    """``graph.ViewPipeline`` (round 6: bench.py's step): one single-branch hipGraph per reference view, each replayed on its own HIP
+    stream, consecutive steps NOT joined.  Several steps are launched back to back without a host wait, the inputs are rewritten
+    (after ``results()`` has joined the streams) between rounds: depth and confidence of the last step equal eager one-item launches on
+    one stream bit for bit -- at a small size and at the headline size, where one view's warp really runs beside another view's U-Net."""
+    L, ops, synthetic, MVSNet, O = env
+    from wild_deep_mvs_amd.graph import ViewPipeline
+    from wild_deep_mvs_amd.models.MVSNet.model import build_proj_matrices
+    H, W, D = size
+    net = MVSNet("variance")
+    net.load_state_dict(synthetic.sharpened_state_dict("mvsnet", synthetic.template_of(net), seed=0))
+    net = net.cuda().eval()
+    net.num_depth, net.graph_replay = D, False
+    V, C, h, w = 5, 32, H // 4, W // 4
+    cams = synthetic.make_cameras(B, V, H, W)
+    Ks = cams["K"].clone()
+    Ks[:, :, :2] /= 4
+    proj = build_proj_matrices(Ks, cams["R"], cams["t"]).cuda()
+    steps = torch.arange(D, dtype=torch.float32).view(1, -1)
+    dv = (cams["depth_min"][:, :1] + (cams["depth_max"][:, :1] - cams["depth_min"][:, :1]) / (D - 1) * steps).cuda().contiguous()
+    feats = synthetic.make_features(B, V, C, h, w, seed=3)
+    fcl = [ops.to_channels_last(feats[i].cuda(), torch.bfloat16) for i in range(V)]
+    net.storage_dtype = torch.bfloat16
+    with torch.no_grad():
+        pipe = ViewPipeline(net, fcl, proj, dv)
+        for rnd in range(4):
+            for f in fcl:                                            # new inputs, in place (the graphs read the live tensors)
+                f.copy_(torch.roll(f, shifts=(1 + rnd, 2), dims=(1, 2)))
+            for _ in range(1 + 2 * rnd):                             # 1, 3, 5, 7 un-joined steps
+                pipe.step()
+            depth, conf = pipe.results()
+            torch.cuda.synchronize()
+            for b in range(B):
+                d1, c1 = net.hot_path([f[b:b + 1] for f in fcl], proj[b:b + 1], dv[b:b + 1])
+                assert torch.equal(depth[b], d1[0]) and torch.equal(conf[b], c1[0]), (rnd, b)

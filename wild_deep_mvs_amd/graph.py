@@ -308,3 +308,65 @@ def replayable(forward):
 def drop_replay_graphs(model: nn.Module) -> None:
     """Forget the graphs captured inside ``model``'s forward (frees their memory pools)."""
     _REPLAY.pop(model, None)
+
+
+# ---- a batch of independent reference views as free-running per-view graphs -----------------------------------------------------
+class ViewPipeline:
+    """The MVSNet hot path over a batch of B independent reference views, one single-branch hipGraph PER VIEW, each replayed on its own
+    HIP stream; ``step()`` launches one replay of every view and returns at once, and consecutive steps are NOT joined: a view's
+    stream runs ahead of the others, so the views drift out of phase and one view's warp runs beside another view's U-Net instead of
+    three warps, then three conv0s ... in lockstep.  ``results()`` joins the view streams into the caller's stream and returns
+    (depth [B,h,w], confidence [B,h,w]) of the LAST step.
+
+    Why not one graph with B parallel branches (``MVSNet._hot_path_streams`` under capture, rounds 3-5's step): measured in round 6
+    (profiles/r06_step_schedule.txt; rocprofv3 timelines) the third branch of such a graph starts ~0.46 ms after the first two on
+    ROCm 7.2, its U-Net then runs alone at the end of the step, and every replay ends with a join: 0.918-0.927 ms per 3-view step
+    against 0.894-0.907 ms for the free-running per-view graphs on the same boxes, bit-identical outputs.  The reference has no
+    counterpart (it runs one sample at a time, depthmap_eval.py:100-106).
+
+    Inputs are read where they lie (``features_cl`` [V x [B,h,w,C]], ``proj`` [B,V,4,4], ``depth_values`` [B,D]): write new inputs
+    into these tensors on the caller's stream before ``step()`` (every view stream waits for the caller's stream first)."""
+
+    def __init__(self, net, features_cl, proj, depth_values, reference_frame: int = 0, warmup: int = 2):
+        if net.training:
+            raise RuntimeError("ViewPipeline replays the eval-mode hot path")
+        self.net = net
+        self.B = int(features_cl[0].shape[0])
+        dev = features_cl[0].device
+        self.device = dev
+        depth_values = depth_values.to(torch.float32)
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.B)]
+        self.graphs, self.outs = [], []
+        self._inputs = (features_cl, proj, depth_values)           # keep the static inputs alive
+        cur = torch.cuda.current_stream(dev)
+        with torch.no_grad():
+            for b in range(self.B):
+                fb = [f[b:b + 1] for f in features_cl]              # contiguous views of one batch item: replays read the live tensors
+                pb, db = proj[b:b + 1], depth_values[b:b + 1]
+                st = self.streams[b]
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    for _ in range(max(1, warmup)):                 # packed-weight caches, dynamic-LDS attributes
+                        net.hot_path(fb, pb, db, reference_frame)
+                st.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=st, capture_error_mode="thread_local"):
+                    out = net.hot_path(fb, pb, db, reference_frame)
+                self.graphs.append(g)
+                self.outs.append(out)
+        torch.cuda.synchronize(dev)
+
+    def step(self) -> None:
+        """One replay of every view's graph on its own stream; returns without waiting for the GPU."""
+        cur = torch.cuda.current_stream(self.device)
+        for st, g in zip(self.streams, self.graphs):
+            st.wait_stream(cur)                                     # inputs written on the caller's stream are visible to the view
+            with torch.cuda.stream(st):
+                g.replay()
+
+    def results(self):
+        """Join: the caller's stream waits for every view stream; (depth, confidence) of the last step, as new tensors."""
+        cur = torch.cuda.current_stream(self.device)
+        for st in self.streams:
+            cur.wait_stream(st)
+        return torch.cat([o[0] for o in self.outs], 0), torch.cat([o[1] for o in self.outs], 0)
