@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PSCV_ABI_VERSION 8
+#define PSCV_ABI_VERSION 9
 
 /* storage dtypes */
 #define PSCV_F32 0
@@ -603,6 +603,16 @@ int pscv_head_index_entropy(const void* in, int dtype, int in_cstride, int in_co
  */
 int pscv_homography_warp(const float* image, const float* H, int per_pixel, float* out, int m, int c, int h, int w, int hs, int ws,
                          void* stream);
+
+/*
+ * Adjoint of pscv_homography_warp with respect to the image (ABI 9).  The reference evaluates the sample positions under no_grad
+ * (models/VisMVSNet/homography.py:110-118) and differentiates only grid_sample's `input` (:101-102): grad_image accumulates
+ * grad_out x the four bilinear weights at the taps the forward read.
+ *   grad_out   device fp32 [m,h,w,c];  H as in the forward
+ *   grad_image device fp32 [m,hs,ws,c], ZEROED by the caller (the kernel adds with fp32 atomics)
+ */
+int pscv_homography_warp_bwd(const float* grad_out, const float* H, int per_pixel, float* grad_image, int m, int c, int h, int w, int hs,
+                             int ws, void* stream);
 
 /*
  * Every camera block of a CVP-MVSNet forward pass in one launch.  Replaces conditionIntrinsics, the per-level projection

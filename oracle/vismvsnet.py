@@ -154,14 +154,21 @@ def scale_camera(cam, scale: float):
     return new
 
 
-def get_homographies(left_cam, right_cam, depth_num: int, depth_start, depth_interval):
+def get_homographies(left_cam, right_cam, depth_num: int, depth_start, depth_interval, inv: bool = False):
     """homography.py:23-74: ``H_d = K_r R_r (I - (c_r - c_l) n_l^T / (d + 1e-9)) R_l^T K_l^-1`` per plane (and per
-    pixel when depth_start is [n,1,h,w]).  Returns [n, d, 1|h, 1|w, 3, 3]."""
+    pixel when depth_start is [n,1,h,w]); ``inv`` = planes uniform in inverse depth between the same end points (:41-46).
+    Returns [n, d, 1|h, 1|w, 3, 3]."""
     n = left_cam.shape[0]
     R_l, R_r = left_cam[:, 0, :3, :3], right_cam[:, 0, :3, :3]
     t_l, t_r = left_cam[:, 0, :3, 3:4], right_cam[:, 0, :3, 3:4]
     K_l, K_r = left_cam[:, 1, :3, :3], right_cam[:, 1, :3, :3]
-    depth = depth_start + depth_interval * torch.arange(depth_num, dtype=left_cam.dtype).view(1, depth_num, 1, 1)
+    steps = torch.arange(depth_num, dtype=left_cam.dtype).view(1, depth_num, 1, 1)
+    if not inv:
+        depth = depth_start + depth_interval * steps
+    else:                                                           # homography.py:41-46
+        depth_end = depth_start + (depth_num - 1) * depth_interval
+        inv_interv = (1 / (depth_start + 1e-9) - 1 / (depth_end + 1e-9)) / (depth_num - 1 + 1e-9)
+        depth = 1 / (1 / (depth_end + 1e-9) + inv_interv * steps)
     depth = depth.unsqueeze(-1).unsqueeze(-1)                       # [n,d,1|h,1|w,1,1]
     K_l_inv = K_l.float().inverse()
     fronto = R_l[:, 2:3, :3]                                        # [n,1,3]

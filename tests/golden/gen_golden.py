@@ -572,6 +572,40 @@ def gen_api_names():
     print(f"wrote {path}: " + ", ".join(f"{k} {len(v)}" for k, v in names.items()))
 
 
+def gen_homography(tag="homography_tiny"):
+    """Function-level API of models/VisMVSNet/homography.py (rows A3 / A0 of the scope table): get_homographies with inv=True (planes
+    uniform in inverse depth, :41-46) and with per-pixel depth; homography_warping with per-pixel matrices, its output and the
+    gradient of sum(out * weight) with respect to `input` (grid_sample's autograd under the no_grad grid, :101-120)."""
+    from models.VisMVSNet.homography import get_homographies, homography_warping
+    sys.path.insert(0, REPO)
+    from wild_deep_mvs_amd import synthetic
+    n, V, h, w, hs, ws, c, d = 2, 2, 20, 28, 24, 36, 8, 6
+    scene = synthetic.make_scene(n, V, h * 4, w * 4, seed=21)
+    row = torch.tensor([0., 0., 0., 1.])
+
+    def cam(v):
+        ext = torch.cat((torch.cat((scene["R"][:, v], scene["t"][:, v]), 2), row.view(1, 1, 4).expand(n, 1, 4)), 1)
+        intr = torch.zeros(n, 4, 4)
+        intr[:, :3, :3] = scene["K"][:, v]
+        intr[:, :2, :3] /= 4
+        return torch.stack((ext, intr), 1)
+    gen = torch.Generator().manual_seed(5)
+    start = torch.full((n, 1, 1, 1), 2.0)
+    interval = torch.full((n, 1, 1, 1), 0.6)
+    H_inv = get_homographies(cam(0), cam(1), d, start, interval, inv=True)              # [n,d,1,1,3,3]
+    H_lin = get_homographies(cam(0), cam(1), d, start, interval, inv=False)
+    depth = 2.5 + 3.0 * torch.rand(n, 1, h, w, generator=gen)
+    Hs = get_homographies(cam(0), cam(1), 1, depth, torch.zeros(n, 1, 1, 1))[:, 0].clone()   # [n,h,w,3,3]
+    Hs[:, :4, :6] *= -1.0                                                                 # behind the source camera
+    src = torch.randn(n, c, hs, ws, generator=gen).requires_grad_(True)
+    wgt = torch.randn(n, c, h, w, generator=gen)
+    out = homography_warping(src, Hs, (h, w))
+    (out * wgt).sum().backward()
+    save(tag + ".npz", left_cam=np32(cam(0)), right_cam=np32(cam(1)), depth_start=np32(start), depth_interval=np32(interval),
+         depth_num=np.int64(d), H_inv=np32(H_inv), H_lin=np32(H_lin), pixel_depth=np32(depth), H_pixel=np32(Hs), src=np32(src),
+         weight=np32(wgt), warped=np32(out), grad_src=np32(src.grad))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -597,6 +631,7 @@ def main():
                            gen_filter("filter_upsample", V=4, seed=3, upsample=True, downscale=2, num_consistent=2)),
     }
     todo["api"] = gen_api_names
+    todo["homography"] = gen_homography
     todo["photo"] = lambda: (gen_photo("photo_tiny"), gen_photo("photo_behind", V=4, behind_view=2, seed=3),
                              gen_photo("photo_masked", V=4, masked=True, i_ref=1, seed=5))
     for k, fn in todo.items():

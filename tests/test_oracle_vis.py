@@ -53,3 +53,32 @@ def test_vis_forward_and_stage_boundaries():
         for vi, (ed, unc) in enumerate(pr):
             close(f"pair_depth_s{3 - si}_v{vi}", ed, g[f"pair_depth_s{3 - si}_v{vi}"], 5e-5)
             close(f"pair_uncert_s{3 - si}_v{vi}", unc[0], g[f"pair_uncert_s{3 - si}_v{vi}"], 1e-4)
+
+
+def test_function_level_homographies_and_per_pixel_warp_match_the_reference():
+    """tests/golden/homography_tiny.npz (written by the reference's models/VisMVSNet/homography.py): get_homographies with planes
+    uniform in depth and in INVERSE depth (inv=True, :41-46), per-pixel matrices, homography_warping with per-pixel matrices and the
+    gradient to its input -- the oracle, and the mirror's get_homographies (plain tensor math: runs on the CPU), against them."""
+    g = load_golden("homography_tiny.npz")
+    lc, rc = t(g["left_cam"]), t(g["right_cam"])
+    d = int(g["depth_num"])
+    start, interval = t(g["depth_start"]), t(g["depth_interval"])
+    from wild_deep_mvs_amd.models.VisMVSNet.homography import get_homographies as mirror_h
+    for inv, key in ((False, "H_lin"), (True, "H_inv")):
+        want = t(g[key])
+        for name, fn in (("oracle", OV.get_homographies), ("mirror", mirror_h)):
+            got = fn(lc, rc, d, start, interval, inv=inv)
+            assert tuple(got.shape) == tuple(want.shape)
+            err = float((got - want).abs().max() / want.abs().max())
+            print(f"[parity] {name} get_homographies(inv={inv}): max rel {err:.2e}")
+            assert err <= 2e-6, (name, inv, err)
+    # inverse-depth planes really differ from the linear ones in the interior and agree at both ends
+    assert float((t(g["H_inv"])[:, 1:-1] - t(g["H_lin"])[:, 1:-1]).abs().max()) > 1e-3
+    Hp = OV.get_homographies(lc, rc, 1, t(g["pixel_depth"]), torch.zeros(lc.shape[0], 1, 1, 1))[:, 0].clone()
+    Hp[:, :4, :6] *= -1.0
+    assert float((Hp - t(g["H_pixel"])).abs().max() / t(g["H_pixel"]).abs().max()) <= 2e-6
+    src = t(g["src"]).clone().requires_grad_(True)
+    out = OV.homography_warping(src, t(g["H_pixel"]), tuple(g["warped"].shape[2:]))
+    (out * t(g["weight"])).sum().backward()
+    assert float((out.detach() - t(g["warped"])).abs().max()) <= 1e-5
+    assert float((src.grad - t(g["grad_src"])).abs().max()) <= 1e-5

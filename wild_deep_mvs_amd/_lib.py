@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("PSCV_LIB") or os.path.join(_HERE, "libpscv.so")     #
 CSRC = os.path.join(_HERE, "csrc")
 
 # mirror of include/pscv.h
-ABI_VERSION = 8
+ABI_VERSION = 9
 F32, BF16, F16 = 0, 1, 2
 GEOM_PROJ, GEOM_HOMOG = 0, 1
 COST_VARIANCE, COST_VARIANCE_CVP, COST_SOFTMIN, COST_GROUPCORR, COST_WARP_ONLY, COST_VARIANCE_PARTIAL = 0, 1, 2, 3, 4, 5
@@ -32,7 +32,7 @@ EXPORTS = ("pscv_last_error", "pscv_abi_version", "pscv_set_tuning", "pscv_proj_
            "pscv_pack_conv3d_weights", "pscv_conv3d", "pscv_softargmin", "pscv_train_workspace_floats", "pscv_bn_stats",
            "pscv_bn_act", "pscv_bn_bwd_reduce", "pscv_bn_bwd_apply", "pscv_softargmin_bwd", "pscv_conv3d_wgrad_workspace",
            "pscv_conv3d_wgrad", "pscv_warp_cost_bwd", "pscv_cvp_depth_hypos", "pscv_relu_bwd", "pscv_fuse_pairs_bwd", "pscv_pack_conv3d_weights_device", "pscv_conv2d_ex", "pscv_variance_finish", "pscv_softargmin_window",
-           "pscv_photo_warp", "pscv_photo_warp_bwd", "pscv_ssim", "pscv_ssim_bwd", "pscv_bn_finalize", "pscv_bn_bwd_coeffs", "pscv_cvp_cams", "pscv_homography_warp", "pscv_prob_softargmin", "pscv_prob_softargmin_workspace",
+           "pscv_photo_warp", "pscv_photo_warp_bwd", "pscv_ssim", "pscv_ssim_bwd", "pscv_bn_finalize", "pscv_bn_bwd_coeffs", "pscv_cvp_cams", "pscv_homography_warp", "pscv_homography_warp_bwd", "pscv_prob_softargmin", "pscv_prob_softargmin_workspace",
            "pscv_set_tuning_thread", "pscv_get_tuning", "pscv_conv3d_cat2", "pscv_uncert_net", "pscv_head_index_entropy", "pscv_image_prep", "pscv_conv3d_block8",
            "pscv_bn_stats_grouped", "pscv_bn_finalize_grouped", "pscv_bn_act_grouped", "pscv_bn_bwd_reduce_grouped", "pscv_bn_bwd_coeffs_grouped",
            "pscv_bn_bwd_apply_grouped", "pscv_pack_conv2d_weights_device", "pscv_leaky_relu_bwd", "pscv_leaky_relu_bwd_sum", "pscv_pack_conv2d_weights_device_ex", "pscv_warp_cost_rows",
@@ -203,6 +203,8 @@ def _declare(lib):
     lib.pscv_tail_sweep_workspace.argtypes = [i, i, i, i]
     lib.pscv_homography_warp.restype = i
     lib.pscv_homography_warp.argtypes = [vp, vp, i, vp, i, i, i, i, i, i, vp]
+    lib.pscv_homography_warp_bwd.restype = i
+    lib.pscv_homography_warp_bwd.argtypes = [vp, vp, i, vp, i, i, i, i, i, i, vp]
     lib.pscv_cvp_cams.restype = i
     lib.pscv_cvp_cams.argtypes = [vp, vp, vp, vp, vp, i, i, i, vp, vp, vp]
     lib.pscv_cvp_depth_hypos.restype = i

@@ -1081,6 +1081,25 @@ def homography_warp(image_cl: torch.Tensor, H: torch.Tensor, ref_hw: Sequence[in
     return out
 
 
+def homography_warp_bwd(grad_out: torch.Tensor, H: torch.Tensor, src_hw: Sequence[int]) -> torch.Tensor:
+    """Adjoint of ``homography_warp`` w.r.t. the image: grad_out fp32 [m,h,w,c], H as in the forward -> grad_image fp32 [m,hs,ws,c]
+    (pscv_homography_warp_bwd; reference: autograd of grid_sample's input, models/VisMVSNet/homography.py:101-102)."""
+    _dev(grad_out, H)
+    if grad_out.dtype != torch.float32 or grad_out.dim() != 4 or H.dtype != torch.float32:
+        raise TypeError("pscv.homography_warp_bwd: fp32 channels-last gradient [m,h,w,c] and fp32 homographies expected")
+    grad_out = grad_out.contiguous()
+    m, h, w, c = grad_out.shape
+    hs, ws = int(src_hw[0]), int(src_hw[1])
+    per_pixel = H.dim() == 5
+    if tuple(H.shape) not in ((m, 3, 3), (m, h, w, 3, 3)):
+        raise ValueError(f"pscv.homography_warp_bwd: H must be [{m},3,3] or [{m},{h},{w},3,3], got {tuple(H.shape)}")
+    gimg = torch.zeros((m, hs, ws, c), dtype=torch.float32, device=grad_out.device)
+    rc = _launch("homography_warp_bwd", lambda: L.lib().pscv_homography_warp_bwd(_p(grad_out), _p(H), int(per_pixel), _p(gimg), m, c, h, w,
+                                                                               hs, ws, _stream()))
+    L.check(rc, "pscv_homography_warp_bwd")
+    return gimg
+
+
 def cvp_cams(ref_in: torch.Tensor, src_in: torch.Tensor, ref_ex: torch.Tensor, src_ex: torch.Tensor, level_scales: Sequence[float],
              *, want_hypo: bool = True):
     """All camera blocks of a CVP-MVSNet forward in one launch (pscv_cvp_cams): ref_in [B,3,3], src_in [B,N,3,3], ref_ex [B,4,4],

@@ -92,6 +92,27 @@ class WarpOnlyFn(torch.autograd.Function):
         return None, None, None, None, dsrcs[0].permute(0, 3, 1, 2).to(dt)
 
 
+class HomographyWarpFn(torch.autograd.Function):
+    """``homography_warping(input, H)`` with arbitrary 3x3 matrices per batch item or per reference pixel and autograd to ``input``
+    (models/VisMVSNet/homography.py:107-120: the sample positions are computed under no_grad, grid_sample differentiates its input,
+    :101-102).  input NCHW -> [m,c,h,w] fp32; forward ``pscv_homography_warp``, backward ``pscv_homography_warp_bwd``."""
+
+    @staticmethod
+    def forward(ctx, H, ref_hw, src):
+        Hc = H.detach().to(torch.float32).contiguous()
+        out = ops.homography_warp(ops.to_channels_last(src.detach(), torch.float32), Hc, ref_hw)
+        ctx.save_for_backward(Hc)
+        ctx.meta = (tuple(src.shape[2:]), src.dtype)
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        (Hc,) = ctx.saved_tensors
+        src_hw, dt = ctx.meta
+        g_cl = g.permute(0, 2, 3, 1).to(torch.float32).contiguous()                        # [m,h,w,c]
+        return None, None, ops.homography_warp_bwd(g_cl, Hc, src_hw).permute(0, 3, 1, 2).to(dt)
+
+
 # --------------------------------------------------------------------------------------------------
 # 3-D U-Net in train() mode
 # --------------------------------------------------------------------------------------------------
