@@ -319,7 +319,7 @@ def gen_vis_train(tag, *, H=64, W=96, V=3, depth_nums=(16, 8, 4), interval_scale
     save(f"{tag}.npz", **arrays)
 
 
-def gen_cvp(tag, *, H=32, W=48, V=3, nscale=2, seed=0, scene_seed=0, baseline_scale=8):
+def gen_cvp(tag, *, H=32, W=48, V=3, nscale=2, seed=0, scene_seed=0, baseline_scale=8, head_mult=1):
     sys.path.insert(0, REPO)
     from wild_deep_mvs_amd import synthetic
     from models.CVP_MVSNet.frontend import Frontend  # reference
@@ -328,6 +328,11 @@ def gen_cvp(tag, *, H=32, W=48, V=3, nscale=2, seed=0, scene_seed=0, baseline_sc
     torch.manual_seed(0)
     net = Frontend()
     sd = synthetic.sharpened_state_dict("cvp", synthetic.template_of(net), seed=seed)
+    # head_mult > 1 ("cvp_peaked"): the shared 1-channel head scaled up until the COARSE level's softmax over 96 planes is peaked too
+    # (with the default gain its mean max-probability is 0.05: the coarse depth hardly depends on the volume; round-5 review)
+    for k in list(sd.keys()):
+        if k.endswith("prob0.weight"):
+            sd[k] = sd[k] * head_mult
     net.load_state_dict(sd, strict=True)
     net.eval()
     net.model.nscale = nscale
@@ -361,7 +366,8 @@ def gen_cvp(tag, *, H=32, W=48, V=3, nscale=2, seed=0, scene_seed=0, baseline_sc
     p0 = torch.softmax(cap["logits"][0], 1)
     print(f"[{tag}] coarse max prob mean {p0.max(1)[0].mean():.3f}, refine max prob {torch.softmax(cap['logits'][-1], 1).max(1)[0].mean():.3f}, "
           f"depth range {out['depth'].min():.3f}..{out['depth'].max():.3f}, conf mean {out['photometric_confidence'].mean():.3f}")
-    arrays = dict(meta=np.array([H, W, V, nscale, seed, scene_seed, baseline_scale], dtype=np.int64),
+    arrays = dict(meta=np.array([H, W, V, nscale, seed, scene_seed, baseline_scale], dtype=np.int64), head_mult=np.int64(head_mult),
+                  coarse_max_prob_mean=np.float32(p0.max(1)[0].mean()),
                   depth=np32(out["depth"]), photometric_confidence=np32(out["photometric_confidence"]),
                   coarse_planes=np.array(PLANES96, dtype=np.int64),
                   coarse_cost=np32(cap["cost"][0][:, :, PLANES96]), coarse_logits=np32(cap["logits"][0]))
@@ -624,6 +630,7 @@ def main():
         "vis": lambda: gen_vis("vis_tiny"),
         "vis_train": lambda: gen_vis_train("vis_train"),
         "cvp": lambda: gen_cvp("cvp_tiny"),
+        "cvp_peaked": lambda: gen_cvp("cvp_peaked", head_mult=int(os.environ.get("PSCV_CVP_HEAD_MULT", "4")), scene_seed=3),
         "cvp_train": lambda: gen_cvp_train("cvp_train"),
         "refframe": gen_refframe,
         "keys": gen_state_dict_keys,

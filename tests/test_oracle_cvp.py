@@ -24,10 +24,29 @@ def cvp_scene(g):
     return scene, nscale, seed
 
 
-def test_cvp_forward_and_stage_boundaries():
-    g = load_golden("cvp_tiny.npz")
+def cvp_weights(g, template, seed):
+    """The fixture's weights: ``sharpened_state_dict`` with the shared 1-channel head scaled by the fixture's ``head_mult``
+    (cvp_peaked.npz: 4 -- the COARSE level's softmax over 96 planes is peaked there too, mean max-probability 0.29 against 0.05 in
+    cvp_tiny.npz, so its depth check is not the near-vacuous case SURVEY section 8c warns about)."""
+    sd = synthetic.sharpened_state_dict("cvp", template, seed=seed)
+    mult = int(g["head_mult"]) if "head_mult" in g else 1
+    if mult != 1:
+        for k in list(sd.keys()):
+            if k.endswith("prob0.weight"):
+                sd[k] = sd[k] * mult
+    return sd
+
+
+import pytest
+
+
+@pytest.mark.parametrize("fixture", ["cvp_tiny.npz", "cvp_peaked.npz"])
+def test_cvp_forward_and_stage_boundaries(fixture):
+    g = load_golden(fixture)
     scene, nscale, seed = cvp_scene(g)
-    sd = synthetic.sharpened_state_dict("cvp", cvp_template(), seed=seed)
+    sd = cvp_weights(g, cvp_template(), seed)
+    if fixture == "cvp_peaked.npz":
+        assert float(g["coarse_max_prob_mean"]) >= 0.25, "the peaked fixture must have a peaked coarse softmax"
     taps = {}
     with torch.no_grad():
         out = OC.forward(scene["imgs"], scene["K"], scene["R"], scene["t"], scene["depth_min"], scene["depth_max"], sd,

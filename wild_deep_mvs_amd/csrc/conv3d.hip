@@ -40,6 +40,7 @@ template <> struct Mfma<f16_t> {
 
 PSCV_PROF_BUFFER(conv)
 Knob g_conv_small_tiles = {1, KNOB_CONV_SMALL_TILES};   // pscv_set_tuning("conv_small_tiles", 0) forces the large-tile variant
+Knob g_conv_small_nt = {0, KNOB_CONV_SMALL_NT};         // pscv_set_tuning("conv_small_nt", 1|2|4): 16-channel output tiles per workgroup of the small-volume / stride-2 variants (0 = default choice)
 Knob g_conv_tall64 = {1, KNOB_SPARE2};                  // pscv_set_tuning("conv_tall64", 0): 64-channel stride-1 layers back on 4x4x16 tiles; 2: 4x8x16 at any size
 
 struct ConvArgs {
@@ -598,9 +599,22 @@ static int launch_kind(ConvArgs& a, int kind, hipStream_t st) {
     // (stride-2 layers keep the large variant: both have 4 row-tiles per workgroup and the N-split would only
     //  re-read the 5x5x33 input brick once per output tile)
     const bool small = big < 1024 && g_conv_small_tiles && kind != PSCV_CONV_S2;
+    // Output-channel tiles per workgroup (NTS) of the small-volume variants and of the stride-2 layers: the grid is
+    // tiles x (NT / NTS); fewer, heavier workgroups re-read the brick less often, more, lighter ones fill the CUs of a small
+    // volume.  Default: one tile per workgroup (small S1 / T2), all tiles (S2); "conv_small_nt" overrides where it divides NT.
+    const int want = (int)g_conv_small_nt;
+    auto nts_of = [&](int dflt) { return (want == 1 || want == 2 || want == 4) && want <= NT && NT % want == 0 ? want : dflt; };
+#define PSCV_NTS_SWITCH(NTSV, KINDV, TDV, THV)                                                                     \
+    switch (NTSV) {                                                                                                  \
+        case 1: return launch_conv<H, CIN, 1, KINDV, TDV, THV>(a, NT, st);                                           \
+        case 2: if constexpr (NT >= 2) return launch_conv<H, CIN, 2, KINDV, TDV, THV>(a, NT / 2, st); break;         \
+        default: if constexpr (NT >= 4) return launch_conv<H, CIN, 4, KINDV, TDV, THV>(a, NT / 4, st); break;        \
+    }
     switch (kind) {
         case PSCV_CONV_S1:
-            if (small) return launch_conv<H, CIN, 1, PSCV_CONV_S1, 1, 4>(a, NT, st);
+            // (measured at the headline size, scripts/dev/small_layers.py: 32 output channels as ONE workgroup per tile -- 1152 workgroups,
+            //  one generation -- 11.3 against 12.5 us for two per tile; 64 output channels stay at one tile per workgroup)
+            if (small) { PSCV_NTS_SWITCH(nts_of(NT == 2 ? 2 : 1), PSCV_CONV_S1, 1, 4) }
             if constexpr (CIN == 64) {
                 // 64 input channels (CVP's 64 -> 64 / 64 -> 32 layers): a wave fetches NT KB of A fragments per k-step for MB x NT
                 // MFMAs, and at MB = 4 (4x4x16 tiles) that is 64 B/clk per CU -- the whole vector-memory path, 25 % of the MFMA
@@ -609,9 +623,12 @@ static int launch_kind(ConvArgs& a, int kind, hipStream_t st) {
                     return launch_conv<H, CIN, NT, PSCV_CONV_S1, 4, 8>(a, 1, st);
             }
             return launch_conv<H, CIN, NT, PSCV_CONV_S1, 4, 4>(a, 1, st);
-        case PSCV_CONV_S2: return launch_conv<H, CIN, NT, PSCV_CONV_S2, 2, 2>(a, 1, st);
-        case PSCV_CONV_T2: return small ? launch_conv<H, CIN, 1, PSCV_CONV_T2, 1, 4>(a, NT, st) : launch_conv<H, CIN, NT, PSCV_CONV_T2, 2, 4>(a, 1, st);
+        case PSCV_CONV_S2: { PSCV_NTS_SWITCH(nts_of(NT), PSCV_CONV_S2, 2, 2) } break;
+        case PSCV_CONV_T2:
+            if (small) { PSCV_NTS_SWITCH(nts_of(1), PSCV_CONV_T2, 1, 4) }
+            return launch_conv<H, CIN, NT, PSCV_CONV_T2, 2, 4>(a, 1, st);
     }
+#undef PSCV_NTS_SWITCH
     set_error("pscv_conv3d: unknown kind %d", kind);
     return -1;
 }

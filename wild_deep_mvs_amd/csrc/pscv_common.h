@@ -29,7 +29,7 @@ struct Knob {
 };
 enum { KNOB_WARP_LPV, KNOB_WARP_PPD, KNOB_WARP_TILED, KNOB_WARP_Q2, KNOB_CONV_SMALL_TILES, KNOB_SWEEP_TH16, KNOB_SWEEP_DC,
        KNOB_SWEEPC_SLOTS, KNOB_SWEEPC_PD, KNOB_C1_NB, KNOB_C1_SWEEP, KNOB_WARP_BWD_DIRECT, KNOB_CONV_S2_SWEEP, KNOB_S2S_SLOTS,
-       KNOB_WARP_TILE, KNOB_FUSE_C0, KNOB_SPARE1, KNOB_SPARE2, KNOB_SPARE3, KNOB_SPARE4, KNOB_SWEEP_KDM, KNOB_SWEEP_KDM_PD, KNOB_WARP_LDS_PAD, KNOB_WARP_GC_LDS, KNOB_TAIL_NBK, KNOB_CONV_WIDE, KNOB_COUNT };
+       KNOB_WARP_TILE, KNOB_FUSE_C0, KNOB_SPARE1, KNOB_SPARE2, KNOB_SPARE3, KNOB_SPARE4, KNOB_SWEEP_KDM, KNOB_SWEEP_KDM_PD, KNOB_WARP_LDS_PAD, KNOB_WARP_GC_LDS, KNOB_TAIL_NBK, KNOB_CONV_WIDE, KNOB_CONV_SMALL_NT, KNOB_COUNT };
 bool knob_thread_value(int id, int* v);             // this thread's override of slot id, if one is set
 void knob_thread_set(int id, int v, bool enable);
 

@@ -353,6 +353,7 @@ Knob g_fuse_c0 = {0, KNOB_FUSE_C0};           // reserved: fused warp -> conv0 e
 Knob g_warp_lds_pad = {0, KNOB_WARP_LDS_PAD};       // KiB of LDS the LDS-staged warp kernel requests on top of its need (fewer workgroups per CU)
 extern Knob g_conv2d_wlds;                    // conv2d.hip
 extern Knob g_conv_tall64;                    // conv3d.hip
+extern Knob g_conv_small_nt;                  // conv3d.hip
 extern Knob g_tail_nbk;                       // conv3d_tail.hip
 extern Knob g_conv_wide;                      // conv3d_wide.hip
 }
@@ -365,7 +366,7 @@ static Knob* find_knob(const char* key) {
         {"warp_tiled", &g_warp_tiled}, {"warp_gc_lds", &g_warp_gc_lds}, {"warp_q2", &g_warp_q2}, {"c1_nb", &g_c1_nb}, {"c1_sweep", &g_c1_sweep},
         {"sweep_th16", &g_sweep_th16}, {"sweep_dc", &g_sweep_dc}, {"sweep_kdm", &g_sweep_kdm}, {"sweep_kdm_pd", &g_sweep_kdm_pd}, {"sweepc_slots", &g_sweepc_slots}, {"sweepc_pd", &g_sweepc_pd},
         {"warp_bwd_direct", &g_warp_bwd_direct}, {"conv_s2_sweep", &g_conv_s2_sweep}, {"s2s_slots", &g_s2s_slots},
-        {"warp_tile", &g_warp_tile}, {"fuse_c0", &g_fuse_c0}, {"warp_lds_pad", &g_warp_lds_pad}, {"conv2d_wlds", &g_conv2d_wlds}, {"conv_tall64", &g_conv_tall64}, {"block8_slots", &::g_block8_slots}, {"softargmin_small", &::g_softargmin_small}, {"tail_nbk", &g_tail_nbk}, {"conv_wide", &g_conv_wide}};
+        {"warp_tile", &g_warp_tile}, {"fuse_c0", &g_fuse_c0}, {"warp_lds_pad", &g_warp_lds_pad}, {"conv2d_wlds", &g_conv2d_wlds}, {"conv_tall64", &g_conv_tall64}, {"block8_slots", &::g_block8_slots}, {"softargmin_small", &::g_softargmin_small}, {"tail_nbk", &g_tail_nbk}, {"conv_wide", &g_conv_wide}, {"conv_small_nt", &g_conv_small_nt}};
     for (const auto& e : table)
         if (!strcmp(key, e.name)) return e.k;
     return nullptr;
