@@ -137,8 +137,9 @@ def build_inputs(device, rank: int, dtype, batch: int = 1):
     return net, sd, feats, feats_cl, proj.to(device), dv.to(device).contiguous(), proj, dv
 
 
-def rig_step(net, device, dtype, rig: str, nb: int, steps: int = 30):
-    """The headline step (a batch of `nb` reference views, hot path, one replayed hipGraph) on the camera rig `rig`: ms per step."""
+def rig_step(net, device, dtype, rig: str, nb: int, steps: int = 30, views: bool = True):
+    """The headline step (a batch of `nb` reference views, hot path; `views`: free-running per-view hipGraphs like the headline region,
+    else one replayed hipGraph of `net.hot_path` on the batch) on the camera rig `rig`: ms per step."""
     cams = synthetic.make_cameras(nb, V, IMG_H, IMG_W, rig=rig)
     Ks = cams["K"].clone()
     Ks[:, :, :2] /= 4
@@ -151,15 +152,23 @@ def rig_step(net, device, dtype, rig: str, nb: int, steps: int = 30):
         for _ in range(3):
             net.hot_path(fcl, proj, dv)
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
-            net.hot_path(fcl, proj, dv)
+        if views and nb >= 2:          # the headline's step: free-running per-view graphs
+            from wild_deep_mvs_amd.graph import ViewPipeline
+            pipe = ViewPipeline(net, fcl, proj, dv)
+            run, finish = pipe.step, pipe.results
+        else:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                net.hot_path(fcl, proj, dv)
+            run, finish = g.replay, (lambda: None)
         for _ in range(10):
-            g.replay()
+            run()
+        finish()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
-            g.replay()
+            run()
+        finish()
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / steps * 1e3
 
@@ -194,7 +203,7 @@ def staging_modes(device, dtype, rig: str):
             [dict(zip(names, hm[v])) for v in range(V - 1)])
 
 
-def geometry_probe(net, device, dtype, reps: int = 20, nb: int = 1):
+def geometry_probe(net, device, dtype, reps: int = 20, nb: int = 1, views: bool = True):
     """The headline workload on BOTH camera rigs of `synthetic.make_cameras`: "probe" (what the bench line is
     measured on: depth 2..6, sources rotated about y and shifted along x, 0.03-0.1 feature texels per plane) and "dtu" (depth
     425..905 as data/dtu_yao.py:109, cameras on an arc with tilt, 0.14-0.32 texels per plane, oblique epipolar lines).  Per rig: the
@@ -262,7 +271,7 @@ def geometry_probe(net, device, dtype, reps: int = 20, nb: int = 1):
             path_ms = (time.perf_counter() - t0) / reps * 1e3
         quad_us = alt_us["direct_gather"]
         try:
-            step_ms = rig_step(net, device, dtype, rig, nb)
+            step_ms = rig_step(net, device, dtype, rig, nb, views=views)
         except Exception as e:   # pragma: no cover
             step_ms = None
         out[rig] = {"step_ms": None if step_ms is None else round(step_ms, 4), "views_per_step": nb,
@@ -271,7 +280,7 @@ def geometry_probe(net, device, dtype, reps: int = 20, nb: int = 1):
                     "warp_cost_us_direct_gather_kernel": round(quad_us, 1), "warp_cost_us_lane_owner_kernel": round(alt_us["lane_owner"], 1),
                     "hot_path_eager_ms_per_view": round(path_ms, 4), "staging_modes_share_of_block_views": modes,
                     "staging_modes_per_view": [dict(zip(names, hm[v])) for v in range(V - 1)]}
-    out["note"] = ("`value` / `step_ms`: the headline step (same batch, one replayed hipGraph) on each rig with DEFAULT tuning -- the top-level "
+    out["note"] = ("`value` / `step_ms`: the headline step (same batch, same launch scheme as the timed region) on each rig with DEFAULT tuning -- the top-level "
                    "`value` is the probe rig's, `value_dtu_rig` repeats the DTU-like rig's.  On the DTU-like rig the source boxes of a 32-plane chunk "
                    "exceed the LDS-staged kernel's 16 x 8 texel / arena budget for the wide-baseline views; since round 5 such a block sweeps its "
                    "chunk as two 16-plane halves with their own boxes (three boxes per view from ONE box phase) instead of taking global taps "
@@ -865,7 +874,7 @@ def run(args):
         line["alt_geometry"] = None
         if world == 1 and not args.no_other_configs:
             try:
-                line["alt_geometry"] = geometry_probe(net, device, DTYPES[args.dtype], nb=NB)
+                line["alt_geometry"] = geometry_probe(net, device, DTYPES[args.dtype], nb=NB, views=views_mode)
                 line["value_dtu_rig"] = (line["alt_geometry"].get("dtu") or {}).get("value")
             except Exception as e:   # pragma: no cover
                 line["alt_geometry"] = {"error": f"{type(e).__name__}: {e}"[:300]}

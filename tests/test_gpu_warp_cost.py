@@ -191,6 +191,57 @@ def test_tiled_kernel_equals_direct_kernel(env, baseline_scale, shape, V, D, cos
     assert float(outs[1].abs().max()) > 0
 
 
+@pytest.mark.parametrize("D", [64, 44, 192])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_adaptive_split_levels_store_the_same_bits_on_the_wide_baseline_rig(env, dtype, D):
+    """The LDS-staged kernel on the DTU-like rig (0.14-0.32 texels per plane: 32-plane boxes overflow the arena) with the adaptive
+    split at its three settings -- `warp_tile` 0: halves, and quarters where a half still has a view on global taps (round 6);
+    3: halves only (round 5); 1: no split -- against the direct-gather kernel: the same stored bits in every case (which planes a
+    staging phase covers never changes the fp32 chain of a voxel), and every split level lowers the share of (range, view) pairs that
+    take global taps.  D = 44: a last chunk of 12 planes (halves of 6, quarters of 4 + 2); D = 192: the headline's six chunks."""
+    import ctypes
+    L, ops, O = env
+    from wild_deep_mvs_amd import synthetic
+    from wild_deep_mvs_amd.models.MVSNet.model import build_proj_matrices
+    V, h, w, C = 5, 128, 160, 32
+    feats = synthetic.make_features(1, V, C, h, w, seed=4)
+    fcl = [ops.to_channels_last(feats[i].cuda(), dtype) for i in range(V)]
+    cam = synthetic.make_cameras(1, V, 4 * h, 4 * w, rig="dtu")
+    Ks = cam["K"].clone()
+    Ks[:, :, :2] /= 4
+    proj = build_proj_matrices(Ks, cam["R"], cam["t"]).cuda()
+    dv = torch.linspace(float(cam["depth_min"][0, 0]), float(cam["depth_max"][0, 0]), D).view(1, D).cuda()
+    cams = ops.proj_cams_device(proj.float().contiguous(), 0)
+    run = lambda: ops.warp_cost(fcl[0], fcl[1:], cams, dv, cost=L.COST_VARIANCE, out_dtype=dtype)
+    fn = L.lib().pscv_debug_wl_mode_hist
+    fn.argtypes, fn.restype = [ctypes.c_void_p], None
+    try:
+        L.set_tuning("warp_tiled", 0)
+        want = run().clone()
+        L.set_tuning("warp_tiled", 1)
+        direct_share = {}
+        for tile in (0, 3, 1):
+            L.set_tuning("warp_tile", tile)
+            hist = torch.zeros(16, dtype=torch.int32, device="cuda")
+            fn(hist.data_ptr())
+            try:
+                got = run()
+                torch.cuda.synchronize()
+            finally:
+                fn(None)
+            assert torch.equal(got, want), f"warp_tile = {tile}: stored bits differ from the direct-gather kernel"
+            hm = hist.view(4, 4).cpu()                       # [view][DIRECT, GEN, FAST, ZERO]
+            direct_share[tile] = float(hm[:, 0].sum()) / float(hm.sum())
+    finally:
+        L.set_tuning("warp_tiled", -1)
+        L.set_tuning("warp_tile", 0)
+    print(f"[parity] DTU-like rig D={D} {dtype}: share of (plane range, view) pairs on global taps: no split {direct_share[1]:.3f}, "
+          f"halves {direct_share[3]:.3f}, halves + quarters {direct_share[0]:.3f}", flush=True)
+    assert direct_share[0] < direct_share[3] < direct_share[1]
+    if D == 192:           # the headline's plane spacing (0.14-0.32 texels per plane): 8-plane boxes fit almost everywhere
+        assert direct_share[0] <= 0.05 and direct_share[3] >= 0.10
+
+
 @pytest.mark.parametrize("dtype,out_dtype", [(torch.float16, torch.float16), (torch.bfloat16, torch.bfloat16), (torch.float16, torch.float32)])
 @pytest.mark.parametrize("cost_name", ["variance", "variance_cvp"])
 @pytest.mark.parametrize("baseline_scale,shape,V,D", [(1.0, (64, 80), 5, 24), (1.0, (37, 53), 5, 24), (12.0, (64, 80), 5, 24),

@@ -58,13 +58,14 @@ constexpr int WL_T = 8;                      // tile width in reference pixels
 constexpr int WL_TH = WL_TILE_H;             // tile height: 8 (512 threads, two workgroups per CU) or 4 (256 threads, four per CU)
 constexpr int WL_THREADS = 64 * WL_TH;       // a wave = 2 tile rows x 8 pixels; (WL_TH / 2) pixel groups x 2 plane parities
 constexpr int WL_PG = WL_TH / 2;             // pixel groups (waves per plane parity)
-constexpr int WL_ARENA = WL_TH == 8 ? 638 : 318;   // staged texels per block (all views): 80 / 40 KiB of fp32
+constexpr int WL_ARENA = WL_TH == 8 ? 636 : 316;   // staged texels per block (all views): 80 / 40 KiB of fp32
 constexpr int WL_HI = WL_ARENA * 64;         // byte offset of the "hi" channel plane
 constexpr int WL_STAGE_ROWS = 8;             // box rows one wave stages (one load batch)
 constexpr int WL_BOX_H = WL_STAGE_ROWS * (WL_THREADS / 64 / WL_MAX_SRC);   // tallest box the staging phase covers: 8 (4-row tile) / 16
-constexpr int WL_TABLE = 2 * WL_HI;          // box records (16 B: X0 | Y0, X1 | Y1, pitch | mode as 16-bit pairs), [3 plane ranges][4 views]:
-                                             // range 0 = the whole chunk, 1 / 2 = its first / second half (adaptive split, round 5)
-constexpr int WL_LDS = WL_TABLE + 3 * WL_MAX_SRC * 16 + 32;
+constexpr int WL_NSETS = 7;                  // plane ranges with their own boxes: the whole chunk, its two halves (round 5), its four quarters (round 6)
+constexpr int WL_TABLE = 2 * WL_HI;          // box records (16 B: X0 | Y0, X1 | Y1, pitch | mode as 16-bit pairs), [7 plane ranges][4 views]:
+                                             // range 0 = the whole chunk, 1 / 2 = its first / second half, 3..6 = the quarters (adaptive split)
+constexpr int WL_LDS = WL_TABLE + WL_NSETS * WL_MAX_SRC * 16 + 32;
 static_assert(WL_LDS <= (WL_TH == 8 ? 81920 : 40960), "two / four blocks per CU");
 
 
@@ -174,22 +175,32 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
     // its second half (lanes 16-23).  If a view's whole-chunk box does not fit (wide baselines: the sample travels 0.3 texels per
     // plane on DTU-like rigs, 10 texels over 32 planes) the block sweeps the two halves one after the other, each with its own, half
     // as long boxes, instead of taking global taps for that view: no extra box phase, one more staging phase for such blocks only.
+    // Round 6: SEVEN boxes per view -- the four quarters too (lanes 24-55).  On the DTU-like rig half of the 16-plane ranges of the
+    // widest-baseline view still took global taps (boxes 15-18 texels wide, or no room left in the arena); 8-plane ranges fit in
+    // 98 % of the cases (profiles/r06_warp_quarter_split.txt), so a half in which some view would take global taps is swept as its two quarters.
     const int nplanes = d1 - d0;
-    const int hsz = nplanes >= 4 ? ((nplanes / 2 + 1) & ~1) : nplanes;        // planes of the first half (even); no split below 4 planes
+    auto split_size = [](int m) { return m >= 4 ? ((m / 2 + 1) & ~1) : m; };     // planes of the first part (even); no split below 4 planes
+    const int hsz = split_size(nplanes);                         // first half: [0, hsz)
+    const int q0 = split_size(hsz), q2 = split_size(nplanes - hsz);   // first quarter of each half: [0, q0), [hsz, hsz + q2)
     if (wave < WL_MAX_SRC) {      // wave k: the boxes of source view k
         const int k = wave;
-        // (depth ranges: wave reductions of the per-lane planes; planes need not be monotone)
+        // (depth ranges: wave reductions of the per-lane planes over the four quarters; planes need not be monotone.  Lanes beyond the
+        //  chunk repeat its last plane and count into the last quarter; an empty quarter reduces to +-inf and is never swept.)
         const float inf = __builtin_inff();
-        const bool in1 = lane < hsz;
-        const float dmin1 = wl_wave_reduce<false>(in1 ? dlane : inf), dmax1 = wl_wave_reduce<true>(in1 ? dlane : -inf);
-        const float dmin2 = hsz < nplanes ? wl_wave_reduce<false>(in1 ? inf : dlane) : dmin1;
-        const float dmax2 = hsz < nplanes ? wl_wave_reduce<true>(in1 ? -inf : dlane) : dmax1;
+        const bool inq0 = lane < q0, inq1 = lane >= q0 && lane < hsz, inq2 = lane >= hsz && lane < hsz + q2, inq3 = lane >= hsz + q2;
+        const float qmin0 = wl_wave_reduce<false>(inq0 ? dlane : inf), qmax0 = wl_wave_reduce<true>(inq0 ? dlane : -inf);
+        const float qmin1 = wl_wave_reduce<false>(inq1 ? dlane : inf), qmax1 = wl_wave_reduce<true>(inq1 ? dlane : -inf);
+        const float qmin2 = wl_wave_reduce<false>(inq2 ? dlane : inf), qmax2 = wl_wave_reduce<true>(inq2 ? dlane : -inf);
+        const float qmin3 = wl_wave_reduce<false>(inq3 ? dlane : inf), qmax3 = wl_wave_reduce<true>(inq3 ? dlane : -inf);
+        const float dmin1 = fminf(qmin0, qmin1), dmax1 = fmaxf(qmax0, qmax1);
+        const float dmin2 = hsz < nplanes ? fminf(qmin2, qmin3) : dmin1, dmax2 = hsz < nplanes ? fmaxf(qmax2, qmax3) : dmax1;
         const float dmin0 = fminf(dmin1, dmin2), dmax0 = fmaxf(dmax1, dmax2);
-        const int set = min(lane >> 3, 2);
+        const int set = min(lane >> 3, WL_NSETS - 1);
         const int corner = lane & 7;
         const float cx = (corner & 1) ? (float)min(x0t + WL_T - 1, a.w - 1) : (float)x0t;
         const float cy = (float)(((corner & 2) ? min(y0t + WL_TH - 1, a.h - 1) : y0t) + a.ref_y0);
-        const float dlo = set == 0 ? dmin0 : set == 1 ? dmin1 : dmin2, dhi = set == 0 ? dmax0 : set == 1 ? dmax1 : dmax2;
+        const float dlo = set == 0 ? dmin0 : set == 1 ? dmin1 : set == 2 ? dmin2 : set == 3 ? qmin0 : set == 4 ? qmin1 : set == 5 ? qmin2 : qmin3;
+        const float dhi = set == 0 ? dmax0 : set == 1 ? dmax1 : set == 2 ? dmax2 : set == 3 ? qmax0 : set == 4 ? qmax1 : set == 5 ? qmax2 : qmax3;
         const float d = (corner & 4) ? dhi : dlo;
         int cX0 = 0, cY0 = 0, cX1 = -1, cY1 = -1, pitch = 4, mode = WL_ZERO;      // mode: WL_FAST / WL_GEN here = "if the arena has room"
         if (k < n_src) {
@@ -223,7 +234,7 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
                 else { cX0 = 0; cY0 = 0; cX1 = -1; cY1 = -1; pitch = 4; }      // (not staged: keep the record inside 16 bits)
             } else { cX0 = 0; cY0 = 0; cX1 = -1; cY1 = -1; pitch = 4; }
         }
-        if (corner == 0 && lane < 24)
+        if (corner == 0 && lane < 8 * WL_NSETS)
             *reinterpret_cast<uint4*>(table + (set * WL_MAX_SRC + k) * 4) =
                 make_uint4(((unsigned)cX0 & 0xffffu) | ((unsigned)cY0 << 16), ((unsigned)cX1 & 0xffffu) | ((unsigned)cY1 << 16),
                            (unsigned)pitch | ((unsigned)mode << 16), 0u);
@@ -257,19 +268,27 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
         }
         return direct;
     };
-    // whole chunk first; if a view would take global taps there, the two halves one after the other
-    // (pscv_set_tuning("warp_tile", 1) switches the split off: A/B runs, scripts/dev/warp_ab.py)
-    int nsub = 1;
-    if (read_records(0) && hsz < nplanes && a.variant != 1) nsub = 2;
-    for (int sub = 0; sub < nsub; ++sub) {
-    if (nsub == 2) {
-        if (sub) {
-            __syncthreads();                             // the first half's sweep is done with the arena
-            __builtin_amdgcn_s_setprio(3);               // (staging phase at raised priority, like the first one)
-        }
-        read_records(1 + sub);
+    // Sweep plan, the same in every wave: the whole chunk if every view's box fits; else each half on its own -- as two quarters if
+    // some view would still take global taps in that half.  A segment = (record set, first plane, end plane) packed into 16 bits.
+    // (pscv_set_tuning("warp_tile", 1) switches the split off, 3 stops at the halves: A/B runs, scripts/dev/warp_ab.py)
+    unsigned long plan = 0;
+    int nseg = 0;
+    auto push = [&](int set, int pa, int pb) { plan |= (unsigned long)((unsigned)set | (unsigned)pa << 3 | (unsigned)pb << 9) << (16 * nseg); ++nseg; };
+    if (!read_records(0) || !(hsz < nplanes) || a.variant == 1) {
+        push(0, 0, nplanes);
+    } else {
+        const bool quarters = a.variant != 3;
+        if (read_records(1) && q0 < hsz && quarters) { push(3, 0, q0); push(4, q0, hsz); } else push(1, 0, hsz);
+        if (read_records(2) && q2 < nplanes - hsz && quarters) { push(5, hsz, hsz + q2); push(6, hsz + q2, nplanes); } else push(2, hsz, nplanes);
     }
-    const int s0 = d0 + (nsub == 2 && sub ? hsz : 0), s1 = nsub == 2 && !sub ? d0 + hsz : d1;
+    for (int sub = 0; sub < nseg; ++sub) {
+    const unsigned seg = (unsigned)(plan >> (16 * sub)) & 0xffffu;
+    if (sub) {
+        __syncthreads();                                 // the previous segment's sweep is done with the arena
+        __builtin_amdgcn_s_setprio(3);                   // (staging phase at raised priority, like the first one)
+    }
+    read_records((int)(seg & 7u));
+    const int s0 = d0 + (int)((seg >> 3) & 63u), s1 = d0 + (int)(seg >> 9);
     if (a.mode_hist && tid == 0) {                       // (bench.py's mode histogram, per swept plane range; off in product launches)
 #pragma unroll
         for (int k = 0; k < WL_MAX_SRC; ++k)
