@@ -4,10 +4,13 @@
 A step = one pass of the hot path (fused warp + variance cost volume -> 3-D U-Net regularisation ->
 softmax / depth regression / confidence) over one batch of synthetic input that is already resident in
 HBM: BASELINE.json configs[1] = MVSNet, 1 ref + 4 src views, 512x640 images (128x160x32 feature maps),
-D = 192 planes, bf16 storage / fp32 accumulation.  3 932 160 cost-volume voxels per reference view; a batch is
---batch reference views (default 3, each with its own source views; --batch-mode streams, the default: each view's launches on
-its own HIP stream, forked and joined INSIDE one replayed hipGraph; --batch-mode batched = one launch per layer for the whole
-batch on one stream, replayed as a hipGraph; --batch 1 = one view at a time as in rounds 1-2, also reported in every line).
+D = 192 planes, bf16 storage / fp32 accumulation (--dtype bf16, the default since round 6; fp16 is measured too and reported under "alt").
+3 932 160 cost-volume voxels per reference view; a batch is --batch reference views (default 3, each with its own source views).
+--batch-mode views (default): one single-branch hipGraph per view, each replayed on its own HIP stream, consecutive steps not joined
+(wild_deep_mvs_amd.graph.ViewPipeline); --batch-mode streams (rounds 3-5): ONE hipGraph whose views are parallel branches;
+--batch-mode batched: one launch per layer for the whole batch on one stream, replayed as a hipGraph; --batch 1 = one view at a time as in
+rounds 1-2, also reported in every line.  The timed region (exactly --steps steps between barrier + synchronize) runs --repeats times
+(default 5); the line reports the median region and min / median / max.
 
 Multi-GPU (--gpus N, one process per GPU): reference views are independent objects, so each rank sweeps its own
 view (global batch = N) with no data-path collective -> weak scaling.  Ranks come either from a launcher
@@ -281,12 +284,13 @@ def geometry_probe(net, device, dtype, reps: int = 20, nb: int = 1, views: bool 
                     "hot_path_eager_ms_per_view": round(path_ms, 4), "staging_modes_share_of_block_views": modes,
                     "staging_modes_per_view": [dict(zip(names, hm[v])) for v in range(V - 1)]}
     out["note"] = ("`value` / `step_ms`: the headline step (same batch, same launch scheme as the timed region) on each rig with DEFAULT tuning -- the top-level "
-                   "`value` is the probe rig's, `value_dtu_rig` repeats the DTU-like rig's.  On the DTU-like rig the source boxes of a 32-plane chunk "
-                   "exceed the LDS-staged kernel's 16 x 8 texel / arena budget for the wide-baseline views; since round 5 such a block sweeps its "
-                   "chunk as two 16-plane halves with their own boxes (three boxes per view from ONE box phase) instead of taking global taps "
-                   "(DIRECT): the histogram counts (swept plane range, view) pairs.  `warp_cost_us*`: stand-alone launches of the three warp kernels, "
-                   "interleaved, medians of five rounds (scripts/dev/warp_ab.py adds the no-split arm: split 150 us, no split 176 us, direct-gather "
-                   "kernel 148 us on the DTU-like rig; 119 / 122 / 155 us on the probe rig).  The DTU-like rig has 97 % of its (block, view) pairs inside "
+                   "`value` is the probe rig's, `value_dtu_rig` repeats the DTU-like rig's.  On the DTU-like rig the source boxes of a whole chunk (48 planes since round 6) "
+                   "exceed the LDS-staged kernel's 16 x 8 texel / arena budget for the wide-baseline views; such a block sweeps its chunk as two "
+                   "halves with their own boxes (round 5), and a half in which some view would still take global taps (DIRECT) as two quarters "
+                   "(round 6; seven boxes per view from ONE box phase): the histogram counts (swept plane range, view) pairs.  `warp_cost_us*`: "
+                   "stand-alone launches of the three warp kernels, interleaved, medians of five rounds (scripts/dev/warp_ab.py adds the split levels: "
+                   "quarters 146-148 us, halves only 153-173 us, no split 180-206 us, direct-gather kernel 149-150 us on the DTU-like rig; "
+                   "117-119 / 118 / 123-125 / 146 us on the probe rig; profiles/r06_warp_quarter_split.txt).  The DTU-like rig has 97 % of its (block, view) pairs inside "
                    "the source images against 80 % on the probe rig (ZERO 0.03 / 0.18): more real work per voxel, not only larger boxes")
     return out
 
