@@ -460,6 +460,15 @@ class SingleStage(nn.Module):
         return full[:, 0], full[:, 1], None, None
 
     PAIR_BATCH_BYTES = 48 << 20   # pair volumes (8 channels, 16-bit) batched into one U-Net pass: at most this many bytes per group
+    # Groups of pair passes on HIP streams (forked from / joined into the caller's stream): an EXPERIMENT, off (1).  Measured
+    # (scripts/dev/vis_pair_streams.py, rounds 4 and 6): two streams 15.99 -> 15.68 ms at configuration 5, 2.320 -> 2.296 ms at
+    # configuration 3, more streams no better (ROCm 7.2 keeps two branches of a captured graph in flight).  Not the default: the pair
+    # volumes are ALLOCATED on the side streams and read on the caller's stream after the join -- the caching allocator may hand such a
+    # block to a later side-stream allocation while the caller's stream still reads it; round 6 switched it on, the unsharded forward
+    # stayed bit-identical, the two-rank source-view shard at configuration 5 did not (depth 6.8e-3 off:
+    # tests/test_gpu_fullsize.py::test_vis_fullsize_shard_equals_unsharded).  A safe version allocates every cross-stream tensor on the
+    # caller's stream first, as CVP's FeaturePyramid.forward_engine_split does.
+    PAIR_STREAMS = 1
     DEPTH_HALO = 16   # planes of redundant compute per side: 8 (pair U-Net + head) + 8 (fuse U-Net + head)
 
     def forward_depth_shard(self, ref_feat, ref_cam, srcs_feat, srcs_cam, depth_num, depth_start, depth_interval, s_scale):
@@ -586,7 +595,7 @@ class SingleStage(nn.Module):
         # per-pair `index * interval + start` (model_cas.py:348) is two launches per stage and the UncertNet reads its batch in place
         index_all = torch.empty((n_s * n_b, h, w), dtype=torch.float32, device=costs.device)
         entropy_all = torch.empty((n_s * n_b, h, w), dtype=torch.float32, device=costs.device)
-        # PAIR_STREAMS > 1 (round 4 experiment; default 1): the per-view passes of a stage are independent until the fusion, so
+        # PAIR_STREAMS > 1 (rounds 4 / 6 experiment; default 1): the per-view passes of a stage are independent until the fusion, so
         # consecutive groups may run on separate HIP streams (forked from / joined into the caller's stream; under the forward's
         # hipGraph capture they become parallel branches of the graph) -- the ramp of one view's kernels under the tail of another's
         n_streams = min(int(getattr(self, "PAIR_STREAMS", 1)), (n_s + group - 1) // group) if taps is None and costs.is_cuda else 1
