@@ -158,11 +158,11 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
         rz = fmaf(cam[7], py, cam[6] * px) + cam[8];
         tx = cam[9]; ty_ = cam[10]; tz = cam[11];
     }
-    float rf[8];
+    float rf[8], rf2[8];     // reference feature and its square: what the two sums of the variance start from
     {
         const f32x8 t = Elem<TIn>::load8(reinterpret_cast<const TIn*>(a.ref) + ((long)b * hw + pflat) * C + l * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) rf[j] = t.v[j];
+        for (int j = 0; j < 8; ++j) { rf[j] = t.v[j]; rf2[j] = t.v[j] * t.v[j]; }
     }
 
     // ---- 1. wave 0: texel box per view from the 8 corner projections (tile corners x depth extremes of the chunk): for a
@@ -357,15 +357,22 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
         const float dval = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dlane), d - d0));
         float s[8], q[8];          // variance: sum, sum of squares; softmin: sum e*diff (s only)
         float sum_e = 0.0f;
+        // The sums start at the reference feature (model.py:121-123).  Variance: view 0 WRITES them in three-address form
+        // (s = rf + w, q = fma(w, w, rf^2): the same bits as s = rf; s += w) and only a block whose view 0 lies outside the image copies
+        // rf / rf^2 -- initialising them up here cost 16 v_mov per trip, 5 % of the loop's vector instructions (round 6).
+        if (!VAR) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (VAR) { s[j] = rf[j]; q[j] = rf[j] * rf[j]; }   // the sums start at the reference feature  model.py:121-123
-            else { s[j] = 0.0f; q[j] = 0.0f; }
+            for (int j = 0; j < 8; ++j) { s[j] = 0.0f; q[j] = 0.0f; }
         }
-        auto accumulate = [&](const float (&wv)[8]) {
+        auto accumulate = [&](const float (&wv)[8], bool first) {
             if (VAR) {
+                if (first) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { s[j] += wv[j]; q[j] = fmaf(wv[j], wv[j], q[j]); }
+                    for (int j = 0; j < 8; ++j) { s[j] = rf[j] + wv[j]; q[j] = fmaf(wv[j], wv[j], rf2[j]); }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { s[j] += wv[j]; q[j] = fmaf(wv[j], wv[j], q[j]); }
+                }
             } else {   // SOFTMIN  model.py:141-173
                 float df[8], part = 0.0f;
 #pragma unroll
@@ -381,7 +388,7 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
         // this lane's view: sample position -> bilinear weights, byte offset E of the top-left tap in the arena and the byte
         // steps DX / DY to the right / lower taps (only meaningful, and only used, when that view's box is staged)
         float w00, w01, w10, w11;
-        int E, DX = 64, DY = mpitch << 6;
+        int E, DX, DY;            // DX / DY: only blocks with a clipped (GEN) view compute and read them
         {
             const float hx = fmaf(rx, dval, tx), hy = fmaf(ry, dval, ty_), hz = fmaf(rz, dval, tz);
             const float inv_z = __builtin_amdgcn_rcpf(hz);
@@ -389,6 +396,9 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
             if (any_gen) {   // (a staged box has every corner in front of the camera: no behind-camera test)
                 ix = __builtin_amdgcn_fmed3f(ix, a.xlo, a.xhi);      // grid clamp  module.py:151-155
                 iy = __builtin_amdgcn_fmed3f(iy, a.ylo, a.yhi);
+                // (any_gen is wave-uniform: keep this a BRANCH -- as a select the two clamps, their two constant moves and two v_cndmask
+                //  ran in every trip of every block, 2 % of the loop's vector instructions for the 15 % of the blocks that need them)
+                asm volatile("" : "+v"(ix), "+v"(iy));
             }
             const float x0f = floorf(ix), y0f = floorf(iy);
             const float fx = ix - x0f, fy = iy - y0f;
@@ -409,6 +419,7 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
                 DY = __mul24(yc1 - yc0, mpitch) << 6;
             } else {
                 E = (__mul24(y0, mpitch) + x0 + meb) << 6;
+                asm volatile("" : "=v"(DX), "=v"(DY));               // (defined, no instruction: never read without a GEN view)
             }
         }
 
@@ -473,7 +484,14 @@ __global__ __launch_bounds__(WL_THREADS, 4) void warp_cost_lds_kernel(const Warp
                 }                                                                                                          \
                 wl_blend8(t, w, wv);                                                                                       \
             }                                                                                                              \
-            accumulate(wv);                                                                                                \
+            accumulate(wv, K == 0);                                                                                        \
+        } else if (K == 0 && VAR) {      /* view 0 contributes nothing to this block: the sums start as plain copies */    \
+            /* (the empty asm pins these copies into THIS block: as plain assignments the compiler hoists them above the branch */ \
+            /*  and every trip pays them again) */                                                                         \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                                \
+                s[j] = rf[j]; q[j] = rf2[j];                                                                               \
+                asm volatile("" : "+v"(s[j]), "+v"(q[j]));                                                                 \
+            }                                                                                                              \
         }
         WL_VIEW(0, 0x00)
         WL_VIEW(1, 0x55)
