@@ -836,7 +836,8 @@ def run(args):
                                    f"features resident in HBM -> depth + confidence; a step = a batch of {NB} reference view(s) per GPU, "
                                    "each with its own 4 source views; synthetic camera rig 'probe'" + zero_note, "global_batch": world * NB, "batch_per_gpu": NB,
                        "voxels_per_step_per_gpu": NB * VOX, "parallelism": f"reference-view shard x{world}, no collective",
-                       "batch_mode": args.batch_mode if NB > 1 else "one view",
+                       "batch_mode": ("one view" if NB == 1 else args.batch_mode if (views_mode or args.batch_mode != "views") else
+                                      "batched (eager: --batch-mode views needs graph replay)"),
                        # like-for-like with rounds 1-2 (whose step was ONE reference view): the same path, one view per replay
                        "one_view_at_a_time_ms": None if one_view is None else one_view * 1e3,
                        "one_view_at_a_time_voxels_per_s": None if one_view is None else world * VOX / one_view},
