@@ -105,11 +105,16 @@ def test_forward_depth_parity_with_reference(env, fname, agg, dtype, feature_eng
     out = net(dev["imgs"], dev["K"], dev["R"], dev["t"], dev["depth_min"], dev["depth_max"], taps=taps)
     assert set(out) == {"depth", "depth_est_list", "depth_pair_list", "photometric_confidence"}
     assert tuple(out["depth"].shape) == (1, H // 4, W // 4) and out["depth_pair_list"] == []
-    # (bf16 activations through the eight 2-D layers add ~1e-2 of relative error to the features' variance)
-    loose = dtype == torch.bfloat16 and feature_engine == "pscv"
+    # Intermediate tensors, bars per storage format at ~2 x the values measured in round 6 (one bar of 1e-2 / 3e-2 for everything
+    # before): fp16 cost volume 3.4e-4 ... 1.3e-3, logits 3.4e-4 ... 7.4e-4; bf16 cost volume 2.8e-3 ... 6.4e-3 with the PyTorch-ROCm
+    # extractor and 6.5e-3 ... 1.05e-2 with the engine's (bf16 activations through its eight 2-D layers), logits 3.6e-3 ... 6.0e-3.
+    if dtype == torch.float16:
+        cv_bar, lg_bar = 2.5e-3, 1.5e-3
+    else:
+        cv_bar, lg_bar = (2e-2 if feature_engine == "pscv" else 1.2e-2), 1.2e-2
     check_close(f"{fname} cost volume ({dtype})", taps["cost_volume"].float().permute(0, 4, 1, 2, 3).cpu(), t(g["cost_volume"]),
-                rel_l2=2e-2 if loose else 1e-2)
-    check_close(f"{fname} logits ({dtype})", taps["logits"].cpu(), t(g["logits"]).squeeze(1), rel_l2=6e-2 if loose else 3e-2)
+                rel_l2=cv_bar)
+    check_close(f"{fname} logits ({dtype})", taps["logits"].cpu(), t(g["logits"]).squeeze(1), rel_l2=lg_bar)
     ref = t(g["depth"])
     s = check_close(f"{fname} depth ({dtype})", out["depth"].cpu(), ref)
     if dtype in DEPTH_TOL:
