@@ -40,13 +40,16 @@ def test_cvp_forward_parity_with_reference(env, dtype, feature_engine, fixture):
     H, W = scene["imgs"].shape[-2:]
     assert tuple(out["depth"].shape) == (1, H, W) and tuple(out["photometric_confidence"].shape) == (1, 1, H, W)
     assert out["depth_pair_list"] == [] and len(out["depth_est_list"]) == nscale
-    tol = 2e-3 if dtype == torch.float16 else 1.5e-2
+    # intermediate tensors: relative-L2 bars at ~2 x the values measured in round 6 on both fixtures (before: 2e-3 / 6e-3 / 2e-2 in fp16 and
+    # 1.5e-2 / 4.5e-2 / 1.5e-1 in bf16) -- fp16 cost 3.2e-4 ... 5.1e-4, coarse logits 7.2e-4 ... 8.4e-4, refinement logits 7.9e-4 ... 9.6e-4;
+    # bf16 2.6e-3 ... 4.4e-3, 4.3e-3 ... 4.5e-3, 4.5e-3 ... 5.7e-3
+    cost_bar, coarse_bar, refine_bar = (1e-3, 2e-3, 2e-3) if dtype == torch.float16 else (9e-3, 9e-3, 1.2e-2)
     planes = g["coarse_planes"].tolist()
-    check_close(f"coarse cost {dtype}", taps["coarse"]["cost"].float().permute(0, 4, 1, 2, 3)[:, :, planes].cpu(), t(g["coarse_cost"]), rel_l2=tol)
-    check_close(f"coarse logits {dtype}", taps["coarse"]["logits"].cpu(), t(g["coarse_logits"]), rel_l2=3 * tol)
+    check_close(f"coarse cost {dtype}", taps["coarse"]["cost"].float().permute(0, 4, 1, 2, 3)[:, :, planes].cpu(), t(g["coarse_cost"]), rel_l2=cost_bar)
+    check_close(f"coarse logits {dtype}", taps["coarse"]["logits"].cpu(), t(g["coarse_logits"]), rel_l2=coarse_bar)
     for i, lt in enumerate(taps["refine"], start=1):
         check_close(f"refine{i} hypotheses {dtype}", lt["hypos"].cpu(), t(g[f"refine{i}_hypos"]), max_abs=0.02 if dtype == torch.float16 else 0.1)
-        check_close(f"refine{i} logits {dtype}", lt["logits"].cpu(), t(g[f"refine{i}_logits"]), rel_l2=10 * tol)
+        check_close(f"refine{i} logits {dtype}", lt["logits"].cpu(), t(g[f"refine{i}_logits"]), rel_l2=refine_bar)
     # fp16: the north-star bar.  bf16: at most 15 % above what the storage format itself costs -- the fp32 oracle with every
     # HBM-resident tensor rounded to bf16 (oracle.cvpmvsnet.storage), computed here on the same inputs.
     if dtype == torch.float16:

@@ -117,11 +117,14 @@ def test_vis_forward_parity_with_reference(env, dtype, feature_engine):
     assert tuple(out["photometric_confidence"].shape) == (1, 3, H // 2, W // 2)
     assert len(out["depth_pair_list"]) == 3 and len(out["depth_pair_list"][0]) == V - 1
     s1 = taps["stages"][0]
-    tol = 2e-3 if dtype == torch.float16 else 2e-2
-    check_close(f"s1 cost v0 {dtype}", s1["cost0"].float().permute(0, 4, 1, 2, 3).cpu(), t(g["s1_cost_v0"]), rel_l2=tol)
-    check_close(f"s1 interm v0 {dtype}", s1["interm0"].float().permute(0, 4, 1, 2, 3).cpu(), t(g["s1_interm_v0"]), rel_l2=tol)
-    check_close(f"s1 fused {dtype}", s1["fused"].float().permute(0, 4, 1, 2, 3).cpu(), t(g["s1_fused"]), rel_l2=tol)
-    check_close(f"s1 score {dtype}", s1["score"].unsqueeze(1).cpu(), t(g["s1_score"]), rel_l2=tol)
+    # stage-1 intermediates, relative L2 at ~2 x the values measured in round 6 (one bar of 2e-3 / 2e-2 for all four before): fp16 cost
+    # 2.7e-4 ... 4.8e-4, pair U-Net output and fused volume 5.6e-4 ... 7.5e-4, scores 1.1e-3 ... 1.3e-3; bf16 2.1e-3 ... 5.1e-3,
+    # 4.4e-3 ... 7.9e-3, 8.2e-3 ... 1.2e-2
+    cost_bar, vol_bar, score_bar = (1e-3, 1.5e-3, 2e-3) if dtype == torch.float16 else (1e-2, 1.5e-2, 2e-2)
+    check_close(f"s1 cost v0 {dtype}", s1["cost0"].float().permute(0, 4, 1, 2, 3).cpu(), t(g["s1_cost_v0"]), rel_l2=cost_bar)
+    check_close(f"s1 interm v0 {dtype}", s1["interm0"].float().permute(0, 4, 1, 2, 3).cpu(), t(g["s1_interm_v0"]), rel_l2=vol_bar)
+    check_close(f"s1 fused {dtype}", s1["fused"].float().permute(0, 4, 1, 2, 3).cpu(), t(g["s1_fused"]), rel_l2=vol_bar)
+    check_close(f"s1 score {dtype}", s1["score"].unsqueeze(1).cpu(), t(g["s1_score"]), rel_l2=score_bar)
     # fp16: the north-star bar.  bf16: at most 15 % above what the storage format itself costs -- the fp32 oracle with every
     # HBM-resident tensor rounded to bf16 (oracle.vismvsnet.storage), computed here on the same inputs.
     dtol = 1e-3
